@@ -1,0 +1,80 @@
+/* CPU oracle (plain C restatement) for the GPTQ QuantLinear hot path -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Never linked into, loaded by, or called from the product (autogptq_amd / libgptq_mi355x.so).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * Scalar, one-value-at-a-time statement of the reference's integer unpack and dequant, written
+ * to be obviously right rather than fast, and structured differently from oracle/gptq_oracle.py
+ * (bit-stream addressing instead of per-word shift tables) so the two check each other.
+ * Reference being restated (AutoGPTQ v0.8.0.dev0):
+ *   layout / pack      auto_gptq/nn_modules/qlinear/qlinear_cuda.py:135-203
+ *   unpack "wrap"      auto_gptq/nn_modules/qlinear/qlinear_cuda_old.py:295-316 (3-bit :317-344)
+ *   unpack "nowrap"    auto_gptq/nn_modules/qlinear/qlinear_cuda.py:257-295
+ *   dequant + matmul   qlinear_cuda_old.py:348-350, qlinear_cuda.py:302,313
+ *
+ * A packed column (qweight) or packed row (qzeros) is a little-endian bit stream: value v
+ * occupies bits [bits*v, bits*v + bits) of the stream formed by concatenating the 32-bit words
+ * in order.  For 2/4/8-bit no value crosses a word; for 3-bit, values 10 and 21 of every 32 do
+ * (qlinear_cuda.py:144-162) -- which is exactly what the stream view gives.
+ */
+#include <stdint.h>
+#include <stddef.h>
+
+static inline uint32_t stream_field(const uint32_t *words, size_t stride, size_t v, int bits)
+{
+    size_t bit = (size_t)bits * v;
+    size_t w = bit >> 5;
+    unsigned sh = (unsigned)(bit & 31);
+    uint64_t lo = words[w * stride];
+    uint64_t hi = (sh + (unsigned)bits > 32) ? words[(w + 1) * stride] : 0;
+    return (uint32_t)(((lo | (hi << 32)) >> sh) & ((1u << bits) - 1u));
+}
+
+/* w[k,n] in [0, maxq]; qweight is int32 [K/32*bits, N] row-major */
+int gptq_oracle_unpack_weights(const int32_t *qweight, int K, int N, int bits, uint16_t *w_out)
+{
+    if (!(bits == 2 || bits == 3 || bits == 4 || bits == 8) || K % 32) return 1;
+    for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n)
+            w_out[(size_t)k * N + n] =
+                (uint16_t)stream_field((const uint32_t *)qweight + n, (size_t)N, (size_t)k, bits);
+    return 0;
+}
+
+/* zero_mode 0 = wrap: (f+1)&maxq ; 1 = nowrap: f+1.  qzeros is int32 [G, N/32*bits] */
+int gptq_oracle_unpack_zeros(const int32_t *qzeros, int G, int N, int bits, int zero_mode, int32_t *z_out)
+{
+    if (!(bits == 2 || bits == 3 || bits == 4 || bits == 8) || N % 32) return 1;
+    size_t row_words = (size_t)N / 32 * bits;
+    for (int g = 0; g < G; ++g)
+        for (int n = 0; n < N; ++n) {
+            int32_t f = (int32_t)stream_field((const uint32_t *)qzeros + g * row_words, 1, (size_t)n, bits);
+            int32_t z = f + 1;
+            if (zero_mode == 0) z &= (1 << bits) - 1;
+            z_out[(size_t)g * N + n] = z;
+        }
+    return 0;
+}
+
+/* y[m,n] = sum_k x[m,k] * scales[g(k),n] * (w[k,n] - z[g(k),n]) (+bias), double accumulation,
+ * exact (unrounded) dequant.  scales/x/bias given as float; g_idx may be NULL (k / group_size). */
+int gptq_oracle_forward_f64(const float *x, const int32_t *qweight, const int32_t *qzeros,
+                            const float *scales, const int32_t *g_idx, const float *bias,
+                            int M, int K, int N, int bits, int group_size, int zero_mode, double *y)
+{
+    if (!(bits == 2 || bits == 3 || bits == 4 || bits == 8) || K % 32 || N % 32) return 1;
+    size_t row_words = (size_t)N / 32 * bits;
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) y[(size_t)m * N + n] = bias ? (double)bias[n] : 0.0;
+    for (int k = 0; k < K; ++k) {
+        int g = g_idx ? g_idx[k] : k / group_size;
+        for (int n = 0; n < N; ++n) {
+            int32_t w = (int32_t)stream_field((const uint32_t *)qweight + n, (size_t)N, (size_t)k, bits);
+            int32_t z = (int32_t)stream_field((const uint32_t *)qzeros + g * row_words, 1, (size_t)n, bits) + 1;
+            if (zero_mode == 0) z &= (1 << bits) - 1;
+            double dq = (double)scales[(size_t)g * N + n] * (double)(w - z);
+            for (int m = 0; m < M; ++m) y[(size_t)m * N + n] += (double)x[(size_t)m * K + k] * dq;
+        }
+    }
+    return 0;
+}
