@@ -1,0 +1,10 @@
+"""autogptq_amd -- the AutoGPTQ quantized-linear hot path, MI355X (gfx950) native.
+
+Only what the path needs: the HIP kernels + C ABI (``csrc/`` -> ``libgptq_mi355x.so``), a ctypes
+loader (``_lib``), the ``QuantLinear`` backend class (``qlinear_mi355x``), the backend selector
+mirror (``import_utils``) and the out_features tensor-parallel wrapper (``tensor_parallel``).
+"""
+from .import_utils import MI355X_KERNELS_AVAILABLE, dynamically_import_QuantLinear  # noqa: F401
+from .qlinear_mi355x import QuantLinear, reserve_workspace  # noqa: F401
+
+__version__ = "0.1.0"

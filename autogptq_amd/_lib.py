@@ -1,0 +1,113 @@
+"""ctypes binding of libgptq_mi355x.so (the C ABI in include/gptq_mi355x.h).
+
+There is deliberately no fallback: if the shared library is missing or an entry point is absent
+this module raises at import/use time -- the product path never silently degrades to PyTorch.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_int, c_int32, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("GPTQ_MI355X_LIB", os.path.join(_HERE, "libgptq_mi355x.so"))
+
+ABI_VERSION = 1
+
+GPTQ_F16, GPTQ_BF16, GPTQ_F32 = 0, 1, 2
+ZERO_WRAP, ZERO_NOWRAP = 0, 1
+
+DTYPE_ENUM = {torch.float16: GPTQ_F16, torch.bfloat16: GPTQ_BF16, torch.float32: GPTQ_F32}
+
+# every symbol include/gptq_mi355x.h declares (tests check the .so exports all of them)
+EXPORTS = (
+    "gptq_abi_version", "gptq_last_error", "gptq_status_string", "gptq_workspace_bytes",
+    "gptq_forward", "gptq_forward_ex", "gptq_gemv", "gptq_gemm", "gptq_dequant",
+    "gptq_unpack_weights", "gptq_unpack_zeros", "gptq_pack_weights", "gptq_pack_zeros",
+    "gptq_make_sequential", "gptq_resequence_qweight", "gptq_permute_columns",
+)
+
+
+class GptqLayer(Structure):
+    _fields_ = [
+        ("qweight", c_void_p), ("qzeros", c_void_p), ("scales", c_void_p), ("g_idx", c_void_p), ("bias", c_void_p),
+        ("K", c_int32), ("N", c_int32), ("bits", c_int32), ("group_size", c_int32),
+        ("dtype", c_int32), ("zero_mode", c_int32),
+        ("qweight_seq", c_void_p), ("perm", c_void_p),
+    ]
+
+
+class GptqTuning(Structure):
+    _fields_ = [("lanes_n", c_int32), ("waves", c_int32), ("ksplit", c_int32), ("path", c_int32),
+                ("reserved", c_int32 * 4)]
+
+
+class GptqError(RuntimeError):
+    """Raised for any non-zero status of the C ABI (the reference surfaces native failures as
+    RuntimeError through TORCH_CHECK, e.g. autogptq_extension/exllama/exllama_ext.cpp:25-43)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status = status
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            f"or make -C autogptq_amd/csrc). autogptq_amd has no PyTorch/CPU fallback for the quantized matmul.")
+    lib = ctypes.CDLL(LIB_PATH)
+    missing = [s for s in EXPORTS if not hasattr(lib, s)]
+    if missing:
+        raise ImportError(f"{LIB_PATH} does not export {missing}")
+    lib.gptq_abi_version.restype = c_int
+    lib.gptq_last_error.restype = c_char_p
+    lib.gptq_status_string.restype = c_char_p
+    lib.gptq_status_string.argtypes = [c_int]
+    lib.gptq_workspace_bytes.restype = c_size_t
+    lib.gptq_workspace_bytes.argtypes = [POINTER(GptqLayer), c_int]
+    fw = [POINTER(GptqLayer), c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]
+    lib.gptq_forward.argtypes = fw
+    for name in ("gptq_forward_ex", "gptq_gemv", "gptq_gemm"):
+        getattr(lib, name).argtypes = fw + [POINTER(GptqTuning)]
+    lib.gptq_dequant.argtypes = [POINTER(GptqLayer), c_void_p, c_void_p]
+    lib.gptq_unpack_weights.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.gptq_unpack_zeros.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.gptq_pack_weights.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_void_p, c_void_p, c_void_p]
+    lib.gptq_pack_zeros.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.gptq_make_sequential.argtypes = [c_void_p, c_int, c_int, c_void_p, POINTER(c_int)]
+    lib.gptq_resequence_qweight.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.gptq_permute_columns.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    for name in EXPORTS:
+        if name not in ("gptq_last_error", "gptq_status_string", "gptq_workspace_bytes"):
+            getattr(lib, name).restype = c_int
+    got = lib.gptq_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {got}, expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        lib = load()
+        msg = lib.gptq_last_error().decode("utf-8", "replace")
+        kind = lib.gptq_status_string(status).decode()
+        raise GptqError(status, f"gptq_mi355x: {kind}: {msg}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def current_stream_handle(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

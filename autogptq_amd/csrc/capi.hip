@@ -1,0 +1,232 @@
+// capi.hip -- the extern "C" boundary declared in include/gptq_mi355x.h: argument validation,
+// path selection, error reporting.  No allocation, no synchronisation, no global mutable state
+// (the only static storage is the thread-local last-error string).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.cuh"
+#include "launch.h"
+
+using namespace gptq;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    return fail(GPTQ_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+bool bits_ok(int b) { return b == 2 || b == 3 || b == 4 || b == 8; }
+bool dtype_ok(int d) { return d == GPTQ_F16 || d == GPTQ_BF16 || d == GPTQ_F32; }
+
+// Shape rules of the checkpoint layout (qlinear_cuda.py:51-75): K % 32 == 0 and N % 32 == 0 are
+// what `infeatures // 32 * bits` / `outfeatures // 32 * bits` silently assume.
+int check_layer(const gptq_layer_t* L) {
+    if (!L) return fail(GPTQ_ERR_NULL, "layer is NULL");
+    if (!L->qweight || !L->qzeros || !L->scales) return fail(GPTQ_ERR_NULL, "qweight/qzeros/scales must be non-NULL");
+    if (!bits_ok(L->bits)) return fail(GPTQ_ERR_UNSUPPORTED, "Only 2,3,4,8 bits are supported. (got %d)", L->bits);
+    if (!dtype_ok(L->dtype)) return fail(GPTQ_ERR_UNSUPPORTED, "unsupported dtype enum %d", L->dtype);
+    if (L->zero_mode != GPTQ_ZERO_WRAP && L->zero_mode != GPTQ_ZERO_NOWRAP)
+        return fail(GPTQ_ERR_UNSUPPORTED, "unknown zero_mode %d", L->zero_mode);
+    if (L->K <= 0 || L->N <= 0 || L->K % 32 || L->N % 32)
+        return fail(GPTQ_ERR_SHAPE, "in_features (%d) and out_features (%d) must be positive multiples of 32", L->K, L->N);
+    if (L->group_size <= 0) return fail(GPTQ_ERR_SHAPE, "group_size must be > 0 (resolve -1 to in_features), got %d", L->group_size);
+    if ((L->qweight_seq == nullptr) != (L->perm == nullptr))
+        return fail(GPTQ_ERR_NULL, "qweight_seq and perm must be given together");
+    return GPTQ_OK;
+}
+
+int check_io(const void* x, const void* out, int M) {
+    if (!x || !out) return fail(GPTQ_ERR_NULL, "x/out must be non-NULL");
+    if (M <= 0) return fail(GPTQ_ERR_SHAPE, "M must be > 0, got %d", M);
+    return GPTQ_OK;
+}
+
+bool want_gemm(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
+    if (t && t->path == 3) return true;
+    if (t && (t->path == 1 || t->path == 2)) return false;
+    if (M <= 8) return false;
+    return plan_gemm(*L, M, t).supported;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gptq_abi_version(void) { return GPTQ_MI355X_ABI_VERSION; }
+const char* gptq_last_error(void) { return g_err; }
+
+const char* gptq_status_string(int s) {
+    switch (s) {
+        case GPTQ_OK: return "ok";
+        case GPTQ_ERR_NULL: return "null pointer";
+        case GPTQ_ERR_SHAPE: return "bad shape";
+        case GPTQ_ERR_UNSUPPORTED: return "unsupported configuration";
+        case GPTQ_ERR_WORKSPACE: return "workspace too small";
+        case GPTQ_ERR_LAUNCH: return "HIP launch failure";
+        default: return "unknown status";
+    }
+}
+
+size_t gptq_workspace_bytes(const gptq_layer_t* L, int M) {
+    if (check_layer(L) != GPTQ_OK || M <= 0) return 0;
+    size_t a = plan_gemv(*L, M, nullptr).workspace_bytes;
+    GemmPlan g = plan_gemm(*L, M, nullptr);
+    size_t b = g.supported ? g.workspace_bytes : 0;
+    return std::max(a, b);
+}
+
+int gptq_gemv(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream,
+              const gptq_tuning_t* tune) {
+    int rc = check_layer(L);
+    if (rc) return rc;
+    rc = check_io(x, out, M);
+    if (rc) return rc;
+    if (tune && tune->lanes_n && tune->lanes_n != 4 && tune->lanes_n != 8 && tune->lanes_n != 16 && tune->lanes_n != 64)
+        return fail(GPTQ_ERR_UNSUPPORTED, "tuning.lanes_n must be 4, 8, 16 or 64");
+    if (tune && (tune->waves < 0 || tune->waves > 16)) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.waves must be 1..16");
+    GemvPlan pl = plan_gemv(*L, M, tune);
+    if (tune && tune->path == 2 && !pl.fast)
+        return fail(GPTQ_ERR_UNSUPPORTED, "fast GEMV needs bits=4, fp16 and sequential (or re-sequenced) groups");
+    if (pl.workspace_bytes > 0 && (!ws || ws_bytes < pl.workspace_bytes))
+        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", pl.workspace_bytes, ws ? ws_bytes : (size_t)0);
+    hipError_t e = launch_gemv(*L, pl, x, out, M, ws, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_gemv launch");
+    return GPTQ_OK;
+}
+
+int gptq_gemm(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream,
+              const gptq_tuning_t* tune) {
+    int rc = check_layer(L);
+    if (rc) return rc;
+    rc = check_io(x, out, M);
+    if (rc) return rc;
+    GemmPlan pl = plan_gemm(*L, M, tune);
+    if (!pl.supported)
+        return fail(GPTQ_ERR_UNSUPPORTED,
+                    "MFMA GEMM needs fp16/bf16, sequential or re-sequenced groups and group_size %% 32 == 0 (bits=%d dtype=%d group_size=%d)",
+                    L->bits, L->dtype, L->group_size);
+    if (pl.workspace_bytes > 0 && (!ws || ws_bytes < pl.workspace_bytes))
+        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", pl.workspace_bytes, ws ? ws_bytes : (size_t)0);
+    hipError_t e = launch_gemm(*L, pl, x, out, M, ws, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_gemm launch");
+    return GPTQ_OK;
+}
+
+int gptq_forward_ex(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream,
+                    const gptq_tuning_t* tune) {
+    int rc = check_layer(L);
+    if (rc) return rc;
+    if (want_gemm(L, M, tune)) return gptq_gemm(L, x, out, M, ws, ws_bytes, stream, tune);
+    return gptq_gemv(L, x, out, M, ws, ws_bytes, stream, tune);
+}
+
+int gptq_forward(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream) {
+    return gptq_forward_ex(L, x, out, M, ws, ws_bytes, stream, nullptr);
+}
+
+int gptq_dequant(const gptq_layer_t* L, void* W_out, void* stream) {
+    int rc = check_layer(L);
+    if (rc) return rc;
+    if (!W_out) return fail(GPTQ_ERR_NULL, "W_out is NULL");
+    hipError_t e = launch_dequant(*L, W_out, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_dequant launch");
+    return GPTQ_OK;
+}
+
+int gptq_unpack_weights(const uint32_t* qweight, int K, int N, int bits, uint8_t* w_out, void* stream) {
+    if (!qweight || !w_out) return fail(GPTQ_ERR_NULL, "qweight/w_out must be non-NULL");
+    if (!bits_ok(bits)) return fail(GPTQ_ERR_UNSUPPORTED, "Only 2,3,4,8 bits are supported. (got %d)", bits);
+    if (K <= 0 || N <= 0 || K % 32 || N % 32) return fail(GPTQ_ERR_SHAPE, "K (%d), N (%d) must be positive multiples of 32", K, N);
+    hipError_t e = launch_unpack_weights(qweight, K, N, bits, w_out, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_unpack_weights launch");
+    return GPTQ_OK;
+}
+
+int gptq_unpack_zeros(const uint32_t* qzeros, int G, int N, int bits, int zero_mode, int32_t* z_out, void* stream) {
+    if (!qzeros || !z_out) return fail(GPTQ_ERR_NULL, "qzeros/z_out must be non-NULL");
+    if (!bits_ok(bits)) return fail(GPTQ_ERR_UNSUPPORTED, "Only 2,3,4,8 bits are supported. (got %d)", bits);
+    if (G <= 0 || N <= 0 || N % 32) return fail(GPTQ_ERR_SHAPE, "G (%d) must be > 0 and N (%d) a positive multiple of 32", G, N);
+    hipError_t e = launch_unpack_zeros(qzeros, G, N, bits, zero_mode, z_out, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_unpack_zeros launch");
+    return GPTQ_OK;
+}
+
+int gptq_pack_weights(const void* W, const void* scale_in, const void* zero_in, const int32_t* g_idx, int K, int N,
+                      int bits, int group_size, int w_dtype, int qparam_dtype, uint32_t* qweight_out, void* scales_out,
+                      void* stream) {
+    if (!W || !scale_in || !zero_in || !qweight_out) return fail(GPTQ_ERR_NULL, "W/scale_in/zero_in/qweight_out must be non-NULL");
+    if (!bits_ok(bits)) return fail(GPTQ_ERR_UNSUPPORTED, "Only 2,3,4,8 bits are supported. (got %d)", bits);
+    if (!dtype_ok(w_dtype) || !dtype_ok(qparam_dtype)) return fail(GPTQ_ERR_UNSUPPORTED, "unsupported dtype enum");
+    if (K <= 0 || N <= 0 || K % 32 || N % 32 || group_size <= 0)
+        return fail(GPTQ_ERR_SHAPE, "K (%d), N (%d) must be positive multiples of 32 and group_size (%d) > 0", K, N, group_size);
+    hipError_t e = launch_pack_weights(W, scale_in, zero_in, g_idx, K, N, bits, group_size, w_dtype, qparam_dtype,
+                                       qweight_out, scales_out, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_pack_weights launch");
+    return GPTQ_OK;
+}
+
+int gptq_pack_zeros(const void* zero_in, int G, int N, int bits, int qparam_dtype, uint32_t* qzeros_out, void* stream) {
+    if (!zero_in || !qzeros_out) return fail(GPTQ_ERR_NULL, "zero_in/qzeros_out must be non-NULL");
+    if (!bits_ok(bits)) return fail(GPTQ_ERR_UNSUPPORTED, "Only 2,3,4,8 bits are supported. (got %d)", bits);
+    if (!dtype_ok(qparam_dtype)) return fail(GPTQ_ERR_UNSUPPORTED, "unsupported dtype enum");
+    if (G <= 0 || N <= 0 || N % 32) return fail(GPTQ_ERR_SHAPE, "G (%d) must be > 0 and N (%d) a positive multiple of 32", G, N);
+    hipError_t e = launch_pack_zeros(zero_in, G, N, bits, qparam_dtype, qzeros_out, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_pack_zeros launch");
+    return GPTQ_OK;
+}
+
+int gptq_make_sequential(const int32_t* g_idx, int K, int group_size, int32_t* perm_out, int* uniform_out) {
+    if (!g_idx || !perm_out) return fail(GPTQ_ERR_NULL, "g_idx/perm_out must be non-NULL");
+    if (K <= 0 || group_size <= 0) return fail(GPTQ_ERR_SHAPE, "K (%d) and group_size (%d) must be > 0", K, group_size);
+    int gmax = 0;
+    for (int k = 0; k < K; ++k) {
+        if (g_idx[k] < 0) return fail(GPTQ_ERR_SHAPE, "g_idx[%d] = %d is negative", k, g_idx[k]);
+        gmax = std::max(gmax, g_idx[k]);
+    }
+    // stable counting sort by group (same ordering rule as Q4Matrix::make_sequential)
+    std::vector<int> start((size_t)gmax + 2, 0);
+    for (int k = 0; k < K; ++k) start[(size_t)g_idx[k] + 1]++;
+    for (int g = 0; g <= gmax; ++g) start[(size_t)g + 1] += start[g];
+    std::vector<int> cursor(start.begin(), start.end() - 1);
+    for (int k = 0; k < K; ++k) perm_out[cursor[g_idx[k]]++] = k;
+    if (uniform_out) {
+        int uni = 1;
+        for (int i = 0; i < K && uni; ++i) uni = (g_idx[perm_out[i]] == i / group_size);
+        *uniform_out = uni;
+    }
+    return GPTQ_OK;
+}
+
+int gptq_resequence_qweight(const uint32_t* qweight, const int32_t* perm, int K, int N, int bits, uint32_t* out, void* stream) {
+    if (!qweight || !perm || !out) return fail(GPTQ_ERR_NULL, "qweight/perm/out must be non-NULL");
+    if (!bits_ok(bits)) return fail(GPTQ_ERR_UNSUPPORTED, "Only 2,3,4,8 bits are supported. (got %d)", bits);
+    if (K <= 0 || N <= 0 || K % 32 || N % 32) return fail(GPTQ_ERR_SHAPE, "K (%d), N (%d) must be positive multiples of 32", K, N);
+    hipError_t e = launch_resequence(qweight, perm, K, N, bits, out, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_resequence_qweight launch");
+    return GPTQ_OK;
+}
+
+int gptq_permute_columns(const void* x, const int32_t* perm, int M, int K, int dtype, void* x_out, void* stream) {
+    if (!x || !perm || !x_out) return fail(GPTQ_ERR_NULL, "x/perm/x_out must be non-NULL");
+    if (!dtype_ok(dtype)) return fail(GPTQ_ERR_UNSUPPORTED, "unsupported dtype enum %d", dtype);
+    if (M <= 0 || K <= 0) return fail(GPTQ_ERR_SHAPE, "M (%d) and K (%d) must be > 0", M, K);
+    hipError_t e = launch_permute_columns(x, perm, M, K, dtype, x_out, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_permute_columns launch");
+    return GPTQ_OK;
+}
+
+}  // extern "C"

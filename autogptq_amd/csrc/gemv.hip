@@ -1,0 +1,502 @@
+// gemv.hip -- memory-bound decode path: out[M,N] = x[M,K] @ dequant(qweight) for small M.
+//
+// Replaces (reference, AutoGPTQ v0.8.0.dev0): VecQuant{2,3,4,8}MatMulKernel* in
+// autogptq_extension/cuda_256/autogptq_cuda_kernel_256.cu:281-1437, q4_matmul_kernel in
+// exllama/cuda_func/q4_matmul.cu:33-143 and gemm_half_q_half_gptq_kernel in
+// exllamav2/cuda/q_gemm_kernel_gptq.cuh:39-194.  Nothing here is derived from that code; the
+// design is CDNA4-first:
+//
+//  * A workgroup owns a COLUMN STRIP of CT = 4*LN output columns over a K range; a lane owns 4
+//    adjacent columns (one 128-bit load per packed row: 16 B/lane) and the 64/LN "row slots" of a
+//    wave walk consecutive packed rows, so one wave-load covers WR rows x (16*LN) contiguous
+//    bytes.  Logical strip ids are remapped so neighbouring strips share an XCD (one L2).
+//  * Every lane issues all of its weight loads before touching LDS: for Llama-7B shapes the whole
+//    matrix is in flight at once (the kernel is one HBM round trip + a reduction).
+//  * x is staged once per workgroup in LDS (fast path: fp16, pre-permuted so one ds_read_b128
+//    yields the (k,k+4) pairs that the 0x6400 magic-number unpack produces; act-order layers
+//    gather x through perm[] here, which is the whole cost of act-order on this path).
+//  * 4-bit fp16 fast path: w-z is formed EXACTLY in packed fp16 ((q & 0x000f000f) | 0x64006400 is
+//    1024+w; adding -(1024+z) is exact), dotted with x by v_dot2_f32_f16 (fp32 accumulate) and
+//    scaled once per 8 k in fp32.  No fp16 accumulation anywhere.
+//  * K reduction: row slots by wavefront shuffles (DPP), waves through LDS in fixed order, then
+//    (only if ksplit > 1) a second pass over fp32 partials.  No atomics: bit-reproducible.
+#include "common.cuh"
+#include "launch.h"
+
+namespace gptq {
+
+struct GemvParams {
+    const unsigned* qweight;
+    const unsigned* qzeros;
+    const void* scales;
+    const int* g_idx;   // per-k groups (PERK mode) or nullptr
+    const int* perm;    // x gather for re-sequenced act-order layers, or nullptr
+    const void* bias;
+    const void* x;
+    void* out;
+    float* partial;     // [ksplit][M][N] when ksplit > 1
+    int M, K, N, group_size, zero_mode;
+    int units_total, units_per_split, chunk_units, ksplit;
+};
+
+// ---- shared epilogue: reduce row slots (shuffles), waves (LDS), then write ------------------
+template <typename T, int LN, int MT>
+__device__ __forceinline__ void reduce_and_store(float (&acc)[MT][4], float* red, const GemvParams& p,
+                                                 int strip, int m0) {
+    constexpr int CT = LN * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = acc[m][c];
+#pragma unroll
+            for (int off = LN; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            acc[m][c] = v;
+        }
+    __syncthreads();  // everyone is done reading the x chunk that aliases `red`
+    if (lane < LN) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[(wave * MT + m) * CT + lane * 4 + c] = acc[m][c];
+    }
+    __syncthreads();
+    for (int i = tid; i < MT * CT; i += blockDim.x) {
+        const int m = i / CT, c = i % CT;
+        const int n = strip * CT + c, row = m0 + m;
+        if (n >= p.N || row >= p.M) continue;
+        float s = 0.f;
+        for (int w = 0; w < W; ++w) s += red[(w * MT + m) * CT + c];
+        if (p.ksplit > 1) {
+            p.partial[((size_t)blockIdx.y * p.M + row) * p.N + n] = s;
+        } else {
+            if (p.bias) s += DType<T>::to_f32(((const T*)p.bias)[n]);
+            ((T*)p.out)[(size_t)row * p.N + n] = DType<T>::from_f32(s);
+        }
+    }
+}
+
+// ---- generic kernel: any bits / dtype / group structure, fp32 math -------------------------
+// PERK = false: one (scale, zero) per packed unit and column (sequential groups, unit inside a
+//               group);  PERK = true: group looked up per k (raw act-order g_idx, odd group sizes).
+template <int BITS, typename T, int LN, int MT, bool PERK>
+__global__ void __launch_bounds__(1024) gemv_generic_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = (float*)smem;
+    constexpr int UW = Pack<BITS>::words, KPU = Pack<BITS>::vals, WR = 64 / LN, CT = LN * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
+    const int cl = lane % LN, rs = lane / LN;
+    const int strip = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = strip * CT + cl * 4;
+    const bool col_ok = n0 < p.N;
+    const int m0 = blockIdx.z * MT;
+    const int ub = blockIdx.y * p.units_per_split;
+    const int ue = min(ub + p.units_per_split, p.units_total);
+    const int xstride = p.chunk_units * KPU;
+    const T* __restrict__ x = (const T*)p.x;
+    const T* __restrict__ scales = (const T*)p.scales;
+    const int zrow_words = p.N / 32 * BITS;
+
+    float acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[m][c] = 0.f;
+
+    for (int cb = ub; cb < ue; cb += p.chunk_units) {
+        const int ce = min(cb + p.chunk_units, ue);
+        const int kc = (ce - cb) * KPU, kbase = cb * KPU;
+        if (cb != ub) __syncthreads();
+        for (int i = tid; i < MT * kc; i += blockDim.x) {
+            const int m = i / kc, kk = i - m * kc;
+            const int k = kbase + kk;
+            const int src = p.perm ? p.perm[k] : k;
+            xs[m * xstride + kk] = (m0 + m < p.M) ? DType<T>::to_f32(x[(size_t)(m0 + m) * p.K + src]) : 0.f;
+        }
+        __syncthreads();
+        for (int it = 0;; ++it) {
+            const int ubase = cb + (it * W + wave) * WR;
+            if (ubase >= ce) break;
+            const int u = ubase + rs;
+            if (u >= ce || !col_ok) continue;
+            u32x4 q[UW];
+#pragma unroll
+            for (int w = 0; w < UW; ++w)
+                q[w] = *(const u32x4*)(p.qweight + (size_t)(u * UW + w) * p.N + n0);
+            const int k0 = u * KPU;
+            const float* xk = xs + (k0 - kbase);
+            if constexpr (!PERK) {
+                const int g = k0 / p.group_size;
+                float s[4];
+                int z[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s[c] = DType<T>::to_f32(scales[(size_t)g * p.N + n0 + c]);
+                zero_points4(p.qzeros + (size_t)g * zrow_words, n0, BITS, p.zero_mode, z);
+                float xsum[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int v = 0; v < KPU; ++v) t += xk[m * xstride + v];
+                    xsum[m] = t;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    unsigned w[UW];
+#pragma unroll
+                    for (int i = 0; i < UW; ++i) w[i] = q[i][c];
+                    float d[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) d[m] = 0.f;
+                    [&]<int... V>(std::integer_sequence<int, V...>) {
+                        (([&] {
+                             const float wf = (float)unit_field<BITS, V>(w);
+#pragma unroll
+                             for (int m = 0; m < MT; ++m) d[m] = fmaf(xk[m * xstride + V], wf, d[m]);
+                         }()),
+                         ...);
+                    }(std::make_integer_sequence<int, KPU>{});
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[m][c] = fmaf(s[c], d[m] - (float)z[c] * xsum[m], acc[m][c]);
+                }
+            } else {
+                [&]<int... V>(std::integer_sequence<int, V...>) {
+                    (([&] {
+                         const int k = k0 + V;
+                         const int g = p.g_idx ? p.g_idx[k] : k / p.group_size;
+                         int z[4];
+                         zero_points4(p.qzeros + (size_t)g * zrow_words, n0, BITS, p.zero_mode, z);
+#pragma unroll
+                         for (int c = 0; c < 4; ++c) {
+                             unsigned w[UW];
+#pragma unroll
+                             for (int i = 0; i < UW; ++i) w[i] = q[i][c];
+                             const float s = DType<T>::to_f32(scales[(size_t)g * p.N + n0 + c]);
+                             const float dq = s * (float)((int)unit_field<BITS, V>(w) - z[c]);
+#pragma unroll
+                             for (int m = 0; m < MT; ++m) acc[m][c] = fmaf(xk[m * xstride + V], dq, acc[m][c]);
+                         }
+                     }()),
+                     ...);
+                }(std::make_integer_sequence<int, KPU>{});
+            }
+        }
+    }
+    reduce_and_store<T, LN, MT>(acc, (float*)smem, p, strip, m0);
+}
+
+// ---- fast kernel: 4-bit, fp16, sequential groups (or re-sequenced act-order via perm) -------
+// x in LDS as fp16 with each 8-group stored in order (0,4,1,5,2,6,3,7).
+template <int LN, int MT, int U>
+__global__ void __launch_bounds__(1024) gemv_q4_f16_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f16* xs = (f16*)smem;
+    constexpr int WR = 64 / LN, CT = LN * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
+    const int cl = lane % LN, rs = lane / LN;
+    const int strip = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = strip * CT + cl * 4;
+    const bool col_ok = n0 < p.N;
+    const int nload = col_ok ? n0 : 0;
+    const int m0 = blockIdx.z * MT;
+    const int ub = blockIdx.y * p.units_per_split;
+    const int ue = min(ub + p.units_per_split, p.units_total);
+    const int xstride = p.chunk_units * 8;  // halfs per m row in LDS
+    const f16* __restrict__ x = (const f16*)p.x;
+    const f16* __restrict__ scales = (const f16*)p.scales;
+    const int zrow_words = p.N >> 3;
+    const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
+    const unsigned zshift = (unsigned)(n0 & 7) * 4u;
+
+    float acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[m][c] = 0.f;
+
+    for (int cb = ub; cb < ue; cb += p.chunk_units) {
+        const int ce = min(cb + p.chunk_units, ue);
+        const int nu = ce - cb;
+        // -- 1. issue the first U weight loads of this thread before anything else ------------
+        u32x4 q[U];
+        int uu[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            uu[j] = cb + (j * W + wave) * WR + rs;
+            const int ul = min(uu[j], ce - 1);
+            q[j] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)ul * p.N + nload));
+        }
+        // -- 2. stage x chunk (permuted pairs) ------------------------------------------------
+        if (cb != ub) __syncthreads();
+        for (int i = tid; i < MT * nu; i += blockDim.x) {
+            const int m = i / nu, ul = i - m * nu;
+            const int k0 = (cb + ul) * 8;
+            f16 v[8];
+            if (m0 + m < p.M) {
+                const f16* xr = x + (size_t)(m0 + m) * p.K;
+                if (p.perm) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = xr[p.perm[k0 + j]];
+                } else {
+                    const f16x8 t = *(const f16x8*)(xr + k0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = t[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (f16)0.f;
+            }
+            f16x8 o = {v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7]};
+            *(f16x8*)(xs + m * xstride + ul * 8) = o;
+        }
+        __syncthreads();
+        // -- 3. consume --------------------------------------------------------------------------
+        for (int it0 = 0;; it0 += U) {
+            if (cb + (it0 * W + wave) * WR >= ce) break;
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int u = uu[j];
+                const u32x4 qv = q[j];
+                // prefetch the load U iterations ahead into the same slot
+                {
+                    const int un = cb + ((it0 + j + U) * W + wave) * WR + rs;
+                    uu[j] = un;
+                    if (cb + ((it0 + j + U) * W + wave) * WR < ce) {
+                        const int ul = min(un, ce - 1);
+                        q[j] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)ul * p.N + nload));
+                    }
+                }
+                if (u >= ce || !col_ok) continue;
+                const int g = (u * 8) / p.group_size;
+                const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * p.N + n0);
+                const unsigned zw = p.qzeros[(size_t)g * zrow_words + (n0 >> 3)] >> zshift;
+                const f16x2 s01 = __builtin_bit_cast(f16x2, sraw[0]);
+                const f16x2 s23 = __builtin_bit_cast(f16x2, sraw[1]);
+                const float sc[4] = {(float)s01[0], (float)s01[1], (float)s23[0], (float)s23[1]};
+                f16x2 xa[MT][4];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const u32x4 xv = *(const u32x4*)(xs + m * xstride + (u - cb) * 8);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xa[m][i] = __builtin_bit_cast(f16x2, xv[i]);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned z = (((zw >> (4 * c)) & 15u) + 1u) & zmask;
+                    const f16x2 c1 = __builtin_bit_cast(f16x2, z * 0x00010001u + 0xE400E400u);  // -(1024+z)
+                    const f16x2 c2 = __builtin_bit_cast(f16x2, z * 0x00100010u + 0xD400D400u);  // -(64+z)
+                    const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+                    const unsigned qw = qv[c], q8 = qw >> 8;
+                    const f16x2 h0 = __builtin_bit_cast(f16x2, (qw & 0x000f000fu) | 0x64006400u) + c1;  // k0,k4
+                    const f16x2 h1 = __builtin_elementwise_fma(
+                        __builtin_bit_cast(f16x2, (qw & 0x00f000f0u) | 0x64006400u), r16, c2);           // k1,k5
+                    const f16x2 h2 = __builtin_bit_cast(f16x2, (q8 & 0x000f000fu) | 0x64006400u) + c1;  // k2,k6
+                    const f16x2 h3 = __builtin_elementwise_fma(
+                        __builtin_bit_cast(f16x2, (q8 & 0x00f000f0u) | 0x64006400u), r16, c2);           // k3,k7
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        float d = __builtin_amdgcn_fdot2(h0, xa[m][0], 0.f, false);
+                        d = __builtin_amdgcn_fdot2(h1, xa[m][1], d, false);
+                        d = __builtin_amdgcn_fdot2(h2, xa[m][2], d, false);
+                        d = __builtin_amdgcn_fdot2(h3, xa[m][3], d, false);
+                        acc[m][c] = fmaf(sc[c], d, acc[m][c]);
+                    }
+                }
+            }
+        }
+    }
+    reduce_and_store<f16, LN, MT>(acc, (float*)smem, p, strip, m0);
+}
+
+// ---- second pass for ksplit > 1: out = sum_s partial[s] (+bias), fixed order ----------------
+template <typename T>
+__global__ void __launch_bounds__(256) gemv_reduce_kernel(const float* __restrict__ partial, const T* __restrict__ bias,
+                                                          T* __restrict__ out, int S, int M, int N) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += partial[(size_t)k * total + i];
+        if (bias) s += DType<T>::to_f32(bias[i % N]);
+        out[i] = DType<T>::from_f32(s);
+    }
+}
+
+// ---- host side: shape heuristic + dispatch ---------------------------------------------------
+static int pick_mt(int M) { return M >= 8 ? 8 : (M >= 4 ? 4 : (M >= 2 ? 2 : 1)); }
+
+GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
+    GemvPlan pl{};
+    const int kpu = unit_vals(L.bits);
+    pl.units_total = L.K / kpu;
+    const bool uniform_groups = (L.group_size % kpu == 0);
+    const bool seq = (L.g_idx == nullptr) || (L.qweight_seq != nullptr && L.perm != nullptr);
+    pl.perk = !(uniform_groups && seq);
+    pl.use_seq = (L.g_idx != nullptr) && !pl.perk;
+    pl.fast = (L.bits == 4 && L.dtype == GPTQ_F16 && !pl.perk);
+    if (tune && tune->path == 1) pl.fast = false;
+    pl.mt = pick_mt(M);
+    if (!pl.fast && pl.mt > 4) pl.mt = 4;
+    pl.mtiles = (M + pl.mt - 1) / pl.mt;
+
+    int ln = (tune && tune->lanes_n) ? tune->lanes_n : 0;
+    if (!ln) {
+        // widest strip that still gives >= 256 workgroups; else the narrowest (16 columns)
+        ln = 4;
+        for (int cand : {16, 8}) {
+            const int strips = (L.N + cand * 4 - 1) / (cand * 4);
+            if (strips * pl.mtiles >= 256) { ln = cand; break; }
+        }
+    }
+    pl.ln = ln;
+    const int wr = 64 / ln;
+    pl.strips = (L.N + ln * 4 - 1) / (ln * 4);
+    int ks = (tune && tune->ksplit) ? tune->ksplit : 0;
+    if (!ks) {
+        ks = 1;
+        while (pl.strips * pl.mtiles * ks < 192 && pl.units_total / (ks * 2) >= wr * 4) ks *= 2;
+    }
+    if (ks > pl.units_total) ks = pl.units_total;
+    pl.ksplit = ks;
+    pl.units_per_split = (pl.units_total + ks - 1) / ks;
+    int waves = (tune && tune->waves) ? tune->waves : 0;
+    if (!waves) {
+        waves = (pl.units_per_split + wr - 1) / wr;   // one unit per lane if possible
+        if (waves > 16) waves = 16;
+        if (waves < 1) waves = 1;
+    }
+    pl.waves = waves;
+    // x chunk: keep LDS <= 64 KiB
+    const int bytes_per_unit = pl.mt * kpu * (pl.fast ? 2 : 4);
+    int cu = (64 * 1024) / bytes_per_unit;
+    if (cu > pl.units_per_split) cu = pl.units_per_split;
+    cu = (cu / (wr * waves)) * (wr * waves);
+    if (cu < wr * waves) cu = wr * waves < pl.units_per_split ? wr * waves : pl.units_per_split;
+    pl.chunk_units = cu;
+    const size_t xbytes = (size_t)cu * bytes_per_unit;
+    const size_t rbytes = (size_t)waves * pl.mt * ln * 4 * sizeof(float);
+    pl.lds_bytes = xbytes > rbytes ? xbytes : rbytes;
+    pl.workspace_bytes = ks > 1 ? (size_t)ks * M * L.N * sizeof(float) : 0;
+    return pl;
+}
+
+template <int BITS, typename T, int LN, int MT>
+static hipError_t launch_generic_ln(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
+    dim3 grid(pl.strips, pl.ksplit, pl.mtiles), block(pl.waves * 64);
+    if (pl.perk)
+        hipLaunchKernelGGL((gemv_generic_kernel<BITS, T, LN, MT, true>), grid, block, pl.lds_bytes, st, p);
+    else
+        hipLaunchKernelGGL((gemv_generic_kernel<BITS, T, LN, MT, false>), grid, block, pl.lds_bytes, st, p);
+    return hipGetLastError();
+}
+
+template <int BITS, typename T, int MT>
+static hipError_t launch_generic_mt(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
+    switch (pl.ln) {
+        case 4: return launch_generic_ln<BITS, T, 4, MT>(pl, p, st);
+        case 8: return launch_generic_ln<BITS, T, 8, MT>(pl, p, st);
+        case 16: return launch_generic_ln<BITS, T, 16, MT>(pl, p, st);
+        case 64: return launch_generic_ln<BITS, T, 64, MT>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int BITS, typename T>
+static hipError_t launch_generic_bits(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
+    switch (pl.mt) {
+        case 1: return launch_generic_mt<BITS, T, 1>(pl, p, st);
+        case 2: return launch_generic_mt<BITS, T, 2>(pl, p, st);
+        case 4: return launch_generic_mt<BITS, T, 4>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <typename T>
+static hipError_t launch_generic(const gptq_layer_t& L, const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
+    switch (L.bits) {
+        case 2: return launch_generic_bits<2, T>(pl, p, st);
+        case 3: return launch_generic_bits<3, T>(pl, p, st);
+        case 4: return launch_generic_bits<4, T>(pl, p, st);
+        case 8: return launch_generic_bits<8, T>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int LN, int MT>
+static hipError_t launch_fast_u(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
+    dim3 grid(pl.strips, pl.ksplit, pl.mtiles), block(pl.waves * 64);
+    const int per_lane = (pl.chunk_units + (64 / LN) * pl.waves - 1) / ((64 / LN) * pl.waves);
+    if (per_lane <= 1)
+        hipLaunchKernelGGL((gemv_q4_f16_kernel<LN, MT, 1>), grid, block, pl.lds_bytes, st, p);
+    else if (per_lane <= 2)
+        hipLaunchKernelGGL((gemv_q4_f16_kernel<LN, MT, 2>), grid, block, pl.lds_bytes, st, p);
+    else
+        hipLaunchKernelGGL((gemv_q4_f16_kernel<LN, MT, 4>), grid, block, pl.lds_bytes, st, p);
+    return hipGetLastError();
+}
+
+template <int MT>
+static hipError_t launch_fast_mt(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
+    switch (pl.ln) {
+        case 4: return launch_fast_u<4, MT>(pl, p, st);
+        case 8: return launch_fast_u<8, MT>(pl, p, st);
+        case 16: return launch_fast_u<16, MT>(pl, p, st);
+        case 64: return launch_fast_u<64, MT>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x, void* out, int M,
+                       void* workspace, hipStream_t st) {
+    GemvParams p{};
+    p.qweight = pl.use_seq ? L.qweight_seq : L.qweight;
+    p.qzeros = L.qzeros;
+    p.scales = L.scales;
+    p.g_idx = pl.perk ? L.g_idx : nullptr;
+    p.perm = pl.use_seq ? L.perm : nullptr;
+    p.bias = L.bias;
+    p.x = x;
+    p.out = out;
+    p.partial = (float*)workspace;
+    p.M = M; p.K = L.K; p.N = L.N; p.group_size = L.group_size; p.zero_mode = L.zero_mode;
+    p.units_total = pl.units_total; p.units_per_split = pl.units_per_split;
+    p.chunk_units = pl.chunk_units; p.ksplit = pl.ksplit;
+
+    hipError_t e;
+    if (pl.fast) {
+        switch (pl.mt) {
+            case 1: e = launch_fast_mt<1>(pl, p, st); break;
+            case 2: e = launch_fast_mt<2>(pl, p, st); break;
+            case 4: e = launch_fast_mt<4>(pl, p, st); break;
+            case 8: e = launch_fast_mt<8>(pl, p, st); break;
+            default: e = hipErrorInvalidValue;
+        }
+    } else {
+        switch (L.dtype) {
+            case GPTQ_F16: e = launch_generic<f16>(L, pl, p, st); break;
+            case GPTQ_BF16: e = launch_generic<bf16>(L, pl, p, st); break;
+            case GPTQ_F32: e = launch_generic<float>(L, pl, p, st); break;
+            default: e = hipErrorInvalidValue;
+        }
+    }
+    if (e != hipSuccess) return e;
+    if (pl.ksplit > 1) {
+        const size_t total = (size_t)M * L.N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        switch (L.dtype) {
+            case GPTQ_F16:
+                hipLaunchKernelGGL(gemv_reduce_kernel<f16>, dim3(blocks), dim3(256), 0, st, p.partial, (const f16*)L.bias, (f16*)out, pl.ksplit, M, L.N);
+                break;
+            case GPTQ_BF16:
+                hipLaunchKernelGGL(gemv_reduce_kernel<bf16>, dim3(blocks), dim3(256), 0, st, p.partial, (const bf16*)L.bias, (bf16*)out, pl.ksplit, M, L.N);
+                break;
+            default:
+                hipLaunchKernelGGL(gemv_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, p.partial, (const float*)L.bias, (float*)out, pl.ksplit, M, L.N);
+        }
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+}  // namespace gptq

@@ -1,0 +1,39 @@
+// launch.h -- host-side declarations shared between the kernel translation units and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "../../include/gptq_mi355x.h"
+
+namespace gptq {
+
+struct GemvPlan {
+    int ln, waves, ksplit, strips, mt, mtiles;
+    int units_total, units_per_split, chunk_units;
+    bool fast, perk, use_seq;
+    size_t lds_bytes, workspace_bytes;
+};
+GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune);
+hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x, void* out, int M,
+                       void* workspace, hipStream_t st);
+
+struct GemmPlan {
+    bool supported, use_seq;
+    int bm, bn;
+    size_t workspace_bytes;   // permuted-x scratch for act-order layers
+};
+GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune);
+hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x, void* out, int M,
+                       void* workspace, hipStream_t st);
+
+hipError_t launch_dequant(const gptq_layer_t& L, void* W_out, hipStream_t st);
+hipError_t launch_unpack_weights(const uint32_t* qweight, int K, int N, int bits, uint8_t* w_out, hipStream_t st);
+hipError_t launch_unpack_zeros(const uint32_t* qzeros, int G, int N, int bits, int zero_mode, int32_t* z_out, hipStream_t st);
+hipError_t launch_pack_weights(const void* W, const void* scale_in, const void* zero_in, const int32_t* g_idx,
+                               int K, int N, int bits, int group_size, int w_dtype, int qparam_dtype,
+                               uint32_t* qweight_out, void* scales_out, hipStream_t st);
+hipError_t launch_pack_zeros(const void* zero_in, int G, int N, int bits, int qparam_dtype, uint32_t* qzeros_out, hipStream_t st);
+hipError_t launch_resequence(const uint32_t* qweight, const int32_t* perm, int K, int N, int bits,
+                             uint32_t* out, hipStream_t st);
+hipError_t launch_permute_columns(const void* x, const int32_t* perm, int M, int K, int dtype, void* x_out, hipStream_t st);
+
+}  // namespace gptq

@@ -1,0 +1,310 @@
+// utils.hip -- layout kernels either side of the matmul: integer unpack, full dequant
+// ("reconstruct"), device pack(), act-order row re-sequencing, x column permutation.
+//
+// Reference behaviour being reproduced (AutoGPTQ v0.8.0.dev0; nothing is copied):
+//   unpack / dequant   auto_gptq/nn_modules/qlinear/qlinear_cuda_old.py:295-349, qlinear_cuda.py:257-302
+//   pack               auto_gptq/nn_modules/qlinear/qlinear_cuda.py:108-203
+//   re-sequencing      semantics of Q4Matrix::make_sequential, autogptq_extension/exllama/cuda_func/q4_matrix.cu:63-169
+//   column remap       autogptq_extension/exllama/cuda_func/column_remap.cu:9-63
+// All of these are HBM-bound integer/byte kernels: lanes run along N (the contiguous axis of
+// every GPTQ tensor) with 4 columns (16 B of packed words) per lane.
+#include "common.cuh"
+#include "launch.h"
+
+namespace gptq {
+
+// ---------------------------------------------------------------------------------------------
+template <int BITS>
+__global__ void __launch_bounds__(256) unpack_weights_kernel(const unsigned* __restrict__ qweight, int units, int N,
+                                                             uint8_t* __restrict__ out) {
+    constexpr int UW = Pack<BITS>::words, KPU = Pack<BITS>::vals;
+    const int n0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int u = blockIdx.y;
+    if (n0 >= N || u >= units) return;
+    u32x4 q[UW];
+#pragma unroll
+    for (int w = 0; w < UW; ++w) q[w] = *(const u32x4*)(qweight + (size_t)(u * UW + w) * N + n0);
+    [&]<int... V>(std::integer_sequence<int, V...>) {
+        (([&] {
+             unsigned o = 0;
+#pragma unroll
+             for (int c = 0; c < 4; ++c) {
+                 unsigned w[UW];
+#pragma unroll
+                 for (int i = 0; i < UW; ++i) w[i] = q[i][c];
+                 o |= unit_field<BITS, V>(w) << (8 * c);
+             }
+             *(unsigned*)(out + (size_t)(u * KPU + V) * N + n0) = o;
+         }()),
+         ...);
+    }(std::make_integer_sequence<int, KPU>{});
+}
+
+__global__ void __launch_bounds__(256) unpack_zeros_kernel(const unsigned* __restrict__ qzeros, int G, int N, int bits,
+                                                           int zero_mode, int* __restrict__ out) {
+    const int n0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int g = blockIdx.y;
+    if (n0 >= N || g >= G) return;
+    int z[4];
+    zero_points4(qzeros + (size_t)g * (N / 32 * bits), n0, bits, zero_mode, z);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[(size_t)g * N + n0 + c] = z[c];
+}
+
+// W[k,n] = T( float(scale[g,n]) * float(w - z) ): the fp32 product is exact for 16-bit scales, so
+// this is the correctly rounded product = what torch computes for scales * (weight - zeros).
+template <int BITS, typename T>
+__global__ void __launch_bounds__(256) dequant_kernel(const unsigned* __restrict__ qweight, const unsigned* __restrict__ qzeros,
+                                                      const T* __restrict__ scales, const int* __restrict__ g_idx,
+                                                      int units, int N, int group_size, int zero_mode,
+                                                      T* __restrict__ out) {
+    constexpr int UW = Pack<BITS>::words, KPU = Pack<BITS>::vals;
+    const int n0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int u = blockIdx.y;
+    if (n0 >= N || u >= units) return;
+    u32x4 q[UW];
+#pragma unroll
+    for (int w = 0; w < UW; ++w) q[w] = *(const u32x4*)(qweight + (size_t)(u * UW + w) * N + n0);
+    const int zrow_words = N / 32 * BITS;
+    [&]<int... V>(std::integer_sequence<int, V...>) {
+        (([&] {
+             const int k = u * KPU + V;
+             const int g = g_idx ? g_idx[k] : k / group_size;
+             int z[4];
+             zero_points4(qzeros + (size_t)g * zrow_words, n0, BITS, zero_mode, z);
+#pragma unroll
+             for (int c = 0; c < 4; ++c) {
+                 unsigned w[UW];
+#pragma unroll
+                 for (int i = 0; i < UW; ++i) w[i] = q[i][c];
+                 const float s = DType<T>::to_f32(scales[(size_t)g * N + n0 + c]);
+                 out[(size_t)k * N + n0 + c] = DType<T>::from_f32(s * (float)((int)unit_field<BITS, V>(w) - z[c]));
+             }
+         }()),
+         ...);
+    }(std::make_integer_sequence<int, KPU>{});
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack(): arithmetic in torch's promoted dtype, rounding after every op like the CPU reference.
+__device__ __forceinline__ float load_as_f32(const void* p, size_t i, int dt) {
+    switch (dt) {
+        case GPTQ_F16: return (float)((const f16*)p)[i];
+        case GPTQ_BF16: return (float)((const bf16*)p)[i];
+        default: return ((const float*)p)[i];
+    }
+}
+__device__ __forceinline__ float round_to(float v, int dt) {
+    switch (dt) {
+        case GPTQ_F16: return (float)(f16)v;
+        case GPTQ_BF16: return (float)(bf16)v;
+        default: return v;
+    }
+}
+__host__ __device__ inline int promote(int a, int b) { return (a == b) ? a : GPTQ_F32; }
+
+template <int BITS>
+__global__ void __launch_bounds__(256) pack_weights_kernel(const void* __restrict__ W, const void* __restrict__ scale_in,
+                                                           const void* __restrict__ zero_in, const int* __restrict__ g_idx,
+                                                           int K, int N, int group_size, int w_dt, int q_dt,
+                                                           unsigned* __restrict__ qweight, void* __restrict__ scales_out) {
+    constexpr int UW = Pack<BITS>::words, KPU = Pack<BITS>::vals;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int u = blockIdx.y;
+    if (n >= N || u >= K / KPU) return;
+    const int p_dt = promote(w_dt, q_dt);
+    unsigned vals[KPU];
+#pragma unroll
+    for (int v = 0; v < KPU; ++v) {
+        const int k = u * KPU + v;
+        const int g = g_idx ? g_idx[k] : k / group_size;
+        const float s_in = load_as_f32(scale_in, (size_t)g * N + n, q_dt);
+        const float z_in = load_as_f32(zero_in, (size_t)g * N + n, q_dt);
+        const float sz = round_to(z_in * s_in, q_dt);                     // scale_zeros = zeros * scales
+        const float s_cast = round_to(s_in, w_dt);                         // self.scales (layer dtype)
+        const float w = load_as_f32(W, (size_t)n * K + k, w_dt);
+        const float sum = round_to(w + sz, p_dt);
+        const float quo = round_to(sum / s_cast, p_dt);
+        vals[v] = (unsigned)(int)rintf(quo);                               // torch.round = half-to-even
+    }
+    unsigned w[UW];
+#pragma unroll
+    for (int i = 0; i < UW; ++i) w[i] = 0u;
+    if constexpr (BITS != 3) {
+#pragma unroll
+        for (int v = 0; v < KPU; ++v) w[0] |= vals[v] << (BITS * v);        // unmasked OR, like the reference
+    } else {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[0] |= vals[j] << (3 * j);
+        w[0] |= vals[10] << 30;
+        w[1] |= (vals[10] >> 2) & 1u;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[1] |= vals[11 + j] << (3 * j + 1);
+        w[1] |= vals[21] << 31;
+        w[2] |= (vals[21] >> 1) & 3u;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[2] |= vals[22 + j] << (3 * j + 2);
+    }
+#pragma unroll
+    for (int i = 0; i < UW; ++i) qweight[(size_t)(u * UW + i) * N + n] = w[i];
+    // scales_out = scales.to(layer dtype); written once per (g, n) by the unit that starts a group row
+    if (scales_out && u == 0) {
+        const int G = (K + group_size - 1) / group_size;
+        for (int g = 0; g < G; ++g) {
+            const float s = round_to(load_as_f32(scale_in, (size_t)g * N + n, q_dt), w_dt);
+            switch (w_dt) {
+                case GPTQ_F16: ((f16*)scales_out)[(size_t)g * N + n] = (f16)s; break;
+                case GPTQ_BF16: ((bf16*)scales_out)[(size_t)g * N + n] = (bf16)s; break;
+                default: ((float*)scales_out)[(size_t)g * N + n] = s;
+            }
+        }
+    }
+}
+
+template <int BITS>
+__global__ void __launch_bounds__(256) pack_zeros_kernel(const void* __restrict__ zero_in, int G, int N, int q_dt,
+                                                         unsigned* __restrict__ qzeros) {
+    constexpr int UW = Pack<BITS>::words, KPU = Pack<BITS>::vals;
+    const int cu = blockIdx.x * blockDim.x + threadIdx.x;   // column unit
+    const int g = blockIdx.y;
+    if (cu >= N / KPU || g >= G) return;
+    unsigned vals[KPU];
+#pragma unroll
+    for (int v = 0; v < KPU; ++v) {
+        const float z = round_to(load_as_f32(zero_in, (size_t)g * N + cu * KPU + v, q_dt) - 1.0f, q_dt);  // zeros -= 1
+        vals[v] = (unsigned)(long long)z;                    // numpy .astype(uint32): -1.0 -> 0xFFFFFFFF
+    }
+    unsigned w[UW];
+#pragma unroll
+    for (int i = 0; i < UW; ++i) w[i] = 0u;
+    if constexpr (BITS != 3) {
+#pragma unroll
+        for (int v = 0; v < KPU; ++v) w[0] |= vals[v] << (BITS * v);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[0] |= vals[j] << (3 * j);
+        w[0] |= vals[10] << 30;
+        w[1] |= (vals[10] >> 2) & 1u;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[1] |= vals[11 + j] << (3 * j + 1);
+        w[1] |= vals[21] << 31;
+        w[2] |= (vals[21] >> 1) & 3u;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) w[2] |= vals[22 + j] << (3 * j + 2);
+    }
+#pragma unroll
+    for (int i = 0; i < UW; ++i) qzeros[(size_t)g * (N / 32 * BITS) + cu * UW + i] = w[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// out row-stream position i holds the field of source k = perm[i] (masked fields, clean re-pack).
+template <int BITS>
+__global__ void __launch_bounds__(256) resequence_kernel(const unsigned* __restrict__ qweight, const int* __restrict__ perm,
+                                                         int units, int N, unsigned* __restrict__ out) {
+    constexpr int UW = Pack<BITS>::words, KPU = Pack<BITS>::vals;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int u = blockIdx.y;
+    if (n >= N || u >= units) return;
+    unsigned long long lo = 0ull;  // bits 0..63 of the unit stream
+    unsigned hi = 0u;              // bits 64..95 (3-bit only)
+#pragma unroll
+    for (int v = 0; v < KPU; ++v) {
+        const unsigned f = stream_field(qweight + n, (size_t)N, (unsigned)perm[u * KPU + v], BITS);
+        const int bit = BITS * v;
+        if (bit < 64) {
+            lo |= (unsigned long long)f << bit;
+            if (bit + BITS > 64) hi |= f >> (64 - bit);
+        } else {
+            hi |= f << (bit - 64);
+        }
+    }
+    out[(size_t)(u * UW) * N + n] = (unsigned)lo;
+    if constexpr (UW == 3) {
+        out[(size_t)(u * UW + 1) * N + n] = (unsigned)(lo >> 32);
+        out[(size_t)(u * UW + 2) * N + n] = hi;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) permute_columns_kernel(const T* __restrict__ x, const int* __restrict__ perm, int M, int K,
+                                                              T* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    const int src = perm[i];
+    for (int m = blockIdx.y; m < M; m += gridDim.y) out[(size_t)m * K + i] = x[(size_t)m * K + src];
+}
+
+// ---------------------------------------------------------------------------------------------
+#define GPTQ_BITS_SWITCH(bits, EXPR)                      \
+    switch (bits) {                                       \
+        case 2: { constexpr int B = 2; EXPR; } break;     \
+        case 3: { constexpr int B = 3; EXPR; } break;     \
+        case 4: { constexpr int B = 4; EXPR; } break;     \
+        case 8: { constexpr int B = 8; EXPR; } break;     \
+        default: return hipErrorInvalidValue;             \
+    }
+
+hipError_t launch_unpack_weights(const uint32_t* qweight, int K, int N, int bits, uint8_t* w_out, hipStream_t st) {
+    const int units = K / unit_vals(bits);
+    dim3 grid((N / 4 + 255) / 256, units), block(256);
+    GPTQ_BITS_SWITCH(bits, hipLaunchKernelGGL(unpack_weights_kernel<B>, grid, block, 0, st, qweight, units, N, w_out));
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_zeros(const uint32_t* qzeros, int G, int N, int bits, int zero_mode, int32_t* z_out, hipStream_t st) {
+    dim3 grid((N / 4 + 255) / 256, G), block(256);
+    hipLaunchKernelGGL(unpack_zeros_kernel, grid, block, 0, st, qzeros, G, N, bits, zero_mode, z_out);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_dequant_t(const gptq_layer_t& L, void* W_out, hipStream_t st) {
+    const int units = L.K / unit_vals(L.bits);
+    dim3 grid((L.N / 4 + 255) / 256, units), block(256);
+    GPTQ_BITS_SWITCH(L.bits, hipLaunchKernelGGL((dequant_kernel<B, T>), grid, block, 0, st, L.qweight, L.qzeros,
+                                                (const T*)L.scales, L.g_idx, units, L.N, L.group_size, L.zero_mode, (T*)W_out));
+    return hipGetLastError();
+}
+
+hipError_t launch_dequant(const gptq_layer_t& L, void* W_out, hipStream_t st) {
+    switch (L.dtype) {
+        case GPTQ_F16: return launch_dequant_t<f16>(L, W_out, st);
+        case GPTQ_BF16: return launch_dequant_t<bf16>(L, W_out, st);
+        case GPTQ_F32: return launch_dequant_t<float>(L, W_out, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_pack_weights(const void* W, const void* scale_in, const void* zero_in, const int32_t* g_idx,
+                               int K, int N, int bits, int group_size, int w_dtype, int qparam_dtype,
+                               uint32_t* qweight_out, void* scales_out, hipStream_t st) {
+    dim3 grid((N + 255) / 256, K / unit_vals(bits)), block(256);
+    GPTQ_BITS_SWITCH(bits, hipLaunchKernelGGL(pack_weights_kernel<B>, grid, block, 0, st, W, scale_in, zero_in, g_idx, K, N,
+                                              group_size, w_dtype, qparam_dtype, qweight_out, scales_out));
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_zeros(const void* zero_in, int G, int N, int bits, int qparam_dtype, uint32_t* qzeros_out, hipStream_t st) {
+    dim3 grid((N / unit_vals(bits) + 255) / 256, G), block(256);
+    GPTQ_BITS_SWITCH(bits, hipLaunchKernelGGL(pack_zeros_kernel<B>, grid, block, 0, st, zero_in, G, N, qparam_dtype, qzeros_out));
+    return hipGetLastError();
+}
+
+hipError_t launch_resequence(const uint32_t* qweight, const int32_t* perm, int K, int N, int bits, uint32_t* out, hipStream_t st) {
+    const int units = K / unit_vals(bits);
+    dim3 grid((N + 255) / 256, units), block(256);
+    GPTQ_BITS_SWITCH(bits, hipLaunchKernelGGL(resequence_kernel<B>, grid, block, 0, st, qweight, perm, units, N, out));
+    return hipGetLastError();
+}
+
+hipError_t launch_permute_columns(const void* x, const int32_t* perm, int M, int K, int dtype, void* x_out, hipStream_t st) {
+    dim3 grid((K + 255) / 256, M < 1024 ? M : 1024), block(256);
+    if (dtype == GPTQ_F32)
+        hipLaunchKernelGGL(permute_columns_kernel<float>, grid, block, 0, st, (const float*)x, perm, M, K, (float*)x_out);
+    else
+        hipLaunchKernelGGL(permute_columns_kernel<unsigned short>, grid, block, 0, st, (const unsigned short*)x, perm, M, K,
+                           (unsigned short*)x_out);
+    return hipGetLastError();
+}
+
+}  // namespace gptq

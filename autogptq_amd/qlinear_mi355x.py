@@ -1,0 +1,357 @@
+"""``QuantLinear`` backend ``QUANT_TYPE = "mi355x"``: AutoGPTQ's quantized linear on MI355X (gfx950).
+
+Mirrors the plugin surface of the reference's backends so it drops into
+``auto_gptq.nn_modules.qlinear`` as just another one:
+
+* constructor signature, attributes and buffers (``qweight / qzeros / scales / g_idx / bias``, same
+  names, shapes, dtypes = the checkpoint ABI)    auto_gptq/nn_modules/qlinear/qlinear_cuda.py:27-103,
+                                                  qlinear_cuda_old.py:26-105
+* ``pack(linear, scales, zeros, g_idx)``          qlinear_cuda.py:108-203
+* ``post_init()``                                 qlinear_exllama.py:106-119 (derive side buffers on device)
+* ``forward(x)``                                  qlinear_cuda_old.py:202-355, qlinear_cuda.py:205-317
+
+The matmul itself always runs in the HIP library (``libgptq_mi355x.so`` through the C ABI of
+``include/gptq_mi355x.h``).  There is no PyTorch/CPU fallback: ``forward`` on a non-GPU tensor or
+without the built library raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from logging import getLogger
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+logger = getLogger(__name__)
+
+_WARNED = set()
+
+
+def _warn_once(msg: str) -> None:
+    if msg not in _WARNED:
+        _WARNED.add(msg)
+        logger.warning(msg)
+
+
+# one scratch buffer per device, shared by every layer (the reference keeps the same kind of
+# per-device scratch in model.device_to_buffers, auto_gptq/modeling/_utils.py:448-470)
+_WORKSPACE: dict = {}
+
+
+def reserve_workspace(device, nbytes: int) -> torch.Tensor:
+    """Make sure the per-device scratch holds ``nbytes``; call before hipGraph capture."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _WORKSPACE.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WORKSPACE[key] = buf
+    return buf
+
+
+def _is_sequential_g_idx(g_idx: torch.Tensor, group_size: int) -> bool:
+    k = g_idx.numel()
+    ref = torch.arange(k, dtype=torch.int64, device=g_idx.device) // group_size
+    return bool(torch.equal(g_idx.to(torch.int64), ref))
+
+
+class QuantLinear(nn.Module):
+    QUANT_TYPE = "mi355x"
+
+    def __init__(
+        self,
+        bits,
+        group_size,
+        infeatures,
+        outfeatures,
+        bias,
+        use_cuda_fp16=True,
+        kernel_switch_threshold=128,
+        trainable=False,
+        weight_dtype=torch.float16,
+        zero_mode="auto",
+        **kwargs,
+    ):
+        super().__init__()
+        if bits not in [2, 3, 4, 8]:
+            raise NotImplementedError("Only 2,3,4,8 bits are supported.")
+        if trainable:
+            raise NotImplementedError("The mi355x QuantLinear backend is inference-only (trainable=True is not supported).")
+        if infeatures % 32 != 0 or outfeatures % 32 != 0:
+            raise ValueError("infeatures and outfeatures must be divisible by 32 (packed-layout requirement).")
+        if weight_dtype not in _lib.DTYPE_ENUM:
+            raise ValueError(f"weight_dtype must be float16, bfloat16 or float32, got {weight_dtype}")
+        if zero_mode not in ("auto", "wrap", "nowrap"):
+            raise ValueError("zero_mode must be 'auto', 'wrap' or 'nowrap'")
+
+        self.infeatures = infeatures
+        self.outfeatures = outfeatures
+        self.bits = bits
+        self.group_size = group_size if group_size != -1 else infeatures
+        self.maxq = 2 ** self.bits - 1
+        self.trainable = trainable
+        self.use_cuda_fp16 = use_cuda_fp16            # accepted for make_quant compatibility; unused
+        self.kernel_switch_threshold = kernel_switch_threshold
+        self.zero_mode = zero_mode
+
+        G = math.ceil(infeatures / self.group_size)
+        self.register_buffer("qweight", torch.zeros((infeatures // 32 * bits, outfeatures), dtype=torch.int32))
+        self.register_buffer("qzeros", torch.zeros((G, outfeatures // 32 * bits), dtype=torch.int32))
+        self.register_buffer("scales", torch.zeros((G, outfeatures), dtype=weight_dtype))
+        self.register_buffer(
+            "g_idx", torch.tensor([i // self.group_size for i in range(infeatures)], dtype=torch.int32))
+        if bias:
+            self.register_buffer("bias", torch.zeros((outfeatures), dtype=weight_dtype))
+        else:
+            self.bias = None
+
+        # derived, non-persistent state (never part of state_dict; checkpoint tensors stay intact)
+        self._layer = None            # ctypes GptqLayer
+        self._keepalive = ()          # tensors the raw pointers in _layer refer to
+        self._ws_need = {}            # M -> workspace bytes
+        self.act_order = None         # resolved by post_init
+
+    # ------------------------------------------------------------------ state handling
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._invalidate()
+        return out
+
+    def _invalidate(self):
+        self._layer = None
+        self._keepalive = ()
+        self._ws_need = {}
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._invalidate()
+
+    def resolved_zero_mode(self) -> int:
+        """'auto' = the convention of the reference class this backend stands in for: no act-order ->
+        cuda_old (wrap, except its 3-bit branch), act-order -> cuda (no wrap). SURVEY App. B #1."""
+        if self.zero_mode == "wrap":
+            return _lib.ZERO_WRAP
+        if self.zero_mode == "nowrap":
+            return _lib.ZERO_NOWRAP
+        if self.bits == 3 or self.act_order:
+            return _lib.ZERO_NOWRAP
+        return _lib.ZERO_WRAP
+
+    # ------------------------------------------------------------------ post_init
+    def post_init(self, temp_dq=None):
+        """Snapshot device pointers and, for act-order layers, derive the group-sorted copy of
+        qweight plus the x permutation (side buffers; qweight itself is never modified -- the
+        reference's exllama backends overwrite it in place, q4_matrix.cu:160)."""
+        dev = self.qweight.device
+        if dev.type != "cuda":
+            raise RuntimeError("mi355x QuantLinear.post_init needs the module on a ROCm GPU device "
+                               f"(got {dev}); there is no CPU path.")
+        lib = _lib.load()
+        if self.g_idx.numel() != self.infeatures:
+            raise NotImplementedError("len(g_idx) != infeatures (fused-QKV g_idx) is not supported.")
+        for name in ("qweight", "qzeros", "scales", "g_idx"):
+            t = getattr(self, name)
+            if not t.is_contiguous():
+                setattr(self, name, t.contiguous())
+        if self.scales.dtype not in _lib.DTYPE_ENUM:
+            raise ValueError(f"unsupported scales dtype {self.scales.dtype}")
+        if self.bias is not None and self.bias.dtype != self.scales.dtype:
+            self.bias = self.bias.to(self.scales.dtype)
+
+        self.act_order = not _is_sequential_g_idx(self.g_idx, self.group_size)
+        qweight_seq = perm = None
+        g_idx_ptr = None
+        if self.act_order:
+            g_host = self.g_idx.to("cpu", torch.int32).contiguous()
+            perm_host = torch.empty(self.infeatures, dtype=torch.int32)
+            uniform = ctypes.c_int(0)
+            _lib.check(lib.gptq_make_sequential(g_host.data_ptr(), self.infeatures, self.group_size,
+                                                perm_host.data_ptr(), ctypes.byref(uniform)))
+            g_idx_ptr = self.g_idx.data_ptr()
+            if uniform.value:
+                perm = perm_host.to(dev)
+                qweight_seq = torch.empty_like(self.qweight)
+                with torch.cuda.device(dev):
+                    _lib.check(lib.gptq_resequence_qweight(self.qweight.data_ptr(), perm.data_ptr(), self.infeatures,
+                                                           self.outfeatures, self.bits, qweight_seq.data_ptr(),
+                                                           _lib.current_stream_handle(dev)))
+        L = _lib.GptqLayer()
+        L.qweight = self.qweight.data_ptr()
+        L.qzeros = self.qzeros.data_ptr()
+        L.scales = self.scales.data_ptr()
+        L.g_idx = g_idx_ptr
+        L.bias = _lib.ptr(self.bias)
+        L.K, L.N, L.bits, L.group_size = self.infeatures, self.outfeatures, self.bits, self.group_size
+        L.dtype = _lib.DTYPE_ENUM[self.scales.dtype]
+        L.zero_mode = self.resolved_zero_mode()
+        L.qweight_seq = _lib.ptr(qweight_seq)
+        L.perm = _lib.ptr(perm)
+        self._layer = L
+        self._keepalive = (self.qweight, self.qzeros, self.scales, self.g_idx, self.bias, qweight_seq, perm)
+        self._ws_need = {}
+        return self
+
+    # ------------------------------------------------------------------ forward
+    def _workspace(self, M: int, device):
+        need = self._ws_need.get(M)
+        if need is None:
+            need = int(_lib.load().gptq_workspace_bytes(ctypes.byref(self._layer), M))
+            self._ws_need[M] = need
+        if need == 0:
+            return None, 0
+        buf = reserve_workspace(device, need)
+        return buf.data_ptr(), buf.numel()
+
+    def forward(self, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = None):
+        if x.device.type != "cuda":
+            raise RuntimeError("mi355x QuantLinear.forward needs a ROCm GPU tensor "
+                               f"(got {x.device}); there is no CPU path in this backend.")
+        if self._layer is None:
+            self.post_init()
+        lib = _lib.load()
+        out_shape = x.shape[:-1] + (self.outfeatures,)
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.shape[-1] != self.infeatures:
+            raise RuntimeError(f"input has {x2.shape[-1]} features, layer expects {self.infeatures}")
+        x_dtype = x2.dtype
+        w_dtype = self.scales.dtype
+        if x_dtype != w_dtype:
+            _warn_once(f"mi355x QuantLinear: activation dtype {x_dtype} != weight dtype {w_dtype}; casting the "
+                       f"activation to {w_dtype} (the result is cast back).")
+            x2 = x2.to(w_dtype)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        out = torch.empty((M, self.outfeatures), dtype=w_dtype, device=x2.device)
+        if M == 0:
+            return out.to(x_dtype).reshape(out_shape)
+        ws_ptr, ws_bytes = self._workspace(M, x2.device)
+        dev_idx = x2.device.index
+        stream = torch.cuda.current_stream(x2.device).cuda_stream
+        if dev_idx is not None and dev_idx != torch.cuda.current_device():
+            with torch.cuda.device(dev_idx):
+                rc = lib.gptq_forward_ex(ctypes.byref(self._layer), x2.data_ptr(), out.data_ptr(), M, ws_ptr, ws_bytes,
+                                         stream, ctypes.byref(tuning) if tuning is not None else None)
+        else:
+            rc = lib.gptq_forward_ex(ctypes.byref(self._layer), x2.data_ptr(), out.data_ptr(), M, ws_ptr, ws_bytes,
+                                     stream, ctypes.byref(tuning) if tuning is not None else None)
+        _lib.check(rc)
+        if x_dtype != w_dtype:
+            out = out.to(x_dtype)
+        return out.reshape(out_shape)
+
+    # ------------------------------------------------------------------ dequant / unpack helpers
+    def dequantize(self) -> torch.Tensor:
+        """[K, N] dequantised weight in the scales dtype (bit-exact w.r.t. the reference's `weights`)."""
+        if self._layer is None:
+            self.post_init()
+        W = torch.empty((self.infeatures, self.outfeatures), dtype=self.scales.dtype, device=self.qweight.device)
+        with torch.cuda.device(self.qweight.device):
+            _lib.check(_lib.load().gptq_dequant(ctypes.byref(self._layer), W.data_ptr(),
+                                                _lib.current_stream_handle(self.qweight.device)))
+        return W
+
+    # ------------------------------------------------------------------ pack
+    def pack(self, linear, scales, zeros, g_idx=None):
+        """Quantise ``linear.weight`` with (scales, zeros) [N, G] and fill qweight/qzeros/scales/g_idx/bias.
+
+        Same arithmetic order and dtype promotion as the reference (qlinear_cuda.py:117-131):
+        ``round((W + zeros*scales) / scales.to(W.dtype))``, fields OR-ed unmasked.  Runs on the GPU
+        through gptq_pack_weights/gptq_pack_zeros when one is present (the reference can only pack on
+        CPU, auto_gptq/modeling/_utils.py:303-309), otherwise as vectorised host tensor ops; results
+        are returned on the device the module lives on, as the reference leaves them on CPU.
+        """
+        import transformers
+
+        W = linear.weight.data.clone()
+        if isinstance(linear, nn.Conv2d):
+            W = W.flatten(1)
+        if isinstance(linear, transformers.pytorch_utils.Conv1D):
+            W = W.t()
+        if g_idx is not None:
+            self.g_idx = g_idx.clone().to(torch.int32)
+        gi = self.g_idx.to(torch.int64)
+        home = self.qweight.device
+
+        scales_t = scales.t().contiguous()
+        zeros_t = zeros.t().contiguous()
+        if linear.bias is not None:
+            self.bias = linear.bias.clone().to(dtype=linear.weight.dtype)
+
+        use_gpu = torch.cuda.is_available() and W.dtype in _lib.DTYPE_ENUM and scales_t.dtype in _lib.DTYPE_ENUM \
+            and zeros_t.dtype == scales_t.dtype
+        if use_gpu:
+            qweight, qzeros, scales_out = self._pack_device(W, scales_t, zeros_t, gi)
+        else:
+            qweight, qzeros, scales_out = self._pack_host(W, scales_t, zeros_t, gi)
+        self.qweight = qweight.to(home)
+        self.qzeros = qzeros.to(home)
+        self.scales = scales_out.to(home)
+        self._invalidate()
+
+    def _pack_device(self, W, scales_t, zeros_t, gi):
+        lib = _lib.load()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        K, N, bits = self.infeatures, self.outfeatures, self.bits
+        Wd = W.contiguous().to(dev)
+        sd, zd = scales_t.to(dev), zeros_t.to(dev)
+        gd = gi.to(dev, torch.int32).contiguous()
+        qweight = torch.empty((K // 32 * bits, N), dtype=torch.int32, device=dev)
+        qzeros = torch.empty((sd.shape[0], N // 32 * bits), dtype=torch.int32, device=dev)
+        scales_out = torch.empty(sd.shape, dtype=W.dtype, device=dev)
+        st = _lib.current_stream_handle(dev)
+        _lib.check(lib.gptq_pack_weights(Wd.data_ptr(), sd.data_ptr(), zd.data_ptr(), gd.data_ptr(), K, N, bits,
+                                         self.group_size, _lib.DTYPE_ENUM[W.dtype], _lib.DTYPE_ENUM[sd.dtype],
+                                         qweight.data_ptr(), scales_out.data_ptr(), st))
+        _lib.check(lib.gptq_pack_zeros(zd.data_ptr(), sd.shape[0], N, bits, _lib.DTYPE_ENUM[zd.dtype],
+                                       qzeros.data_ptr(), st))
+        torch.cuda.synchronize(dev)
+        return qweight, qzeros, scales_out
+
+    def _pack_host(self, W, scales_t, zeros_t, gi):
+        bits = self.bits
+        scale_zeros = zeros_t * scales_t
+        s_cast = scales_t.clone().to(dtype=W.dtype)
+        intweight = torch.round((W.t() + scale_zeros[gi]) / s_cast[gi]).to(torch.int)   # [K, N]
+        qweight = _pack_fields(intweight.to(torch.int64) & 0xFFFFFFFF, bits)
+        zm1 = (zeros_t - 1).to(torch.int64) & 0xFFFFFFFF                                 # [G, N]
+        qzeros = _pack_fields(zm1.t().contiguous(), bits).t().contiguous()
+        return qweight, qzeros, s_cast
+
+
+def _pack_fields(vals_u32: torch.Tensor, bits: int) -> torch.Tensor:
+    """Pack uint32 values (held in int64) along dim 0 into int32 words, OR-ing whole (unmasked)
+    values exactly as the reference does (qlinear_cuda.py:139-162)."""
+    mask = 0xFFFFFFFF
+    V = vals_u32.shape[0]
+    if bits in (2, 4, 8):
+        per = 32 // bits
+        v = vals_u32.reshape(V // per, per, *vals_u32.shape[1:])
+        out = torch.zeros((V // per,) + tuple(vals_u32.shape[1:]), dtype=torch.int64)
+        for j in range(per):
+            out |= (v[:, j] << (bits * j)) & mask
+    else:
+        v = vals_u32.reshape(V // 32, 32, *vals_u32.shape[1:])
+        w0 = torch.zeros((V // 32,) + tuple(vals_u32.shape[1:]), dtype=torch.int64)
+        w1 = torch.zeros_like(w0)
+        w2 = torch.zeros_like(w0)
+        for j in range(10):
+            w0 |= (v[:, j] << (3 * j)) & mask
+        w0 |= (v[:, 10] << 30) & mask
+        w1 |= (v[:, 10] >> 2) & 1
+        for j in range(10):
+            w1 |= (v[:, 11 + j] << (3 * j + 1)) & mask
+        w1 |= (v[:, 21] << 31) & mask
+        w2 |= (v[:, 21] >> 1) & 3
+        for j in range(10):
+            w2 |= (v[:, 22 + j] << (3 * j + 2)) & mask
+        out = torch.stack([w0, w1, w2], dim=1).reshape((V // 32 * 3,) + tuple(vals_u32.shape[1:]))
+    out = torch.where(out >= 2 ** 31, out - 2 ** 32, out)
+    return out.to(torch.int32).contiguous()
+
+
+__all__ = ["QuantLinear", "reserve_workspace"]

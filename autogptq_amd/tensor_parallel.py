@@ -1,0 +1,82 @@
+"""out_features (column) tensor parallelism for QuantLinear: one process per GPU, one exchange.
+
+The reference has no multi-GPU execution of a layer at all (accelerate layer placement only,
+auto_gptq/modeling/_utils.py:341-377; ``test_multigpu`` is an empty TODO, tests/test_q4.py:1224-1226).
+What makes the split legal is the layout itself: output column n depends only on column n of
+``qweight``/``scales`` and on field n of ``qzeros[:, n // P]`` -- the reference relies on the same
+fact when it concatenates packed q/k/v along dim=1 (auto_gptq/nn_modules/fused_llama_attn.py:171-186).
+
+Rank r of T owns columns [r*N/T, (r+1)*N/T): ``qweight[:, n0:n1]``, ``qzeros[:, n0*bits/32 : n1*bits/32]``,
+``scales[:, n0:n1]``, ``bias[n0:n1]``; ``g_idx`` and x are replicated.  (N/T) must be a multiple of
+32 (the 3-bit packing unit).  forward = local GEMV/GEMM + ONE all-gather of the [M, N/T] outputs
+(RCCL over xGMI when the process group backend is "nccl").
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def shard_bounds(N: int, rank: int, world: int):
+    if N % world != 0 or (N // world) % 32 != 0:
+        raise ValueError(f"out_features={N} cannot be split over {world} ranks in multiples of 32 columns")
+    n = N // world
+    return rank * n, (rank + 1) * n
+
+
+def shard_packed(qweight, qzeros, scales, bias, bits: int, rank: int, world: int):
+    """Column slice of the four checkpoint tensors for ``rank`` (contiguous copies)."""
+    N = qweight.shape[1]
+    n0, n1 = shard_bounds(N, rank, world)
+    z0, z1 = n0 * bits // 32, n1 * bits // 32
+    return (qweight[:, n0:n1].contiguous(), qzeros[:, z0:z1].contiguous(), scales[:, n0:n1].contiguous(),
+            None if bias is None else bias[n0:n1].contiguous())
+
+
+class ColumnParallelQuantLinear(nn.Module):
+    """Wraps the rank-local shard (any module mapping [M,K] -> [M,N/T]) and gathers the output."""
+
+    def __init__(self, local: Callable[[torch.Tensor], torch.Tensor], outfeatures: int,
+                 group: Optional[dist.ProcessGroup] = None, gather_output: bool = True):
+        super().__init__()
+        self.local = local
+        self.outfeatures = outfeatures
+        self.group = group
+        self.gather_output = gather_output
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    @classmethod
+    def from_full(cls, full, rank: int, world: int, group=None, device=None, gather_output=True):
+        """Build the rank's shard from a full (unsharded) mi355x QuantLinear."""
+        from .qlinear_mi355x import QuantLinear
+
+        qw, qz, sc, b = shard_packed(full.qweight, full.qzeros, full.scales, full.bias, full.bits, rank, world)
+        local = QuantLinear(full.bits, full.group_size, full.infeatures, qw.shape[1], b is not None,
+                            weight_dtype=full.scales.dtype, zero_mode=full.zero_mode)
+        local.qweight, local.qzeros, local.scales, local.g_idx = qw, qz, sc, full.g_idx.clone()
+        if b is not None:
+            local.bias = b
+        if device is not None:
+            local = local.to(device)
+        return cls(local, full.outfeatures, group=group, gather_output=gather_output)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = self.local(x)                                   # [..., N/T]
+        if not self.gather_output or self.world == 1:
+            return y
+        lead = y.shape[:-1]
+        y2 = y.reshape(-1, y.shape[-1]).contiguous()         # [M, N/T]
+        M, nl = y2.shape
+        buf = torch.empty((self.world, M, nl), dtype=y2.dtype, device=y2.device)
+        dist.all_gather_into_tensor(buf, y2, group=self.group)
+        if M == 1:
+            out = buf.reshape(1, self.world * nl)            # rank-major == column-major for one row
+        else:
+            out = buf.permute(1, 0, 2).reshape(M, self.world * nl)
+        return out.reshape(lead + (self.world * nl,))
+
+
+__all__ = ["ColumnParallelQuantLinear", "shard_packed", "shard_bounds"]

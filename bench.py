@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""bench.py -- int4 g128 QuantLinear forward on Llama-7B linear shapes (BASELINE.json metric).
+
+One STEP = one token (M = 1 rows) pushed through every quantized linear of a Llama-7B decoder
+stack: 32 blocks x {q,k,v,o: 4096->4096, gate,up: 4096->11008, down: 11008->4096} = 224 distinct
+layers = 3.37 GB of packed weights, so every launch streams its weights from HBM (the working set
+is 13x the 256 MiB Infinity Cache -- a single-layer repeat loop would measure the cache instead).
+The 224 launches are captured once in a hipGraph (through torch's stream capture; the kernels are
+enqueued by libgptq_mi355x.so on the capturing stream) and replayed per step.
+
+  value      = algorithmic GB/s over the whole job (SURVEY App. C byte formula), inputs resident in HBM
+  tokens/s   = steps / time ("linear-only": attention/norm/sampling are not part of this path)
+  roofline   = dominant kernel: algorithmic bytes per launch / mean launch duration from HIP events
+               bracketing a graph that holds only that kernel's launches (rotating weights)
+  cpu_baseline = the oracle (port of the reference's CPU QuantLinear.forward) timed on host cores
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank streams its own token
+through its own copy of the stack -- independent requests, no data-path collective ("weak").  The
+optional out_features tensor-parallel mode (one RCCL all-gather per layer) is timed separately and
+reported under "tp" (Llama-2-70B shapes, BASELINE config 4).
+
+Workloads: --workload decode (default) | prefill (M = 2048, act-order, MFMA path, reports TFLOP/s).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA peak
+
+LLAMA7B_BLOCK = [("q_proj", 4096, 4096), ("k_proj", 4096, 4096), ("v_proj", 4096, 4096), ("o_proj", 4096, 4096),
+                 ("gate_proj", 4096, 11008), ("up_proj", 4096, 11008), ("down_proj", 11008, 4096)]
+LLAMA70B_TP = [("attn", 8192, 8192), ("gate_up", 8192, 28672)]
+
+
+def algorithmic_bytes(K, N, M, bits=4, gs=128, act_order=False, dtype_bytes=2, bias=False):
+    G = -(-K // gs)
+    b = K * N * bits // 8 + G * N * bits // 8 + G * N * dtype_bytes + dtype_bytes * M * K + dtype_bytes * M * N
+    if act_order:
+        b += 4 * K
+    if bias:
+        b += dtype_bytes * N
+    return b
+
+
+def make_layer(K, N, device, bits=4, gs=128, act_order=False, dtype=torch.float16, seed=0):
+    """Synthetic layer, generated on the device: random packed words (every bit pattern is legal),
+    scales 0.002*(1+0.1*rand) -- the recipe of SURVEY section 8(d) / tests/test_q4.py:1086-1112."""
+    import autogptq_amd
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    q = autogptq_amd.QuantLinear(bits, gs, K, N, False, weight_dtype=dtype)
+    G = -(-K // gs)
+    q.qweight = torch.randint(-2**31, 2**31 - 1, (K // 32 * bits, N), dtype=torch.int64, device=device, generator=g).to(torch.int32)
+    q.qzeros = torch.randint(-2**31, 2**31 - 1, (G, N // 32 * bits), dtype=torch.int64, device=device, generator=g).to(torch.int32)
+    q.scales = (0.002 * (1 + 0.1 * torch.rand(G, N, device=device, generator=g))).to(dtype)
+    gi = torch.arange(K, device=device, dtype=torch.int32) // gs
+    if act_order:
+        gi = gi[torch.randperm(K, device=device, generator=g)]
+    q.g_idx = gi.contiguous()
+    q = q.to(device)
+    q.post_init()
+    return q
+
+
+def build_stack(device, n_blocks, M, act_order, dtype=torch.float16):
+    layers = []
+    for b in range(n_blocks):
+        for i, (name, K, N) in enumerate(LLAMA7B_BLOCK):
+            layers.append((name, K, N, make_layer(K, N, device, act_order=act_order, dtype=dtype, seed=b * 16 + i)))
+    xs = {K: (torch.rand(M, K, device=device) - 0.5).to(dtype) for K in (4096, 11008)}
+    return layers, xs
+
+
+def capture(layers, xs, device):
+    """Capture one forward of every layer into a graph; returns (graph, keepalive outputs)."""
+    from autogptq_amd.qlinear_mi355x import reserve_workspace
+    import ctypes
+    from autogptq_amd import _lib
+
+    need = 0
+    for _, K, N, q in layers:
+        need = max(need, int(_lib.load().gptq_workspace_bytes(ctypes.byref(q._layer), xs[K].shape[0])))
+    reserve_workspace(device, max(need, 1))
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side), torch.no_grad():       # warm-up run (allocator, lazy init)
+        for _, K, N, q in layers:
+            q(xs[K])
+    torch.cuda.current_stream(device).wait_stream(side)
+    torch.cuda.synchronize(device)
+    g = torch.cuda.CUDAGraph()
+    outs = []
+    with torch.cuda.graph(g), torch.no_grad():
+        for _, K, N, q in layers:
+            outs.append(q(xs[K]))
+    return g, outs
+
+
+def time_graph(g, reps, device, dist_barrier=None):
+    """Wall clock (barrier + synchronize on both sides) and HIP events around `reps` replays."""
+    torch.cuda.synchronize(device)
+    if dist_barrier:
+        dist_barrier()
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize(device)
+    if dist_barrier:
+        dist_barrier()
+    t1 = time.perf_counter()
+    return t1 - t0, e0.elapsed_time(e1) * 1e-3
+
+
+def cpu_baseline(M, act_order, budget_s=20.0):
+    """Time the oracle (a port of the reference's pure-PyTorch CPU QuantLinear.forward: materialise
+    the unpacked ints, dequantise, torch.matmul) on the host cores, on a bounded sample: the three
+    distinct Llama-7B layer shapes, a few repetitions each."""
+    from oracle import gptq_oracle as O
+
+    threads = torch.get_num_threads()
+    total_b, total_t, reps_done = 0, 0.0, []
+    per_shape = budget_s / 3
+    for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
+        L = O.random_quant_layer(K, N, 4, 128, act_order=act_order, seed=1)
+        x = (torch.rand(M, K) - 0.5).half()
+        mode = O.reference_zero_mode(act_order, 4)
+        O.forward(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], None, 4, mode)   # warm-up
+        n, t_acc = 0, 0.0
+        while t_acc < per_shape and n < 10:
+            t0 = time.perf_counter()
+            O.forward(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], None, 4, mode)
+            t_acc += time.perf_counter() - t0
+            n += 1
+        total_b += n * algorithmic_bytes(K, N, M, act_order=act_order)
+        total_t += t_acc
+        reps_done.append(f"{K}x{N}x{n}")
+    return {"value": round(total_b / total_t / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": "oracle.forward (torch CPU, fp16) M=%d, shapes x reps: %s" % (M, ", ".join(reps_done)),
+            "ms_per_layer_mean": round(1e3 * total_t / sum(int(r.split('x')[2]) for r in reps_done), 2)}
+
+
+def bench_tp(device, rank, world, steps):
+    """Column-parallel Llama-2-70B shapes (BASELINE config 4), M = 1: local GEMV + one all-gather."""
+    import torch.distributed as dist
+    from autogptq_amd.tensor_parallel import ColumnParallelQuantLinear
+
+    res = {}
+    for name, K, N in LLAMA70B_TP:
+        nl = N // world
+        local = make_layer(K, nl, device, seed=rank)
+        mod = ColumnParallelQuantLinear(local, N)
+        x = (torch.rand(1, K, device=device) - 0.5).half()
+        for _ in range(5):
+            mod(x)
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            y = mod(x)
+        e1.record()
+        torch.cuda.synchronize(device)
+        t_all = e0.elapsed_time(e1) * 1e-3 / steps
+        e0.record()
+        for _ in range(steps):
+            local(x)
+        e1.record()
+        torch.cuda.synchronize(device)
+        t_loc = e0.elapsed_time(e1) * 1e-3 / steps
+        t = torch.tensor([t_all, t_loc], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        res[name] = {"K": K, "N": N, "tp": world, "us_per_layer_with_allgather": round(t[0].item() * 1e6, 2),
+                     "us_local_only": round(t[1].item() * 1e6, 2), "out_cols": int(y.shape[-1])}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="decode", choices=["decode", "prefill"])
+    ap.add_argument("--blocks", type=int, default=32, help="decoder blocks in the stack (32 = Llama-7B)")
+    ap.add_argument("--m", type=int, default=0, help="rows per step (default 1 for decode, 2048 for prefill)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tp", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    barrier = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+        barrier = dist.barrier
+
+    prefill = args.workload == "prefill"
+    M = args.m or (2048 if prefill else 1)
+    act_order = prefill                      # BASELINE config 3: desc_act=True on the prefill path
+    n_blocks = args.blocks if not prefill else min(args.blocks, 4)
+    layers, xs = build_stack(device, n_blocks, M, act_order)
+    g, outs = capture(layers, xs, device)
+
+    for _ in range(args.warmup):
+        g.replay()
+    wall, ev = time_graph(g, args.steps, device, barrier)
+    if world > 1:
+        t = torch.tensor([wall], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = t.item()
+
+    bytes_step = sum(algorithmic_bytes(K, N, M, act_order=act_order) for _, K, N, _ in layers)
+    flops_step = sum(2 * M * K * N for _, K, N, _ in layers)
+    launches = len(layers)
+
+    # ---- roofline of the dominant kernel: a graph holding only that layer type --------------------
+    roof = None
+    if rank == 0:
+        by_type = {}
+        for name, K, N, q in layers:
+            by_type.setdefault((K, N), []).append((name, K, N, q))
+        best = None
+        for (K, N), ls in by_type.items():
+            gg, oo = capture(ls, xs, device)
+            for _ in range(3):
+                gg.replay()
+            reps = max(3, args.steps // 2)
+            _, evt = time_graph(gg, reps, device)
+            per = evt / (reps * len(ls))
+            share = per * len(ls)
+            ent = dict(K=K, N=N, per_launch_s=per, share=share, n=len(ls))
+            if best is None or share > best["share"]:
+                best = ent
+            del gg, oo
+        K, N = best["K"], best["N"]
+        if prefill:
+            ach = 2 * M * K * N / best["per_launch_s"] / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None}
+        else:
+            ach = algorithmic_bytes(K, N, M, act_order=act_order) / best["per_launch_s"] / 1e9
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        roof["kernel"] = "gptq gemm (MFMA)" if prefill else "gptq::gemv_q4_f16_kernel"
+        roof["shape"] = f"K={K} N={N} M={M}"
+        roof["us_per_launch_events"] = round(best["per_launch_s"] * 1e6, 3)
+        roof["algorithmic_bytes_per_launch"] = algorithmic_bytes(K, N, M, act_order=act_order)
+
+    tp = None
+    if world > 1 and not args.no_tp and not prefill:
+        tp = bench_tp(device, rank, world, 50)
+
+    if rank == 0:
+        if prefill:
+            value, unit, metric = flops_step * args.steps * world / wall / 1e12, "TFLOP/s", \
+                "int4 g128 QuantLinear fwd TFLOP/s, Llama-7B shapes, prefill (desc_act)"
+        else:
+            value, unit, metric = bytes_step * args.steps * world / wall / 1e9, "GB/s", \
+                "int4 g128 QuantLinear fwd GB/s + tokens/s, Llama-7B shapes"
+        out = {
+            "metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": ("Llama-7B linear shapes (4096->4096 x4, 4096->11008 x2, 11008->4096) x %d blocks, int4 g128 %s, "
+                                    "M=%d rows per step, %d launches/step in one hipGraph" %
+                                    (n_blocks, "desc_act=True" if act_order else "no act-order", M, launches)),
+                       "rows_per_step": M, "layers": launches, "parallelism": f"dp{world}" if world > 1 else "single"},
+            "tokens_per_s": round(M * args.steps * world / wall, 1),
+            "tokens_per_s_note": "linear-only (the %d quantized linears of the stack; no attention/norm)" % launches,
+            "event_ms_per_step_rank0": round(1e3 * ev / args.steps, 4),
+            "algorithmic_bytes_per_step": bytes_step,
+            "roofline": roof,
+        }
+        if tp is not None:
+            out["tp"] = tp
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(1 if not prefill else 16, act_order)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+/* gptq_mi355x.h -- C ABI of libgptq_mi355x.so: the MI355X (gfx950) quantized-linear hot path.
+ *
+ * This is the drop-in boundary.  Every entry point takes plain device pointers, ints and an
+ * opaque stream handle (a hipStream_t passed as void*); no torch / pybind types.  Each one
+ * replaces a pybind11 function (or group of functions) of the reference's native extensions,
+ * cited as `file:line` into the AutoGPTQ tree (v0.8.0.dev0):
+ *
+ *   gptq_forward / gptq_gemv / gptq_gemm
+ *       <- autogptq_cuda_{64,256}: vecquant{2,3,4,8}matmul            autogptq_extension/cuda_256/autogptq_cuda_256.cpp:5-64,175-178
+ *                                  vecquant{2,3,4,8}matmul_old        :68-126,180-183
+ *                                  vecquant{2,3,4}matmul_faster_old   :128-171,184-186
+ *       <- exllama_kernels.q4_matmul                                  autogptq_extension/exllama/exllama_ext.cpp:176-217,258
+ *       <- exllamav2_kernels.gemm_half_q_half                         autogptq_extension/exllamav2/ext.cpp:95-126,133
+ *       <- autogptq_marlin_cuda.mul                                   autogptq_extension/marlin/marlin_cuda.cpp:30-75,78
+ *       and the pure-PyTorch fallback they all share                  auto_gptq/nn_modules/qlinear/qlinear_cuda_old.py:291-355, qlinear_cuda.py:253-317
+ *   gptq_dequant
+ *       <- the `reconstruct` step of exllama / exllamav2              exllama/cuda_func/q4_matrix.cu:171-225, exllamav2/cuda/q_matrix.cu:158-279,452-500
+ *   gptq_make_sequential + gptq_resequence_qweight + gptq_permute_columns
+ *       <- exllama_kernels.make_q4 (Q4Matrix::make_sequential)        exllama/exllama_ext.cpp:134-171, cuda_func/q4_matrix.cu:63-169
+ *          exllamav2_kernels.make_q_matrix                            exllamav2/ext.cpp:26-93, cuda/q_matrix.cu:502-627
+ *          column_remap_cuda                                          exllama/cuda_func/column_remap.cu:9-63
+ *       (unlike those, never mutates qweight in place: results go to caller-owned side buffers)
+ *   gptq_pack_weights / gptq_pack_zeros
+ *       <- QuantLinear.pack (CPU-only in the reference)               auto_gptq/nn_modules/qlinear/qlinear_cuda.py:108-203
+ *   gptq_unpack_weights / gptq_unpack_zeros
+ *       <- the integer unpack of the Python path                      qlinear_cuda_old.py:295-344, qlinear_cuda.py:257-295
+ *
+ * Tensor layout = the GPTQ v1 checkpoint ABI (K = in_features, N = out_features):
+ *   qweight uint32 [K/32*bits, N]   row-major; values packed along K, LSB first
+ *   qzeros  uint32 [G, N/32*bits]   G = ceil(K/group_size); packed along N; stores zero-1
+ *   scales  dtype  [G, N]
+ *   g_idx   int32  [K] or NULL      NULL = sequential groups (k / group_size)
+ *   bias    dtype  [N] or NULL
+ *   x       dtype  [M, K] row-major; out dtype [M, N] row-major
+ *
+ * Conventions
+ *   - every function returns GPTQ_OK (0) or a gptq_status_t > 0; gptq_last_error() returns a
+ *     thread-local human-readable message for the last failure on the calling thread.
+ *   - nothing allocates or frees device memory; scratch is caller-provided and sized by
+ *     gptq_workspace_bytes().  Kernels are enqueued on the caller's stream, never synchronise,
+ *     and are legal inside hipGraph capture.  No global mutable state.
+ *   - results are run-to-run deterministic (no floating-point atomics).
+ */
+#ifndef GPTQ_MI355X_H
+#define GPTQ_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPTQ_MI355X_ABI_VERSION 1
+
+typedef enum gptq_status_t {
+    GPTQ_OK = 0,
+    GPTQ_ERR_NULL = 1,         /* required pointer is NULL */
+    GPTQ_ERR_SHAPE = 2,        /* K/N/M/group_size violate the layout rules */
+    GPTQ_ERR_UNSUPPORTED = 3,  /* bits/dtype/mode combination not implemented by this entry point */
+    GPTQ_ERR_WORKSPACE = 4,    /* workspace missing or smaller than gptq_workspace_bytes() */
+    GPTQ_ERR_LAUNCH = 5        /* HIP reported a launch/runtime error */
+} gptq_status_t;
+
+typedef enum gptq_dtype_t { GPTQ_F16 = 0, GPTQ_BF16 = 1, GPTQ_F32 = 2 } gptq_dtype_t;
+
+/* Zero-point convention:
+ *   WRAP   z = (field + 1) & maxq   -- qlinear_cuda_old.py:301-304 and every native 4-bit kernel
+ *   NOWRAP z =  field + 1           -- qlinear_cuda.py:262-264; also cuda_old's 3-bit branch */
+typedef enum gptq_zero_mode_t { GPTQ_ZERO_WRAP = 0, GPTQ_ZERO_NOWRAP = 1 } gptq_zero_mode_t;
+
+/* One quantized linear layer.  POD; the caller owns every pointer and keeps it alive. */
+typedef struct gptq_layer_t {
+    const uint32_t *qweight;   /* [K/32*bits, N] */
+    const uint32_t *qzeros;    /* [G, N/32*bits] */
+    const void     *scales;    /* [G, N] dtype */
+    const int32_t  *g_idx;     /* [K] or NULL (sequential) */
+    const void     *bias;      /* [N] dtype or NULL */
+    int32_t K, N, bits, group_size;   /* group_size > 0 (the module resolves -1 to K) */
+    int32_t dtype;             /* gptq_dtype_t of x / scales / bias / out */
+    int32_t zero_mode;         /* gptq_zero_mode_t */
+    /* Optional derived (post_init) side buffers; all NULL = run straight from the checkpoint
+     * tensors.  Built by gptq_make_sequential + gptq_resequence_qweight for act-order layers:
+     * rows of qweight_seq are in group-sorted order and perm[i] is the original k of sorted
+     * position i, so group(i) = i / group_size. */
+    const uint32_t *qweight_seq;  /* [K/32*bits, N] or NULL */
+    const int32_t  *perm;         /* [K] or NULL */
+} gptq_layer_t;
+
+/* Optional launch-shape override for experiments; NULL / zero fields = built-in heuristic. */
+typedef struct gptq_tuning_t {
+    int32_t lanes_n;     /* lanes of a wave laid along N (4,8,16,32,64); 4 columns per lane */
+    int32_t waves;       /* waves per workgroup (1..16) */
+    int32_t ksplit;      /* workgroups along K (1 = no cross-workgroup reduction) */
+    int32_t path;        /* 0 auto, 1 force generic GEMV, 2 force fast GEMV, 3 force MFMA GEMM */
+    int32_t reserved[4];
+} gptq_tuning_t;
+
+int         gptq_abi_version(void);
+const char *gptq_last_error(void);
+const char *gptq_status_string(int status);
+
+/* Bytes of scratch gptq_forward/gptq_gemv/gptq_gemm may need for this layer and M (0 possible). */
+size_t gptq_workspace_bytes(const gptq_layer_t *layer, int M);
+
+/* out[M,N] = x[M,K] @ dequant(layer) (+ bias).  Picks GEMV (small M) or MFMA GEMM. */
+int gptq_forward(const gptq_layer_t *layer, const void *x, void *out, int M,
+                 void *workspace, size_t workspace_bytes, void *stream);
+
+/* Same, with an explicit launch shape / path (tuning may be NULL). */
+int gptq_forward_ex(const gptq_layer_t *layer, const void *x, void *out, int M,
+                    void *workspace, size_t workspace_bytes, void *stream,
+                    const gptq_tuning_t *tuning);
+
+/* Memory-bound decode path (wavefront reductions); any M, intended for M <= 8. */
+int gptq_gemv(const gptq_layer_t *layer, const void *x, void *out, int M,
+              void *workspace, size_t workspace_bytes, void *stream, const gptq_tuning_t *tuning);
+
+/* MFMA prefill path; fp16/bf16 only. */
+int gptq_gemm(const gptq_layer_t *layer, const void *x, void *out, int M,
+              void *workspace, size_t workspace_bytes, void *stream, const gptq_tuning_t *tuning);
+
+/* W_out[K,N] (dtype) = scales[g(k),n] * (w[k,n] - z[g(k),n]); bit-exact vs the reference's
+ * `weights` tensor (one rounding of the exact product). */
+int gptq_dequant(const gptq_layer_t *layer, void *W_out, void *stream);
+
+/* Integer unpack (bit-exact targets). w_out uint8 [K,N]; z_out int32 [G,N] (zero-point as used). */
+int gptq_unpack_weights(const uint32_t *qweight, int K, int N, int bits, uint8_t *w_out, void *stream);
+int gptq_unpack_zeros(const uint32_t *qzeros, int G, int N, int bits, int zero_mode, int32_t *z_out, void *stream);
+
+/* Device pack(): intweight[k,n] = round((W[n,k] + zero[g,n]*scale[g,n]) / scale_cast[g,n]) packed
+ * along K exactly like the reference (fields OR-ed unmasked).  W is [N,K] in w_dtype; scale_in /
+ * zero_in are [G,N] in qparam_dtype (already transposed); scales_out [G,N] in w_dtype receives the
+ * cast scales.  g_idx NULL = sequential. */
+int gptq_pack_weights(const void *W, const void *scale_in, const void *zero_in, const int32_t *g_idx,
+                      int K, int N, int bits, int group_size, int w_dtype, int qparam_dtype,
+                      uint32_t *qweight_out, void *scales_out, void *stream);
+int gptq_pack_zeros(const void *zero_in, int G, int N, int bits, int qparam_dtype,
+                    uint32_t *qzeros_out, void *stream);
+
+/* Act-order support.  HOST function: stable counting sort of k by g_idx (host pointers).
+ * perm_out[i] = original k at sorted position i.  *uniform_out = 1 iff sorted position i has
+ * group i / group_size for every i (then the fast kernels can use qweight_seq + perm). */
+int gptq_make_sequential(const int32_t *g_idx_host, int K, int group_size,
+                         int32_t *perm_out_host, int *uniform_out);
+/* qweight_seq[row-order = perm] from qweight; device pointers. */
+int gptq_resequence_qweight(const uint32_t *qweight, const int32_t *perm, int K, int N, int bits,
+                            uint32_t *qweight_seq_out, void *stream);
+/* x_out[m, i] = x[m, perm[i]] */
+int gptq_permute_columns(const void *x, const int32_t *perm, int M, int K, int dtype, void *x_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPTQ_MI355X_H */

@@ -1,0 +1,291 @@
+"""GPU (-m gpu): parity of the HIP path (through the C ABI) against the oracle, the reference's
+known-answer vectors and the reference-generated fixtures.
+
+Bars:  integer unpack / pack / dequant -> bit-exact.
+       matmul -> |y - y_ref| <= atol + rtol*|y_ref| with the tolerances written at each test; the HIP
+       kernels accumulate in fp32 (never fp16), so they are also required to be at least as close to
+       the exact-math (fp64) result as the reference's own fp16 CPU path is.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from autogptq_amd import _lib
+from autogptq_amd.qlinear_mi355x import QuantLinear
+from oracle import gptq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+# fp tolerance of the matmul, per I/O dtype: (rtol, atol_per_sqrt(K/1024) relative to output scale)
+TOL = {torch.float32: (1e-4, 1e-5), torch.float16: (2e-3, 2e-3), torch.bfloat16: (1.6e-2, 1.6e-2)}
+
+
+def _module_from(qweight, qzeros, scales, g_idx, bias, bits, group_size, zero_mode="auto"):
+    K = qweight.shape[0] * 32 // bits
+    N = qweight.shape[1]
+    q = QuantLinear(bits, group_size, K, N, bias is not None, weight_dtype=scales.dtype, zero_mode=zero_mode)
+    q.qweight, q.qzeros, q.scales = qweight.clone(), qzeros.clone(), scales.clone()
+    if g_idx is not None:
+        q.g_idx = g_idx.clone().to(torch.int32)
+    if bias is not None:
+        q.bias = bias.clone()
+    return q.to(DEV)
+
+
+def _tuning(**kw):
+    t = _lib.GptqTuning()
+    for k, v in kw.items():
+        setattr(t, k, v)
+    return t
+
+
+def _assert_close(y, ref, y64, dtype, K, what=""):
+    rtol, atol = TOL[dtype]
+    scale = max(1.0, float(y64.abs().max())) if y64 is not None else 1.0
+    a = atol * scale * max(1.0, (K / 1024) ** 0.5)
+    yf, rf = y.double().cpu(), ref.double().cpu()
+    bad = (yf - rf).abs() > a + rtol * rf.abs()
+    assert not bad.any(), f"{what}: {int(bad.sum())} / {bad.numel()} out of tolerance, max abs diff {float((yf - rf).abs().max())}"
+
+
+# ------------------------------------------------------------------------------------------- KATs
+@pytest.mark.parametrize("fname,path", [
+    ("kat_cuda_old_reference_1024.npz", 0), ("kat_cuda_old_reference_1024.npz", 1),
+    ("kat_reference_old_half_256.npz", 0), ("kat_reference_old_half_256.npz", 1),
+    ("kat_reference_old_no_half_256.npz", 0),
+])
+def test_known_answer_vectors(golden_dir, fname, path):
+    """The reference's own golden vectors (tests/test_q4.py:1060-1122, 1752-1802, 1899-1941) with the
+    reference's own tolerances."""
+    import os
+    z = np.load(os.path.join(golden_dir, fname))
+    k, n = int(z["k"]), int(z["n"])
+    dtype = {"float16": torch.float16, "float32": torch.float32}[str(z["dtype"])]
+    qweight, qzeros, scales, x = O.golden_recipe_inputs(k, n, dtype=dtype)
+    q = _module_from(qweight, qzeros, scales, None, None, 4, 128)
+    with torch.no_grad():
+        y = q(x.to(DEV), tuning=_tuning(path=path))[0][0].cpu()
+    ref = torch.from_numpy(z["y"]).to(dtype)
+    assert torch.allclose(y, ref, rtol=float(z["rtol"]), atol=max(float(z["atol"]), 1e-8)), (y - ref).abs().max()
+
+
+# ------------------------------------------------------------------------------ integer / dequant
+def test_unpack_bit_exact(ref_case):
+    c = ref_case
+    lib = _lib.load()
+    qw, qz = c.qweight.to(DEV), c.qzeros.to(DEV)
+    w = torch.empty((c.K, c.N), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.gptq_unpack_weights(qw.data_ptr(), c.K, c.N, c.bits, w.data_ptr(), None))
+    G = c.qzeros.shape[0]
+    for mode in (O.ZERO_WRAP, O.ZERO_NOWRAP):
+        zt = torch.empty((G, c.N), dtype=torch.int32, device=DEV)
+        _lib.check(lib.gptq_unpack_zeros(qz.data_ptr(), G, c.N, c.bits, int(mode == O.ZERO_NOWRAP), zt.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert np.array_equal(zt.cpu().numpy(), O.unpack_zeros(c.qzeros, c.bits, mode))
+    torch.cuda.synchronize()
+    assert np.array_equal(w.cpu().numpy().astype(np.uint16), O.unpack_weights(c.qweight, c.bits))
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4, 8])
+def test_unpack_bit_exact_random_words(bits):
+    L = O.random_quant_layer(512, 384, bits, 64, seed=10 + bits)
+    lib = _lib.load()
+    w = torch.empty((512, 384), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.gptq_unpack_weights(L["qweight"].to(DEV).data_ptr(), 512, 384, bits, w.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(w.cpu().numpy().astype(np.uint16), O.unpack_weights(L["qweight"], bits))
+
+
+def test_dequant_bit_exact_vs_reference(ref_case):
+    """gptq_dequant == the reference's `weights` tensor, bit for bit (fixtures produced by pushing an
+    identity through the reference forward)."""
+    c = ref_case
+    q = _module_from(c.qweight, c.qzeros, c.scales, c.g_idx, None, c.bits, c.group_size)
+    W = q.dequantize().cpu()
+    mode = O.reference_zero_mode(c.desc_act_class, c.bits)
+    assert q.resolved_zero_mode() == int(mode == O.ZERO_NOWRAP)
+    assert torch.equal(W, O.dequantize(c.qweight, c.qzeros, c.scales, c.g_idx, c.bits, mode))
+    if c.bias is None:
+        assert torch.equal(W, c.Wdq)
+
+
+@pytest.mark.parametrize("bits,dtype", [(4, torch.float16), (3, torch.float16), (8, torch.bfloat16), (2, torch.float32)])
+@pytest.mark.parametrize("act", [False, True])
+def test_dequant_bit_exact_random_words(bits, dtype, act):
+    L = O.random_quant_layer(512, 256, bits, 32, act_order=act, dtype=dtype, seed=3)
+    for zm, mode in (("wrap", O.ZERO_WRAP), ("nowrap", O.ZERO_NOWRAP)):
+        q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], None, bits, 32, zero_mode=zm)
+        assert torch.equal(q.dequantize().cpu(), O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], bits, mode))
+
+
+# ------------------------------------------------------------------------------------ forward
+@pytest.mark.parametrize("path", [0, 1])
+def test_forward_matches_reference_fixture(ref_case, path):
+    c = ref_case
+    q = _module_from(c.qweight, c.qzeros, c.scales, c.g_idx, c.bias, c.bits, c.group_size)
+    with torch.no_grad():
+        y = q(c.x.to(DEV), tuning=_tuning(path=path))
+    assert y.dtype == c.dtype and tuple(y.shape) == tuple(c.y.shape)
+    mode = O.reference_zero_mode(c.desc_act_class, c.bits)
+    y64 = O.forward_f64(c.x, c.qweight, c.qzeros, c.scales, c.g_idx, c.bias, c.bits, mode)
+    _assert_close(y, c.y, y64, c.dtype, c.K, f"{c.name} vs reference y")
+    # accumulating in fp32, the kernel must sit at least as close to exact math as the reference does
+    err_k = (y.double().cpu() - y64).abs().max()
+    err_r = (c.y.double() - y64).abs().max()
+    assert err_k <= err_r * 3 + 2e-6 * max(1.0, float(y64.abs().max())), (float(err_k), float(err_r))
+
+
+CASES = [
+    # bits, gs, K, N, act, dtype, M
+    (4, 128, 1024, 1024, False, torch.float16, 1),      # BASELINE config 1 (parity gate shape)
+    (4, 128, 1024, 1024, False, torch.float16, 3),
+    (4, 128, 2048, 512, False, torch.float16, 8),
+    (4, 128, 1024, 1024, True, torch.float16, 1),       # act-order, re-sequenced fast path
+    (4, 128, 1024, 1024, True, torch.float16, 5),
+    (4, 32, 512, 768, False, torch.float16, 2),
+    (4, 64, 512, 96, False, torch.bfloat16, 2),
+    (4, 128, 512, 256, False, torch.float32, 2),
+    (3, 32, 1024, 512, False, torch.float16, 1),        # BASELINE config 5 flavours
+    (8, 32, 1024, 512, False, torch.float16, 1),
+    (3, 32, 512, 256, True, torch.float16, 2),
+    (8, 32, 512, 256, True, torch.float16, 2),
+    (2, 64, 512, 256, False, torch.float16, 2),
+    (2, 64, 512, 256, True, torch.bfloat16, 3),
+    (4, 1024, 1024, 256, False, torch.float16, 1),      # group_size = -1 (one group)
+    (4, 16, 256, 128, False, torch.float16, 2),         # group smaller than a 3-bit unit, fine for 4-bit
+    (3, 16, 256, 128, False, torch.float16, 2),         # 3-bit unit (32 k) spans two groups -> per-k path
+]
+
+
+@pytest.mark.parametrize("bits,gs,K,N,act,dtype,M", CASES)
+def test_forward_random_words_vs_oracle(bits, gs, K, N, act, dtype, M):
+    L = O.random_quant_layer(K, N, bits, gs, act_order=act, dtype=dtype, seed=K + N + bits, bias=True)
+    gen = torch.Generator().manual_seed(7)
+    x = (torch.rand(M, K, generator=gen) - 0.5).to(dtype)
+    for zm, mode in (("wrap", O.ZERO_WRAP), ("nowrap", O.ZERO_NOWRAP)):
+        q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], bits, gs, zero_mode=zm)
+        yref = O.forward(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], bits, mode)
+        y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], bits, mode)
+        for path in (0, 1):
+            with torch.no_grad():
+                y = q(x.to(DEV), tuning=_tuning(path=path))
+            _assert_close(y, yref, y64, dtype, K, f"path={path} zero={zm}")
+            _assert_close(y, y64, y64, dtype, K, f"path={path} zero={zm} vs f64")
+
+
+@pytest.mark.parametrize("ln,waves,ksplit", [(4, 16, 1), (4, 4, 1), (8, 8, 2), (16, 16, 4), (64, 4, 8), (64, 1, 1), (4, 2, 3)])
+@pytest.mark.parametrize("path", [1, 2])
+def test_forward_launch_shapes_agree(ln, waves, ksplit, path):
+    """Every launch shape (strip width, waves, K split) of both GEMV kernels gives the same answer
+    (up to fp32 summation order) and is run-to-run bit-reproducible."""
+    K, N, M = 2048, 1024, 2
+    L = O.random_quant_layer(K, N, 4, 128, seed=5, bias=True)
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(1)) - 0.5).half()
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, 128)
+    y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP)
+    t = _tuning(lanes_n=ln, waves=waves, ksplit=ksplit, path=path)
+    with torch.no_grad():
+        y1 = q(x.to(DEV), tuning=t)
+        y2 = q(x.to(DEV), tuning=t)
+    assert torch.equal(y1, y2)
+    _assert_close(y1, y64, y64, torch.float16, K, f"ln={ln} waves={waves} ksplit={ksplit}")
+
+
+def test_act_order_resequencing_is_bit_exact():
+    """qweight_seq (derived at post_init) holds exactly the rows of qweight in group-sorted order and
+    leaves the checkpoint tensor untouched (the reference's exllama path overwrites it in place)."""
+    K, N, bits, gs = 1024, 256, 4, 128
+    L = O.random_quant_layer(K, N, bits, gs, act_order=True, seed=9)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], None, bits, gs)
+    q.post_init()
+    assert q.act_order and q._layer.qweight_seq
+    qweight_seq, perm = q._keepalive[5], q._keepalive[6]
+    assert np.array_equal(perm.cpu().numpy(), O.sequential_permutation(L["g_idx"]))
+    w = O.unpack_weights(L["qweight"], bits)
+    w_seq = O.unpack_weights(qweight_seq.cpu(), bits)
+    assert np.array_equal(w_seq, w[perm.cpu().numpy()])
+    assert torch.equal(q.qweight.cpu(), L["qweight"])
+    for b in (2, 3, 8):
+        Lb = O.random_quant_layer(512, 128, b, 32, act_order=True, seed=b)
+        qb = _module_from(Lb["qweight"], Lb["qzeros"], Lb["scales"], Lb["g_idx"], None, b, 32)
+        qb.post_init()
+        p = qb._keepalive[6].cpu().numpy()
+        assert np.array_equal(O.unpack_weights(qb._keepalive[5].cpu(), b), O.unpack_weights(Lb["qweight"], b)[p])
+
+
+def test_device_pack_bit_exact(ref_case):
+    """QuantLinear.pack on the GPU (gptq_pack_weights / gptq_pack_zeros) == reference pack()."""
+    c = ref_case
+    lin = torch.nn.Linear(c.K, c.N, bias=c.lin_bias is not None)
+    lin.weight.data = c.W.to(c.dtype)
+    if c.lin_bias is not None:
+        lin.bias.data = c.lin_bias.clone()
+    q = QuantLinear(c.bits, c.group_size, c.K, c.N, c.lin_bias is not None, weight_dtype=c.dtype)
+    q.pack(lin, c.scale.to(c.qparams_dtype), c.zero.to(c.qparams_dtype), c.g_idx.clone())
+    assert torch.equal(q.qweight.cpu(), c.qweight)
+    assert torch.equal(q.qzeros.cpu(), c.qzeros)
+    assert torch.equal(q.scales.cpu(), c.scales)
+    # pack -> forward round trip reproduces the reference output
+    q = q.to(DEV)
+    with torch.no_grad():
+        y = q(c.x.to(DEV))
+    mode = O.reference_zero_mode(c.desc_act_class, c.bits)
+    y64 = O.forward_f64(c.x, c.qweight, c.qzeros, c.scales, c.g_idx, c.bias, c.bits, mode)
+    _assert_close(y, c.y, y64, c.dtype, c.K, "pack->forward")
+
+
+def test_permute_columns_and_errors():
+    lib = _lib.load()
+    x = torch.randn(5, 256, device=DEV).half()
+    perm = torch.randperm(256, device=DEV).to(torch.int32)
+    out = torch.empty_like(x)
+    _lib.check(lib.gptq_permute_columns(x.data_ptr(), perm.data_ptr(), 5, 256, 0, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(out, x[:, perm.long()])
+    q = QuantLinear(4, 128, 256, 64, False).to(DEV)
+    with pytest.raises(RuntimeError, match="features"):
+        q(torch.zeros(1, 128, dtype=torch.float16, device=DEV))
+    assert q(torch.zeros(0, 256, dtype=torch.float16, device=DEV)).shape == (0, 64)   # empty batch
+    y = q(torch.zeros(2, 3, 256, dtype=torch.float32, device=DEV))                      # dtype cast + 3-D
+    assert y.shape == (2, 3, 64) and y.dtype == torch.float32
+
+
+# ---------------------------------------------------- BASELINE full sizes: size-independent properties
+FULL = [(4096, 4096), (4096, 11008), (11008, 4096)]
+
+
+@pytest.mark.parametrize("K,N", FULL)
+def test_full_size_decode_properties(K, N):
+    """Llama-7B shapes (BASELINE config 2), M=1: (a) agreement with the oracle on a random column
+    subset computed in fp64, (b) linearity  f(a*x1 + x2) = a*f(x1) + f(x2)  within fp16 rounding,
+    (c) column-slice consistency: the layer restricted to columns [n0,n1) gives the same outputs
+    (the out_features sharding used for TP), (d) bit reproducibility."""
+    L = O.random_quant_layer(K, N, 4, 128, seed=K // 7 + N)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], None, None, 4, 128)
+    gen = torch.Generator().manual_seed(3)
+    x1 = (torch.rand(1, K, generator=gen) - 0.5).half()
+    x2 = (torch.rand(1, K, generator=gen) - 0.5).half()
+    with torch.no_grad():
+        y1, y1b = q(x1.to(DEV)), q(x1.to(DEV))
+        y2 = q(x2.to(DEV))
+        y3 = q((0.5 * x1 + x2).to(DEV))
+    assert torch.equal(y1, y1b)
+    # (a) oracle on 256 columns (slice the packed tensors: 32-aligned columns)
+    n0 = (N // 2) // 32 * 32
+    sl = slice(n0, n0 + 256)
+    y64 = O.forward_f64(x1, L["qweight"][:, sl], L["qzeros"][:, n0 // 8:(n0 + 256) // 8], L["scales"][:, sl], None, None, 4, O.ZERO_WRAP)
+    _assert_close(y1[:, sl], y64, y64, torch.float16, K, "full-size vs f64 slice")
+    # (b) linearity (x combination is rounded to fp16 -> compare loosely, relative to output scale)
+    lin = 0.5 * y1.float() + y2.float()
+    scale = float(lin.abs().max())
+    assert float((y3.float() - lin).abs().max()) <= 6e-3 * scale
+    # (c) column slice as its own layer
+    qs = _module_from(L["qweight"][:, sl].contiguous(), L["qzeros"][:, n0 // 8:(n0 + 256) // 8].contiguous(),
+                      L["scales"][:, sl].contiguous(), None, None, 4, 128)
+    with torch.no_grad():
+        ys = qs(x1.to(DEV))
+    _assert_close(ys, y1[:, sl], y64, torch.float16, K, "column-sliced layer")

@@ -1,0 +1,145 @@
+"""CPU (-m "not gpu"): the C-ABI library loads and exports every declared symbol, argument
+validation returns the documented status codes before any launch, and the host-side logic
+(backend class surface, host pack, act-order permutation) matches the reference fixtures."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import autogptq_amd as A
+from autogptq_amd import _lib
+from autogptq_amd.qlinear_mi355x import QuantLinear
+from oracle import gptq_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_header_symbols():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "gptq_mi355x.h")).read()
+    declared = set(re.findall(r"\b(gptq_[a-z_0-9]+)\s*\(", header))
+    declared -= {"gptq_status_t", "gptq_dtype_t", "gptq_zero_mode_t", "gptq_layer_t", "gptq_tuning_t"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.gptq_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layout_matches_header():
+    # 5 pointers, 6 int32, 2 pointers  (include/gptq_mi355x.h: gptq_layer_t)
+    assert ctypes.sizeof(_lib.GptqLayer) == 5 * 8 + 6 * 4 + 2 * 8
+    assert _lib.GptqLayer.qweight_seq.offset == 64
+    assert ctypes.sizeof(_lib.GptqTuning) == 8 * 4
+
+
+def _layer(**kw):
+    L = _lib.GptqLayer()
+    L.qweight = L.qzeros = L.scales = 0x1000  # never dereferenced: validation fails first
+    L.K, L.N, L.bits, L.group_size, L.dtype, L.zero_mode = 256, 256, 4, 128, 0, 0
+    for k, v in kw.items():
+        setattr(L, k, v)
+    return L
+
+
+@pytest.mark.parametrize("kw,code,frag", [
+    (dict(bits=5), 3, "Only 2,3,4,8 bits are supported"),
+    (dict(K=100), 2, "multiples of 32"),
+    (dict(N=48), 2, "multiples of 32"),
+    (dict(group_size=0), 2, "group_size"),
+    (dict(dtype=7), 3, "dtype"),
+    (dict(qweight=None), 1, "non-NULL"),
+    (dict(perm=0x1000), 1, "together"),
+])
+def test_validation_status_codes(kw, code, frag):
+    lib = _lib.load()
+    L = _layer(**kw)
+    rc = lib.gptq_forward(ctypes.byref(L), 0x1000, 0x1000, 1, None, 0, None)
+    assert rc == code
+    assert frag in lib.gptq_last_error().decode()
+    with pytest.raises(_lib.GptqError) as ei:
+        _lib.check(rc)
+    assert ei.value.status == code and isinstance(ei.value, RuntimeError)
+
+
+def test_validation_io_and_workspace_query():
+    lib = _lib.load()
+    L = _layer()
+    assert lib.gptq_forward(ctypes.byref(L), None, 0x1000, 1, None, 0, None) == 1
+    assert lib.gptq_forward(ctypes.byref(L), 0x1000, 0x1000, 0, None, 0, None) == 2
+    assert lib.gptq_forward(None, 0x1000, 0x1000, 1, None, 0, None) == 1
+    # tiny N forces a K split -> needs workspace -> refused without one (no launch happens)
+    Ls = _layer(N=32, K=4096)
+    need = lib.gptq_workspace_bytes(ctypes.byref(Ls), 1)
+    assert need > 0
+    assert lib.gptq_gemv(ctypes.byref(Ls), 0x1000, 0x1000, 1, None, 0, None, None) == 4
+    assert "workspace too small" in lib.gptq_last_error().decode()
+    assert lib.gptq_workspace_bytes(ctypes.byref(_layer(bits=5)), 1) == 0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_make_sequential_matches_oracle(seed):
+    lib = _lib.load()
+    rng = np.random.default_rng(seed)
+    K, gs = 512, 64
+    g = (np.arange(K) // gs).astype(np.int32)[rng.permutation(K)]
+    gt = torch.from_numpy(g.copy())
+    perm = torch.empty(K, dtype=torch.int32)
+    uni = ctypes.c_int(-1)
+    assert lib.gptq_make_sequential(gt.data_ptr(), K, gs, perm.data_ptr(), ctypes.byref(uni)) == 0
+    assert np.array_equal(perm.numpy(), O.sequential_permutation(g))
+    assert uni.value == 1
+    # uneven groups -> not uniform
+    g2 = g.copy(); g2[:3] = 0
+    assert lib.gptq_make_sequential(torch.from_numpy(g2).data_ptr(), K, gs, perm.data_ptr(), ctypes.byref(uni)) == 0
+    assert np.array_equal(perm.numpy(), O.sequential_permutation(g2))
+    assert uni.value == int(np.array_equal(g2[perm.numpy()], np.arange(K) // gs))
+    bad = g.copy(); bad[5] = -1
+    assert lib.gptq_make_sequential(torch.from_numpy(bad).data_ptr(), K, gs, perm.data_ptr(), None) == 2
+
+
+def test_class_surface_matches_reference_contract():
+    q = QuantLinear(4, 128, 256, 64, True, use_cuda_fp16=True, trainable=False, weight_dtype=torch.float16,
+                    some_unknown_kwarg=1)
+    assert q.QUANT_TYPE == "mi355x"
+    sd = q.state_dict()
+    assert list(sd.keys()) == ["qweight", "qzeros", "scales", "g_idx", "bias"]   # checkpoint ABI
+    assert sd["qweight"].shape == (32, 64) and sd["qweight"].dtype == torch.int32
+    assert sd["qzeros"].shape == (2, 8) and sd["qzeros"].dtype == torch.int32
+    assert sd["scales"].shape == (2, 64) and sd["scales"].dtype == torch.float16
+    assert sd["g_idx"].tolist() == [i // 128 for i in range(256)]
+    for attr in ("infeatures", "outfeatures", "bits", "group_size", "maxq", "trainable"):
+        assert hasattr(q, attr)
+    assert QuantLinear(4, -1, 64, 32, False).group_size == 64
+    with pytest.raises(NotImplementedError, match="Only 2,3,4,8 bits"):
+        QuantLinear(5, 128, 256, 64, False)
+    with pytest.raises(NotImplementedError):
+        QuantLinear(4, 128, 256, 64, False, trainable=True)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        q(torch.zeros(1, 256, dtype=torch.float16))
+    assert A.dynamically_import_QuantLinear(False, True, 128, 4) is QuantLinear
+    with pytest.raises(ValueError):
+        A.dynamically_import_QuantLinear(use_triton=True, desc_act=False, group_size=128, bits=4)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="host pack path is taken only without a GPU")
+def test_host_pack_bit_exact(ref_case):
+    c = ref_case
+    lin = torch.nn.Linear(c.K, c.N, bias=c.lin_bias is not None)
+    lin.weight.data = c.W.to(c.dtype)
+    if c.lin_bias is not None:
+        lin.bias.data = c.lin_bias.clone()
+    q = QuantLinear(c.bits, c.group_size, c.K, c.N, c.lin_bias is not None, weight_dtype=c.dtype)
+    q.pack(lin, c.scale.to(c.qparams_dtype), c.zero.to(c.qparams_dtype), c.g_idx.clone())
+    assert torch.equal(q.qweight, c.qweight)
+    assert torch.equal(q.qzeros, c.qzeros)
+    assert torch.equal(q.scales, c.scales)
+    assert q.scales.dtype == c.dtype
+    if c.bias is not None:
+        assert torch.equal(q.bias, c.bias)
+    # checkpoint round trip through state_dict
+    q2 = QuantLinear(c.bits, c.group_size, c.K, c.N, c.lin_bias is not None, weight_dtype=c.dtype)
+    q2.load_state_dict(q.state_dict())
+    assert torch.equal(q2.qweight, c.qweight) and torch.equal(q2.g_idx, c.g_idx)
