@@ -19,6 +19,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WAVE = 64;
 
+// Bit casts take their operand BY VALUE on purpose: hipcc (ROCm 7.2 / clang 22) miscompiles
+// __builtin_bit_cast(T, vec[i]) on an ext_vector element -- every i reads element 0.
+__device__ __forceinline__ f16x2 as_f16x2(unsigned v) { return __builtin_bit_cast(f16x2, v); }
+__device__ __forceinline__ float as_f32(unsigned v) { return __builtin_bit_cast(float, v); }
+__device__ __forceinline__ unsigned as_u32(float v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ f16 as_f16(unsigned short v) { return __builtin_bit_cast(f16, v); }
+__device__ __forceinline__ unsigned short as_u16(f16 v) { return __builtin_bit_cast(unsigned short, v); }
+
 // ---- dtype traits ---------------------------------------------------------------------------
 template <typename T> struct DType;
 template <> struct DType<f16> {

@@ -37,6 +37,7 @@ struct GemvParams {
     float* partial;     // [ksplit][M][N] when ksplit > 1
     int M, K, N, group_size, zero_mode;
     int units_total, units_per_split, chunk_units, ksplit;
+    int gu_shift;       // log2(group_size / 8) or -1 (fast path)
 };
 
 // ---- shared epilogue: reduce row slots (shuffles), waves (LDS), then write ------------------
@@ -187,12 +188,17 @@ __global__ void __launch_bounds__(1024) gemv_generic_kernel(GemvParams p) {
 }
 
 // ---- fast kernel: 4-bit, fp16, sequential groups (or re-sequenced act-order via perm) -------
-// x in LDS as fp16 with each 8-group stored in order (0,4,1,5,2,6,3,7).
+// LDS per K-chunk (all accesses typed u32x4/u32x2 -- no type punning through memory):
+//   xs [MT][chunk_units]      u32x4 : 8 fp16 of x per packed row, stored as pairs (0,4)(1,5)(2,6)(3,7)
+//   sz [chunk_groups][CT]     u32x2 : { half2(-(1024+z), -(1024+z)) bits , scale as fp32 bits }
+// Per lane: all weight loads of the chunk are issued first (U deep, nontemporal), then the
+// workgroup stages x / scale / zero constants, one barrier, then the lanes consume their units.
 template <int LN, int MT, int U>
 __global__ void __launch_bounds__(1024) gemv_q4_f16_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f16* xs = (f16*)smem;
     constexpr int WR = 64 / LN, CT = LN * 4;
+    u32x4* xs = (u32x4*)smem;
+    u32x2* sz = (u32x2*)(smem + (size_t)MT * p.chunk_units * 16);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
     const int cl = lane % LN, rs = lane / LN;
     const int strip = xcd_remap(blockIdx.x, gridDim.x);
@@ -202,12 +208,12 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_kernel(GemvParams p) {
     const int m0 = blockIdx.z * MT;
     const int ub = blockIdx.y * p.units_per_split;
     const int ue = min(ub + p.units_per_split, p.units_total);
-    const int xstride = p.chunk_units * 8;  // halfs per m row in LDS
     const f16* __restrict__ x = (const f16*)p.x;
     const f16* __restrict__ scales = (const f16*)p.scales;
     const int zrow_words = p.N >> 3;
     const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
-    const unsigned zshift = (unsigned)(n0 & 7) * 4u;
+    const int gunits = p.group_size >> 3;   // packed rows per group
+    const int gshift = p.gu_shift;
 
     float acc[MT][4];
 #pragma unroll
@@ -218,82 +224,92 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_kernel(GemvParams p) {
     for (int cb = ub; cb < ue; cb += p.chunk_units) {
         const int ce = min(cb + p.chunk_units, ue);
         const int nu = ce - cb;
-        // -- 1. issue the first U weight loads of this thread before anything else ------------
-        u32x4 q[U];
-        int uu[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            uu[j] = cb + (j * W + wave) * WR + rs;
-            const int ul = min(uu[j], ce - 1);
-            q[j] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)ul * p.N + nload));
-        }
-        // -- 2. stage x chunk (permuted pairs) ------------------------------------------------
-        if (cb != ub) __syncthreads();
-        for (int i = tid; i < MT * nu; i += blockDim.x) {
-            const int m = i / nu, ul = i - m * nu;
-            const int k0 = (cb + ul) * 8;
-            f16 v[8];
-            if (m0 + m < p.M) {
-                const f16* xr = x + (size_t)(m0 + m) * p.K;
-                if (p.perm) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = xr[p.perm[k0 + j]];
-                } else {
-                    const f16x8 t = *(const f16x8*)(xr + k0);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = t[j];
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (f16)0.f;
-            }
-            f16x8 o = {v[0], v[4], v[1], v[5], v[2], v[6], v[3], v[7]};
-            *(f16x8*)(xs + m * xstride + ul * 8) = o;
-        }
-        __syncthreads();
-        // -- 3. consume --------------------------------------------------------------------------
-        for (int it0 = 0;; it0 += U) {
-            if (cb + (it0 * W + wave) * WR >= ce) break;
+        const int g_first = gshift >= 0 ? (cb >> gshift) : (cb / gunits);
+        const int g_last = gshift >= 0 ? ((ce - 1) >> gshift) : ((ce - 1) / gunits);
+        const int ng = g_last - g_first + 1;
+        const int row_step = W * WR;
+        for (int base = cb; base < ce; base += U * row_step) {
+            // -- 1. weights first: U independent 16-B loads per lane, all in flight ---------------
+            u32x4 q[U];
 #pragma unroll
             for (int j = 0; j < U; ++j) {
-                const int u = uu[j];
-                const u32x4 qv = q[j];
-                // prefetch the load U iterations ahead into the same slot
-                {
-                    const int un = cb + ((it0 + j + U) * W + wave) * WR + rs;
-                    uu[j] = un;
-                    if (cb + ((it0 + j + U) * W + wave) * WR < ce) {
-                        const int ul = min(un, ce - 1);
-                        q[j] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)ul * p.N + nload));
+                const int u = base + j * row_step + wave * WR + rs;
+                const int ul = min(u, ce - 1);
+                q[j] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)ul * p.N + nload));
+            }
+            // -- 2. first pass of the chunk: stage x and the (scale, zero) constants ---------------
+            if (base == cb) {
+                if (cb != ub) __syncthreads();
+                for (int i = tid; i < MT * nu; i += blockDim.x) {
+                    const int m = i / nu, ul = i - m * nu;
+                    const int k0 = (cb + ul) * 8;
+                    u32x4 o = {0u, 0u, 0u, 0u};
+                    if (m0 + m < p.M) {
+                        const f16* xr = x + (size_t)(m0 + m) * p.K;
+                        unsigned short h[8];
+                        if (p.perm) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) h[j] = as_u16(xr[p.perm[k0 + j]]);
+                        } else {
+                            const u32x4 t = *(const u32x4*)(xr + k0);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { h[2 * j] = (unsigned short)(t[j] & 0xffffu); h[2 * j + 1] = (unsigned short)(t[j] >> 16); }
+                        }
+                        o[0] = (unsigned)h[0] | ((unsigned)h[4] << 16);
+                        o[1] = (unsigned)h[1] | ((unsigned)h[5] << 16);
+                        o[2] = (unsigned)h[2] | ((unsigned)h[6] << 16);
+                        o[3] = (unsigned)h[3] | ((unsigned)h[7] << 16);
+                    }
+                    xs[m * p.chunk_units + ul] = o;
+                }
+                for (int i = tid; i < ng * LN; i += blockDim.x) {
+                    const int gl = i / LN, c4 = i - gl * LN;
+                    const int g = g_first + gl;
+                    const int nn = strip * CT + c4 * 4;
+                    if (nn < p.N) {
+                        const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * p.N + nn);
+                        const unsigned zw = p.qzeros[(size_t)g * zrow_words + (nn >> 3)] >> ((nn & 7) * 4);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const unsigned z = (((zw >> (4 * c)) & 15u) + 1u) & zmask;
+                            const unsigned sh = (c & 1) ? (sraw[c >> 1] >> 16) : (sraw[c >> 1] & 0xffffu);
+                            const float sf = (float)as_f16((unsigned short)sh);
+                            u32x2 e = {z * 0x00010001u + 0xE400E400u, as_u32(sf)};
+                            sz[(gl * CT) + c4 * 4 + c] = e;
+                        }
                     }
                 }
+                __syncthreads();
+            }
+            // -- 3. consume -----------------------------------------------------------------------
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int u = base + j * row_step + wave * WR + rs;
                 if (u >= ce || !col_ok) continue;
-                const int g = (u * 8) / p.group_size;
-                const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * p.N + n0);
-                const unsigned zw = p.qzeros[(size_t)g * zrow_words + (n0 >> 3)] >> zshift;
-                const f16x2 s01 = __builtin_bit_cast(f16x2, sraw[0]);
-                const f16x2 s23 = __builtin_bit_cast(f16x2, sraw[1]);
-                const float sc[4] = {(float)s01[0], (float)s01[1], (float)s23[0], (float)s23[1]};
+                const u32x4 qv = q[j];
+                const int gl = (gshift >= 0 ? (u >> gshift) : (u / gunits)) - g_first;
+                const u32x4 e01 = *(const u32x4*)(sz + gl * CT + cl * 4);
+                const u32x4 e23 = *(const u32x4*)(sz + gl * CT + cl * 4 + 2);
+                const unsigned c1b[4] = {e01[0], e01[2], e23[0], e23[2]};
+                const float sc[4] = {as_f32(e01[1]), as_f32(e01[3]), as_f32(e23[1]), as_f32(e23[3])};
                 f16x2 xa[MT][4];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const u32x4 xv = *(const u32x4*)(xs + m * xstride + (u - cb) * 8);
+                    const u32x4 xv = xs[m * p.chunk_units + (u - cb)];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) xa[m][i] = __builtin_bit_cast(f16x2, xv[i]);
+                    for (int i = 0; i < 4; ++i) xa[m][i] = as_f16x2(xv[i]);
                 }
+                const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+                const f16x2 k960 = {(f16)960.f, (f16)960.f};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const unsigned z = (((zw >> (4 * c)) & 15u) + 1u) & zmask;
-                    const f16x2 c1 = __builtin_bit_cast(f16x2, z * 0x00010001u + 0xE400E400u);  // -(1024+z)
-                    const f16x2 c2 = __builtin_bit_cast(f16x2, z * 0x00100010u + 0xD400D400u);  // -(64+z)
-                    const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+                    const f16x2 c1 = as_f16x2(c1b[c]);   // -(1024+z)
+                    const f16x2 c2 = c1 + k960;                            // -(64+z), exact
                     const unsigned qw = qv[c], q8 = qw >> 8;
-                    const f16x2 h0 = __builtin_bit_cast(f16x2, (qw & 0x000f000fu) | 0x64006400u) + c1;  // k0,k4
-                    const f16x2 h1 = __builtin_elementwise_fma(
-                        __builtin_bit_cast(f16x2, (qw & 0x00f000f0u) | 0x64006400u), r16, c2);           // k1,k5
-                    const f16x2 h2 = __builtin_bit_cast(f16x2, (q8 & 0x000f000fu) | 0x64006400u) + c1;  // k2,k6
-                    const f16x2 h3 = __builtin_elementwise_fma(
-                        __builtin_bit_cast(f16x2, (q8 & 0x00f000f0u) | 0x64006400u), r16, c2);           // k3,k7
+                    const f16x2 h0 = as_f16x2((qw & 0x000f000fu) | 0x64006400u) + c1;                 // k0,k4
+                    const f16x2 h1 = as_f16x2((qw & 0x00f000f0u) | 0x64006400u) * r16 + c2;           // k1,k5
+                    const f16x2 h2 = as_f16x2((q8 & 0x000f000fu) | 0x64006400u) + c1;                 // k2,k6
+                    const f16x2 h3 = as_f16x2((q8 & 0x00f000f0u) | 0x64006400u) * r16 + c2;           // k3,k7
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         float d = __builtin_amdgcn_fdot2(h0, xa[m][0], 0.f, false);
@@ -366,14 +382,18 @@ GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
         if (waves < 1) waves = 1;
     }
     pl.waves = waves;
-    // x chunk: keep LDS <= 64 KiB
-    const int bytes_per_unit = pl.mt * kpu * (pl.fast ? 2 : 4);
-    int cu = (64 * 1024) / bytes_per_unit;
-    if (cu > pl.units_per_split) cu = pl.units_per_split;
-    cu = (cu / (wr * waves)) * (wr * waves);
-    if (cu < wr * waves) cu = wr * waves < pl.units_per_split ? wr * waves : pl.units_per_split;
+    // LDS per K-chunk, kept <= 64 KiB: x tile (+ for the fast path the per-group constants)
+    const int rows_per_iter = wr * waves;
+    const int gunits = (pl.fast && L.group_size >= kpu) ? L.group_size / kpu : 1;
+    auto lds_for = [&](int cu) -> size_t {
+        if (pl.fast) return (size_t)pl.mt * cu * 16 + (size_t)(cu / gunits + 2) * ln * 4 * 8;
+        return (size_t)pl.mt * cu * kpu * 4;
+    };
+    int cu = pl.units_per_split;
+    while (cu > rows_per_iter && lds_for(cu) > 64 * 1024) cu = ((cu / 2 + rows_per_iter - 1) / rows_per_iter) * rows_per_iter;
+    if (pl.fast && cu < pl.units_per_split && cu > gunits) cu = (cu / gunits) * gunits;   // chunk on group boundaries
     pl.chunk_units = cu;
-    const size_t xbytes = (size_t)cu * bytes_per_unit;
+    const size_t xbytes = lds_for(cu);
     const size_t rbytes = (size_t)waves * pl.mt * ln * 4 * sizeof(float);
     pl.lds_bytes = xbytes > rbytes ? xbytes : rbytes;
     pl.workspace_bytes = ks > 1 ? (size_t)ks * M * L.N * sizeof(float) : 0;
@@ -430,8 +450,10 @@ static hipError_t launch_fast_u(const GemvPlan& pl, const GemvParams& p, hipStre
         hipLaunchKernelGGL((gemv_q4_f16_kernel<LN, MT, 1>), grid, block, pl.lds_bytes, st, p);
     else if (per_lane <= 2)
         hipLaunchKernelGGL((gemv_q4_f16_kernel<LN, MT, 2>), grid, block, pl.lds_bytes, st, p);
-    else
+    else if (per_lane <= 4)
         hipLaunchKernelGGL((gemv_q4_f16_kernel<LN, MT, 4>), grid, block, pl.lds_bytes, st, p);
+    else
+        hipLaunchKernelGGL((gemv_q4_f16_kernel<LN, MT, 8>), grid, block, pl.lds_bytes, st, p);
     return hipGetLastError();
 }
 
@@ -461,6 +483,10 @@ hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x,
     p.M = M; p.K = L.K; p.N = L.N; p.group_size = L.group_size; p.zero_mode = L.zero_mode;
     p.units_total = pl.units_total; p.units_per_split = pl.units_per_split;
     p.chunk_units = pl.chunk_units; p.ksplit = pl.ksplit;
+    {
+        const int gu = L.group_size / 8;
+        p.gu_shift = (pl.fast && gu > 0 && (gu & (gu - 1)) == 0) ? __builtin_ctz(gu) : -1;
+    }
 
     hipError_t e;
     if (pl.fast) {

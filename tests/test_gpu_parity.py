@@ -36,6 +36,12 @@ def _module_from(qweight, qzeros, scales, g_idx, bias, bits, group_size, zero_mo
     return q.to(DEV)
 
 
+def _zm(c):
+    """zero_mode for a reference fixture: 'auto' resolves to the cuda_old convention for sequential
+    g_idx; fixtures produced by the act-order class (qlinear_cuda.py) need its convention spelled out."""
+    return "nowrap" if c.desc_act_class else "auto"
+
+
 def _tuning(**kw):
     t = _lib.GptqTuning()
     for k, v in kw.items():
@@ -104,7 +110,7 @@ def test_dequant_bit_exact_vs_reference(ref_case):
     """gptq_dequant == the reference's `weights` tensor, bit for bit (fixtures produced by pushing an
     identity through the reference forward)."""
     c = ref_case
-    q = _module_from(c.qweight, c.qzeros, c.scales, c.g_idx, None, c.bits, c.group_size)
+    q = _module_from(c.qweight, c.qzeros, c.scales, c.g_idx, None, c.bits, c.group_size, zero_mode=_zm(c))
     W = q.dequantize().cpu()
     mode = O.reference_zero_mode(c.desc_act_class, c.bits)
     assert q.resolved_zero_mode() == int(mode == O.ZERO_NOWRAP)
@@ -126,7 +132,7 @@ def test_dequant_bit_exact_random_words(bits, dtype, act):
 @pytest.mark.parametrize("path", [0, 1])
 def test_forward_matches_reference_fixture(ref_case, path):
     c = ref_case
-    q = _module_from(c.qweight, c.qzeros, c.scales, c.g_idx, c.bias, c.bits, c.group_size)
+    q = _module_from(c.qweight, c.qzeros, c.scales, c.g_idx, c.bias, c.bits, c.group_size, zero_mode=_zm(c))
     with torch.no_grad():
         y = q(c.x.to(DEV), tuning=_tuning(path=path))
     assert y.dtype == c.dtype and tuple(y.shape) == tuple(c.y.shape)
@@ -224,7 +230,7 @@ def test_device_pack_bit_exact(ref_case):
     lin.weight.data = c.W.to(c.dtype)
     if c.lin_bias is not None:
         lin.bias.data = c.lin_bias.clone()
-    q = QuantLinear(c.bits, c.group_size, c.K, c.N, c.lin_bias is not None, weight_dtype=c.dtype)
+    q = QuantLinear(c.bits, c.group_size, c.K, c.N, c.lin_bias is not None, weight_dtype=c.dtype, zero_mode=_zm(c))
     q.pack(lin, c.scale.to(c.qparams_dtype), c.zero.to(c.qparams_dtype), c.g_idx.clone())
     assert torch.equal(q.qweight.cpu(), c.qweight)
     assert torch.equal(q.qzeros.cpu(), c.qzeros)

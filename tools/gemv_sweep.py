@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--bits", type=int, default=4)
     ap.add_argument("--gs", type=int, default=128)
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--heuristic-only", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for shp in args.shapes.split(","):
@@ -52,6 +53,8 @@ def main():
                 for ks in ((1, 2, 4, 8) if ln >= 16 else (1, 2)):
                     cfgs.append(dict(lanes_n=ln, waves=waves, ksplit=ks, path=2 if args.bits == 4 else 1))
         cfgs.append(dict(path=1))
+        if args.heuristic_only:
+            cfgs = [dict(), dict(path=1)]
         res = []
         for c in cfgs:
             t = _lib.GptqTuning()
