@@ -23,7 +23,7 @@ DTYPE_ENUM = {torch.float16: GPTQ_F16, torch.bfloat16: GPTQ_BF16, torch.float32:
 
 # every symbol include/gptq_mi355x.h declares (tests check the .so exports all of them)
 EXPORTS = (
-    "gptq_abi_version", "gptq_last_error", "gptq_status_string", "gptq_workspace_bytes",
+    "gptq_abi_version", "gptq_last_error", "gptq_status_string", "gptq_workspace_bytes", "gptq_workspace_bytes_ex",
     "gptq_forward", "gptq_forward_ex", "gptq_gemv", "gptq_gemm", "gptq_dequant",
     "gptq_unpack_weights", "gptq_unpack_zeros", "gptq_pack_weights", "gptq_pack_zeros",
     "gptq_make_sequential", "gptq_resequence_qweight", "gptq_permute_columns",
@@ -74,6 +74,8 @@ def load() -> ctypes.CDLL:
     lib.gptq_status_string.argtypes = [c_int]
     lib.gptq_workspace_bytes.restype = c_size_t
     lib.gptq_workspace_bytes.argtypes = [POINTER(GptqLayer), c_int]
+    lib.gptq_workspace_bytes_ex.restype = c_size_t
+    lib.gptq_workspace_bytes_ex.argtypes = [POINTER(GptqLayer), c_int, POINTER(GptqTuning)]
     fw = [POINTER(GptqLayer), c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]
     lib.gptq_forward.argtypes = fw
     for name in ("gptq_forward_ex", "gptq_gemv", "gptq_gemm"):
@@ -88,7 +90,7 @@ def load() -> ctypes.CDLL:
     lib.gptq_resequence_qweight.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.gptq_permute_columns.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
-        if name not in ("gptq_last_error", "gptq_status_string", "gptq_workspace_bytes"):
+        if name not in ("gptq_last_error", "gptq_status_string", "gptq_workspace_bytes", "gptq_workspace_bytes_ex"):
             getattr(lib, name).restype = c_int
     got = lib.gptq_abi_version()
     if got != ABI_VERSION:

@@ -57,7 +57,7 @@ int check_io(const void* x, const void* out, int M) {
 
 bool want_gemm(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
     if (t && t->path == 3) return true;
-    if (t && (t->path == 1 || t->path == 2)) return false;
+    if (t && (t->path == 1 || t->path == 2 || t->path == 4 || t->path == 5)) return false;
     if (M <= 8) return false;
     return plan_gemm(*L, M, t).supported;
 }
@@ -81,13 +81,15 @@ const char* gptq_status_string(int s) {
     }
 }
 
-size_t gptq_workspace_bytes(const gptq_layer_t* L, int M) {
+size_t gptq_workspace_bytes_ex(const gptq_layer_t* L, int M, const gptq_tuning_t* tune) {
     if (check_layer(L) != GPTQ_OK || M <= 0) return 0;
-    size_t a = plan_gemv(*L, M, nullptr).workspace_bytes;
-    GemmPlan g = plan_gemm(*L, M, nullptr);
+    size_t a = plan_gemv(*L, M, tune).workspace_bytes;
+    GemmPlan g = plan_gemm(*L, M, tune);
     size_t b = g.supported ? g.workspace_bytes : 0;
     return std::max(a, b);
 }
+
+size_t gptq_workspace_bytes(const gptq_layer_t* L, int M) { return gptq_workspace_bytes_ex(L, M, nullptr); }
 
 int gptq_gemv(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream,
               const gptq_tuning_t* tune) {
@@ -99,6 +101,10 @@ int gptq_gemv(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, 
         return fail(GPTQ_ERR_UNSUPPORTED, "tuning.lanes_n must be 4, 8, 16 or 64");
     if (tune && (tune->waves < 0 || tune->waves > 16)) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.waves must be 1..16");
     GemvPlan pl = plan_gemv(*L, M, tune);
+    if (tune && tune->path == 5 && !pl.mfma)
+        return fail(GPTQ_ERR_UNSUPPORTED, "matrix-core GEMV needs bits=4, fp16, no act-order and a power-of-two group_size >= 8");
+    if (tune && tune->path == 4 && !pl.direct)
+        return fail(GPTQ_ERR_UNSUPPORTED, "direct GEMV needs bits=4, fp16, no act-order and a power-of-two group_size >= 8");
     if (tune && tune->path == 2 && !pl.fast)
         return fail(GPTQ_ERR_UNSUPPORTED, "fast GEMV needs bits=4, fp16 and sequential (or re-sequenced) groups");
     if (pl.workspace_bytes > 0 && (!ws || ws_bytes < pl.workspace_bytes))

@@ -1,7 +1,469 @@
-// gemm.hip -- MFMA prefill path (placeholder until the kernel lands)
+// gemm.hip -- MFMA prefill path: out[M,N] = x[M,K] @ dequant(qweight) for M > 8 (fp16 / bf16).
+//
+// Replaces (reference, AutoGPTQ v0.8.0.dev0): Marlin<...> in autogptq_extension/marlin/marlin_cuda_kernel.cu:216-727,
+// the dequant + cublasHgemm fallbacks of exllama (exllama/cuda_func/q4_matmul.cu:225-260) and exllamav2
+// (exllamav2/cuda/q_gemm.cu:104-181), and the torch.matmul branch of the Python classes
+// (qlinear_cuda.py:253-317).  Nothing is derived from that code.  The design starts from one property of the
+// GPTQ checkpoint layout on CDNA4:
+//
+//   v_mfma_f32_32x32x16_{f16,bf16} wants, in lane l, the 8 consecutive k values  k0 + 8*(l>>5) .. +7  of column
+//   n = l & 31 of B -- and one 4-bit qweight word IS 8 consecutive k of one column.  So the packed weights
+//   never go through LDS: each lane loads the words of its own columns straight from the unmodified
+//   [K/8, N] tensor (row-contiguous => coalesced), dequantises them in registers and feeds them to the
+//   matrix core as the B fragment.  A lane owns 2 adjacent columns (one 8-byte load per packed row), a
+//   wave a 64-column strip, a workgroup 4 waves side by side = 256 columns x BM rows; every dequantised
+//   word is reused by the MT = BM/32 row tiles of the wave.
+//
+//   * x (the A operand) is staged through LDS in BK-wide K-steps, double buffered, one barrier per K-step,
+//     global loads for step t+1 issued before the MFMAs of step t.  Rows are padded by 16 B, which makes
+//     the 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots (conflict free).
+//   * 4-bit fp16 dequant is the exact magic-number form: (q & 0x000f000f) | 0x64006400 is the half2
+//     (1024+w_k, 1024+w_{k+4}); adding -(1024+z) is exact and ONE multiply by the scale rounds exactly like the
+//     reference's  scales * (weight - zeros)  (qlinear_cuda_old.py:348).  The words therefore come out in
+//     slot order k0,k4,k1,k5,k2,k6,k3,k7 -- x is written to LDS in the same slot order (4 v_perm per 16 B), which
+//     is all the MFMA needs (A and B only have to agree on which k sits in which slot).
+//     Every other (bits, dtype) uses fp32 math per field: T(float(s) * float(w - z)) -- also exactly the reference's W.
+//   * group_size % BK == 0, so one (scale, zero) pair per column per K-step, fetched one step ahead.
+//   * act-order: weights come from the group-sorted side copy (qweight_seq) and x is permuted once per call
+//     into the workspace by a small LDS-staged gather kernel (the column_remap of exllama, column_remap.cu:9-63).
+//   * fp32 accumulation in the MFMA; optional split-K (only when M*N is too small to fill 256 CUs) writes
+//     fp32 partial slabs that a second pass sums in fixed order: bit-reproducible, no atomics.
 #include "common.cuh"
 #include "launch.h"
+
 namespace gptq {
-GemmPlan plan_gemm(const gptq_layer_t&, int, const gptq_tuning_t*) { return GemmPlan{false, false, 0, 0, 0}; }
-hipError_t launch_gemm(const gptq_layer_t&, const GemmPlan&, const void*, void*, int, void*, hipStream_t) { return hipErrorNotSupported; }
+
+struct GemmParams {
+    const unsigned* qweight;
+    const unsigned* qzeros;
+    const void* scales;
+    const void* bias;
+    const void* x;
+    void* out;
+    float* partial;   // [ksplit][M][N] fp32 when ksplit > 1
+    int M, K, N, group_size, zero_mode;
+    int nbm, nbn, ksplit, ksteps_total, ksteps_per_split;
+    int qrows;        // rows of qweight (K/32*bits)
+};
+
+__device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ unsigned f16x2_bits(f16x2 v) { return __builtin_bit_cast(unsigned, v); }
+// (a & mask) | orv in one VALU op (hipcc emits v_and + v_or for the C expression: VOP3 takes no literals on gfx9)
+__device__ __forceinline__ unsigned and_or(unsigned a, unsigned mask, unsigned orv) {
+    unsigned r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(orv));
+    return r;
 }
+
+template <typename T> struct Mma;
+template <> struct Mma<f16> {
+    static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(a), as_f16x8(b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16> {
+    static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ unsigned short t_bits(f16 v) { return __builtin_bit_cast(unsigned short, v); }
+__device__ __forceinline__ unsigned short t_bits(bf16 v) { return __builtin_bit_cast(unsigned short, v); }
+
+// ---- per-lane weight words of one 16-deep MFMA k-step -----------------------------------------
+// The lane's 8 k values start at bit B0 = (k0 + 8*half) * BITS of its column's bit stream (words down the
+// column, N apart).  NW = words it has to fetch (per column) to cover 8*BITS bits from B0.
+template <int BITS> struct BWords { static constexpr int n = (BITS == 3 || BITS == 8) ? 2 : 1; };
+
+template <int BITS>
+struct BRaw {                       // raw words of the lane's 2 columns for one k16 step
+    u32x2 w[BWords<BITS>::n];
+};
+
+template <int BITS>
+__device__ __forceinline__ void load_braw(BRaw<BITS>& r, const unsigned* __restrict__ qcol, int N, int qrows, int k) {
+    const unsigned bit = (unsigned)k * BITS;
+    const int wi = (int)(bit >> 5);
+#pragma unroll
+    for (int i = 0; i < BWords<BITS>::n; ++i) {
+        const int row = min(wi + i, qrows - 1);     // the clamp only ever triggers for a word that is not used
+        r.w[i] = *(const u32x2*)(qcol + (size_t)row * N);
+    }
+}
+
+// 64-bit window of column c holding the lane's 8 fields starting at bit 0
+template <int BITS>
+__device__ __forceinline__ unsigned long long window(const BRaw<BITS>& r, int c, int k) {
+    const unsigned sh = ((unsigned)k * BITS) & 31u;
+    unsigned long long v = r.w[0][c];
+    if constexpr (BWords<BITS>::n == 2) v |= (unsigned long long)r.w[1][c] << 32;
+    return v >> sh;
+}
+
+// ---- per-column group constants ----------------------------------------------------------------
+struct CRaw { unsigned s; unsigned long long z; };   // 2 scales (T,T) ; qzeros window aligned to the lane's first column
+
+template <int BITS>
+__device__ __forceinline__ void load_craw(CRaw& c, const void* __restrict__ scales, const unsigned* __restrict__ qzeros,
+                                          int g, int N, int n) {
+    c.s = *(const unsigned*)((const unsigned short*)scales + (size_t)g * N + n);
+    const int zrow_words = N / 32 * BITS;
+    const unsigned bit = (unsigned)n * BITS;
+    const int wi = (int)(bit >> 5);
+    const unsigned sh = bit & 31u;
+    const unsigned* zr = qzeros + (size_t)g * zrow_words;
+    unsigned long long v = zr[wi];
+    if constexpr (BITS == 3) v |= (unsigned long long)zr[min(wi + 1, zrow_words - 1)] << 32;
+    c.z = v >> sh;
+}
+
+template <int BITS>
+__device__ __forceinline__ int zero_point(const CRaw& c, int col, int zero_mode) {
+    constexpr unsigned maxq = (1u << BITS) - 1u;
+    const int f = (int)((unsigned)(c.z >> (BITS * col)) & maxq) + 1;
+    return zero_mode == GPTQ_ZERO_WRAP ? (f & (int)maxq) : f;
+}
+
+// ---- dequant of one word -> B fragment (4 regs, slot order k0,k4,k1,k5,k2,k6,k3,k7) -------------
+template <int BITS, typename T> struct Deq {
+    float s[2];
+    int z[2];
+    __device__ __forceinline__ void setup(const CRaw& c, int zero_mode) {
+#pragma unroll
+        for (int col = 0; col < 2; ++col) {
+            const unsigned short sb = (unsigned short)(col ? (c.s >> 16) : (c.s & 0xffffu));
+            s[col] = DType<T>::to_f32(__builtin_bit_cast(T, sb));
+            z[col] = zero_point<BITS>(c, col, zero_mode);
+        }
+    }
+    __device__ __forceinline__ u32x4 frag(const BRaw<BITS>& r, int col, int k) const {
+        constexpr unsigned maxq = (1u << BITS) - 1u;
+        const unsigned long long v = window<BITS>(r, col, k);
+        unsigned short e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int f = (int)((unsigned)(v >> (BITS * j)) & maxq);
+            e[j] = t_bits(DType<T>::from_f32(s[col] * (float)(f - z[col])));   // exact product, one rounding
+        }
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (unsigned)e[i] | ((unsigned)e[i + 4] << 16);
+        return o;
+    }
+};
+
+template <> struct Deq<4, f16> {
+    f16x2 s2[2], c1[2], c2[2];
+    __device__ __forceinline__ void setup(const CRaw& c, int zero_mode) {
+#pragma unroll
+        for (int col = 0; col < 2; ++col) {
+            const unsigned sb = col ? (c.s >> 16) : (c.s & 0xffffu);
+            s2[col] = as_f16x2(sb * 0x00010001u);
+            const unsigned z = (unsigned)zero_point<4>(c, col, zero_mode);   // 0..16
+            c1[col] = as_f16x2(z * 0x00010001u + 0xE400E400u);               // -(1024 + z): 0xE400 = -1024, ulp 1
+            const f16x2 k960 = {(f16)960.f, (f16)960.f};
+            c2[col] = c1[col] + k960;                                        // -(64 + z), exact
+        }
+    }
+    __device__ __forceinline__ u32x4 frag(const BRaw<4>& r, int col, int) const {
+        const unsigned q = r.w[0][col], q8 = q >> 8;
+        const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+        const f16x2 h0 = as_f16x2(and_or(q, 0x000f000fu, 0x64006400u)) + c1[col];          // k0,k4 : w - z
+        const f16x2 h1 = as_f16x2(and_or(q, 0x00f000f0u, 0x64006400u)) * r16 + c2[col];    // k1,k5
+        const f16x2 h2 = as_f16x2(and_or(q8, 0x000f000fu, 0x64006400u)) + c1[col];         // k2,k6
+        const f16x2 h3 = as_f16x2(and_or(q8, 0x00f000f0u, 0x64006400u)) * r16 + c2[col];   // k3,k7
+        u32x4 o;
+        o[0] = f16x2_bits(h0 * s2[col]);
+        o[1] = f16x2_bits(h1 * s2[col]);
+        o[2] = f16x2_bits(h2 * s2[col]);
+        o[3] = f16x2_bits(h3 * s2[col]);
+        return o;
+    }
+};
+
+// ---- the kernel -------------------------------------------------------------------------------
+// Workgroup = 4 waves side by side along N: tile BM = 32*MT rows x 256 columns, K-step BK.
+template <int BITS, typename T, int MT, int BK>
+__global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
+    constexpr int KS = BK / 16;                // MFMA k-steps per K-step
+    constexpr int BM = 32 * MT;
+    constexpr int STRIDE = BK * 2 + 16;        // bytes per LDS row of x (padded)
+    constexpr int CPR = BK / 8;                // 16-byte chunks per row
+    constexpr int CHUNKS = BM * CPR;
+    constexpr int NCH = (CHUNKS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x BM x STRIDE
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int L = xcd_remap(blockIdx.x, p.nbm * p.nbn);
+    const int bn = L / p.nbm, bm = L - bn * p.nbm;     // neighbours on an XCD share the weight columns
+    const int m0 = bm * BM;
+    const int n = bn * 256 + wave * 64 + 2 * l31;      // this lane's first column (second is n + 1)
+    const bool col_ok = n < p.N;
+    const int nl = col_ok ? n : 0;
+    const unsigned* __restrict__ qcol = p.qweight + nl;
+    const unsigned short* __restrict__ x = (const unsigned short*)p.x;
+
+    const int kt0 = blockIdx.y * p.ksteps_per_split;
+    const int kt1 = min(kt0 + p.ksteps_per_split, p.ksteps_total);
+
+    // A staging assignment: chunk c -> (row, 16-byte column)
+    // Rows past M are clamped to row M-1 (never predicated: a predicated load splits the K-loop into several
+    // basic blocks and the prefetch stops overlapping the MFMAs); their accumulators are simply not stored.
+    int a_row[NCH], a_kc[NCH];
+    const unsigned short* a_src[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + i * 256;
+        a_row[i] = c / CPR;
+        a_kc[i] = c - a_row[i] * CPR;
+        a_src[i] = x + (size_t)min(m0 + a_row[i], p.M - 1) * p.K + a_kc[i] * 8;
+    }
+    auto load_a = [&](int kt, u32x4 (&r)[NCH]) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) r[i] = *(const u32x4*)(a_src[i] + (size_t)kt * BK);
+    };
+    auto store_a = [&](int buf, const u32x4 (&r)[NCH]) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if (CHUNKS % 256 != 0 && tid + i * 256 >= CHUNKS) continue;
+            // (x0,x1)(x2,x3)(x4,x5)(x6,x7) -> (x0,x4)(x1,x5)(x2,x6)(x3,x7): the slot order of the B fragments
+            u32x4 o;
+            o[0] = __builtin_amdgcn_perm(r[i][2], r[i][0], 0x05040100u);
+            o[1] = __builtin_amdgcn_perm(r[i][2], r[i][0], 0x07060302u);
+            o[2] = __builtin_amdgcn_perm(r[i][3], r[i][1], 0x05040100u);
+            o[3] = __builtin_amdgcn_perm(r[i][3], r[i][1], 0x07060302u);
+            *(u32x4*)(smem + (size_t)buf * (BM * STRIDE) + a_row[i] * STRIDE + a_kc[i] * 16) = o;
+        }
+    };
+    auto load_b = [&](int kt, BRaw<BITS> (&b)[KS]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) load_braw<BITS>(b[ks], qcol, p.N, p.qrows, kt * BK + ks * 16 + half * 8);
+    };
+    auto load_c = [&](int kt, CRaw& c) { load_craw<BITS>(c, p.scales, p.qzeros, (kt * BK) / p.group_size, p.N, nl); };
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    u32x4 a_next[NCH];
+    BRaw<BITS> b_cur[KS], b_next[KS];
+    CRaw c_cur, c_next;
+    load_a(kt0, a_next);
+    load_b(kt0, b_cur);
+    load_c(kt0, c_cur);
+    store_a(0, a_next);
+    __syncthreads();
+
+    const int a_lane_off = l31 * STRIDE + half * 16;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        const int ktn = min(kt + 1, kt1 - 1);          // last step re-loads itself (no branch in the pipeline)
+        load_a(ktn, a_next);
+        load_b(ktn, b_next);
+        load_c(ktn, c_next);
+        __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of this step's MFMAs
+
+        Deq<BITS, T> dq;
+        dq.setup(c_cur, p.zero_mode);
+        const char* abase = smem + (size_t)buf * (BM * STRIDE) + a_lane_off;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 a[MT], b[2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + ks * 32);
+            const int k = kt * BK + ks * 16 + half * 8;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) b[nt] = dq.frag(b_cur[ks], nt, k);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = Mma<T>::run(a[mt], b[nt], acc[mt][nt]);
+        }
+        store_a(buf ^ 1, a_next);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b_cur[ks] = b_next[ks];
+        c_cur = c_next;
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (!col_ok) return;
+    float bias0 = 0.f, bias1 = 0.f;
+    if (p.bias && p.ksplit == 1) {
+        bias0 = DType<T>::to_f32(((const T*)p.bias)[n]);
+        bias1 = DType<T>::to_f32(((const T*)p.bias)[n + 1]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m >= p.M) continue;
+            const float v0 = acc[mt][0][r], v1 = acc[mt][1][r];
+            if (p.ksplit > 1) {
+                float2 o = {v0, v1};
+                *(float2*)(p.partial + ((size_t)blockIdx.y * p.M + m) * p.N + n) = o;
+            } else {
+                const unsigned o = (unsigned)t_bits(DType<T>::from_f32(v0 + bias0)) |
+                                   ((unsigned)t_bits(DType<T>::from_f32(v1 + bias1)) << 16);
+                *(unsigned*)((unsigned short*)p.out + (size_t)m * p.N + n) = o;
+            }
+        }
+}
+
+// out = sum_s partial[s] (+bias), fixed order; 4 columns per thread
+template <typename T>
+__global__ void __launch_bounds__(256) gemm_reduce_kernel(const float* __restrict__ partial, const T* __restrict__ bias,
+                                                          T* __restrict__ out, int S, int M, int N) {
+    const size_t total4 = (size_t)M * N / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < S; ++k) s += *(const f32x4*)(partial + (size_t)k * M * N + i * 4);
+        const int nn = (int)((i * 4) % (size_t)N);
+        unsigned short o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = s[c];
+            if (bias) v += DType<T>::to_f32(bias[nn + c]);
+            o[c] = t_bits(DType<T>::from_f32(v));
+        }
+        u32x2 w = {(unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16)};
+        *(u32x2*)((unsigned short*)out + i * 4) = w;
+    }
+}
+
+// x_out[m, i] = x[m, perm[i]] for 2-byte elements: one row per workgroup pass, the row staged in LDS
+// (coalesced 16-byte loads and stores; the gather itself runs on the LDS).
+__global__ void __launch_bounds__(256) permute_rows_kernel(const unsigned short* __restrict__ x, const int* __restrict__ perm,
+                                                           int M, int K, unsigned short* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned short* row = (unsigned short*)smem;
+    for (int m = blockIdx.x; m < M; m += gridDim.x) {
+        for (int i = threadIdx.x * 8; i < K; i += 256 * 8) *(u32x4*)(row + i) = *(const u32x4*)(x + (size_t)m * K + i);
+        __syncthreads();
+        for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+            const u32x4 p0 = *(const u32x4*)(perm + i), p1 = *(const u32x4*)(perm + i + 4);
+            u32x4 o;
+            o[0] = (unsigned)row[p0[0]] | ((unsigned)row[p0[1]] << 16);
+            o[1] = (unsigned)row[p0[2]] | ((unsigned)row[p0[3]] << 16);
+            o[2] = (unsigned)row[p1[0]] | ((unsigned)row[p1[1]] << 16);
+            o[3] = (unsigned)row[p1[2]] | ((unsigned)row[p1[3]] << 16);
+            *(u32x4*)(out + (size_t)m * K + i) = o;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int K, void* x_out, hipStream_t st) {
+    const int blocks = M < 2048 ? M : 2048;
+    hipLaunchKernelGGL(permute_rows_kernel, dim3(blocks), dim3(256), (size_t)K * 2, st, (const unsigned short*)x, perm, M, K,
+                       (unsigned short*)x_out);
+    return hipGetLastError();
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
+    GemmPlan pl{};
+    const int kpu = unit_vals(L.bits);
+    const bool seq = (L.g_idx == nullptr) || (L.qweight_seq != nullptr && L.perm != nullptr);
+    pl.supported = (L.dtype == GPTQ_F16 || L.dtype == GPTQ_BF16) && seq && (L.group_size % 32 == 0) && (L.K % 32 == 0) &&
+                   (L.N % 32 == 0) && (L.group_size % kpu == 0) && ((size_t)L.K * 2 <= 64 * 1024 || L.g_idx == nullptr);
+    if (!pl.supported) return pl;
+    pl.use_seq = (L.g_idx != nullptr);
+    pl.mt = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
+    pl.bk = (L.bits == 4 && pl.mt == 4 && L.K % 64 == 0 && L.group_size % 64 == 0) ? 64 : 32;
+    pl.bm = 32 * pl.mt;
+    pl.bn = 256;
+    pl.nbm = (M + pl.bm - 1) / pl.bm;
+    pl.nbn = (L.N + 255) / 256;
+    pl.ksteps_total = L.K / pl.bk;
+    int ks = (tune && tune->ksplit > 0 && tune->path == 3) ? tune->ksplit : 0;
+    if (!ks) {
+        ks = 1;
+        const long blocks = (long)pl.nbm * pl.nbn;
+        while (blocks * ks < 192 && ks < 8 && pl.ksteps_total / (ks * 2) >= 4) ks *= 2;
+    }
+    if (ks > pl.ksteps_total) ks = pl.ksteps_total;
+    pl.ksteps_per_split = (pl.ksteps_total + ks - 1) / ks;
+    pl.ksplit = (pl.ksteps_total + pl.ksteps_per_split - 1) / pl.ksteps_per_split;   // no empty slices
+    pl.xperm_bytes = pl.use_seq ? align_up((size_t)M * L.K * 2, 256) : 0;
+    pl.workspace_bytes = pl.xperm_bytes + (pl.ksplit > 1 ? (size_t)pl.ksplit * M * L.N * sizeof(float) : 0);
+    return pl;
+}
+
+template <int BITS, typename T, int MT, int BK>
+static hipError_t launch_one(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
+    const size_t lds = (size_t)2 * (32 * MT) * (BK * 2 + 16);
+    hipLaunchKernelGGL((gemm_kernel<BITS, T, MT, BK>), dim3(pl.nbm * pl.nbn, pl.ksplit), dim3(256), lds, st, p);
+    return hipGetLastError();
+}
+
+template <int BITS, typename T>
+static hipError_t launch_bits(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
+    if constexpr (BITS == 4) {
+        if (pl.bk == 64) return launch_one<BITS, T, 4, 64>(pl, p, st);
+    }
+    switch (pl.mt) {
+        case 1: return launch_one<BITS, T, 1, 32>(pl, p, st);
+        case 2: return launch_one<BITS, T, 2, 32>(pl, p, st);
+        case 4: return launch_one<BITS, T, 4, 32>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <typename T>
+static hipError_t launch_t(const gptq_layer_t& L, const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
+    switch (L.bits) {
+        case 2: return launch_bits<2, T>(pl, p, st);
+        case 3: return launch_bits<3, T>(pl, p, st);
+        case 4: return launch_bits<4, T>(pl, p, st);
+        case 8: return launch_bits<8, T>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x, void* out, int M,
+                       void* workspace, hipStream_t st) {
+    if (!pl.supported) return hipErrorNotSupported;
+    GemmParams p{};
+    p.qweight = pl.use_seq ? L.qweight_seq : L.qweight;
+    p.qzeros = L.qzeros;
+    p.scales = L.scales;
+    p.bias = L.bias;
+    p.x = x;
+    p.out = out;
+    p.M = M; p.K = L.K; p.N = L.N; p.group_size = L.group_size; p.zero_mode = L.zero_mode;
+    p.nbm = pl.nbm; p.nbn = pl.nbn; p.ksplit = pl.ksplit;
+    p.ksteps_total = pl.ksteps_total; p.ksteps_per_split = pl.ksteps_per_split;
+    p.qrows = L.K / 32 * L.bits;
+    hipError_t e;
+    if (pl.use_seq) {
+        e = launch_permute_rows16(x, L.perm, M, L.K, workspace, st);
+        if (e != hipSuccess) return e;
+        p.x = workspace;
+    }
+    p.partial = (float*)((char*)workspace + pl.xperm_bytes);
+    e = (L.dtype == GPTQ_F16) ? launch_t<f16>(L, pl, p, st) : launch_t<bf16>(L, pl, p, st);
+    if (e != hipSuccess) return e;
+    if (pl.ksplit > 1) {
+        const size_t total4 = (size_t)M * L.N / 4;
+        int blocks = (int)((total4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        if (L.dtype == GPTQ_F16)
+            hipLaunchKernelGGL(gemm_reduce_kernel<f16>, dim3(blocks), dim3(256), 0, st, p.partial, (const f16*)L.bias, (f16*)out, pl.ksplit, M, L.N);
+        else
+            hipLaunchKernelGGL(gemm_reduce_kernel<bf16>, dim3(blocks), dim3(256), 0, st, p.partial, (const bf16*)L.bias, (bf16*)out, pl.ksplit, M, L.N);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+}  // namespace gptq

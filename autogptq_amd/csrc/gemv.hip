@@ -325,6 +325,263 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_kernel(GemvParams p) {
     reduce_and_store<f16, LN, MT>(acc, (float*)smem, p, strip, m0);
 }
 
+// ---- direct kernel: 4-bit, fp16, sequential groups, NO LDS staging ----------------------------
+// Same decomposition as gemv_q4_f16_kernel, but nothing is staged before the math: each lane loads,
+// next to its U packed rows (16 B each, nontemporal), the 8 fp16 of x those rows multiply (16 B, L1/L2
+// resident) and ONE (scales, zeros) pair for its 4 columns -- the lane's U rows are consecutive and lie
+// in one group.  All loads are issued back to back, then the lane computes out of registers; the only
+// workgroup-level step is the final cross-wave sum (one barrier in the whole kernel).
+template <int LN, int MT, int U>
+__global__ void __launch_bounds__(1024) gemv_q4_f16_direct_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = (float*)smem;
+    constexpr int WR = 64 / LN, CT = LN * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
+    const int cl = lane % LN, rs = lane / LN;
+    const int strip = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = strip * CT + cl * 4;
+    const bool col_ok = n0 < p.N;
+    const int nload = col_ok ? n0 : 0;
+    const int m0 = blockIdx.z * MT;
+    const int ub = blockIdx.y * p.units_per_split;
+    const int ue = min(ub + p.units_per_split, p.units_total);
+    const f16* __restrict__ x = (const f16*)p.x;
+    const f16* __restrict__ scales = (const f16*)p.scales;
+    const int zrow_words = p.N >> 3;
+    const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
+    const int gshift = p.gu_shift;          // log2(packed rows per group); the launcher guarantees it exists
+
+    float acc[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[m][c] = 0.f;
+
+    const int rows_per_iter = W * WR * U;
+    for (int base = ub; base < ue; base += rows_per_iter) {
+        const int u0 = base + (wave * WR + rs) * U;        // this lane's first row of the iteration
+        // -- 1. every load of the iteration, back to back ---------------------------------------
+        u32x4 q[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int ul = min(u0 + j, ue - 1);
+            q[j] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)ul * p.N + nload));
+        }
+        u32x4 xr[MT][U];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const f16* xrow = x + (size_t)min(m0 + m, p.M - 1) * p.K;
+#pragma unroll
+            for (int j = 0; j < U; ++j) xr[m][j] = *(const u32x4*)(xrow + (size_t)min(u0 + j, ue - 1) * 8);
+        }
+        const int g = min(u0, ue - 1) >> gshift;
+        const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * p.N + nload);
+        const unsigned zw = p.qzeros[(size_t)g * zrow_words + (nload >> 3)] >> ((nload & 7) * 4);
+        // -- 2. per-column constants -------------------------------------------------------------
+        f16x2 c1[4], c2[4];
+        float sc[4];
+        const f16x2 k960 = {(f16)960.f, (f16)960.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned z = (((zw >> (4 * c)) & 15u) + 1u) & zmask;
+            c1[c] = as_f16x2(z * 0x00010001u + 0xE400E400u);    // -(1024+z)
+            c2[c] = c1[c] + k960;                               // -(64+z)
+            const unsigned sh = (c & 1) ? (sraw[c >> 1] >> 16) : (sraw[c >> 1] & 0xffffu);
+            sc[c] = (float)as_f16((unsigned short)sh);
+        }
+        // -- 3. math out of registers ------------------------------------------------------------
+        const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            if (u0 + j >= ue) continue;                         // tail rows (clamped loads) contribute nothing
+            const u32x4 qv = q[j];
+            f16x2 xa[MT][4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const u32x4 t = xr[m][j];                       // (x0,x1)(x2,x3)(x4,x5)(x6,x7) -> (0,4)(1,5)(2,6)(3,7)
+                xa[m][0] = as_f16x2(__builtin_amdgcn_perm(t[2], t[0], 0x05040100u));
+                xa[m][1] = as_f16x2(__builtin_amdgcn_perm(t[2], t[0], 0x07060302u));
+                xa[m][2] = as_f16x2(__builtin_amdgcn_perm(t[3], t[1], 0x05040100u));
+                xa[m][3] = as_f16x2(__builtin_amdgcn_perm(t[3], t[1], 0x07060302u));
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned qw = qv[c], q8 = qw >> 8;
+                const f16x2 h0 = as_f16x2((qw & 0x000f000fu) | 0x64006400u) + c1[c];
+                const f16x2 h1 = as_f16x2((qw & 0x00f000f0u) | 0x64006400u) * r16 + c2[c];
+                const f16x2 h2 = as_f16x2((q8 & 0x000f000fu) | 0x64006400u) + c1[c];
+                const f16x2 h3 = as_f16x2((q8 & 0x00f000f0u) | 0x64006400u) * r16 + c2[c];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float d = __builtin_amdgcn_fdot2(h0, xa[m][0], 0.f, false);
+                    d = __builtin_amdgcn_fdot2(h1, xa[m][1], d, false);
+                    d = __builtin_amdgcn_fdot2(h2, xa[m][2], d, false);
+                    d = __builtin_amdgcn_fdot2(h3, xa[m][3], d, false);
+                    acc[m][c] = fmaf(sc[c], d, acc[m][c]);
+                }
+            }
+        }
+    }
+    // ---- reduce: row slots by shuffles, waves through LDS (the kernel's only barrier), write ----
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = acc[m][c];
+#pragma unroll
+            for (int off = LN; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            acc[m][c] = v;
+        }
+    if (lane < LN) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f32x4 v = {acc[m][0], acc[m][1], acc[m][2], acc[m][3]};
+            *(f32x4*)(red + (wave * MT + m) * CT + lane * 4) = v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < MT * CT; i += blockDim.x) {
+        const int m = i / CT, c = i % CT;
+        const int n = strip * CT + c, row = m0 + m;
+        if (n >= p.N || row >= p.M) continue;
+        float s = 0.f;
+        for (int w = 0; w < W; ++w) s += red[(w * MT + m) * CT + c];
+        if (p.ksplit > 1) {
+            p.partial[((size_t)blockIdx.y * p.M + row) * p.N + n] = s;
+        } else {
+            if (p.bias) s += (float)((const f16*)p.bias)[n];
+            ((f16*)p.out)[(size_t)row * p.N + n] = (f16)s;
+        }
+    }
+}
+
+// ---- matrix-core GEMV: 4-bit, fp16, sequential groups -------------------------------------------
+// Same load structure as the direct kernel, but the k-reduction runs on the matrix core:
+// v_mfma_f32_4x4x4_16b_f16 is 16 independent 4x4x4 products, one per aligned group of 4 lanes -- and an
+// aligned group of 4 lanes here is exactly one packed row x 16 columns.  Lane j of a group supplies B = 4
+// consecutive-slot k of ITS OWN column, lane i supplies A = the same 4 k of x row i, and lane j receives
+// D[0..3][j]: the partial sums of its own column for 4 rows of x.  So up to 4 rows of x cost the same as
+// one, the 16 v_dot2 per packed word become 8 MFMAs (on a pipe that runs beside the VALU), and the scale is
+// applied once per (lane, group) to the fp32 sums instead of once per weight:
+//     out[m, n] = sum_g  s[g, n] * ( sum_{k in g} x[m, k] * (w[k, n] - z[g, n]) )      (w - z exact in fp16)
+template <int LN, int MT, int U>
+__global__ void __launch_bounds__(1024) gemv_q4_f16_mfma_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = (float*)smem;
+    constexpr int WR = 64 / LN, CT = LN * 4;
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
+    const int cl = lane % LN, rs = lane / LN;
+    const int strip = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = strip * CT + cl * 4;
+    const bool col_ok = n0 < p.N;
+    const int nload = col_ok ? n0 : 0;
+    const int m0 = blockIdx.z * 4;
+    const int ub = blockIdx.y * p.units_per_split;
+    const int ue = min(ub + p.units_per_split, p.units_total);
+    // A operand: lane i of each 4-lane group carries x row m0 + i (clamped: surplus rows are never stored)
+    const f16* __restrict__ xrow = (const f16*)p.x + (size_t)min(m0 + (lane & 3), p.M - 1) * p.K;
+    const f16* __restrict__ scales = (const f16*)p.scales;
+    const int zrow_words = p.N >> 3;
+    const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
+    const int gshift = p.gu_shift;
+
+    f32x4 acc[4];                       // [column][row of x]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int rows_per_iter = W * WR * U;
+    for (int base = ub; base < ue; base += rows_per_iter) {
+        const int u0 = base + (wave * WR + rs) * U;
+        u32x4 q[U], xr[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int ul = min(u0 + j, ue - 1);
+            q[j] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)ul * p.N + nload));
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) xr[j] = *(const u32x4*)(xrow + (size_t)min(u0 + j, ue - 1) * 8);
+        const int g = min(u0, ue - 1) >> gshift;
+        const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * p.N + nload);
+        const unsigned zw = p.qzeros[(size_t)g * zrow_words + (nload >> 3)] >> ((nload & 7) * 4);
+
+        f16x2 c1[4], c2[4];
+        const f16x2 k960 = {(f16)960.f, (f16)960.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned z = (((zw >> (4 * c)) & 15u) + 1u) & zmask;
+            c1[c] = as_f16x2(z * 0x00010001u + 0xE400E400u);    // -(1024+z)
+            c2[c] = c1[c] + k960;                               // -(64+z)
+        }
+        f32x4 accg[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) accg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            u32x4 qv = q[j];
+            if (u0 + j >= ue) qv = u32x4{0u, 0u, 0u, 0u};       // tail rows: x is zeroed below, value irrelevant
+            const u32x4 t = xr[j];
+            const bool live = (u0 + j < ue);
+            // x slots (k0,k4,k1,k5) and (k2,k6,k3,k7): the order the magic-number unpack produces
+            u32x2 a01 = {__builtin_amdgcn_perm(t[2], t[0], 0x05040100u), __builtin_amdgcn_perm(t[2], t[0], 0x07060302u)};
+            u32x2 a23 = {__builtin_amdgcn_perm(t[3], t[1], 0x05040100u), __builtin_amdgcn_perm(t[3], t[1], 0x07060302u)};
+            if (!live) { a01 = u32x2{0u, 0u}; a23 = u32x2{0u, 0u}; }
+            const f16x4 xa01 = __builtin_bit_cast(f16x4, a01), xa23 = __builtin_bit_cast(f16x4, a23);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned qw = qv[c], q8 = qw >> 8;
+                const f16x2 h0 = as_f16x2((qw & 0x000f000fu) | 0x64006400u) + c1[c];
+                const f16x2 h1 = as_f16x2((qw & 0x00f000f0u) | 0x64006400u) * r16 + c2[c];
+                const f16x2 h2 = as_f16x2((q8 & 0x000f000fu) | 0x64006400u) + c1[c];
+                const f16x2 h3 = as_f16x2((q8 & 0x00f000f0u) | 0x64006400u) * r16 + c2[c];
+                const u32x2 b01 = {__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+                const u32x2 b23 = {__builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
+                accg[c] = __builtin_amdgcn_mfma_f32_4x4x4f16(xa01, __builtin_bit_cast(f16x4, b01), accg[c], 0, 0, 0);
+                accg[c] = __builtin_amdgcn_mfma_f32_4x4x4f16(xa23, __builtin_bit_cast(f16x4, b23), accg[c], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned sh = (c & 1) ? (sraw[c >> 1] >> 16) : (sraw[c >> 1] & 0xffffu);
+            const float sc = (float)as_f16((unsigned short)sh);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[c][m] = fmaf(sc, accg[c][m], acc[c][m]);
+        }
+    }
+    // ---- reduce: row slots by shuffles, waves through LDS (one barrier), write ---------------------
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = acc[c][m];
+#pragma unroll
+            for (int off = LN; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            acc[c][m] = v;
+        }
+    if (lane < LN) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f32x4 v = {acc[0][m], acc[1][m], acc[2][m], acc[3][m]};
+            *(f32x4*)(red + (wave * MT + m) * CT + lane * 4) = v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < MT * CT; i += blockDim.x) {
+        const int m = i / CT, c = i % CT;
+        const int n = strip * CT + c, row = m0 + m;
+        if (n >= p.N || row >= p.M) continue;
+        float s = 0.f;
+        for (int w = 0; w < W; ++w) s += red[(w * MT + m) * CT + c];
+        if (p.ksplit > 1) {
+            p.partial[((size_t)blockIdx.y * p.M + row) * p.N + n] = s;
+        } else {
+            if (p.bias) s += (float)((const f16*)p.bias)[n];
+            ((f16*)p.out)[(size_t)row * p.N + n] = (f16)s;
+        }
+    }
+}
+
 // ---- second pass for ksplit > 1: out = sum_s partial[s] (+bias), fixed order ----------------
 template <typename T>
 __global__ void __launch_bounds__(256) gemv_reduce_kernel(const float* __restrict__ partial, const T* __restrict__ bias,
@@ -397,6 +654,25 @@ GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     const size_t rbytes = (size_t)waves * pl.mt * ln * 4 * sizeof(float);
     pl.lds_bytes = xbytes > rbytes ? xbytes : rbytes;
     pl.workspace_bytes = ks > 1 ? (size_t)ks * M * L.N * sizeof(float) : 0;
+    // direct variant: needs power-of-two rows per group and no x gather
+    pl.direct = false;
+    pl.u = 1;
+    const int gu = L.group_size / 8;
+    pl.mfma = false;
+    if (pl.fast && !pl.use_seq && gu > 0 && (gu & (gu - 1)) == 0 && tune && (tune->path == 4 || tune->path == 5)) {
+        int per_lane = (pl.units_per_split + rows_per_iter - 1) / rows_per_iter;
+        const bool mf = tune->path == 5;
+        if (mf) {                      // 4 rows of x per pass, whatever M is
+            pl.mt = M >= 3 ? 4 : M;
+            pl.mtiles = (M + 3) / 4;
+        }
+        int u = 1;
+        while (u * 2 <= per_lane && u * 2 <= gu && u * 2 <= 8 && (mf || u * 2 * pl.mt <= 8) && pl.units_per_split % (u * 2) == 0) u *= 2;
+        pl.direct = !mf;
+        pl.mfma = mf;
+        pl.u = u;
+        pl.lds_bytes = (size_t)waves * pl.mt * ln * 4 * sizeof(float);
+    }
     return pl;
 }
 
@@ -457,6 +733,54 @@ static hipError_t launch_fast_u(const GemvPlan& pl, const GemvParams& p, hipStre
     return hipGetLastError();
 }
 
+template <int LN, int MT>
+static hipError_t launch_direct_u(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
+    dim3 grid(pl.strips, pl.ksplit, pl.mtiles), block(pl.waves * 64);
+    switch (pl.u) {
+        case 1: hipLaunchKernelGGL((gemv_q4_f16_direct_kernel<LN, MT, 1>), grid, block, pl.lds_bytes, st, p); break;
+        case 2: if constexpr (MT <= 4) { hipLaunchKernelGGL((gemv_q4_f16_direct_kernel<LN, MT, 2>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
+        case 4: if constexpr (MT <= 2) { hipLaunchKernelGGL((gemv_q4_f16_direct_kernel<LN, MT, 4>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
+        case 8: if constexpr (MT <= 1) { hipLaunchKernelGGL((gemv_q4_f16_direct_kernel<LN, MT, 8>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <int LN, int MT>
+static hipError_t launch_mfma_u(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
+    dim3 grid(pl.strips, pl.ksplit, pl.mtiles), block(pl.waves * 64);
+    switch (pl.u) {
+        case 1: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1>), grid, block, pl.lds_bytes, st, p); break;
+        case 2: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2>), grid, block, pl.lds_bytes, st, p); break;
+        case 4: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 4>), grid, block, pl.lds_bytes, st, p); break;
+        case 8: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 8>), grid, block, pl.lds_bytes, st, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <int MT>
+static hipError_t launch_mfma_mt(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
+    switch (pl.ln) {
+        case 4: return launch_mfma_u<4, MT>(pl, p, st);
+        case 8: return launch_mfma_u<8, MT>(pl, p, st);
+        case 16: return launch_mfma_u<16, MT>(pl, p, st);
+        case 64: return launch_mfma_u<64, MT>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int MT>
+static hipError_t launch_direct_mt(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
+    switch (pl.ln) {
+        case 4: return launch_direct_u<4, MT>(pl, p, st);
+        case 8: return launch_direct_u<8, MT>(pl, p, st);
+        case 16: return launch_direct_u<16, MT>(pl, p, st);
+        case 64: return launch_direct_u<64, MT>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 template <int MT>
 static hipError_t launch_fast_mt(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
     switch (pl.ln) {
@@ -485,11 +809,26 @@ hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x,
     p.chunk_units = pl.chunk_units; p.ksplit = pl.ksplit;
     {
         const int gu = L.group_size / 8;
-        p.gu_shift = (pl.fast && gu > 0 && (gu & (gu - 1)) == 0) ? __builtin_ctz(gu) : -1;
+        p.gu_shift = (pl.fast && gu > 0 && (gu & (gu - 1)) == 0) ? __builtin_ctz((unsigned)gu) : -1;
     }
 
     hipError_t e;
-    if (pl.fast) {
+    if (pl.mfma) {
+        switch (pl.mt) {
+            case 1: e = launch_mfma_mt<1>(pl, p, st); break;
+            case 2: e = launch_mfma_mt<2>(pl, p, st); break;
+            case 4: e = launch_mfma_mt<4>(pl, p, st); break;
+            default: e = hipErrorInvalidValue;
+        }
+    } else if (pl.direct) {
+        switch (pl.mt) {
+            case 1: e = launch_direct_mt<1>(pl, p, st); break;
+            case 2: e = launch_direct_mt<2>(pl, p, st); break;
+            case 4: e = launch_direct_mt<4>(pl, p, st); break;
+            case 8: e = launch_direct_mt<8>(pl, p, st); break;
+            default: e = hipErrorInvalidValue;
+        }
+    } else if (pl.fast) {
         switch (pl.mt) {
             case 1: e = launch_fast_mt<1>(pl, p, st); break;
             case 2: e = launch_fast_mt<2>(pl, p, st); break;

@@ -10,6 +10,9 @@ struct GemvPlan {
     int ln, waves, ksplit, strips, mt, mtiles;
     int units_total, units_per_split, chunk_units;
     bool fast, perk, use_seq;
+    bool direct;   // fast path without LDS staging (x / scales / zeros straight from L2)
+    bool mfma;     // direct path with the k-reduction on v_mfma_f32_4x4x4_16b_f16
+    int u;         // direct path: consecutive packed rows per lane and iteration
     size_t lds_bytes, workspace_bytes;
 };
 GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune);
@@ -18,8 +21,10 @@ hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x,
 
 struct GemmPlan {
     bool supported, use_seq;
-    int bm, bn;
-    size_t workspace_bytes;   // permuted-x scratch for act-order layers
+    int mt, bk, bm, bn;       // row tiles per wave, K-step, workgroup tile
+    int nbm, nbn, ksplit, ksteps_total, ksteps_per_split;
+    size_t xperm_bytes;       // permuted-x scratch for act-order layers (front of the workspace)
+    size_t workspace_bytes;   // xperm + split-K partial slabs
 };
 GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune);
 hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x, void* out, int M,
@@ -34,6 +39,7 @@ hipError_t launch_pack_weights(const void* W, const void* scale_in, const void* 
 hipError_t launch_pack_zeros(const void* zero_in, int G, int N, int bits, int qparam_dtype, uint32_t* qzeros_out, hipStream_t st);
 hipError_t launch_resequence(const uint32_t* qweight, const int32_t* perm, int K, int N, int bits,
                              uint32_t* out, hipStream_t st);
+hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int K, void* x_out, hipStream_t st);
 hipError_t launch_permute_columns(const void* x, const int32_t* perm, int M, int K, int dtype, void* x_out, hipStream_t st);
 
 }  // namespace gptq

@@ -298,6 +298,7 @@ hipError_t launch_resequence(const uint32_t* qweight, const int32_t* perm, int K
 }
 
 hipError_t launch_permute_columns(const void* x, const int32_t* perm, int M, int K, int dtype, void* x_out, hipStream_t st) {
+    if (dtype != GPTQ_F32 && K % 8 == 0 && (size_t)K * 2 <= 64 * 1024) return launch_permute_rows16(x, perm, M, K, x_out, st);
     dim3 grid((K + 255) / 256, M < 1024 ? M : 1024), block(256);
     if (dtype == GPTQ_F32)
         hipLaunchKernelGGL(permute_columns_kernel<float>, grid, block, 0, st, (const float*)x, perm, M, K, (float*)x_out);

@@ -196,11 +196,13 @@ class QuantLinear(nn.Module):
         return self
 
     # ------------------------------------------------------------------ forward
-    def _workspace(self, M: int, device):
-        need = self._ws_need.get(M)
+    def _workspace(self, M: int, device, tuning=None):
+        need = self._ws_need.get(M) if tuning is None else None
         if need is None:
-            need = int(_lib.load().gptq_workspace_bytes(ctypes.byref(self._layer), M))
-            self._ws_need[M] = need
+            need = int(_lib.load().gptq_workspace_bytes_ex(ctypes.byref(self._layer), M,
+                                                            ctypes.byref(tuning) if tuning is not None else None))
+            if tuning is None:
+                self._ws_need[M] = need
         if need == 0:
             return None, 0
         buf = reserve_workspace(device, need)
@@ -229,7 +231,7 @@ class QuantLinear(nn.Module):
         out = torch.empty((M, self.outfeatures), dtype=w_dtype, device=x2.device)
         if M == 0:
             return out.to(x_dtype).reshape(out_shape)
-        ws_ptr, ws_bytes = self._workspace(M, x2.device)
+        ws_ptr, ws_bytes = self._workspace(M, x2.device, tuning)
         dev_idx = x2.device.index
         stream = torch.cuda.current_stream(x2.device).cuda_stream
         if dev_idx is not None and dev_idx != torch.cuda.current_device():

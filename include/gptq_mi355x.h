@@ -92,7 +92,7 @@ typedef struct gptq_tuning_t {
     int32_t lanes_n;     /* lanes of a wave laid along N (4,8,16,32,64); 4 columns per lane */
     int32_t waves;       /* waves per workgroup (1..16) */
     int32_t ksplit;      /* workgroups along K (1 = no cross-workgroup reduction) */
-    int32_t path;        /* 0 auto, 1 force generic GEMV, 2 force fast GEMV, 3 force MFMA GEMM */
+    int32_t path;        /* 0 auto, 1 generic GEMV, 2 LDS-staged q4/fp16 GEMV, 3 MFMA GEMM, 4 direct q4/fp16 GEMV, 5 matrix-core q4/fp16 GEMV */
     int32_t reserved[4];
 } gptq_tuning_t;
 
@@ -102,6 +102,8 @@ const char *gptq_status_string(int status);
 
 /* Bytes of scratch gptq_forward/gptq_gemv/gptq_gemm may need for this layer and M (0 possible). */
 size_t gptq_workspace_bytes(const gptq_layer_t *layer, int M);
+/* Same for an explicit launch shape (what gptq_forward_ex/gptq_gemv/gptq_gemm need with `tuning`). */
+size_t gptq_workspace_bytes_ex(const gptq_layer_t *layer, int M, const gptq_tuning_t *tuning);
 
 /* out[M,N] = x[M,K] @ dequant(layer) (+ bias).  Picks GEMV (small M) or MFMA GEMM. */
 int gptq_forward(const gptq_layer_t *layer, const void *x, void *out, int M,

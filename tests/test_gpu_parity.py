@@ -184,7 +184,7 @@ def test_forward_random_words_vs_oracle(bits, gs, K, N, act, dtype, M):
 
 
 @pytest.mark.parametrize("ln,waves,ksplit", [(4, 16, 1), (4, 4, 1), (8, 8, 2), (16, 16, 4), (64, 4, 8), (64, 1, 1), (4, 2, 3)])
-@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("path", [1, 2, 4, 5])
 def test_forward_launch_shapes_agree(ln, waves, ksplit, path):
     """Every launch shape (strip width, waves, K split) of both GEMV kernels gives the same answer
     (up to fp32 summation order) and is run-to-run bit-reproducible."""
@@ -295,3 +295,145 @@ def test_full_size_decode_properties(K, N):
     with torch.no_grad():
         ys = qs(x1.to(DEV))
     _assert_close(ys, y1[:, sl], y64, torch.float16, K, "column-sliced layer")
+
+
+# ------------------------------------------------------------------- MFMA prefill path (gptq_gemm)
+GEMM_CASES = [
+    # bits, gs, K, N, act, dtype, M
+    (4, 128, 1024, 1024, False, torch.float16, 128),    # BK=64 kernel, one full tile
+    (4, 128, 1024, 512, False, torch.float16, 200),     # ragged M (2 row tiles, second partial)
+    (4, 128, 512, 96, False, torch.float16, 9),         # N not a multiple of the 256-column tile, MT=1
+    (4, 128, 512, 320, False, torch.float16, 33),       # MT=2, ragged N
+    (4, 32, 512, 256, False, torch.float16, 64),        # group_size 32 -> BK=32 kernel
+    (4, 128, 1024, 1024, True, torch.float16, 128),     # act-order: qweight_seq + permuted x
+    (4, 128, 2048, 256, True, torch.float16, 70),
+    (4, 64, 1024, 256, False, torch.bfloat16, 128),     # bf16: fp32-math dequant
+    (4, 128, 1024, 256, True, torch.bfloat16, 40),
+    (3, 32, 1024, 256, False, torch.float16, 128),      # 3-bit units straddle words
+    (3, 64, 1024, 160, True, torch.float16, 48),
+    (8, 32, 512, 256, False, torch.float16, 128),
+    (8, 128, 1024, 256, True, torch.bfloat16, 20),
+    (2, 64, 1024, 256, False, torch.float16, 128),
+    (2, 32, 512, 128, True, torch.float16, 16),
+    (4, 1024, 1024, 256, False, torch.float16, 96),     # one group for the whole layer
+    (4, 32, 32 * 7, 64, False, torch.float16, 12),      # K = 224: odd number of K-steps
+]
+
+
+@pytest.mark.parametrize("bits,gs,K,N,act,dtype,M", GEMM_CASES)
+def test_gemm_random_words_vs_oracle(bits, gs, K, N, act, dtype, M):
+    """MFMA path forced (tuning.path = 3), both zero conventions, against the oracle's reference-order
+    result and the exact (fp64) result.  The dequantised B fragments equal the reference's `weights`
+    bit for bit, so the only difference left is fp32 MFMA accumulation vs ATen's CPU summation."""
+    L = O.random_quant_layer(K, N, bits, gs, act_order=act, dtype=dtype, seed=K + N + bits + M, bias=True)
+    gen = torch.Generator().manual_seed(11)
+    x = (torch.rand(M, K, generator=gen) - 0.5).to(dtype)
+    for zm, mode in (("wrap", O.ZERO_WRAP), ("nowrap", O.ZERO_NOWRAP)):
+        q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], bits, gs, zero_mode=zm)
+        yref = O.forward(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], bits, mode)
+        y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], bits, mode)
+        with torch.no_grad():
+            y = q(x.to(DEV), tuning=_tuning(path=3))
+            y_auto = q(x.to(DEV))
+        assert torch.equal(y, y_auto), "auto dispatch for M > 8 must take the MFMA path"
+        _assert_close(y, yref, y64, dtype, K, f"gemm zero={zm}")
+        _assert_close(y, y64, y64, dtype, K, f"gemm zero={zm} vs f64")
+
+
+def test_gemm_transpose_detecting():
+    """x = one-hot rows and an asymmetric weight: out[m, :] must be exactly the dequantised row k(m)
+    (catches any row/column or k-slot mix-up in the MFMA fragment layouts)."""
+    K, N, bits, gs = 256, 256, 4, 128
+    L = O.random_quant_layer(K, N, bits, gs, seed=77)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], None, bits, gs)
+    M = 160
+    ks = torch.arange(M) * 37 % K
+    x = torch.zeros(M, K, dtype=torch.float16)
+    x[torch.arange(M), ks] = 1.0
+    with torch.no_grad():
+        y = q(x.to(DEV), tuning=_tuning(path=3)).cpu()
+    W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], bits, O.ZERO_WRAP)
+    assert torch.equal(y, W[ks])
+
+
+@pytest.mark.parametrize("ksplit", [2, 3, 8])
+def test_gemm_split_k_agrees_and_is_deterministic(ksplit):
+    K, N, M = 2048, 512, 24
+    L = O.random_quant_layer(K, N, 4, 128, seed=5, bias=True)
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(1)) - 0.5).half()
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, 128)
+    y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP)
+    t = _tuning(ksplit=ksplit, path=3)
+    with torch.no_grad():
+        y1 = q(x.to(DEV), tuning=t)
+        y2 = q(x.to(DEV), tuning=t)
+    assert torch.equal(y1, y2)
+    _assert_close(y1, y64, y64, torch.float16, K, f"ksplit={ksplit}")
+
+
+def test_gemm_matches_gemv_paths():
+    """The three kernels (generic GEMV, fast GEMV, MFMA GEMM) are three summation orders of the same
+    exactly-dequantised products."""
+    K, N, M = 1024, 512, 8
+    L = O.random_quant_layer(K, N, 4, 128, seed=21)
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(2)) - 0.5).half()
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], None, 4, 128)
+    y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], None, 4, O.ZERO_WRAP)
+    with torch.no_grad():
+        ys = [q(x.to(DEV), tuning=_tuning(path=p)) for p in (1, 2, 3, 4, 5)]
+    for y in ys:
+        _assert_close(y, y64, y64, torch.float16, K, "path agreement")
+
+
+@pytest.mark.parametrize("K,N,M,act", [(4096, 4096, 2048, True), (4096, 11008, 512, True), (11008, 4096, 300, False),
+                                       (4096, 4096, 4096, False)])
+def test_full_size_prefill_properties(K, N, M, act):
+    """Llama-7B shapes at prefill sizes (BASELINE config 3 / north_star M=4096): (a) a row subset against
+    the fp64 oracle on a column slice, (b) every output against x @ W with W = this library's own
+    dequantize() (itself bit-exact vs the reference, tested above) multiplied in fp32 on the GPU,
+    (c) row-block independence: rows [r0, r1) pushed alone give bit-identical outputs when the tile
+    decomposition is unchanged, (d) bit reproducibility."""
+    L = O.random_quant_layer(K, N, 4, 128, act_order=act, seed=K // 11 + N + M)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], None, 4, 128)
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(M, K, generator=gen) - 0.5).half().to(DEV)
+    with torch.no_grad():
+        y, yb = q(x), q(x)
+    assert torch.equal(y, yb)
+    W = q.dequantize().float()
+    ref = x.float() @ W
+    scale = float(ref.abs().max())
+    err = float((y.float() - ref).abs().max())
+    assert err <= 2e-3 * scale, (err, scale)          # fp16 output rounding (2^-11) + accumulation order
+    # (a) fp64 oracle on 8 rows x 256 columns
+    mode = O.reference_zero_mode(act, 4)
+    assert q.resolved_zero_mode() == int(mode == O.ZERO_NOWRAP)
+    n0 = (N // 3) // 32 * 32
+    sl = slice(n0, n0 + 256)
+    rows = torch.tensor([0, 1, 31, 32, M // 2, M - 33, M - 2, M - 1])
+    y64 = O.forward_f64(x[rows].cpu(), L["qweight"][:, sl], L["qzeros"][:, n0 // 8:(n0 + 256) // 8], L["scales"][:, sl],
+                        L["g_idx"] if act else None, None, 4, mode)
+    _assert_close(y[rows][:, sl], y64, y64, torch.float16, K, "prefill rows vs f64")
+    # (c) a 128-aligned row block on its own
+    r0 = (M // 2) // 128 * 128
+    with torch.no_grad():
+        yblk = q(x[r0:r0 + 128].contiguous(), tuning=_tuning(path=3, ksplit=1))
+    assert torch.equal(yblk, y[r0:r0 + 128])
+
+
+@pytest.mark.parametrize("gs,K,N,M", [(128, 1024, 1024, 1), (128, 2048, 512, 3), (32, 512, 768, 2), (64, 1024, 96, 5),
+                                     (128, 4096, 256, 8), (1024, 1024, 256, 4), (128, 11008, 64, 1)])
+@pytest.mark.parametrize("path", [4, 5])
+def test_direct_gemv_vs_oracle(gs, K, N, M, path):
+    """The no-LDS-staging q4/fp16 GEMVs (tuning.path = 4: VALU dot products, 5: matrix core): x / scales /
+    zeros read straight from L2."""
+    L = O.random_quant_layer(K, N, 4, gs, seed=K + N + M, bias=True)
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(9)) - 0.5).half()
+    for zm, mode in (("wrap", O.ZERO_WRAP), ("nowrap", O.ZERO_NOWRAP)):
+        q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, gs, zero_mode=zm)
+        y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, mode)
+        yref = O.forward(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, mode)
+        with torch.no_grad():
+            y = q(x.to(DEV), tuning=_tuning(path=path))
+        _assert_close(y, yref, y64, torch.float16, K, f"direct zero={zm}")
+        _assert_close(y, y64, y64, torch.float16, K, f"direct zero={zm} vs f64")

@@ -52,6 +52,9 @@ def main():
             for waves in ((4, 8, 16) if not args.full else (2, 4, 8, 16)):
                 for ks in ((1, 2, 4, 8) if ln >= 16 else (1, 2)):
                     cfgs.append(dict(lanes_n=ln, waves=waves, ksplit=ks, path=2 if args.bits == 4 else 1))
+                    if args.bits == 4:
+                        cfgs.append(dict(lanes_n=ln, waves=waves, ksplit=ks, path=4))
+                        cfgs.append(dict(lanes_n=ln, waves=waves, ksplit=ks, path=5))
         cfgs.append(dict(path=1))
         if args.heuristic_only:
             cfgs = [dict(), dict(path=1)]
@@ -67,7 +70,7 @@ def main():
             res.append((s, c))
         res.sort(key=lambda r: r[0])
         print(f"== {K}x{N} M={args.m} bits={args.bits}: {nl} layers, {ab} B/launch")
-        for s, c in res[:12]:
+        for s, c in res[:24]:
             print(f"   {s*1e6:8.2f} us  {ab/s/1e9:8.1f} GB/s  {c}")
         hs = [r for r in res if r[1] == {}]
         print(f"   heuristic: {hs[0][0]*1e6:.2f} us   generic: {[r for r in res if r[1]==dict(path=1)][0][0]*1e6:.2f} us")
