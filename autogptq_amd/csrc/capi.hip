@@ -105,7 +105,7 @@ int gptq_gemv(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, 
         return fail(GPTQ_ERR_UNSUPPORTED, "matrix-core GEMV needs bits=4, fp16, no act-order and a power-of-two group_size >= 8");
     if (tune && tune->path == 4 && !pl.direct)
         return fail(GPTQ_ERR_UNSUPPORTED, "direct GEMV needs bits=4, fp16, no act-order and a power-of-two group_size >= 8");
-    if (tune && tune->path == 2 && !pl.fast)
+    if (tune && tune->path == 2 && (!pl.fast || pl.mfma || pl.direct))
         return fail(GPTQ_ERR_UNSUPPORTED, "fast GEMV needs bits=4, fp16 and sequential (or re-sequenced) groups");
     if (pl.workspace_bytes > 0 && (!ws || ws_bytes < pl.workspace_bytes))
         return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", pl.workspace_bytes, ws ? ws_bytes : (size_t)0);

@@ -380,6 +380,7 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.use_seq = (L.g_idx != nullptr);
     pl.mt = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
     pl.bk = (L.bits == 4 && pl.mt == 4 && L.K % 64 == 0 && L.group_size % 64 == 0) ? 64 : 32;
+    if (tune && tune->reserved[1] == 32) pl.bk = 32;      // experiment knob: force the 32-deep K-step
     pl.bm = 32 * pl.mt;
     pl.bn = 256;
     pl.nbm = (M + pl.bm - 1) / pl.bm;

@@ -40,6 +40,20 @@ struct GemvParams {
     int gu_shift;       // log2(group_size / 8) or -1 (fast path)
 };
 
+// Sum over the 64/LN row slots of a wave (lanes l, l+LN, l+2LN, ...): DPP rotates inside a 16-lane row,
+// ds_bpermute across rows.  Every lane ends up with the total.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+    return v + __builtin_bit_cast(float, r);
+}
+template <int LN> __device__ __forceinline__ float row_slot_sum(float v) {
+    if constexpr (LN <= 4) v = dpp_add<0x124>(v);     // row_ror:4
+    if constexpr (LN <= 8) v = dpp_add<0x128>(v);     // row_ror:8
+    if constexpr (LN <= 16) v += __shfl_xor(v, 16, 64);
+    if constexpr (LN <= 32) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 // ---- shared epilogue: reduce row slots (shuffles), waves (LDS), then write ------------------
 template <typename T, int LN, int MT>
 __device__ __forceinline__ void reduce_and_store(float (&acc)[MT][4], float* red, const GemvParams& p,
@@ -361,12 +375,9 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_direct_kernel(GemvParams p) 
     for (int base = ub; base < ue; base += rows_per_iter) {
         const int u0 = base + (wave * WR + rs) * U;        // this lane's first row of the iteration
         // -- 1. every load of the iteration, back to back ---------------------------------------
-        u32x4 q[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int ul = min(u0 + j, ue - 1);
-            q[j] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)ul * p.N + nload));
-        }
+        const int g = min(u0, ue - 1) >> gshift;
+        const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * p.N + nload);
+        const unsigned zw = p.qzeros[(size_t)g * zrow_words + (nload >> 3)] >> ((nload & 7) * 4);
         u32x4 xr[MT][U];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -374,9 +385,12 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_direct_kernel(GemvParams p) 
 #pragma unroll
             for (int j = 0; j < U; ++j) xr[m][j] = *(const u32x4*)(xrow + (size_t)min(u0 + j, ue - 1) * 8);
         }
-        const int g = min(u0, ue - 1) >> gshift;
-        const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * p.N + nload);
-        const unsigned zw = p.qzeros[(size_t)g * zrow_words + (nload >> 3)] >> ((nload & 7) * 4);
+        u32x4 q[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int ul = min(u0 + j, ue - 1);
+            q[j] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)ul * p.N + nload));
+        }
         // -- 2. per-column constants -------------------------------------------------------------
         f16x2 c1[4], c2[4];
         float sc[4];
@@ -493,17 +507,19 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_mfma_kernel(GemvParams p) {
     const int rows_per_iter = W * WR * U;
     for (int base = ub; base < ue; base += rows_per_iter) {
         const int u0 = base + (wave * WR + rs) * U;
+        // loads return in issue order: the small L2-resident ones (scales, zeros, x) go first so that the math
+        // on row j can start as soon as weight row j lands, instead of behind the whole weight burst
+        const int g = min(u0, ue - 1) >> gshift;
+        const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * p.N + nload);
+        const unsigned zw = p.qzeros[(size_t)g * zrow_words + (nload >> 3)] >> ((nload & 7) * 4);
         u32x4 q[U], xr[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) xr[j] = *(const u32x4*)(xrow + (size_t)min(u0 + j, ue - 1) * 8);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int ul = min(u0 + j, ue - 1);
             q[j] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)ul * p.N + nload));
         }
-#pragma unroll
-        for (int j = 0; j < U; ++j) xr[j] = *(const u32x4*)(xrow + (size_t)min(u0 + j, ue - 1) * 8);
-        const int g = min(u0, ue - 1) >> gshift;
-        const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * p.N + nload);
-        const unsigned zw = p.qzeros[(size_t)g * zrow_words + (nload >> 3)] >> ((nload & 7) * 4);
 
         f16x2 c1[4], c2[4];
         const f16x2 k960 = {(f16)960.f, (f16)960.f};
@@ -553,12 +569,7 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_mfma_kernel(GemvParams p) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float v = acc[c][m];
-#pragma unroll
-            for (int off = LN; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-            acc[c][m] = v;
-        }
+        for (int c = 0; c < 4; ++c) acc[c][m] = row_slot_sum<LN>(acc[c][m]);
     if (lane < LN) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -601,24 +612,41 @@ static int pick_mt(int M) { return M >= 8 ? 8 : (M >= 4 ? 4 : (M >= 2 ? 2 : 1));
 GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     GemvPlan pl{};
     const int kpu = unit_vals(L.bits);
+    const int path = tune ? tune->path : 0;
     pl.units_total = L.K / kpu;
     const bool uniform_groups = (L.group_size % kpu == 0);
     const bool seq = (L.g_idx == nullptr) || (L.qweight_seq != nullptr && L.perm != nullptr);
     pl.perk = !(uniform_groups && seq);
     pl.use_seq = (L.g_idx != nullptr) && !pl.perk;
     pl.fast = (L.bits == 4 && L.dtype == GPTQ_F16 && !pl.perk);
-    if (tune && tune->path == 1) pl.fast = false;
-    pl.mt = pick_mt(M);
-    if (!pl.fast && pl.mt > 4) pl.mt = 4;
-    pl.mtiles = (M + pl.mt - 1) / pl.mt;
+    if (path == 1) pl.fast = false;
+    // register-direct variants (no LDS staging): power-of-two packed rows per group, no x gather
+    const int gu = L.group_size / 8;
+    const bool can_direct = pl.fast && !pl.use_seq && gu > 0 && (gu & (gu - 1)) == 0;
+    pl.mfma = can_direct && (path == 0 || path == 5);   // default for 4-bit fp16 layers without act-order
+    pl.direct = can_direct && path == 4;
+    if (pl.mfma) {                 // the matrix core handles 4 rows of x per pass, whatever M is
+        pl.mt = M >= 3 ? 4 : M;
+        pl.mtiles = (M + 3) / 4;
+    } else {
+        pl.mt = pick_mt(M);
+        if (pl.direct && pl.mt > 4) pl.mt = 4;
+        if (!pl.fast && pl.mt > 4) pl.mt = 4;
+        pl.mtiles = (M + pl.mt - 1) / pl.mt;
+    }
 
     int ln = (tune && tune->lanes_n) ? tune->lanes_n : 0;
     if (!ln) {
-        // widest strip that still gives >= 256 workgroups; else the narrowest (16 columns)
-        ln = 4;
-        for (int cand : {16, 8}) {
-            const int strips = (L.N + cand * 4 - 1) / (cand * 4);
-            if (strips * pl.mtiles >= 256) { ln = cand; break; }
+        if (pl.mfma || pl.direct) {
+            // measured (tools/gemvlab, tools/membench): without a K split the 16-column strip wins on every
+            // Llama shape -- a second (reduce) launch costs more than the 64-byte row segments do
+            ln = 4;
+        } else {
+            ln = 4;   // widest strip that still gives >= 256 workgroups; else the narrowest (16 columns)
+            for (int cand : {16, 8}) {
+                const int strips = (L.N + cand * 4 - 1) / (cand * 4);
+                if (strips * pl.mtiles >= 256) { ln = cand; break; }
+            }
         }
     }
     pl.ln = ln;
@@ -639,8 +667,24 @@ GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
         if (waves < 1) waves = 1;
     }
     pl.waves = waves;
-    // LDS per K-chunk, kept <= 64 KiB: x tile (+ for the fast path the per-group constants)
     const int rows_per_iter = wr * waves;
+    const size_t rbytes = (size_t)waves * pl.mt * ln * 4 * sizeof(float);
+    pl.workspace_bytes = ks > 1 ? (size_t)ks * M * L.N * sizeof(float) : 0;
+    pl.u = 1;
+    if (pl.mfma || pl.direct) {
+        // consecutive packed rows per lane and iteration: same group, so one (scales, zeros) fetch serves them
+        const int per_lane = (pl.units_per_split + rows_per_iter - 1) / rows_per_iter;
+        const int want = pl.units_per_split >= 1024 ? 1 : 2;       // long K: more, shorter iterations pipeline better
+        int u = 1;
+        while (u * 2 <= per_lane && u * 2 <= gu && u * 2 <= 8 && (pl.mfma || u * 2 * pl.mt <= 8) &&
+               pl.units_per_split % (u * 2) == 0 && (tune && tune->reserved[0] > 0 ? u * 2 <= tune->reserved[0] : u * 2 <= want))
+            u *= 2;
+        pl.u = u;
+        pl.chunk_units = pl.units_per_split;
+        pl.lds_bytes = rbytes;
+        return pl;
+    }
+    // LDS-staged kernels: x tile (+ for the fast path the per-group constants) per K-chunk, kept <= 64 KiB
     const int gunits = (pl.fast && L.group_size >= kpu) ? L.group_size / kpu : 1;
     auto lds_for = [&](int cu) -> size_t {
         if (pl.fast) return (size_t)pl.mt * cu * 16 + (size_t)(cu / gunits + 2) * ln * 4 * 8;
@@ -651,28 +695,7 @@ GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     if (pl.fast && cu < pl.units_per_split && cu > gunits) cu = (cu / gunits) * gunits;   // chunk on group boundaries
     pl.chunk_units = cu;
     const size_t xbytes = lds_for(cu);
-    const size_t rbytes = (size_t)waves * pl.mt * ln * 4 * sizeof(float);
     pl.lds_bytes = xbytes > rbytes ? xbytes : rbytes;
-    pl.workspace_bytes = ks > 1 ? (size_t)ks * M * L.N * sizeof(float) : 0;
-    // direct variant: needs power-of-two rows per group and no x gather
-    pl.direct = false;
-    pl.u = 1;
-    const int gu = L.group_size / 8;
-    pl.mfma = false;
-    if (pl.fast && !pl.use_seq && gu > 0 && (gu & (gu - 1)) == 0 && tune && (tune->path == 4 || tune->path == 5)) {
-        int per_lane = (pl.units_per_split + rows_per_iter - 1) / rows_per_iter;
-        const bool mf = tune->path == 5;
-        if (mf) {                      // 4 rows of x per pass, whatever M is
-            pl.mt = M >= 3 ? 4 : M;
-            pl.mtiles = (M + 3) / 4;
-        }
-        int u = 1;
-        while (u * 2 <= per_lane && u * 2 <= gu && u * 2 <= 8 && (mf || u * 2 * pl.mt <= 8) && pl.units_per_split % (u * 2) == 0) u *= 2;
-        pl.direct = !mf;
-        pl.mfma = mf;
-        pl.u = u;
-        pl.lds_bytes = (size_t)waves * pl.mt * ln * 4 * sizeof(float);
-    }
     return pl;
 }
 

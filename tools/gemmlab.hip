@@ -1,0 +1,88 @@
+// gemmlab.hip -- timing harness for the PRODUCT MFMA prefill kernel (measurement tool, not product).
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++20 -I autogptq_amd/csrc -I include tools/gemmlab.hip -o tools/gemmlab
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "gemm.hip"
+using namespace gptq;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void fill(unsigned* p, size_t n, unsigned seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned v = (unsigned)(i * 2654435761u) ^ (unsigned)(i >> 7) ^ seed;
+        v ^= v << 13; v ^= v >> 17; v ^= v << 5;
+        p[i] = v;
+    }
+}
+__global__ void fill_f16(f16* p, size_t n, float lo, float hi) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned v = (unsigned)(i * 2246822519u) ^ 0x9e3779b9u; v ^= v >> 15; v *= 2654435761u; v ^= v >> 13;
+        p[i] = (f16)(lo + (hi - lo) * (float)(v & 0xffff) / 65536.f);
+    }
+}
+__global__ void iota_perm(int* p, int K) {   // a fixed pseudo-random permutation of 0..K-1 (K power-of-two multiple friendly)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < K; i += gridDim.x * blockDim.x) p[i] = (int)(((long long)i * 2731 + 17) % K);
+}
+
+int main(int argc, char** argv) {
+    hipStream_t st; CK(hipStreamCreate(&st));
+    struct Shape { int M, K, N; };
+    std::vector<Shape> shapes = {{2048, 4096, 4096}, {4096, 4096, 4096}, {2048, 4096, 11008}, {2048, 11008, 4096}, {512, 4096, 4096}, {128, 4096, 4096}, {32, 4096, 4096}, {16, 4096, 11008}};
+    int only_variant = -1, reps = 5;
+    if (argc >= 4) { shapes = {{atoi(argv[1]), atoi(argv[2]), atoi(argv[3])}}; }
+    if (argc >= 5) only_variant = atoi(argv[4]);
+    if (argc >= 6) reps = atoi(argv[5]);
+    for (auto s : shapes) {
+        const int M = s.M, K = s.K, N = s.N;
+        const size_t qw_b = (size_t)K / 8 * N * 4, qz_b = (size_t)(K / 128) * N / 8 * 4, sc_b = (size_t)(K / 128) * N * 2;
+        const int nl = 4;   // rotate a few layers (weights are L2/MALL resident in prefill anyway)
+        unsigned *qw, *qz; f16 *sc, *x, *out; char* ws; int* perm;
+        CK(hipMalloc(&qw, qw_b * nl)); CK(hipMalloc(&qz, qz_b * nl)); CK(hipMalloc(&sc, sc_b * nl));
+        CK(hipMalloc(&x, (size_t)M * K * 2)); CK(hipMalloc(&out, (size_t)M * N * 2)); CK(hipMalloc(&perm, (size_t)K * 4));
+        const size_t ws_b = (size_t)M * K * 2 + (size_t)8 * M * N * 4 + 4096;
+        CK(hipMalloc(&ws, ws_b));
+        fill<<<2048, 256, 0, st>>>(qw, qw_b * nl / 4, 1u);
+        fill<<<256, 256, 0, st>>>(qz, qz_b * nl / 4, 2u);
+        fill_f16<<<256, 256, 0, st>>>(sc, sc_b * nl / 2, 0.002f, 0.0022f);
+        fill_f16<<<2048, 256, 0, st>>>(x, (size_t)M * K, -0.5f, 0.5f);
+        iota_perm<<<64, 256, 0, st>>>(perm, K);
+        CK(hipStreamSynchronize(st));
+        printf("== M=%d K=%d N=%d : %.2f GFLOP per launch\n", M, K, N, 2.0 * M * K * N / 1e9);
+        for (int variant = 0; variant < 3; ++variant) {
+            if (only_variant >= 0 && variant != only_variant) continue;
+            gptq_layer_t L{};
+            L.K = K; L.N = N; L.bits = 4; L.group_size = 128; L.dtype = GPTQ_F16; L.zero_mode = GPTQ_ZERO_WRAP;
+            gptq_tuning_t tu{}; tu.path = 3;
+            const char* name = "default";
+            if (variant == 1) { tu.reserved[1] = 32; name = "BK=32"; }
+            if (variant == 2) { L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; name = "act-order (x permute + qweight_seq)"; }
+            GemmPlan pl = plan_gemm(L, M, &tu);
+            if (!pl.supported) { printf("  unsupported\n"); continue; }
+            auto launch_all = [&]() {
+                for (int i = 0; i < nl; ++i) {
+                    L.qweight = qw + (size_t)i * qw_b / 4; L.qzeros = qz + (size_t)i * qz_b / 4; L.scales = sc + (size_t)i * sc_b / 2;
+                    L.qweight_seq = variant == 2 ? L.qweight : nullptr;
+                    hipError_t e = launch_gemm(L, pl, x, out, M, ws, st);
+                    if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); exit(1); }
+                }
+            };
+            launch_all();
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            CK(hipStreamSynchronize(st));
+            CK(hipEventRecord(e0, st));
+            for (int r = 0; r < reps; ++r) launch_all();
+            CK(hipEventRecord(e1, st));
+            CK(hipStreamSynchronize(st));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = ms * 1e3 / (reps * nl);
+            printf("  %9.2f us  %8.1f TFLOP/s  %-38s mt=%d bk=%d grid=%dx%d ksplit=%d\n", us, 2.0 * M * K * N / us / 1e6, name, pl.mt, pl.bk,
+                   pl.nbm, pl.nbn, pl.ksplit);
+        }
+        CK(hipFree(qw)); CK(hipFree(qz)); CK(hipFree(sc)); CK(hipFree(x)); CK(hipFree(out)); CK(hipFree(ws)); CK(hipFree(perm));
+    }
+    return 0;
+}

@@ -86,13 +86,12 @@ int main(int argc, char** argv) {
 #define TRY(LN, U, NT, W, KS) do { if (N % (LN * 4) == 0) { R r; r.us = run<LN, U, NT>(buf, mats, rows, N, W, KS, out, 3, st); \
         snprintf(r.name, sizeof r.name, "LN=%2d U=%d nt=%d waves=%2d ksplit=%3d blocks=%5d", LN, U, NT, W, KS, N / (LN * 4) * KS); res.push_back(r); } } while (0)
 #define TRYR(LN, U, W, KS) do { if (N % (LN * 4) == 0) { R r; r.us = run<LN, U, true, true>(buf, mats, rows, N, W, KS, out, 3, st); \
-        snprintf(r.name, sizeof r.name, "LN=%2d U=%d nt=1 waves=%2d ksplit=%3d blocks=%5d XCD-REMAP", LN, U, W, KS, N / (LN * 4) * KS); res.push_back(r); } } while (0)
+        snprintf(r.name, sizeof r.name, "LN=%2d U=%d nt=1 waves=%2d ksplit=%3d blocks=%5d XCD-REMAP", LN, U, W, KS, N / (LN * 4) * KS); res.push_back(r); \
+        r.us = run<LN, U, false, true>(buf, mats, rows, N, W, KS, out, 3, st); \
+        snprintf(r.name, sizeof r.name, "LN=%2d U=%d nt=0 waves=%2d ksplit=%3d blocks=%5d XCD-REMAP", LN, U, W, KS, N / (LN * 4) * KS); res.push_back(r); } } while (0)
         for (int W : {4, 8, 16}) {
             TRYR(4, 4, W, 1); TRYR(4, 8, W, 1); TRYR(4, 2, W, 1); TRYR(8, 4, W, 1); TRYR(8, 8, W, 1); TRYR(8, 4, W, 2); TRYR(16, 4, W, 1); TRYR(16, 4, W, 4);
-            TRY(4, 4, true, W, 1); TRY(4, 8, true, W, 1); TRY(4, 4, true, W, 2);
-            TRY(8, 4, true, W, 1); TRY(8, 4, true, W, 2); TRY(8, 4, true, W, 4); TRY(8, 8, true, W, 2);
-            TRY(16, 4, true, W, 4); TRY(16, 4, true, W, 8); TRY(16, 8, true, W, 4); TRY(16, 2, true, W, 16); TRY(16, 4, false, W, 4);
-            TRY(64, 4, true, W, 16); TRY(64, 4, true, W, 32); TRY(64, 8, true, W, 16); TRY(64, 2, true, W, 64); TRY(64, 4, false, W, 16); TRY(64, 1, true, W, 64);
+            TRY(16, 4, true, W, 4); TRY(64, 1, true, W, 64);
         }
         std::sort(res.begin(), res.end(), [](const R& a, const R& b) { return a.us < b.us; });
         for (size_t i = 0; i < res.size(); ++i)
