@@ -196,8 +196,23 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
+    // Logical tile order: column blocks 8 tiles wide, walked row by row, so the contiguous run of logical ids
+    // an XCD receives is a compact (rows x 8 columns) patch: its L2 holds 8 weight panels and a few x panels
+    // instead of every x panel (measured: L2 fill traffic was 0.49 GB per 4096^3 launch with a column-major order).
     const int L = xcd_remap(blockIdx.x, p.nbm * p.nbn);
-    const int bn = L / p.nbm, bm = L - bn * p.nbm;     // neighbours on an XCD share the weight columns
+    int bm, bn;
+    {
+        const int full = p.nbn >> 3, per = p.nbm * 8;
+        if (L < full * per) {
+            const int cb = L / per, r = L - cb * per;
+            bm = r >> 3;
+            bn = cb * 8 + (r & 7);
+        } else {
+            const int w = p.nbn & 7, r = L - full * per;
+            bm = r / w;
+            bn = full * 8 + (r - bm * w);
+        }
+    }
     const int m0 = bm * BM;
     const int n = bn * 256 + wave * 64 + 2 * l31;      // this lane's first column (second is n + 1)
     const bool col_ok = n < p.N;
@@ -317,6 +332,117 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
         }
 }
 
+// ---- skinny variant: 8 < M <= 128 (weight-streaming regime) --------------------------------------
+// Same fragment scheme (weights straight into B fragments), different decomposition: the work is bandwidth
+// bound on the packed weights, so it is cut like the GEMV -- a workgroup owns ONE 64-column strip and its
+// W waves split K (contiguous runs of 16-deep steps), which gives N/64 x ksplit workgroups of wide (256 B)
+// row segments.  x is tiny and L2 resident, so A fragments are loaded straight from global (no LDS staging,
+// no barrier in the K loop); the only synchronisation is the final cross-wave sum through LDS.
+template <int BITS, typename T, int MT, int UNR>
+__global__ void __launch_bounds__(512) gemm_skinny_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // W x 8 KiB
+    float* red = (float*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int strip = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = blockIdx.z * (32 * MT);
+    const int n = strip * 64 + 2 * l31;
+    const bool col_ok = n < p.N;
+    const int nl = col_ok ? n : 0;
+    const unsigned* __restrict__ qcol = p.qweight + nl;
+    const unsigned short* __restrict__ x = (const unsigned short*)p.x;
+    const int S = p.K >> 4;                                       // 16-deep steps in K
+    const int b0 = blockIdx.y * p.ksteps_per_split;               // this workgroup's steps [b0, b1)
+    const int b1 = min(b0 + p.ksteps_per_split, S);
+    const int spw = ((p.ksteps_per_split + W - 1) / W + UNR - 1) / UNR * UNR;
+    const int ws = b0 + wave * spw, we = min(ws + spw, b1);
+
+    const unsigned short* a_src[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_src[mt] = x + (size_t)min(m0 + mt * 32 + l31, p.M - 1) * p.K + half * 8;
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    for (int s0 = ws; s0 < we; s0 += UNR) {
+        // the UNR steps of a chunk share one group (group_size % (16*UNR) == 0, chunks are UNR-aligned)
+        CRaw craw;
+        load_craw<BITS>(craw, p.scales, p.qzeros, (s0 * 16) / p.group_size, p.N, nl);
+        u32x4 a[UNR][MT];
+        BRaw<BITS> braw[UNR];
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            const int sj = min(s0 + j, we - 1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[j][mt] = *(const u32x4*)(a_src[mt] + (size_t)sj * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) load_braw<BITS>(braw[j], qcol, p.N, p.qrows, min(s0 + j, we - 1) * 16 + half * 8);
+        Deq<BITS, T> dq;
+        dq.setup(craw, p.zero_mode);
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            const bool live = s0 + j < we;
+            const int k = min(s0 + j, we - 1) * 16 + half * 8;
+            u32x4 b[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) b[nt] = dq.frag(braw[j], nt, k);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const u32x4 t = a[j][mt];
+                u32x4 o;
+                o[0] = __builtin_amdgcn_perm(t[2], t[0], 0x05040100u);
+                o[1] = __builtin_amdgcn_perm(t[2], t[0], 0x07060302u);
+                o[2] = __builtin_amdgcn_perm(t[3], t[1], 0x05040100u);
+                o[3] = __builtin_amdgcn_perm(t[3], t[1], 0x07060302u);
+                if (!live) o = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = Mma<T>::run(o, b[nt], acc[mt][nt]);
+            }
+        }
+    }
+
+    // ---- cross-wave sum, one 32-row tile at a time (W x 8 KiB of LDS) -------------------------------
+    float bias0 = 0.f, bias1 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (mt) __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave * 2 + nt) * 16 + r) * 64 + lane] = acc[mt][nt][r];
+        __syncthreads();
+        for (int e = tid; e < 16 * 64; e += blockDim.x) {        // e = r * 64 + lane'
+            const int r = e >> 6, ln = e & 63;
+            float v0 = 0.f, v1 = 0.f;
+            for (int w = 0; w < W; ++w) {
+                v0 += red[((w * 2 + 0) * 16 + r) * 64 + ln];
+                v1 += red[((w * 2 + 1) * 16 + r) * 64 + ln];
+            }
+            const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+            const int nn = strip * 64 + 2 * (ln & 31);
+            if (m >= p.M || nn >= p.N) continue;
+            if (p.ksplit > 1) {
+                float2 o = {v0, v1};
+                *(float2*)(p.partial + ((size_t)blockIdx.y * p.M + m) * p.N + nn) = o;
+            } else {
+                if (p.bias) {
+                    bias0 = DType<T>::to_f32(((const T*)p.bias)[nn]);
+                    bias1 = DType<T>::to_f32(((const T*)p.bias)[nn + 1]);
+                }
+                const unsigned o = (unsigned)t_bits(DType<T>::from_f32(v0 + bias0)) |
+                                   ((unsigned)t_bits(DType<T>::from_f32(v1 + bias1)) << 16);
+                *(unsigned*)((unsigned short*)p.out + (size_t)m * p.N + nn) = o;
+            }
+        }
+    }
+}
+
 // out = sum_s partial[s] (+bias), fixed order; 4 columns per thread
 template <typename T>
 __global__ void __launch_bounds__(256) gemm_reduce_kernel(const float* __restrict__ partial, const T* __restrict__ bias,
@@ -378,6 +504,32 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
                    (L.N % 32 == 0) && (L.group_size % kpu == 0) && ((size_t)L.K * 2 <= 64 * 1024 || L.g_idx == nullptr);
     if (!pl.supported) return pl;
     pl.use_seq = (L.g_idx != nullptr);
+    pl.xperm_bytes = pl.use_seq ? align_up((size_t)M * L.K * 2, 256) : 0;
+    const int force_skinny = tune ? tune->reserved[2] : 0;      // experiment knob: 1 = skinny, 2 = tiled
+    pl.skinny = (force_skinny == 1) || (force_skinny == 0 && M <= 64);
+    if (pl.skinny && M > 128) pl.skinny = false;
+    if (pl.skinny) {
+        pl.mt = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
+        pl.bk = (L.group_size % 64 == 0 && L.K % 64 == 0) ? 64 : 32;      // = 16 * UNR
+        pl.bm = 32 * pl.mt;
+        pl.bn = 64;
+        pl.nbm = (M + pl.bm - 1) / pl.bm;
+        pl.nbn = (L.N + 63) / 64;
+        pl.waves = 8;
+        const int S = L.K / 16;
+        int ks = (tune && tune->ksplit > 0 && tune->path == 3) ? tune->ksplit : 0;
+        if (!ks) {
+            ks = 1;
+            while ((long)pl.nbm * pl.nbn * ks < 224 && S / (ks * 2) >= pl.waves * 4) ks *= 2;
+        }
+        if (ks > S) ks = S;
+        pl.ksteps_total = S;
+        pl.ksteps_per_split = (S + ks - 1) / ks;
+        pl.ksteps_per_split = (pl.ksteps_per_split + pl.bk / 16 - 1) / (pl.bk / 16) * (pl.bk / 16);   // chunk aligned
+        pl.ksplit = (S + pl.ksteps_per_split - 1) / pl.ksteps_per_split;
+        pl.workspace_bytes = pl.xperm_bytes + (pl.ksplit > 1 ? (size_t)pl.ksplit * M * L.N * sizeof(float) : 0);
+        return pl;
+    }
     pl.mt = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
     pl.bk = (L.bits == 4 && pl.mt == 4 && L.K % 64 == 0 && L.group_size % 64 == 0) ? 64 : 32;
     if (tune && tune->reserved[1] == 32) pl.bk = 32;      // experiment knob: force the 32-deep K-step
@@ -395,7 +547,6 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     if (ks > pl.ksteps_total) ks = pl.ksteps_total;
     pl.ksteps_per_split = (pl.ksteps_total + ks - 1) / ks;
     pl.ksplit = (pl.ksteps_total + pl.ksteps_per_split - 1) / pl.ksteps_per_split;   // no empty slices
-    pl.xperm_bytes = pl.use_seq ? align_up((size_t)M * L.K * 2, 256) : 0;
     pl.workspace_bytes = pl.xperm_bytes + (pl.ksplit > 1 ? (size_t)pl.ksplit * M * L.N * sizeof(float) : 0);
     return pl;
 }
@@ -407,8 +558,27 @@ static hipError_t launch_one(const GemmPlan& pl, const GemmParams& p, hipStream_
     return hipGetLastError();
 }
 
+template <int BITS, typename T, int MT, int UNR>
+static hipError_t launch_skinny_one(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
+    const size_t lds = (size_t)pl.waves * 8192;
+    hipLaunchKernelGGL((gemm_skinny_kernel<BITS, T, MT, UNR>), dim3(pl.nbn, pl.ksplit, pl.nbm), dim3(pl.waves * 64), lds, st, p);
+    return hipGetLastError();
+}
+
+template <int BITS, typename T>
+static hipError_t launch_skinny(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
+    const bool u4 = pl.bk == 64;
+    switch (pl.mt) {
+        case 1: return u4 ? launch_skinny_one<BITS, T, 1, 4>(pl, p, st) : launch_skinny_one<BITS, T, 1, 2>(pl, p, st);
+        case 2: return u4 ? launch_skinny_one<BITS, T, 2, 4>(pl, p, st) : launch_skinny_one<BITS, T, 2, 2>(pl, p, st);
+        case 4: return u4 ? launch_skinny_one<BITS, T, 4, 4>(pl, p, st) : launch_skinny_one<BITS, T, 4, 2>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 template <int BITS, typename T>
 static hipError_t launch_bits(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
+    if (pl.skinny) return launch_skinny<BITS, T>(pl, p, st);
     if constexpr (BITS == 4) {
         if (pl.bk == 64) return launch_one<BITS, T, 4, 64>(pl, p, st);
     }

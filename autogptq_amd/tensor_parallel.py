@@ -70,8 +70,9 @@ class ColumnParallelQuantLinear(nn.Module):
         lead = y.shape[:-1]
         y2 = y.reshape(-1, y.shape[-1]).contiguous()         # [M, N/T]
         M, nl = y2.shape
-        buf = torch.empty((self.world, M, nl), dtype=y2.dtype, device=y2.device)
+        buf = torch.empty((self.world * M, nl), dtype=y2.dtype, device=y2.device)    # rank-major concatenation
         dist.all_gather_into_tensor(buf, y2, group=self.group)
+        buf = buf.view(self.world, M, nl)
         if M == 1:
             out = buf.reshape(1, self.world * nl)            # rank-major == column-major for one row
         else:

@@ -123,6 +123,24 @@ def time_graph(g, reps, device, dist_barrier=None):
     return t1 - t0, e0.elapsed_time(e1) * 1e-3
 
 
+def pmc_traffic(kernel, K, N, M):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE
+    passes (profiles/pmc_traffic.json, produced by tools/pmc_traffic.py from separate counter-only runs of this
+    same command; FETCH_SIZE already doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        for ent in d.get("kernels", []):
+            if (ent["kernel"] in kernel or kernel in ent["kernel"]) and ent["K"] == K and ent["N"] == N and ent["M"] == M:
+                return ent["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+    return None
+
+
 def cpu_baseline(M, act_order, budget_s=20.0):
     """Time the oracle (a port of the reference's pure-PyTorch CPU QuantLinear.forward: materialise
     the unpacked ints, dequantise, torch.matmul) on the host cores, on a bounded sample: the three
@@ -260,7 +278,8 @@ def main():
             ach = algorithmic_bytes(K, N, M, act_order=act_order) / best["per_launch_s"] / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
-        roof["kernel"] = "gptq gemm (MFMA)" if prefill else "gptq::gemv_q4_f16_kernel"
+        roof["kernel"] = "gptq::gemm_kernel<4, f16, 4, 64>" if prefill else "gptq::gemv_q4_f16_mfma_kernel"
+        roof["traffic"] = pmc_traffic(roof["kernel"], K, N, M)
         roof["shape"] = f"K={K} N={N} M={M}"
         roof["us_per_launch_events"] = round(best["per_launch_s"] * 1e6, 3)
         roof["algorithmic_bytes_per_launch"] = algorithmic_bytes(K, N, M, act_order=act_order)

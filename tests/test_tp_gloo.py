@@ -1,0 +1,71 @@
+"""CPU (-m "not gpu"), 2 processes over gloo: the out_features tensor-parallel split (shard_packed) and the
+single all-gather that reassembles [M, N] (ColumnParallelQuantLinear).  The rank-local matmul is played by the
+oracle here (this is a test of the sharding + exchange logic; the HIP kernels are covered by the -m gpu tests,
+whose column-slice property test proves a shard computes exactly the columns it owns)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from autogptq_amd.tensor_parallel import ColumnParallelQuantLinear, shard_bounds, shard_packed
+from oracle import gptq_oracle as O
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, bits, gs, K, N, M, act, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L = O.random_quant_layer(K, N, bits, gs, act_order=act, seed=3, bias=True)     # same on every rank
+        x = (torch.rand(M, K, generator=torch.Generator().manual_seed(5)) - 0.5).float()
+        mode = O.reference_zero_mode(act, bits)
+        qw, qz, sc, b = shard_packed(L["qweight"], L["qzeros"], L["scales"].float(), L["bias"].float(), bits, rank, world)
+
+        def local(xx):
+            return O.forward(xx, qw, qz, sc, L["g_idx"], b, bits, mode)
+
+        mod = ColumnParallelQuantLinear(local, N)
+        y = mod(x)
+        ref = O.forward(x, L["qweight"], L["qzeros"], L["scales"].float(), L["g_idx"], L["bias"].float(), bits, mode)
+        ok = tuple(y.shape) == (M, N) and torch.allclose(y, ref, rtol=1e-5, atol=1e-6)
+        y3 = mod(x.reshape(1, M, K))                      # leading dims preserved
+        ok = ok and tuple(y3.shape) == (1, M, N) and torch.equal(y3[0], y)
+        q.put((rank, bool(ok), float((y - ref).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bits,gs,K,N,M,act", [(4, 128, 256, 256, 1, False), (4, 32, 128, 192, 3, True), (3, 32, 128, 128, 2, False),
+                                              (8, 64, 128, 64, 2, True)])
+def test_column_parallel_two_ranks_gloo(bits, gs, K, N, M, act):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bits, gs, K, N, M, act, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+
+
+def test_shard_bounds_rules():
+    assert shard_bounds(4096, 3, 8) == (1536, 2048)
+    assert shard_bounds(11008, 7, 8) == (9632, 11008)       # 1376 columns per rank
+    assert shard_bounds(28672, 0, 8) == (0, 3584)
+    with pytest.raises(ValueError):
+        shard_bounds(4096 + 32, 0, 8)                        # not a multiple of 32 columns per rank
+    with pytest.raises(ValueError):
+        shard_bounds(96, 0, 8)

@@ -30,7 +30,7 @@ __global__ void iota_perm(int* p, int K) {   // a fixed pseudo-random permutatio
 int main(int argc, char** argv) {
     hipStream_t st; CK(hipStreamCreate(&st));
     struct Shape { int M, K, N; };
-    std::vector<Shape> shapes = {{2048, 4096, 4096}, {4096, 4096, 4096}, {2048, 4096, 11008}, {2048, 11008, 4096}, {512, 4096, 4096}, {128, 4096, 4096}, {32, 4096, 4096}, {16, 4096, 11008}};
+    std::vector<Shape> shapes = {{2048, 4096, 4096}, {4096, 4096, 4096}, {2048, 4096, 11008}, {2048, 11008, 4096}, {512, 4096, 4096}, {128, 4096, 4096}, {64, 4096, 4096}, {32, 4096, 4096}, {16, 4096, 4096}, {16, 4096, 11008}, {64, 11008, 4096}, {128, 4096, 11008}};
     int only_variant = -1, reps = 5;
     if (argc >= 4) { shapes = {{atoi(argv[1]), atoi(argv[2]), atoi(argv[3])}}; }
     if (argc >= 5) only_variant = atoi(argv[4]);
@@ -51,13 +51,15 @@ int main(int argc, char** argv) {
         iota_perm<<<64, 256, 0, st>>>(perm, K);
         CK(hipStreamSynchronize(st));
         printf("== M=%d K=%d N=%d : %.2f GFLOP per launch\n", M, K, N, 2.0 * M * K * N / 1e9);
-        for (int variant = 0; variant < 3; ++variant) {
+        for (int variant = 0; variant < 5; ++variant) {
             if (only_variant >= 0 && variant != only_variant) continue;
             gptq_layer_t L{};
             L.K = K; L.N = N; L.bits = 4; L.group_size = 128; L.dtype = GPTQ_F16; L.zero_mode = GPTQ_ZERO_WRAP;
             gptq_tuning_t tu{}; tu.path = 3;
             const char* name = "default";
-            if (variant == 1) { tu.reserved[1] = 32; name = "BK=32"; }
+            if (variant == 1) continue;
+            if (variant == 3) { if (M > 128) continue; tu.reserved[2] = 1; name = "forced skinny"; }
+            if (variant == 4) { if (M > 128) continue; tu.reserved[2] = 2; name = "forced tiled"; }
             if (variant == 2) { L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; name = "act-order (x permute + qweight_seq)"; }
             GemmPlan pl = plan_gemm(L, M, &tu);
             if (!pl.supported) { printf("  unsupported\n"); continue; }
@@ -79,8 +81,8 @@ int main(int argc, char** argv) {
             CK(hipStreamSynchronize(st));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             const double us = ms * 1e3 / (reps * nl);
-            printf("  %9.2f us  %8.1f TFLOP/s  %-38s mt=%d bk=%d grid=%dx%d ksplit=%d\n", us, 2.0 * M * K * N / us / 1e6, name, pl.mt, pl.bk,
-                   pl.nbm, pl.nbn, pl.ksplit);
+            printf("  %9.2f us  %8.1f TFLOP/s  %7.1f GB/s(w)  %-38s %s mt=%d bk=%d grid=%dx%d ksplit=%d\n", us, 2.0 * M * K * N / us / 1e6, qw_b / us / 1e3, name,
+                   pl.skinny ? "skinny" : "tiled", pl.mt, pl.bk, pl.nbm, pl.nbn, pl.ksplit);
         }
         CK(hipFree(qw)); CK(hipFree(qz)); CK(hipFree(sc)); CK(hipFree(x)); CK(hipFree(out)); CK(hipFree(ws)); CK(hipFree(perm));
     }

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Per-launch HBM-side traffic of the gptq kernels from rocprofv3 PMC databases.
+
+  python tools/pmc_traffic.py --fetch <FETCH_SIZE db> [--write <WRITE_SIZE db>] --out profiles/pmc_traffic.json
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide
+coalesced reads, so the read side is doubled (MI355X_MICROARCH.md, section HBM).  Dispatches are keyed by kernel
+name + grid so the three Llama-7B layer shapes of bench.py are told apart:
+  grid.x (threads) / workgroup = column strips  ->  N = strips * 16 for the 16-column-strip decode kernels.
+"""
+import argparse
+import json
+import sqlite3
+
+
+def per_kernel(db, counter):
+    c = sqlite3.connect(db)
+    rows = c.execute(
+        "select k.name, k.grid_x, k.grid_y, k.workgroup_x, avg(p.counter_value), count(*) from pmc_events p join kernels k "
+        "on p.dispatch_id = k.dispatch_id where p.counter_name = ? and k.name like '%gptq%' group by k.name, k.grid_x, k.grid_y, k.workgroup_x",
+        (counter,)).fetchall()
+    return {(r[0], r[1], r[2], r[3]): (r[4], r[5]) for r in rows}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fetch", required=True)
+    ap.add_argument("--write")
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--shapes", default="4096x4096,4096x11008,11008x4096", help="KxN list used to label decode dispatches")
+    ap.add_argument("--m", type=int, default=1)
+    ap.add_argument("--prefill-m", type=int, default=0, help="rows per step of the prefill bench (labels gemm_kernel dispatches)")
+    args = ap.parse_args()
+    fetch = per_kernel(args.fetch, "FETCH_SIZE")
+    write = per_kernel(args.write, "WRITE_SIZE") if args.write else {}
+    shapes = [tuple(map(int, s.split("x"))) for s in args.shapes.split(",")]
+    out = []
+    for key, (kib, n) in sorted(fetch.items()):
+        name, gx, gy, wg = key
+        blocks = gx // wg
+        ent = {"kernel": name.split("(")[0].replace("void ", ""), "grid_blocks": [blocks, gy], "workgroup": wg, "dispatches": n,
+               "FETCH_SIZE_KiB": round(kib, 1), "fetch_bytes_x2": int(kib * 1024 * 2)}
+        w = write.get(key)
+        ent["WRITE_SIZE_KiB"] = round(w[0], 1) if w else None
+        ent["hbm_bytes_per_launch"] = ent["fetch_bytes_x2"] + (int(w[0] * 1024) if w else 0)
+        # label with (K, N, M) when the grid matches a decode strip decomposition (16-column strips)
+        ent["K"] = ent["N"] = ent["M"] = None
+        for K, N in shapes:
+            if blocks * 16 == N and "gemv" in name:
+                ent["N"], ent["M"] = N, args.m
+                cands = [k for k, n2 in shapes if n2 == N]
+                ent["K_candidates"] = cands
+                if len(cands) == 1:
+                    ent["K"] = cands[0]
+            if "gemm_kernel" in name and args.prefill_m:        # 128 x 256 workgroup tiles
+                if blocks == -(-args.prefill_m // 128) * -(-N // 256):
+                    ent["N"], ent["M"] = N, args.prefill_m
+                    cands = [k for k, n2 in shapes if n2 == N]
+                    ent["K_candidates"] = cands
+                    if len(cands) == 1:
+                        ent["K"] = cands[0]
+        out.append(ent)
+    with open(args.out, "w") as f:
+        json.dump({"source": {"fetch": args.fetch, "write": args.write}, "note": "FETCH_SIZE doubled (gfx950 correction)",
+                   "kernels": out}, f, indent=1)
+    for e in out:
+        print(e)
+
+
+if __name__ == "__main__":
+    main()
