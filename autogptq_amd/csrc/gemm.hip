@@ -28,6 +28,8 @@
 //     into the workspace by a small LDS-staged gather kernel (the column_remap of exllama, column_remap.cu:9-63).
 //   * fp32 accumulation in the MFMA; optional split-K (only when M*N is too small to fill 256 CUs) writes
 //     fp32 partial slabs that a second pass sums in fixed order: bit-reproducible, no atomics.
+#include <type_traits>
+
 #include "common.cuh"
 #include "launch.h"
 
@@ -184,14 +186,19 @@ template <> struct Deq<4, f16> {
 
 // ---- the kernel -------------------------------------------------------------------------------
 // Workgroup = 4 waves side by side along N: tile BM = 32*MT rows x 256 columns, K-step BK.
-template <int BITS, typename T, int MT, int BK>
+// VAR selects the inner-loop schedule: 1 (default) = explicit software pipeline over the MFMA k-steps, 0 = plain loop
+// scheduled by hipcc, 2 = plain + s_setprio around the MFMA groups.  Within-run A/B on MI355X (tools/gemmlab, min of 3
+// rounds, TFLOP/s at M=2048 4096^2 / M=4096 4096^2 / 4096x11008 / 11008x4096): VAR1 793/1002/908/889, VAR0 678/990/888/840,
+// VAR2 743/972/852/815.  (Also tried: 8 waves per workgroup, one column of each pair per wave -- slower everywhere.)
+template <int BITS, typename T, int MT, int BK, int VAR = 1>
 __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
     constexpr int KS = BK / 16;                // MFMA k-steps per K-step
     constexpr int BM = 32 * MT;
     constexpr int STRIDE = BK * 2 + 16;        // bytes per LDS row of x (padded)
     constexpr int CPR = BK / 8;                // 16-byte chunks per row
     constexpr int CHUNKS = BM * CPR;
-    constexpr int NCH = (CHUNKS + 255) / 256;
+    constexpr int NTHR = 256;
+    constexpr int NCH = (CHUNKS + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x BM x STRIDE
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -230,7 +237,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
     const unsigned short* a_src[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int c = tid + i * 256;
+        const int c = tid + i * NTHR;
         a_row[i] = c / CPR;
         a_kc[i] = c - a_row[i] * CPR;
         a_src[i] = x + (size_t)min(m0 + a_row[i], p.M - 1) * p.K + a_kc[i] * 8;
@@ -242,7 +249,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
     auto store_a = [&](int buf, const u32x4 (&r)[NCH]) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            if (CHUNKS % 256 != 0 && tid + i * 256 >= CHUNKS) continue;
+            if (CHUNKS % NTHR != 0 && tid + i * NTHR >= CHUNKS) continue;
             // (x0,x1)(x2,x3)(x4,x5)(x6,x7) -> (x0,x4)(x1,x5)(x2,x6)(x3,x7): the slot order of the B fragments
             u32x4 o;
             o[0] = __builtin_amdgcn_perm(r[i][2], r[i][0], 0x05040100u);
@@ -266,45 +273,78 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+    // Two K-steps per loop trip, ping-ponging between register sets (b0,c0)/(b1,c1) and LDS buffers 0/1, so
+    // nothing is copied and every LDS offset is an immediate.  Inside a step the A fragments of MFMA k-step
+    // ks+1 are read from LDS before the MFMAs of ks are issued (their latency hides behind 8 MFMAs).
     u32x4 a_next[NCH];
-    BRaw<BITS> b_cur[KS], b_next[KS];
-    CRaw c_cur, c_next;
+    BRaw<BITS> b0[KS], b1[KS];
+    CRaw c0, c1;
     load_a(kt0, a_next);
-    load_b(kt0, b_cur);
-    load_c(kt0, c_cur);
+    load_b(kt0, b0);
+    load_c(kt0, c0);
     store_a(0, a_next);
     __syncthreads();
 
     const int a_lane_off = l31 * STRIDE + half * 16;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
+    auto step = [&](int kt, auto bufc, const BRaw<BITS> (&b_use)[KS], const CRaw& c_use, BRaw<BITS> (&b_fill)[KS], CRaw& c_fill) {
+        constexpr int BUF = decltype(bufc)::value;
         const int ktn = min(kt + 1, kt1 - 1);          // last step re-loads itself (no branch in the pipeline)
         load_a(ktn, a_next);
-        load_b(ktn, b_next);
-        load_c(ktn, c_next);
+        load_b(ktn, b_fill);
+        load_c(ktn, c_fill);
         __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of this step's MFMAs
 
         Deq<BITS, T> dq;
-        dq.setup(c_cur, p.zero_mode);
-        const char* abase = smem + (size_t)buf * (BM * STRIDE) + a_lane_off;
+        dq.setup(c_use, p.zero_mode);
+        const char* abase = smem + BUF * (BM * STRIDE) + a_lane_off;
+        if constexpr (VAR == 1) {
+            // explicit software pipeline over the KS MFMA k-steps: the fragments of ks+1 (A from LDS, B dequantised in
+            // registers) are produced while the 2*MT MFMAs of ks run; sched_barrier pins the LDS reads at the top of
+            // each region (hipcc otherwise sinks them right in front of their first use and exposes the LDS latency)
+            u32x4 a[2][MT], bq[2][2];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            u32x4 a[MT], b[2];
+            for (int mt = 0; mt < MT; ++mt) a[0][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + ks * 32);
-            const int k = kt * BK + ks * 16 + half * 8;
+            for (int nt = 0; nt < 2; ++nt) bq[0][nt] = dq.frag(b_use[0], nt, kt * BK + half * 8);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) b[nt] = dq.frag(b_cur[ks], nt, k);
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                    for (int mt = 0; mt < MT; ++mt) a[(ks + 1) & 1][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (ks + 1) * 32);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 1 < KS) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = Mma<T>::run(a[mt], b[nt], acc[mt][nt]);
+                    for (int nt = 0; nt < 2; ++nt) bq[(ks + 1) & 1][nt] = dq.frag(b_use[ks + 1], nt, kt * BK + (ks + 1) * 16 + half * 8);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = Mma<T>::run(a[ks & 1][mt], bq[ks & 1][nt], acc[mt][nt]);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                u32x4 a[MT], b[2];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + ks * 32);
+                const int k = kt * BK + ks * 16 + half * 8;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) b[nt] = dq.frag(b_use[ks], nt, k);
+                if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = Mma<T>::run(a[mt], b[nt], acc[mt][nt]);
+                if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(0);
+            }
         }
-        store_a(buf ^ 1, a_next);
+        store_a(BUF ^ 1, a_next);
         __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) b_cur[ks] = b_next[ks];
-        c_cur = c_next;
+    };
+    for (int kt = kt0; kt < kt1; kt += 2) {
+        step(kt, std::integral_constant<int, 0>{}, b0, c0, b1, c1);
+        if (kt + 1 < kt1) step(kt + 1, std::integral_constant<int, 1>{}, b1, c1, b0, c0);
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -532,7 +572,8 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     }
     pl.mt = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
     pl.bk = (L.bits == 4 && pl.mt == 4 && L.K % 64 == 0 && L.group_size % 64 == 0) ? 64 : 32;
-    if (tune && tune->reserved[1] == 32) pl.bk = 32;      // experiment knob: force the 32-deep K-step
+    if (tune && tune->reserved[1] == 32) pl.bk = 32;
+    pl.variant = tune ? tune->reserved[3] : 0;            // experiment knob: inner-loop schedule variant      // experiment knob: force the 32-deep K-step
     pl.bm = 32 * pl.mt;
     pl.bn = 256;
     pl.nbm = (M + pl.bm - 1) / pl.bm;
@@ -551,10 +592,10 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     return pl;
 }
 
-template <int BITS, typename T, int MT, int BK>
+template <int BITS, typename T, int MT, int BK, int VAR = 1>
 static hipError_t launch_one(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
     const size_t lds = (size_t)2 * (32 * MT) * (BK * 2 + 16);
-    hipLaunchKernelGGL((gemm_kernel<BITS, T, MT, BK>), dim3(pl.nbm * pl.nbn, pl.ksplit), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gemm_kernel<BITS, T, MT, BK, VAR>), dim3(pl.nbm * pl.nbn, pl.ksplit), dim3(256), lds, st, p);
     return hipGetLastError();
 }
 
@@ -580,7 +621,13 @@ template <int BITS, typename T>
 static hipError_t launch_bits(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
     if (pl.skinny) return launch_skinny<BITS, T>(pl, p, st);
     if constexpr (BITS == 4) {
-        if (pl.bk == 64) return launch_one<BITS, T, 4, 64>(pl, p, st);
+        if (pl.bk == 64) {
+            if constexpr (std::is_same_v<T, f16>) {
+                if (pl.variant == 1) return launch_one<BITS, T, 4, 64, 0>(pl, p, st);   // experiment: plain loop
+                if (pl.variant == 2) return launch_one<BITS, T, 4, 64, 2>(pl, p, st);   // experiment: plain + setprio
+            }
+            return launch_one<BITS, T, 4, 64>(pl, p, st);
+        }
     }
     switch (pl.mt) {
         case 1: return launch_one<BITS, T, 1, 32>(pl, p, st);

@@ -22,7 +22,7 @@ hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x,
 struct GemmPlan {
     bool supported, use_seq;
     bool skinny;              // weight-streaming decomposition for 8 < M <= 128 (64-column strips, waves split K)
-    int waves;
+    int waves, variant;
     int mt, bk, bm, bn;       // row tiles per wave, K-step, workgroup tile
     int nbm, nbn, ksplit, ksteps_total, ksteps_per_split;
     size_t xperm_bytes;       // permuted-x scratch for act-order layers (front of the workspace)

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 #include "gemm.hip"
 using namespace gptq;
 
@@ -51,39 +52,50 @@ int main(int argc, char** argv) {
         iota_perm<<<64, 256, 0, st>>>(perm, K);
         CK(hipStreamSynchronize(st));
         printf("== M=%d K=%d N=%d : %.2f GFLOP per launch\n", M, K, N, 2.0 * M * K * N / 1e9);
-        for (int variant = 0; variant < 5; ++variant) {
+        struct V { int id; const char* name; gptq_layer_t L; gptq_tuning_t tu; GemmPlan pl; double us; };
+        std::vector<V> vs;
+        for (int variant = 0; variant < 7; ++variant) {
             if (only_variant >= 0 && variant != only_variant) continue;
-            gptq_layer_t L{};
+            V v{}; v.id = variant; v.us = 1e30;
+            gptq_layer_t& L = v.L;
             L.K = K; L.N = N; L.bits = 4; L.group_size = 128; L.dtype = GPTQ_F16; L.zero_mode = GPTQ_ZERO_WRAP;
-            gptq_tuning_t tu{}; tu.path = 3;
-            const char* name = "default";
+            v.tu.path = 3;
+            v.name = "default";
             if (variant == 1) continue;
-            if (variant == 3) { if (M > 128) continue; tu.reserved[2] = 1; name = "forced skinny"; }
-            if (variant == 4) { if (M > 128) continue; tu.reserved[2] = 2; name = "forced tiled"; }
-            if (variant == 2) { L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; name = "act-order (x permute + qweight_seq)"; }
-            GemmPlan pl = plan_gemm(L, M, &tu);
-            if (!pl.supported) { printf("  unsupported\n"); continue; }
-            auto launch_all = [&]() {
-                for (int i = 0; i < nl; ++i) {
-                    L.qweight = qw + (size_t)i * qw_b / 4; L.qzeros = qz + (size_t)i * qz_b / 4; L.scales = sc + (size_t)i * sc_b / 2;
-                    L.qweight_seq = variant == 2 ? L.qweight : nullptr;
-                    hipError_t e = launch_gemm(L, pl, x, out, M, ws, st);
-                    if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); exit(1); }
-                }
-            };
-            launch_all();
-            hipEvent_t e0, e1;
-            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-            CK(hipStreamSynchronize(st));
-            CK(hipEventRecord(e0, st));
-            for (int r = 0; r < reps; ++r) launch_all();
-            CK(hipEventRecord(e1, st));
-            CK(hipStreamSynchronize(st));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            const double us = ms * 1e3 / (reps * nl);
-            printf("  %9.2f us  %8.1f TFLOP/s  %7.1f GB/s(w)  %-38s %s mt=%d bk=%d grid=%dx%d ksplit=%d\n", us, 2.0 * M * K * N / us / 1e6, qw_b / us / 1e3, name,
-                   pl.skinny ? "skinny" : "tiled", pl.mt, pl.bk, pl.nbm, pl.nbn, pl.ksplit);
+            if (variant == 5) { if (M < 512) continue; v.tu.reserved[3] = 1; v.name = "VAR0 plain loop"; }
+            if (variant == 6) { if (M < 512) continue; v.tu.reserved[3] = 2; v.name = "VAR2 setprio"; }
+            if (variant == 3) { if (M > 128) continue; v.tu.reserved[2] = 1; v.name = "forced skinny"; }
+            if (variant == 4) { if (M > 128) continue; v.tu.reserved[2] = 2; v.name = "forced tiled"; }
+            if (variant == 2) { L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.name = "act-order (x permute + qweight_seq)"; }
+            v.pl = plan_gemm(L, M, &v.tu);
+            if (!v.pl.supported) { printf("  unsupported\n"); continue; }
+            vs.push_back(v);
         }
+        auto launch_all = [&](V& v) {
+            for (int i = 0; i < nl; ++i) {
+                gptq_layer_t L = v.L;
+                L.qweight = qw + (size_t)i * qw_b / 4; L.qzeros = qz + (size_t)i * qz_b / 4; L.scales = sc + (size_t)i * sc_b / 2;
+                L.qweight_seq = v.id == 2 ? L.qweight : nullptr;
+                hipError_t e = launch_gemm(L, v.pl, x, out, M, ws, st);
+                if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); exit(1); }
+            }
+        };
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int w = 0; w < 20; ++w) for (auto& v : vs) launch_all(v);          // warm the clocks up
+        CK(hipStreamSynchronize(st));
+        for (int round = 0; round < 5; ++round)                                     // interleaved rounds, min per variant
+            for (auto& v : vs) {
+                CK(hipEventRecord(e0, st));
+                for (int r = 0; r < reps; ++r) launch_all(v);
+                CK(hipEventRecord(e1, st));
+                CK(hipStreamSynchronize(st));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                v.us = std::min(v.us, ms * 1e3 / (reps * nl));
+            }
+        for (auto& v : vs)
+            printf("  %9.2f us  %8.1f TFLOP/s  %7.1f GB/s(w)  %-38s %s mt=%d bk=%d grid=%dx%d ksplit=%d\n", v.us, 2.0 * M * K * N / v.us / 1e6, qw_b / v.us / 1e3, v.name,
+                   v.pl.skinny ? "skinny" : "tiled", v.pl.mt, v.pl.bk, v.pl.nbm, v.pl.nbn, v.pl.ksplit);
         CK(hipFree(qw)); CK(hipFree(qz)); CK(hipFree(sc)); CK(hipFree(x)); CK(hipFree(out)); CK(hipFree(ws)); CK(hipFree(perm));
     }
     return 0;
