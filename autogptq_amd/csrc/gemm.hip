@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
     auto step = [&](int kt, auto bufc, const BRaw<BITS> (&b_use)[KS], const CRaw& c_use, BRaw<BITS> (&b_fill)[KS], CRaw& c_fill) {
         constexpr int BUF = decltype(bufc)::value;
         const int ktn = min(kt + 1, kt1 - 1);          // last step re-loads itself (no branch in the pipeline)
-        load_a(ktn, a_next);
+        if constexpr (!(VAR >= 8 && (VAR & 2))) load_a(ktn, a_next);
         load_b(ktn, b_fill);
         load_c(ktn, c_fill);
         __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of this step's MFMAs
@@ -297,7 +297,13 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
         Deq<BITS, T> dq;
         dq.setup(c_use, p.zero_mode);
         const char* abase = smem + BUF * (BM * STRIDE) + a_lane_off;
-        if constexpr (VAR == 1) {
+        if constexpr (VAR == 1 || VAR >= 8) {
+            // (VAR >= 8: timing ablations of this schedule -- bit 0 skips the dequant math, bit 1 the x staging,
+            //  bit 2 the barrier; their results are wrong by construction and only tools/gemmlab selects them)
+            auto frag = [&](const BRaw<BITS>& r, int col, int k) -> u32x4 {
+                if constexpr (VAR >= 8 && (VAR & 1)) { const unsigned q = r.w[0][col]; return u32x4{q, q ^ 0x11111111u, q ^ 0x22222222u, q ^ 0x44444444u}; }
+                else return dq.frag(r, col, k);
+            };
             // explicit software pipeline over the KS MFMA k-steps: the fragments of ks+1 (A from LDS, B dequantised in
             // registers) are produced while the 2*MT MFMAs of ks run; sched_barrier pins the LDS reads at the top of
             // each region (hipcc otherwise sinks them right in front of their first use and exposes the LDS latency)
@@ -305,7 +311,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[0][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) bq[0][nt] = dq.frag(b_use[0], nt, kt * BK + half * 8);
+            for (int nt = 0; nt < 2; ++nt) bq[0][nt] = frag(b_use[0], nt, kt * BK + half * 8);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + 1 < KS) {
@@ -315,7 +321,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks + 1 < KS) {
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) bq[(ks + 1) & 1][nt] = dq.frag(b_use[ks + 1], nt, kt * BK + (ks + 1) * 16 + half * 8);
+                    for (int nt = 0; nt < 2; ++nt) bq[(ks + 1) & 1][nt] = frag(b_use[ks + 1], nt, kt * BK + (ks + 1) * 16 + half * 8);
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -339,8 +345,8 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
                 if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(0);
             }
         }
-        store_a(BUF ^ 1, a_next);
-        __syncthreads();
+        if constexpr (!(VAR >= 8 && (VAR & 2))) store_a(BUF ^ 1, a_next);
+        if constexpr (!(VAR >= 8 && (VAR & 4))) __syncthreads();
     };
     for (int kt = kt0; kt < kt1; kt += 2) {
         step(kt, std::integral_constant<int, 0>{}, b0, c0, b1, c1);
@@ -625,6 +631,13 @@ static hipError_t launch_bits(const GemmPlan& pl, const GemmParams& p, hipStream
             if constexpr (std::is_same_v<T, f16>) {
                 if (pl.variant == 1) return launch_one<BITS, T, 4, 64, 0>(pl, p, st);   // experiment: plain loop
                 if (pl.variant == 2) return launch_one<BITS, T, 4, 64, 2>(pl, p, st);   // experiment: plain + setprio
+#ifdef GPTQ_GEMM_ABLATIONS
+                if (pl.variant == 9) return launch_one<BITS, T, 4, 64, 9>(pl, p, st);
+                if (pl.variant == 10) return launch_one<BITS, T, 4, 64, 10>(pl, p, st);
+                if (pl.variant == 11) return launch_one<BITS, T, 4, 64, 11>(pl, p, st);
+                if (pl.variant == 12) return launch_one<BITS, T, 4, 64, 12>(pl, p, st);
+                if (pl.variant == 15) return launch_one<BITS, T, 4, 64, 15>(pl, p, st);
+#endif
             }
             return launch_one<BITS, T, 4, 64>(pl, p, st);
         }

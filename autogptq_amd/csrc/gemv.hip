@@ -478,8 +478,10 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_direct_kernel(GemvParams p) 
 // one, the 16 v_dot2 per packed word become 8 MFMAs (on a pipe that runs beside the VALU), and the scale is
 // applied once per (lane, group) to the fp32 sums instead of once per weight:
 //     out[m, n] = sum_g  s[g, n] * ( sum_{k in g} x[m, k] * (w[k, n] - z[g, n]) )      (w - z exact in fp16)
+// Occupancy: a 16-wave workgroup needs <= 64 VGPRs for two of them to share a CU (8 waves per SIMD); that is what
+// keeps the second "round" of workgroups of wide layers (N = 11008: 688 strips) from serialising behind the first.
 template <int LN, int MT, int U>
-__global__ void __launch_bounds__(1024) gemv_q4_f16_mfma_kernel(GemvParams p) {
+__global__ void __launch_bounds__(1024, ((U == 1 && MT <= 4) || (U == 2 && MT <= 2)) ? 8 : 4) gemv_q4_f16_mfma_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;
     constexpr int WR = 64 / LN, CT = LN * 4;
@@ -490,19 +492,27 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_mfma_kernel(GemvParams p) {
     const int n0 = strip * CT + cl * 4;
     const bool col_ok = n0 < p.N;
     const int nload = col_ok ? n0 : 0;
-    const int m0 = blockIdx.z * 4;
+    constexpr int RG = (MT == 8) ? 2 : 1;              // groups of 4 x rows handled per pass (MT = 8: two MFMA sets)
+    constexpr int MTR = (MT == 8) ? 4 : MT;            // rows reduced / stored per group
+    const int m0 = blockIdx.z * (4 * RG);
     const int ub = blockIdx.y * p.units_per_split;
     const int ue = min(ub + p.units_per_split, p.units_total);
     // A operand: lane i of each 4-lane group carries x row m0 + i (clamped: surplus rows are never stored)
-    const f16* __restrict__ xrow = (const f16*)p.x + (size_t)min(m0 + (lane & 3), p.M - 1) * p.K;
+    const f16* xrow[RG];
+#pragma unroll
+    for (int rg = 0; rg < RG; ++rg) xrow[rg] = (const f16*)p.x + (size_t)min(m0 + rg * 4 + (lane & 3), p.M - 1) * p.K;
     const f16* __restrict__ scales = (const f16*)p.scales;
     const int zrow_words = p.N >> 3;
     const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
     const int gshift = p.gu_shift;
 
-    f32x4 acc[4];                       // [column][row of x]
+    float acc[RG][4][MTR];              // [row group][column][row of x]: only the rows that are stored
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int m = 0; m < MTR; ++m) acc[rg][c][m] = 0.f;
 
     const int rows_per_iter = W * WR * U;
     for (int base = ub; base < ue; base += rows_per_iter) {
@@ -512,9 +522,11 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_mfma_kernel(GemvParams p) {
         const int g = min(u0, ue - 1) >> gshift;
         const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * p.N + nload);
         const unsigned zw = p.qzeros[(size_t)g * zrow_words + (nload >> 3)] >> ((nload & 7) * 4);
-        u32x4 q[U], xr[U];
+        u32x4 q[U], xr[RG][U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) xr[j] = *(const u32x4*)(xrow + (size_t)min(u0 + j, ue - 1) * 8);
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int j = 0; j < U; ++j) xr[rg][j] = *(const u32x4*)(xrow[rg] + (size_t)min(u0 + j, ue - 1) * 8);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int ul = min(u0 + j, ue - 1);
@@ -529,21 +541,28 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_mfma_kernel(GemvParams p) {
             c1[c] = as_f16x2(z * 0x00010001u + 0xE400E400u);    // -(1024+z)
             c2[c] = c1[c] + k960;                               // -(64+z)
         }
-        f32x4 accg[4];
+        f32x4 accg[RG][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) accg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) accg[rg][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             u32x4 qv = q[j];
             if (u0 + j >= ue) qv = u32x4{0u, 0u, 0u, 0u};       // tail rows: x is zeroed below, value irrelevant
-            const u32x4 t = xr[j];
             const bool live = (u0 + j < ue);
             // x slots (k0,k4,k1,k5) and (k2,k6,k3,k7): the order the magic-number unpack produces
-            u32x2 a01 = {__builtin_amdgcn_perm(t[2], t[0], 0x05040100u), __builtin_amdgcn_perm(t[2], t[0], 0x07060302u)};
-            u32x2 a23 = {__builtin_amdgcn_perm(t[3], t[1], 0x05040100u), __builtin_amdgcn_perm(t[3], t[1], 0x07060302u)};
-            if (!live) { a01 = u32x2{0u, 0u}; a23 = u32x2{0u, 0u}; }
-            const f16x4 xa01 = __builtin_bit_cast(f16x4, a01), xa23 = __builtin_bit_cast(f16x4, a23);
+            f16x4 xa01[RG], xa23[RG];
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg) {
+                const u32x4 t = xr[rg][j];
+                u32x2 a01 = {__builtin_amdgcn_perm(t[2], t[0], 0x05040100u), __builtin_amdgcn_perm(t[2], t[0], 0x07060302u)};
+                u32x2 a23 = {__builtin_amdgcn_perm(t[3], t[1], 0x05040100u), __builtin_amdgcn_perm(t[3], t[1], 0x07060302u)};
+                if (!live) { a01 = u32x2{0u, 0u}; a23 = u32x2{0u, 0u}; }
+                xa01[rg] = __builtin_bit_cast(f16x4, a01);
+                xa23[rg] = __builtin_bit_cast(f16x4, a23);
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const unsigned qw = qv[c], q8 = qw >> 8;
@@ -553,8 +572,11 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_mfma_kernel(GemvParams p) {
                 const f16x2 h3 = as_f16x2((q8 & 0x00f000f0u) | 0x64006400u) * r16 + c2[c];
                 const u32x2 b01 = {__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
                 const u32x2 b23 = {__builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
-                accg[c] = __builtin_amdgcn_mfma_f32_4x4x4f16(xa01, __builtin_bit_cast(f16x4, b01), accg[c], 0, 0, 0);
-                accg[c] = __builtin_amdgcn_mfma_f32_4x4x4f16(xa23, __builtin_bit_cast(f16x4, b23), accg[c], 0, 0, 0);
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg) {
+                    accg[rg][c] = __builtin_amdgcn_mfma_f32_4x4x4f16(xa01[rg], __builtin_bit_cast(f16x4, b01), accg[rg][c], 0, 0, 0);
+                    accg[rg][c] = __builtin_amdgcn_mfma_f32_4x4x4f16(xa23[rg], __builtin_bit_cast(f16x4, b23), accg[rg][c], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -562,33 +584,65 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_mfma_kernel(GemvParams p) {
             const unsigned sh = (c & 1) ? (sraw[c >> 1] >> 16) : (sraw[c >> 1] & 0xffffu);
             const float sc = (float)as_f16((unsigned short)sh);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[c][m] = fmaf(sc, accg[c][m], acc[c][m]);
+            for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                for (int m = 0; m < MTR; ++m) acc[rg][c][m] = fmaf(sc, accg[rg][c][m], acc[rg][c][m]);
         }
     }
     // ---- reduce: row slots by shuffles, waves through LDS (one barrier), write ---------------------
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c][m] = row_slot_sum<LN>(acc[c][m]);
+        for (int m = 0; m < MTR; ++m)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[rg][c][m] = row_slot_sum<LN>(acc[rg][c][m]);
+    constexpr int ROWS = RG * MTR;
     if (lane < LN) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            f32x4 v = {acc[0][m], acc[1][m], acc[2][m], acc[3][m]};
-            *(f32x4*)(red + (wave * MT + m) * CT + lane * 4) = v;
-        }
+        for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+            for (int m = 0; m < MTR; ++m) {
+                f32x4 v = {acc[rg][0][m], acc[rg][1][m], acc[rg][2][m], acc[rg][3][m]};
+                *(f32x4*)(red + (wave * ROWS + rg * MTR + m) * CT + lane * 4) = v;
+            }
     }
     __syncthreads();
-    for (int i = tid; i < MT * CT; i += blockDim.x) {
-        const int m = i / CT, c = i % CT;
-        const int n = strip * CT + c, row = m0 + m;
-        if (n >= p.N || row >= p.M) continue;
-        float s = 0.f;
-        for (int w = 0; w < W; ++w) s += red[(w * MT + m) * CT + c];
-        if (p.ksplit > 1) {
-            p.partial[((size_t)blockIdx.y * p.M + row) * p.N + n] = s;
-        } else {
-            if (p.bias) s += (float)((const f16*)p.bias)[n];
-            ((f16*)p.out)[(size_t)row * p.N + n] = (f16)s;
+    // final cross-wave sum.  E = ROWS * CT entries; when E <= 64 one wave does it with P = 64 / E lanes per entry
+    // (each lane adds every P-th wave's slab, then the P partial sums meet through shuffles) instead of E threads
+    // walking all W slabs one after the other.
+    constexpr int E = ROWS * CT;
+    if constexpr (E <= 64 && (E & (E - 1)) == 0) {
+        if (wave == 0) {
+            constexpr int P = 64 / E;
+            const int e = lane % E, part = lane / E;
+            float s = 0.f;
+            for (int w = part; w < W; w += P) s += red[w * E + e];
+#pragma unroll
+            for (int off = E; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
+            const int mm = e / CT, c = e % CT;                  // mm = rg * MTR + m
+            const int n = strip * CT + c, row = m0 + (mm / MTR) * 4 + (mm % MTR);
+            if (part == 0 && n < p.N && row < p.M) {
+                if (p.ksplit > 1) {
+                    p.partial[((size_t)blockIdx.y * p.M + row) * p.N + n] = s;
+                } else {
+                    if (p.bias) s += (float)((const f16*)p.bias)[n];
+                    ((f16*)p.out)[(size_t)row * p.N + n] = (f16)s;
+                }
+            }
+        }
+    } else {
+        for (int i = tid; i < E; i += blockDim.x) {
+            const int mm = i / CT, c = i % CT;
+            const int n = strip * CT + c, row = m0 + (mm / MTR) * 4 + (mm % MTR);
+            if (n >= p.N || row >= p.M) continue;
+            float s = 0.f;
+            for (int w = 0; w < W; ++w) s += red[(w * ROWS + mm) * CT + c];
+            if (p.ksplit > 1) {
+                p.partial[((size_t)blockIdx.y * p.M + row) * p.N + n] = s;
+            } else {
+                if (p.bias) s += (float)((const f16*)p.bias)[n];
+                ((f16*)p.out)[(size_t)row * p.N + n] = (f16)s;
+            }
         }
     }
 }
@@ -626,8 +680,8 @@ GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.mfma = can_direct && (path == 0 || path == 5);   // default for 4-bit fp16 layers without act-order
     pl.direct = can_direct && path == 4;
     if (pl.mfma) {                 // the matrix core handles 4 rows of x per pass, whatever M is
-        pl.mt = M >= 3 ? 4 : M;
-        pl.mtiles = (M + 3) / 4;
+        pl.mt = M >= 5 ? 8 : (M >= 3 ? 4 : M);         // 8 = two groups of 4 rows in one pass
+        pl.mtiles = M >= 5 ? (M + 7) / 8 : 1;
     } else {
         pl.mt = pick_mt(M);
         if (pl.direct && pl.mt > 4) pl.mt = 4;
@@ -841,6 +895,7 @@ hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x,
             case 1: e = launch_mfma_mt<1>(pl, p, st); break;
             case 2: e = launch_mfma_mt<2>(pl, p, st); break;
             case 4: e = launch_mfma_mt<4>(pl, p, st); break;
+            case 8: e = launch_mfma_mt<8>(pl, p, st); break;
             default: e = hipErrorInvalidValue;
         }
     } else if (pl.direct) {

@@ -253,6 +253,7 @@ def main():
     # ---- roofline of the dominant kernel: a graph holding only that layer type --------------------
     roof = None
     if rank == 0:
+      try:
         by_type = {}
         for name, K, N, q in layers:
             by_type.setdefault((K, N), []).append((name, K, N, q))
@@ -283,10 +284,17 @@ def main():
         roof["shape"] = f"K={K} N={N} M={M}"
         roof["us_per_launch_events"] = round(best["per_launch_s"] * 1e6, 3)
         roof["algorithmic_bytes_per_launch"] = algorithmic_bytes(K, N, M, act_order=act_order)
+        if prefill and act_order:
+            roof["note"] = "per-launch time includes the x column-permute launch of act-order layers (rocprof splits them: profiles/)"
+      except Exception as e:
+        roof = {"error": repr(e)[:300]}
 
     tp = None
     if world > 1 and not args.no_tp and not prefill:
-        tp = bench_tp(device, rank, world, 50)
+        try:
+            tp = bench_tp(device, rank, world, 50)
+        except Exception as e:                       # the headline line must still be printed
+            tp = {"error": repr(e)[:300]}
 
     if rank == 0:
         if prefill:

@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
         printf("== M=%d K=%d N=%d : %.2f GFLOP per launch\n", M, K, N, 2.0 * M * K * N / 1e9);
         struct V { int id; const char* name; gptq_layer_t L; gptq_tuning_t tu; GemmPlan pl; double us; };
         std::vector<V> vs;
-        for (int variant = 0; variant < 7; ++variant) {
+        for (int variant = 0; variant < 12; ++variant) {
             if (only_variant >= 0 && variant != only_variant) continue;
             V v{}; v.id = variant; v.us = 1e30;
             gptq_layer_t& L = v.L;
@@ -64,6 +64,11 @@ int main(int argc, char** argv) {
             if (variant == 1) continue;
             if (variant == 5) { if (M < 512) continue; v.tu.reserved[3] = 1; v.name = "VAR0 plain loop"; }
             if (variant == 6) { if (M < 512) continue; v.tu.reserved[3] = 2; v.name = "VAR2 setprio"; }
+            if (variant == 7) { if (M < 512) continue; v.tu.reserved[3] = 9; v.name = "ABL -dequant"; }
+            if (variant == 8) { if (M < 512) continue; v.tu.reserved[3] = 10; v.name = "ABL -xstaging"; }
+            if (variant == 9) { if (M < 512) continue; v.tu.reserved[3] = 11; v.name = "ABL -dequant -xstaging"; }
+            if (variant == 10) { if (M < 512) continue; v.tu.reserved[3] = 12; v.name = "ABL -barrier"; }
+            if (variant == 11) { if (M < 512) continue; v.tu.reserved[3] = 15; v.name = "ABL -dequant -xstaging -barrier"; }
             if (variant == 3) { if (M > 128) continue; v.tu.reserved[2] = 1; v.name = "forced skinny"; }
             if (variant == 4) { if (M > 128) continue; v.tu.reserved[2] = 2; v.name = "forced tiled"; }
             if (variant == 2) { L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.name = "act-order (x permute + qweight_seq)"; }
