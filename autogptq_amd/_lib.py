@@ -14,10 +14,11 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPTQ_MI355X_LIB", os.path.join(_HERE, "libgptq_mi355x.so"))
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 GPTQ_F16, GPTQ_BF16, GPTQ_F32 = 0, 1, 2
 ZERO_WRAP, ZERO_NOWRAP = 0, 1
+EPI_NONE, EPI_SILU_MUL = 0, 1
 
 DTYPE_ENUM = {torch.float16: GPTQ_F16, torch.bfloat16: GPTQ_BF16, torch.float32: GPTQ_F32}
 
@@ -36,6 +37,7 @@ class GptqLayer(Structure):
         ("K", c_int32), ("N", c_int32), ("bits", c_int32), ("group_size", c_int32),
         ("dtype", c_int32), ("zero_mode", c_int32),
         ("qweight_seq", c_void_p), ("perm", c_void_p),
+        ("epilogue", c_int32), ("reserved_", c_int32),
     ]
 
 

@@ -46,6 +46,10 @@ int check_layer(const gptq_layer_t* L) {
     if (L->group_size <= 0) return fail(GPTQ_ERR_SHAPE, "group_size must be > 0 (resolve -1 to in_features), got %d", L->group_size);
     if ((L->qweight_seq == nullptr) != (L->perm == nullptr))
         return fail(GPTQ_ERR_NULL, "qweight_seq and perm must be given together");
+    if (L->epilogue != GPTQ_EPI_NONE && L->epilogue != GPTQ_EPI_SILU_MUL)
+        return fail(GPTQ_ERR_UNSUPPORTED, "unknown epilogue %d", L->epilogue);
+    if (L->epilogue == GPTQ_EPI_SILU_MUL && L->N % 64)
+        return fail(GPTQ_ERR_SHAPE, "the SILU_MUL epilogue needs out_features (%d) to be a multiple of 64 ([gate | up] halves)", L->N);
     return GPTQ_OK;
 }
 
@@ -81,8 +85,22 @@ const char* gptq_status_string(int s) {
     }
 }
 
+// Unfused SILU_MUL: y[M, N] goes to the front of the workspace, the elementwise pass writes out[M, N/2].
+static size_t epi_scratch_bytes(const gptq_layer_t* L, int M) {
+    const size_t b = (size_t)M * L->N * dtype_size(L->dtype);
+    return (b + 255) / 256 * 256;
+}
+static bool fused_epilogue_ok(const gptq_layer_t* L, int M, const gptq_tuning_t* tune) {
+    return L->epilogue == GPTQ_EPI_SILU_MUL && !want_gemm(L, M, tune) && plan_gemv(*L, M, tune).pair;
+}
+
 size_t gptq_workspace_bytes_ex(const gptq_layer_t* L, int M, const gptq_tuning_t* tune) {
     if (check_layer(L) != GPTQ_OK || M <= 0) return 0;
+    if (L->epilogue != GPTQ_EPI_NONE && !fused_epilogue_ok(L, M, tune)) {
+        gptq_layer_t Lc = *L;
+        Lc.epilogue = GPTQ_EPI_NONE;
+        return epi_scratch_bytes(L, M) + gptq_workspace_bytes_ex(&Lc, M, tune);
+    }
     size_t a = plan_gemv(*L, M, tune).workspace_bytes;
     GemmPlan g = plan_gemm(*L, M, tune);
     size_t b = g.supported ? g.workspace_bytes : 0;
@@ -101,6 +119,8 @@ int gptq_gemv(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, 
         return fail(GPTQ_ERR_UNSUPPORTED, "tuning.lanes_n must be 4, 8, 16 or 64");
     if (tune && (tune->waves < 0 || tune->waves > 16)) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.waves must be 1..16");
     GemvPlan pl = plan_gemv(*L, M, tune);
+    if (L->epilogue != GPTQ_EPI_NONE && !pl.pair)
+        return fail(GPTQ_ERR_UNSUPPORTED, "this GEMV kernel has no fused epilogue; call gptq_forward[_ex], which stages y in the workspace");
     if (tune && tune->path == 5 && !pl.mfma)
         return fail(GPTQ_ERR_UNSUPPORTED, "matrix-core GEMV needs bits=4, fp16, no act-order and a power-of-two group_size >= 8");
     if (tune && tune->path == 4 && !pl.direct)
@@ -120,6 +140,8 @@ int gptq_gemm(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, 
     if (rc) return rc;
     rc = check_io(x, out, M);
     if (rc) return rc;
+    if (L->epilogue != GPTQ_EPI_NONE)
+        return fail(GPTQ_ERR_UNSUPPORTED, "the MFMA GEMM has no fused epilogue; call gptq_forward[_ex], which stages y in the workspace");
     GemmPlan pl = plan_gemm(*L, M, tune);
     if (!pl.supported)
         return fail(GPTQ_ERR_UNSUPPORTED,
@@ -136,6 +158,20 @@ int gptq_forward_ex(const gptq_layer_t* L, const void* x, void* out, int M, void
                     const gptq_tuning_t* tune) {
     int rc = check_layer(L);
     if (rc) return rc;
+    if (L->epilogue != GPTQ_EPI_NONE && !fused_epilogue_ok(L, M, tune)) {
+        rc = check_io(x, out, M);
+        if (rc) return rc;
+        const size_t yb = epi_scratch_bytes(L, M);
+        if (!ws || ws_bytes < yb)
+            return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", gptq_workspace_bytes_ex(L, M, tune), ws ? ws_bytes : (size_t)0);
+        gptq_layer_t Lc = *L;
+        Lc.epilogue = GPTQ_EPI_NONE;
+        rc = gptq_forward_ex(&Lc, x, ws, M, (char*)ws + yb, ws_bytes - yb, stream, tune);
+        if (rc) return rc;
+        hipError_t e = launch_silu_mul(ws, out, M, L->N, L->dtype, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "silu_mul launch");
+        return GPTQ_OK;
+    }
     if (want_gemm(L, M, tune)) return gptq_gemm(L, x, out, M, ws, ws_bytes, stream, tune);
     return gptq_gemv(L, x, out, M, ws, ws_bytes, stream, tune);
 }

@@ -38,6 +38,7 @@ struct GemvParams {
     int M, K, N, group_size, zero_mode;
     int units_total, units_per_split, chunk_units, ksplit;
     int gu_shift;       // log2(group_size / 8) or -1 (fast path)
+    int pair_off;       // SILU_MUL epilogue: column distance between the gate and the up half (N / 2), else 0
 };
 
 // Sum over the 64/LN row slots of a wave (lanes l, l+LN, l+2LN, ...): DPP rotates inside a 16-lane row,
@@ -480,8 +481,11 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_direct_kernel(GemvParams p) 
 //     out[m, n] = sum_g  s[g, n] * ( sum_{k in g} x[m, k] * (w[k, n] - z[g, n]) )      (w - z exact in fp16)
 // Occupancy: a 16-wave workgroup needs <= 64 VGPRs for two of them to share a CU (8 waves per SIMD); that is what
 // keeps the second "round" of workgroups of wide layers (N = 11008: 688 strips) from serialising behind the first.
-template <int LN, int MT, int U>
-__global__ void __launch_bounds__(1024, ((U == 1 && MT <= 4) || (U == 2 && MT <= 2)) ? 8 : 4) gemv_q4_f16_mfma_kernel(GemvParams p) {
+// PAIR = fused SILU_MUL epilogue: the workgroup walks K twice, once for its strip of the gate half and once for the same
+// strip of the up half (p.pair_off columns further), and writes silu(gate) * up -- one launch and no [M, N] round trip
+// for the gate/up pair of a gated MLP.
+template <int LN, int MT, int U, bool PAIR = false>
+__global__ void __launch_bounds__(1024, (!PAIR && ((U == 1 && MT <= 4) || (U == 2 && MT <= 2))) ? 8 : 4) gemv_q4_f16_mfma_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;
     constexpr int WR = 64 / LN, CT = LN * 4;
@@ -489,9 +493,11 @@ __global__ void __launch_bounds__(1024, ((U == 1 && MT <= 4) || (U == 2 && MT <=
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
     const int cl = lane % LN, rs = lane / LN;
     const int strip = xcd_remap(blockIdx.x, gridDim.x);
+    constexpr int H = PAIR ? 2 : 1;
+    const int NH = PAIR ? p.pair_off : p.N;            // output columns
     const int n0 = strip * CT + cl * 4;
-    const bool col_ok = n0 < p.N;
-    const int nload = col_ok ? n0 : 0;
+    const bool col_ok = n0 < NH;
+    const int nbase = col_ok ? n0 : 0;
     constexpr int RG = (MT == 8) ? 2 : 1;              // groups of 4 x rows handled per pass (MT = 8: two MFMA sets)
     constexpr int MTR = (MT == 8) ? 4 : MT;            // rows reduced / stored per group
     const int m0 = blockIdx.z * (4 * RG);
@@ -506,15 +512,20 @@ __global__ void __launch_bounds__(1024, ((U == 1 && MT <= 4) || (U == 2 && MT <=
     const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
     const int gshift = p.gu_shift;
 
-    float acc[RG][4][MTR];              // [row group][column][row of x]: only the rows that are stored
+    float acc[H][RG][4][MTR];           // [half][row group][column][row of x]: only the rows that are stored
 #pragma unroll
-    for (int rg = 0; rg < RG; ++rg)
+    for (int h = 0; h < H; ++h)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
-            for (int m = 0; m < MTR; ++m) acc[rg][c][m] = 0.f;
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int m = 0; m < MTR; ++m) acc[h][rg][c][m] = 0.f;
 
     const int rows_per_iter = W * WR * U;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+    const int nload = nbase + h * p.pair_off;
     for (int base = ub; base < ue; base += rows_per_iter) {
         const int u0 = base + (wave * WR + rs) * U;
         // loads return in issue order: the small L2-resident ones (scales, zeros, x) go first so that the math
@@ -586,63 +597,75 @@ __global__ void __launch_bounds__(1024, ((U == 1 && MT <= 4) || (U == 2 && MT <=
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
-                for (int m = 0; m < MTR; ++m) acc[rg][c][m] = fmaf(sc, accg[rg][c][m], acc[rg][c][m]);
+                for (int m = 0; m < MTR; ++m) acc[h][rg][c][m] = fmaf(sc, accg[rg][c][m], acc[h][rg][c][m]);
         }
+    }
     }
     // ---- reduce: row slots by shuffles, waves through LDS (one barrier), write ---------------------
 #pragma unroll
-    for (int rg = 0; rg < RG; ++rg)
-#pragma unroll
-        for (int m = 0; m < MTR; ++m)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[rg][c][m] = row_slot_sum<LN>(acc[rg][c][m]);
-    constexpr int ROWS = RG * MTR;
-    if (lane < LN) {
+    for (int h = 0; h < H; ++h)
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
-            for (int m = 0; m < MTR; ++m) {
-                f32x4 v = {acc[rg][0][m], acc[rg][1][m], acc[rg][2][m], acc[rg][3][m]};
-                *(f32x4*)(red + (wave * ROWS + rg * MTR + m) * CT + lane * 4) = v;
-            }
+            for (int m = 0; m < MTR; ++m)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[h][rg][c][m] = row_slot_sum<LN>(acc[h][rg][c][m]);
+    constexpr int ROWS = RG * MTR;
+    constexpr int E = ROWS * CT;                            // entries per half
+    if (lane < LN) {
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int rg = 0; rg < RG; ++rg)
+#pragma unroll
+                for (int m = 0; m < MTR; ++m) {
+                    f32x4 v = {acc[h][rg][0][m], acc[h][rg][1][m], acc[h][rg][2][m], acc[h][rg][3][m]};
+                    *(f32x4*)(red + ((wave * H + h) * ROWS + rg * MTR + m) * CT + lane * 4) = v;
+                }
     }
     __syncthreads();
-    // final cross-wave sum.  E = ROWS * CT entries; when E <= 64 one wave does it with P = 64 / E lanes per entry
-    // (each lane adds every P-th wave's slab, then the P partial sums meet through shuffles) instead of E threads
-    // walking all W slabs one after the other.
-    constexpr int E = ROWS * CT;
+    auto finish = [&](int e, float s0, float s1) {          // e = mm * CT + c, mm = rg * MTR + m
+        const int mm = e / CT, c = e % CT;
+        const int n = strip * CT + c, row = m0 + (mm / MTR) * 4 + (mm % MTR);
+        if (n >= NH || row >= p.M) return;
+        if constexpr (PAIR) {
+            if (p.bias) { s0 += (float)((const f16*)p.bias)[n]; s1 += (float)((const f16*)p.bias)[n + p.pair_off]; }
+            const float g = s0 / (1.f + __expf(-s0));            // silu on the fp32 sum
+            ((f16*)p.out)[(size_t)row * NH + n] = (f16)(g * s1);
+        } else if (p.ksplit > 1) {
+            p.partial[((size_t)blockIdx.y * p.M + row) * p.N + n] = s0;
+        } else {
+            if (p.bias) s0 += (float)((const f16*)p.bias)[n];
+            ((f16*)p.out)[(size_t)row * p.N + n] = (f16)s0;
+        }
+    };
+    // final cross-wave sum.  When E <= 64 one wave does it with P = 64 / E lanes per entry (each lane adds every
+    // P-th wave's slab, then the P partial sums meet through shuffles) instead of E threads walking all W slabs.
     if constexpr (E <= 64 && (E & (E - 1)) == 0) {
         if (wave == 0) {
             constexpr int P = 64 / E;
             const int e = lane % E, part = lane / E;
-            float s = 0.f;
-            for (int w = part; w < W; w += P) s += red[w * E + e];
+            float s[H];
 #pragma unroll
-            for (int off = E; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
-            const int mm = e / CT, c = e % CT;                  // mm = rg * MTR + m
-            const int n = strip * CT + c, row = m0 + (mm / MTR) * 4 + (mm % MTR);
-            if (part == 0 && n < p.N && row < p.M) {
-                if (p.ksplit > 1) {
-                    p.partial[((size_t)blockIdx.y * p.M + row) * p.N + n] = s;
-                } else {
-                    if (p.bias) s += (float)((const f16*)p.bias)[n];
-                    ((f16*)p.out)[(size_t)row * p.N + n] = (f16)s;
-                }
+            for (int h = 0; h < H; ++h) {
+                float t = 0.f;
+                for (int w = part; w < W; w += P) t += red[(w * H + h) * E + e];
+#pragma unroll
+                for (int off = E; off < 64; off <<= 1) t += __shfl_xor(t, off, 64);
+                s[h] = t;
             }
+            if (part == 0) finish(e, s[0], s[H - 1]);
         }
     } else {
-        for (int i = tid; i < E; i += blockDim.x) {
-            const int mm = i / CT, c = i % CT;
-            const int n = strip * CT + c, row = m0 + (mm / MTR) * 4 + (mm % MTR);
-            if (n >= p.N || row >= p.M) continue;
-            float s = 0.f;
-            for (int w = 0; w < W; ++w) s += red[(w * ROWS + mm) * CT + c];
-            if (p.ksplit > 1) {
-                p.partial[((size_t)blockIdx.y * p.M + row) * p.N + n] = s;
-            } else {
-                if (p.bias) s += (float)((const f16*)p.bias)[n];
-                ((f16*)p.out)[(size_t)row * p.N + n] = (f16)s;
+        for (int e = tid; e < E; e += blockDim.x) {
+            float s[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                float t = 0.f;
+                for (int w = 0; w < W; ++w) t += red[(w * H + h) * E + e];
+                s[h] = t;
             }
+            finish(e, s[0], s[H - 1]);
         }
     }
 }
@@ -663,7 +686,25 @@ __global__ void __launch_bounds__(256) gemv_reduce_kernel(const float* __restric
 // ---- host side: shape heuristic + dispatch ---------------------------------------------------
 static int pick_mt(int M) { return M >= 8 ? 8 : (M >= 4 ? 4 : (M >= 2 ? 2 : 1)); }
 
+static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* tune, int N_cols);
+
 GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
+    if (L.epilogue == GPTQ_EPI_SILU_MUL) {
+        // fused epilogue: the workgroup grid covers the N/2 output columns; only the matrix-core kernel implements it
+        GemvPlan pl = plan_gemv_n(L, M, tune, L.N / 2);
+        if (pl.mfma && pl.ksplit == 1 && pl.ln == 4 && M <= 8) {
+            pl.pair = true;
+            if (pl.u > 2) pl.u = 2;
+            pl.lds_bytes *= 2;
+            return pl;
+        }
+    }
+    GemvPlan pl = plan_gemv_n(L, M, tune, L.N);
+    pl.pair = false;
+    return pl;
+}
+
+static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* tune, int N_cols) {
     GemvPlan pl{};
     const int kpu = unit_vals(L.bits);
     const int path = tune ? tune->path : 0;
@@ -698,14 +739,14 @@ GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
         } else {
             ln = 4;   // widest strip that still gives >= 256 workgroups; else the narrowest (16 columns)
             for (int cand : {16, 8}) {
-                const int strips = (L.N + cand * 4 - 1) / (cand * 4);
+                const int strips = (N_cols + cand * 4 - 1) / (cand * 4);
                 if (strips * pl.mtiles >= 256) { ln = cand; break; }
             }
         }
     }
     pl.ln = ln;
     const int wr = 64 / ln;
-    pl.strips = (L.N + ln * 4 - 1) / (ln * 4);
+    pl.strips = (N_cols + ln * 4 - 1) / (ln * 4);
     int ks = (tune && tune->ksplit) ? tune->ksplit : 0;
     if (!ks) {
         ks = 1;
@@ -826,6 +867,15 @@ static hipError_t launch_direct_u(const GemvPlan& pl, const GemvParams& p, hipSt
 template <int LN, int MT>
 static hipError_t launch_mfma_u(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
     dim3 grid(pl.strips, pl.ksplit, pl.mtiles), block(pl.waves * 64);
+    if (pl.pair) {
+        if constexpr (LN == 4) {
+            if (pl.u == 1) hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, true>), grid, block, pl.lds_bytes, st, p);
+            else hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, true>), grid, block, pl.lds_bytes, st, p);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     switch (pl.u) {
         case 1: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1>), grid, block, pl.lds_bytes, st, p); break;
         case 2: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2>), grid, block, pl.lds_bytes, st, p); break;
@@ -882,6 +932,7 @@ hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x,
     p.out = out;
     p.partial = (float*)workspace;
     p.M = M; p.K = L.K; p.N = L.N; p.group_size = L.group_size; p.zero_mode = L.zero_mode;
+    p.pair_off = pl.pair ? L.N / 2 : 0;
     p.units_total = pl.units_total; p.units_per_split = pl.units_per_split;
     p.chunk_units = pl.chunk_units; p.ksplit = pl.ksplit;
     {

@@ -12,6 +12,7 @@ struct GemvPlan {
     bool fast, perk, use_seq;
     bool direct;   // fast path without LDS staging (x / scales / zeros straight from L2)
     bool mfma;     // direct path with the k-reduction on v_mfma_f32_4x4x4_16b_f16
+    bool pair;     // mfma path with the fused SILU_MUL epilogue (gate/up halves walked by the same workgroup)
     int u;         // direct path: consecutive packed rows per lane and iteration
     size_t lds_bytes, workspace_bytes;
 };
@@ -41,6 +42,7 @@ hipError_t launch_pack_weights(const void* W, const void* scale_in, const void* 
 hipError_t launch_pack_zeros(const void* zero_in, int G, int N, int bits, int qparam_dtype, uint32_t* qzeros_out, hipStream_t st);
 hipError_t launch_resequence(const uint32_t* qweight, const int32_t* perm, int K, int N, int bits,
                              uint32_t* out, hipStream_t st);
+hipError_t launch_silu_mul(const void* y, void* out, int M, int N, int dtype, hipStream_t st);
 hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int K, void* x_out, hipStream_t st);
 hipError_t launch_permute_columns(const void* x, const int32_t* perm, int M, int K, int dtype, void* x_out, hipStream_t st);
 

@@ -234,6 +234,32 @@ __global__ void __launch_bounds__(256) permute_columns_kernel(const T* __restric
     for (int m = blockIdx.y; m < M; m += gridDim.y) out[(size_t)m * K + i] = x[(size_t)m * K + src];
 }
 
+// out[m, n] = T( silu(y[m, n]) * y[m, n + N/2] ): the unfused form of the SILU_MUL epilogue (used after the GEMM paths
+// and the GEMV kernels that have no fused epilogue); y is the [M, N] = [gate | up] result already rounded to T, which is
+// exactly what the reference computes without its fused MLP: act_fn(gate_proj(x)) * up_proj(x).
+template <typename T>
+__global__ void __launch_bounds__(256) silu_mul_kernel(const T* __restrict__ y, T* __restrict__ out, int M, int N) {
+    const int NH = N / 2;
+    const size_t total = (size_t)M * NH;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / NH, n = i - m * NH;
+        const float g = DType<T>::to_f32(y[m * N + n]), u = DType<T>::to_f32(y[m * N + n + NH]);
+        out[i] = DType<T>::from_f32(g / (1.f + __expf(-g)) * u);
+    }
+}
+
+hipError_t launch_silu_mul(const void* y, void* out, int M, int N, int dtype, hipStream_t st) {
+    const size_t total = (size_t)M * (N / 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    switch (dtype) {
+        case GPTQ_F16: hipLaunchKernelGGL(silu_mul_kernel<f16>, dim3(blocks), dim3(256), 0, st, (const f16*)y, (f16*)out, M, N); break;
+        case GPTQ_BF16: hipLaunchKernelGGL(silu_mul_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)y, (bf16*)out, M, N); break;
+        default: hipLaunchKernelGGL(silu_mul_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)y, (float*)out, M, N);
+    }
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 #define GPTQ_BITS_SWITCH(bits, EXPR)                      \
     switch (bits) {                                       \

@@ -74,6 +74,7 @@ class QuantLinear(nn.Module):
         trainable=False,
         weight_dtype=torch.float16,
         zero_mode="auto",
+        epilogue="none",
         **kwargs,
     ):
         super().__init__()
@@ -87,6 +88,10 @@ class QuantLinear(nn.Module):
             raise ValueError(f"weight_dtype must be float16, bfloat16 or float32, got {weight_dtype}")
         if zero_mode not in ("auto", "wrap", "nowrap"):
             raise ValueError("zero_mode must be 'auto', 'wrap' or 'nowrap'")
+        if epilogue not in ("none", "silu_mul"):
+            raise ValueError("epilogue must be 'none' or 'silu_mul'")
+        if epilogue == "silu_mul" and outfeatures % 64 != 0:
+            raise ValueError("epilogue='silu_mul' needs outfeatures divisible by 64 (columns are [gate | up])")
 
         self.infeatures = infeatures
         self.outfeatures = outfeatures
@@ -97,6 +102,8 @@ class QuantLinear(nn.Module):
         self.use_cuda_fp16 = use_cuda_fp16            # accepted for make_quant compatibility; unused
         self.kernel_switch_threshold = kernel_switch_threshold
         self.zero_mode = zero_mode
+        # 'silu_mul': the layer holds [gate | up] and forward returns silu(gate(x)) * up(x), [.., outfeatures // 2]
+        self.epilogue = epilogue
 
         G = math.ceil(infeatures / self.group_size)
         self.register_buffer("qweight", torch.zeros((infeatures // 32 * bits, outfeatures), dtype=torch.int32))
@@ -190,6 +197,8 @@ class QuantLinear(nn.Module):
         L.zero_mode = self.resolved_zero_mode()
         L.qweight_seq = _lib.ptr(qweight_seq)
         L.perm = _lib.ptr(perm)
+        L.epilogue = _lib.EPI_SILU_MUL if self.epilogue == "silu_mul" else _lib.EPI_NONE
+        L.reserved_ = 0
         self._layer = L
         self._keepalive = (self.qweight, self.qzeros, self.scales, self.g_idx, self.bias, qweight_seq, perm)
         self._ws_need = {}
@@ -215,7 +224,8 @@ class QuantLinear(nn.Module):
         if self._layer is None:
             self.post_init()
         lib = _lib.load()
-        out_shape = x.shape[:-1] + (self.outfeatures,)
+        n_out = self.outfeatures // 2 if self.epilogue == "silu_mul" else self.outfeatures
+        out_shape = x.shape[:-1] + (n_out,)
         x2 = x.reshape(-1, x.shape[-1])
         if x2.shape[-1] != self.infeatures:
             raise RuntimeError(f"input has {x2.shape[-1]} features, layer expects {self.infeatures}")
@@ -228,7 +238,7 @@ class QuantLinear(nn.Module):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         M = x2.shape[0]
-        out = torch.empty((M, self.outfeatures), dtype=w_dtype, device=x2.device)
+        out = torch.empty((M, n_out), dtype=w_dtype, device=x2.device)
         if M == 0:
             return out.to(x_dtype).reshape(out_shape)
         ws_ptr, ws_bytes = self._workspace(M, x2.device, tuning)

@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define GPTQ_MI355X_ABI_VERSION 1
+#define GPTQ_MI355X_ABI_VERSION 2
 
 typedef enum gptq_status_t {
     GPTQ_OK = 0,
@@ -69,6 +69,13 @@ typedef enum gptq_dtype_t { GPTQ_F16 = 0, GPTQ_BF16 = 1, GPTQ_F32 = 2 } gptq_dty
  *   NOWRAP z =  field + 1           -- qlinear_cuda.py:262-264; also cuda_old's 3-bit branch */
 typedef enum gptq_zero_mode_t { GPTQ_ZERO_WRAP = 0, GPTQ_ZERO_NOWRAP = 1 } gptq_zero_mode_t;
 
+/* Fused epilogue of the caller.  SILU_MUL is the gate/up pair of a gated MLP stored as ONE layer
+ * whose columns are [gate | up] (the reference concatenates packed tensors along out_features the same way,
+ * fused_llama_attn.py:171-173):  out[M, N/2] = silu(y[:, :N/2]) * y[:, N/2:]  with y = x @ W (+ bias), silu and the
+ * product evaluated on the fp32 sums and rounded once -- the arithmetic of the reference's fused MLP kernel
+ * (fused_llama_mlp.py:237-239).  Needs N % 64 == 0. */
+typedef enum gptq_epilogue_t { GPTQ_EPI_NONE = 0, GPTQ_EPI_SILU_MUL = 1 } gptq_epilogue_t;
+
 /* One quantized linear layer.  POD; the caller owns every pointer and keeps it alive. */
 typedef struct gptq_layer_t {
     const uint32_t *qweight;   /* [K/32*bits, N] */
@@ -85,6 +92,8 @@ typedef struct gptq_layer_t {
      * position i, so group(i) = i / group_size. */
     const uint32_t *qweight_seq;  /* [K/32*bits, N] or NULL */
     const int32_t  *perm;         /* [K] or NULL */
+    int32_t epilogue;             /* gptq_epilogue_t; with SILU_MUL `out` is [M, N/2] */
+    int32_t reserved_;            /* must be 0 */
 } gptq_layer_t;
 
 /* Optional launch-shape override for experiments; NULL / zero fields = built-in heuristic. */

@@ -439,3 +439,53 @@ def test_direct_gemv_vs_oracle(gs, K, N, M, path):
             y = q(x.to(DEV), tuning=_tuning(path=path))
         _assert_close(y, yref, y64, torch.float16, K, f"direct zero={zm}")
         _assert_close(y, y64, y64, torch.float16, K, f"direct zero={zm} vs f64")
+
+
+# ---------------------------------------------------------------------------------- fused callers
+@pytest.mark.parametrize("M", [1, 3, 8, 20, 130])
+def test_fused_qkv_matches_separate_layers(M):
+    """q/k/v concatenated along out_features (the reference's fused attention layout) = the three layers one by one."""
+    from autogptq_amd.fused import fuse_qkv
+    K = 1024
+    Ls = [O.random_quant_layer(K, N, 4, 128, seed=40 + i, bias=True) for i, N in enumerate((512, 256, 256))]
+    mods = [_module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, 128) for L in Ls]
+    fused = fuse_qkv(*mods).to(DEV)
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(3)) - 0.5).half()
+    with torch.no_grad():
+        y = fused(x.to(DEV))
+        ys = [m(x.to(DEV)) for m in mods]
+    assert tuple(y.shape) == (M, 1024)
+    y64 = torch.cat([O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP) for L in Ls], dim=1)
+    _assert_close(y, y64, y64, torch.float16, K, "fused qkv vs f64")
+    _assert_close(y, torch.cat(ys, dim=1), y64, torch.float16, K, "fused qkv vs separate")
+
+
+@pytest.mark.parametrize("M,dtype,bits", [(1, torch.float16, 4), (2, torch.float16, 4), (4, torch.float16, 4), (7, torch.float16, 4),
+                                         (8, torch.float16, 4), (16, torch.float16, 4), (130, torch.float16, 4),
+                                         (1, torch.bfloat16, 4), (3, torch.float16, 8), (40, torch.bfloat16, 3)])
+def test_fused_gate_up_silu_mul(M, dtype, bits):
+    """silu(x @ W_gate) * (x @ W_up) from ONE layer ([gate | up] columns, epilogue='silu_mul'): the fused matrix-core GEMV
+    epilogue for 4-bit fp16 M <= 8, the staged y + elementwise pass otherwise.  Oracle: fp64 of the same expression."""
+    from autogptq_amd.fused import fuse_gate_up
+    K, N = 1024, 704                                  # 704 = 11 * 64: ragged against the 16-column strips' XCD remap
+    Lg = O.random_quant_layer(K, N, bits, 128, dtype=dtype, seed=60, bias=True)
+    Lu = O.random_quant_layer(K, N, bits, 128, dtype=dtype, seed=61, bias=True)
+    for L in (Lg, Lu):
+        L["scales"] = (L["scales"].float() * 4).to(dtype)     # gate pre-activations of order 1: silu is exercised off its linear part
+    mg = _module_from(Lg["qweight"], Lg["qzeros"], Lg["scales"], Lg["g_idx"], Lg["bias"], bits, 128)
+    mu = _module_from(Lu["qweight"], Lu["qzeros"], Lu["scales"], Lu["g_idx"], Lu["bias"], bits, 128)
+    fused = fuse_gate_up(mg, mu).to(DEV)
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(4)) - 0.5).to(dtype)
+    with torch.no_grad():
+        y = fused(x.to(DEV))
+        y2 = fused(x.to(DEV))
+    assert tuple(y.shape) == (M, N) and torch.equal(y, y2)
+    mode = O.reference_zero_mode(False, bits)
+    g64 = O.forward_f64(x, Lg["qweight"], Lg["qzeros"], Lg["scales"], Lg["g_idx"], Lg["bias"], bits, mode)
+    u64 = O.forward_f64(x, Lu["qweight"], Lu["qzeros"], Lu["scales"], Lu["g_idx"], Lu["bias"], bits, mode)
+    ref = torch.nn.functional.silu(g64) * u64
+    assert float(g64.abs().max()) > 1.0
+    rtol = {torch.float16: 4e-3, torch.bfloat16: 3e-2}[dtype]       # up to 3 roundings to T on the unfused path
+    scale = float(ref.abs().max())
+    err = (y.double().cpu() - ref).abs()
+    assert bool((err <= rtol * (ref.abs() + 0.05 * scale)).all()), float(err.max())

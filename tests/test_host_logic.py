@@ -29,8 +29,9 @@ def test_library_loads_and_exports_header_symbols():
 
 
 def test_struct_layout_matches_header():
-    # 5 pointers, 6 int32, 2 pointers  (include/gptq_mi355x.h: gptq_layer_t)
-    assert ctypes.sizeof(_lib.GptqLayer) == 5 * 8 + 6 * 4 + 2 * 8
+    # 5 pointers, 6 int32, 2 pointers, 2 int32  (include/gptq_mi355x.h: gptq_layer_t)
+    assert ctypes.sizeof(_lib.GptqLayer) == 5 * 8 + 6 * 4 + 2 * 8 + 2 * 4
+    assert _lib.GptqLayer.epilogue.offset == 80
     assert _lib.GptqLayer.qweight_seq.offset == 64
     assert ctypes.sizeof(_lib.GptqTuning) == 8 * 4
 
@@ -143,3 +144,27 @@ def test_host_pack_bit_exact(ref_case):
     q2 = QuantLinear(c.bits, c.group_size, c.K, c.N, c.lin_bias is not None, weight_dtype=c.dtype)
     q2.load_state_dict(q.state_dict())
     assert torch.equal(q2.qweight, c.qweight) and torch.equal(q2.g_idx, c.g_idx)
+
+
+def test_fuse_quant_linears_host_logic():
+    """fuse_qkv / fuse_gate_up only concatenate checkpoint tensors (CPU-checkable); the fused forward is in the GPU tests."""
+    from autogptq_amd.fused import fuse_gate_up, fuse_qkv
+
+    def mk(N, seed, act=False):
+        L = O.random_quant_layer(256, N, 4, 64, act_order=act, seed=seed, bias=True)
+        q = QuantLinear(4, 64, 256, N, True)
+        q.qweight, q.qzeros, q.scales, q.g_idx, q.bias = L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"]
+        return q
+    a, b, c = mk(128, 1), mk(64, 2), mk(64, 3)
+    f = fuse_qkv(a, b, c)
+    assert f.outfeatures == 256 and f.qweight.shape == (32, 256) and f.qzeros.shape == (4, 32) and f.scales.shape == (4, 256)
+    assert torch.equal(f.qweight[:, 128:192], b.qweight) and torch.equal(f.qzeros[:, 16:24], b.qzeros)
+    assert torch.equal(f.bias[192:], c.bias) and f.epilogue == "none"
+    g = fuse_gate_up(b, c)
+    assert g.epilogue == "silu_mul" and g.outfeatures == 128
+    with pytest.raises(ValueError, match="g_idx"):
+        fuse_qkv(a, mk(64, 4, act=True), c)
+    with pytest.raises(ValueError, match="equal width"):
+        fuse_gate_up(a, b)
+    with pytest.raises(ValueError, match="64"):
+        QuantLinear(4, 64, 256, 96, False, epilogue="silu_mul")
