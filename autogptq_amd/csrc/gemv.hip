@@ -484,8 +484,10 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_direct_kernel(GemvParams p) 
 // PAIR = fused SILU_MUL epilogue: the workgroup walks K twice, once for its strip of the gate half and once for the same
 // strip of the up half (p.pair_off columns further), and writes silu(gate) * up -- one launch and no [M, N] round trip
 // for the gate/up pair of a gated MLP.
-template <int LN, int MT, int U, bool PAIR = false>
-__global__ void __launch_bounds__(1024, (!PAIR && ((U == 1 && MT <= 4) || (U == 2 && MT <= 2))) ? 8 : 4) gemv_q4_f16_mfma_kernel(GemvParams p) {
+// PERM = act-order layer: weights come from the group-sorted copy and the 8 x values of a packed row are gathered
+// through perm[] (two 16-byte index loads + eight 2-byte gathers per row, all L2 resident) straight into slot order.
+template <int LN, int MT, int U, bool PAIR = false, bool PERM = false>
+__global__ void __launch_bounds__(1024, (!PAIR && !PERM && ((U == 1 && MT <= 4) || (U == 2 && MT <= 2))) ? 8 : 4) gemv_q4_f16_mfma_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;
     constexpr int WR = 64 / LN, CT = LN * 4;
@@ -534,10 +536,25 @@ __global__ void __launch_bounds__(1024, (!PAIR && ((U == 1 && MT <= 4) || (U == 
         const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * p.N + nload);
         const unsigned zw = p.qzeros[(size_t)g * zrow_words + (nload >> 3)] >> ((nload & 7) * 4);
         u32x4 q[U], xr[RG][U];
+        if constexpr (!PERM) {
 #pragma unroll
-        for (int rg = 0; rg < RG; ++rg)
+            for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
-            for (int j = 0; j < U; ++j) xr[rg][j] = *(const u32x4*)(xrow[rg] + (size_t)min(u0 + j, ue - 1) * 8);
+                for (int j = 0; j < U; ++j) xr[rg][j] = *(const u32x4*)(xrow[rg] + (size_t)min(u0 + j, ue - 1) * 8);
+        } else {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int* pp = p.perm + (size_t)min(u0 + j, ue - 1) * 8;
+                const u32x4 p0 = *(const u32x4*)pp, p1 = *(const u32x4*)(pp + 4);
+#pragma unroll
+                for (int rg = 0; rg < RG; ++rg) {
+                    const unsigned short* xs = (const unsigned short*)xrow[rg];
+                    // already in slot order (k0,k4)(k1,k5)(k2,k6)(k3,k7)
+                    xr[rg][j] = u32x4{(unsigned)xs[p0[0]] | ((unsigned)xs[p1[0]] << 16), (unsigned)xs[p0[1]] | ((unsigned)xs[p1[1]] << 16),
+                                      (unsigned)xs[p0[2]] | ((unsigned)xs[p1[2]] << 16), (unsigned)xs[p0[3]] | ((unsigned)xs[p1[3]] << 16)};
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int ul = min(u0 + j, ue - 1);
@@ -568,8 +585,14 @@ __global__ void __launch_bounds__(1024, (!PAIR && ((U == 1 && MT <= 4) || (U == 
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) {
                 const u32x4 t = xr[rg][j];
-                u32x2 a01 = {__builtin_amdgcn_perm(t[2], t[0], 0x05040100u), __builtin_amdgcn_perm(t[2], t[0], 0x07060302u)};
-                u32x2 a23 = {__builtin_amdgcn_perm(t[3], t[1], 0x05040100u), __builtin_amdgcn_perm(t[3], t[1], 0x07060302u)};
+                u32x2 a01, a23;
+                if constexpr (PERM) {
+                    a01 = u32x2{t[0], t[1]};
+                    a23 = u32x2{t[2], t[3]};
+                } else {
+                    a01 = u32x2{__builtin_amdgcn_perm(t[2], t[0], 0x05040100u), __builtin_amdgcn_perm(t[2], t[0], 0x07060302u)};
+                    a23 = u32x2{__builtin_amdgcn_perm(t[3], t[1], 0x05040100u), __builtin_amdgcn_perm(t[3], t[1], 0x07060302u)};
+                }
                 if (!live) { a01 = u32x2{0u, 0u}; a23 = u32x2{0u, 0u}; }
                 xa01[rg] = __builtin_bit_cast(f16x4, a01);
                 xa23[rg] = __builtin_bit_cast(f16x4, a23);
@@ -717,9 +740,11 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     if (path == 1) pl.fast = false;
     // register-direct variants (no LDS staging): power-of-two packed rows per group, no x gather
     const int gu = L.group_size / 8;
-    const bool can_direct = pl.fast && !pl.use_seq && gu > 0 && (gu & (gu - 1)) == 0;
-    pl.mfma = can_direct && (path == 0 || path == 5);   // default for 4-bit fp16 layers without act-order
-    pl.direct = can_direct && path == 4;
+    const bool pow2_groups = pl.fast && gu > 0 && (gu & (gu - 1)) == 0;
+    const bool ln_ok = !(tune && tune->lanes_n && tune->lanes_n != 4);
+    // default for 4-bit fp16 layers; act-order layers (x gathered through perm) only with 16-column strips
+    pl.mfma = pow2_groups && (path == 0 || path == 5) && (!pl.use_seq || ln_ok);
+    pl.direct = pow2_groups && !pl.use_seq && path == 4;
     if (pl.mfma) {                 // the matrix core handles 4 rows of x per pass, whatever M is
         pl.mt = M >= 5 ? 8 : (M >= 3 ? 4 : M);         // 8 = two groups of 4 rows in one pass
         pl.mtiles = M >= 5 ? (M + 7) / 8 : 1;
@@ -771,7 +796,7 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
         const int per_lane = (pl.units_per_split + rows_per_iter - 1) / rows_per_iter;
         const int want = pl.units_per_split >= 1024 ? 1 : 2;       // long K: more, shorter iterations pipeline better
         int u = 1;
-        while (u * 2 <= per_lane && u * 2 <= gu && u * 2 <= 8 && (pl.mfma || u * 2 * pl.mt <= 8) &&
+        while (u * 2 <= per_lane && u * 2 <= gu && u * 2 <= (pl.use_seq ? 2 : 8) && (pl.mfma || u * 2 * pl.mt <= 8) &&
                pl.units_per_split % (u * 2) == 0 && (tune && tune->reserved[0] > 0 ? u * 2 <= tune->reserved[0] : u * 2 <= want))
             u *= 2;
         pl.u = u;
@@ -867,6 +892,20 @@ static hipError_t launch_direct_u(const GemvPlan& pl, const GemvParams& p, hipSt
 template <int LN, int MT>
 static hipError_t launch_mfma_u(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
     dim3 grid(pl.strips, pl.ksplit, pl.mtiles), block(pl.waves * 64);
+    if (pl.use_seq) {
+        if constexpr (LN == 4) {
+            if (pl.pair) {
+                if (pl.u == 1) hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, true, true>), grid, block, pl.lds_bytes, st, p);
+                else hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, true, true>), grid, block, pl.lds_bytes, st, p);
+            } else {
+                if (pl.u == 1) hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, false, true>), grid, block, pl.lds_bytes, st, p);
+                else hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, false, true>), grid, block, pl.lds_bytes, st, p);
+            }
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if (pl.pair) {
         if constexpr (LN == 4) {
             if (pl.u == 1) hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, true>), grid, block, pl.lds_bytes, st, p);

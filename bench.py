@@ -79,6 +79,40 @@ def build_stack(device, n_blocks, M, act_order, dtype=torch.float16):
     return layers, xs
 
 
+def make_fused_block(device, seed):
+    """The same Llama-7B block as four launches: [q|k|v] (4096 -> 12288), o, [gate|up] with the SiLU*mul epilogue
+    (4096 -> 22016, output 11008) and down -- the reference's fused attention / fused MLP callers."""
+    import autogptq_amd
+
+    def mk(K, N, epilogue, sd):
+        g = torch.Generator(device=device).manual_seed(sd)
+        q = autogptq_amd.QuantLinear(4, 128, K, N, False, epilogue=epilogue)
+        G = K // 128
+        q.qweight = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int64, device=device, generator=g).to(torch.int32)
+        q.qzeros = torch.randint(-2**31, 2**31 - 1, (G, N // 8), dtype=torch.int64, device=device, generator=g).to(torch.int32)
+        q.scales = (0.002 * (1 + 0.1 * torch.rand(G, N, device=device, generator=g))).half()
+        q = q.to(device)
+        q.post_init()
+        return q
+    return [("qkv", 4096, 12288, mk(4096, 12288, "none", seed)), ("o", 4096, 4096, mk(4096, 4096, "none", seed + 1)),
+            ("gate_up", 4096, 22016, mk(4096, 22016, "silu_mul", seed + 2)), ("down", 11008, 4096, mk(11008, 4096, "none", seed + 3))]
+
+
+def bench_fused(device, n_blocks, steps):
+    layers = []
+    for b in range(n_blocks):
+        layers += make_fused_block(device, 1000 + 8 * b)
+    xs = {K: (torch.rand(1, K, device=device) - 0.5).half() for K in (4096, 11008)}
+    g, outs = capture(layers, xs, device)
+    for _ in range(5):
+        g.replay()
+    wall, ev = time_graph(g, steps, device)
+    bytes_step = sum(algorithmic_bytes(K, N, 1) for _, K, N, _ in layers)
+    return {"launches_per_step": len(layers), "ms_per_step": round(1e3 * ev / steps, 4), "GB_per_s": round(bytes_step * steps / ev / 1e9, 1),
+            "tokens_per_s": round(steps / ev, 1),
+            "note": "same weights volume as the headline run, 4 launches per block: [q|k|v], o, [gate|up]+SiLU*mul epilogue, down"}
+
+
 def capture(layers, xs, device):
     """Capture one forward of every layer into a graph; returns (graph, keepalive outputs)."""
     from autogptq_amd.qlinear_mi355x import reserve_workspace
@@ -214,6 +248,7 @@ def main():
     ap.add_argument("--m", type=int, default=0, help="rows per step (default 1 for decode, 2048 for prefill)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tp", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="skip the extra fused-callers measurement (decode, 1 GPU only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -319,6 +354,13 @@ def main():
         }
         if tp is not None:
             out["tp"] = tp
+        if not prefill and world == 1 and not args.no_fused:
+            try:
+                del g, outs, layers
+                torch.cuda.empty_cache()
+                out["fused_callers"] = bench_fused(device, n_blocks, args.steps)
+            except Exception as e:
+                out["fused_callers"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(1 if not prefill else 16, act_order)
         print(json.dumps(out))

@@ -460,16 +460,18 @@ def test_fused_qkv_matches_separate_layers(M):
     _assert_close(y, torch.cat(ys, dim=1), y64, torch.float16, K, "fused qkv vs separate")
 
 
+@pytest.mark.parametrize("act", [False, True])
 @pytest.mark.parametrize("M,dtype,bits", [(1, torch.float16, 4), (2, torch.float16, 4), (4, torch.float16, 4), (7, torch.float16, 4),
                                          (8, torch.float16, 4), (16, torch.float16, 4), (130, torch.float16, 4),
                                          (1, torch.bfloat16, 4), (3, torch.float16, 8), (40, torch.bfloat16, 3)])
-def test_fused_gate_up_silu_mul(M, dtype, bits):
+def test_fused_gate_up_silu_mul(M, dtype, bits, act):
     """silu(x @ W_gate) * (x @ W_up) from ONE layer ([gate | up] columns, epilogue='silu_mul'): the fused matrix-core GEMV
     epilogue for 4-bit fp16 M <= 8, the staged y + elementwise pass otherwise.  Oracle: fp64 of the same expression."""
     from autogptq_amd.fused import fuse_gate_up
     K, N = 1024, 704                                  # 704 = 11 * 64: ragged against the 16-column strips' XCD remap
-    Lg = O.random_quant_layer(K, N, bits, 128, dtype=dtype, seed=60, bias=True)
-    Lu = O.random_quant_layer(K, N, bits, 128, dtype=dtype, seed=61, bias=True)
+    Lg = O.random_quant_layer(K, N, bits, 128, dtype=dtype, seed=60, bias=True, act_order=act)
+    Lu = O.random_quant_layer(K, N, bits, 128, dtype=dtype, seed=61, bias=True, act_order=act)
+    Lu["g_idx"] = Lg["g_idx"].clone()                 # a fused pair shares its input permutation
     for L in (Lg, Lu):
         L["scales"] = (L["scales"].float() * 4).to(dtype)     # gate pre-activations of order 1: silu is exercised off its linear part
     mg = _module_from(Lg["qweight"], Lg["qzeros"], Lg["scales"], Lg["g_idx"], Lg["bias"], bits, 128)
@@ -480,7 +482,7 @@ def test_fused_gate_up_silu_mul(M, dtype, bits):
         y = fused(x.to(DEV))
         y2 = fused(x.to(DEV))
     assert tuple(y.shape) == (M, N) and torch.equal(y, y2)
-    mode = O.reference_zero_mode(False, bits)
+    mode = O.reference_zero_mode(act, bits)
     g64 = O.forward_f64(x, Lg["qweight"], Lg["qzeros"], Lg["scales"], Lg["g_idx"], Lg["bias"], bits, mode)
     u64 = O.forward_f64(x, Lu["qweight"], Lu["qzeros"], Lu["scales"], Lu["g_idx"], Lu["bias"], bits, mode)
     ref = torch.nn.functional.silu(g64) * u64
