@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_direct_kernel(GemvParams p) 
 // PERM = act-order layer: weights come from the group-sorted copy and the 8 x values of a packed row are gathered
 // through perm[] (two 16-byte index loads + eight 2-byte gathers per row, all L2 resident) straight into slot order.
 template <int LN, int MT, int U, bool PAIR = false, bool PERM = false>
-__global__ void __launch_bounds__(1024, (!PAIR && !PERM && ((U == 1 && MT <= 4) || (U == 2 && MT <= 2))) ? 8 : 4) gemv_q4_f16_mfma_kernel(GemvParams p) {
+__global__ void __launch_bounds__(1024, (!PAIR && (!PERM || MT == 1) && ((U == 1 && MT <= 4) || (U == 2 && MT <= 2))) ? 8 : 4) gemv_q4_f16_mfma_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;
     constexpr int WR = 64 / LN, CT = LN * 4;
@@ -525,6 +525,22 @@ __global__ void __launch_bounds__(1024, (!PAIR && !PERM && ((U == 1 && MT <= 4) 
                 for (int m = 0; m < MTR; ++m) acc[h][rg][c][m] = 0.f;
 
     const int rows_per_iter = W * WR * U;
+    // act-order, M = 1: the whole x row (perm[] points anywhere in [0, K)) goes to LDS first -- coalesced 16-byte loads
+    // issued before anything else, so they return first; the per-row gather through perm[] then runs on the LDS (a 2-byte
+    // gather from global costs the texture path about one address per cycle: 11008 cycles for K = 11008, as long as the
+    // whole weight stream)
+    constexpr bool XLDS = PERM && MT == 1 && LN == 4;
+    constexpr int NXST = XLDS ? 4 : 1;                     // staging loads per thread: up to 4 x 1024 x 8 = 32768 values
+    unsigned short* xlds = (unsigned short*)(smem + (size_t)W * H * (RG * MTR) * CT * sizeof(float));
+    u32x4 xst[NXST];
+    if constexpr (XLDS) {
+#pragma unroll
+        for (int v = 0; v < NXST; ++v) {
+            const int kk = (v * (int)blockDim.x + tid) * 8;
+            xst[v] = *(const u32x4*)(xrow[0] + min(kk, p.K - 8));
+        }
+    }
+    bool x_staged = false;
 #pragma unroll
     for (int h = 0; h < H; ++h) {
     const int nload = nbase + h * p.pair_off;
@@ -536,16 +552,75 @@ __global__ void __launch_bounds__(1024, (!PAIR && !PERM && ((U == 1 && MT <= 4) 
         const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * p.N + nload);
         const unsigned zw = p.qzeros[(size_t)g * zrow_words + (nload >> 3)] >> ((nload & 7) * 4);
         u32x4 q[U], xr[RG][U];
+        auto load_q = [&]() {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int ul = min(u0 + j, ue - 1);
+                q[j] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)ul * p.N + nload));
+            }
+        };
+        // act-order: the x gathers depend on the perm[] loads, so the weight loads are issued in between (they must
+        // not wait behind that dependency); otherwise x first (see above)
         if constexpr (!PERM) {
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
                 for (int j = 0; j < U; ++j) xr[rg][j] = *(const u32x4*)(xrow[rg] + (size_t)min(u0 + j, ue - 1) * 8);
+        } else if constexpr (MT == 1 && LN == 4) {
+            // M = 1: the wave gathers its WR*U = 16*U consecutive packed rows cooperatively -- every lane fetches the
+            // 2*U consecutive x values at flat offset lane*2U of the window through perm (U/2 index loads + 2U two-byte
+            // gathers instead of 10 loads per row), then each row pulls its four dwords from their owner lanes with
+            // ds_bpermute.  The weight loads are issued between the index loads and the gathers that depend on them.
+            constexpr int VPL = 2 * U;                                    // x values gathered per lane (U dwords)
+            const int wrow0 = base + wave * WR * U;                       // first packed row of this wave's window
+            const int flat = min(wrow0 * 8 + lane * VPL, ue * 8 - VPL);   // clamped: tail rows are masked by `live`
+            int pi[VPL];
+            if constexpr (U == 1) {
+                const u32x2 t = *(const u32x2*)(p.perm + flat);
+                pi[0] = (int)t[0]; pi[1] = (int)t[1];
+            } else {
+#pragma unroll
+                for (int v = 0; v < VPL / 4; ++v) {
+                    const u32x4 t = *(const u32x4*)(p.perm + flat + 4 * v);
+                    pi[4 * v] = (int)t[0]; pi[4 * v + 1] = (int)t[1]; pi[4 * v + 2] = (int)t[2]; pi[4 * v + 3] = (int)t[3];
+                }
+            }
+            load_q();
+            if (!x_staged) {                                              // first iteration only (uniform)
+#pragma unroll
+                for (int v = 0; v < NXST; ++v) {
+                    const int kk = (v * (int)blockDim.x + tid) * 8;
+                    if (kk < p.K) *(u32x4*)(xlds + kk) = xst[v];
+                }
+                __syncthreads();
+                x_staged = true;
+            }
+            unsigned mine[U];
+#pragma unroll
+            for (int v = 0; v < U; ++v) mine[v] = (unsigned)xlds[pi[2 * v]] | ((unsigned)xlds[pi[2 * v + 1]] << 16);
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int r = rs * U + j;                                 // row inside the window (0 .. 16*U-1)
+                u32x4 t;
+#pragma unroll
+                for (int d = 0; d < 4; ++d)                               // dword d of row r = x[2d], x[2d+1]: flat dword r*4+d
+                    t[d] = (unsigned)__builtin_amdgcn_ds_bpermute(((r * 4 + d) / U) * 4, (int)mine[(j * 4 + d) % U]);
+                // natural (x0,x1)(x2,x3)(x4,x5)(x6,x7) -> slot order
+                xr[0][j] = u32x4{__builtin_amdgcn_perm(t[2], t[0], 0x05040100u), __builtin_amdgcn_perm(t[2], t[0], 0x07060302u),
+                                 __builtin_amdgcn_perm(t[3], t[1], 0x05040100u), __builtin_amdgcn_perm(t[3], t[1], 0x07060302u)};
+            }
         } else {
+            u32x4 pidx[U][2];
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 const int* pp = p.perm + (size_t)min(u0 + j, ue - 1) * 8;
-                const u32x4 p0 = *(const u32x4*)pp, p1 = *(const u32x4*)(pp + 4);
+                pidx[j][0] = *(const u32x4*)pp;
+                pidx[j][1] = *(const u32x4*)(pp + 4);
+            }
+            load_q();
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const u32x4 p0 = pidx[j][0], p1 = pidx[j][1];
 #pragma unroll
                 for (int rg = 0; rg < RG; ++rg) {
                     const unsigned short* xs = (const unsigned short*)xrow[rg];
@@ -555,11 +630,7 @@ __global__ void __launch_bounds__(1024, (!PAIR && !PERM && ((U == 1 && MT <= 4) 
                 }
             }
         }
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int ul = min(u0 + j, ue - 1);
-            q[j] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)ul * p.N + nload));
-        }
+        if constexpr (!PERM) load_q();
 
         f16x2 c1[4], c2[4];
         const f16x2 k960 = {(f16)960.f, (f16)960.f};
@@ -743,7 +814,7 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     const bool pow2_groups = pl.fast && gu > 0 && (gu & (gu - 1)) == 0;
     const bool ln_ok = !(tune && tune->lanes_n && tune->lanes_n != 4);
     // default for 4-bit fp16 layers; act-order layers (x gathered through perm) only with 16-column strips
-    pl.mfma = pow2_groups && (path == 0 || path == 5) && (!pl.use_seq || ln_ok);
+    pl.mfma = pow2_groups && (path == 0 || path == 5) && (!pl.use_seq || (ln_ok && L.K <= 24576));
     pl.direct = pow2_groups && !pl.use_seq && path == 4;
     if (pl.mfma) {                 // the matrix core handles 4 rows of x per pass, whatever M is
         pl.mt = M >= 5 ? 8 : (M >= 3 ? 4 : M);         // 8 = two groups of 4 rows in one pass
@@ -794,14 +865,17 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     if (pl.mfma || pl.direct) {
         // consecutive packed rows per lane and iteration: same group, so one (scales, zeros) fetch serves them
         const int per_lane = (pl.units_per_split + rows_per_iter - 1) / rows_per_iter;
-        const int want = pl.units_per_split >= 1024 ? 1 : 2;       // long K: more, shorter iterations pipeline better
+        int want = pl.units_per_split >= 1024 ? 1 : 2;             // long K: more, shorter iterations pipeline better
+        if (pl.use_seq) want = (M == 1 && !(L.epilogue == GPTQ_EPI_SILU_MUL)) ? 8 : 2;   // act-order: the x gather is a dependent
+                                                                    // round trip per iteration -> as few iterations as possible
         int u = 1;
-        while (u * 2 <= per_lane && u * 2 <= gu && u * 2 <= (pl.use_seq ? 2 : 8) && (pl.mfma || u * 2 * pl.mt <= 8) &&
+        while (u * 2 <= per_lane && u * 2 <= gu && u * 2 <= 8 && (pl.mfma || u * 2 * pl.mt <= 8) &&
                pl.units_per_split % (u * 2) == 0 && (tune && tune->reserved[0] > 0 ? u * 2 <= tune->reserved[0] : u * 2 <= want))
             u *= 2;
         pl.u = u;
         pl.chunk_units = pl.units_per_split;
         pl.lds_bytes = rbytes;
+        if (pl.mfma && pl.use_seq && pl.mt == 1) pl.lds_bytes += (size_t)L.K * 2;   // whole x row for the LDS gather
         return pl;
     }
     // LDS-staged kernels: x tile (+ for the fast path the per-group constants) per K-chunk, kept <= 64 KiB
@@ -897,9 +971,14 @@ static hipError_t launch_mfma_u(const GemvPlan& pl, const GemvParams& p, hipStre
             if (pl.pair) {
                 if (pl.u == 1) hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, true, true>), grid, block, pl.lds_bytes, st, p);
                 else hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, true, true>), grid, block, pl.lds_bytes, st, p);
+            } else if (pl.u == 1) {
+                hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, false, true>), grid, block, pl.lds_bytes, st, p);
+            } else if (pl.u == 2) {
+                hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, false, true>), grid, block, pl.lds_bytes, st, p);
+            } else if (pl.u == 4) {
+                hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 4, false, true>), grid, block, pl.lds_bytes, st, p);
             } else {
-                if (pl.u == 1) hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, false, true>), grid, block, pl.lds_bytes, st, p);
-                else hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, false, true>), grid, block, pl.lds_bytes, st, p);
+                hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 8, false, true>), grid, block, pl.lds_bytes, st, p);
             }
             return hipGetLastError();
         } else {
