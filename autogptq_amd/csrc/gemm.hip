@@ -190,11 +190,17 @@ template <> struct Deq<4, f16> {
 // scheduled by hipcc, 2 = plain + s_setprio around the MFMA groups.  Within-run A/B on MI355X (tools/gemmlab, min of 3
 // rounds, TFLOP/s at M=2048 4096^2 / M=4096 4096^2 / 4096x11008 / 11008x4096): VAR1 793/1002/908/889, VAR0 678/990/888/840,
 // VAR2 743/972/852/815.  (Also tried: 8 waves per workgroup, one column of each pair per wave -- slower everywhere.)
-template <int BITS, typename T, int MT, int BK, int VAR = 1>
+// XPRE: x already arrives in k-slot order (act-order layers: the column-permute pre-pass writes it that way).
+// GLDS (needs XPRE, BK = 64): x goes global -> LDS by DMA (global_load_lds_dwordx4): no VGPR round trip, no ds_write, no
+// v_perm.  The LDS image of a wave's 64 lanes is linear (8 rows x 128 B), so rows are unpadded and the bank spread comes
+// from an XOR swizzle applied to the SOURCE chunk: LDS slot s of row r holds k-chunk s ^ ((r >> 1) & 7); the A-fragment
+// reads apply the same XOR (16 distinct 16-byte units per ds_read_b128 lane group -> conflict free).
+template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, bool GLDS = false>
 __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
     constexpr int KS = BK / 16;                // MFMA k-steps per K-step
     constexpr int BM = 32 * MT;
-    constexpr int STRIDE = BK * 2 + 16;        // bytes per LDS row of x (padded)
+    static_assert(!GLDS || (XPRE && BK == 64), "the DMA staging needs pre-slotted x and 128-byte rows");
+    constexpr int STRIDE = GLDS ? BK * 2 : BK * 2 + 16;   // bytes per LDS row of x (padded unless DMA-staged)
     constexpr int CPR = BK / 8;                // 16-byte chunks per row
     constexpr int CHUNKS = BM * CPR;
     constexpr int NTHR = 256;
@@ -240,8 +246,18 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
         const int c = tid + i * NTHR;
         a_row[i] = c / CPR;
         a_kc[i] = c - a_row[i] * CPR;
-        a_src[i] = x + (size_t)min(m0 + a_row[i], p.M - 1) * p.K + a_kc[i] * 8;
+        const int src_kc = GLDS ? (a_kc[i] ^ ((a_row[i] >> 1) & 7)) : a_kc[i];
+        a_src[i] = x + (size_t)min(m0 + a_row[i], p.M - 1) * p.K + src_kc * 8;
     }
+    // DMA: instruction i of wave w fills LDS chunks [(i*4 + w)*64, +64) = 1 KiB, lane l -> chunk base + l (= tid + i*256)
+    auto dma_a = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            char* dst = smem + (size_t)buf * (BM * STRIDE) + (size_t)(i * NTHR + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (size_t)kt * BK),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
     auto load_a = [&](int kt, u32x4 (&r)[NCH]) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) r[i] = *(const u32x4*)(a_src[i] + (size_t)kt * BK);
@@ -252,10 +268,14 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
             if (CHUNKS % NTHR != 0 && tid + i * NTHR >= CHUNKS) continue;
             // (x0,x1)(x2,x3)(x4,x5)(x6,x7) -> (x0,x4)(x1,x5)(x2,x6)(x3,x7): the slot order of the B fragments
             u32x4 o;
-            o[0] = __builtin_amdgcn_perm(r[i][2], r[i][0], 0x05040100u);
-            o[1] = __builtin_amdgcn_perm(r[i][2], r[i][0], 0x07060302u);
-            o[2] = __builtin_amdgcn_perm(r[i][3], r[i][1], 0x05040100u);
-            o[3] = __builtin_amdgcn_perm(r[i][3], r[i][1], 0x07060302u);
+            if constexpr (XPRE) {
+                o = r[i];
+            } else {
+                o[0] = __builtin_amdgcn_perm(r[i][2], r[i][0], 0x05040100u);
+                o[1] = __builtin_amdgcn_perm(r[i][2], r[i][0], 0x07060302u);
+                o[2] = __builtin_amdgcn_perm(r[i][3], r[i][1], 0x05040100u);
+                o[3] = __builtin_amdgcn_perm(r[i][3], r[i][1], 0x07060302u);
+            }
             *(u32x4*)(smem + (size_t)buf * (BM * STRIDE) + a_row[i] * STRIDE + a_kc[i] * 16) = o;
         }
     };
@@ -279,17 +299,19 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
     u32x4 a_next[NCH];
     BRaw<BITS> b0[KS], b1[KS];
     CRaw c0, c1;
-    load_a(kt0, a_next);
+    if constexpr (GLDS) dma_a(kt0, 0); else load_a(kt0, a_next);
     load_b(kt0, b0);
     load_c(kt0, c0);
-    store_a(0, a_next);
+    if constexpr (!GLDS) store_a(0, a_next);
     __syncthreads();
 
-    const int a_lane_off = l31 * STRIDE + half * 16;
+    const int a_lane_off = GLDS ? l31 * STRIDE : l31 * STRIDE + half * 16;
+    const int a_swz = (l31 >> 1) & 7;                  // GLDS: XOR applied to the 16-byte slot index
     auto step = [&](int kt, auto bufc, const BRaw<BITS> (&b_use)[KS], const CRaw& c_use, BRaw<BITS> (&b_fill)[KS], CRaw& c_fill) {
         constexpr int BUF = decltype(bufc)::value;
         const int ktn = min(kt + 1, kt1 - 1);          // last step re-loads itself (no branch in the pipeline)
-        if constexpr (!(VAR >= 8 && (VAR & 2))) load_a(ktn, a_next);
+        if constexpr (GLDS) dma_a(ktn, BUF ^ 1);
+        else if constexpr (!(VAR >= 8 && (VAR & 2))) load_a(ktn, a_next);
         load_b(ktn, b_fill);
         load_c(ktn, c_fill);
         __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of this step's MFMAs
@@ -309,14 +331,15 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
             // each region (hipcc otherwise sinks them right in front of their first use and exposes the LDS latency)
             u32x4 a[2][MT], bq[2][2];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[0][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE);
+            for (int mt = 0; mt < MT; ++mt) a[0][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (GLDS ? ((half ^ a_swz) * 16) : 0));
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) bq[0][nt] = frag(b_use[0], nt, kt * BK + half * 8);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + 1 < KS) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) a[(ks + 1) & 1][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (ks + 1) * 32);
+                    for (int mt = 0; mt < MT; ++mt)
+                        a[(ks + 1) & 1][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (GLDS ? ((((ks + 1) * 2 + half) ^ a_swz) * 16) : (ks + 1) * 32));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks + 1 < KS) {
@@ -333,7 +356,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
             for (int ks = 0; ks < KS; ++ks) {
                 u32x4 a[MT], b[2];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a[mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + ks * 32);
+                for (int mt = 0; mt < MT; ++mt) a[mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (GLDS ? (((ks * 2 + half) ^ a_swz) * 16) : ks * 32));
                 const int k = kt * BK + ks * 16 + half * 8;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) b[nt] = dq.frag(b_use[ks], nt, k);
@@ -345,7 +368,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
                 if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(0);
             }
         }
-        if constexpr (!(VAR >= 8 && (VAR & 2))) store_a(BUF ^ 1, a_next);
+        if constexpr (!GLDS && !(VAR >= 8 && (VAR & 2))) store_a(BUF ^ 1, a_next);
         if constexpr (!(VAR >= 8 && (VAR & 4))) __syncthreads();
     };
     for (int kt = kt0; kt < kt1; kt += 2) {
@@ -512,6 +535,9 @@ __global__ void __launch_bounds__(256) gemm_reduce_kernel(const float* __restric
 
 // x_out[m, i] = x[m, perm[i]] for 2-byte elements: one row per workgroup pass, the row staged in LDS
 // (coalesced 16-byte loads and stores; the gather itself runs on the LDS).
+// SLOT: each 8-chunk is written in the k-slot order of the 4-bit fp16 B fragments (k0,k4,k1,k5,k2,k6,k3,k7), so the tiled
+// GEMM can copy it to LDS verbatim (no v_perm in its K loop).
+template <bool SLOT>
 __global__ void __launch_bounds__(256) permute_rows_kernel(const unsigned short* __restrict__ x, const int* __restrict__ perm,
                                                            int M, int K, unsigned short* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -522,20 +548,31 @@ __global__ void __launch_bounds__(256) permute_rows_kernel(const unsigned short*
         for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
             const u32x4 p0 = *(const u32x4*)(perm + i), p1 = *(const u32x4*)(perm + i + 4);
             u32x4 o;
-            o[0] = (unsigned)row[p0[0]] | ((unsigned)row[p0[1]] << 16);
-            o[1] = (unsigned)row[p0[2]] | ((unsigned)row[p0[3]] << 16);
-            o[2] = (unsigned)row[p1[0]] | ((unsigned)row[p1[1]] << 16);
-            o[3] = (unsigned)row[p1[2]] | ((unsigned)row[p1[3]] << 16);
+            if constexpr (SLOT) {
+                o[0] = (unsigned)row[p0[0]] | ((unsigned)row[p1[0]] << 16);
+                o[1] = (unsigned)row[p0[1]] | ((unsigned)row[p1[1]] << 16);
+                o[2] = (unsigned)row[p0[2]] | ((unsigned)row[p1[2]] << 16);
+                o[3] = (unsigned)row[p0[3]] | ((unsigned)row[p1[3]] << 16);
+            } else {
+                o[0] = (unsigned)row[p0[0]] | ((unsigned)row[p0[1]] << 16);
+                o[1] = (unsigned)row[p0[2]] | ((unsigned)row[p0[3]] << 16);
+                o[2] = (unsigned)row[p1[0]] | ((unsigned)row[p1[1]] << 16);
+                o[3] = (unsigned)row[p1[2]] | ((unsigned)row[p1[3]] << 16);
+            }
             *(u32x4*)(out + (size_t)m * K + i) = o;
         }
         __syncthreads();
     }
 }
 
-hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int K, void* x_out, hipStream_t st) {
+hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int K, void* x_out, hipStream_t st, bool slot_order) {
     const int blocks = M < 2048 ? M : 2048;
-    hipLaunchKernelGGL(permute_rows_kernel, dim3(blocks), dim3(256), (size_t)K * 2, st, (const unsigned short*)x, perm, M, K,
-                       (unsigned short*)x_out);
+    if (slot_order)
+        hipLaunchKernelGGL(permute_rows_kernel<true>, dim3(blocks), dim3(256), (size_t)K * 2, st, (const unsigned short*)x, perm, M, K,
+                           (unsigned short*)x_out);
+    else
+        hipLaunchKernelGGL(permute_rows_kernel<false>, dim3(blocks), dim3(256), (size_t)K * 2, st, (const unsigned short*)x, perm, M, K,
+                           (unsigned short*)x_out);
     return hipGetLastError();
 }
 
@@ -595,13 +632,16 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.ksteps_per_split = (pl.ksteps_total + ks - 1) / ks;
     pl.ksplit = (pl.ksteps_total + pl.ksteps_per_split - 1) / pl.ksteps_per_split;   // no empty slices
     pl.workspace_bytes = pl.xperm_bytes + (pl.ksplit > 1 ? (size_t)pl.ksplit * M * L.N * sizeof(float) : 0);
+    // act-order + the 4-bit fp16 128x256x64 kernel: the permute pre-pass delivers x in k-slot order
+    pl.xslot = pl.use_seq && L.bits == 4 && L.dtype == GPTQ_F16 && pl.mt == 4 && pl.bk == 64 && (pl.variant == 0 || pl.variant == 5);
+    pl.glds = pl.xslot && pl.variant != 5;            // variant 5 (experiment): register-staged x
     return pl;
 }
 
-template <int BITS, typename T, int MT, int BK, int VAR = 1>
+template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, bool GLDS = false>
 static hipError_t launch_one(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
-    const size_t lds = (size_t)2 * (32 * MT) * (BK * 2 + 16);
-    hipLaunchKernelGGL((gemm_kernel<BITS, T, MT, BK, VAR>), dim3(pl.nbm * pl.nbn, pl.ksplit), dim3(256), lds, st, p);
+    const size_t lds = (size_t)2 * (32 * MT) * (GLDS ? BK * 2 : BK * 2 + 16);
+    hipLaunchKernelGGL((gemm_kernel<BITS, T, MT, BK, VAR, XPRE, GLDS>), dim3(pl.nbm * pl.nbn, pl.ksplit), dim3(256), lds, st, p);
     return hipGetLastError();
 }
 
@@ -629,6 +669,8 @@ static hipError_t launch_bits(const GemmPlan& pl, const GemmParams& p, hipStream
     if constexpr (BITS == 4) {
         if (pl.bk == 64) {
             if constexpr (std::is_same_v<T, f16>) {
+                if (pl.xslot && pl.glds) return launch_one<BITS, T, 4, 64, 1, true, true>(pl, p, st);
+                if (pl.xslot) return launch_one<BITS, T, 4, 64, 1, true>(pl, p, st);
                 if (pl.variant == 1) return launch_one<BITS, T, 4, 64, 0>(pl, p, st);   // experiment: plain loop
                 if (pl.variant == 2) return launch_one<BITS, T, 4, 64, 2>(pl, p, st);   // experiment: plain + setprio
 #ifdef GPTQ_GEMM_ABLATIONS
@@ -677,7 +719,7 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
     p.qrows = L.K / 32 * L.bits;
     hipError_t e;
     if (pl.use_seq) {
-        e = launch_permute_rows16(x, L.perm, M, L.K, workspace, st);
+        e = launch_permute_rows16(x, L.perm, M, L.K, workspace, st, pl.xslot);
         if (e != hipSuccess) return e;
         p.x = workspace;
     }

@@ -22,6 +22,8 @@ hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x,
 
 struct GemmPlan {
     bool supported, use_seq;
+    bool glds;                // ... and stages it with global_load_lds (DMA) into swizzled, unpadded LDS rows
+    bool xslot;               // act-order: the x pre-pass writes k-slot order, the kernel copies x to LDS verbatim
     bool skinny;              // weight-streaming decomposition for 8 < M <= 128 (64-column strips, waves split K)
     int waves, variant;
     int mt, bk, bm, bn;       // row tiles per wave, K-step, workgroup tile
@@ -43,7 +45,7 @@ hipError_t launch_pack_zeros(const void* zero_in, int G, int N, int bits, int qp
 hipError_t launch_resequence(const uint32_t* qweight, const int32_t* perm, int K, int N, int bits,
                              uint32_t* out, hipStream_t st);
 hipError_t launch_silu_mul(const void* y, void* out, int M, int N, int dtype, hipStream_t st);
-hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int K, void* x_out, hipStream_t st);
+hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int K, void* x_out, hipStream_t st, bool slot_order = false);
 hipError_t launch_permute_columns(const void* x, const int32_t* perm, int M, int K, int dtype, void* x_out, hipStream_t st);
 
 }  // namespace gptq
