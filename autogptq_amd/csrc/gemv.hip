@@ -20,6 +20,8 @@
 //    scaled once per 8 k in fp32.  No fp16 accumulation anywhere.
 //  * K reduction: row slots by wavefront shuffles (DPP), waves through LDS in fixed order, then
 //    (only if ksplit > 1) a second pass over fp32 partials.  No atomics: bit-reproducible.
+#include <type_traits>
+
 #include "common.cuh"
 #include "launch.h"
 
@@ -764,6 +766,145 @@ __global__ void __launch_bounds__(1024, (!PAIR && (!PERM || MT == 1) && ((U == 1
     }
 }
 
+// ---- matrix-core GEMV, any bits, fp16 / bf16 -----------------------------------------------------
+// The same structure for the other packings (2/3/8-bit, and 4-bit with bf16): a lane owns 4 columns and U consecutive
+// packing units (1 word = 16/8/4 values, or 3 words = 32 values for 3-bit) of one group; fields are extracted with
+// v_bfe, w - z is formed in integers and converted exactly to T (|w - z| <= 256 fits both fp16 and bf16), 4 values of
+// the lane's own column feed one 4x4x4 MFMA against the matching 4 x values of up to 4 x rows (natural k order: no x
+// permutation).  out = sum_g s_g * (sum_{k in g} x_k (w_k - z_g)), fp32 sums.
+template <typename T> struct Mma4;
+template <> struct Mma4<f16> {
+    typedef _Float16 v4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f32x4 run(u32x2 a, u32x2 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(v4, a), __builtin_bit_cast(v4, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned short bits_of_int(int d) { return as_u16((f16)(short)d); }
+};
+template <> struct Mma4<bf16> {
+    typedef short v4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f32x4 run(u32x2 a, u32x2 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(v4, a), __builtin_bit_cast(v4, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned short bits_of_int(int d) { return (unsigned short)(as_u32((float)d) >> 16); }  // exact
+};
+
+template <int BITS, typename T, int LN, int MT, int U>
+__global__ void __launch_bounds__(1024, 4) gemv_mfma_generic_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = (float*)smem;
+    constexpr int UW = Pack<BITS>::words, KPU = Pack<BITS>::vals, WR = 64 / LN, CT = LN * 4;
+    constexpr int XV = KPU / 8;                         // 16-byte x pieces per unit (8-bit: half a piece)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
+    const int cl = lane % LN, rs = lane / LN;
+    const int strip = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = strip * CT + cl * 4;
+    const bool col_ok = n0 < p.N;
+    const int nload = col_ok ? n0 : 0;
+    const int m0 = blockIdx.z * 4;
+    const int ub = blockIdx.y * p.units_per_split;
+    const int ue = min(ub + p.units_per_split, p.units_total);
+    const T* __restrict__ xrow = (const T*)p.x + (size_t)min(m0 + (lane & 3), p.M - 1) * p.K;
+    const T* __restrict__ scales = (const T*)p.scales;
+    const int zrow_words = p.N / 32 * BITS;
+    const int gunits = p.group_size / KPU;              // units per group (>= 1, the launcher checks divisibility)
+
+    float acc[4][MT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[c][m] = 0.f;
+
+    const int rows_per_iter = W * WR * U;
+    for (int base = ub; base < ue; base += rows_per_iter) {
+        const int u0 = base + (wave * WR + rs) * U;
+        const int g = min(u0, ue - 1) / gunits;
+        const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * p.N + nload);
+        int z[4];
+        zero_points4(p.qzeros + (size_t)g * zrow_words, nload, BITS, p.zero_mode, z);
+        // x: KPU values per unit (8-byte piece for 8-bit, 1/2/4 16-byte pieces for 4/2/3-bit)
+        unsigned xr[U][KPU / 2];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const T* xp = xrow + (size_t)min(u0 + j, ue - 1) * KPU;
+            if constexpr (KPU == 4) {
+                const u32x2 t = *(const u32x2*)xp;
+                xr[j][0] = t[0]; xr[j][1] = t[1];
+            } else {
+#pragma unroll
+                for (int v = 0; v < XV; ++v) {
+                    const u32x4 t = *(const u32x4*)(xp + 8 * v);
+                    xr[j][4 * v] = t[0]; xr[j][4 * v + 1] = t[1]; xr[j][4 * v + 2] = t[2]; xr[j][4 * v + 3] = t[3];
+                }
+            }
+        }
+        u32x4 q[U][UW];
+#pragma unroll
+        for (int j = 0; j < U; ++j)
+#pragma unroll
+            for (int w = 0; w < UW; ++w)
+                q[j][w] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)(min(u0 + j, ue - 1) * UW + w) * p.N + nload));
+
+        f32x4 accg[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) accg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const bool live = (u0 + j < ue);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned wds[UW];
+#pragma unroll
+                for (int w = 0; w < UW; ++w) wds[w] = q[j][w][c];
+                [&]<int... Q>(std::integer_sequence<int, Q...>) {          // Q = quad of 4 consecutive k inside the unit
+                    (([&] {
+                         const unsigned short e0 = Mma4<T>::bits_of_int((int)unit_field<BITS, 4 * Q + 0>(wds) - z[c]);
+                         const unsigned short e1 = Mma4<T>::bits_of_int((int)unit_field<BITS, 4 * Q + 1>(wds) - z[c]);
+                         const unsigned short e2 = Mma4<T>::bits_of_int((int)unit_field<BITS, 4 * Q + 2>(wds) - z[c]);
+                         const unsigned short e3 = Mma4<T>::bits_of_int((int)unit_field<BITS, 4 * Q + 3>(wds) - z[c]);
+                         const u32x2 b = {(unsigned)e0 | ((unsigned)e1 << 16), (unsigned)e2 | ((unsigned)e3 << 16)};
+                         u32x2 a = {xr[j][2 * Q], xr[j][2 * Q + 1]};
+                         if (!live) a = u32x2{0u, 0u};
+                         accg[c] = Mma4<T>::run(a, b, accg[c]);
+                     }()),
+                     ...);
+                }(std::make_integer_sequence<int, KPU / 4>{});
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned sh = (c & 1) ? (sraw[c >> 1] >> 16) : (sraw[c >> 1] & 0xffffu);
+            const float sc = DType<T>::to_f32(__builtin_bit_cast(T, (unsigned short)sh));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[c][m] = fmaf(sc, accg[c][m], acc[c][m]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c][m] = row_slot_sum<LN>(acc[c][m]);
+    if (lane < LN) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f32x4 v = {acc[0][m], acc[1][m], acc[2][m], acc[3][m]};
+            *(f32x4*)(red + (wave * MT + m) * CT + lane * 4) = v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < MT * CT; i += blockDim.x) {
+        const int m = i / CT, c = i % CT;
+        const int n = strip * CT + c, row = m0 + m;
+        if (n >= p.N || row >= p.M) continue;
+        float s = 0.f;
+        for (int w = 0; w < W; ++w) s += red[(w * MT + m) * CT + c];
+        if (p.ksplit > 1) {
+            p.partial[((size_t)blockIdx.y * p.M + row) * p.N + n] = s;
+        } else {
+            if (p.bias) s += DType<T>::to_f32(((const T*)p.bias)[n]);
+            ((T*)p.out)[(size_t)row * p.N + n] = DType<T>::from_f32(s);
+        }
+    }
+}
+
 // ---- second pass for ksplit > 1: out = sum_s partial[s] (+bias), fixed order ----------------
 template <typename T>
 __global__ void __launch_bounds__(256) gemv_reduce_kernel(const float* __restrict__ partial, const T* __restrict__ bias,
@@ -816,9 +957,15 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     // default for 4-bit fp16 layers; act-order layers (x gathered through perm) only with 16-column strips
     pl.mfma = pow2_groups && (path == 0 || path == 5) && (!pl.use_seq || (ln_ok && L.K <= 24576));
     pl.direct = pow2_groups && !pl.use_seq && path == 4;
+    // the other packings (and 4-bit bf16): matrix-core kernel with integer field extraction; 16-column strips only
+    pl.mfmag = !pl.mfma && !pl.direct && (path == 0 || path == 5) && !pl.perk && !pl.use_seq && ln_ok &&
+               (L.dtype == GPTQ_F16 || L.dtype == GPTQ_BF16) && !(L.bits == 4 && L.dtype == GPTQ_F16);
     if (pl.mfma) {                 // the matrix core handles 4 rows of x per pass, whatever M is
         pl.mt = M >= 5 ? 8 : (M >= 3 ? 4 : M);         // 8 = two groups of 4 rows in one pass
         pl.mtiles = M >= 5 ? (M + 7) / 8 : 1;
+    } else if (pl.mfmag) {
+        pl.mt = M >= 3 ? 4 : M;
+        pl.mtiles = (M + 3) / 4;
     } else {
         pl.mt = pick_mt(M);
         if (pl.direct && pl.mt > 4) pl.mt = 4;
@@ -828,7 +975,7 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
 
     int ln = (tune && tune->lanes_n) ? tune->lanes_n : 0;
     if (!ln) {
-        if (pl.mfma || pl.direct) {
+        if (pl.mfma || pl.direct || pl.mfmag) {
             // measured (tools/gemvlab, tools/membench): without a K split the 16-column strip wins on every
             // Llama shape -- a second (reduce) launch costs more than the 64-byte row segments do
             ln = 4;
@@ -862,6 +1009,18 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     const size_t rbytes = (size_t)waves * pl.mt * ln * 4 * sizeof(float);
     pl.workspace_bytes = ks > 1 ? (size_t)ks * M * L.N * sizeof(float) : 0;
     pl.u = 1;
+    if (pl.mfmag) {
+        const int gunits = L.group_size / kpu;
+        const int per_lane = (pl.units_per_split + rows_per_iter - 1) / rows_per_iter;
+        const int ucap = L.bits == 3 ? 1 : (L.bits == 2 ? 2 : 4);      // register budget: U * words and U * x values per lane
+        int u = 1;
+        for (int cand : {4, 2})
+            if (cand <= ucap && cand <= per_lane && gunits % cand == 0 && pl.units_per_split % cand == 0) { u = cand; break; }
+        pl.u = u;
+        pl.chunk_units = pl.units_per_split;
+        pl.lds_bytes = rbytes;
+        return pl;
+    }
     if (pl.mfma || pl.direct) {
         // consecutive packed rows per lane and iteration: same group, so one (scales, zeros) fetch serves them
         const int per_lane = (pl.units_per_split + rows_per_iter - 1) / rows_per_iter;
@@ -1015,6 +1174,40 @@ static hipError_t launch_mfma_mt(const GemvPlan& pl, const GemvParams& p, hipStr
     }
 }
 
+template <int BITS, typename T, int MT>
+static hipError_t launch_mfmag_u(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
+    dim3 grid(pl.strips, pl.ksplit, pl.mtiles), block(pl.waves * 64);
+    if (pl.ln != 4) return hipErrorInvalidValue;
+    switch (pl.u) {
+        case 1: hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 1>), grid, block, pl.lds_bytes, st, p); break;
+        case 2: if constexpr (BITS != 3) { hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 2>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
+        case 4: if constexpr (BITS == 4 || BITS == 8) { hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 4>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <int BITS, typename T>
+static hipError_t launch_mfmag_mt(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
+    switch (pl.mt) {
+        case 1: return launch_mfmag_u<BITS, T, 1>(pl, p, st);
+        case 2: return launch_mfmag_u<BITS, T, 2>(pl, p, st);
+        case 4: return launch_mfmag_u<BITS, T, 4>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <typename T>
+static hipError_t launch_mfmag(const gptq_layer_t& L, const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
+    switch (L.bits) {
+        case 2: return launch_mfmag_mt<2, T>(pl, p, st);
+        case 3: return launch_mfmag_mt<3, T>(pl, p, st);
+        case 4: if constexpr (std::is_same_v<T, bf16>) return launch_mfmag_mt<4, T>(pl, p, st); else return hipErrorInvalidValue;
+        case 8: return launch_mfmag_mt<8, T>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 template <int MT>
 static hipError_t launch_direct_mt(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
     switch (pl.ln) {
@@ -1059,7 +1252,9 @@ hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x,
     }
 
     hipError_t e;
-    if (pl.mfma) {
+    if (pl.mfmag) {
+        e = (L.dtype == GPTQ_F16) ? launch_mfmag<f16>(L, pl, p, st) : launch_mfmag<bf16>(L, pl, p, st);
+    } else if (pl.mfma) {
         switch (pl.mt) {
             case 1: e = launch_mfma_mt<1>(pl, p, st); break;
             case 2: e = launch_mfma_mt<2>(pl, p, st); break;

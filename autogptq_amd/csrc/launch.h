@@ -12,6 +12,7 @@ struct GemvPlan {
     bool fast, perk, use_seq;
     bool direct;   // fast path without LDS staging (x / scales / zeros straight from L2)
     bool mfma;     // direct path with the k-reduction on v_mfma_f32_4x4x4_16b_f16
+    bool mfmag;    // matrix-core kernel for the other packings / bf16 (gemv_mfma_generic_kernel)
     bool pair;     // mfma path with the fused SILU_MUL epilogue (gate/up halves walked by the same workgroup)
     int u;         // direct path: consecutive packed rows per lane and iteration
     size_t lds_bytes, workspace_bytes;
