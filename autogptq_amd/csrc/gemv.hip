@@ -1025,6 +1025,8 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
         // consecutive packed rows per lane and iteration: same group, so one (scales, zeros) fetch serves them
         const int per_lane = (pl.units_per_split + rows_per_iter - 1) / rows_per_iter;
         int want = pl.units_per_split >= 1024 ? 1 : 2;             // long K: more, shorter iterations pipeline better
+        // more than one workgroup per CU only fits with <= 64 VGPRs: U = 1 once 3+ rows of x are carried
+        if (pl.mfma && pl.mt == 4 && (long)pl.strips * pl.mtiles > 256) want = 1;
         if (pl.use_seq) want = (M == 1 && !(L.epilogue == GPTQ_EPI_SILU_MUL)) ? 8 : 2;   // act-order: the x gather is a dependent
                                                                     // round trip per iteration -> as few iterations as possible
         int u = 1;

@@ -248,6 +248,8 @@ def main():
     ap.add_argument("--m", type=int, default=0, help="rows per step (default 1 for decode, 2048 for prefill)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tp", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for launcher smoke tests)")
+    ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--no-fused", action="store_true", help="skip the extra fused-callers measurement (decode, 1 GPU only)")
     args = ap.parse_args()
 
@@ -257,13 +259,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     barrier = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
         barrier = dist.barrier
 
     prefill = args.workload == "prefill"
