@@ -7,5 +7,6 @@ mirror (``import_utils``) and the out_features tensor-parallel wrapper (``tensor
 from .import_utils import MI355X_KERNELS_AVAILABLE, dynamically_import_QuantLinear  # noqa: F401
 from .qlinear_mi355x import QuantLinear, reserve_workspace  # noqa: F401
 from .fused import fuse_gate_up, fuse_qkv, fuse_quant_linears  # noqa: F401
+from .model_utils import autogptq_post_init, make_quant, pack_model  # noqa: F401
 
 __version__ = "0.1.0"

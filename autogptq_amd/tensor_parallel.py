@@ -80,4 +80,59 @@ class ColumnParallelQuantLinear(nn.Module):
         return out.reshape(lead + (self.world * nl,))
 
 
-__all__ = ["ColumnParallelQuantLinear", "shard_packed", "shard_bounds"]
+def shard_packed_rows(qweight, qzeros, scales, bits: int, group_size: int, rank: int, world: int):
+    """Row (in_features) slice for ``rank``: K/T input features = whole groups and whole packing units."""
+    K = qweight.shape[0] * 32 // bits
+    if K % world != 0 or (K // world) % group_size != 0 or (K // world) % 32 != 0:
+        raise ValueError(f"in_features={K} cannot be split over {world} ranks in whole groups of {group_size} (and 32-value units)")
+    k0, k1 = rank * (K // world), (rank + 1) * (K // world)
+    r0, r1 = k0 * bits // 32, k1 * bits // 32
+    g0, g1 = k0 // group_size, k1 // group_size
+    return qweight[r0:r1].contiguous(), qzeros[g0:g1].contiguous(), scales[g0:g1].contiguous(), (k0, k1)
+
+
+class RowParallelQuantLinear(nn.Module):
+    """The pair of ColumnParallelQuantLinear (Megatron style): the layer is split along in_features, every rank multiplies
+    its slice of x (the un-gathered output of a preceding column-parallel layer) and ONE all-reduce sums the partial
+    outputs; bias is added after the reduction.  Sequential groups only (an act-order g_idx mixes groups across the whole K)."""
+
+    def __init__(self, local: Callable[[torch.Tensor], torch.Tensor], k_range, bias: Optional[torch.Tensor] = None,
+                 group: Optional[dist.ProcessGroup] = None, input_is_parallel: bool = True):
+        super().__init__()
+        self.local = local
+        self.k0, self.k1 = k_range
+        self.bias = bias
+        self.group = group
+        self.input_is_parallel = input_is_parallel
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    @classmethod
+    def from_full(cls, full, rank: int, world: int, group=None, device=None, input_is_parallel=True):
+        from .qlinear_mi355x import QuantLinear, _is_sequential_g_idx
+
+        if not _is_sequential_g_idx(full.g_idx, full.group_size):
+            raise ValueError("row-parallel split needs sequential groups (no act-order)")
+        qw, qz, sc, (k0, k1) = shard_packed_rows(full.qweight, full.qzeros, full.scales, full.bits, full.group_size, rank, world)
+        local = QuantLinear(full.bits, full.group_size, k1 - k0, full.outfeatures, False, weight_dtype=full.scales.dtype,
+                            zero_mode=full.zero_mode)
+        local.qweight, local.qzeros, local.scales = qw, qz, sc
+        bias = full.bias
+        if device is not None:
+            local = local.to(device)
+            bias = None if bias is None else bias.to(device)
+        return cls(local, (k0, k1), bias=bias, group=group, input_is_parallel=input_is_parallel)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.input_is_parallel:
+            x = x[..., self.k0:self.k1].contiguous()
+        y = self.local(x)
+        if self.world > 1:
+            y = y.float()                                   # partial sums are reduced in fp32, rounded once
+            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+            y = y.to(x.dtype)
+        if self.bias is not None:
+            y = y + self.bias
+        return y
+
+
+__all__ = ["ColumnParallelQuantLinear", "RowParallelQuantLinear", "shard_packed", "shard_packed_rows", "shard_bounds"]

@@ -491,3 +491,57 @@ def test_fused_gate_up_silu_mul(M, dtype, bits, act):
     scale = float(ref.abs().max())
     err = (y.double().cpu() - ref).abs()
     assert bool((err <= rtol * (ref.abs() + 0.05 * scale)).all()), float(err.max())
+
+
+# ------------------------------------------------------------------------- callers around the path
+def test_model_level_flow_make_quant_pack_post_init_forward():
+    """make_quant -> pack_model (device pack) -> autogptq_post_init -> forward on a toy module: the quantized model tracks the
+    float model whose weights were replaced by their dequantised values."""
+    from autogptq_amd.model_utils import autogptq_post_init, pack_model
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.up = torch.nn.Linear(256, 512, bias=True)
+            self.down = torch.nn.Linear(512, 256, bias=False)
+
+        def forward(self, x):
+            return self.down(torch.nn.functional.relu(self.up(x)))
+
+    torch.manual_seed(1)
+    m = Toy().half()
+    quantizers, Wq = {}, {}
+    for nme, lin in (("up", m.up), ("down", m.down)):
+        s, z = O.minmax_quantize(lin.weight.data.float(), 4, 64)
+        gi = torch.from_numpy(O.default_g_idx(lin.in_features, 64))
+        quantizers[nme] = (None, s.half(), z.half(), gi)
+        qw, qz, sc = O.pack(lin.weight.data.clone(), s.half(), z.half(), gi, 4, torch.float16)
+        Wq[nme] = O.dequantize(qw, qz, sc, gi, 4, O.ZERO_WRAP).t().contiguous()      # [N, K]
+    ref = Toy().half()
+    ref.load_state_dict(m.state_dict())
+    ref.up.weight.data, ref.down.weight.data = Wq["up"], Wq["down"]
+    pack_model(m, quantizers, 4, 64)
+    m = autogptq_post_init(m.to(DEV), use_act_order=False, max_input_length=64)
+    for M in (1, 5, 40):
+        x = (torch.rand(M, 256, generator=torch.Generator().manual_seed(M)) - 0.5).half()
+        with torch.no_grad():
+            y = m(x.to(DEV)).float().cpu()
+            yr = ref.float()(x.float())
+        assert float((y - yr).abs().max()) <= 4e-3 * max(1.0, float(yr.abs().max())), M
+
+
+def test_row_and_column_shards_on_one_gpu():
+    """Both tensor-parallel splits, all shards evaluated on one GPU: column shards concatenate to the full output, row
+    shards sum to it (what the RCCL all-gather / all-reduce assemble across ranks)."""
+    from autogptq_amd.tensor_parallel import ColumnParallelQuantLinear, RowParallelQuantLinear
+    K, N, T = 2048, 1024, 4
+    L = O.random_quant_layer(K, N, 4, 128, seed=33, bias=True)
+    full = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, 128)
+    x = (torch.rand(3, K, generator=torch.Generator().manual_seed(8)) - 0.5).half().to(DEV)
+    y64 = O.forward_f64(x.cpu(), L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP)
+    with torch.no_grad():
+        cols = [ColumnParallelQuantLinear.from_full(full, r, T, device=DEV, gather_output=False)(x) for r in range(T)]
+        _assert_close(torch.cat(cols, dim=-1), y64, y64, torch.float16, K, "column shards")
+        rows = [RowParallelQuantLinear.from_full(full, r, T, device=DEV, input_is_parallel=False) for r in range(T)]
+        part = sum(rp.local(x[:, rp.k0:rp.k1].contiguous()).float() for rp in rows) + L["bias"].float().to(DEV)
+        _assert_close(part.half(), y64, y64, torch.float16, K, "row shards")

@@ -168,3 +168,35 @@ def test_fuse_quant_linears_host_logic():
         fuse_gate_up(a, b)
     with pytest.raises(ValueError, match="64"):
         QuantLinear(4, 64, 256, 96, False, epilogue="silu_mul")
+
+
+def test_make_quant_and_pack_model_host():
+    """make_quant / pack_model mirrors (auto_gptq/modeling/_utils.py:69-147, 257-330) on a toy module: modules are swapped for
+    the mi355x QuantLinear with the reference's constructor arguments and pack() fills the checkpoint tensors bit-exactly."""
+    from autogptq_amd.model_utils import find_layers, make_quant, pack_model
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(64, 32, bias=True)
+            self.blk = torch.nn.Sequential(torch.nn.Linear(32, 64, bias=False), torch.nn.ReLU())
+            self.head = torch.nn.Linear(64, 32)
+
+    torch.manual_seed(0)
+    m = Toy().half()
+    names = ["a", "blk.0"]
+    quantizers = {}
+    for nme in names:
+        lin = dict(m.named_modules())[nme]
+        s, z = O.minmax_quantize(lin.weight.data.float(), 4, 32)
+        quantizers[nme] = (None, s.half(), z.half(), torch.from_numpy(O.default_g_idx(lin.in_features, 32)))
+    ref = {nme: O.pack(dict(m.named_modules())[nme].weight.data.clone(), quantizers[nme][1], quantizers[nme][2],
+                       quantizers[nme][3], 4, torch.float16) for nme in names}
+    pack_model(m, quantizers, 4, 32)
+    assert isinstance(m.a, QuantLinear) and isinstance(m.blk[0], QuantLinear) and isinstance(m.head, torch.nn.Linear)
+    assert m.a.bias is not None and m.blk[0].bias is None and m.a.infeatures == 64 and m.a.outfeatures == 32
+    for nme in names:
+        ql = dict(m.named_modules())[nme]
+        assert torch.equal(ql.qweight.cpu(), ref[nme][0]) and torch.equal(ql.qzeros.cpu(), ref[nme][1])
+        assert torch.equal(ql.scales.cpu(), ref[nme][2])
+    assert set(find_layers(m, [QuantLinear])) == set(names)

@@ -69,3 +69,41 @@ def test_shard_bounds_rules():
         shard_bounds(4096 + 32, 0, 8)                        # not a multiple of 32 columns per rank
     with pytest.raises(ValueError):
         shard_bounds(96, 0, 8)
+
+
+def _worker_row(rank, world, port, bits, gs, K, N, M, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from autogptq_amd.tensor_parallel import RowParallelQuantLinear, shard_packed_rows
+        L = O.random_quant_layer(K, N, bits, gs, seed=4, bias=True)
+        x = (torch.rand(M, K, generator=torch.Generator().manual_seed(6)) - 0.5).float()
+        mode = O.reference_zero_mode(False, bits)
+        qw, qz, sc, (k0, k1) = shard_packed_rows(L["qweight"], L["qzeros"], L["scales"].float(), bits, gs, rank, world)
+
+        def local(xx):                                   # the rank's [M, K/T] x [K/T, N] partial product (oracle as stand-in)
+            return O.forward(xx, qw, qz, sc, None, None, bits, mode)
+
+        mod = RowParallelQuantLinear(local, (k0, k1), bias=L["bias"].float(), input_is_parallel=False)
+        y = mod(x)
+        ref = O.forward(x, L["qweight"], L["qzeros"], L["scales"].float(), L["g_idx"], L["bias"].float(), bits, mode)
+        q.put((rank, bool(torch.allclose(y, ref, rtol=1e-4, atol=1e-5)), float((y - ref).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bits,gs,K,N,M", [(4, 128, 512, 64, 2), (3, 32, 256, 96, 1), (8, 64, 256, 32, 3)])
+def test_row_parallel_two_ranks_gloo(bits, gs, K, N, M):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_row, args=(r, world, port, bits, gs, K, N, M, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
