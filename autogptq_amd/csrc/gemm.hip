@@ -46,6 +46,7 @@ struct GemmParams {
     int M, K, N, group_size, zero_mode;
     int nbm, nbn, ksplit, ksteps_total, ksteps_per_split;
     int qrows;        // rows of qweight (K/32*bits)
+    unsigned long long kpg_inv;   // ceil(2^32 / (group_size / BK)): group of K-step kt = (kt * kpg_inv) >> 32, exact for kt < 2^16
 };
 
 __device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
@@ -240,6 +241,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
     // Rows past M are clamped to row M-1 (never predicated: a predicated load splits the K-loop into several
     // basic blocks and the prefetch stops overlapping the MFMAs); their accumulators are simply not stored.
     int a_row[NCH], a_kc[NCH];
+    unsigned a_off[NCH];
     const unsigned short* a_src[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -248,19 +250,28 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
         a_kc[i] = c - a_row[i] * CPR;
         const int src_kc = GLDS ? (a_kc[i] ^ ((a_row[i] >> 1) & 7)) : a_kc[i];
         a_src[i] = x + (size_t)min(m0 + a_row[i], p.M - 1) * p.K + src_kc * 8;
+        a_off[i] = (unsigned)(min(m0 + a_row[i], p.M - 1) - m0) * (unsigned)p.K * 2u + (unsigned)src_kc * 16u;   // < 2^32: BM rows
     }
+    const char* a_base = (const char*)(x + (size_t)m0 * p.K);             // uniform
+    // Buffer descriptors (wave-uniform: kernel arguments and blockIdx only) -- buffer_load takes (SGPR descriptor, VGPR 32-bit
+    // offset, SGPR offset), so the per-K-step part of every address is scalar arithmetic.
+    const auto rsrc_q = __builtin_amdgcn_make_buffer_rsrc((void*)p.qweight, 0, (int)((size_t)p.qrows * p.N * 4), 0x00020000);
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (int)((size_t)BM * p.K * 2), 0x00020000);
+    const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.scales, 0, (int)((size_t)(p.K / p.group_size) * p.N * 2), 0x00020000);
+    const int zrow_bytes = p.N / 32 * BITS * 4;
+    const auto rsrc_z = __builtin_amdgcn_make_buffer_rsrc((void*)p.qzeros, 0, (p.K / p.group_size) * zrow_bytes, 0x00020000);
     // DMA: instruction i of wave w fills LDS chunks [(i*4 + w)*64, +64) = 1 KiB, lane l -> chunk base + l (= tid + i*256)
     auto dma_a = [&](int kt, int buf) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             char* dst = smem + (size_t)buf * (BM * STRIDE) + (size_t)(i * NTHR + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (size_t)kt * BK),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + (size_t)kt * (BK * 2) + a_off[i]),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
     auto load_a = [&](int kt, u32x4 (&r)[NCH]) {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) r[i] = *(const u32x4*)(a_src[i] + (size_t)kt * BK);
+        for (int i = 0; i < NCH; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, a_off[i], (unsigned)kt * (BK * 2), 0);
     };
     auto store_a = [&](int buf, const u32x4 (&r)[NCH]) {
 #pragma unroll
@@ -279,11 +290,34 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
             *(u32x4*)(smem + (size_t)buf * (BM * STRIDE) + a_row[i] * STRIDE + a_kc[i] * 16) = o;
         }
     };
+    // Addresses are split into a wave-uniform part (K-step / k-step: scalar ALU) and a loop-invariant 32-bit per-lane byte
+    // offset, so a load costs no vector address arithmetic inside the K loop (global_load with an SGPR base).
+    const unsigned b_lane_off = ((unsigned)nl + (unsigned)half * (BITS == 8 ? 2u : 1u) * (unsigned)p.N) * 4u;
+    const unsigned s_lane_off = (unsigned)nl * 2u;
+    const unsigned z_lane_off = (((unsigned)nl * BITS) >> 5) * 4u, z_lane_sh = ((unsigned)nl * BITS) & 31u;
     auto load_b = [&](int kt, BRaw<BITS> (&b)[KS]) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) load_braw<BITS>(b[ks], qcol, p.N, p.qrows, kt * BK + ks * 16 + half * 8);
+        for (int ks = 0; ks < KS; ++ks) {
+            if constexpr (BITS == 4 || BITS == 8) {
+                constexpr int WPH = (BITS == 8) ? 2 : 1;                       // words per 8 k
+                const size_t row_u = (size_t)(kt * (BK / 8) + ks * 2) * WPH;      // uniform packed row of lane-half 0
+#pragma unroll
+                for (int i = 0; i < WPH; ++i)
+                    b[ks].w[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_q, b_lane_off, (unsigned)((row_u + i) * (size_t)p.N * 4), 0);
+            } else {
+                load_braw<BITS>(b[ks], qcol, p.N, p.qrows, kt * BK + ks * 16 + half * 8);
+            }
+        }
     };
-    auto load_c = [&](int kt, CRaw& c) { load_craw<BITS>(c, p.scales, p.qzeros, (kt * BK) / p.group_size, p.N, nl); };
+    auto load_c = [&](int kt, CRaw& c) {
+        const int g = (int)(((unsigned long long)(unsigned)kt * p.kpg_inv) >> 32);
+        if constexpr (BITS != 3) {
+            c.s = __builtin_amdgcn_raw_buffer_load_b32(rsrc_s, s_lane_off, (unsigned)g * (unsigned)p.N * 2u, 0);
+            c.z = (unsigned long long)(__builtin_amdgcn_raw_buffer_load_b32(rsrc_z, z_lane_off, (unsigned)(g * zrow_bytes), 0) >> z_lane_sh);
+        } else {
+            load_craw<BITS>(c, p.scales, p.qzeros, g, p.N, nl);
+        }
+    };
 
     f32x16 acc[MT][2];
 #pragma unroll
@@ -717,6 +751,10 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
     p.nbm = pl.nbm; p.nbn = pl.nbn; p.ksplit = pl.ksplit;
     p.ksteps_total = pl.ksteps_total; p.ksteps_per_split = pl.ksteps_per_split;
     p.qrows = L.K / 32 * L.bits;
+    {
+        const unsigned long long kpg = (unsigned long long)(L.group_size / pl.bk);       // K-steps per group (>= 1: group_size % bk == 0)
+        p.kpg_inv = ((1ull << 32) + kpg - 1) / kpg;
+    }
     hipError_t e;
     if (pl.use_seq) {
         e = launch_permute_rows16(x, L.perm, M, L.K, workspace, st, pl.xslot);
