@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
         printf("== M=%d K=%d N=%d : %.2f GFLOP per launch\n", M, K, N, 2.0 * M * K * N / 1e9);
         struct V { int id; const char* name; gptq_layer_t L; gptq_tuning_t tu; GemmPlan pl; double us; };
         std::vector<V> vs;
-        for (int variant = 0; variant < 13; ++variant) {
+        for (int variant = 0; variant < 14; ++variant) {
             if (only_variant >= 0 && variant != only_variant) continue;
             V v{}; v.id = variant; v.us = 1e30;
             gptq_layer_t& L = v.L;
@@ -72,6 +72,7 @@ int main(int argc, char** argv) {
             if (variant == 3) { if (M > 128) continue; v.tu.reserved[2] = 1; v.name = "forced skinny"; }
             if (variant == 4) { if (M > 128) continue; v.tu.reserved[2] = 2; v.name = "forced tiled"; }
             if (variant == 12) { if (M < 512) continue; L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.tu.reserved[3] = 5; v.name = "act-order, register-staged x (no DMA)"; }
+            if (variant == 13) { if (M < 512) continue; L.dtype = GPTQ_BF16; v.name = "bf16 (bit patterns reused: timing only)"; }
             if (variant == 2) { L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.name = "act-order (x permute + qweight_seq)"; }
             v.pl = plan_gemm(L, M, &v.tu);
             if (!v.pl.supported) { printf("  unsupported\n"); continue; }
