@@ -472,6 +472,23 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_direct_kernel(GemvParams p) 
     }
 }
 
+// 4x4x4 matrix-core step on packed 2-byte operands (u32x2 = 4 values) for both fp16 and bf16
+template <typename T> struct Mma4;
+template <> struct Mma4<f16> {
+    typedef _Float16 v4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f32x4 run(u32x2 a, u32x2 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(v4, a), __builtin_bit_cast(v4, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned short bits_of_int(int d) { return as_u16((f16)(short)d); }
+};
+template <> struct Mma4<bf16> {
+    typedef short v4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f32x4 run(u32x2 a, u32x2 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(v4, a), __builtin_bit_cast(v4, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned short bits_of_int(int d) { return (unsigned short)(as_u32((float)d) >> 16); }  // exact
+};
+
 // ---- matrix-core GEMV: 4-bit, fp16, sequential groups -------------------------------------------
 // Same load structure as the direct kernel, but the k-reduction runs on the matrix core:
 // v_mfma_f32_4x4x4_16b_f16 is 16 independent 4x4x4 products, one per aligned group of 4 lanes -- and an
@@ -488,12 +505,16 @@ __global__ void __launch_bounds__(1024) gemv_q4_f16_direct_kernel(GemvParams p) 
 // for the gate/up pair of a gated MLP.
 // PERM = act-order layer: weights come from the group-sorted copy and the 8 x values of a packed row are gathered
 // through perm[] (two 16-byte index loads + eight 2-byte gathers per row, all L2 resident) straight into slot order.
-template <int LN, int MT, int U, bool PAIR = false, bool PERM = false>
-__global__ void __launch_bounds__(1024, (!PAIR && (!PERM || MT == 1) && ((U == 1 && MT <= 4) || (U == 2 && MT <= 2))) ? 8 : 4) gemv_q4_f16_mfma_kernel(GemvParams p) {
+// T = bf16: gfx950 has no packed bf16 arithmetic, so w - z is not formed per weight.  B is the bf16 magic number 128 + w
+// ((q & 0x000f000f) | 0x43004300, exact) and one extra MFMA per x piece against a vector of ones yields sum_k x_k, so
+//     sum_k x_k (w_k - z) = sum_k x_k (128 + w_k) - (128 + z) * sum_k x_k
+// with exact products and fp32 sums (the 128 offset costs 7 of fp32's 24 bits -- far below bf16's 8-bit significand).
+template <int LN, int MT, int U, bool PAIR = false, bool PERM = false, typename T = f16>
+__global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && (!PERM || MT == 1) && ((U == 1 && MT <= 4) || (U == 2 && MT <= 2))) ? 8 : 4) gemv_q4_f16_mfma_kernel(GemvParams p) {
+    constexpr bool BF = std::is_same_v<T, bf16>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;
     constexpr int WR = 64 / LN, CT = LN * 4;
-    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
     const int cl = lane % LN, rs = lane / LN;
     const int strip = xcd_remap(blockIdx.x, gridDim.x);
@@ -508,10 +529,10 @@ __global__ void __launch_bounds__(1024, (!PAIR && (!PERM || MT == 1) && ((U == 1
     const int ub = blockIdx.y * p.units_per_split;
     const int ue = min(ub + p.units_per_split, p.units_total);
     // A operand: lane i of each 4-lane group carries x row m0 + i (clamped: surplus rows are never stored)
-    const f16* xrow[RG];
+    const T* xrow[RG];
 #pragma unroll
-    for (int rg = 0; rg < RG; ++rg) xrow[rg] = (const f16*)p.x + (size_t)min(m0 + rg * 4 + (lane & 3), p.M - 1) * p.K;
-    const f16* __restrict__ scales = (const f16*)p.scales;
+    for (int rg = 0; rg < RG; ++rg) xrow[rg] = (const T*)p.x + (size_t)min(m0 + rg * 4 + (lane & 3), p.M - 1) * p.K;
+    const T* __restrict__ scales = (const T*)p.scales;
     const int zrow_words = p.N >> 3;
     const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
     const int gshift = p.gu_shift;
@@ -635,13 +656,21 @@ __global__ void __launch_bounds__(1024, (!PAIR && (!PERM || MT == 1) && ((U == 1
         if constexpr (!PERM) load_q();
 
         f16x2 c1[4], c2[4];
+        float zoff[4];                                          // bf16: 128 + z
         const f16x2 k960 = {(f16)960.f, (f16)960.f};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const unsigned z = (((zw >> (4 * c)) & 15u) + 1u) & zmask;
-            c1[c] = as_f16x2(z * 0x00010001u + 0xE400E400u);    // -(1024+z)
-            c2[c] = c1[c] + k960;                               // -(64+z)
+            if constexpr (BF) {
+                zoff[c] = (float)(128u + z);
+            } else {
+                c1[c] = as_f16x2(z * 0x00010001u + 0xE400E400u);    // -(1024+z)
+                c2[c] = c1[c] + k960;                               // -(64+z)
+            }
         }
+        f32x4 accx[RG];                                         // bf16: sum_k x_k per x row (ones MFMA)
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) accx[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 accg[RG][4];
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg)
@@ -654,7 +683,7 @@ __global__ void __launch_bounds__(1024, (!PAIR && (!PERM || MT == 1) && ((U == 1
             if (u0 + j >= ue) qv = u32x4{0u, 0u, 0u, 0u};       // tail rows: x is zeroed below, value irrelevant
             const bool live = (u0 + j < ue);
             // x slots (k0,k4,k1,k5) and (k2,k6,k3,k7): the order the magic-number unpack produces
-            f16x4 xa01[RG], xa23[RG];
+            u32x2 xa01[RG], xa23[RG];
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg) {
                 const u32x4 t = xr[rg][j];
@@ -667,33 +696,48 @@ __global__ void __launch_bounds__(1024, (!PAIR && (!PERM || MT == 1) && ((U == 1
                     a23 = u32x2{__builtin_amdgcn_perm(t[3], t[1], 0x05040100u), __builtin_amdgcn_perm(t[3], t[1], 0x07060302u)};
                 }
                 if (!live) { a01 = u32x2{0u, 0u}; a23 = u32x2{0u, 0u}; }
-                xa01[rg] = __builtin_bit_cast(f16x4, a01);
-                xa23[rg] = __builtin_bit_cast(f16x4, a23);
+                xa01[rg] = a01;
+                xa23[rg] = a23;
+                if constexpr (BF) {
+                    const u32x2 ones = {0x3F803F80u, 0x3F803F80u};
+                    accx[rg] = Mma4<T>::run(a01, ones, accx[rg]);
+                    accx[rg] = Mma4<T>::run(a23, ones, accx[rg]);
+                }
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const unsigned qw = qv[c], q8 = qw >> 8;
-                const f16x2 h0 = as_f16x2((qw & 0x000f000fu) | 0x64006400u) + c1[c];
-                const f16x2 h1 = as_f16x2((qw & 0x00f000f0u) | 0x64006400u) * r16 + c2[c];
-                const f16x2 h2 = as_f16x2((q8 & 0x000f000fu) | 0x64006400u) + c1[c];
-                const f16x2 h3 = as_f16x2((q8 & 0x00f000f0u) | 0x64006400u) * r16 + c2[c];
-                const u32x2 b01 = {__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
-                const u32x2 b23 = {__builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
+                u32x2 b01, b23;
+                if constexpr (BF) {
+                    b01 = u32x2{(qw & 0x000f000fu) | 0x43004300u, ((qw >> 4) & 0x000f000fu) | 0x43004300u};     // 128 + w: (k0,k4)(k1,k5)
+                    b23 = u32x2{(q8 & 0x000f000fu) | 0x43004300u, ((q8 >> 4) & 0x000f000fu) | 0x43004300u};     // (k2,k6)(k3,k7)
+                } else {
+                    const f16x2 h0 = as_f16x2((qw & 0x000f000fu) | 0x64006400u) + c1[c];
+                    const f16x2 h1 = as_f16x2((qw & 0x00f000f0u) | 0x64006400u) * r16 + c2[c];
+                    const f16x2 h2 = as_f16x2((q8 & 0x000f000fu) | 0x64006400u) + c1[c];
+                    const f16x2 h3 = as_f16x2((q8 & 0x00f000f0u) | 0x64006400u) * r16 + c2[c];
+                    b01 = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+                    b23 = u32x2{__builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
+                }
 #pragma unroll
                 for (int rg = 0; rg < RG; ++rg) {
-                    accg[rg][c] = __builtin_amdgcn_mfma_f32_4x4x4f16(xa01[rg], __builtin_bit_cast(f16x4, b01), accg[rg][c], 0, 0, 0);
-                    accg[rg][c] = __builtin_amdgcn_mfma_f32_4x4x4f16(xa23[rg], __builtin_bit_cast(f16x4, b23), accg[rg][c], 0, 0, 0);
+                    accg[rg][c] = Mma4<T>::run(xa01[rg], b01, accg[rg][c]);
+                    accg[rg][c] = Mma4<T>::run(xa23[rg], b23, accg[rg][c]);
                 }
             }
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const unsigned sh = (c & 1) ? (sraw[c >> 1] >> 16) : (sraw[c >> 1] & 0xffffu);
-            const float sc = (float)as_f16((unsigned short)sh);
+            const float sc = DType<T>::to_f32(__builtin_bit_cast(T, (unsigned short)sh));
 #pragma unroll
             for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
-                for (int m = 0; m < MTR; ++m) acc[h][rg][c][m] = fmaf(sc, accg[rg][c][m], acc[h][rg][c][m]);
+                for (int m = 0; m < MTR; ++m) {
+                    float gsum = accg[rg][c][m];
+                    if constexpr (BF) gsum = fmaf(-zoff[c], accx[rg][m], gsum);
+                    acc[h][rg][c][m] = fmaf(sc, gsum, acc[h][rg][c][m]);
+                }
         }
     }
     }
@@ -725,14 +769,14 @@ __global__ void __launch_bounds__(1024, (!PAIR && (!PERM || MT == 1) && ((U == 1
         const int n = strip * CT + c, row = m0 + (mm / MTR) * 4 + (mm % MTR);
         if (n >= NH || row >= p.M) return;
         if constexpr (PAIR) {
-            if (p.bias) { s0 += (float)((const f16*)p.bias)[n]; s1 += (float)((const f16*)p.bias)[n + p.pair_off]; }
+            if (p.bias) { s0 += DType<T>::to_f32(((const T*)p.bias)[n]); s1 += DType<T>::to_f32(((const T*)p.bias)[n + p.pair_off]); }
             const float g = s0 / (1.f + __expf(-s0));            // silu on the fp32 sum
-            ((f16*)p.out)[(size_t)row * NH + n] = (f16)(g * s1);
+            ((T*)p.out)[(size_t)row * NH + n] = DType<T>::from_f32(g * s1);
         } else if (p.ksplit > 1) {
             p.partial[((size_t)blockIdx.y * p.M + row) * p.N + n] = s0;
         } else {
-            if (p.bias) s0 += (float)((const f16*)p.bias)[n];
-            ((f16*)p.out)[(size_t)row * p.N + n] = (f16)s0;
+            if (p.bias) s0 += DType<T>::to_f32(((const T*)p.bias)[n]);
+            ((T*)p.out)[(size_t)row * p.N + n] = DType<T>::from_f32(s0);
         }
     };
     // final cross-wave sum.  When E <= 64 one wave does it with P = 64 / E lanes per entry (each lane adds every
@@ -772,22 +816,6 @@ __global__ void __launch_bounds__(1024, (!PAIR && (!PERM || MT == 1) && ((U == 1
 // v_bfe, w - z is formed in integers and converted exactly to T (|w - z| <= 256 fits both fp16 and bf16), 4 values of
 // the lane's own column feed one 4x4x4 MFMA against the matching 4 x values of up to 4 x rows (natural k order: no x
 // permutation).  out = sum_g s_g * (sum_{k in g} x_k (w_k - z_g)), fp32 sums.
-template <typename T> struct Mma4;
-template <> struct Mma4<f16> {
-    typedef _Float16 v4 __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ f32x4 run(u32x2 a, u32x2 b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(v4, a), __builtin_bit_cast(v4, b), c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ unsigned short bits_of_int(int d) { return as_u16((f16)(short)d); }
-};
-template <> struct Mma4<bf16> {
-    typedef short v4 __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ f32x4 run(u32x2 a, u32x2 b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(v4, a), __builtin_bit_cast(v4, b), c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ unsigned short bits_of_int(int d) { return (unsigned short)(as_u32((float)d) >> 16); }  // exact
-};
-
 template <int BITS, typename T, int LN, int MT, int U>
 __global__ void __launch_bounds__(1024, 4) gemv_mfma_generic_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -952,11 +980,12 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     if (path == 1) pl.fast = false;
     // register-direct variants (no LDS staging): power-of-two packed rows per group, no x gather
     const int gu = L.group_size / 8;
-    const bool pow2_groups = pl.fast && gu > 0 && (gu & (gu - 1)) == 0;
+    const bool q4_16 = L.bits == 4 && !pl.perk && path != 1 && (L.dtype == GPTQ_F16 || L.dtype == GPTQ_BF16);
+    const bool pow2_groups = q4_16 && gu > 0 && (gu & (gu - 1)) == 0;
     const bool ln_ok = !(tune && tune->lanes_n && tune->lanes_n != 4);
-    // default for 4-bit fp16 layers; act-order layers (x gathered through perm) only with 16-column strips
-    pl.mfma = pow2_groups && (path == 0 || path == 5) && (!pl.use_seq || (ln_ok && L.K <= 24576));
-    pl.direct = pow2_groups && !pl.use_seq && path == 4;
+    // default for 4-bit fp16 / bf16 layers; act-order layers (x gathered through perm) and bf16 only with 16-column strips
+    pl.mfma = pow2_groups && (path == 0 || path == 5) && (!pl.use_seq || (ln_ok && L.K <= 24576)) && (L.dtype == GPTQ_F16 || ln_ok);
+    pl.direct = pow2_groups && L.dtype == GPTQ_F16 && !pl.use_seq && path == 4;
     // the other packings (and 4-bit bf16): matrix-core kernel with integer field extraction; 16-column strips only
     pl.mfmag = !pl.mfma && !pl.direct && (path == 0 || path == 5) && !pl.perk && !pl.use_seq && ln_ok &&
                (L.dtype == GPTQ_F16 || L.dtype == GPTQ_BF16) && !(L.bits == 4 && L.dtype == GPTQ_F16);
@@ -1124,22 +1153,22 @@ static hipError_t launch_direct_u(const GemvPlan& pl, const GemvParams& p, hipSt
     return hipGetLastError();
 }
 
-template <int LN, int MT>
+template <int LN, int MT, typename T>
 static hipError_t launch_mfma_u(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
     dim3 grid(pl.strips, pl.ksplit, pl.mtiles), block(pl.waves * 64);
     if (pl.use_seq) {
         if constexpr (LN == 4) {
             if (pl.pair) {
-                if (pl.u == 1) hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, true, true>), grid, block, pl.lds_bytes, st, p);
-                else hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, true, true>), grid, block, pl.lds_bytes, st, p);
+                if (pl.u == 1) hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, true, true, T>), grid, block, pl.lds_bytes, st, p);
+                else hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, true, true, T>), grid, block, pl.lds_bytes, st, p);
             } else if (pl.u == 1) {
-                hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, false, true>), grid, block, pl.lds_bytes, st, p);
+                hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, false, true, T>), grid, block, pl.lds_bytes, st, p);
             } else if (pl.u == 2) {
-                hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, false, true>), grid, block, pl.lds_bytes, st, p);
+                hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, false, true, T>), grid, block, pl.lds_bytes, st, p);
             } else if (pl.u == 4) {
-                hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 4, false, true>), grid, block, pl.lds_bytes, st, p);
+                hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 4, false, true, T>), grid, block, pl.lds_bytes, st, p);
             } else {
-                hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 8, false, true>), grid, block, pl.lds_bytes, st, p);
+                hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 8, false, true, T>), grid, block, pl.lds_bytes, st, p);
             }
             return hipGetLastError();
         } else {
@@ -1148,30 +1177,45 @@ static hipError_t launch_mfma_u(const GemvPlan& pl, const GemvParams& p, hipStre
     }
     if (pl.pair) {
         if constexpr (LN == 4) {
-            if (pl.u == 1) hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, true>), grid, block, pl.lds_bytes, st, p);
-            else hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, true>), grid, block, pl.lds_bytes, st, p);
+            if (pl.u == 1) hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, true, false, T>), grid, block, pl.lds_bytes, st, p);
+            else hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, true, false, T>), grid, block, pl.lds_bytes, st, p);
             return hipGetLastError();
         } else {
             return hipErrorInvalidValue;
         }
     }
     switch (pl.u) {
-        case 1: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1>), grid, block, pl.lds_bytes, st, p); break;
-        case 2: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2>), grid, block, pl.lds_bytes, st, p); break;
-        case 4: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 4>), grid, block, pl.lds_bytes, st, p); break;
-        case 8: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 8>), grid, block, pl.lds_bytes, st, p); break;
+        case 1: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, false, false, T>), grid, block, pl.lds_bytes, st, p); break;
+        case 2: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, false, false, T>), grid, block, pl.lds_bytes, st, p); break;
+        case 4: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 4, false, false, T>), grid, block, pl.lds_bytes, st, p); break;
+        case 8: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 8, false, false, T>), grid, block, pl.lds_bytes, st, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-template <int MT>
+template <int MT, typename T>
 static hipError_t launch_mfma_mt(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
-    switch (pl.ln) {
-        case 4: return launch_mfma_u<4, MT>(pl, p, st);
-        case 8: return launch_mfma_u<8, MT>(pl, p, st);
-        case 16: return launch_mfma_u<16, MT>(pl, p, st);
-        case 64: return launch_mfma_u<64, MT>(pl, p, st);
+    if constexpr (std::is_same_v<T, bf16>) {
+        return pl.ln == 4 ? launch_mfma_u<4, MT, T>(pl, p, st) : hipErrorInvalidValue;
+    } else {
+        switch (pl.ln) {
+            case 4: return launch_mfma_u<4, MT, T>(pl, p, st);
+            case 8: return launch_mfma_u<8, MT, T>(pl, p, st);
+            case 16: return launch_mfma_u<16, MT, T>(pl, p, st);
+            case 64: return launch_mfma_u<64, MT, T>(pl, p, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
+}
+
+template <typename T>
+static hipError_t launch_mfma_t(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
+    switch (pl.mt) {
+        case 1: return launch_mfma_mt<1, T>(pl, p, st);
+        case 2: return launch_mfma_mt<2, T>(pl, p, st);
+        case 4: return launch_mfma_mt<4, T>(pl, p, st);
+        case 8: return launch_mfma_mt<8, T>(pl, p, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1250,20 +1294,14 @@ hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x,
     p.chunk_units = pl.chunk_units; p.ksplit = pl.ksplit;
     {
         const int gu = L.group_size / 8;
-        p.gu_shift = (pl.fast && gu > 0 && (gu & (gu - 1)) == 0) ? __builtin_ctz((unsigned)gu) : -1;
+        p.gu_shift = ((pl.fast || pl.mfma) && gu > 0 && (gu & (gu - 1)) == 0) ? __builtin_ctz((unsigned)gu) : -1;
     }
 
     hipError_t e;
     if (pl.mfmag) {
         e = (L.dtype == GPTQ_F16) ? launch_mfmag<f16>(L, pl, p, st) : launch_mfmag<bf16>(L, pl, p, st);
     } else if (pl.mfma) {
-        switch (pl.mt) {
-            case 1: e = launch_mfma_mt<1>(pl, p, st); break;
-            case 2: e = launch_mfma_mt<2>(pl, p, st); break;
-            case 4: e = launch_mfma_mt<4>(pl, p, st); break;
-            case 8: e = launch_mfma_mt<8>(pl, p, st); break;
-            default: e = hipErrorInvalidValue;
-        }
+        e = (L.dtype == GPTQ_BF16) ? launch_mfma_t<bf16>(pl, p, st) : launch_mfma_t<f16>(pl, p, st);
     } else if (pl.direct) {
         switch (pl.mt) {
             case 1: e = launch_direct_mt<1>(pl, p, st); break;

@@ -423,6 +423,25 @@ def test_full_size_prefill_properties(K, N, M, act):
     assert float((y_ns.float() - ref).abs().max()) <= 2e-3 * scale
 
 
+@pytest.mark.parametrize("act", [False, True])
+@pytest.mark.parametrize("gs,K,N,M", [(128, 1024, 1024, 1), (128, 2048, 512, 3), (32, 512, 768, 2), (64, 1024, 96, 5),
+                                     (128, 4096, 256, 8), (1024, 1024, 256, 4), (128, 11008, 64, 1)])
+def test_matrix_core_gemv_bf16(gs, K, N, M, act):
+    """4-bit bf16 through the matrix-core GEMV: B = 128 + w (bf16 magic number), sum_k x_k from a ones MFMA, fp32 fix-up."""
+    L = O.random_quant_layer(K, N, 4, gs, dtype=torch.bfloat16, act_order=act, seed=K + N + M, bias=True)
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(9)) - 0.5).bfloat16()
+    for zm, mode in (("wrap", O.ZERO_WRAP), ("nowrap", O.ZERO_NOWRAP)):
+        q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, gs, zero_mode=zm)
+        y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, mode)
+        yref = O.forward(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, mode)
+        with torch.no_grad():
+            y = q(x.to(DEV), tuning=_tuning(path=5))
+        _assert_close(y, yref, y64, torch.bfloat16, K, f"bf16 mfma zero={zm}")
+        _assert_close(y, y64, y64, torch.bfloat16, K, f"bf16 mfma zero={zm} vs f64")
+        # fp32 sums: the only bf16 rounding is the output's -> error vs fp64 within one bf16 ulp of the result scale
+        assert float((y.double().cpu() - y64).abs().max()) <= 2.0 ** -8 * max(1.0, float(y64.abs().max()))
+
+
 @pytest.mark.parametrize("gs,K,N,M", [(128, 1024, 1024, 1), (128, 2048, 512, 3), (32, 512, 768, 2), (64, 1024, 96, 5),
                                      (128, 4096, 256, 8), (1024, 1024, 256, 4), (128, 11008, 64, 1)])
 @pytest.mark.parametrize("path", [4, 5])

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--gs", type=int, default=128)
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--heuristic-only", action="store_true")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--act", action="store_true", help="act-order layers (desc_act=True)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -44,8 +45,9 @@ def main():
         K, N = map(int, shp.split("x"))
         per = K * N * args.bits // 8
         nl = max(4, min(64, (640 << 20) // per))           # > 256 MiB of distinct weights
-        layers = [make_layer(K, N, dev, bits=args.bits, gs=args.gs, act_order=args.act, seed=i) for i in range(nl)]
-        x = (torch.rand(args.m, K, device=dev) - 0.5).half()
+        dt = torch.float16 if args.dtype == 'f16' else torch.bfloat16
+        layers = [make_layer(K, N, dev, bits=args.bits, gs=args.gs, act_order=args.act, dtype=dt, seed=i) for i in range(nl)]
+        x = (torch.rand(args.m, K, device=dev) - 0.5).to(dt)
         ab = algorithmic_bytes(K, N, args.m, bits=args.bits, gs=args.gs, act_order=args.act)
         cfgs = [dict()]  # heuristic
         lns = (4, 8, 16, 64)
@@ -58,7 +60,7 @@ def main():
                         cfgs.append(dict(lanes_n=ln, waves=waves, ksplit=ks, path=5))
         cfgs.append(dict(path=1))
         if args.heuristic_only:
-            cfgs = [dict(), dict(path=1)] + ([dict(path=2)] if args.bits == 4 else [])
+            cfgs = [dict(), dict(path=1)] + ([dict(path=2)] if args.bits == 4 and args.dtype == 'f16' else [])
         res = []
         for c in cfgs:
             t = _lib.GptqTuning()
