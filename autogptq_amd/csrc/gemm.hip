@@ -238,8 +238,12 @@ template <> struct Deq<4, bf16> {
 // v_perm.  The LDS image of a wave's 64 lanes is linear (8 rows x 128 B), so rows are unpadded and the bank spread comes
 // from an XOR swizzle applied to the SOURCE chunk: LDS slot s of row r holds k-chunk s ^ ((r >> 1) & 7); the A-fragment
 // reads apply the same XOR (16 distinct 16-byte units per ds_read_b128 lane group -> conflict free).
-template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, bool GLDS = false>
-__global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
+// KG = 2 (needs MT = 4): 8 waves; waves 4-7 are a second copy of the 1x4 arrangement working on the other half of the
+// block's K range with their own x buffers, and the two halves are summed through LDS at the end.  Used when the launch
+// has at most one 128x256 tile per CU: a CU then holds two waves per SIMD (what two co-resident workgroups would give a
+// larger problem), so one wave's dequant/LDS work fills the other's MFMA shadows, at the same weight/x traffic per flop.
+template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, bool GLDS = false, int KG = 1>
+__global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
     constexpr int KS = BK / 16;                // MFMA k-steps per K-step
     constexpr int BM = 32 * MT;
     static_assert(!GLDS || (XPRE && BK == 64), "the DMA staging needs pre-slotted x and 128-byte rows");
@@ -248,9 +252,12 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
     constexpr int CHUNKS = BM * CPR;
     constexpr int NTHR = 256;
     constexpr int NCH = (CHUNKS + NTHR - 1) / NTHR;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x BM x STRIDE
+    static_assert(KG == 1 || (KG == 2 && MT == 4), "K groups: 1, or 2 with the 128-row tile");
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];   // KG x 2 x BM x STRIDE
+    const int kg = KG == 1 ? 0 : (int)(threadIdx.x >> 8);
+    char* const smem = smem_all + (size_t)kg * (2 * BM * STRIDE);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
     // Logical tile order: column blocks 8 tiles wide, walked row by row, so the contiguous run of logical ids
     // an XCD receives is a compact (rows x 8 columns) patch: its L2 holds 8 weight panels and a few x panels
@@ -276,8 +283,13 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
     const unsigned* __restrict__ qcol = p.qweight + nl;
     const unsigned short* __restrict__ x = (const unsigned short*)p.x;
 
-    const int kt0 = blockIdx.y * p.ksteps_per_split;
-    const int kt1 = min(kt0 + p.ksteps_per_split, p.ksteps_total);
+    int kt0 = blockIdx.y * p.ksteps_per_split;
+    int kt1 = min(kt0 + p.ksteps_per_split, p.ksteps_total);
+    if constexpr (KG == 2) {                   // the planner only picks KG = 2 when every slice has an even step count
+        const int hs = (kt1 - kt0) >> 1;
+        kt0 += kg * hs;
+        kt1 = kt0 + hs;
+    }
 
     // A staging assignment: chunk c -> (row, 16-byte column)
     // Rows past M are clamped to row M-1 (never predicated: a predicated load splits the K-loop into several
@@ -383,6 +395,21 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
 
     const int a_lane_off = GLDS ? l31 * STRIDE : l31 * STRIDE + half * 16;
     const int a_swz = (l31 >> 1) & 7;                  // GLDS: XOR applied to the 16-byte slot index
+    // VAR == 3: fragments of the NEXT K-step's first MFMA k-step, produced under the last MFMAs of the current K-step
+    u32x4 a_first[MT], bq_first[2];
+    Deq<BITS, T> dq_cur;
+    auto read_a = [&](int buf, int ks, u32x4 (&dst)[MT]) {
+        const char* base = smem + buf * (BM * STRIDE) + a_lane_off;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            dst[mt] = *(const u32x4*)(base + mt * 32 * STRIDE + (GLDS ? (((ks * 2 + half) ^ a_swz) * 16) : ks * 32));
+    };
+    if constexpr (VAR == 3) {
+        dq_cur.setup(c0, p.zero_mode);
+        read_a(0, 0, a_first);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bq_first[nt] = dq_cur.frag(b0[0], nt, kt0 * BK + half * 8);
+    }
     auto step = [&](int kt, auto bufc, const BRaw<BITS> (&b_use)[KS], const CRaw& c_use, BRaw<BITS> (&b_fill)[KS], CRaw& c_fill) {
         constexpr int BUF = decltype(bufc)::value;
         const int ktn = min(kt + 1, kt1 - 1);          // last step re-loads itself (no branch in the pipeline)
@@ -392,6 +419,43 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
         load_c(ktn, c_fill);
         __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of this step's MFMAs
 
+        if constexpr (VAR == 3) {
+            // One continuous software pipeline across K-steps: the barrier sits in front of the LAST MFMA group of the
+            // step (its operands are already in registers), and right behind it the first A fragments of the next step
+            // are read and its first B fragments dequantised -- so the 8 MFMAs of that group cover the barrier wait, the
+            // LDS latency and the dequant, and a K-step starts with its MFMAs instead of a fragment-production bubble.
+            u32x4 a[2][MT], bq[2][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[0][mt] = a_first[mt];
+            bq[0][0] = bq_first[0];
+            bq[0][1] = bq_first[1];
+            Deq<BITS, T> dq_nx;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) {
+                    read_a(BUF, ks + 1, a[(ks + 1) & 1]);
+                } else {
+                    if constexpr (!GLDS) store_a(BUF ^ 1, a_next);
+                    __syncthreads();
+                    read_a(BUF ^ 1, 0, a_first);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) bq[(ks + 1) & 1][nt] = dq_cur.frag(b_use[ks + 1], nt, kt * BK + (ks + 1) * 16 + half * 8);
+                } else {
+                    dq_nx.setup(c_fill, p.zero_mode);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) bq_first[nt] = dq_nx.frag(b_fill[0], nt, ktn * BK + half * 8);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = Mma<T>::run(a[ks & 1][mt], bq[ks & 1][nt], acc[mt][nt]);
+            }
+            dq_cur = dq_nx;
+            return;
+        }
         Deq<BITS, T> dq;
         dq.setup(c_use, p.zero_mode);
         const char* abase = smem + BUF * (BM * STRIDE) + a_lane_off;
@@ -452,6 +516,40 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
         if (kt + 1 < kt1) step(kt + 1, std::integral_constant<int, 1>{}, b1, c1, b0, c0);
     }
 
+    if constexpr (KG == 2) {
+        // sum the two K halves through LDS (the x buffers are dead after the last barrier): group 1 hands rows 0-63 to
+        // group 0, then group 0 hands rows 64-127 to group 1; each group stores the half it completed.
+        float4* ex = (float4*)smem_all;        // [(mt, nt, quad)][256 threads] float4: lane-contiguous, conflict free
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (kg != pass) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x16& a = acc[pass * 2 + mt][nt];
+                            ex[((mt * 2 + nt) * 4 + q) * 256 + tid] = float4{a[q * 4], a[q * 4 + 1], a[q * 4 + 2], a[q * 4 + 3]};
+                        }
+            }
+            __syncthreads();
+            if (kg == pass) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 v = ex[((mt * 2 + nt) * 4 + q) * 256 + tid];
+                            f32x16& a = acc[pass * 2 + mt][nt];
+                            a[q * 4] += v.x; a[q * 4 + 1] += v.y; a[q * 4 + 2] += v.z; a[q * 4 + 3] += v.w;
+                        }
+            }
+            if (pass == 0) __syncthreads();
+        }
+    }
+
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     if (!col_ok) return;
     float bias0 = 0.f, bias1 = 0.f;
@@ -460,7 +558,8 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
         bias1 = DType<T>::to_f32(((const T*)p.bias)[n + 1]);
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+        if (KG == 2 && (mt >> 1) != kg) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -475,6 +574,7 @@ __global__ void __launch_bounds__(256, 2) gemm_kernel(GemmParams p) {
                 *(unsigned*)((unsigned short*)p.out + (size_t)m * p.N + n) = o;
             }
         }
+    }
 }
 
 // ---- skinny variant: 8 < M <= 128 (weight-streaming regime) --------------------------------------
@@ -709,15 +809,25 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.ksplit = (pl.ksteps_total + pl.ksteps_per_split - 1) / pl.ksteps_per_split;   // no empty slices
     pl.workspace_bytes = pl.xperm_bytes + (pl.ksplit > 1 ? (size_t)pl.ksplit * M * L.N * sizeof(float) : 0);
     // act-order + the 4-bit fp16 128x256x64 kernel: the permute pre-pass delivers x in k-slot order
-    pl.xslot = pl.use_seq && L.bits == 4 && L.dtype == GPTQ_F16 && pl.mt == 4 && pl.bk == 64 && (pl.variant == 0 || pl.variant == 5);
+    pl.xslot = pl.use_seq && L.bits == 4 && L.dtype == GPTQ_F16 && pl.mt == 4 && pl.bk == 64 && (pl.variant == 0 || pl.variant == 3 || pl.variant == 5 || pl.variant == 6 || pl.variant == 7);
     pl.glds = pl.xslot && pl.variant != 5;            // variant 5 (experiment): register-staged x
+    // At most one tile per CU: run the tile's K range as two concurrent halves inside the workgroup (8 waves).
+    const bool even_slices = pl.ksteps_total % pl.ksteps_per_split == 0 && pl.ksteps_per_split % 2 == 0 && pl.ksteps_per_split >= 4;
+    const bool kg_ok = L.bits == 4 && pl.bk == 64 && pl.mt == 4 && even_slices && (pl.variant == 0 || pl.variant == 6 || pl.variant == 7) &&
+                       (!pl.use_seq || pl.xslot == pl.glds);
+    pl.kg = (kg_ok && pl.variant != 6 && ((long)pl.nbm * pl.nbn * pl.ksplit <= 256 || pl.variant == 7)) ? 2 : 1;
     return pl;
 }
 
-template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, bool GLDS = false>
+template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, bool GLDS = false, int KG = 1>
 static hipError_t launch_one(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
-    const size_t lds = (size_t)2 * (32 * MT) * (GLDS ? BK * 2 : BK * 2 + 16);
-    hipLaunchKernelGGL((gemm_kernel<BITS, T, MT, BK, VAR, XPRE, GLDS>), dim3(pl.nbm * pl.nbn, pl.ksplit), dim3(256), lds, st, p);
+    const size_t lds = (size_t)KG * 2 * (32 * MT) * (GLDS ? BK * 2 : BK * 2 + 16);   // KG = 2: >= the 64 KiB exchange area
+    auto* kern = gemm_kernel<BITS, T, MT, BK, VAR, XPRE, GLDS, KG>;
+    if constexpr (KG == 2) {
+        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return attr;
+    }
+    hipLaunchKernelGGL(kern, dim3(pl.nbm * pl.nbn, pl.ksplit), dim3(256 * KG), lds, st, p);
     return hipGetLastError();
 }
 
@@ -744,7 +854,15 @@ static hipError_t launch_bits(const GemmPlan& pl, const GemmParams& p, hipStream
     if (pl.skinny) return launch_skinny<BITS, T>(pl, p, st);
     if constexpr (BITS == 4) {
         if (pl.bk == 64) {
+            if (pl.kg == 2) {
+                if constexpr (std::is_same_v<T, f16>) {
+                    if (pl.xslot && pl.glds) return launch_one<BITS, T, 4, 64, 1, true, true, 2>(pl, p, st);
+                }
+                return launch_one<BITS, T, 4, 64, 1, false, false, 2>(pl, p, st);
+            }
             if constexpr (std::is_same_v<T, f16>) {
+                if (pl.variant == 3) return (pl.xslot && pl.glds) ? launch_one<BITS, T, 4, 64, 3, true, true>(pl, p, st)
+                                                                  : launch_one<BITS, T, 4, 64, 3>(pl, p, st);   // experiment: cross-step pipeline
                 if (pl.xslot && pl.glds) return launch_one<BITS, T, 4, 64, 1, true, true>(pl, p, st);
                 if (pl.xslot) return launch_one<BITS, T, 4, 64, 1, true>(pl, p, st);
                 if (pl.variant == 1) return launch_one<BITS, T, 4, 64, 0>(pl, p, st);   // experiment: plain loop

@@ -27,6 +27,7 @@ struct GemmPlan {
     bool xslot;               // act-order: the x pre-pass writes k-slot order, the kernel copies x to LDS verbatim
     bool skinny;              // weight-streaming decomposition for 8 < M <= 128 (64-column strips, waves split K)
     int waves, variant;
+    int kg;                   // K groups inside a workgroup (2 = 8 waves, two K halves summed through LDS)
     int mt, bk, bm, bn;       // row tiles per wave, K-step, workgroup tile
     int nbm, nbn, ksplit, ksteps_total, ksteps_per_split;
     size_t xperm_bytes;       // permuted-x scratch for act-order layers (front of the workspace)

@@ -371,6 +371,57 @@ def test_gemm_split_k_agrees_and_is_deterministic(ksplit):
     _assert_close(y1, y64, y64, torch.float16, K, f"ksplit={ksplit}")
 
 
+@pytest.mark.parametrize("act", [False, True])
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_gemm_schedule_variants(variant, act):
+    """tuning.reserved[3] selects an instruction schedule of the big-tile kernel (1 plain, 2 setprio, 3 cross-step
+    pipeline).  Without act-order all of them accumulate the same products in the same order: bit-identical."""
+    K, N, M = 1024, 512, 300
+    L = O.random_quant_layer(K, N, 4, 128, act_order=act, seed=31 + variant, bias=True)
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(3)) - 0.5).half().to(DEV)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, 128, zero_mode="wrap")
+    t = _tuning(path=3)
+    t.reserved[3] = variant
+    t6 = _tuning(path=3)
+    t6.reserved[3] = 6
+    with torch.no_grad():
+        y0 = q(x, tuning=t6)
+        y1 = q(x, tuning=t)
+    if not act:
+        assert torch.equal(y0, y1)
+    y64 = O.forward_f64(x.cpu(), L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP)
+    _assert_close(y1, y64, y64, torch.float16, K, f"variant {variant}")
+
+
+@pytest.mark.parametrize("dtype,act,K,N,M,ksplit", [
+    (torch.float16, False, 1024, 512, 300, 0), (torch.float16, True, 1024, 512, 300, 0), (torch.bfloat16, False, 2048, 256, 130, 0),
+    (torch.bfloat16, True, 1024, 256, 128, 0), (torch.float16, False, 2048, 320, 97, 2), (torch.float16, True, 4096, 4096, 2048, 0),
+    (torch.float16, False, 4096, 4096, 1500, 0)])
+def test_gemm_k_groups_inside_workgroup(dtype, act, K, N, M, ksplit):
+    """8-wave form of the big-tile kernel (two K halves per workgroup summed through LDS; the planner picks it when a launch
+    has at most one tile per CU, reserved[3] = 7 / 6 force it on / off): against the fp64 oracle on a row/column sample and
+    against the 4-wave form everywhere; bit-reproducible."""
+    L = O.random_quant_layer(K, N, 4, 128, act_order=act, seed=K + N + M, bias=True, dtype=dtype)
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(4)) - 0.5).to(dtype).to(DEV)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, 128, zero_mode="wrap")
+    t6, t7 = _tuning(path=3, ksplit=ksplit), _tuning(path=3, ksplit=ksplit)
+    t6.reserved[3], t7.reserved[3] = 6, 7
+    with torch.no_grad():
+        y6 = q(x, tuning=t6)
+        y7 = q(x, tuning=t7)
+        y7b = q(x, tuning=t7)
+        y_auto = q(x)
+    assert torch.equal(y7, y7b)
+    if ksplit == 0:
+        assert torch.equal(y_auto, y7), "at most one tile per CU here: auto dispatch must pick the 8-wave form"
+    rows = torch.arange(0, M, max(1, M // 61))
+    cols = slice(0, min(N, 512))
+    y64 = O.forward_f64(x[rows].cpu(), L["qweight"][:, cols], L["qzeros"][:, : cols.stop * 4 // 32], L["scales"][:, cols], L["g_idx"],
+                        L["bias"][cols], 4, O.ZERO_WRAP)
+    _assert_close(y7[rows][:, cols], y64, y64, dtype, K, "8-wave vs f64")
+    _assert_close(y7, y6.double(), y64, dtype, K, "8-wave vs 4-wave")
+
+
 def test_gemm_matches_gemv_paths():
     """The three kernels (generic GEMV, fast GEMV, MFMA GEMM) are three summation orders of the same
     exactly-dequantised products."""
@@ -416,9 +467,11 @@ def test_full_size_prefill_properties(K, N, M, act):
     _assert_close(y[rows][:, sl], y64, y64, torch.float16, K, "prefill rows vs f64")
     # (c) a 128-aligned row block on its own
     r0 = (M // 2) // 128 * 128
+    t = _tuning(path=3, ksplit=1)
+    t.reserved[3] = 6                  # same K decomposition for both launches (no K groups inside the workgroup)
     with torch.no_grad():
-        y_ns = q(x, tuning=_tuning(path=3, ksplit=1))
-        yblk = q(x[r0:r0 + 128].contiguous(), tuning=_tuning(path=3, ksplit=1))
+        y_ns = q(x, tuning=t)
+        yblk = q(x[r0:r0 + 128].contiguous(), tuning=t)
     assert torch.equal(yblk, y_ns[r0:r0 + 128])
     assert float((y_ns.float() - ref).abs().max()) <= 2e-3 * scale
 

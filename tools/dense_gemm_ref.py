@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Context number for DESIGN.md: what the vendor dense GEMM (torch.matmul -> hipBLASLt) reaches on this GPU for the prefill
+shapes, with fp16/bf16 weights already dequantised (i.e. the path "dequantise once, then dense GEMM", 4x the weight bytes).
+Weights are rotated through > 256 MiB so they do not sit in the Infinity Cache between launches."""
+import sys
+import torch
+
+def main():
+    dev = torch.device("cuda:0")
+    shapes = [(2048, 4096, 4096), (2048, 4096, 11008), (2048, 11008, 4096), (4096, 4096, 4096), (512, 4096, 4096)]
+    for dtype in (torch.float16, torch.bfloat16):
+        for M, K, N in shapes:
+            nl = max(2, (300 << 20) // (K * N * 2))
+            W = [(torch.rand(K, N, device=dev) - 0.5).to(dtype) for _ in range(nl)]
+            x = (torch.rand(M, K, device=dev) - 0.5).to(dtype)
+            out = torch.empty(M, N, device=dev, dtype=dtype)
+            for w in W:
+                torch.matmul(x, w, out=out)
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for w in W:
+                    torch.matmul(x, w, out=out)
+                e1.record()
+                torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) / nl)
+            print(f"{str(dtype):16s} M={M} K={K} N={N}: {best * 1e3:8.1f} us  {2 * M * K * N / best / 1e9:7.1f} TFLOP/s", flush=True)
+
+if __name__ == "__main__":
+    sys.exit(main())

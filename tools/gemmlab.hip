@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
         printf("== M=%d K=%d N=%d : %.2f GFLOP per launch\n", M, K, N, 2.0 * M * K * N / 1e9);
         struct V { int id; const char* name; gptq_layer_t L; gptq_tuning_t tu; GemmPlan pl; double us; };
         std::vector<V> vs;
-        for (int variant = 0; variant < 14; ++variant) {
+        for (int variant = 0; variant < 20; ++variant) {
             if (only_variant >= 0 && variant != only_variant) continue;
             V v{}; v.id = variant; v.us = 1e30;
             gptq_layer_t& L = v.L;
@@ -72,6 +72,12 @@ int main(int argc, char** argv) {
             if (variant == 3) { if (M > 128) continue; v.tu.reserved[2] = 1; v.name = "forced skinny"; }
             if (variant == 4) { if (M > 128) continue; v.tu.reserved[2] = 2; v.name = "forced tiled"; }
             if (variant == 12) { if (M < 512) continue; L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.tu.reserved[3] = 5; v.name = "act-order, register-staged x (no DMA)"; }
+            if (variant == 14) { if (M < 512) continue; v.tu.reserved[3] = 3; v.name = "VAR3 cross-step pipeline"; }
+            if (variant == 15) { if (M < 512) continue; L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.tu.reserved[3] = 3; v.name = "VAR3 cross-step pipeline, act-order + DMA"; }
+            if (variant == 16) { if (M < 128) continue; v.tu.reserved[3] = 6; v.name = "KG=1 forced (4 waves)"; }
+            if (variant == 17) { if (M < 128) continue; v.tu.reserved[3] = 7; v.name = "KG=2 forced (8 waves, K halves)"; }
+            if (variant == 18) { if (M < 128) continue; L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.tu.reserved[3] = 6; v.name = "KG=1 forced, act-order + DMA"; }
+            if (variant == 19) { if (M < 128) continue; L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.tu.reserved[3] = 7; v.name = "KG=2 forced, act-order + DMA"; }
             if (variant == 13) { if (M < 512) continue; L.dtype = GPTQ_BF16; v.name = "bf16 (bit patterns reused: timing only)"; }
             if (variant == 2) { L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.name = "act-order (x permute + qweight_seq)"; }
             v.pl = plan_gemm(L, M, &v.tu);
@@ -82,7 +88,7 @@ int main(int argc, char** argv) {
             for (int i = 0; i < nl; ++i) {
                 gptq_layer_t L = v.L;
                 L.qweight = qw + (size_t)i * qw_b / 4; L.qzeros = qz + (size_t)i * qz_b / 4; L.scales = sc + (size_t)i * sc_b / 2;
-                L.qweight_seq = (v.id == 2 || v.id == 12) ? L.qweight : nullptr;
+                L.qweight_seq = (v.id == 2 || v.id == 12 || v.id == 15 || v.id >= 18) ? L.qweight : nullptr;
                 hipError_t e = launch_gemm(L, v.pl, x, out, M, ws, st);
                 if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); exit(1); }
             }
