@@ -28,6 +28,7 @@ EXPORTS = (
     "gptq_forward", "gptq_forward_ex", "gptq_gemv", "gptq_gemm", "gptq_dequant",
     "gptq_unpack_weights", "gptq_unpack_zeros", "gptq_pack_weights", "gptq_pack_zeros",
     "gptq_make_sequential", "gptq_resequence_qweight", "gptq_permute_columns",
+    "gptq_awq_unpack", "gptq_awq_repack",
 )
 
 
@@ -91,6 +92,8 @@ def load() -> ctypes.CDLL:
     lib.gptq_make_sequential.argtypes = [c_void_p, c_int, c_int, c_void_p, POINTER(c_int)]
     lib.gptq_resequence_qweight.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.gptq_permute_columns.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.gptq_awq_unpack.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    lib.gptq_awq_repack.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     for name in EXPORTS:
         if name not in ("gptq_last_error", "gptq_status_string", "gptq_workspace_bytes", "gptq_workspace_bytes_ex"):
             getattr(lib, name).restype = c_int

@@ -271,4 +271,31 @@ int gptq_permute_columns(const void* x, const int32_t* perm, int M, int K, int d
     return GPTQ_OK;
 }
 
+static int awq_shape_check(int K, int N, int group_size) {
+    if (K <= 0 || N <= 0 || group_size <= 0) return fail(GPTQ_ERR_SHAPE, "K (%d), N (%d), group_size (%d) must be > 0", K, N, group_size);
+    if (K % 8 || N % 8) return fail(GPTQ_ERR_SHAPE, "K (%d) and N (%d) must be multiples of 8 (4-bit words)", K, N);
+    if (K % group_size) return fail(GPTQ_ERR_SHAPE, "K (%d) must be a multiple of group_size (%d)", K, group_size);
+    return GPTQ_OK;
+}
+
+int gptq_awq_unpack(const uint32_t* awq_qweight, const uint32_t* awq_qzeros, const void* awq_scales, int K, int N,
+                    int group_size, void* weight_kn_out, int8_t* zeros_out, void* stream) {
+    if (!awq_qweight || !awq_qzeros || !awq_scales || !weight_kn_out || !zeros_out)
+        return fail(GPTQ_ERR_NULL, "awq_qweight/awq_qzeros/awq_scales/weight_kn_out/zeros_out must be non-NULL");
+    if (int rc = awq_shape_check(K, N, group_size)) return rc;
+    hipError_t e = launch_awq_unpack(awq_qweight, awq_qzeros, awq_scales, K, N, group_size, weight_kn_out, zeros_out, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_awq_unpack launch");
+    return GPTQ_OK;
+}
+
+int gptq_awq_repack(const uint32_t* awq_qweight, const uint32_t* awq_qzeros, int K, int N, int group_size,
+                    uint32_t* qweight_out, uint32_t* qzeros_out, void* stream) {
+    if (!awq_qweight || !awq_qzeros || !qweight_out || !qzeros_out)
+        return fail(GPTQ_ERR_NULL, "awq_qweight/awq_qzeros/qweight_out/qzeros_out must be non-NULL");
+    if (int rc = awq_shape_check(K, N, group_size)) return rc;
+    hipError_t e = launch_awq_repack(awq_qweight, awq_qzeros, K, N, group_size, qweight_out, qzeros_out, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_awq_repack launch");
+    return GPTQ_OK;
+}
+
 }  // extern "C"

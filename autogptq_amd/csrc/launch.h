@@ -46,6 +46,8 @@ hipError_t launch_pack_weights(const void* W, const void* scale_in, const void* 
 hipError_t launch_pack_zeros(const void* zero_in, int G, int N, int bits, int qparam_dtype, uint32_t* qzeros_out, hipStream_t st);
 hipError_t launch_resequence(const uint32_t* qweight, const int32_t* perm, int K, int N, int bits,
                              uint32_t* out, hipStream_t st);
+hipError_t launch_awq_unpack(const uint32_t* aq, const uint32_t* az, const void* scales, int K, int N, int group_size, void* w_kn, int8_t* zeros, hipStream_t st);
+hipError_t launch_awq_repack(const uint32_t* aq, const uint32_t* az, int K, int N, int group_size, uint32_t* qweight, uint32_t* qzeros, hipStream_t st);
 hipError_t launch_silu_mul(const void* y, void* out, int M, int N, int dtype, hipStream_t st);
 hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int K, void* x_out, hipStream_t st, bool slot_order = false);
 hipError_t launch_permute_columns(const void* x, const int32_t* perm, int M, int K, int dtype, void* x_out, hipStream_t st);

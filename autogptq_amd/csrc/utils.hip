@@ -323,6 +323,97 @@ hipError_t launch_resequence(const uint32_t* qweight, const int32_t* perm, int K
     return hipGetLastError();
 }
 
+// ---- AWQ ingest (auto_gptq/modeling/_utils.py:525-701) -------------------------------------------------------------
+// AutoAWQ packs column 8c + {0,2,4,6,1,3,5,7}[p] into nibble p of word c; so column 8c + i sits at nibble {0,4,1,5,2,6,3,7}[i]
+// (the permutation awq_reverse_reorder_int_tensor applies, _utils.py:533-553).  One lane = one AWQ word column (8 output
+// columns): 4-byte loads and 16/32-byte stores, both contiguous across the wave.
+__device__ __forceinline__ unsigned awq_nibble(unsigned word, int i) {
+    const int pos = ((i & 1) << 2) | (i >> 1);               // {0,4,1,5,2,6,3,7}[i]
+    return (word >> (4 * pos)) & 15u;
+}
+
+// unpack_awq (_utils.py:556-621): w_kn[k, n] = half(w * s) - half(z * s), zeros[g, n] = z; grid.y walks k
+__global__ void __launch_bounds__(256) awq_unpack_kernel(const unsigned* __restrict__ aq, const unsigned* __restrict__ az,
+                                                         const f16* __restrict__ scales, int K, int N, int group_size,
+                                                         f16* __restrict__ w_kn, signed char* __restrict__ zeros) {
+    const int NW = N / 8;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= NW) return;
+    for (int k = blockIdx.y; k < K; k += gridDim.y) {
+        const int g = k / group_size;
+        const unsigned qw = aq[(size_t)k * NW + c], qz = az[(size_t)g * NW + c];
+        const u32x4 sraw = *(const u32x4*)(scales + (size_t)g * N + c * 8);
+        u32x4 o;
+        unsigned zb[2] = {0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned sbits = (sraw[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+            const float sf = (float)__builtin_bit_cast(f16, (unsigned short)sbits);
+            const unsigned w = awq_nibble(qw, i), z = awq_nibble(qz, i);
+            const f16 ws = (f16)((float)w * sf);             // int8 * half -> half (one rounding)
+            const f16 zs = (f16)((float)z * sf);
+            const f16 d = (f16)((float)ws - (float)zs);      // half - half -> half
+            const unsigned db = (unsigned)__builtin_bit_cast(unsigned short, d);
+            if (i & 1) o[i >> 1] |= db << 16; else o[i >> 1] = db;
+            zb[i >> 2] |= z << (8 * (i & 3));
+        }
+        *(u32x4*)(w_kn + (size_t)k * N + c * 8) = o;
+        if (k % group_size == 0) *(uint2*)(zeros + (size_t)g * N + c * 8) = uint2{zb[0], zb[1]};
+    }
+}
+
+// unpack_awq + pack_from_tensors as one integer pass: 8 AWQ rows x 1 word column -> 1 GPTQ packed row x 8 columns
+__global__ void __launch_bounds__(256) awq_repack_kernel(const unsigned* __restrict__ aq, int K, int N, unsigned* __restrict__ qweight) {
+    const int NW = N / 8;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= NW) return;
+    for (int r = blockIdx.y; r < K / 8; r += gridDim.y) {
+        unsigned a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = __builtin_nontemporal_load(aq + (size_t)(r * 8 + j) * NW + c);
+        unsigned o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            unsigned v = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v |= awq_nibble(a[j], i) << (4 * j);
+            o[i] = v;
+        }
+        u32x4* dst = (u32x4*)(qweight + (size_t)r * N + c * 8);
+        dst[0] = u32x4{o[0], o[1], o[2], o[3]};
+        dst[1] = u32x4{o[4], o[5], o[6], o[7]};
+    }
+}
+
+// GPTQ qzeros word (g, c): field i = (z[g, 8c + i] - 1) & 15   (pack_from_tensors, _utils.py:679-680)
+__global__ void __launch_bounds__(256) awq_repack_zeros_kernel(const unsigned* __restrict__ az, int total, unsigned* __restrict__ qzeros) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const unsigned q = az[t];
+    unsigned v = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v |= ((awq_nibble(q, i) - 1u) & 15u) << (4 * i);
+    qzeros[t] = v;
+}
+
+hipError_t launch_awq_unpack(const uint32_t* aq, const uint32_t* az, const void* scales, int K, int N, int group_size, void* w_kn,
+                             int8_t* zeros, hipStream_t st) {
+    const int NW = N / 8;
+    dim3 grid((NW + 255) / 256, K < 4096 ? K : 4096), block(256);
+    hipLaunchKernelGGL(awq_unpack_kernel, grid, block, 0, st, aq, az, (const f16*)scales, K, N, group_size, (f16*)w_kn, (signed char*)zeros);
+    return hipGetLastError();
+}
+
+hipError_t launch_awq_repack(const uint32_t* aq, const uint32_t* az, int K, int N, int group_size, uint32_t* qweight, uint32_t* qzeros,
+                             hipStream_t st) {
+    const int NW = N / 8, R = K / 8;
+    dim3 grid((NW + 255) / 256, R < 4096 ? R : 4096), block(256);
+    hipLaunchKernelGGL(awq_repack_kernel, grid, block, 0, st, aq, K, N, qweight);
+    const int total = (K / group_size) * NW;
+    hipLaunchKernelGGL(awq_repack_zeros_kernel, dim3((total + 255) / 256), dim3(256), 0, st, az, total, qzeros);
+    return hipGetLastError();
+}
+
 hipError_t launch_permute_columns(const void* x, const int32_t* perm, int M, int K, int dtype, void* x_out, hipStream_t st) {
     if (dtype != GPTQ_F32 && K % 8 == 0 && (size_t)K * 2 <= 64 * 1024) return launch_permute_rows16(x, perm, M, K, x_out, st);
     dim3 grid((K + 255) / 256, M < 1024 ? M : 1024), block(256);

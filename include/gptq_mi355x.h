@@ -160,6 +160,21 @@ int gptq_resequence_qweight(const uint32_t *qweight, const int32_t *perm, int K,
 /* x_out[m, i] = x[m, perm[i]] */
 int gptq_permute_columns(const void *x, const int32_t *perm, int M, int K, int dtype, void *x_out, void *stream);
 
+/* ---- AWQ checkpoint ingest (4-bit only, as the reference: auto_gptq/modeling/_utils.py:525-701) ----------------
+ * AWQ side: awq_qweight u32 [K, N/8] (nibble p of word c = column 8c + {0,2,4,6,1,3,5,7}[p]), awq_qzeros u32 [G, N/8]
+ * (same order, raw zero-point, no -1), awq_scales fp16 [G, N] (= the GPTQ `scales` tensor, passed through unchanged).
+ *
+ * gptq_awq_unpack replaces unpack_awq (_utils.py:556-621): weight_kn_out fp16 [K, N] =
+ *   half(w * s) - half(z * s)   (each product and the difference rounded to fp16 once, the reference's op order);
+ *   the reference returns its transpose view [N, K].  zeros_out int8 [G, N] = the raw zero-points in natural column order.
+ * gptq_awq_repack is unpack_awq + pack_from_tensors (_utils.py:624-701) as one integer pass: GPTQ qweight_out u32 [K/8, N]
+ *   (nibble j of word r = w[8r + j, n]) and qzeros_out u32 [G, N/8] (field = (z - 1) & 15).  Identical to the reference's
+ *   fp16 round trip whenever that round trip is faithful (finite, normal scales; tests/golden/awq_*.npz). */
+int gptq_awq_unpack(const uint32_t *awq_qweight, const uint32_t *awq_qzeros, const void *awq_scales, int K, int N,
+                    int group_size, void *weight_kn_out, int8_t *zeros_out, void *stream);
+int gptq_awq_repack(const uint32_t *awq_qweight, const uint32_t *awq_qzeros, int K, int N, int group_size,
+                    uint32_t *qweight_out, uint32_t *qzeros_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@ Bars:  integer unpack / pack / dequant -> bit-exact.
        the exact-math (fp64) result as the reference's own fp16 CPU path is.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -617,3 +618,77 @@ def test_row_and_column_shards_on_one_gpu():
         rows = [RowParallelQuantLinear.from_full(full, r, T, device=DEV, input_is_parallel=False) for r in range(T)]
         part = sum(rp.local(x[:, rp.k0:rp.k1].contiguous()).float() for rp in rows) + L["bias"].float().to(DEV)
         _assert_close(part.half(), y64, y64, torch.float16, K, "row shards")
+
+
+# ------------------------------------------------------------------- AWQ ingest (auto_gptq/modeling/_utils.py:525-701)
+AWQ_GOLDEN = ["awq_k128_n64_g32.npz", "awq_k256_n128_g128.npz", "awq_k64_n64_g32_zero_edges.npz"]
+_GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("fname", AWQ_GOLDEN)
+def test_awq_ingest_matches_reference_outputs(fname):
+    """gptq_awq_unpack / gptq_pack_* / gptq_awq_repack against what the reference's unpack_awq and pack_from_tensors
+    themselves returned for the same AWQ words (tests/golden/make_golden_awq.py): every array bit for bit."""
+    from autogptq_amd import awq
+    d = np.load(os.path.join(_GOLDEN_DIR, fname))
+    gs = int(d["group_size"])
+    aq, az, sc = (torch.from_numpy(d[k]) for k in ("awq_qweight", "awq_qzeros", "scales"))
+    W, Z = awq.unpack_awq(aq, az, sc, 4, gs)
+    assert W.dtype == torch.float16 and Z.dtype == torch.int8 and tuple(W.shape) == (int(d["N"]), int(d["K"]))
+    assert np.array_equal(W.contiguous().cpu().numpy().view(np.uint16), d["fp16_weight"].view(np.uint16))
+    assert np.array_equal(Z.cpu().numpy(), d["zeros"])
+    qw, qz = awq.pack_from_tensors(W, Z, sc, 4, gs)
+    assert np.array_equal(qw.cpu().numpy(), d["qweight"]) and np.array_equal(qz.cpu().numpy(), d["qzeros"])
+    qw2, qz2 = awq.repack_awq_to_gptq(aq, az, gs)
+    assert np.array_equal(qw2.cpu().numpy(), d["qweight"]) and np.array_equal(qz2.cpu().numpy(), d["qzeros"])
+    zt = torch.from_numpy(np.ascontiguousarray(d["z"].astype(np.int8).T))         # [N, G]: the function transposes first
+    from oracle import awq_oracle as A
+    assert np.array_equal(awq.awq_reverse_reorder_int_tensor(zt.to(DEV), 4).cpu().numpy(), A.reverse_reorder(zt.numpy()))
+
+
+@pytest.mark.parametrize("K,N,gs", [(1024, 512, 128), (4096, 4096, 128), (11008, 4096, 128), (512, 2056, 64), (64, 8, 8)])
+def test_awq_ingest_random_vs_oracle(K, N, gs):
+    """Llama-7B sizes and ragged widths (N/8 not a multiple of the block): the integer repack against the numpy oracle on
+    every word; the fp16 unpack on a row sample; and the round trip unpack -> pack_from_tensors == repack (a property that
+    needs no oracle, checked at full size)."""
+    from autogptq_amd import awq
+    from oracle import awq_oracle as A
+    rng = np.random.default_rng(K + N)
+    G = K // gs
+    aq = rng.integers(-2**31, 2**31 - 1, size=(K, N // 8), dtype=np.int64).astype(np.int32)
+    az = rng.integers(-2**31, 2**31 - 1, size=(G, N // 8), dtype=np.int64).astype(np.int32)
+    sc = (0.002 * (1 + rng.random((G, N)))).astype(np.float16)
+    qw, qz = awq.repack_awq_to_gptq(torch.from_numpy(aq), torch.from_numpy(az), gs)
+    eqw, eqz = A.awq_to_gptq(aq, az)
+    assert np.array_equal(qw.cpu().numpy(), eqw) and np.array_equal(qz.cpu().numpy(), eqz)
+    W, Z = awq.unpack_awq(torch.from_numpy(aq), torch.from_numpy(az), torch.from_numpy(sc), 4, gs)
+    rows = np.unique(np.concatenate([np.arange(0, K, max(1, K // 97)), [K - 1]]))
+    Wo, Zo = A.unpack_awq(aq[rows], az[rows // gs], sc[rows // gs], 1)          # row k with its own group row: group_size 1
+    assert np.array_equal(W.T[torch.from_numpy(rows).to(DEV)].cpu().numpy().view(np.uint16), Wo.T.view(np.uint16))
+    assert np.array_equal(Z.cpu().numpy()[rows // gs], Zo)
+    if K % 32 == 0 and N % 32 == 0:        # pack() geometry of the reference (qlinear_cuda.py:39-40)
+        qw3, qz3 = awq.pack_from_tensors(W, Z, torch.from_numpy(sc), 4, gs)
+        assert torch.equal(qw3, qw) and torch.equal(qz3, qz)
+
+
+def test_awq_ingested_layer_forward():
+    """End to end: AWQ words -> gptq_awq_repack -> QuantLinear (cuda_old zero convention, the one that maps the stored
+    (z - 1) & 15 back to z) -> forward == x @ (s * (w - z)) of the AWQ checkpoint, including z = 0 and z = 15."""
+    from autogptq_amd import awq
+    from oracle import awq_oracle as A
+    rng = np.random.default_rng(9)
+    K, N, gs = 1024, 768, 128
+    w = rng.integers(0, 16, size=(K, N))
+    z = rng.integers(0, 16, size=(K // gs, N))
+    z[0, :16], z[1, :16] = 0, 15
+    s = torch.from_numpy((0.002 * (1 + rng.random((K // gs, N)))).astype(np.float16))
+    qw, qz = awq.repack_awq_to_gptq(torch.from_numpy(A.awq_pack(w)), torch.from_numpy(A.awq_pack(z)), gs)
+    q = _module_from(qw.cpu(), qz.cpu(), s, None, None, 4, gs, zero_mode="wrap")
+    Wd = torch.from_numpy(w - np.repeat(z, gs, axis=0)).double() * s.double().repeat_interleave(gs, 0)
+    assert torch.equal(q.dequantize().cpu(), Wd.to(torch.float16))
+    for M in (1, 4, 48, 300):
+        x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).half()
+        y64 = x.double() @ Wd
+        with torch.no_grad():
+            y = q(x.to(DEV))
+        _assert_close(y, y64, y64, torch.float16, K, f"AWQ-ingested layer, M={M}")

@@ -130,3 +130,41 @@ def test_c_oracle_random_words(bits):
     for mode in (O.ZERO_WRAP, O.ZERO_NOWRAP):
         assert np.array_equal(C.unpack_zeros(L["qzeros"].numpy(), bits, mode == O.ZERO_NOWRAP),
                               O.unpack_zeros(L["qzeros"], bits, mode))
+
+
+# ---------------------------------------------------------------- AWQ ingest (auto_gptq/modeling/_utils.py:525-701)
+AWQ_GOLDEN = ["awq_k128_n64_g32.npz", "awq_k256_n128_g128.npz", "awq_k64_n64_g32_zero_edges.npz"]
+
+
+@pytest.mark.parametrize("fname", AWQ_GOLDEN)
+def test_awq_oracle_matches_reference_outputs(golden_dir, fname):
+    """tests/golden/awq_*.npz hold what the reference's unpack_awq / pack_from_tensors returned (make_golden_awq.py);
+    the numpy restatement must reproduce every array bit for bit, and the one-pass integer composition must agree."""
+    from oracle import awq_oracle as A
+    d = np.load(os.path.join(golden_dir, fname))
+    gs = int(d["group_size"])
+    assert np.array_equal(A.awq_pack(d["w"].astype(np.int64)), d["awq_qweight"])
+    assert np.array_equal(A.awq_pack(d["z"].astype(np.int64)), d["awq_qzeros"])
+    W, Z = A.unpack_awq(d["awq_qweight"], d["awq_qzeros"], d["scales"], gs)
+    assert np.array_equal(W.view(np.uint16), d["fp16_weight"].view(np.uint16))
+    assert Z.dtype == np.int8 and np.array_equal(Z, d["zeros"])
+    qw, qz = A.pack_from_tensors(d["fp16_weight"], d["zeros"], d["scales"], gs)
+    assert np.array_equal(qw, d["qweight"]) and np.array_equal(qz, d["qzeros"])
+    qw2, qz2 = A.awq_to_gptq(d["awq_qweight"], d["awq_qzeros"])
+    assert np.array_equal(qw2, d["qweight"]) and np.array_equal(qz2, d["qzeros"])
+
+
+def test_awq_ingested_layer_dequantises_to_awq_weights():
+    """GPTQ fields (z - 1) & 15 read back with the +1-then-mask convention (cuda_old) give z again, also for z = 0 and 15:
+    the ingested layer's W equals AWQ's s * (w - z)."""
+    from oracle import awq_oracle as A
+    rng = np.random.default_rng(3)
+    K, N, gs = 128, 64, 32
+    w = rng.integers(0, 16, size=(K, N))
+    z = rng.integers(0, 16, size=(K // gs, N))
+    z[0, :4], z[1, :4] = 0, 15
+    s = torch.from_numpy((0.002 * (1 + rng.random((K // gs, N)))).astype(np.float16))
+    qw, qz = A.awq_to_gptq(A.awq_pack(w), A.awq_pack(z))
+    W = O.dequantize(torch.from_numpy(qw), torch.from_numpy(qz), s, None, 4, O.ZERO_WRAP)
+    expect = (torch.from_numpy(w - np.repeat(z, gs, axis=0)).to(torch.float16) * s.repeat_interleave(gs, 0))
+    assert torch.equal(W, expect)
