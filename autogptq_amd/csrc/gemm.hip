@@ -688,6 +688,159 @@ __global__ void __launch_bounds__(512) gemm_skinny_kernel(GemmParams p) {
     }
 }
 
+// ---- 16-column strips for 8 < M <= 64, 4-bit fp16 / bf16 ("batched decode") ----------------------------------------
+// The decode decomposition (N/16 strips x 16 waves splitting K, no second launch for any Llama width) carried over to the
+// matrix core that fits it: v_mfma_f32_16x16x32 takes, in lane l, the 8 consecutive k  8*(l>>4)..+7  of column l&15 of B --
+// again exactly one 4-bit word -- and of row l&15 of A.  A wave-load of weights is 4 packed rows x 64 B; x fragments are
+// 16-byte loads from L2 (x is M*K*2 bytes, shared by all strips).  Everything a wave needs for U k-steps is requested
+// before the first MFMA.  RT row tiles of 16 reuse every dequantised word.  Cross-wave sum through LDS as in the GEMV.
+template <typename T> struct Deq1;                       // one column: (scale bits, zero-point) -> fragment of one word
+template <> struct Deq1<f16> {
+    f16x2 s2, c1, c2;
+    __device__ __forceinline__ void setup(unsigned sbits, unsigned z) {
+        s2 = as_f16x2(sbits * 0x00010001u);
+        c1 = as_f16x2(z * 0x00010001u + 0xE400E400u);
+        const f16x2 k960 = {(f16)960.f, (f16)960.f};
+        c2 = c1 + k960;
+    }
+    __device__ __forceinline__ u32x4 frag(unsigned q) const {
+        const unsigned q8 = q >> 8;
+        const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+        u32x4 o;
+        o[0] = f16x2_bits((as_f16x2(and_or(q, 0x000f000fu, 0x64006400u)) + c1) * s2);
+        o[1] = f16x2_bits((as_f16x2(and_or(q, 0x00f000f0u, 0x64006400u)) * r16 + c2) * s2);
+        o[2] = f16x2_bits((as_f16x2(and_or(q8, 0x000f000fu, 0x64006400u)) + c1) * s2);
+        o[3] = f16x2_bits((as_f16x2(and_or(q8, 0x00f000f0u, 0x64006400u)) * r16 + c2) * s2);
+        return o;
+    }
+};
+template <> struct Deq1<bf16> {
+    f16x2 c1, c2;
+    float s;
+    __device__ __forceinline__ void setup(unsigned sbits, unsigned z) {
+        s = (float)__builtin_bit_cast(bf16, (unsigned short)sbits);
+        c1 = as_f16x2(z * 0x00010001u + 0xE400E400u);
+        const f16x2 k960 = {(f16)960.f, (f16)960.f};
+        c2 = c1 + k960;
+    }
+    __device__ __forceinline__ u32x4 frag(unsigned q) const {
+        const unsigned q8 = q >> 8;
+        const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+        u32x4 o;
+        o[0] = Deq<4, bf16>::scaled_pair(as_f16x2(and_or(q, 0x000f000fu, 0x64006400u)) + c1, s);
+        o[1] = Deq<4, bf16>::scaled_pair(as_f16x2(and_or(q, 0x00f000f0u, 0x64006400u)) * r16 + c2, s);
+        o[2] = Deq<4, bf16>::scaled_pair(as_f16x2(and_or(q8, 0x000f000fu, 0x64006400u)) + c1, s);
+        o[3] = Deq<4, bf16>::scaled_pair(as_f16x2(and_or(q8, 0x00f000f0u, 0x64006400u)) * r16 + c2, s);
+        return o;
+    }
+};
+template <typename T> struct Mma16;
+template <> struct Mma16<f16> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(a), as_f16x8(b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma16<bf16> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
+    }
+};
+
+template <typename T, int RT, int U>
+__global__ void __launch_bounds__(1024) gemm_strip16_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // W x RT x 1 KiB
+    float* red = (float*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
+    const int c = lane & 15, kg = lane >> 4;
+    const int strip = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = blockIdx.z * (16 * RT);
+    const int n = strip * 16 + c;                                 // N % 16 == 0 (planner)
+    const int S = p.K >> 5;                                       // 32-deep steps in K
+    const int b0 = blockIdx.y * p.ksteps_per_split;               // this workgroup's steps [b0, b1)
+    const int b1 = min(b0 + p.ksteps_per_split, S);
+    const int spw = ((p.ksteps_per_split + W - 1) / W + U - 1) / U * U;
+    const int ws = b0 + wave * spw, we = min(ws + spw, b1);
+
+    const auto rsrc_q = __builtin_amdgcn_make_buffer_rsrc((void*)p.qweight, 0, (int)((size_t)p.qrows * p.N * 4), 0x00020000);
+    const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.scales, 0, (int)((size_t)(p.K / p.group_size) * p.N * 2), 0x00020000);
+    const int zrow_bytes = p.N / 8 * 4;
+    const auto rsrc_z = __builtin_amdgcn_make_buffer_rsrc((void*)p.qzeros, 0, (p.K / p.group_size) * zrow_bytes, 0x00020000);
+    const unsigned q_lane = ((unsigned)kg * (unsigned)p.N + (unsigned)n) * 4u;
+    const unsigned s_lane = (unsigned)n * 2u, z_lane = ((unsigned)n >> 3) * 4u, z_sh = ((unsigned)n & 7u) * 4u;
+    const unsigned short* a_src[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+        a_src[rt] = (const unsigned short*)p.x + (size_t)min(m0 + rt * 16 + c, p.M - 1) * p.K + kg * 8;
+
+    f32x4 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int s0 = ws; s0 < we; s0 += U) {
+        unsigned sraw[U], zraw[U], braw[U];
+        u32x4 a[U][RT];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {                             // group constants first: loads return in issue order
+            const int sj = min(s0 + j, we - 1);
+            const unsigned g = (unsigned)(sj * 32) / (unsigned)p.group_size;
+            sraw[j] = __builtin_amdgcn_raw_buffer_load_b16(rsrc_s, s_lane, g * (unsigned)p.N * 2u, 0);
+            zraw[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_z, z_lane, g * (unsigned)zrow_bytes, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int sj = min(s0 + j, we - 1);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a[j][rt] = *(const u32x4*)(a_src[rt] + (size_t)sj * 32);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int sj = min(s0 + j, we - 1);
+            braw[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_q, q_lane, (unsigned)sj * 4u * (unsigned)p.N * 4u, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const bool live = s0 + j < we;
+            unsigned z = ((zraw[j] >> z_sh) & 15u) + 1u;
+            if (p.zero_mode == GPTQ_ZERO_WRAP) z &= 15u;
+            Deq1<T> dq;
+            dq.setup(sraw[j] & 0xffffu, z);
+            const u32x4 b = dq.frag(braw[j]);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const u32x4 t = a[j][rt];
+                u32x4 o;                                          // x in the slot order of the fragments: k0,k4,k1,k5,k2,k6,k3,k7
+                o[0] = __builtin_amdgcn_perm(t[2], t[0], 0x05040100u);
+                o[1] = __builtin_amdgcn_perm(t[2], t[0], 0x07060302u);
+                o[2] = __builtin_amdgcn_perm(t[3], t[1], 0x05040100u);
+                o[3] = __builtin_amdgcn_perm(t[3], t[1], 0x07060302u);
+                if (!live) o = u32x4{0u, 0u, 0u, 0u};
+                acc[rt] = Mma16<T>::run(o, b, acc[rt]);
+            }
+        }
+    }
+
+    // ---- cross-wave sum: C/D layout col = lane & 15, row = 4 * (lane >> 4) + r
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * RT + rt) * 4 + r) * 64 + lane] = acc[rt][r];
+    __syncthreads();
+    for (int e = tid; e < RT * 256; e += blockDim.x) {             // e = (rt, r, lane')
+        const int rt = e >> 8, idx = e & 255, r = idx >> 6, ln = idx & 63;
+        float v = 0.f;
+        for (int w = 0; w < W; ++w) v += red[(w * RT + rt) * 256 + idx];
+        const int m = m0 + rt * 16 + 4 * (ln >> 4) + r;
+        const int nn = strip * 16 + (ln & 15);
+        if (m >= p.M) continue;
+        if (p.ksplit > 1) {
+            p.partial[((size_t)blockIdx.y * p.M + m) * p.N + nn] = v;
+        } else {
+            if (p.bias) v += DType<T>::to_f32(((const T*)p.bias)[nn]);
+            ((T*)p.out)[(size_t)m * p.N + nn] = DType<T>::from_f32(v);
+        }
+    }
+}
+
 // out = sum_s partial[s] (+bias), fixed order; 4 columns per thread
 template <typename T>
 __global__ void __launch_bounds__(256) gemm_reduce_kernel(const float* __restrict__ partial, const T* __restrict__ bias,
@@ -765,8 +918,39 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.use_seq = (L.g_idx != nullptr);
     pl.xperm_bytes = pl.use_seq ? align_up((size_t)M * L.K * 2, 256) : 0;
     const int force_skinny = tune ? tune->reserved[2] : 0;      // experiment knob: 1 = skinny, 2 = tiled
-    pl.skinny = (force_skinny == 1) || (force_skinny == 0 && M <= 64);
+    // Measured crossovers (tools/midm_bench.py, us per launch at M = 9/16/32/64):
+    //   4096x4096   strips16  8.0/ 9.1/12.3/19.6   skinny64 12.1/12.3/12.7/15.5   tiled 15.5/15.7/17.1/22.6
+    //   11008x4096  strips16 17.9/20.1/27.9/47.9   skinny64 23.2/23.1/24.0/27.4   tiled 27.6/28.0/28.8/37.2
+    //   4096x11008  strips16 19.5/22.4/31.4/53.7   skinny64 19.2/19.5/22.8/33.0   tiled 17.8/18.7/20.9/25.7
+    // 16-column strips re-read x from L2 once per strip (M*K*N/8 bytes), so they only pay up to M = 16; a wide N gives the
+    // tiled kernel enough 256-column tiles to fill the chip without help.
+    pl.skinny = (force_skinny == 1) || (force_skinny == 0 && M <= 64 && (L.N + 255) / 256 < 32);
     if (pl.skinny && M > 128) pl.skinny = false;
+    // 16-column strips on the 16x16x32 matrix core: 4-bit fp16/bf16, M <= 64
+    const bool strip16_ok = L.bits == 4 && M <= 64 && L.group_size % 32 == 0 && L.K % 32 == 0 && L.N % 16 == 0;
+    pl.strip16 = strip16_ok && (force_skinny == 3 || (force_skinny == 0 && M <= 16 && L.N <= 8192));
+    if (pl.strip16) {
+        pl.skinny = false;
+        pl.mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);                  // row tiles of 16
+        pl.bk = 32;
+        pl.bm = 16 * pl.mt;
+        pl.bn = 16;
+        pl.nbm = (M + pl.bm - 1) / pl.bm;
+        pl.nbn = L.N / 16;
+        pl.waves = 16;
+        const int S = L.K / 32;
+        int ks = (tune && tune->ksplit > 0 && tune->path == 3) ? tune->ksplit : 0;
+        if (!ks) {
+            ks = 1;
+            while ((long)pl.nbm * pl.nbn * ks < 192 && S / (ks * 2) >= pl.waves) ks *= 2;
+        }
+        if (ks > S) ks = S;
+        pl.ksteps_total = S;
+        pl.ksteps_per_split = (S + ks - 1) / ks;
+        pl.ksplit = (S + pl.ksteps_per_split - 1) / pl.ksteps_per_split;
+        pl.workspace_bytes = pl.xperm_bytes + (pl.ksplit > 1 ? (size_t)pl.ksplit * M * L.N * sizeof(float) : 0);
+        return pl;
+    }
     if (pl.skinny) {
         pl.mt = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
         pl.bk = (L.group_size % 64 == 0 && L.K % 64 == 0) ? 64 : 32;      // = 16 * UNR
@@ -838,6 +1022,23 @@ static hipError_t launch_skinny_one(const GemmPlan& pl, const GemmParams& p, hip
     return hipGetLastError();
 }
 
+template <typename T, int RT, int U>
+static hipError_t launch_strip16_one(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
+    const size_t lds = (size_t)pl.waves * RT * 1024;
+    hipLaunchKernelGGL((gemm_strip16_kernel<T, RT, U>), dim3(pl.nbn, pl.ksplit, pl.nbm), dim3(pl.waves * 64), lds, st, p);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_strip16(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
+    switch (pl.mt) {
+        case 1: return launch_strip16_one<T, 1, 8>(pl, p, st);
+        case 2: return launch_strip16_one<T, 2, 4>(pl, p, st);
+        case 4: return launch_strip16_one<T, 4, 2>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 template <int BITS, typename T>
 static hipError_t launch_skinny(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
     const bool u4 = pl.bk == 64;
@@ -851,6 +1052,9 @@ static hipError_t launch_skinny(const GemmPlan& pl, const GemmParams& p, hipStre
 
 template <int BITS, typename T>
 static hipError_t launch_bits(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
+    if constexpr (BITS == 4) {
+        if (pl.strip16) return launch_strip16<T>(pl, p, st);
+    }
     if (pl.skinny) return launch_skinny<BITS, T>(pl, p, st);
     if constexpr (BITS == 4) {
         if (pl.bk == 64) {

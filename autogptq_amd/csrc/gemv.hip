@@ -1008,6 +1008,12 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
             // measured (tools/gemvlab, tools/membench): without a K split the 16-column strip wins on every
             // Llama shape -- a second (reduce) launch costs more than the 64-byte row segments do
             ln = 4;
+            // ... except when 32-column strips tile the chip exactly (N = 8192, 16384: one 16-wave workgroup per CU per
+            // round): 8192x8192 13.1 -> 12.1 us, 3584x8192 7.2 -> 6.5 us (tools/gemv_sweep.py)
+            const int strips8 = N_cols / 32;
+            if (pl.mfma && L.dtype == GPTQ_F16 && !pl.use_seq && L.epilogue == GPTQ_EPI_NONE && M == 1 && N_cols % 32 == 0 &&
+                strips8 % 256 == 0)
+                ln = 8;
         } else {
             ln = 4;   // widest strip that still gives >= 256 workgroups; else the narrowest (16 columns)
             for (int cand : {16, 8}) {

@@ -102,7 +102,7 @@ typedef struct gptq_tuning_t {
     int32_t waves;       /* waves per workgroup (1..16) */
     int32_t ksplit;      /* workgroups along K (1 = no cross-workgroup reduction) */
     int32_t path;        /* 0 auto, 1 generic GEMV, 2 LDS-staged q4/fp16 GEMV, 3 MFMA GEMM, 4 direct q4/fp16 GEMV, 5 matrix-core q4/fp16 GEMV */
-    int32_t reserved[4]; /* [0]: max packed rows per lane and iteration for the register-direct GEMVs (0 = heuristic); [1]: 32 = force the 32-deep K-step in the MFMA GEMM; [2]: 1 = force the skinny GEMM, 2 = force the tiled GEMM; [3]: tiled-GEMM inner-loop schedule variant */
+    int32_t reserved[4]; /* [0]: max packed rows per lane and iteration for the register-direct GEMVs (0 = heuristic); [1]: 32 = force the 32-deep K-step in the MFMA GEMM; [2]: 1 = force the 64-column skinny GEMM, 2 = force the tiled GEMM, 3 = force the 16-column-strip GEMM (4-bit, M <= 64); [3]: tiled-GEMM inner-loop schedule variant */
 } gptq_tuning_t;
 
 int         gptq_abi_version(void);

@@ -262,7 +262,7 @@ def test_permute_columns_and_errors():
 
 
 # ---------------------------------------------------- BASELINE full sizes: size-independent properties
-FULL = [(4096, 4096), (4096, 11008), (11008, 4096)]
+FULL = [(4096, 4096), (4096, 11008), (11008, 4096), (3584, 8192), (8192, 1024)]   # + Llama-2-70B TP=8 shards (32-column strips / K split)
 
 
 @pytest.mark.parametrize("K,N", FULL)
@@ -421,6 +421,41 @@ def test_gemm_k_groups_inside_workgroup(dtype, act, K, N, M, ksplit):
                         L["bias"][cols], 4, O.ZERO_WRAP)
     _assert_close(y7[rows][:, cols], y64, y64, dtype, K, "8-wave vs f64")
     _assert_close(y7, y6.double(), y64, dtype, K, "8-wave vs 4-wave")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N,gs,act", [(9, 512, 96, 128, False), (16, 1024, 256, 32, False), (17, 1024, 256, 64, True),
+                                          (32, 2048, 512, 128, False), (50, 4096, 1024, 128, True), (64, 224, 64, 32, False),
+                                          (33, 11008, 512, 128, False)])
+def test_strip16_batched_decode_kernel(M, K, N, gs, act, dtype):
+    """8 < M <= 64, 4-bit: the 16-column-strip kernel (tuning.reserved[2] = 3; the default up to M = 16) against the
+    fp64 oracle, against the 64-column skinny kernel (reserved[2] = 1), with one-hot rows (exact dequantised rows come back:
+    catches any row/column/k-slot mix-up of the 16x16x32 fragment layouts), with a forced K split, and bit-reproducible."""
+    L = O.random_quant_layer(K, N, 4, gs, act_order=act, seed=M + K + N, bias=True, dtype=dtype)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, gs, zero_mode="wrap")
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype)
+    y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP)
+    t3, t1, t3k = _tuning(path=3), _tuning(path=3), _tuning(path=3, ksplit=3)
+    t3.reserved[2], t1.reserved[2], t3k.reserved[2] = 3, 1, 3
+    with torch.no_grad():
+        y3, y3b = q(x.to(DEV), tuning=t3), q(x.to(DEV), tuning=t3)
+        y1 = q(x.to(DEV), tuning=t1)
+        y3k = q(x.to(DEV), tuning=t3k)
+        y_auto = q(x.to(DEV))
+    assert torch.equal(y3, y3b)
+    if M <= 16:
+        assert torch.equal(y_auto, y3), "4-bit, 8 < M <= 16: auto dispatch must take the 16-column-strip kernel"
+    _assert_close(y3, y64, y64, dtype, K, "strip16 vs f64")
+    _assert_close(y3k, y64, y64, dtype, K, "strip16 split-K vs f64")
+    _assert_close(y1, y64, y64, dtype, K, "skinny64 vs f64")
+    ks = (torch.arange(M) * 37 + 5) % K
+    xo = torch.zeros(M, K, dtype=dtype)
+    xo[torch.arange(M), ks] = 1.0
+    with torch.no_grad():
+        yo = q(xo.to(DEV), tuning=t3).cpu()
+    W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], 4, O.ZERO_WRAP)
+    expect = (W[ks].float() + L["bias"].float()).to(dtype)
+    assert torch.equal(yo, expect)
 
 
 def test_gemm_matches_gemv_paths():
