@@ -230,7 +230,8 @@ template <> struct Deq<4, bf16> {
 // ---- the kernel -------------------------------------------------------------------------------
 // Workgroup = 4 waves side by side along N: tile BM = 32*MT rows x 256 columns, K-step BK.
 // VAR selects the inner-loop schedule: 1 (default) = explicit software pipeline over the MFMA k-steps, 0 = plain loop
-// scheduled by hipcc, 2 = plain + s_setprio around the MFMA groups.  Within-run A/B on MI355X (tools/gemmlab, min of 3
+// scheduled by hipcc, 2 = plain + s_setprio around the MFMA groups, 3 = the pipeline carried across K-steps (+-1 %: kept as
+// an experiment, tuning.reserved[3] = 3).  Within-run A/B on MI355X (tools/gemmlab, min of 3
 // rounds, TFLOP/s at M=2048 4096^2 / M=4096 4096^2 / 4096x11008 / 11008x4096): VAR1 793/1002/908/889, VAR0 678/990/888/840,
 // VAR2 743/972/852/815.  (Also tried: 8 waves per workgroup, one column of each pair per wave -- slower everywhere.)
 // XPRE: x already arrives in k-slot order (act-order layers: the column-permute pre-pass writes it that way).

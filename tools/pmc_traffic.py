@@ -10,7 +10,12 @@ name + grid so the three Llama-7B layer shapes of bench.py are told apart:
 """
 import argparse
 import json
+import os
 import sqlite3
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rocprof_summary import demangle
 
 
 def per_kernel(db, counter):
@@ -37,6 +42,7 @@ def main():
     out = []
     for key, (kib, n) in sorted(fetch.items()):
         name, gx, gy, wg = key
+        name = demangle(name)
         blocks = gx // wg
         ent = {"kernel": name.split("(")[0].replace("void ", ""), "grid_blocks": [blocks, gy], "workgroup": wg, "dispatches": n,
                "FETCH_SIZE_KiB": round(kib, 1), "fetch_bytes_x2": int(kib * 1024 * 2)}

@@ -11,8 +11,37 @@ import re
 import sqlite3
 import sys
 
+def demangle(name: str) -> str:
+    """rocprofv3 leaves names it cannot demangle itself mangled (the Itanium demanglers at hand do not know the _Float16 /
+    __bf16 template arguments DF16_ / DF16b).  This handles exactly the shape of this library's kernels:
+    _ZN4gptq<len><name>I<template args>EEv... with integer, bool and scalar-type arguments."""
+    m = re.match(r"^_ZN4gptq(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    base = name[m.end():m.end() + n]
+    rest = name[m.end() + n:]
+    if not rest.startswith("I"):
+        return "gptq::" + base
+    args, i = [], 1
+    while i < len(rest) and rest[i] != "E":
+        for pat, fn in ((r"Li(\d+)E", lambda g: g.group(1)), (r"Lin(\d+)E", lambda g: "-" + g.group(1)),
+                        (r"Lb([01])E", lambda g: "true" if g.group(1) == "1" else "false"),
+                        (r"DF16_", lambda g: "f16"), (r"DF16b", lambda g: "bf16"), (r"f", lambda g: "float"),
+                        (r"t", lambda g: "unsigned short")):
+            g = re.match(pat, rest[i:])
+            if g:
+                args.append(fn(g))
+                i += g.end()
+                break
+        else:
+            return name
+    return f"gptq::{base}<{', '.join(args)}>"
 
-def short(name: str, width: int = 110) -> str:
+
+def short(name: str, width: int = 150) -> str:
+    name = demangle(name)
+    name = re.sub(r"\(gptq::Ge[a-z]+Params\)$", "", name)
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     return name if len(name) <= width else name[: width - 3] + "..."
@@ -28,8 +57,9 @@ def main():
     cur = c.cursor()
     rows = cur.execute(
         "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
-        "max(grid_x), max(grid_y), max(grid_z), max(workgroup_x), max(lds_size), max(vgpr_count), "
-        "max(accum_vgpr_count), max(sgpr_count) from kernels group by name order by sum(duration) desc").fetchall()
+        "grid_x, grid_y, grid_z, workgroup_x, max(lds_size), max(vgpr_count), "
+        "max(accum_vgpr_count), max(sgpr_count) from kernels group by name, grid_x, grid_y, grid_z, workgroup_x "
+        "order by sum(duration) desc").fetchall()      # one row per (kernel, launch geometry): layer shapes stay apart
     total = sum(r[2] for r in rows) or 1
     print(f"# source: {args.db}")
     print(f"# {'calls':>6} {'total_ms':>9} {'%':>5} {'avg_us':>8} {'min_us':>8} {'max_us':>8}  grid(x,y,z)/wg  lds  vgpr agpr sgpr  kernel")
@@ -41,7 +71,7 @@ def main():
         if n > args.top:
             break
         print(f"  {r[1]:6d} {r[2] / 1e6:9.3f} {100 * r[2] / total:5.1f} {r[3] / 1e3:8.2f} {r[4] / 1e3:8.2f} {r[5] / 1e3:8.2f}  "
-              f"({r[6]},{r[7]},{r[8]})/{r[9]}  {r[10]}  {r[11]} {r[12]} {r[13]}  {short(r[0])}")
+              f"({r[6]},{r[7]},{r[8]})/{r[9]} = {r[6] // max(1, r[9]) * r[7] * r[8]}  {r[10]}  {r[11]} {r[12]} {r[13]}  {short(r[0])}")
     try:
         pmc = cur.execute(
             "select k.name, p.counter_name, avg(p.counter_value), count(*) from pmc_events p join kernels k "
