@@ -727,3 +727,19 @@ def test_awq_ingested_layer_forward():
         with torch.no_grad():
             y = q(x.to(DEV))
         _assert_close(y, y64, y64, torch.float16, K, f"AWQ-ingested layer, M={M}")
+
+
+@pytest.mark.parametrize("act", [False, True])
+@pytest.mark.parametrize("M", [1, 3, 12, 40, 200])
+def test_longest_k_of_the_baseline_configs(M, act):
+    """K = 28672 (Llama-2-70B down_proj, BASELINE config 4): the longest reduction any config has -- beyond the K range of
+    the act-order matrix-core GEMV (x row staged in LDS, K <= 24576), so the dispatcher has to fall back correctly."""
+    K, N = 28672, 256
+    L = O.random_quant_layer(K, N, 4, 128, act_order=act, seed=M, bias=True)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, 128, zero_mode="wrap")
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).half()
+    y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP)
+    with torch.no_grad():
+        y, yb = q(x.to(DEV)), q(x.to(DEV))
+    assert torch.equal(y, yb)
+    _assert_close(y, y64, y64, torch.float16, K, f"K=28672 M={M} act={act}")
