@@ -151,14 +151,6 @@ __global__ void __launch_bounds__(1024) gemv_generic_kernel(GemvParams p) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) s[c] = DType<T>::to_f32(scales[(size_t)g * p.N + n0 + c]);
                 zero_points4(p.qzeros + (size_t)g * zrow_words, n0, BITS, p.zero_mode, z);
-                float xsum[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    float t = 0.f;
-#pragma unroll
-                    for (int v = 0; v < KPU; ++v) t += xk[m * xstride + v];
-                    xsum[m] = t;
-                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     unsigned w[UW];
@@ -167,16 +159,18 @@ __global__ void __launch_bounds__(1024) gemv_generic_kernel(GemvParams p) {
                     float d[MT];
 #pragma unroll
                     for (int m = 0; m < MT; ++m) d[m] = 0.f;
+                    // w - z in integers (exact), like the reference's (weight - zeros): a layer whose fields equal their
+                    // zero-point gives exactly 0, with no cancellation between sum(x*w) and z*sum(x)
                     [&]<int... V>(std::integer_sequence<int, V...>) {
                         (([&] {
-                             const float wf = (float)unit_field<BITS, V>(w);
+                             const float wf = (float)((int)unit_field<BITS, V>(w) - z[c]);
 #pragma unroll
                              for (int m = 0; m < MT; ++m) d[m] = fmaf(xk[m * xstride + V], wf, d[m]);
                          }()),
                          ...);
                     }(std::make_integer_sequence<int, KPU>{});
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m][c] = fmaf(s[c], d[m] - (float)z[c] * xsum[m], acc[m][c]);
+                    for (int m = 0; m < MT; ++m) acc[m][c] = fmaf(s[c], d[m], acc[m][c]);
                 }
             } else {
                 [&]<int... V>(std::integer_sequence<int, V...>) {
@@ -505,10 +499,13 @@ template <> struct Mma4<bf16> {
 // for the gate/up pair of a gated MLP.
 // PERM = act-order layer: weights come from the group-sorted copy and the 8 x values of a packed row are gathered
 // through perm[] (two 16-byte index loads + eight 2-byte gathers per row, all L2 resident) straight into slot order.
-// T = bf16: gfx950 has no packed bf16 arithmetic, so w - z is not formed per weight.  B is the bf16 magic number 128 + w
-// ((q & 0x000f000f) | 0x43004300, exact) and one extra MFMA per x piece against a vector of ones yields sum_k x_k, so
-//     sum_k x_k (w_k - z) = sum_k x_k (128 + w_k) - (128 + z) * sum_k x_k
-// with exact products and fp32 sums (the 128 offset costs 7 of fp32's 24 bits -- far below bf16's 8-bit significand).
+// T = bf16: gfx950 has no packed bf16 arithmetic.  (q & 0x000f000f) | 0x43004300 is the bf16 pair (128 + w_lo, 128 + w_hi);
+// each half is widened to fp32 (a shift / a mask), -(128 + z) is added in fp32 (exact: small integers) and the upper halves
+// of the two results -- bf16(w - z), exact -- are packed back with one v_perm: 4 VALU per pair instead of 1, invisible in a
+// latency-bound kernel.  (A first version fed 128 + w to the matrix core and subtracted (128 + z) * sum_k x_k per group
+// afterwards; algebraically the same, but the cancellation between the two large terms breaks the one property every other
+// kernel here has -- a layer whose fields equal their zero-points gives exactly 0 -- and failed the reference's
+// "range/range/range" value pattern (tests/test_hpu_linear.py:107) with scales ~ 10^4.)
 template <int LN, int MT, int U, bool PAIR = false, bool PERM = false, typename T = f16>
 __global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && (!PERM || MT == 1) && ((U == 1 && MT <= 4) || (U == 2 && MT <= 2))) ? 8 : 4) gemv_q4_f16_mfma_kernel(GemvParams p) {
     constexpr bool BF = std::is_same_v<T, bf16>;
@@ -656,21 +653,18 @@ __global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && (!PE
         if constexpr (!PERM) load_q();
 
         f16x2 c1[4], c2[4];
-        float zoff[4];                                          // bf16: 128 + z
+        float nzoff[4];                                         // bf16: -(128 + z)
         const f16x2 k960 = {(f16)960.f, (f16)960.f};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const unsigned z = (((zw >> (4 * c)) & 15u) + 1u) & zmask;
             if constexpr (BF) {
-                zoff[c] = (float)(128u + z);
+                nzoff[c] = -(float)(128u + z);
             } else {
                 c1[c] = as_f16x2(z * 0x00010001u + 0xE400E400u);    // -(1024+z)
                 c2[c] = c1[c] + k960;                               // -(64+z)
             }
         }
-        f32x4 accx[RG];                                         // bf16: sum_k x_k per x row (ones MFMA)
-#pragma unroll
-        for (int rg = 0; rg < RG; ++rg) accx[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 accg[RG][4];
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg)
@@ -698,19 +692,22 @@ __global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && (!PE
                 if (!live) { a01 = u32x2{0u, 0u}; a23 = u32x2{0u, 0u}; }
                 xa01[rg] = a01;
                 xa23[rg] = a23;
-                if constexpr (BF) {
-                    const u32x2 ones = {0x3F803F80u, 0x3F803F80u};
-                    accx[rg] = Mma4<T>::run(a01, ones, accx[rg]);
-                    accx[rg] = Mma4<T>::run(a23, ones, accx[rg]);
-                }
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const unsigned qw = qv[c], q8 = qw >> 8;
                 u32x2 b01, b23;
                 if constexpr (BF) {
-                    b01 = u32x2{(qw & 0x000f000fu) | 0x43004300u, ((qw >> 4) & 0x000f000fu) | 0x43004300u};     // 128 + w: (k0,k4)(k1,k5)
-                    b23 = u32x2{(q8 & 0x000f000fu) | 0x43004300u, ((q8 >> 4) & 0x000f000fu) | 0x43004300u};     // (k2,k6)(k3,k7)
+                    // (scalar floats on purpose: hipcc 7.2 drops the second lane of a float2 built from these two bit patterns
+                    //  when its elements are bit_cast back -- it emits v_perm_b32 d, lo, lo)
+                    auto exact_pair = [&](unsigned src) -> unsigned {        // nibbles 0 and 4 of src -> (w_lo - z, w_hi - z) as bf16
+                        const unsigned pr = (src & 0x000f000fu) | 0x43004300u;  // (128 + w_lo, 128 + w_hi) as bf16
+                        const float lo = __builtin_bit_cast(float, pr << 16) + nzoff[c];          // exact: small integers
+                        const float hi = __builtin_bit_cast(float, pr & 0xffff0000u) + nzoff[c];
+                        return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
+                    };
+                    b01 = u32x2{exact_pair(qw), exact_pair(qw >> 4)};         // (k0,k4)(k1,k5)
+                    b23 = u32x2{exact_pair(q8), exact_pair(q8 >> 4)};         // (k2,k6)(k3,k7)
                 } else {
                     const f16x2 h0 = as_f16x2((qw & 0x000f000fu) | 0x64006400u) + c1[c];
                     const f16x2 h1 = as_f16x2((qw & 0x00f000f0u) | 0x64006400u) * r16 + c2[c];
@@ -734,9 +731,7 @@ __global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && (!PE
             for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
                 for (int m = 0; m < MTR; ++m) {
-                    float gsum = accg[rg][c][m];
-                    if constexpr (BF) gsum = fmaf(-zoff[c], accx[rg][m], gsum);
-                    acc[h][rg][c][m] = fmaf(sc, gsum, acc[h][rg][c][m]);
+                    acc[h][rg][c][m] = fmaf(sc, accg[rg][c][m], acc[h][rg][c][m]);
                 }
         }
     }
@@ -1062,7 +1057,7 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
         int want = pl.units_per_split >= 1024 ? 1 : 2;             // long K: more, shorter iterations pipeline better
         // more than one workgroup per CU only fits with <= 64 VGPRs: U = 1 once 3+ rows of x are carried
         if (pl.mfma && pl.mt == 4 && (long)pl.strips * pl.mtiles > 256) want = 1;
-        if (pl.use_seq) want = (M == 1 && !(L.epilogue == GPTQ_EPI_SILU_MUL)) ? 8 : 2;   // act-order: the x gather is a dependent
+        if (pl.use_seq) want = (M == 1 && !(L.epilogue == GPTQ_EPI_SILU_MUL)) ? (L.dtype == GPTQ_BF16 ? 4 : 8) : 2;   // bf16: U = 8 spills   // act-order: the x gather is a dependent
                                                                     // round trip per iteration -> as few iterations as possible
         int u = 1;
         while (u * 2 <= per_lane && u * 2 <= gu && u * 2 <= 8 && (pl.mfma || u * 2 * pl.mt <= 8) &&

@@ -289,6 +289,10 @@ class QuantLinear(nn.Module):
         gi = self.g_idx.to(torch.int64)
         home = self.qweight.device
 
+        if not zeros.is_floating_point():
+            # integer zero-points (tests/test_hpu_linear.py:140-150 hands over int32): zeros * scales promotes to the scales
+            # dtype and (zeros - 1).astype(uint32) wraps -1 to 0xFFFFFFFF -- both identical after an exact cast to float
+            zeros = zeros.to(scales.dtype)
         scales_t = scales.t().contiguous()
         zeros_t = zeros.t().contiguous()
         if linear.bias is not None:

@@ -743,3 +743,75 @@ def test_longest_k_of_the_baseline_configs(M, act):
         y, yb = q(x.to(DEV)), q(x.to(DEV))
     assert torch.equal(y, yb)
     _assert_close(y, y64, y64, torch.float16, K, f"K=28672 M={M} act={act}")
+
+
+# ------------------------------------------------------------------- the reference's backend-vs-cuda_old grid
+# tests/test_hpu_linear.py:102-181 compares a backend with the cuda_old Python path over group sizes, square layer sizes, 13
+# (scales, weight, zeros) value patterns and two dtypes; the same grid here, with the oracle standing in for cuda_old.
+HPU_PATTERNS = [("normal", "normal", "normal"), ("normal", "normal", "range"), ("normal", "normal", "zeros"), ("ones", "zeros", "zeros"),
+                ("ones", "zeros", "eights"), ("ones", "range", "zeros"), ("ones", "range", "ones"), ("ones", "7", "ones"),
+                ("ones", "zeros", "range"), ("ones", "zeros", "ones"), ("ones", "range", "range"), ("range", "range", "range"),
+                ("range", "range", "zeros")]
+
+
+def _pattern_layer(K, N, gs, pattern, dtype, bias, seed):
+    """(linear, scales [N, G] fp32, zeros [N, G] int32) in the value patterns of the reference grid (:121-150)."""
+    sv, wv, zv = pattern
+    gen = torch.Generator().manual_seed(seed)
+    G = K // gs
+    W = torch.randn(N, K, generator=gen) * 0.05
+    s = W.reshape(N, G, gs).abs().amax(dim=2) / 7 + 1e-4                      # symmetric 4-bit scale per (column, group)
+    if sv == "ones":
+        s = torch.ones_like(s)
+    elif sv == "range":
+        s = torch.arange(1, s.numel() + 1, dtype=torch.float32).reshape(G, N).t().contiguous()
+    if wv == "normal":
+        Wq = (torch.clamp(torch.round(W / s.repeat_interleave(gs, 1)), -8, 7)) * s.repeat_interleave(gs, 1)
+    elif wv == "zeros":
+        Wq = torch.zeros(N, K)
+    elif wv == "range":
+        Wq = torch.arange(8, dtype=torch.float32).repeat(N * K // 8).reshape(N, K)
+    else:
+        Wq = torch.full((N, K), float(wv))
+    if zv == "zeros":
+        z = torch.zeros(N, G, dtype=torch.int32)
+    elif zv == "range":
+        z = torch.arange(1, 9, dtype=torch.int32).repeat(N * G // 8).reshape(G, N).t().contiguous()
+    elif zv == "eights":
+        z = torch.full((N, G), 8, dtype=torch.int32)
+    elif zv == "ones":
+        z = torch.ones(N, G, dtype=torch.int32)
+    else:                                   # "normal": the symmetric mid-point
+        z = torch.full((N, G), 8, dtype=torch.int32)
+    lin = torch.nn.Linear(K, N, bias=bias)
+    lin.weight.data = Wq.to(dtype)
+    if bias:
+        lin.bias.data = (torch.randn(N, generator=gen) * 0.1).to(dtype)
+    return lin, s, z
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+@pytest.mark.parametrize("pi", range(len(HPU_PATTERNS)), ids=["-".join(p) for p in HPU_PATTERNS])
+@pytest.mark.parametrize("KN", [64, 128, 512])
+@pytest.mark.parametrize("gs", [16, 32, 128])
+def test_reference_backend_grid(gs, KN, pi, dtype):
+    if KN < gs:
+        pytest.skip("infeatures < group_size (the reference grid skips these too, test_hpu_linear.py:115-116)")
+    K = N = KN
+    bias = bool((pi + KN // 64) & 1)
+    lin, s, z = _pattern_layer(K, N, gs, HPU_PATTERNS[pi], dtype, bias, seed=pi * 7 + gs)
+    q = QuantLinear(4, gs, K, N, bias, weight_dtype=dtype)
+    q.pack(lin, s.clone(), z.clone(), g_idx=None)                 # device pack (gptq_pack_weights / gptq_pack_zeros)
+    qw, qz, sc = O.pack(lin.weight.data.clone(), s.clone(), z.clone(), None, 4, dtype)
+    assert torch.equal(q.qweight.cpu(), qw) and torch.equal(q.qzeros.cpu(), qz) and torch.equal(q.scales.cpu(), sc)
+    q = q.to(DEV)
+    b = lin.bias.data.clone() if bias else None
+    for M in (1, 5, 64):
+        x = torch.rand(M, K, generator=torch.Generator().manual_seed(M)).to(dtype)
+        yref = O.forward(x, qw, qz, sc, None, b, 4, O.ZERO_WRAP)
+        y64 = O.forward_f64(x, qw, qz, sc, None, b, 4, O.ZERO_WRAP)
+        with torch.no_grad():
+            y = q(x.to(DEV))
+        assert y.dtype == dtype
+        _assert_close(y, yref, y64, dtype, K, f"{HPU_PATTERNS[pi]} gs={gs} M={M} vs reference order")
+        _assert_close(y, y64, y64, dtype, K, f"{HPU_PATTERNS[pi]} gs={gs} M={M} vs f64")

@@ -200,3 +200,25 @@ def test_make_quant_and_pack_model_host():
         assert torch.equal(ql.qweight.cpu(), ref[nme][0]) and torch.equal(ql.qzeros.cpu(), ref[nme][1])
         assert torch.equal(ql.scales.cpu(), ref[nme][2])
     assert set(find_layers(m, [QuantLinear])) == set(names)
+
+
+def test_awq_entry_points_validate_before_touching_memory():
+    """gptq_awq_unpack / gptq_awq_repack: argument validation runs on the host (no GPU needed), the Python mirror refuses
+    to run without a device (there is no host implementation of the ingest), and the bits != 4 assertion of the
+    reference (auto_gptq/modeling/_utils.py:526,572,647) is kept."""
+    import torch
+    from autogptq_amd import awq
+    lib = _lib.load()
+    p = 0x1000
+    assert lib.gptq_awq_repack(p, p, 100, 64, 32, p, p, None) == 2 and "multiples of 8" in lib.gptq_last_error().decode()
+    assert lib.gptq_awq_repack(p, p, 128, 64, 48, p, p, None) == 2 and "group_size" in lib.gptq_last_error().decode()
+    assert lib.gptq_awq_repack(None, p, 128, 64, 32, p, p, None) == 1
+    assert lib.gptq_awq_unpack(p, p, None, 128, 64, 32, p, p, None) == 1
+    assert lib.gptq_awq_unpack(p, p, p, 128, 60, 32, p, p, None) == 2
+    with pytest.raises(AssertionError):
+        awq.unpack_awq(torch.zeros(8, 1, dtype=torch.int32), torch.zeros(1, 1, dtype=torch.int32), torch.ones(1, 8).half(), 8, 8)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no host implementation"):
+            awq.repack_awq_to_gptq(torch.zeros(8, 1, dtype=torch.int32), torch.zeros(1, 1, dtype=torch.int32), 8)
+    t = torch.arange(16, dtype=torch.int8).reshape(16, 1)                     # [N, G] -> transposed inside
+    assert awq.awq_reverse_reorder_int_tensor(t, 4).flatten().tolist() == [0, 4, 1, 5, 2, 6, 3, 7, 8, 12, 9, 13, 10, 14, 11, 15]
