@@ -509,6 +509,10 @@ template <> struct Mma4<bf16> {
 template <int LN, int MT, int U, bool PAIR = false, bool PERM = false, typename T = f16>
 __global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && (!PERM || MT == 1) && ((U == 1 && MT <= 4) || (U == 2 && MT <= 2))) ? 8 : 4) gemv_q4_f16_mfma_kernel(GemvParams p) {
     constexpr bool BF = std::is_same_v<T, bf16>;
+    unsigned m_lo, m_hi, magic;                                   // see the dequant below
+    asm("s_mov_b32 %0, 0x000f000f" : "=s"(m_lo));
+    asm("s_mov_b32 %0, 0x00f000f0" : "=s"(m_hi));
+    asm("v_mov_b32 %0, 0x64006400" : "=v"(magic));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;
     constexpr int WR = 64 / LN, CT = LN * 4;
@@ -653,17 +657,12 @@ __global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && (!PE
         if constexpr (!PERM) load_q();
 
         f16x2 c1[4], c2[4];
-        float nzoff[4];                                         // bf16: -(128 + z)
         const f16x2 k960 = {(f16)960.f, (f16)960.f};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const unsigned z = (((zw >> (4 * c)) & 15u) + 1u) & zmask;
-            if constexpr (BF) {
-                nzoff[c] = -(float)(128u + z);
-            } else {
-                c1[c] = as_f16x2(z * 0x00010001u + 0xE400E400u);    // -(1024+z)
-                c2[c] = c1[c] + k960;                               // -(64+z)
-            }
+            c1[c] = as_f16x2(z * 0x00010001u + 0xE400E400u);        // -(1024+z)
+            c2[c] = c1[c] + k960;                                   // -(64+z)
         }
         f32x4 accg[RG][4];
 #pragma unroll
@@ -697,22 +696,22 @@ __global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && (!PE
             for (int c = 0; c < 4; ++c) {
                 const unsigned qw = qv[c], q8 = qw >> 8;
                 u32x2 b01, b23;
+                // w - z exactly in packed fp16.  The masks and the magic number are opaque to the compiler (defined by asm
+                // above), so (q & mask) | magic is selected as ONE v_and_or_b32 (mask in an SGPR, magic in a VGPR) instead of
+                // v_and_b32 + v_or_b32 with two literals: 4 VALU fewer per word.
+                const f16x2 h0 = as_f16x2((qw & m_lo) | magic) + c1[c];             // k0,k4
+                const f16x2 h1 = as_f16x2((qw & m_hi) | magic) * r16 + c2[c];       // k1,k5
+                const f16x2 h2 = as_f16x2((q8 & m_lo) | magic) + c1[c];             // k2,k6
+                const f16x2 h3 = as_f16x2((q8 & m_hi) | magic) * r16 + c2[c];       // k3,k7
                 if constexpr (BF) {
-                    // (scalar floats on purpose: hipcc 7.2 drops the second lane of a float2 built from these two bit patterns
-                    //  when its elements are bit_cast back -- it emits v_perm_b32 d, lo, lo)
-                    auto exact_pair = [&](unsigned src) -> unsigned {        // nibbles 0 and 4 of src -> (w_lo - z, w_hi - z) as bf16
-                        const unsigned pr = (src & 0x000f000fu) | 0x43004300u;  // (128 + w_lo, 128 + w_hi) as bf16
-                        const float lo = __builtin_bit_cast(float, pr << 16) + nzoff[c];          // exact: small integers
-                        const float hi = __builtin_bit_cast(float, pr & 0xffff0000u) + nzoff[c];
-                        return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
+                    // fp16 -> fp32 -> bf16 per pair (2 v_cvt_f32_f16 + 1 v_cvt_pk_bf16_f32; exact: integers in [-16, 15])
+                    auto to_bf = [&](f16x2 hv) -> unsigned {
+                        const bf16x2 o = {(bf16)(float)hv[0], (bf16)(float)hv[1]};
+                        return __builtin_bit_cast(unsigned, o);
                     };
-                    b01 = u32x2{exact_pair(qw), exact_pair(qw >> 4)};         // (k0,k4)(k1,k5)
-                    b23 = u32x2{exact_pair(q8), exact_pair(q8 >> 4)};         // (k2,k6)(k3,k7)
+                    b01 = u32x2{to_bf(h0), to_bf(h1)};
+                    b23 = u32x2{to_bf(h2), to_bf(h3)};
                 } else {
-                    const f16x2 h0 = as_f16x2((qw & 0x000f000fu) | 0x64006400u) + c1[c];
-                    const f16x2 h1 = as_f16x2((qw & 0x00f000f0u) | 0x64006400u) * r16 + c2[c];
-                    const f16x2 h2 = as_f16x2((q8 & 0x000f000fu) | 0x64006400u) + c1[c];
-                    const f16x2 h3 = as_f16x2((q8 & 0x00f000f0u) | 0x64006400u) * r16 + c2[c];
                     b01 = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
                     b23 = u32x2{__builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
                 }
