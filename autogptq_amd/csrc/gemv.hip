@@ -699,10 +699,13 @@ __global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && (!PE
                 // w - z exactly in packed fp16.  The masks and the magic number are opaque to the compiler (defined by asm
                 // above), so (q & mask) | magic is selected as ONE v_and_or_b32 (mask in an SGPR, magic in a VGPR) instead of
                 // v_and_b32 + v_or_b32 with two literals: 4 VALU fewer per word.
-                const f16x2 h0 = as_f16x2((qw & m_lo) | magic) + c1[c];             // k0,k4
-                const f16x2 h1 = as_f16x2((qw & m_hi) | magic) * r16 + c2[c];       // k1,k5
-                const f16x2 h2 = as_f16x2((q8 & m_lo) | magic) + c1[c];             // k2,k6
-                const f16x2 h3 = as_f16x2((q8 & m_hi) | magic) * r16 + c2[c];       // k3,k7
+                // (not for the two-pass PAIR kernel: there the opaque form makes hipcc hoist the second pass's unpack in front of
+                //  its loads' use and the [gate|up] launch drops from 2625 to 2455 GB/s -- A/B/C in one session, bench.py)
+                const unsigned ml = PAIR ? 0x000f000fu : m_lo, mh = PAIR ? 0x00f000f0u : m_hi, mg = PAIR ? 0x64006400u : magic;
+                const f16x2 h0 = as_f16x2((qw & ml) | mg) + c1[c];             // k0,k4
+                const f16x2 h1 = as_f16x2((qw & mh) | mg) * r16 + c2[c];       // k1,k5
+                const f16x2 h2 = as_f16x2((q8 & ml) | mg) + c1[c];             // k2,k6
+                const f16x2 h3 = as_f16x2((q8 & mh) | mg) * r16 + c2[c];       // k3,k7
                 if constexpr (BF) {
                     // fp16 -> fp32 -> bf16 per pair (2 v_cvt_f32_f16 + 1 v_cvt_pk_bf16_f32; exact: integers in [-16, 15])
                     auto to_bf = [&](f16x2 hv) -> unsigned {
