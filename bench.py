@@ -368,7 +368,7 @@ def main():
                 out["fused_callers"] = bench_fused(device, n_blocks, args.steps)
             except Exception as e:
                 out["fused_callers"] = {"error": repr(e)[:300]}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (bounded sample, ~25 s of host time)
             out["cpu_baseline"] = cpu_baseline(1 if not prefill else 16, act_order)
         print(json.dumps(out))
     if world > 1:
