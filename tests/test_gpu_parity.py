@@ -318,6 +318,8 @@ GEMM_CASES = [
     (2, 32, 512, 128, True, torch.float16, 16),
     (4, 1024, 1024, 256, False, torch.float16, 96),     # one group for the whole layer
     (4, 32, 32 * 7, 64, False, torch.float16, 12),      # K = 224: odd number of K-steps
+    (4, 128, 512, 8448, False, torch.float16, 6),       # M = 5..8 on a wide layer (N > 8192): auto dispatch takes the tiled kernel
+    (4, 128, 1024, 8448, True, torch.float16, 8),
 ]
 
 
