@@ -616,6 +616,8 @@ __global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && (!PE
                     const int kk = (v * (int)blockDim.x + tid) * 8;
                     if (kk < p.K) *(u32x4*)(xlds + kk) = xst[v];
                 }
+                for (int kk = (NXST * (int)blockDim.x + tid) * 8; kk < p.K; kk += (int)blockDim.x * 8)   // small workgroup (deep K split), long K
+                    *(u32x4*)(xlds + kk) = *(const u32x4*)(xrow[0] + kk);
                 __syncthreads();
                 x_staged = true;
             }
@@ -996,6 +998,7 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
         pl.mt = pick_mt(M);
         if (pl.direct && pl.mt > 4) pl.mt = 4;
         if (!pl.fast && pl.mt > 4) pl.mt = 4;
+        if (!pl.fast && L.bits == 3) pl.mt = pl.perk ? 1 : (pl.mt > 2 ? 2 : pl.mt);   // 32 fields per unit: more rows of x spill
         pl.mtiles = (M + pl.mt - 1) / pl.mt;
     }
 

@@ -817,3 +817,23 @@ def test_reference_backend_grid(gs, KN, pi, dtype):
         assert y.dtype == dtype
         _assert_close(y, yref, y64, dtype, K, f"{HPU_PATTERNS[pi]} gs={gs} M={M} vs reference order")
         _assert_close(y, y64, y64, dtype, K, f"{HPU_PATTERNS[pi]} gs={gs} M={M} vs f64")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("K,N,gs", [(15360, 64, 128), (8192, 32, 64), (4096, 4096, 128), (14336, 256, 128), (24576, 64, 128), (1024, 96, 32)])
+def test_act_order_decode_long_k_small_n(K, N, gs, dtype):
+    """act-order, M = 1: the whole x row is staged in LDS (perm[] points anywhere in [0, K)).  Tiny N forces a deep K split,
+    i.e. small workgroups that still have to stage the WHOLE row; the default plan and forced splits of the matrix-core GEMV."""
+    L = O.random_quant_layer(K, N, 4, gs, act_order=True, seed=K + N, bias=True, dtype=dtype)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, gs, zero_mode="nowrap")
+    x = (torch.rand(1, K, generator=torch.Generator().manual_seed(K)) - 0.5).to(dtype)
+    y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_NOWRAP)
+    with torch.no_grad():
+        y = q(x.to(DEV))
+        yb = q(x.to(DEV))
+    assert torch.equal(y, yb)
+    _assert_close(y, y64, y64, dtype, K, "act-order decode, default plan")
+    for ks in (2, 16, 32):
+        with torch.no_grad():
+            yk = q(x.to(DEV), tuning=_tuning(path=5, ksplit=ks))
+        _assert_close(yk, y64, y64, dtype, K, f"act-order decode, ksplit={ks}")
