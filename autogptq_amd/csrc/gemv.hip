@@ -983,7 +983,9 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     const bool pow2_groups = q4_16 && gu > 0 && (gu & (gu - 1)) == 0;
     const bool ln_ok = !(tune && tune->lanes_n && tune->lanes_n != 4);
     // default for 4-bit fp16 / bf16 layers; act-order layers (x gathered through perm) and bf16 only with 16-column strips
-    pl.mfma = pow2_groups && (path == 0 || path == 5) && (!pl.use_seq || (ln_ok && L.K <= 24576)) && (L.dtype == GPTQ_F16 || ln_ok);
+    const bool ln_wide = tune && (tune->lanes_n == 8 || tune->lanes_n == 16);      // bf16: 16/32/64-column strips (plain layers)
+    pl.mfma = pow2_groups && (path == 0 || path == 5) && (!pl.use_seq || (ln_ok && L.K <= 24576)) &&
+              (L.dtype == GPTQ_F16 || ln_ok || (ln_wide && !pl.use_seq));
     pl.direct = pow2_groups && L.dtype == GPTQ_F16 && !pl.use_seq && path == 4;
     // the other packings (and 4-bit bf16): matrix-core kernel with integer field extraction; 16-column strips only
     pl.mfmag = !pl.mfma && !pl.direct && (path == 0 || path == 5) && !pl.perk && !pl.use_seq && ln_ok &&
@@ -1008,12 +1010,24 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
             // measured (tools/gemvlab, tools/membench): without a K split the 16-column strip wins on every
             // Llama shape -- a second (reduce) launch costs more than the 64-byte row segments do
             ln = 4;
-            // ... except when 32-column strips tile the chip exactly (N = 8192, 16384: one 16-wave workgroup per CU per
-            // round): 8192x8192 13.1 -> 12.1 us, 3584x8192 7.2 -> 6.5 us (tools/gemv_sweep.py)
-            const int strips8 = N_cols / 32;
-            if (pl.mfma && L.dtype == GPTQ_F16 && !pl.use_seq && L.epilogue == GPTQ_EPI_NONE && M == 1 && N_cols % 32 == 0 &&
-                strips8 % 256 == 0)
-                ln = 8;
+            // ... for the Llama-7B widths.  Much wider fp16 layers have enough columns for wider strips AND enough workgroups:
+            // from 12288 columns up, the widest strip (64, then 32 columns: 256- / 128-byte row segments) that still leaves
+            // >= 160 workgroups (tools/gemv_sweep.py, us per launch, 16-column strips -> chosen: 4096x12288 10.5 -> 9.0,
+            // 5120x13824 16.8 -> 11.0, 4096x14336 11.5 -> 9.2, 8192x28672 36.5 -> 27.8 = 4.4 TB/s; confirmed inside the
+            // decode graph by the fused [q|k|v] launch: 2625 -> 2730 GB/s for the fused stack); 32-column strips when they
+            // tile the chip exactly (N = 8192: 13.1 -> 12.1 us).  NOT for 11008 columns: 64-column strips look 5 % faster
+            // back to back (9.1 vs 9.6 us) but are 11 % slower between the other layers of a decoder block (10.6 us), and
+            // not for bf16, whose conversion work needs every CU (4096x11008: 12.4 -> 14.6 us with 172 workgroups).
+            if (pl.mfma && L.dtype == GPTQ_F16 && !pl.use_seq && L.epilogue == GPTQ_EPI_NONE && M <= 4) {
+                if (N_cols >= 12288) {
+                    for (int cand : {16, 8}) {
+                        const int strips = (N_cols + cand * 4 - 1) / (cand * 4);
+                        if (N_cols % (cand * 4) == 0 && strips * pl.mtiles >= 160) { ln = cand; break; }
+                    }
+                } else if (M == 1 && N_cols % 8192 == 0) {
+                    ln = 8;
+                }
+            }
         } else {
             ln = 4;   // widest strip that still gives >= 256 workgroups; else the narrowest (16 columns)
             for (int cand : {16, 8}) {
@@ -1203,7 +1217,12 @@ static hipError_t launch_mfma_u(const GemvPlan& pl, const GemvParams& p, hipStre
 template <int MT, typename T>
 static hipError_t launch_mfma_mt(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
     if constexpr (std::is_same_v<T, bf16>) {
-        return pl.ln == 4 ? launch_mfma_u<4, MT, T>(pl, p, st) : hipErrorInvalidValue;
+        switch (pl.ln) {
+            case 4: return launch_mfma_u<4, MT, T>(pl, p, st);
+            case 8: return (pl.use_seq || pl.pair) ? hipErrorInvalidValue : launch_mfma_u<8, MT, T>(pl, p, st);
+            case 16: return (pl.use_seq || pl.pair) ? hipErrorInvalidValue : launch_mfma_u<16, MT, T>(pl, p, st);
+            default: return hipErrorInvalidValue;
+        }
     } else {
         switch (pl.ln) {
             case 4: return launch_mfma_u<4, MT, T>(pl, p, st);

@@ -300,6 +300,7 @@ def main():
         for name, K, N, q in layers:
             by_type.setdefault((K, N), []).append((name, K, N, q))
         best = None
+        per_type = {}
         for (K, N), ls in by_type.items():
             gg, oo = capture(ls, xs, device)
             for _ in range(3):
@@ -309,6 +310,7 @@ def main():
             per = evt / (reps * len(ls))
             share = per * len(ls)
             ent = dict(K=K, N=N, per_launch_s=per, share=share, n=len(ls))
+            per_type[f"{K}x{N}"] = round(per * 1e6, 3)
             if best is None or share > best["share"]:
                 best = ent
             del gg, oo
@@ -325,6 +327,7 @@ def main():
         roof["traffic"] = pmc_traffic(roof["kernel"], K, N, M)
         roof["shape"] = f"K={K} N={N} M={M}"
         roof["us_per_launch_events"] = round(best["per_launch_s"] * 1e6, 3)
+        roof["us_per_launch_by_shape"] = per_type
         roof["algorithmic_bytes_per_launch"] = algorithmic_bytes(K, N, M, act_order=act_order)
         if prefill and act_order:
             roof["note"] = "per-launch time includes the x column-permute launch of act-order layers (rocprof splits them: profiles/)"

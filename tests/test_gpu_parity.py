@@ -837,3 +837,21 @@ def test_act_order_decode_long_k_small_n(K, N, gs, dtype):
         with torch.no_grad():
             yk = q(x.to(DEV), tuning=_tuning(path=5, ksplit=ks))
         _assert_close(yk, y64, y64, dtype, K, f"act-order decode, ksplit={ks}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("K,N,M", [(512, 11008, 1), (1024, 5120, 2), (256, 12288, 4), (512, 13824, 3), (1024, 10240, 1), (512, 11008, 5)])
+def test_wide_layers_take_wide_strips(K, N, M, dtype):
+    """Plain layers wider than 4096 columns: the planner picks 64- or 32-column strips (>= 160 workgroups) for M <= 4 -- fp16 and
+    bf16 -- and the result must not depend on the strip width (explicit 16-column strips give the same sums in another order)."""
+    L = O.random_quant_layer(K, N, 4, 128, seed=K + N + M, bias=True, dtype=dtype)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, 128)
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype)
+    y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP)
+    with torch.no_grad():
+        y, yb = q(x.to(DEV)), q(x.to(DEV))
+        y4 = q(x.to(DEV), tuning=_tuning(path=5, lanes_n=4))
+        y16 = q(x.to(DEV), tuning=_tuning(path=5, lanes_n=16))
+    assert torch.equal(y, yb)
+    for t, what in ((y, "auto"), (y4, "16-column strips"), (y16, "64-column strips")):
+        _assert_close(t, y64, y64, dtype, K, what)
