@@ -855,3 +855,27 @@ def test_wide_layers_take_wide_strips(K, N, M, dtype):
     assert torch.equal(y, yb)
     for t, what in ((y, "auto"), (y4, "16-column strips"), (y16, "64-column strips")):
         _assert_close(t, y64, y64, dtype, K, what)
+
+
+@pytest.mark.parametrize("fname", ["marlin_k256_n256_g128.npz", "marlin_k512_n512_g128.npz", "marlin_k128_n256_g128.npz"])
+def test_marlin_checkpoint_layer_forward(fname):
+    """A layer serialised in the reference's Marlin format (tests/golden/marlin_*.npz = the reference's own pack()) converted
+    to GPTQ tensors by autogptq_amd.marlin and run through this backend: its dequantised matrix is exactly the fake-quantised
+    weight that was packed, and forward = x @ that weight (+ bias) at GEMV, strip and tiled sizes."""
+    from autogptq_amd import marlin
+    d = np.load(os.path.join(_GOLDEN_DIR, fname))
+    gs = int(d["group_size"])
+    qw, qz, sc = marlin.marlin_to_gptq(torch.from_numpy(d["B"]), torch.from_numpy(d["s"]), gs)
+    bias = torch.from_numpy(d["bias"]) if d["bias"].size else None
+    q = _module_from(qw, qz, sc, None, bias, 4, gs)
+    Wq = torch.from_numpy(d["Wq"]).t().contiguous()                     # [K, N] fp16
+    assert torch.equal(q.dequantize().cpu(), Wq)
+    K = int(d["K"])
+    for M in (1, 4, 12, 40, 200):
+        x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).half()
+        y64 = x.double() @ Wq.double()
+        if bias is not None:
+            y64 = y64 + bias.double()
+        with torch.no_grad():
+            y = q(x.to(DEV))
+        _assert_close(y, y64, y64, torch.float16, K, f"Marlin-format layer, M={M}")

@@ -222,3 +222,30 @@ def test_awq_entry_points_validate_before_touching_memory():
             awq.repack_awq_to_gptq(torch.zeros(8, 1, dtype=torch.int32), torch.zeros(1, 1, dtype=torch.int32), 8)
     t = torch.arange(16, dtype=torch.int8).reshape(16, 1)                     # [N, G] -> transposed inside
     assert awq.awq_reverse_reorder_int_tensor(t, 4).flatten().tolist() == [0, 4, 1, 5, 2, 6, 3, 7, 8, 12, 9, 13, 10, 14, 11, 15]
+
+
+@pytest.mark.parametrize("fname", ["marlin_k128_n256_g128.npz", "marlin_k256_n256_g128.npz", "marlin_k512_n512_g128.npz"])
+def test_marlin_format_conversion(golden_dir, fname):
+    """autogptq_amd.marlin (index arithmetic on whole tensors): Marlin -> GPTQ equals the oracle, GPTQ -> Marlin gives back the
+    reference's B and s bit for bit, the permutation tables equal the oracle's, and the guards of the reference's Marlin class
+    (shape divisibility, group sizes, symmetric zero-points) raise."""
+    import numpy as np
+    import torch
+    from autogptq_amd import marlin
+    from oracle import marlin_oracle as M
+    for a, b in zip(marlin.marlin_perms(), M.perms()):
+        assert np.array_equal(a.numpy(), b)
+    d = np.load(os.path.join(golden_dir, fname))
+    gs = int(d["group_size"])
+    qw, qz, sc = marlin.marlin_to_gptq(torch.from_numpy(d["B"]), torch.from_numpy(d["s"]), gs)
+    eq, ez, es = M.to_gptq(d["B"], d["s"], gs)
+    assert qw.dtype == torch.int32 and qz.dtype == torch.int32 and sc.dtype == torch.float16
+    assert np.array_equal(qw.numpy(), eq) and np.array_equal(qz.numpy(), ez) and np.array_equal(sc.numpy().view(np.uint16), es.view(np.uint16))
+    B2, s2 = marlin.gptq_to_marlin(qw, qz, sc, gs)
+    assert np.array_equal(B2.numpy(), d["B"]) and np.array_equal(s2.numpy().view(np.uint16), d["s"].view(np.uint16))
+    with pytest.raises(ValueError, match="symmetric"):
+        marlin.gptq_to_marlin(qw, qz + 1, sc, gs)
+    with pytest.raises(ValueError, match="divisible"):
+        marlin.marlin_to_gptq(torch.zeros(4, 512, dtype=torch.int32), torch.zeros(1, 256).half(), 64)
+    with pytest.raises(ValueError, match="group_size"):
+        marlin.marlin_to_gptq(torch.zeros(16, 512, dtype=torch.int32), torch.zeros(4, 256).half(), 64)

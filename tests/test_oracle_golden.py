@@ -168,3 +168,25 @@ def test_awq_ingested_layer_dequantises_to_awq_weights():
     W = O.dequantize(torch.from_numpy(qw), torch.from_numpy(qz), s, None, 4, O.ZERO_WRAP)
     expect = (torch.from_numpy(w - np.repeat(z, gs, axis=0)).to(torch.float16) * s.repeat_interleave(gs, 0))
     assert torch.equal(W, expect)
+
+
+# ---------------------------------------------------------------- Marlin checkpoint format (qlinear_marlin.py:51-176)
+MARLIN_GOLDEN = ["marlin_k128_n256_g128.npz", "marlin_k256_n256_g128.npz", "marlin_k512_n512_g128.npz"]
+
+
+@pytest.mark.parametrize("fname", MARLIN_GOLDEN)
+def test_marlin_oracle_matches_reference_pack(golden_dir, fname):
+    """tests/golden/marlin_*.npz hold what the reference's QuantLinear.pack wrote (make_golden_marlin.py): the numpy
+    restatement reproduces B and s bit for bit, its inverse recovers the integers and the natural scale order, and the GPTQ
+    tensors derived from them dequantise exactly to the fake-quantised weight that was packed."""
+    from oracle import marlin_oracle as M
+    d = np.load(os.path.join(golden_dir, fname))
+    gs = int(d["group_size"])
+    B, sm = M.pack_ints(np.ascontiguousarray(d["ints"].T).astype(np.int64), np.ascontiguousarray(d["scales"].T), gs)
+    assert np.array_equal(B, d["B"]) and np.array_equal(sm.view(np.uint16), d["s"].view(np.uint16))
+    w, s = M.unpack_ints(d["B"], d["s"], gs)
+    assert np.array_equal(w, d["ints"].T) and np.array_equal(s.view(np.uint16), np.ascontiguousarray(d["scales"].T).view(np.uint16))
+    qw, qz, sc = M.to_gptq(d["B"], d["s"], gs)
+    for mode in (O.ZERO_WRAP, O.ZERO_NOWRAP):
+        W = O.dequantize(torch.from_numpy(qw), torch.from_numpy(qz), torch.from_numpy(sc), None, 4, mode)
+        assert torch.equal(W, torch.from_numpy(d["Wq"]).t())
