@@ -28,7 +28,7 @@ EXPORTS = (
     "gptq_forward", "gptq_forward_ex", "gptq_gemv", "gptq_gemm", "gptq_dequant",
     "gptq_unpack_weights", "gptq_unpack_zeros", "gptq_pack_weights", "gptq_pack_zeros",
     "gptq_make_sequential", "gptq_resequence_qweight", "gptq_permute_columns",
-    "gptq_awq_unpack", "gptq_awq_repack",
+    "gptq_awq_unpack", "gptq_awq_repack", "gptq_describe_plan",
 )
 
 
@@ -92,6 +92,7 @@ def load() -> ctypes.CDLL:
     lib.gptq_make_sequential.argtypes = [c_void_p, c_int, c_int, c_void_p, POINTER(c_int)]
     lib.gptq_resequence_qweight.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.gptq_permute_columns.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.gptq_describe_plan.argtypes = [POINTER(GptqLayer), c_int, POINTER(GptqTuning), c_char_p, c_size_t]
     lib.gptq_awq_unpack.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.gptq_awq_repack.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     for name in EXPORTS:
@@ -110,6 +111,18 @@ def check(status: int) -> None:
         msg = lib.gptq_last_error().decode("utf-8", "replace")
         kind = lib.gptq_status_string(status).decode()
         raise GptqError(status, f"gptq_mi355x: {kind}: {msg}")
+
+
+def describe_plan(layer: "GptqLayer", M: int, tuning: "GptqTuning | None" = None) -> dict:
+    """Kernel and launch geometry gptq_forward_ex would pick (host-only query, see gptq_describe_plan in the header)."""
+    lib = load()
+    buf = ctypes.create_string_buffer(512)
+    check(lib.gptq_describe_plan(ctypes.byref(layer), M, ctypes.byref(tuning) if tuning is not None else None, buf, len(buf)))
+    out = {}
+    for kv in buf.value.decode().split():
+        k, v = kv.split("=", 1)
+        out[k] = int(v) if v.lstrip("-").isdigit() else v
+    return out
 
 
 def ptr(t):

@@ -274,6 +274,30 @@ int gptq_permute_columns(const void* x, const int32_t* perm, int M, int K, int d
     return GPTQ_OK;
 }
 
+int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, char* out, size_t out_bytes) {
+    if (!out || out_bytes == 0) return fail(GPTQ_ERR_NULL, "out must be non-NULL");
+    out[0] = 0;
+    int rc = check_layer(L);
+    if (rc) return rc;
+    if (M <= 0) return fail(GPTQ_ERR_SHAPE, "M must be > 0, got %d", M);
+    const bool unfused_epilogue = L->epilogue != GPTQ_EPI_NONE && !fused_epilogue_ok(L, M, tune);
+    gptq_layer_t Lc = *L;
+    if (unfused_epilogue) Lc.epilogue = GPTQ_EPI_NONE;
+    if (want_gemm(&Lc, M, tune)) {
+        const GemmPlan g = plan_gemm(Lc, M, tune);
+        const char* kern = g.strip16 ? "strip16" : (g.skinny ? "skinny64" : "tiled");
+        snprintf(out, out_bytes, "path=gemm kernel=%s mt=%d bk=%d kg=%d ksplit=%d tiles=%dx%d perm=%d dma=%d epilogue=%s", kern, g.mt, g.bk,
+                 g.kg == 2 ? 2 : 1, g.ksplit, g.nbm, g.nbn, g.use_seq ? 1 : 0, g.glds ? 1 : 0, unfused_epilogue ? "separate" : "none");
+    } else {
+        const GemvPlan v = plan_gemv(Lc, M, tune);
+        const char* kern = v.mfma ? "mfma" : (v.mfmag ? "mfma_generic" : (v.direct ? "direct" : (v.fast ? "lds_staged" : "generic")));
+        snprintf(out, out_bytes, "path=gemv kernel=%s ln=%d waves=%d u=%d ksplit=%d mt=%d strips=%d pair=%d perm=%d epilogue=%s", kern, v.ln,
+                 v.waves, v.u, v.ksplit, v.mt, v.strips, v.pair ? 1 : 0, v.use_seq ? 1 : 0,
+                 v.pair ? "fused" : (unfused_epilogue ? "separate" : "none"));
+    }
+    return GPTQ_OK;
+}
+
 static int awq_shape_check(int K, int N, int group_size) {
     if (K <= 0 || N <= 0 || group_size <= 0) return fail(GPTQ_ERR_SHAPE, "K (%d), N (%d), group_size (%d) must be > 0", K, N, group_size);
     if (K % 8 || N % 8) return fail(GPTQ_ERR_SHAPE, "K (%d) and N (%d) must be multiples of 8 (4-bit words)", K, N);

@@ -160,6 +160,14 @@ int gptq_resequence_qweight(const uint32_t *qweight, const int32_t *perm, int K,
 /* x_out[m, i] = x[m, perm[i]] */
 int gptq_permute_columns(const void *x, const int32_t *perm, int M, int K, int dtype, void *x_out, void *stream);
 
+/* Host-only introspection: which kernel and launch geometry gptq_forward_ex would use for (layer, M, tuning), written as a
+ * short "key=value ..." line into out (NUL-terminated, truncated to out_bytes).  No device work, no pointer is dereferenced
+ * except the struct fields; returns GPTQ_OK or the validation status gptq_forward_ex would return.  Examples:
+ *   "path=gemv kernel=mfma ln=4 waves=16 u=2 ksplit=1 mt=1 strips=256 pair=0 perm=0"
+ *   "path=gemm kernel=tiled mt=4 bk=64 kg=2 ksplit=1 tiles=16x16 perm=1 dma=1"
+ * (the reference's dispatch thresholds, SURVEY §8 a15, are constants in its sources; here they are queryable.) */
+int gptq_describe_plan(const gptq_layer_t *layer, int M, const gptq_tuning_t *tuning, char *out, size_t out_bytes);
+
 /* ---- AWQ checkpoint ingest (4-bit only, as the reference: auto_gptq/modeling/_utils.py:525-701) ----------------
  * AWQ side: awq_qweight u32 [K, N/8] (nibble p of word c = column 8c + {0,2,4,6,1,3,5,7}[p]), awq_qzeros u32 [G, N/8]
  * (same order, raw zero-point, no -1), awq_scales fp16 [G, N] (= the GPTQ `scales` tensor, passed through unchanged).

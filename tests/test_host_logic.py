@@ -249,3 +249,57 @@ def test_marlin_format_conversion(golden_dir, fname):
         marlin.marlin_to_gptq(torch.zeros(4, 512, dtype=torch.int32), torch.zeros(1, 256).half(), 64)
     with pytest.raises(ValueError, match="group_size"):
         marlin.marlin_to_gptq(torch.zeros(16, 512, dtype=torch.int32), torch.zeros(4, 256).half(), 64)
+
+
+def _plan(K, N, M, *, bits=4, gs=128, dtype=0, act=False, epilogue=0, tuning=None):
+    L = _layer(K=K, N=N, bits=bits, group_size=gs, dtype=dtype, epilogue=epilogue)
+    if act:
+        L.g_idx = L.qweight_seq = L.perm = 0x1000        # re-sequenced act-order layer (never dereferenced by the planner)
+    return _lib.describe_plan(L, M, tuning)
+
+
+def test_dispatch_rules_are_the_measured_ones():
+    """gptq_describe_plan (host only): the kernel / geometry gptq_forward_ex picks.  These are the crossovers DESIGN.md §4
+    reports measurements for -- pinned here so a planner edit that moves one shows up without a GPU."""
+    # decode, Llama-7B shapes: matrix-core GEMV, 16-column strips, one launch
+    for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
+        p = _plan(K, N, 1)
+        assert (p["path"], p["kernel"], p["ln"], p["ksplit"], p["waves"]) == ("gemv", "mfma", 4, 1, 16), p
+    assert _plan(4096, 4096, 1)["strips"] == 256 and _plan(4096, 11008, 1)["strips"] == 688
+    # wider plain fp16 layers: 64- / 32-column strips with >= 160 workgroups; bf16 and act-order stay at 16 columns
+    assert _plan(4096, 12288, 1)["ln"] == 16 and _plan(5120, 13824, 1)["ln"] == 16 and _plan(8192, 28672, 1)["ln"] == 16
+    assert _plan(8192, 8192, 1)["ln"] == 8 and _plan(3584, 8192, 1)["ln"] == 8
+    assert _plan(4096, 12288, 1, dtype=1)["ln"] == 4 and _plan(4096, 12288, 1, act=True)["ln"] == 4
+    assert _plan(4096, 12288, 1, act=True)["perm"] == 1
+    # small N: K split (second, fixed-order reduce launch)
+    assert _plan(8192, 1024, 1)["ksplit"] > 1
+    # fused gate/up epilogue lives in the GEMV for M <= 8, and is a separate elementwise pass behind the GEMM paths
+    assert _plan(4096, 22016, 1, epilogue=1)["epilogue"] == "fused" and _plan(4096, 22016, 1, epilogue=1)["pair"] == 1
+    assert _plan(4096, 22016, 64, epilogue=1)["epilogue"] == "separate"
+    # other packings: matrix-core kernel with field extraction (fp16/bf16), fp32 -> generic
+    assert _plan(4096, 4096, 1, bits=3, gs=32)["kernel"] == "mfma_generic" and _plan(4096, 4096, 1, bits=8, gs=32)["kernel"] == "mfma_generic"
+    assert _plan(4096, 4096, 1, dtype=2)["kernel"] == "generic"
+    # rows of x: GEMV up to 8 (two passes for 5..8), except wide layers where 5..8 rows go to the tiled kernel
+    assert _plan(4096, 4096, 4)["mt"] == 4 and _plan(4096, 4096, 8)["mt"] == 8 and _plan(4096, 4096, 8)["path"] == "gemv"
+    assert _plan(4096, 11008, 8)["path"] == "gemm" and _plan(4096, 11008, 8)["kernel"] == "tiled" and _plan(4096, 11008, 4)["path"] == "gemv"
+    # batched decode: strips up to 16 rows, 64-column skinny up to 64 rows on narrow layers, tiled on wide ones
+    assert _plan(4096, 4096, 9)["kernel"] == "strip16" and _plan(4096, 4096, 16)["kernel"] == "strip16"
+    assert _plan(4096, 4096, 17)["kernel"] == "skinny64" and _plan(4096, 4096, 64)["kernel"] == "skinny64"
+    assert _plan(4096, 11008, 16)["kernel"] == "tiled" and _plan(4096, 11008, 64)["kernel"] == "tiled"
+    assert _plan(4096, 4096, 16, bits=8, gs=32)["kernel"] == "skinny64"          # the 16-column-strip kernel is 4-bit only
+    # prefill: 128 x 256 tiles, 64-deep K-steps; two K groups per workgroup when there is at most one tile per CU
+    p = _plan(4096, 4096, 2048)
+    assert (p["kernel"], p["mt"], p["bk"], p["kg"], p["ksplit"], p["tiles"]) == ("tiled", 4, 64, 2, 1, "16x16"), p
+    assert _plan(4096, 4096, 4096)["kg"] == 1 and _plan(4096, 11008, 2048)["kg"] == 1 and _plan(11008, 4096, 2048)["kg"] == 2
+    pa = _plan(4096, 4096, 2048, act=True)
+    assert pa["perm"] == 1 and pa["dma"] == 1 and pa["kg"] == 2
+    assert _plan(4096, 4096, 512)["ksplit"] > 1                                       # too few tiles to fill 256 CUs
+    assert _plan(4096, 4096, 2048, gs=32)["bk"] == 32
+    # forcing a path through tuning
+    t = _lib.GptqTuning()
+    t.path = 3
+    assert _plan(4096, 4096, 1, tuning=t)["path"] == "gemm"
+    t.path = 1
+    assert _plan(4096, 4096, 1, tuning=t)["kernel"] == "generic"
+    with pytest.raises(_lib.GptqError):
+        _plan(4096, 4096, 0)
