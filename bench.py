@@ -238,7 +238,23 @@ def bench_tp(device, rank, world, steps):
     return res
 
 
+def _watchdog(seconds: float):
+    """A wedged GPU call never returns to Python; a timer thread (the GIL is released inside HIP calls) ends the process
+    instead of letting the launcher's own limit expire on a hung box."""
+    import threading
+
+    def fire():
+        sys.stderr.write(f"bench.py: no result after {seconds:.0f} s -- aborting (BENCH_WATCHDOG_S to change)\n")
+        sys.stderr.flush()
+        os._exit(3)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def main():
+    _watchdog(float(os.environ.get("BENCH_WATCHDOG_S", "900")))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)

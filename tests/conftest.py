@@ -15,6 +15,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timeout: per-test limit (pytest-timeout; ignored when the plugin is absent)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests get a per-test limit (pytest-timeout, thread method: the process is ended even if the main thread is stuck
+    inside a HIP call) so that a wedged kernel fails one test loudly instead of hanging the whole run on the GPU box."""
+    for item in items:
+        if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600, method="thread"))
 
 
 def _torch_dtype(name):
