@@ -107,3 +107,53 @@ def test_row_parallel_two_ranks_gloo(bits, gs, K, N, M):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
+
+
+def _worker_mlp(rank, world, port, K, F, gs, M, q):
+    """Megatron pairing on a gated MLP: gate/up column-parallel WITHOUT gather, down row-parallel with input_is_parallel=True:
+    one all-reduce per block, no all-gather.  Rank-local matmuls are played by the oracle (fp32)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from autogptq_amd.tensor_parallel import RowParallelQuantLinear, shard_packed_rows
+        gate = O.random_quant_layer(K, F, 4, gs, seed=11)
+        up = O.random_quant_layer(K, F, 4, gs, seed=12)
+        down = O.random_quant_layer(F, K, 4, gs, seed=13, bias=True)
+        x = (torch.rand(M, K, generator=torch.Generator().manual_seed(7)) - 0.5).float()
+        mode = O.ZERO_WRAP
+
+        def col(L):
+            qw, qz, sc, _ = shard_packed(L["qweight"], L["qzeros"], L["scales"].float(), None, 4, rank, world)
+            return ColumnParallelQuantLinear(lambda xx: O.forward(xx, qw, qz, sc, None, None, 4, mode), F, gather_output=False)
+
+        g_mod, u_mod = col(gate), col(up)
+        qw, qz, sc, (k0, k1) = shard_packed_rows(down["qweight"], down["qzeros"], down["scales"].float(), 4, gs, rank, world)
+        d_mod = RowParallelQuantLinear(lambda xx: O.forward(xx, qw, qz, sc, None, None, 4, mode), (k0, k1), bias=down["bias"].float(),
+                                       input_is_parallel=True)
+        h = torch.nn.functional.silu(g_mod(x)) * u_mod(x)                 # [M, F / world]: stays sharded
+        assert tuple(h.shape) == (M, F // world) and (k0, k1) == shard_bounds(F, rank, world)
+        y = d_mod(h)
+
+        def full(L, xx, b=None):
+            return O.forward(xx, L["qweight"], L["qzeros"], L["scales"].float(), None, b, 4, mode)
+
+        ref = full(down, torch.nn.functional.silu(full(gate, x)) * full(up, x), down["bias"].float())
+        q.put((rank, bool(torch.allclose(y, ref, rtol=1e-4, atol=1e-5)), float((y - ref).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_column_then_row_parallel_mlp_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mlp, args=(r, world, port, 256, 512, 128, 3, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
