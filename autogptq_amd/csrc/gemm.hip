@@ -28,6 +28,7 @@
 //     into the workspace by a small LDS-staged gather kernel (the column_remap of exllama, column_remap.cu:9-63).
 //   * fp32 accumulation in the MFMA; optional split-K (only when M*N is too small to fill 256 CUs) writes
 //     fp32 partial slabs that a second pass sums in fixed order: bit-reproducible, no atomics.
+#include <atomic>
 #include <type_traits>
 
 #include "common.cuh"
@@ -1009,8 +1010,16 @@ static hipError_t launch_one(const GemmPlan& pl, const GemmParams& p, hipStream_
     const size_t lds = (size_t)KG * 2 * (32 * MT) * (GLDS ? BK * 2 : BK * 2 + 16);   // KG = 2: >= the 64 KiB exchange area
     auto* kern = gemm_kernel<BITS, T, MT, BK, VAR, XPRE, GLDS, KG>;
     if constexpr (KG == 2) {
-        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (attr != hipSuccess) return attr;
+        // > 64 KiB of dynamic LDS has to be granted per function AND per device (a process that places layers on several GPUs,
+        // as accelerate's device_map does for the reference, launches this kernel on each of them)
+        static std::atomic<unsigned long long> granted{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;
+        if (!((granted.load(std::memory_order_relaxed) >> dev) & 1ull) || dev == 63) {
+            const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (attr != hipSuccess) return attr;
+            granted.fetch_or(1ull << dev, std::memory_order_relaxed);
+        }
     }
     hipLaunchKernelGGL(kern, dim3(pl.nbm * pl.nbn, pl.ksplit), dim3(256 * KG), lds, st, p);
     return hipGetLastError();
