@@ -301,8 +301,13 @@ class QuantLinear(nn.Module):
         use_gpu = torch.cuda.is_available() and W.dtype in _lib.DTYPE_ENUM and scales_t.dtype in _lib.DTYPE_ENUM \
             and zeros_t.dtype == scales_t.dtype
         if use_gpu:
-            qweight, qzeros, scales_out = self._pack_device(W, scales_t, zeros_t, gi)
+            qweight, qzeros, scales_out = self._pack_device(W, scales_t, zeros_t, gi)      # raises if the library is missing
         else:
+            # No HIP device (or a dtype outside the C ABI): the reference's own pack() is CPU code, and this is its
+            # vectorised equivalent, bit-identical (tests/test_host_logic.py::test_host_pack_bit_exact).  Said out loud,
+            # because everything else in this backend refuses to run on the host.
+            _warn_once("mi355x QuantLinear.pack: no HIP device available (or unsupported dtype) -- packing on the host, "
+                       "as the reference does")
             qweight, qzeros, scales_out = self._pack_host(W, scales_t, zeros_t, gi)
         self.qweight = qweight.to(home)
         self.qzeros = qzeros.to(home)
