@@ -303,3 +303,31 @@ def test_dispatch_rules_are_the_measured_ones():
     assert _plan(4096, 4096, 1, tuning=t)["kernel"] == "generic"
     with pytest.raises(_lib.GptqError):
         _plan(4096, 4096, 0)
+
+
+def test_format_round_trips_random():
+    """Random layers through the three checkpoint formats: GPTQ -> Marlin -> GPTQ is the identity on symmetric layers, and
+    AWQ words -> GPTQ words unpack (oracle) to the integers that were packed, for several shapes and seeds."""
+    import numpy as np
+    import torch
+    from autogptq_amd import marlin
+    from oracle import awq_oracle as A
+    from oracle import gptq_oracle as O
+    rng = np.random.default_rng(0)
+    for K, N, gs in ((128, 256, 128), (256, 512, 128), (384, 256, 384)):
+        w = rng.integers(0, 16, size=(K, N))
+        qw = torch.from_numpy(O.pack_rows(w.astype(np.uint32), 4).copy())
+        G = K // gs
+        qz = torch.full((G, N // 8), 0x77777777, dtype=torch.int32)
+        sc = torch.from_numpy((0.001 * (1 + rng.random((G, N)))).astype(np.float16))
+        B, s = marlin.gptq_to_marlin(qw, qz, sc, gs)
+        assert tuple(B.shape) == (K // 16, 2 * N) and tuple(s.shape) == (G, N)
+        qw2, qz2, sc2 = marlin.marlin_to_gptq(B, s, gs)
+        assert torch.equal(qw2, qw) and torch.equal(qz2, qz) and torch.equal(sc2, sc)
+    for K, N, gs in ((64, 64, 32), (128, 200, 64), (256, 8, 128)):
+        w = rng.integers(0, 16, size=(K, N))
+        z = rng.integers(0, 16, size=(K // gs, N))
+        qw, qz = A.awq_to_gptq(A.awq_pack(w), A.awq_pack(z))
+        assert np.array_equal(O.unpack_rows(qw, 4), w)
+        zz = O.unpack_rows(np.ascontiguousarray(qz.T), 4).T            # stored fields: (z - 1) & 15
+        assert np.array_equal(zz, (z - 1) & 15)
