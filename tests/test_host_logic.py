@@ -331,3 +331,68 @@ def test_format_round_trips_random():
         assert np.array_equal(O.unpack_rows(qw, 4), w)
         zz = O.unpack_rows(np.ascontiguousarray(qz.T), 4).T            # stored fields: (z - 1) & 15
         assert np.array_equal(zz, (z - 1) & 15)
+
+
+def test_load_packed_layers_from_gptq_and_marlin_state(tmp_path):
+    """load_packed_layers: a model skeleton filled from (a) a GPTQ state dict written with safetensors and (b) the same layers
+    serialised in the Marlin layout -- both must leave exactly the GPTQ tensors in the swapped QuantLinear modules, load the
+    non-quantized rest, and refuse inconsistent inputs."""
+    from safetensors.torch import load_file, save_file
+    from autogptq_amd import marlin
+    from autogptq_amd.model_utils import load_packed_layers
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.up = torch.nn.Linear(128, 256, bias=True)
+            self.norm = torch.nn.LayerNorm(256)
+            self.down = torch.nn.Linear(256, 256, bias=False)
+
+    torch.manual_seed(1)
+    src = Toy().half()
+    gptq_state = {k: v.clone() for k, v in src.state_dict().items() if k.startswith("norm")}
+    for name, lin in (("up", src.up), ("down", src.down)):
+        K = lin.in_features
+        G = K // 128
+        W = lin.weight.data.float()
+        s = (W.reshape(-1, G, 128).abs().amax(dim=2) / 7 + 1e-4).half()                  # symmetric: zero-point 8
+        z = torch.full_like(s, 8)
+        qw, qz, sc = O.pack(lin.weight.data.clone(), s, z, torch.from_numpy(O.default_g_idx(K, 128)), 4, torch.float16)
+        gptq_state.update({f"{name}.qweight": qw, f"{name}.qzeros": qz, f"{name}.scales": sc,
+                           f"{name}.g_idx": torch.from_numpy(O.default_g_idx(K, 128))})
+        if lin.bias is not None:
+            gptq_state[f"{name}.bias"] = lin.bias.data.clone()
+    path = str(tmp_path / "model.safetensors")
+    save_file({k: v.contiguous() for k, v in gptq_state.items()}, path)
+
+    m1 = load_packed_layers(Toy().half(), load_file(path), 4, 128)
+    assert isinstance(m1.up, QuantLinear) and isinstance(m1.down, QuantLinear) and isinstance(m1.norm, torch.nn.LayerNorm)
+    for name in ("up", "down"):
+        q = getattr(m1, name)
+        for attr in ("qweight", "qzeros", "scales"):
+            assert torch.equal(getattr(q, attr), gptq_state[f"{name}.{attr}"]), (name, attr)
+    assert torch.equal(m1.up.bias, gptq_state["up.bias"]) and m1.down.bias is None
+    assert torch.equal(m1.norm.weight, src.norm.weight)
+
+    marlin_state = {k: v for k, v in gptq_state.items() if k.startswith("norm") or k.endswith(".bias")}
+    for name in ("up", "down"):
+        B, s = marlin.gptq_to_marlin(gptq_state[f"{name}.qweight"], gptq_state[f"{name}.qzeros"], gptq_state[f"{name}.scales"], 128)
+        marlin_state.update({f"{name}.B": B, f"{name}.s": s, f"{name}.workspace": torch.zeros(32, dtype=torch.int32)})
+    m2 = load_packed_layers(Toy().half(), marlin_state, 4, 128, checkpoint_format="marlin")
+    for name in ("up", "down"):
+        for attr in ("qweight", "qzeros", "scales"):
+            assert torch.equal(getattr(getattr(m2, name), attr), gptq_state[f"{name}.{attr}"]), (name, attr)
+    assert torch.equal(m2.up.bias, gptq_state["up.bias"])
+
+    with pytest.raises(ValueError, match="not supported"):
+        load_packed_layers(Toy().half(), gptq_state, 4, 128, quant_method="awq", checkpoint_format="marlin")
+    with pytest.raises(KeyError):
+        load_packed_layers(Toy().half(), {"nope.qweight": gptq_state["up.qweight"]}, 4, 128)
+    bad = dict(gptq_state)
+    bad["up.qweight"] = bad["up.qweight"][:, :128]
+    with pytest.raises(ValueError, match="shape"):
+        load_packed_layers(Toy().half(), bad, 4, 128)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no host implementation"):
+            load_packed_layers(Toy().half(), {"up.qweight": torch.zeros(128, 32, dtype=torch.int32), "up.qzeros": torch.zeros(1, 32, dtype=torch.int32),
+                                              "up.scales": torch.ones(1, 256).half()}, 4, 128, quant_method="awq", checkpoint_format="gemm")
