@@ -396,3 +396,39 @@ def test_load_packed_layers_from_gptq_and_marlin_state(tmp_path):
         with pytest.raises(RuntimeError, match="no host implementation"):
             load_packed_layers(Toy().half(), {"up.qweight": torch.zeros(128, 32, dtype=torch.int32), "up.qzeros": torch.zeros(1, 32, dtype=torch.int32),
                                               "up.scales": torch.ones(1, 256).half()}, 4, 128, quant_method="awq", checkpoint_format="gemm")
+
+
+def test_pack_accepts_conv1d_and_conv2d_modules():
+    """pack() takes nn.Linear, HF Conv1D (weight stored [in, out] -> transposed) and nn.Conv2d (weight flattened to [out, in*kh*kw])
+    exactly like the reference (qlinear_cuda.py:109-113), and make_quant sizes the replacement from the right attributes
+    (auto_gptq/modeling/_utils.py:108-119)."""
+    import transformers
+    from autogptq_amd.model_utils import make_quant
+    torch.manual_seed(3)
+    K, N, gs = 64, 96, 32
+    g_idx = torch.from_numpy(O.default_g_idx(K, gs))
+
+    c1 = transformers.pytorch_utils.Conv1D(N, K)                       # nf = out, nx = in; weight [K, N]
+    c1.weight.data = torch.randn(K, N) * 0.05
+    c1.bias.data = torch.randn(N) * 0.1
+    c1 = c1.half()
+    c2 = torch.nn.Conv2d(K, N, kernel_size=1, bias=False).half()       # weight [N, K, 1, 1]
+    for mod, W_nk in ((c1, c1.weight.data.t().contiguous()), (c2, c2.weight.data.flatten(1).contiguous())):
+        s, z = O.minmax_quantize(W_nk.float(), 4, gs)
+        q = QuantLinear(4, gs, K, N, mod.bias is not None)
+        q.pack(mod, s.half(), z.half(), g_idx)
+        qw, qz, sc = O.pack(W_nk.clone(), s.half(), z.half(), g_idx, 4, torch.float16)
+        assert torch.equal(q.qweight, qw) and torch.equal(q.qzeros, qz) and torch.equal(q.scales, sc)
+        if mod.bias is not None:
+            assert torch.equal(q.bias, mod.bias.data)
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = transformers.pytorch_utils.Conv1D(N, K)
+            self.c2 = torch.nn.Conv2d(K, N, kernel_size=1)
+
+    m = Toy().half()
+    make_quant(m, ["c1", "c2"], 4, gs)
+    assert (m.c1.infeatures, m.c1.outfeatures, m.c2.infeatures, m.c2.outfeatures) == (K, N, K, N)
+    assert m.c1.bias is not None and m.c2.bias is not None
