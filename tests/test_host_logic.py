@@ -432,3 +432,24 @@ def test_pack_accepts_conv1d_and_conv2d_modules():
     make_quant(m, ["c1", "c2"], 4, gs)
     assert (m.c1.infeatures, m.c1.outfeatures, m.c2.infeatures, m.c2.outfeatures) == (K, N, K, N)
     assert m.c1.bias is not None and m.c2.bias is not None
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16], ids=["bf16", "fp32", "fp16"])
+@pytest.mark.parametrize("gs", [16, 32, 128])
+def test_host_pack_on_the_reference_value_patterns(gs, dtype):
+    """The pack() half of the reference's backend grid (tests/test_hpu_linear.py:102-160: 13 scale/weight/zero value patterns,
+    integer zero-points, zero-point 0 that wraps to an all-ones word) on the host implementation, against the oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_parity_helpers", os.path.join(ROOT, "tests", "test_gpu_parity.py"))
+    # the pattern generator lives next to the GPU grid test; import only the two names (the module's GPU fixtures are lazy)
+    src = open(spec.origin).read()
+    start, end = src.index("HPU_PATTERNS = ["), src.index('@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])')
+    ns = {"torch": torch}
+    exec(src[start:end], ns)
+    K = N = 128
+    for pi, pattern in enumerate(ns["HPU_PATTERNS"]):
+        lin, s, z = ns["_pattern_layer"](K, N, gs, pattern, dtype, bool(pi & 1), seed=pi + gs)
+        q = QuantLinear(4, gs, K, N, bool(pi & 1), weight_dtype=dtype)
+        q.pack(lin, s.clone(), z.clone(), g_idx=None)
+        qw, qz, sc = O.pack(lin.weight.data.clone(), s.clone(), z.clone(), None, 4, dtype)
+        assert torch.equal(q.qweight, qw) and torch.equal(q.qzeros, qz) and torch.equal(q.scales, sc), (pattern, gs, dtype)
