@@ -190,7 +190,7 @@ def cpu_baseline(M, act_order, budget_s=20.0):
         mode = O.reference_zero_mode(act_order, 4)
         O.forward(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], None, 4, mode)   # warm-up
         n, t_acc = 0, 0.0
-        while t_acc < per_shape and n < 10:
+        while t_acc < per_shape and n < 24:                          # ~ 15-20 s of host work in total
             t0 = time.perf_counter()
             O.forward(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], None, 4, mode)
             t_acc += time.perf_counter() - t0
