@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPTQ_MI355X_LIB", os.path.join(_HERE, "libgptq_mi355x.so"))
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 GPTQ_F16, GPTQ_BF16, GPTQ_F32 = 0, 1, 2
 ZERO_WRAP, ZERO_NOWRAP = 0, 1
@@ -29,6 +29,7 @@ EXPORTS = (
     "gptq_unpack_weights", "gptq_unpack_zeros", "gptq_pack_weights", "gptq_pack_zeros",
     "gptq_make_sequential", "gptq_resequence_qweight", "gptq_permute_columns",
     "gptq_awq_unpack", "gptq_awq_repack", "gptq_describe_plan",
+    "gptq_init", "gptq_workspace_bytes_max", "gptq_validate_g_idx",
 )
 
 
@@ -79,6 +80,10 @@ def load() -> ctypes.CDLL:
     lib.gptq_workspace_bytes.argtypes = [POINTER(GptqLayer), c_int]
     lib.gptq_workspace_bytes_ex.restype = c_size_t
     lib.gptq_workspace_bytes_ex.argtypes = [POINTER(GptqLayer), c_int, POINTER(GptqTuning)]
+    lib.gptq_workspace_bytes_max.restype = c_size_t
+    lib.gptq_workspace_bytes_max.argtypes = [POINTER(GptqLayer), c_int]
+    lib.gptq_init.argtypes = []
+    lib.gptq_validate_g_idx.argtypes = [c_void_p, c_int, c_int]
     fw = [POINTER(GptqLayer), c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]
     lib.gptq_forward.argtypes = fw
     for name in ("gptq_forward_ex", "gptq_gemv", "gptq_gemm"):
@@ -96,7 +101,8 @@ def load() -> ctypes.CDLL:
     lib.gptq_awq_unpack.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.gptq_awq_repack.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     for name in EXPORTS:
-        if name not in ("gptq_last_error", "gptq_status_string", "gptq_workspace_bytes", "gptq_workspace_bytes_ex"):
+        if name not in ("gptq_last_error", "gptq_status_string", "gptq_workspace_bytes", "gptq_workspace_bytes_ex",
+                        "gptq_workspace_bytes_max"):
             getattr(lib, name).restype = c_int
     got = lib.gptq_abi_version()
     if got != ABI_VERSION:
@@ -123,6 +129,21 @@ def describe_plan(layer: "GptqLayer", M: int, tuning: "GptqTuning | None" = None
         k, v = kv.split("=", 1)
         out[k] = int(v) if v.lstrip("-").isdigit() else v
     return out
+
+
+_INITED = set()
+
+
+def ensure_init(device) -> None:
+    """gptq_init() once per device (outside stream capture: QuantLinear.post_init calls this)."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx in _INITED:
+        return
+    with torch.cuda.device(idx):
+        check(load().gptq_init())
+    _INITED.add(idx)
 
 
 def ptr(t):

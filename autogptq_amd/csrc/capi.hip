@@ -112,13 +112,34 @@ size_t gptq_workspace_bytes_ex(const gptq_layer_t* L, int M, const gptq_tuning_t
 
 size_t gptq_workspace_bytes(const gptq_layer_t* L, int M) { return gptq_workspace_bytes_ex(L, M, nullptr); }
 
+size_t gptq_workspace_bytes_max(const gptq_layer_t* L, int max_M) {
+    size_t best = 0;
+    for (int M = 1; M <= max_M; ++M) best = std::max(best, gptq_workspace_bytes_ex(L, M, nullptr));   // host arithmetic only
+    return best;
+}
+
+int gptq_init(void) {
+    hipError_t e = init_gemm_device();
+    if (e != hipSuccess) return hip_fail(e, "gptq_init (hipFuncSetAttribute)");
+    return GPTQ_OK;
+}
+
+int gptq_validate_g_idx(const int32_t* g_idx, int K, int G) {
+    if (!g_idx) return fail(GPTQ_ERR_NULL, "g_idx is NULL");
+    if (K <= 0 || G <= 0) return fail(GPTQ_ERR_SHAPE, "K (%d) and G (%d) must be > 0", K, G);
+    for (int k = 0; k < K; ++k)
+        if (g_idx[k] < 0 || g_idx[k] >= G)
+            return fail(GPTQ_ERR_SHAPE, "g_idx[%d] = %d is outside [0, %d) (rows of scales / qzeros)", k, g_idx[k], G);
+    return GPTQ_OK;
+}
+
 int gptq_gemv(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream,
               const gptq_tuning_t* tune) {
     int rc = check_layer(L);
     if (rc) return rc;
     rc = check_io(x, out, M);
     if (rc) return rc;
-    if (tune && tune->lanes_n && tune->lanes_n != 4 && tune->lanes_n != 8 && tune->lanes_n != 16 && tune->lanes_n != 64)
+    if (tune && tune->lanes_n && tune->lanes_n != 4 && tune->lanes_n != 8 && tune->lanes_n != 16 && tune->lanes_n != 64)   // = the header's list
         return fail(GPTQ_ERR_UNSUPPORTED, "tuning.lanes_n must be 4, 8, 16 or 64");
     if (tune && (tune->waves < 0 || tune->waves > 16)) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.waves must be 1..16");
     GemvPlan pl = plan_gemv(*L, M, tune);
@@ -153,7 +174,9 @@ int gptq_gemm(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, 
     if (pl.workspace_bytes > 0 && (!ws || ws_bytes < pl.workspace_bytes))
         return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", pl.workspace_bytes, ws ? ws_bytes : (size_t)0);
     hipError_t e = launch_gemm(*L, pl, x, out, M, ws, (hipStream_t)stream);
-    if (e != hipSuccess) return hip_fail(e, "gptq_gemm launch");
+    if (e != hipSuccess)
+        return hip_fail(e, pl.kg == 2 ? "gptq_gemm launch (this kernel needs > 64 KiB of LDS: was gptq_init() called on this device?)"
+                                      : "gptq_gemm launch");
     return GPTQ_OK;
 }
 

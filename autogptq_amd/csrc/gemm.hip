@@ -28,7 +28,6 @@
 //     into the workspace by a small LDS-staged gather kernel (the column_remap of exllama, column_remap.cu:9-63).
 //   * fp32 accumulation in the MFMA; optional split-K (only when M*N is too small to fill 256 CUs) writes
 //     fp32 partial slabs that a second pass sums in fixed order: bit-reproducible, no atomics.
-#include <atomic>
 #include <type_traits>
 
 #include "common.cuh"
@@ -908,6 +907,23 @@ hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int 
 }
 
 // ---- host side ----------------------------------------------------------------------------------
+template <int BITS, typename T, int MT, int BK, int VAR, bool XPRE, bool GLDS, int KG>
+static constexpr size_t gemm_lds_bytes() { return (size_t)KG * 2 * (32 * MT) * (GLDS ? BK * 2 : BK * 2 + 16); }
+
+template <int BITS, typename T, int MT, int BK, int VAR, bool XPRE, bool GLDS, int KG>
+static hipError_t grant_lds() {
+    return hipFuncSetAttribute((const void*)gemm_kernel<BITS, T, MT, BK, VAR, XPRE, GLDS, KG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)gemm_lds_bytes<BITS, T, MT, BK, VAR, XPRE, GLDS, KG>());
+}
+
+// Per-device, once, outside any capture (gptq_init): kernels whose dynamic LDS exceeds the 64 KiB default.
+hipError_t init_gemm_device() {
+    hipError_t e = grant_lds<4, f16, 4, 64, 1, true, true, 2>();
+    if (e == hipSuccess) e = grant_lds<4, f16, 4, 64, 1, false, false, 2>();
+    if (e == hipSuccess) e = grant_lds<4, bf16, 4, 64, 1, false, false, 2>();
+    return e;
+}
+
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
@@ -1009,18 +1025,8 @@ template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, 
 static hipError_t launch_one(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
     const size_t lds = (size_t)KG * 2 * (32 * MT) * (GLDS ? BK * 2 : BK * 2 + 16);   // KG = 2: >= the 64 KiB exchange area
     auto* kern = gemm_kernel<BITS, T, MT, BK, VAR, XPRE, GLDS, KG>;
-    if constexpr (KG == 2) {
-        // > 64 KiB of dynamic LDS has to be granted per function AND per device (a process that places layers on several GPUs,
-        // as accelerate's device_map does for the reference, launches this kernel on each of them)
-        static std::atomic<unsigned long long> granted{0};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;
-        if (!((granted.load(std::memory_order_relaxed) >> dev) & 1ull) || dev == 63) {
-            const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (attr != hipSuccess) return attr;
-            granted.fetch_or(1ull << dev, std::memory_order_relaxed);
-        }
-    }
+    // KG = 2 asks for > 64 KiB of dynamic LDS: granted per function and device by init_gemm_device() (gptq_init), never here --
+    // the launch path makes no runtime-API call besides the launch itself, so it is legal under stream capture.
     hipLaunchKernelGGL(kern, dim3(pl.nbm * pl.nbn, pl.ksplit), dim3(256 * KG), lds, st, p);
     return hipGetLastError();
 }

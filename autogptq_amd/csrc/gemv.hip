@@ -7,19 +7,25 @@
 // design is CDNA4-first:
 //
 //  * A workgroup owns a COLUMN STRIP of CT = 4*LN output columns over a K range; a lane owns 4
-//    adjacent columns (one 128-bit load per packed row: 16 B/lane) and the 64/LN "row slots" of a
-//    wave walk consecutive packed rows, so one wave-load covers WR rows x (16*LN) contiguous
-//    bytes.  Logical strip ids are remapped so neighbouring strips share an XCD (one L2).
-//  * Every lane issues all of its weight loads before touching LDS: for Llama-7B shapes the whole
-//    matrix is in flight at once (the kernel is one HBM round trip + a reduction).
-//  * x is staged once per workgroup in LDS (fast path: fp16, pre-permuted so one ds_read_b128
-//    yields the (k,k+4) pairs that the 0x6400 magic-number unpack produces; act-order layers
-//    gather x through perm[] here, which is the whole cost of act-order on this path).
-//  * 4-bit fp16 fast path: w-z is formed EXACTLY in packed fp16 ((q & 0x000f000f) | 0x64006400 is
-//    1024+w; adding -(1024+z) is exact), dotted with x by v_dot2_f32_f16 (fp32 accumulate) and
-//    scaled once per 8 k in fp32.  No fp16 accumulation anywhere.
-//  * K reduction: row slots by wavefront shuffles (DPP), waves through LDS in fixed order, then
-//    (only if ksplit > 1) a second pass over fp32 partials.  No atomics: bit-reproducible.
+//    adjacent columns (one 128-bit nontemporal load per packed row: 16 B/lane) and the 64/LN "row
+//    slots" of a wave walk consecutive packed rows, so one wave-load covers WR rows x (16*LN)
+//    contiguous bytes.  Logical strip ids are remapped so neighbouring strips share an XCD (one L2).
+//  * Default kernel (4-bit, fp16/bf16, power-of-two rows per group): gemv_q4_f16_mfma_kernel.  Nothing is
+//    staged in LDS before the math: every lane issues, in this order, its (scales, zeros) pair, the 16 B of x
+//    per packed row (L2 resident) and its U consecutive packed rows -- for the Llama-7B shapes the whole
+//    matrix is in flight at once (one HBM round trip + a reduction).  w - z is formed EXACTLY in packed
+//    fp16 ((q & 0x000f000f) | 0x64006400 is 1024 + w; adding -(1024 + z) is exact) and the k-reduction runs
+//    on the matrix core: v_mfma_f32_4x4x4_16b_f16 is 16 independent 4x4x4 products, one per aligned 4-lane
+//    group = one packed row x 16 columns, so up to 4 rows of x cost the same as one.  The scale multiplies
+//    the fp32 group sums once per (lane, group).  No fp16 accumulation anywhere.
+//  * Other packings (2/3/8-bit, fp16/bf16): gemv_mfma_generic_kernel, same structure, fields by v_bfe.
+//    fp32 I/O, raw (non-uniform) act-order g_idx, odd group sizes: gemv_generic_kernel (fp32 FMA, x in LDS).
+//    gemv_q4_f16_direct_kernel (v_dot2 reduction) and gemv_q4_f16_kernel (LDS-staged x / group constants,
+//    the first working path of round 1) are kept as comparison variants behind tuning.path = 4 / 2.
+//  * act-order layers read the group-sorted side copy of qweight; x is gathered through perm[] (whole row
+//    staged in LDS once, rows pulled with ds_bpermute), which is the whole cost of act-order on this path.
+//  * K reduction: row slots by DPP rotates / ds_bpermute, waves through LDS in fixed order (the kernel's
+//    only barrier), then (only if ksplit > 1) a second pass over fp32 partials.  No atomics: bit-reproducible.
 #include <type_traits>
 
 #include "common.cuh"

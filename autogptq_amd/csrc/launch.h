@@ -38,6 +38,8 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune);
 hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x, void* out, int M,
                        void* workspace, hipStream_t st);
 
+hipError_t init_gemm_device();
+
 hipError_t launch_dequant(const gptq_layer_t& L, void* W_out, hipStream_t st);
 hipError_t launch_unpack_weights(const uint32_t* qweight, int K, int N, int bits, uint8_t* w_out, hipStream_t st);
 hipError_t launch_unpack_zeros(const uint32_t* qzeros, int G, int N, int bits, int zero_mode, int32_t* z_out, hipStream_t st);

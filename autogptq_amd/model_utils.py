@@ -97,9 +97,9 @@ def autogptq_post_init(model: nn.Module, use_act_order: bool = False, max_input_
             continue
         sub.post_init()
         lib = _lib.load()
-        for m in {1, 8, 64, rows}:
-            b = int(lib.gptq_workspace_bytes(ctypes.byref(sub._layer), m))
-            need[sub.qweight.device] = max(need.get(sub.qweight.device, 0), b)
+        # the need is not monotone in M (K splits come and go with the kernel the planner picks): maximum over 1..rows
+        b = int(lib.gptq_workspace_bytes_max(ctypes.byref(sub._layer), rows))
+        need[sub.qweight.device] = max(need.get(sub.qweight.device, 0), b)
     for dev, b in need.items():
         reserve_workspace(dev, b)
     return model

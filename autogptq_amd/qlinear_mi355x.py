@@ -37,20 +37,44 @@ def _warn_once(msg: str) -> None:
         logger.warning(msg)
 
 
-# one scratch buffer per device, shared by every layer (the reference keeps the same kind of
-# per-device scratch in model.device_to_buffers, auto_gptq/modeling/_utils.py:448-470)
-_WORKSPACE: dict = {}
+# Scratch (split-K slabs, permuted x): one buffer per (device, stream), shared by every layer that runs on that stream (the
+# reference keeps the same kind of per-device scratch in model.device_to_buffers, auto_gptq/modeling/_utils.py:448-470).
+#   * keyed by stream: layers running concurrently on different streams never share split-K partials;
+#   * a buffer that is outgrown is RETIRED, never freed: a hipGraph captured earlier has its address baked in, and memory
+#     handed back to the caching allocator would be overwritten by later replays;
+#   * a buffer allocated while its stream is capturing belongs to that graph's private pool: it serves that capture only and
+#     is not reused by eager calls that later land on the same stream handle.
+_WORKSPACE: dict = {}      # (device index, stream handle) -> (tensor, allocated_during_capture)
+_RETIRED: list = []
 
 
-def reserve_workspace(device, nbytes: int) -> torch.Tensor:
-    """Make sure the per-device scratch holds ``nbytes``; call before hipGraph capture."""
+def reserve_workspace(device, nbytes: int, stream=None) -> torch.Tensor:
+    """Make sure the scratch of (device, stream) holds ``nbytes`` (stream: a handle, default = the current stream).
+    Call with the largest need before hipGraph capture (``autogptq_post_init`` does) so that forward never allocates."""
     device = torch.device(device)
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    buf = _WORKSPACE.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _WORKSPACE[key] = buf
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    device = torch.device("cuda", idx)
+    if stream is None:
+        stream = torch.cuda.current_stream(device).cuda_stream
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (idx, int(stream))
+    ent = _WORKSPACE.get(key)
+    if ent is not None:
+        buf, was_captured = ent
+        if buf.numel() >= nbytes and (capturing or not was_captured):
+            return buf
+        _RETIRED.append(buf)
+        nbytes = max(int(nbytes), 2 * buf.numel() if buf.numel() < nbytes else buf.numel())
+    buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+    _WORKSPACE[key] = (buf, capturing)
     return buf
+
+
+try:                                   # raw hipStream_t of the current stream without building a torch.cuda.Stream object
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:                 # pragma: no cover
+    def _raw_stream(idx):
+        return torch.cuda.current_stream(idx).cuda_stream
 
 
 def _is_sequential_g_idx(g_idx: torch.Tensor, group_size: int) -> bool:
@@ -160,6 +184,13 @@ class QuantLinear(nn.Module):
         lib = _lib.load()
         if self.g_idx.numel() != self.infeatures:
             raise NotImplementedError("len(g_idx) != infeatures (fused-QKV g_idx) is not supported.")
+        # raw device pointers go to the kernels: every buffer has to live on the module's GPU (a host pointer would fault there)
+        for name in ("qzeros", "scales", "g_idx", "bias"):
+            t = getattr(self, name)
+            if t is not None and t.device != dev:
+                raise RuntimeError(f"mi355x QuantLinear.post_init: {name} is on {t.device} but qweight is on {dev}; move the "
+                                   "whole module with .to(device) first")
+        _lib.ensure_init(dev)
         for name in ("qweight", "qzeros", "scales", "g_idx"):
             t = getattr(self, name)
             if not t.is_contiguous():
@@ -174,6 +205,7 @@ class QuantLinear(nn.Module):
         g_idx_ptr = None
         if self.act_order:
             g_host = self.g_idx.to("cpu", torch.int32).contiguous()
+            _lib.check(lib.gptq_validate_g_idx(g_host.data_ptr(), self.infeatures, self.scales.shape[0]))
             perm_host = torch.empty(self.infeatures, dtype=torch.int32)
             uniform = ctypes.c_int(0)
             _lib.check(lib.gptq_make_sequential(g_host.data_ptr(), self.infeatures, self.group_size,
@@ -200,6 +232,13 @@ class QuantLinear(nn.Module):
         L.epilogue = _lib.EPI_SILU_MUL if self.epilogue == "silu_mul" else _lib.EPI_NONE
         L.reserved_ = 0
         self._layer = L
+        self._layer_ref = ctypes.byref(L)
+        self._fwd = lib.gptq_forward_ex
+        self._dev = dev
+        self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+        self._dev = torch.device("cuda", self._dev_index)
+        self._w_dtype = self.scales.dtype
+        self._n_out = self.outfeatures // 2 if self.epilogue == "silu_mul" else self.outfeatures
         self._keepalive = (self.qweight, self.qzeros, self.scales, self.g_idx, self.bias, qweight_seq, perm)
         self._ws_need = {}
         return self
@@ -218,43 +257,57 @@ class QuantLinear(nn.Module):
         return buf.data_ptr(), buf.numel()
 
     def forward(self, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = None):
-        if x.device.type != "cuda":
-            raise RuntimeError("mi355x QuantLinear.forward needs a ROCm GPU tensor "
-                               f"(got {x.device}); there is no CPU path in this backend.")
+        # The reference's callers are eager (generate() under inference_mode, auto_gptq/modeling/_base.py:415-418), and a decode
+        # kernel here runs for ~5 us: everything per call that is not the launch is kept to attribute reads -- device, dtype,
+        # ctypes handles and the layer pointer are resolved once in post_init.
         if self._layer is None:
+            if x.device.type != "cuda":
+                raise RuntimeError("mi355x QuantLinear.forward needs a ROCm GPU tensor "
+                                   f"(got {x.device}); there is no CPU path in this backend.")
             self.post_init()
-        lib = _lib.load()
-        n_out = self.outfeatures // 2 if self.epilogue == "silu_mul" else self.outfeatures
-        out_shape = x.shape[:-1] + (n_out,)
-        x2 = x.reshape(-1, x.shape[-1])
-        if x2.shape[-1] != self.infeatures:
-            raise RuntimeError(f"input has {x2.shape[-1]} features, layer expects {self.infeatures}")
-        x_dtype = x2.dtype
-        w_dtype = self.scales.dtype
+        dev = self._dev
+        if x.device != dev:
+            if x.device.type != "cuda":
+                raise RuntimeError("mi355x QuantLinear.forward needs a ROCm GPU tensor "
+                                   f"(got {x.device}); there is no CPU path in this backend.")
+            raise RuntimeError(f"mi355x QuantLinear.forward: input is on {x.device}, the layer on {dev}")
+        K = self.infeatures
+        if x.shape[-1] != K:
+            raise RuntimeError(f"input has {x.shape[-1]} features, layer expects {K}")
+        w_dtype = self._w_dtype
+        x_dtype = x.dtype
+        x2 = x
         if x_dtype != w_dtype:
             _warn_once(f"mi355x QuantLinear: activation dtype {x_dtype} != weight dtype {w_dtype}; casting the "
                        f"activation to {w_dtype} (the result is cast back).")
             x2 = x2.to(w_dtype)
+        if x2.dim() != 2:
+            x2 = x2.reshape(-1, K)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         M = x2.shape[0]
-        out = torch.empty((M, n_out), dtype=w_dtype, device=x2.device)
-        if M == 0:
-            return out.to(x_dtype).reshape(out_shape)
-        ws_ptr, ws_bytes = self._workspace(M, x2.device, tuning)
-        dev_idx = x2.device.index
-        stream = torch.cuda.current_stream(x2.device).cuda_stream
-        if dev_idx is not None and dev_idx != torch.cuda.current_device():
-            with torch.cuda.device(dev_idx):
-                rc = lib.gptq_forward_ex(ctypes.byref(self._layer), x2.data_ptr(), out.data_ptr(), M, ws_ptr, ws_bytes,
-                                         stream, ctypes.byref(tuning) if tuning is not None else None)
-        else:
-            rc = lib.gptq_forward_ex(ctypes.byref(self._layer), x2.data_ptr(), out.data_ptr(), M, ws_ptr, ws_bytes,
-                                     stream, ctypes.byref(tuning) if tuning is not None else None)
-        _lib.check(rc)
+        n_out = self._n_out
+        out = torch.empty((M, n_out), dtype=w_dtype, device=dev)
+        if M != 0:
+            need = self._ws_need.get(M) if tuning is None else None
+            if need == 0:
+                ws_ptr, ws_bytes = None, 0
+            else:
+                ws_ptr, ws_bytes = self._workspace(M, dev, tuning)
+            idx = self._dev_index
+            tref = ctypes.byref(tuning) if tuning is not None else None
+            if idx != torch.cuda.current_device():
+                with torch.cuda.device(idx):
+                    rc = self._fwd(self._layer_ref, x2.data_ptr(), out.data_ptr(), M, ws_ptr, ws_bytes, _raw_stream(idx), tref)
+            else:
+                rc = self._fwd(self._layer_ref, x2.data_ptr(), out.data_ptr(), M, ws_ptr, ws_bytes, _raw_stream(idx), tref)
+            if rc:
+                _lib.check(rc)
         if x_dtype != w_dtype:
             out = out.to(x_dtype)
-        return out.reshape(out_shape)
+        if x.dim() != 2:
+            out = out.reshape(x.shape[:-1] + (n_out,))
+        return out
 
     # ------------------------------------------------------------------ dequant / unpack helpers
     def dequantize(self) -> torch.Tensor:
@@ -312,6 +365,9 @@ class QuantLinear(nn.Module):
         self.qweight = qweight.to(home)
         self.qzeros = qzeros.to(home)
         self.scales = scales_out.to(home)
+        self.g_idx = self.g_idx.to(home)                     # every buffer ends up where the module lives
+        if self.bias is not None:
+            self.bias = self.bias.to(home)
         self._invalidate()
 
     def _pack_device(self, W, scales_t, zeros_t, gi):

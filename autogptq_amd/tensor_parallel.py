@@ -53,6 +53,9 @@ class ColumnParallelQuantLinear(nn.Module):
         """Build the rank's shard from a full (unsharded) mi355x QuantLinear."""
         from .qlinear_mi355x import QuantLinear
 
+        if getattr(full, "epilogue", "none") != "none":
+            # a plain column split of [gate | up] gives rank 0 only gate columns: the SiLU*mul pairing cannot be applied locally
+            raise ValueError("column-parallel split of a layer with a fused epilogue is not supported; shard gate and up separately")
         qw, qz, sc, b = shard_packed(full.qweight, full.qzeros, full.scales, full.bias, full.bits, rank, world)
         local = QuantLinear(full.bits, full.group_size, full.infeatures, qw.shape[1], b is not None,
                             weight_dtype=full.scales.dtype, zero_mode=full.zero_mode)
@@ -112,6 +115,8 @@ class RowParallelQuantLinear(nn.Module):
 
         if not _is_sequential_g_idx(full.g_idx, full.group_size):
             raise ValueError("row-parallel split needs sequential groups (no act-order)")
+        if getattr(full, "epilogue", "none") != "none":
+            raise ValueError("row-parallel split of a layer with a fused epilogue is not supported")
         qw, qz, sc, (k0, k1) = shard_packed_rows(full.qweight, full.qzeros, full.scales, full.bits, full.group_size, rank, world)
         local = QuantLinear(full.bits, full.group_size, k1 - k0, full.outfeatures, False, weight_dtype=full.scales.dtype,
                             zero_mode=full.zero_mode)

@@ -175,6 +175,112 @@ def pmc_traffic(kernel, K, N, M):
     return None
 
 
+def _time_layers(layers, xs, device, reps):
+    """Mean seconds per launch of a graph that holds exactly these layers (HIP events around `reps` replays)."""
+    gg, oo = capture(layers, xs, device)
+    for _ in range(2):
+        gg.replay()
+    _, evt = time_graph(gg, reps, device)
+    del gg, oo
+    return evt / (reps * len(layers))
+
+
+def bench_prefill(device, steps):
+    """BASELINE config 3 + north_star's M = 4096 target inside the default run: 4 decoder blocks of int4 g128 desc_act=True
+    layers at M = 2048 (28 launches + their x permutations, one hipGraph), then the dominant GEMM on its own, then one
+    M = 4096 4096x4096 layer (no act-order).  flops = 2*M*K*N per layer; peak = dense fp16 MFMA 2.5 PFLOP/s."""
+    M = 2048
+    layers, xs = build_stack(device, 4, M, True)
+    g, outs = capture(layers, xs, device)
+    for _ in range(2):
+        g.replay()
+    _, ev = time_graph(g, steps, device)
+    flops_step = sum(2 * M * K * N for _, K, N, _ in layers)
+    by_type = {}
+    for ent in layers:
+        by_type.setdefault((ent[1], ent[2]), []).append(ent)
+    per_type, best = {}, None
+    for (K, N), ls in by_type.items():
+        per = _time_layers(ls, xs, device, max(2, steps // 2))
+        per_type[f"{K}x{N}"] = {"us": round(per * 1e6, 2), "TFLOP_s": round(2 * M * K * N / per / 1e12, 1)}
+        if best is None or per * len(ls) > best[0]:
+            best = (per * len(ls), K, N, per)
+    _, K, N, per = best
+    ach = 2 * M * K * N / per / 1e12
+    plan = _plan_of(layers, K, N, M)
+    roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+            "traffic": pmc_traffic("gemm", K, N, M), "kernel": "gptq::gemm_kernel<4, f16, ...> (%s)" % plan, "shape": f"K={K} N={N} M={M} desc_act",
+            "us_per_launch_events": round(per * 1e6, 2), "flops_per_launch": 2 * M * K * N,
+            "note": "per-launch time is the whole layer call: x permutation (if the plan has a separate pass) + GEMM"}
+    del g, outs, layers
+    torch.cuda.empty_cache()
+    # north_star: (batch x seq = 4096, 4096 -> 4096), int4 g128, sequential groups; 40 distinct layers (> 256 MiB with x / out)
+    M2 = 4096
+    ls = [("q", 4096, 4096, make_layer(4096, 4096, device, seed=900 + i)) for i in range(8)]
+    xs2 = {4096: (torch.rand(M2, 4096, device=device) - 0.5).half()}
+    per2 = _time_layers(ls, xs2, device, max(2, steps // 2))
+    ach2 = 2 * M2 * 4096 * 4096 / per2 / 1e12
+    out = {"workload": "Llama-7B shapes x 4 blocks, int4 g128 desc_act=True, M=2048 (BASELINE config 3), 28 layers in one hipGraph",
+           "TFLOP_s": round(flops_step * steps / ev / 1e12, 1), "ms_per_step": round(1e3 * ev / steps, 3), "tokens_per_s": round(M * steps / ev, 1),
+           "by_shape": per_type, "roofline": roof,
+           "m4096_4096x4096": {"us_per_launch_events": round(per2 * 1e6, 2), "TFLOP_s": round(ach2, 1), "frac": round(ach2 / MFMA_PEAK_TFLOPS, 4),
+                               "plan": _plan_of(ls, 4096, 4096, M2)}}
+    del ls, xs2
+    torch.cuda.empty_cache()
+    return out
+
+
+def _plan_of(layers, K, N, M):
+    import ctypes
+    from autogptq_amd import _lib
+    for _, k, n, q in layers:
+        if (k, n) == (K, N):
+            d = _lib.describe_plan(q._layer, M)
+            return " ".join(f"{a}={b}" for a, b in d.items())
+    return ""
+
+
+def bench_config5(device, steps):
+    """BASELINE config 5: int3 / int8, group_size 32, Llama-7B shapes, M = 1 decode.  Per shape: a graph of distinct layers whose
+    packed weights exceed the 256 MiB Infinity Cache, HIP events, algorithmic GB/s (SURVEY App. C formula)."""
+    res = {}
+    for bits in (3, 8):
+        for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
+            wbytes = K * N * bits // 8
+            n = max(4, -(-(320 << 20) // wbytes))
+            ls = [(f"b{bits}", K, N, make_layer(K, N, device, bits=bits, gs=32, seed=5000 + i)) for i in range(n)]
+            xs = {K: (torch.rand(1, K, device=device) - 0.5).half()}
+            per = _time_layers(ls, xs, device, max(3, steps // 2))
+            ab = algorithmic_bytes(K, N, 1, bits=bits, gs=32)
+            res[f"int{bits}_g32_{K}x{N}"] = {"us": round(per * 1e6, 2), "GB_per_s": round(ab / per / 1e9, 1), "frac": round(ab / per / 1e9 / HBM_PEAK_GBS, 4),
+                                              "plan": _plan_of(ls, K, N, 1)}
+            del ls, xs
+            torch.cuda.empty_cache()
+    return res
+
+
+def bench_eager(layers, xs, device, steps):
+    """The same 224 layers called one by one through QuantLinear.forward with no graph: what the reference's callers do
+    (generate() under inference_mode, auto_gptq/modeling/_base.py:415-418).  Wall clock per call incl. Python + ctypes."""
+    with torch.no_grad():
+        for _ in range(2):
+            for _, K, N, q in layers:
+                q(xs[K])
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for _, K, N, q in layers:
+                q(xs[K])
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize(device)
+        t = time.perf_counter() - t0
+    M = next(iter(xs.values())).shape[0]
+    bytes_step = sum(algorithmic_bytes(K, N, M) for _, K, N, _ in layers)
+    return {"us_per_call": round(1e6 * t / (steps * len(layers)), 2), "host_us_per_call": round(1e6 * t_issue / (steps * len(layers)), 2),
+            "GB_per_s": round(bytes_step * steps / t / 1e9, 1), "tokens_per_s": round(M * steps / t, 1),
+            "note": "eager QuantLinear.forward per layer (torch.empty + ctypes + launch), no hipGraph"}
+
+
 def cpu_baseline(M, act_order, budget_s=20.0):
     """Time the oracle (a port of the reference's pure-PyTorch CPU QuantLinear.forward: materialise
     the unpacked ints, dequantise, torch.matmul) on the host cores, on a bounded sample: the three
@@ -267,6 +373,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for launcher smoke tests)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--no-fused", action="store_true", help="skip the extra fused-callers measurement (decode, 1 GPU only)")
+    ap.add_argument("--no-extras", action="store_true", help="decode, 1 GPU: skip the prefill / config5 / eager blocks of the default line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -380,6 +487,11 @@ def main():
         }
         if tp is not None:
             out["tp"] = tp
+        if not prefill and world == 1 and not args.no_extras:
+            try:
+                out["eager"] = bench_eager(layers, xs, device, max(3, args.steps // 4))
+            except Exception as e:
+                out["eager"] = {"error": repr(e)[:300]}
         if not prefill and world == 1 and not args.no_fused:
             try:
                 del g, outs, layers
@@ -387,6 +499,14 @@ def main():
                 out["fused_callers"] = bench_fused(device, n_blocks, args.steps)
             except Exception as e:
                 out["fused_callers"] = {"error": repr(e)[:300]}
+        if not prefill and world == 1 and not args.no_extras:
+            for name, fn in (("prefill", lambda: bench_prefill(device, max(3, args.steps // 4))),
+                             ("config5", lambda: bench_config5(device, args.steps))):
+                try:
+                    torch.cuda.empty_cache()
+                    out[name] = fn()
+                except Exception as e:
+                    out[name] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (bounded sample, ~25 s of host time)
             out["cpu_baseline"] = cpu_baseline(1 if not prefill else 16, act_order)
         print(json.dumps(out))

@@ -38,7 +38,10 @@
  *     thread-local human-readable message for the last failure on the calling thread.
  *   - nothing allocates or frees device memory; scratch is caller-provided and sized by
  *     gptq_workspace_bytes().  Kernels are enqueued on the caller's stream, never synchronise,
- *     and are legal inside hipGraph capture.  No global mutable state.
+ *     and are legal inside hipGraph capture: the forward entry points make no runtime-API call
+ *     besides the kernel launches.  No global mutable state in the library; the one per-device
+ *     setting it needs (kernels with > 64 KiB of dynamic LDS) is applied by gptq_init(), which the
+ *     caller runs once per device, outside any capture, before the first forward.
  *   - results are run-to-run deterministic (no floating-point atomics).
  */
 #ifndef GPTQ_MI355X_H
@@ -51,7 +54,7 @@
 extern "C" {
 #endif
 
-#define GPTQ_MI355X_ABI_VERSION 2
+#define GPTQ_MI355X_ABI_VERSION 3
 
 typedef enum gptq_status_t {
     GPTQ_OK = 0,
@@ -98,7 +101,7 @@ typedef struct gptq_layer_t {
 
 /* Optional launch-shape override for experiments; NULL / zero fields = built-in heuristic. */
 typedef struct gptq_tuning_t {
-    int32_t lanes_n;     /* lanes of a wave laid along N (4,8,16,32,64); 4 columns per lane */
+    int32_t lanes_n;     /* lanes of a wave laid along N (4,8,16,64); 4 columns per lane */
     int32_t waves;       /* waves per workgroup (1..16) */
     int32_t ksplit;      /* workgroups along K (1 = no cross-workgroup reduction) */
     int32_t path;        /* 0 auto, 1 generic GEMV, 2 LDS-staged q4/fp16 GEMV, 3 MFMA GEMM, 4 direct q4/fp16 GEMV, 5 matrix-core q4/fp16 GEMV */
@@ -109,10 +112,20 @@ int         gptq_abi_version(void);
 const char *gptq_last_error(void);
 const char *gptq_status_string(int status);
 
+/* Once per device (the calling thread's current HIP device), outside stream capture, before the first forward on it:
+ * grants the dynamic-LDS size of the kernels that use more than the 64 KiB default.  Idempotent.  The reference's
+ * equivalents are the one-time per-device set-up calls of its backends (exllama_ext.cpp:100-131 prepare_buffers /
+ * set_tuning_params; exllamav2 ext.cpp:26-93 make_q_matrix's temp_dq hand-over). */
+int gptq_init(void);
+
 /* Bytes of scratch gptq_forward/gptq_gemv/gptq_gemm may need for this layer and M (0 possible). */
 size_t gptq_workspace_bytes(const gptq_layer_t *layer, int M);
 /* Same for an explicit launch shape (what gptq_forward_ex/gptq_gemv/gptq_gemm need with `tuning`). */
 size_t gptq_workspace_bytes_ex(const gptq_layer_t *layer, int M, const gptq_tuning_t *tuning);
+
+/* max over M = 1..max_M of gptq_workspace_bytes(layer, M): the need is not monotone in M (K splits appear and disappear as
+ * the planner changes kernels), so a caller that sizes ONE scratch buffer before hipGraph capture asks for this. */
+size_t gptq_workspace_bytes_max(const gptq_layer_t *layer, int max_M);
 
 /* out[M,N] = x[M,K] @ dequant(layer) (+ bias).  Picks GEMV (small M) or MFMA GEMM. */
 int gptq_forward(const gptq_layer_t *layer, const void *x, void *out, int M,
@@ -154,6 +167,10 @@ int gptq_pack_zeros(const void *zero_in, int G, int N, int bits, int qparam_dtyp
  * group i / group_size for every i (then the fast kernels can use qweight_seq + perm). */
 int gptq_make_sequential(const int32_t *g_idx_host, int K, int group_size,
                          int32_t *perm_out_host, int *uniform_out);
+/* HOST function: every g_idx[k] must name an existing group, 0 <= g_idx[k] < G (G = rows of scales / qzeros).  The kernels
+ * index scales / qzeros with raw g_idx values on act-order layers; the reference's torch indexing raises on a bad index
+ * (qlinear_cuda.py:302 `self.scales[self.g_idx.long()]`), this is the same check for a C caller.  GPTQ_ERR_SHAPE on violation. */
+int gptq_validate_g_idx(const int32_t *g_idx_host, int K, int G);
 /* qweight_seq[row-order = perm] from qweight; device pointers. */
 int gptq_resequence_qweight(const uint32_t *qweight, const int32_t *perm, int K, int N, int bits,
                             uint32_t *qweight_seq_out, void *stream);

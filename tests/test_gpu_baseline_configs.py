@@ -1,0 +1,135 @@
+"""GPU (-m gpu): parity at the shapes BASELINE.json's configs name, not at scaled-down stand-ins.
+
+config 3  Llama-7B shapes, int4 g128 desc_act=True, M = 2048 (all three layer shapes)
+config 4  Llama-2-70B TP=8 shards: column shards 8192->1024, 8192->3584, 28672->1024; row shard 3584->8192
+config 5  int3 / int8 group_size=32 on the Llama-7B shapes, decode (GEMV, M = 1/4/8), batched decode
+          (M = 16/64) and prefill (tiled MFMA GEMM, M = 2048), fp16 and bf16, act-order on and off
+
+Every case is checked three ways, all against the oracle / the bit-exact dequantised weights (not against
+another kernel of this library):
+  (a) fp64 oracle (oracle/gptq_oracle.py: the reference's unpack + dequant, accumulated in fp64) on two
+      column slices -- one in the middle, one at the ragged right edge of the layer -- for a row subset;
+  (b) one-hot rows of x return the dequantised weight rows EXACTLY (bit for bit the reference's
+      scales * (weight - zeros), qlinear_cuda_old.py:348 / qlinear_cuda.py:302) through whatever kernel the
+      planner picks for that M;
+  (c) bit reproducibility of a repeated call.
+Reference test this mirrors in spirit: tests/test_hpu_linear.py:102-181 (shape x dtype x pattern grid) and
+tests/test_q4.py:1060-1122 (kernel output vs the Python path).
+"""
+import pytest
+import torch
+
+from autogptq_amd.qlinear_mi355x import QuantLinear
+from oracle import gptq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = {torch.float16: (2e-3, 2e-3), torch.bfloat16: (1.6e-2, 1.6e-2)}      # (rtol, atol relative to the output scale)
+LLAMA7B = [(4096, 4096), (4096, 11008), (11008, 4096)]
+
+_LAYERS = {}
+
+
+def _layer(bits, gs, K, N, act, dtype):
+    key = (bits, gs, K, N, act, dtype)
+    if key not in _LAYERS:
+        _LAYERS.clear()                       # one full-size layer alive at a time
+        L = O.random_quant_layer(K, N, bits, gs, act_order=act, dtype=dtype, seed=bits * 131 + K // 64 + N // 32 + int(act))
+        q = QuantLinear(bits, gs, K, N, False, weight_dtype=dtype)
+        q.qweight, q.qzeros, q.scales, q.g_idx = L["qweight"].clone(), L["qzeros"].clone(), L["scales"].clone(), L["g_idx"].clone()
+        q = q.to(DEV)
+        q.post_init()
+        with torch.no_grad():
+            W = q.dequantize()                # [K, N] dtype; bit-exact vs the reference (test_gpu_parity.py::test_dequant_*)
+        _LAYERS[key] = (L, q, W)
+    return _LAYERS[key]
+
+
+def _slice_cols(L, bits, n0, n1):
+    z0, z1 = n0 * bits // 32, n1 * bits // 32
+    return L["qweight"][:, n0:n1], L["qzeros"][:, z0:z1], L["scales"][:, n0:n1]
+
+
+def _check(bits, gs, K, N, M, act, dtype):
+    L, q, W = _layer(bits, gs, K, N, act, dtype)
+    mode = O.reference_zero_mode(act, bits)
+    assert q.resolved_zero_mode() == int(mode == O.ZERO_NOWRAP)
+    gen = torch.Generator().manual_seed(M * 7 + bits)
+    x = (torch.rand(M, K, generator=gen) - 0.5).to(dtype)
+    # (b) one-hot rows: rows 0 .. min(M, 4) - 1 of x select weight rows spread over K (first, last, a group edge, a 3-bit straddler)
+    hot = [0, K - 1, gs, 10][:min(M, 4)] if M > 1 else []
+    for r, k in enumerate(hot):
+        x[r].zero_()
+        x[r, k] = 1.0
+    xd = x.to(DEV)
+    with torch.no_grad():
+        y, yb = q(xd), q(xd)
+    assert y.shape == (M, N) and y.dtype == dtype
+    assert torch.equal(y, yb), "not bit-reproducible"                       # (c)
+    for r, k in enumerate(hot):
+        assert torch.equal(y[r], W[k]), f"one-hot row {k}: output is not the exact dequantised weight row (M={M})"
+    # (a) fp64 oracle on a row subset x two column slices (middle, ragged right edge)
+    rows = sorted(set([0, 1, M // 2, M - 2, M - 1]) & set(range(M)))
+    mid = (N // 2) // 32 * 32
+    rtol, atol = TOL[dtype]
+    for n0, n1 in ((mid, mid + 256), (N - 96, N)):
+        qw, qz, sc = _slice_cols(L, bits, n0, n1)
+        y64 = O.forward_f64(x[rows], qw, qz, sc, L["g_idx"] if act else None, None, bits, mode)
+        got = y[rows][:, n0:n1].double().cpu()
+        scale = max(1e-6, float(y64.abs().max()))
+        bad = (got - y64).abs() > atol * scale * max(1.0, (K / 1024) ** 0.5) + rtol * y64.abs()
+        assert not bad.any(), (f"bits={bits} g={gs} {K}x{N} M={M} act={act} {dtype} cols[{n0}:{n1}]: {int(bad.sum())}/{bad.numel()} "
+                               f"out of tolerance, max abs diff {float((got - y64).abs().max())} (scale {scale})")
+
+
+# ------------------------------------------------------------------------------------------ config 5
+@pytest.mark.parametrize("act", [False, True], ids=["seq", "act"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("K,N", LLAMA7B)
+@pytest.mark.parametrize("bits", [3, 8])
+def test_config5_int3_int8_g32_llama7b_shapes(bits, K, N, dtype, act):
+    """BASELINE config 5: int3 / int8, group_size 32, on the Llama-7B layer shapes -- GEMV-generic plans at full
+    K (16 waves, U = 4 for int8, masked tail rows), strips / skinny at M = 16 / 64, tiled BK = 32 GEMM with two-word
+    B fragments at M = 2048."""
+    for M in (1, 4, 8, 16, 64, 2048):
+        _check(bits, 32, K, N, M, act, dtype)
+
+
+# ------------------------------------------------------------------------------------------ config 3
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("K,N", LLAMA7B)
+def test_config3_int4_g128_desc_act_prefill_2048(K, N, dtype):
+    """BASELINE config 3: int4 g128 desc_act=True, seq_len 2048 prefill on all three Llama-7B shapes (the tiled MFMA
+    kernel with the group-sorted weight copy and permuted x), plus the decode / batched-decode row counts."""
+    for M in (2048, 1, 8, 64):
+        _check(4, 128, K, N, M, True, dtype)
+
+
+def test_north_star_m4096_4096x4096():
+    """north_star's second target: batch x seq = 4096 rows on 4096 -> 4096, int4 g128."""
+    _check(4, 128, 4096, 4096, 4096, False, torch.float16)
+
+
+# ------------------------------------------------------------------------------------------ config 4
+@pytest.mark.parametrize("K,N", [(8192, 1024), (8192, 3584), (28672, 1024)])
+@pytest.mark.parametrize("act", [False, True], ids=["seq", "act"])
+def test_config4_llama70b_tp8_column_shards(K, N, act):
+    """BASELINE config 4: the per-GPU column shards of Llama-2-70B at TP = 8 (8192 -> 8192/8, 8192 -> 28672/8,
+    28672 -> 8192/8), decode and prefill row counts."""
+    for M in (1, 4, 64, 2048):
+        _check(4, 128, K, N, M, act, torch.float16)
+
+
+def test_config4_llama70b_row_shard_and_act_order_refusal():
+    """Row-parallel pairing of the down projection: the K shard 28672/8 = 3584 -> 8192 is an ordinary layer; an
+    act-order layer cannot be row-split (its g_idx mixes groups across the whole K) and the wrapper refuses."""
+    from autogptq_amd.tensor_parallel import RowParallelQuantLinear
+
+    for M in (1, 8, 2048):
+        _check(4, 128, 3584, 8192, M, False, torch.float16)
+    L = O.random_quant_layer(1024, 256, 4, 128, act_order=True, seed=3)
+    full = QuantLinear(4, 128, 1024, 256, False)
+    full.qweight, full.qzeros, full.scales, full.g_idx = L["qweight"], L["qzeros"], L["scales"], L["g_idx"]
+    with pytest.raises(ValueError, match="sequential groups"):
+        RowParallelQuantLinear.from_full(full, 0, 8)

@@ -879,3 +879,65 @@ def test_marlin_checkpoint_layer_forward(fname):
         with torch.no_grad():
             y = q(x.to(DEV))
         _assert_close(y, y64, y64, torch.float16, K, f"Marlin-format layer, M={M}")
+
+
+# ------------------------------------------------------------------------- scratch / device hygiene
+def test_workspace_outgrown_after_capture_stays_valid_for_the_graph():
+    """A hipGraph captured with a small scratch keeps working after a later call needed (and got) a much larger one: outgrown
+    buffers are retired, never freed (the captured launches have their address baked in)."""
+    from autogptq_amd import qlinear_mi355x as QM
+    L = O.random_quant_layer(8192, 1024, 4, 128, seed=11)                 # narrow layer: K split -> needs scratch at M = 1
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], None, None, 4, 128)
+    assert _lib.describe_plan(q._layer if q._layer else q.post_init()._layer, 1)["ksplit"] > 1
+    x = (torch.rand(1, 8192) - 0.5).half().to(DEV)
+    with torch.no_grad():
+        ref = q(x).clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), torch.no_grad():
+        y = q(x)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)
+    retired_before = len(QM._RETIRED)
+    La = O.random_quant_layer(4096, 4096, 4, 128, act_order=True, seed=12)   # act-order prefill: permuted x + slabs, tens of MB
+    qa = _module_from(La["qweight"], La["qzeros"], La["scales"], La["g_idx"], None, 4, 128)
+    xb = (torch.rand(2048, 4096) - 0.5).half().to(DEV)
+    side = torch.cuda.Stream()
+    for st in (torch.cuda.current_stream(), side):
+        with torch.cuda.stream(st), torch.no_grad():
+            qa(xb)
+            junk = [torch.randn(1 << 20, device=DEV) for _ in range(8)]       # would land on freed scratch memory, if any were freed
+    torch.cuda.synchronize()
+    del junk
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)
+    assert len(QM._RETIRED) >= retired_before
+    keys = [k for k in QM._WORKSPACE if k[0] == torch.cuda.current_device()]
+    assert len(keys) >= 2, "scratch is keyed by (device, stream)"
+
+
+def test_pack_on_gpu_module_from_cpu_quantizer_outputs_and_device_mismatch_error():
+    """pack() leaves EVERY buffer (incl. g_idx and bias) on the module's device; a module whose buffers were split across
+    devices by hand gets a Python error from post_init instead of a GPU fault."""
+    lin = torch.nn.Linear(256, 128, bias=True).half()
+    s, z = O.minmax_quantize(lin.weight.data.float(), 4, 64)
+    gi = torch.from_numpy(O.default_g_idx(256, 64))[torch.randperm(256, generator=torch.Generator().manual_seed(0))].contiguous()
+    q = QuantLinear(4, 64, 256, 128, True).to(DEV)
+    q.pack(lin, s.half(), z.half(), gi)                       # CPU tensors into a GPU module
+    for name in ("qweight", "qzeros", "scales", "g_idx", "bias"):
+        assert getattr(q, name).device.type == "cuda", name
+    x = (torch.rand(3, 256) - 0.5).half()
+    qw, qz, sc = O.pack(lin.weight.data.clone(), s.half(), z.half(), gi, 4, torch.float16)
+    ref = O.forward_f64(x, qw, qz, sc, gi, lin.bias.data, 4, O.ZERO_NOWRAP)
+    with torch.no_grad():
+        y = q(x.to(DEV))
+    _assert_close(y, ref, ref, torch.float16, 256, "pack on GPU module")
+    q2 = QuantLinear(4, 64, 256, 128, True).to(DEV)
+    q2.g_idx = q2.g_idx.cpu()
+    with pytest.raises(RuntimeError, match="g_idx is on cpu"):
+        q2.post_init()
+    bad = QuantLinear(4, 64, 256, 128, False).to(DEV)
+    bad.g_idx = (torch.arange(256, dtype=torch.int32) % 5).to(DEV)         # group 4 does not exist (G = 4)
+    with pytest.raises(_lib.GptqError, match="outside"):
+        bad.post_init()

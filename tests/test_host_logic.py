@@ -453,3 +453,32 @@ def test_host_pack_on_the_reference_value_patterns(gs, dtype):
         q.pack(lin, s.clone(), z.clone(), g_idx=None)
         qw, qz, sc = O.pack(lin.weight.data.clone(), s.clone(), z.clone(), None, 4, dtype)
         assert torch.equal(q.qweight, qw) and torch.equal(q.qzeros, qz) and torch.equal(q.scales, sc), (pattern, gs, dtype)
+
+
+def test_workspace_max_covers_every_m_and_g_idx_validation():
+    """gptq_workspace_bytes_max = max over M of the per-M query (the need is not monotone: K splits come and go), and
+    gptq_validate_g_idx rejects group indices the scales / qzeros tensors do not have (host-only, no device work)."""
+    lib = _lib.load()
+    for K, N, act in ((4096, 4096, False), (4096, 4096, True), (8192, 1024, False), (11008, 4096, True)):
+        L = _layer(K=K, N=N)
+        if act:
+            L.g_idx = L.qweight_seq = L.perm = 0x1000
+        per_m = [int(lib.gptq_workspace_bytes(ctypes.byref(L), m)) for m in range(1, 300)]
+        assert int(lib.gptq_workspace_bytes_max(ctypes.byref(L), 299)) == max(per_m)
+        assert int(lib.gptq_workspace_bytes_max(ctypes.byref(L), 16)) == max(per_m[:16])
+    assert any(per_m[i] > per_m[i + 1] for i in range(len(per_m) - 1)), "expected a non-monotone need somewhere in 1..299"
+    g = torch.arange(256, dtype=torch.int32) // 128
+    assert lib.gptq_validate_g_idx(g.data_ptr(), 256, 2) == 0
+    assert lib.gptq_validate_g_idx(g.data_ptr(), 256, 1) == 2 and b"outside [0, 1)" in lib.gptq_last_error()
+    g[7] = -1
+    assert lib.gptq_validate_g_idx(g.data_ptr(), 256, 2) == 2 and b"g_idx[7]" in lib.gptq_last_error()
+    assert lib.gptq_validate_g_idx(None, 256, 2) == 1
+
+
+def test_tensor_parallel_wrappers_refuse_fused_epilogue_layers():
+    from autogptq_amd.tensor_parallel import ColumnParallelQuantLinear, RowParallelQuantLinear
+    f = QuantLinear(4, 128, 256, 512, False, epilogue="silu_mul")
+    with pytest.raises(ValueError, match="fused epilogue"):
+        ColumnParallelQuantLinear.from_full(f, 0, 2)
+    with pytest.raises(ValueError, match="fused epilogue"):
+        RowParallelQuantLinear.from_full(f, 0, 2)
