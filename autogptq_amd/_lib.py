@@ -30,7 +30,9 @@ EXPORTS = (
     "gptq_make_sequential", "gptq_resequence_qweight", "gptq_permute_columns",
     "gptq_awq_unpack", "gptq_awq_repack", "gptq_describe_plan",
     "gptq_init", "gptq_workspace_bytes_max", "gptq_validate_g_idx",
+    "gptq_forward_multi", "gptq_workspace_bytes_multi", "gptq_forward_multi_ex", "gptq_workspace_bytes_multi_ex",
 )
+WS_HEADER_BYTES = 65536
 
 
 class GptqLayer(Structure):
@@ -83,6 +85,12 @@ def load() -> ctypes.CDLL:
     lib.gptq_workspace_bytes_max.restype = c_size_t
     lib.gptq_workspace_bytes_max.argtypes = [POINTER(GptqLayer), c_int]
     lib.gptq_init.argtypes = []
+    lib.gptq_workspace_bytes_multi.restype = c_size_t
+    lib.gptq_workspace_bytes_multi.argtypes = [POINTER(POINTER(GptqLayer)), c_int, c_int]
+    lib.gptq_forward_multi.argtypes = [POINTER(POINTER(GptqLayer)), c_int, c_void_p, POINTER(c_void_p), c_int, c_void_p, c_size_t, c_void_p]
+    lib.gptq_workspace_bytes_multi_ex.restype = c_size_t
+    lib.gptq_workspace_bytes_multi_ex.argtypes = [POINTER(POINTER(GptqLayer)), c_int, c_int, POINTER(GptqTuning)]
+    lib.gptq_forward_multi_ex.argtypes = lib.gptq_forward_multi.argtypes + [POINTER(GptqTuning)]
     lib.gptq_validate_g_idx.argtypes = [c_void_p, c_int, c_int]
     fw = [POINTER(GptqLayer), c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]
     lib.gptq_forward.argtypes = fw
@@ -102,7 +110,7 @@ def load() -> ctypes.CDLL:
     lib.gptq_awq_repack.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     for name in EXPORTS:
         if name not in ("gptq_last_error", "gptq_status_string", "gptq_workspace_bytes", "gptq_workspace_bytes_ex",
-                        "gptq_workspace_bytes_max"):
+                        "gptq_workspace_bytes_max", "gptq_workspace_bytes_multi", "gptq_workspace_bytes_multi_ex"):
             getattr(lib, name).restype = c_int
     got = lib.gptq_abi_version()
     if got != ABI_VERSION:

@@ -69,6 +69,25 @@ bool want_gemm(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
     return plan_gemm(*L, M, t).supported;
 }
 
+// The streamed GEMV (weights by LDS DMA, in-launch K-split combine) for a single layer: forced by tuning.path = 6, else by
+// the planner's measured preference.
+bool want_stream(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
+    if (M > 4 || L->epilogue != GPTQ_EPI_NONE) return false;
+    if (t && t->path != 0 && t->path != 6) return false;
+    const gptq_layer_t* one[1] = {L};
+    const StreamPlan sp = plan_stream(one, 1, M, t);
+    if (!sp.ok) return false;
+    if (t && t->path == 6) return true;
+    return stream_preferred(*L, M);
+}
+
+// workspace split: [ticket header | body]
+struct WsView { void* header; void* body; size_t body_bytes; };
+WsView split_ws(void* ws, size_t ws_bytes) {
+    if (!ws || ws_bytes <= WS_HEADER_BYTES) return WsView{nullptr, nullptr, 0};
+    return WsView{ws, (char*)ws + WS_HEADER_BYTES, ws_bytes - WS_HEADER_BYTES};
+}
+
 }  // namespace
 
 extern "C" {
@@ -97,17 +116,29 @@ static bool fused_epilogue_ok(const gptq_layer_t* L, int M, const gptq_tuning_t*
     return L->epilogue == GPTQ_EPI_SILU_MUL && !want_gemm(L, M, tune) && plan_gemv(*L, M, tune).pair;
 }
 
-size_t gptq_workspace_bytes_ex(const gptq_layer_t* L, int M, const gptq_tuning_t* tune) {
-    if (check_layer(L) != GPTQ_OK || M <= 0) return 0;
+// Body = what the kernels use behind the ticket header; the public figure adds the header whenever there is a body.
+static size_t body_bytes(const gptq_layer_t* L, int M, const gptq_tuning_t* tune) {
     if (L->epilogue != GPTQ_EPI_NONE && !fused_epilogue_ok(L, M, tune)) {
         gptq_layer_t Lc = *L;
         Lc.epilogue = GPTQ_EPI_NONE;
-        return epi_scratch_bytes(L, M) + gptq_workspace_bytes_ex(&Lc, M, tune);
+        const size_t inner = body_bytes(&Lc, M, tune);          // the inner call sees a complete workspace: header + body
+        return epi_scratch_bytes(L, M) + (inner ? WS_HEADER_BYTES + inner : 0);
     }
     size_t a = plan_gemv(*L, M, tune).workspace_bytes;
     GemmPlan g = plan_gemm(*L, M, tune);
     size_t b = g.supported ? g.workspace_bytes : 0;
-    return std::max(a, b);
+    size_t c = 0;
+    if (want_stream(L, M, tune)) {
+        const gptq_layer_t* one[1] = {L};
+        c = plan_stream(one, 1, M, tune).partial_bytes;
+    }
+    return std::max(std::max(a, b), c);
+}
+
+size_t gptq_workspace_bytes_ex(const gptq_layer_t* L, int M, const gptq_tuning_t* tune) {
+    if (check_layer(L) != GPTQ_OK || M <= 0) return 0;
+    const size_t b = body_bytes(L, M, tune);
+    return b ? WS_HEADER_BYTES + b : 0;
 }
 
 size_t gptq_workspace_bytes(const gptq_layer_t* L, int M) { return gptq_workspace_bytes_ex(L, M, nullptr); }
@@ -120,6 +151,7 @@ size_t gptq_workspace_bytes_max(const gptq_layer_t* L, int max_M) {
 
 int gptq_init(void) {
     hipError_t e = init_gemm_device();
+    if (e == hipSuccess) e = init_gemv_device();
     if (e != hipSuccess) return hip_fail(e, "gptq_init (hipFuncSetAttribute)");
     return GPTQ_OK;
 }
@@ -151,9 +183,10 @@ int gptq_gemv(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, 
         return fail(GPTQ_ERR_UNSUPPORTED, "direct GEMV needs bits=4, fp16, no act-order and a power-of-two group_size >= 8");
     if (tune && tune->path == 2 && (!pl.fast || pl.mfma || pl.direct))
         return fail(GPTQ_ERR_UNSUPPORTED, "fast GEMV needs bits=4, fp16 and sequential (or re-sequenced) groups");
-    if (pl.workspace_bytes > 0 && (!ws || ws_bytes < pl.workspace_bytes))
-        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", pl.workspace_bytes, ws ? ws_bytes : (size_t)0);
-    hipError_t e = launch_gemv(*L, pl, x, out, M, ws, (hipStream_t)stream);
+    const WsView wv = split_ws(ws, ws_bytes);
+    if (pl.workspace_bytes > 0 && wv.body_bytes < pl.workspace_bytes)
+        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + pl.workspace_bytes, ws ? ws_bytes : (size_t)0);
+    hipError_t e = launch_gemv(*L, pl, x, out, M, wv.body, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "gptq_gemv launch");
     return GPTQ_OK;
 }
@@ -171,35 +204,106 @@ int gptq_gemm(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, 
         return fail(GPTQ_ERR_UNSUPPORTED,
                     "MFMA GEMM needs fp16/bf16, sequential or re-sequenced groups and group_size %% 32 == 0 (bits=%d dtype=%d group_size=%d)",
                     L->bits, L->dtype, L->group_size);
-    if (pl.workspace_bytes > 0 && (!ws || ws_bytes < pl.workspace_bytes))
-        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", pl.workspace_bytes, ws ? ws_bytes : (size_t)0);
-    hipError_t e = launch_gemm(*L, pl, x, out, M, ws, (hipStream_t)stream);
+    const WsView wv = split_ws(ws, ws_bytes);
+    if (pl.workspace_bytes > 0 && wv.body_bytes < pl.workspace_bytes)
+        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + pl.workspace_bytes, ws ? ws_bytes : (size_t)0);
+    hipError_t e = launch_gemm(*L, pl, x, out, M, wv.body, (hipStream_t)stream);
     if (e != hipSuccess)
         return hip_fail(e, pl.kg == 2 ? "gptq_gemm launch (this kernel needs > 64 KiB of LDS: was gptq_init() called on this device?)"
                                       : "gptq_gemm launch");
     return GPTQ_OK;
 }
 
-int gptq_forward_ex(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream,
-                    const gptq_tuning_t* tune) {
+static int stream_call(const gptq_layer_t* const* Ls, int n, const StreamPlan& sp, const void* x, void* const* outs, int M, void* ws,
+                       size_t ws_bytes, void* stream) {
+    const WsView wv = split_ws(ws, ws_bytes);
+    if (sp.partial_bytes > 0 && wv.body_bytes < sp.partial_bytes)
+        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + sp.partial_bytes, ws ? ws_bytes : (size_t)0);
+    hipError_t e = launch_stream(Ls, sp, x, outs, M, wv.header, wv.body, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq streamed GEMV launch (16 waves x U = 8 needs > 64 KiB of LDS: was gptq_init() called on this device?)");
+    return GPTQ_OK;
+}
+
+static int forward_impl(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream,
+                        const gptq_tuning_t* tune) {
     int rc = check_layer(L);
     if (rc) return rc;
     if (L->epilogue != GPTQ_EPI_NONE && !fused_epilogue_ok(L, M, tune)) {
         rc = check_io(x, out, M);
         if (rc) return rc;
         const size_t yb = epi_scratch_bytes(L, M);
-        if (!ws || ws_bytes < yb)
+        const WsView wv = split_ws(ws, ws_bytes);
+        if (wv.body_bytes < yb)
             return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", gptq_workspace_bytes_ex(L, M, tune), ws ? ws_bytes : (size_t)0);
+        // y = [gate | up] at the front of the body; the rest of the body is a complete workspace (header + body) of the inner call
         gptq_layer_t Lc = *L;
         Lc.epilogue = GPTQ_EPI_NONE;
-        rc = gptq_forward_ex(&Lc, x, ws, M, (char*)ws + yb, ws_bytes - yb, stream, tune);
+        rc = forward_impl(&Lc, x, wv.body, M, (char*)wv.body + yb, wv.body_bytes - yb, stream, tune);
         if (rc) return rc;
-        hipError_t e = launch_silu_mul(ws, out, M, L->N, L->dtype, (hipStream_t)stream);
+        hipError_t e = launch_silu_mul(wv.body, out, M, L->N, L->dtype, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "silu_mul launch");
         return GPTQ_OK;
     }
+    if (want_stream(L, M, tune)) {
+        rc = check_io(x, out, M);
+        if (rc) return rc;
+        const gptq_layer_t* one[1] = {L};
+        void* outs[1] = {out};
+        return stream_call(one, 1, plan_stream(one, 1, M, tune), x, outs, M, ws, ws_bytes, stream);
+    }
     if (want_gemm(L, M, tune)) return gptq_gemm(L, x, out, M, ws, ws_bytes, stream, tune);
     return gptq_gemv(L, x, out, M, ws, ws_bytes, stream, tune);
+}
+
+int gptq_forward_ex(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream,
+                    const gptq_tuning_t* tune) {
+    return forward_impl(L, x, out, M, ws, ws_bytes, stream, tune);
+}
+
+size_t gptq_workspace_bytes_multi(const gptq_layer_t* const* layers, int n_layers, int M) {
+    return gptq_workspace_bytes_multi_ex(layers, n_layers, M, nullptr);
+}
+
+size_t gptq_workspace_bytes_multi_ex(const gptq_layer_t* const* layers, int n_layers, int M, const gptq_tuning_t* tune) {
+    if (!layers || n_layers <= 0 || M <= 0) return 0;
+    for (int i = 0; i < n_layers; ++i)
+        if (check_layer(layers[i]) != GPTQ_OK) return 0;
+    size_t need = 0;
+    if (n_layers <= 4) {
+        const StreamPlan sp = plan_stream(layers, n_layers, M, tune);
+        if (sp.ok && multi_preferred(layers, n_layers, M)) return sp.partial_bytes ? WS_HEADER_BYTES + sp.partial_bytes : 0;
+    }
+    for (int i = 0; i < n_layers; ++i) need = std::max(need, gptq_workspace_bytes_ex(layers[i], M, nullptr));
+    return need;
+}
+
+int gptq_forward_multi(const gptq_layer_t* const* layers, int n_layers, const void* x, void* const* outs, int M, void* ws,
+                       size_t ws_bytes, void* stream) {
+    return gptq_forward_multi_ex(layers, n_layers, x, outs, M, ws, ws_bytes, stream, nullptr);
+}
+
+int gptq_forward_multi_ex(const gptq_layer_t* const* layers, int n_layers, const void* x, void* const* outs, int M, void* ws,
+                          size_t ws_bytes, void* stream, const gptq_tuning_t* tune) {
+    if (!layers || !outs) return fail(GPTQ_ERR_NULL, "layers/outs must be non-NULL");
+    if (n_layers <= 0) return fail(GPTQ_ERR_SHAPE, "n_layers must be > 0, got %d", n_layers);
+    for (int i = 0; i < n_layers; ++i) {
+        int rc = check_layer(layers[i]);
+        if (rc) return rc;
+        rc = check_io(x, outs[i], M);
+        if (rc) return rc;
+        if (layers[i]->K != layers[0]->K) return fail(GPTQ_ERR_SHAPE, "layers of one gptq_forward_multi call read the same x: in_features %d != %d", layers[i]->K, layers[0]->K);
+        if (layers[i]->dtype != layers[0]->dtype) return fail(GPTQ_ERR_UNSUPPORTED, "layers of one gptq_forward_multi call share the dtype of x");
+    }
+    if (n_layers <= 4 && M <= 4) {
+        const StreamPlan sp = plan_stream(layers, n_layers, M, tune);
+        if (sp.ok && multi_preferred(layers, n_layers, M)) return stream_call(layers, n_layers, sp, x, outs, M, ws, ws_bytes, stream);
+        if (tune && tune->path == 6) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 6: these layers / this launch shape do not fit the streamed GEMV");
+    }
+    for (int i = 0; i < n_layers; ++i) {           // anything the one-launch kernel does not cover: the same result, layer by layer
+        int rc = gptq_forward_ex(layers[i], x, outs[i], M, ws, ws_bytes, stream, nullptr);
+        if (rc) return rc;
+    }
+    return GPTQ_OK;
 }
 
 int gptq_forward(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream) {
@@ -306,7 +410,12 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
     const bool unfused_epilogue = L->epilogue != GPTQ_EPI_NONE && !fused_epilogue_ok(L, M, tune);
     gptq_layer_t Lc = *L;
     if (unfused_epilogue) Lc.epilogue = GPTQ_EPI_NONE;
-    if (want_gemm(&Lc, M, tune)) {
+    if (want_stream(&Lc, M, tune)) {
+        const gptq_layer_t* one[1] = {&Lc};
+        const StreamPlan sp = plan_stream(one, 1, M, tune);
+        snprintf(out, out_bytes, "path=gemv kernel=stream ln=%d waves=%d u=%d ksplit=%d mt=%d strips=%d pair=0 perm=0 epilogue=none", sp.ln, sp.waves,
+                 sp.u, sp.ksplit, sp.mt, sp.strips_total);
+    } else if (want_gemm(&Lc, M, tune)) {
         const GemmPlan g = plan_gemm(Lc, M, tune);
         const char* kern = g.strip16 ? "strip16" : (g.skinny ? "skinny64" : "tiled");
         snprintf(out, out_bytes, "path=gemm kernel=%s mt=%d bk=%d kg=%d ksplit=%d tiles=%dx%d perm=%d dma=%d epilogue=%s", kern, g.mt, g.bk,

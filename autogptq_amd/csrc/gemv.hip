@@ -815,6 +815,216 @@ __global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && (!PE
     }
 }
 
+// ---- streamed matrix-core GEMV: weights by LDS DMA, up to 4 layers that share x in ONE launch ------------------
+// Same lane decomposition and arithmetic as gemv_q4_f16_mfma_kernel (plain layers: no act-order, no fused epilogue,
+// M <= 4), with two structural changes aimed at what bounds a one-shot decode launch -- bytes in flight and fixed cost
+// per launch:
+//  * the packed rows go global -> LDS by DMA (global_load_lds_dwordx4, nontemporal: 1 KiB per wave instruction, no VGPR
+//    destination), each wave into its own U KiB region, and are read back by the SAME lanes (ds_read_b128, lane-linear:
+//    conflict free) -- no barrier, the wave's own vmcnt orders DMA before read.  Bytes in flight per CU are bounded by the
+//    160 KiB of LDS instead of the VGPR budget: U = 8 with 16 waves puts a whole 11008-row strip (88 KB) in flight from the
+//    first cycle, where the register version walked it in 5.4 dependent iterations of 16 KB;  U = 4 with 8 waves stays
+//    under 64 VGPRs, so the 688 strips of a 4096 x 11008 layer are all resident at once (3 workgroups per CU).
+//  * the workgroup grid runs over the strips of up to four layers that read the same x (q/k/v, gate/up): one launch
+//    boundary, one ramp and one drain for 25 / 45 MB instead of three / two (gptq_forward_multi).  The reference gets this
+//    by concatenating the packed tensors (fused_llama_attn.py:171-186); here the checkpoint tensors stay where they are.
+//  * K split (narrow layers / wide strips) is combined INSIDE the launch: every slice publishes its fp32 partials with
+//    write-through (sc1) stores, drains them, takes a ticket; the slice that draws the last ticket sums all slices in
+//    index order with sc1 loads (bit-reproducible: fixed order, no float atomics) and resets the ticket.  Correct for any
+//    placement of the slices over XCDs / CUs.  Tickets live at the front of the workspace, which the caller hands over
+//    zeroed once (gptq_mi355x.h).
+// 16 bytes per lane, global -> LDS (destination = lds_dst + lane * 16), nontemporal.  Inline asm on purpose: with the
+// builtin, hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) behind EVERY LDS-DMA instruction of a burst (it cannot prove that two
+// DMA writes into the one __shared__ array do not overlap), which serialises the burst into dependent round trips.  Hidden
+// in asm the instruction is not counted by the compiler's own vmcnt bookkeeping -- that only ever makes its waits for
+// ordinary loads longer, never shorter (vmcnt retires in order) -- and the kernel waits for the DMA data explicitly.
+__device__ __forceinline__ void dma16_nt(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+struct GemvSeg {
+    const unsigned* qweight;
+    const unsigned* qzeros;
+    const void* scales;
+    const void* bias;
+    void* out;
+    int N;         // columns of this layer
+    int blk_end;   // cumulative strip count up to and including this layer
+    int col0;      // first column of this layer in the concatenated partial slab
+    int pad_;
+};
+struct GemvStreamParams {
+    GemvSeg seg[4];
+    const void* x;
+    float* partial;      // [ksplit][M][nsum]
+    unsigned* tickets;   // [strips_total]
+    int nseg, M, K, zero_mode, units_total, units_per_split, ksplit, gu_shift, nsum;
+};
+
+template <int LN, int MT, int U, typename T, int WPS>
+__global__ void __launch_bounds__(1024, WPS) gemv_q4_stream_kernel(GemvStreamParams p) {
+    constexpr bool BF = std::is_same_v<T, bf16>;
+    unsigned m_lo, m_hi, magic;
+    asm("s_mov_b32 %0, 0x000f000f" : "=s"(m_lo));
+    asm("s_mov_b32 %0, 0x00f000f0" : "=s"(m_hi));
+    asm("v_mov_b32 %0, 0x64006400" : "=v"(magic));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WR = 64 / LN, CT = LN * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
+    const int cl = lane % LN, rs = lane / LN;
+    char* const wq = smem + (size_t)wave * (U * 1024);                        // this wave's DMA landing area
+    const unsigned wq_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)wq);   // its LDS byte address (SGPR)
+    float* const red = (float*)(smem + (size_t)W * (U * 1024));               // [W][MT][CT] cross-wave sums, + 1 word
+    // logical block -> (strip over all layers, K slice); slices of one strip are adjacent logical ids (same XCD after the remap)
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int sidx = L / p.ksplit, ks = L - sidx * p.ksplit;
+    int s = 0;
+    while (s + 1 < p.nseg && sidx >= p.seg[s].blk_end) ++s;                   // wave-uniform (kernel arguments only)
+    const GemvSeg& sg = p.seg[s];
+    const int strip = sidx - (s ? p.seg[s - 1].blk_end : 0);
+    const int N = sg.N;
+    const int n0 = strip * CT + cl * 4;
+    const bool col_ok = n0 < N;
+    const int nload = col_ok ? n0 : 0;
+    const int ub = ks * p.units_per_split;
+    const int ue = min(ub + p.units_per_split, p.units_total);
+    const T* xrow = (const T*)p.x + (size_t)min(lane & 3, p.M - 1) * p.K;     // A operand: lane i of a 4-lane group carries x row i
+    const T* __restrict__ scales = (const T*)sg.scales;
+    const unsigned* __restrict__ qweight = sg.qweight;
+    const int zrow_words = N >> 3;
+    const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
+    const int gshift = p.gu_shift;
+
+    float acc[4][MT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[c][m] = 0.f;
+
+    const int rows_per_iter = W * WR * U;
+    for (int base = ub; base < ue; base += rows_per_iter) {
+        const int u0 = base + (wave * WR + rs) * U;
+        const int g = min(u0, ue - 1) >> gshift;
+        // small L2-resident loads first (they return first), then the DMA burst
+        const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * N + nload);
+        const unsigned zw = sg.qzeros[(size_t)g * zrow_words + (nload >> 3)] >> ((nload & 7) * 4);
+        u32x4 xr[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) xr[j] = *(const u32x4*)(xrow + (size_t)min(u0 + j, ue - 1) * 8);
+        if (base != ub) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // WAR: last iteration's ds_reads are done
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int ul = min(u0 + j, ue - 1);
+            dma16_nt(qweight + (size_t)ul * N + nload, wq_lds + j * 1024);
+        }
+        f16x2 c1[4], c2[4];
+        const f16x2 k960 = {(f16)960.f, (f16)960.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned z = (((zw >> (4 * c)) & 15u) + 1u) & zmask;
+            c1[c] = as_f16x2(z * 0x00010001u + 0xE400E400u);        // -(1024+z)
+            c2[c] = c1[c] + k960;                                   // -(64+z)
+        }
+        f32x4 accg[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) accg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+        // row j is consumed as soon as DMA j has landed: vmcnt retires in order and the U DMAs are the youngest VMEM
+        // operations of the wave, so "at most U-1-j outstanding" means DMAs 0..j (and every older load) are complete
+        [&]<int... J>(std::integer_sequence<int, J...>) {
+            (([&] {
+                 constexpr int j = J;
+                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(U - 1 - j) : "memory");
+                 const u32x4 qv = *(const u32x4*)(wq + j * 1024 + lane * 16);
+                 const bool live = (u0 + j < ue);
+                 const u32x4 t = xr[j];
+                 u32x2 a01 = u32x2{__builtin_amdgcn_perm(t[2], t[0], 0x05040100u), __builtin_amdgcn_perm(t[2], t[0], 0x07060302u)};
+                 u32x2 a23 = u32x2{__builtin_amdgcn_perm(t[3], t[1], 0x05040100u), __builtin_amdgcn_perm(t[3], t[1], 0x07060302u)};
+                 if (!live) { a01 = u32x2{0u, 0u}; a23 = u32x2{0u, 0u}; }
+#pragma unroll
+                 for (int c = 0; c < 4; ++c) {
+                     const unsigned qw = qv[c], q8 = qw >> 8;
+                     const f16x2 h0 = as_f16x2((qw & m_lo) | magic) + c1[c];             // k0,k4
+                     const f16x2 h1 = as_f16x2((qw & m_hi) | magic) * r16 + c2[c];       // k1,k5
+                     const f16x2 h2 = as_f16x2((q8 & m_lo) | magic) + c1[c];             // k2,k6
+                     const f16x2 h3 = as_f16x2((q8 & m_hi) | magic) * r16 + c2[c];       // k3,k7
+                     u32x2 b01, b23;
+                     if constexpr (BF) {
+                         auto to_bf = [&](f16x2 hv) -> unsigned {
+                             const bf16x2 o = {(bf16)(float)hv[0], (bf16)(float)hv[1]};
+                             return __builtin_bit_cast(unsigned, o);
+                         };
+                         b01 = u32x2{to_bf(h0), to_bf(h1)};
+                         b23 = u32x2{to_bf(h2), to_bf(h3)};
+                     } else {
+                         b01 = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+                         b23 = u32x2{__builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
+                     }
+                     accg[c] = Mma4<T>::run(a01, b01, accg[c]);
+                     accg[c] = Mma4<T>::run(a23, b23, accg[c]);
+                 }
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, U>{});
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned sh = (c & 1) ? (sraw[c >> 1] >> 16) : (sraw[c >> 1] & 0xffffu);
+            const float sc = DType<T>::to_f32(__builtin_bit_cast(T, (unsigned short)sh));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[c][m] = fmaf(sc, accg[c][m], acc[c][m]);
+        }
+    }
+    // ---- row slots (DPP / bpermute), waves (LDS, the only barrier), then write or publish ------------------------------
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c][m] = row_slot_sum<LN>(acc[c][m]);
+    constexpr int E = MT * CT;
+    if (lane < LN) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f32x4 v = {acc[0][m], acc[1][m], acc[2][m], acc[3][m]};
+            *(f32x4*)(red + (wave * MT + m) * CT + lane * 4) = v;
+        }
+    }
+    __syncthreads();
+    unsigned* const flag = (unsigned*)(red + W * E);                          // one word behind the slabs (same LDS array)
+    const size_t slab = (size_t)p.M * p.nsum;
+    for (int e = tid; e < E; e += blockDim.x) {
+        const int m = e / CT, c = e % CT;
+        float t = 0.f;
+        for (int w = 0; w < W; ++w) t += red[w * E + e];
+        const int n = strip * CT + c;
+        if (n >= N || m >= p.M) continue;
+        if (p.ksplit > 1) {
+            __hip_atomic_store(p.partial + (size_t)ks * slab + (size_t)m * p.nsum + sg.col0 + n, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+        } else {
+            if (sg.bias) t += DType<T>::to_f32(((const T*)sg.bias)[n]);
+            ((T*)sg.out)[(size_t)m * N + n] = DType<T>::from_f32(t);
+        }
+    }
+    if (p.ksplit > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // every publishing wave drains its stores
+        __syncthreads();
+        if (tid == 0) *flag = __hip_atomic_fetch_add(p.tickets + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != (unsigned)(p.ksplit - 1)) return;                        // not the last slice of this strip
+        for (int e = tid; e < E; e += blockDim.x) {
+            const int m = e / CT, c = e % CT;
+            const int n = strip * CT + c;
+            if (n >= N || m >= p.M) continue;
+            float t = 0.f;
+            for (int k = 0; k < p.ksplit; ++k)                                // fixed order, sc1 loads (bypass this XCD's non-coherent L2 lines)
+                t += __hip_atomic_load(p.partial + (size_t)k * slab + (size_t)m * p.nsum + sg.col0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sg.bias) t += DType<T>::to_f32(((const T*)sg.bias)[n]);
+            ((T*)sg.out)[(size_t)m * N + n] = DType<T>::from_f32(t);
+        }
+        if (tid == 0) __hip_atomic_store(p.tickets + sidx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+}
+
 // ---- matrix-core GEMV, any bits, fp16 / bf16 -----------------------------------------------------
 // The same structure for the other packings (2/3/8-bit, and 4-bit with bf16): a lane owns 4 columns and U consecutive
 // packing units (1 word = 16/8/4 values, or 3 words = 32 values for 3-bit) of one group; fields are extracted with
@@ -1305,6 +1515,146 @@ static hipError_t launch_fast_mt(const GemvPlan& pl, const GemvParams& p, hipStr
         case 64: return launch_fast_u<64, MT>(pl, p, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+// ---- streamed kernel: plan + launch ------------------------------------------------------------------------------------
+static bool stream_layer_ok(const gptq_layer_t& L) {
+    const int gu = L.group_size / 8;
+    return L.bits == 4 && (L.dtype == GPTQ_F16 || L.dtype == GPTQ_BF16) && L.g_idx == nullptr && L.epilogue == GPTQ_EPI_NONE &&
+           L.group_size % 8 == 0 && gu >= 2 && (gu & (gu - 1)) == 0 && L.K % 8 == 0;
+}
+
+// Measured preferences (bench.py roofline.us_per_launch_by_shape, tools/gemv_sweep.py --stream): see DESIGN.md section 4.1.
+bool stream_preferred(const gptq_layer_t& L, int M) { return false; }
+bool multi_preferred(const gptq_layer_t* const* layers, int n, int M) { return n >= 2; }
+
+StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* tune) {
+    StreamPlan pl{};
+    if (n < 1 || n > 4 || M < 1 || M > 4) return pl;
+    const gptq_layer_t& A = *Ls[0];
+    for (int i = 0; i < n; ++i) {
+        const gptq_layer_t& L = *Ls[i];
+        if (!stream_layer_ok(L)) return pl;
+        if (L.K != A.K || L.group_size != A.group_size || L.dtype != A.dtype || L.zero_mode != A.zero_mode) return pl;
+    }
+    pl.nseg = n;
+    pl.mt = M >= 3 ? 4 : M;
+    pl.units_total = A.K / 8;
+    const int gu = A.group_size / 8;
+    int ln = (tune && tune->lanes_n) ? tune->lanes_n : 4;
+    if (ln != 4 && ln != 16) return pl;
+    const int ct = ln * 4, wr = 64 / ln;
+    int strips = 0, nsum = 0;
+    for (int i = 0; i < n; ++i) {
+        strips += (Ls[i]->N + ct - 1) / ct;
+        nsum += Ls[i]->N;
+    }
+    pl.ln = ln;
+    pl.strips_total = strips;
+    pl.nsum = nsum;
+    int ks = (tune && tune->ksplit) ? tune->ksplit : 0;
+    if (!ks) {
+        ks = 1;
+        while (strips * ks < 192 && pl.units_total / (ks * 2) >= wr * 4) ks *= 2;
+    }
+    if (ks > pl.units_total) ks = pl.units_total;
+    pl.units_per_split = (pl.units_total + ks - 1) / ks;
+    pl.ksplit = (pl.units_total + pl.units_per_split - 1) / pl.units_per_split;      // no empty slices
+    if ((size_t)strips * 4 > WS_HEADER_BYTES) return pl;
+    // (waves, U): the smallest capacity that holds a slice in ONE pass -- everything in flight from the first cycle;
+    // U rows of a lane lie in one group (U <= rows per group), <= 64 VGPRs up to U = 4
+    const int ucap = gu < 8 ? gu : 8;
+    int waves = 0, u = 0;
+    if (tune && tune->waves && tune->reserved[0]) {
+        waves = tune->waves; u = tune->reserved[0];
+    } else {
+        static const int cand[][2] = {{4, 2}, {8, 2}, {8, 4}, {16, 4}, {16, 8}};
+        for (auto& c : cand) {
+            if (c[1] > ucap) continue;
+            waves = c[0]; u = c[1];
+            if (c[0] * wr * c[1] >= pl.units_per_split) break;
+        }
+    }
+    if (waves < 1 || waves > 16 || (u != 2 && u != 4 && u != 8) || u > ucap || pl.units_per_split % u) return pl;
+    pl.waves = waves;
+    pl.u = u;
+    pl.lds_bytes = (size_t)waves * u * 1024 + (size_t)waves * pl.mt * ct * sizeof(float) + 16;
+    if (pl.lds_bytes > 160 * 1024) return pl;
+    pl.partial_bytes = pl.ksplit > 1 ? (size_t)pl.ksplit * M * nsum * sizeof(float) : 0;
+    pl.ok = true;
+    return pl;
+}
+
+// minimum waves per SIMD the kernel is compiled for (= VGPR cap 64 / 80 / 128): no spills at these pairings
+template <int LN, int MT, int U, typename T>
+static constexpr int stream_wps() { return (U <= 2 && MT == 1) ? 8 : ((U <= 2 || (U == 4 && MT <= 2)) ? 6 : 4); }
+
+template <int LN, int MT, int U, typename T>
+static hipError_t launch_stream_one(const StreamPlan& pl, const GemvStreamParams& p, hipStream_t st) {
+    hipLaunchKernelGGL((gemv_q4_stream_kernel<LN, MT, U, T, stream_wps<LN, MT, U, T>()>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64),
+                       pl.lds_bytes, st, p);
+    return hipGetLastError();
+}
+template <int LN, int MT, typename T>
+static hipError_t launch_stream_u(const StreamPlan& pl, const GemvStreamParams& p, hipStream_t st) {
+    switch (pl.u) {
+        case 2: return launch_stream_one<LN, MT, 2, T>(pl, p, st);
+        case 4: return launch_stream_one<LN, MT, 4, T>(pl, p, st);
+        case 8: return launch_stream_one<LN, MT, 8, T>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+template <int LN, typename T>
+static hipError_t launch_stream_mt(const StreamPlan& pl, const GemvStreamParams& p, hipStream_t st) {
+    switch (pl.mt) {
+        case 1: return launch_stream_u<LN, 1, T>(pl, p, st);
+        case 2: return launch_stream_u<LN, 2, T>(pl, p, st);
+        case 4: return launch_stream_u<LN, 4, T>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+template <typename T>
+static hipError_t launch_stream_t(const StreamPlan& pl, const GemvStreamParams& p, hipStream_t st) {
+    return pl.ln == 4 ? launch_stream_mt<4, T>(pl, p, st) : launch_stream_mt<16, T>(pl, p, st);
+}
+
+hipError_t launch_stream(const gptq_layer_t* const* Ls, const StreamPlan& pl, const void* x, void* const* outs, int M,
+                         void* ws_header, void* ws_body, hipStream_t st) {
+    if (!pl.ok) return hipErrorInvalidValue;
+    GemvStreamParams p{};
+    const int ct = pl.ln * 4;
+    int blk = 0, col = 0;
+    for (int i = 0; i < pl.nseg; ++i) {
+        const gptq_layer_t& L = *Ls[i];
+        blk += (L.N + ct - 1) / ct;
+        p.seg[i] = GemvSeg{L.qweight, L.qzeros, L.scales, L.bias, outs[i], L.N, blk, col, 0};
+        col += L.N;
+    }
+    const gptq_layer_t& A = *Ls[0];
+    p.x = x;
+    p.partial = (float*)ws_body;
+    p.tickets = (unsigned*)ws_header;
+    p.nseg = pl.nseg; p.M = M; p.K = A.K; p.zero_mode = A.zero_mode;
+    p.units_total = pl.units_total; p.units_per_split = pl.units_per_split; p.ksplit = pl.ksplit;
+    p.gu_shift = __builtin_ctz((unsigned)(A.group_size / 8));
+    p.nsum = pl.nsum;
+    return A.dtype == GPTQ_BF16 ? launch_stream_t<bf16>(pl, p, st) : launch_stream_t<f16>(pl, p, st);
+}
+
+// Per-device, once (gptq_init): instantiations whose dynamic LDS can exceed the 64 KiB default (16 waves x U = 8).
+template <int LN, int MT, typename T>
+static hipError_t grant_stream() {
+    return hipFuncSetAttribute((const void*)gemv_q4_stream_kernel<LN, MT, 8, T, stream_wps<LN, MT, 8, T>()>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+hipError_t init_gemv_device() {
+    hipError_t e = hipSuccess;
+    auto acc = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    acc(grant_stream<4, 1, f16>()); acc(grant_stream<4, 2, f16>()); acc(grant_stream<4, 4, f16>());
+    acc(grant_stream<16, 1, f16>()); acc(grant_stream<16, 2, f16>()); acc(grant_stream<16, 4, f16>());
+    acc(grant_stream<4, 1, bf16>()); acc(grant_stream<4, 2, bf16>()); acc(grant_stream<4, 4, bf16>());
+    acc(grant_stream<16, 1, bf16>()); acc(grant_stream<16, 2, bf16>()); acc(grant_stream<16, 4, bf16>());
+    return e;
 }
 
 hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x, void* out, int M,

@@ -38,6 +38,20 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune);
 hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x, void* out, int M,
                        void* workspace, hipStream_t st);
 
+// Streamed GEMV (gemv_q4_stream_kernel): 1..4 plain 4-bit layers that read the same x, one launch.
+constexpr size_t WS_HEADER_BYTES = 65536;      // front of every workspace: arrival tickets of the in-launch K-split combine (kept zero)
+struct StreamPlan {
+    bool ok;                 // every layer qualifies and the geometry fits
+    int nseg, ln, waves, u, mt, ksplit, units_total, units_per_split, strips_total, nsum;
+    size_t lds_bytes;
+    size_t partial_bytes;    // behind the header: [ksplit][M][nsum] fp32 when ksplit > 1
+};
+StreamPlan plan_stream(const gptq_layer_t* const* layers, int n, int M, const gptq_tuning_t* tune);
+hipError_t launch_stream(const gptq_layer_t* const* layers, const StreamPlan& pl, const void* x, void* const* outs, int M,
+                         void* ws_header, void* ws_body, hipStream_t st);
+bool stream_preferred(const gptq_layer_t& L, int M);                              // single layer: streamed kernel instead of the register one?
+bool multi_preferred(const gptq_layer_t* const* layers, int n, int M);             // several layers sharing x: one streamed launch?
+hipError_t init_gemv_device();
 hipError_t init_gemm_device();
 
 hipError_t launch_dequant(const gptq_layer_t& L, void* W_out, hipStream_t st);

@@ -65,7 +65,8 @@ def reserve_workspace(device, nbytes: int, stream=None) -> torch.Tensor:
             return buf
         _RETIRED.append(buf)
         nbytes = max(int(nbytes), 2 * buf.numel() if buf.numel() < nbytes else buf.numel())
-    buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+    # zeroed: the front of the buffer holds the arrival tickets of the in-launch K-split combine (gptq_mi355x.h)
+    buf = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
     _WORKSPACE[key] = (buf, capturing)
     return buf
 
@@ -431,4 +432,61 @@ def _pack_fields(vals_u32: torch.Tensor, bits: int) -> torch.Tensor:
     return out.to(torch.int32).contiguous()
 
 
-__all__ = ["QuantLinear", "reserve_workspace"]
+def forward_multi(layers, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = None):
+    """``[l(x) for l in layers]`` for mi355x QuantLinears that read the same input, through gptq_forward_multi: ONE launch for
+    q/k/v or gate/up of a decode step (M <= 4, plain 4-bit layers), the layers one by one otherwise.  The checkpoint tensors
+    are used where they are (the reference's fused modules concatenate copies of them, fused_llama_attn.py:171-203)."""
+    a = layers[0]
+    for l in layers:
+        if l._layer is None:
+            l.post_init()
+    dev = a._dev
+    if x.device != dev:
+        raise RuntimeError(f"mi355x forward_multi: input is on {x.device}, the layers on {dev}")
+    K = a.infeatures
+    if x.shape[-1] != K or any(l.infeatures != K for l in layers):
+        raise RuntimeError("forward_multi: every layer must take the input's feature count")
+    w_dtype = a._w_dtype
+    if any(l._w_dtype != w_dtype for l in layers):
+        raise RuntimeError("forward_multi: the layers must share the weight dtype")
+    x_dtype = x.dtype
+    x2 = x.to(w_dtype) if x_dtype != w_dtype else x
+    if x2.dim() != 2:
+        x2 = x2.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    outs = [torch.empty((M, l._n_out), dtype=w_dtype, device=dev) for l in layers]
+    if M:
+        n = len(layers)
+        key = tuple(id(l._layer) for l in layers)
+        ent = _MULTI.get(key)
+        if ent is None:
+            arr = (ctypes.POINTER(_lib.GptqLayer) * n)(*[ctypes.pointer(l._layer) for l in layers])
+            ent = _MULTI[key] = (arr, {}, [l._layer for l in layers])
+        arr, need_by_m, _ = ent
+        tref = ctypes.byref(tuning) if tuning is not None else None
+        need = need_by_m.get(M) if tuning is None else None
+        if need is None:
+            need = int(_lib.load().gptq_workspace_bytes_multi_ex(arr, n, M, tref))
+            if tuning is None:
+                need_by_m[M] = need
+        ws_ptr, ws_bytes = None, 0
+        if need:
+            buf = reserve_workspace(dev, need)
+            ws_ptr, ws_bytes = buf.data_ptr(), buf.numel()
+        optrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+        idx = a._dev_index
+        with torch.cuda.device(idx):
+            _lib.check(_lib.load().gptq_forward_multi_ex(arr, n, x2.data_ptr(), optrs, M, ws_ptr, ws_bytes, _raw_stream(idx), tref))
+    if x_dtype != w_dtype:
+        outs = [o.to(x_dtype) for o in outs]
+    if x.dim() != 2:
+        outs = [o.reshape(x.shape[:-1] + (o.shape[-1],)) for o in outs]
+    return outs
+
+
+_MULTI: dict = {}
+
+
+__all__ = ["QuantLinear", "reserve_workspace", "forward_multi"]

@@ -37,7 +37,10 @@
  *   - every function returns GPTQ_OK (0) or a gptq_status_t > 0; gptq_last_error() returns a
  *     thread-local human-readable message for the last failure on the calling thread.
  *   - nothing allocates or frees device memory; scratch is caller-provided and sized by
- *     gptq_workspace_bytes().  Kernels are enqueued on the caller's stream, never synchronise,
+ *     gptq_workspace_bytes().  The first GPTQ_WORKSPACE_HEADER_BYTES of a workspace hold the arrival
+ *     tickets of the in-launch K-split combine: they must be ZERO when the buffer is first handed to
+ *     the library (one hipMemset at allocation) and the library leaves them zero after every launch.
+ *     One workspace serves one stream at a time (launches that may overlap need their own).  Kernels are enqueued on the caller's stream, never synchronise,
  *     and are legal inside hipGraph capture: the forward entry points make no runtime-API call
  *     besides the kernel launches.  No global mutable state in the library; the one per-device
  *     setting it needs (kernels with > 64 KiB of dynamic LDS) is applied by gptq_init(), which the
@@ -55,6 +58,7 @@ extern "C" {
 #endif
 
 #define GPTQ_MI355X_ABI_VERSION 3
+#define GPTQ_WORKSPACE_HEADER_BYTES 65536
 
 typedef enum gptq_status_t {
     GPTQ_OK = 0,
@@ -104,8 +108,8 @@ typedef struct gptq_tuning_t {
     int32_t lanes_n;     /* lanes of a wave laid along N (4,8,16,64); 4 columns per lane */
     int32_t waves;       /* waves per workgroup (1..16) */
     int32_t ksplit;      /* workgroups along K (1 = no cross-workgroup reduction) */
-    int32_t path;        /* 0 auto, 1 generic GEMV, 2 LDS-staged q4/fp16 GEMV, 3 MFMA GEMM, 4 direct q4/fp16 GEMV, 5 matrix-core q4/fp16 GEMV */
-    int32_t reserved[4]; /* [0]: max packed rows per lane and iteration for the register-direct GEMVs (0 = heuristic); [1]: 32 = force the 32-deep K-step in the MFMA GEMM; [2]: 1 = force the 64-column skinny GEMM, 2 = force the tiled GEMM, 3 = force the 16-column-strip GEMM (4-bit, M <= 64); [3]: tiled-GEMM inner-loop schedule variant */
+    int32_t path;        /* 0 auto, 1 generic GEMV, 2 LDS-staged q4/fp16 GEMV, 3 MFMA GEMM, 4 direct q4/fp16 GEMV, 5 matrix-core q4/fp16 GEMV, 6 streamed (LDS-DMA) q4 GEMV */
+    int32_t reserved[4]; /* [0]: max packed rows per lane and iteration for the register-direct GEMVs, = rows per lane for the streamed one (0 = heuristic); [1]: 32 = force the 32-deep K-step in the MFMA GEMM; [2]: 1 = force the 64-column skinny GEMM, 2 = force the tiled GEMM, 3 = force the 16-column-strip GEMM (4-bit, M <= 64); [3]: tiled-GEMM inner-loop schedule variant */
 } gptq_tuning_t;
 
 int         gptq_abi_version(void);
@@ -130,6 +134,20 @@ size_t gptq_workspace_bytes_max(const gptq_layer_t *layer, int max_M);
 /* out[M,N] = x[M,K] @ dequant(layer) (+ bias).  Picks GEMV (small M) or MFMA GEMM. */
 int gptq_forward(const gptq_layer_t *layer, const void *x, void *out, int M,
                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* n_layers independent layers that read the SAME x[M, K] -- q/k/v of an attention block, gate/up of a gated MLP -- in one
+ * call: outs[i] is [M, layers[i]->N].  The reference fuses such layers by concatenating their packed tensors along
+ * out_features into one QuantLinear (fused_llama_attn.py:171-203, fused_llama_mlp.py:157-242); this entry point gives the
+ * same single launch (M <= 4, plain 4-bit fp16/bf16 layers, <= 4 of them: one streamed GEMV over the strips of all layers)
+ * without touching or copying the checkpoint tensors, and runs the layers one after the other in every other case --
+ * results are those of n gptq_forward calls either way.  Workspace: gptq_workspace_bytes_multi. */
+size_t gptq_workspace_bytes_multi(const gptq_layer_t *const *layers, int n_layers, int M);
+int gptq_forward_multi(const gptq_layer_t *const *layers, int n_layers, const void *x, void *const *outs, int M,
+                       void *workspace, size_t workspace_bytes, void *stream);
+/* ... with an explicit launch shape for the one-launch kernel (experiments; tuning.path = 6 makes "does not fit" an error). */
+size_t gptq_workspace_bytes_multi_ex(const gptq_layer_t *const *layers, int n_layers, int M, const gptq_tuning_t *tuning);
+int gptq_forward_multi_ex(const gptq_layer_t *const *layers, int n_layers, const void *x, void *const *outs, int M,
+                          void *workspace, size_t workspace_bytes, void *stream, const gptq_tuning_t *tuning);
 
 /* Same, with an explicit launch shape / path (tuning may be NULL). */
 int gptq_forward_ex(const gptq_layer_t *layer, const void *x, void *out, int M,

@@ -941,3 +941,78 @@ def test_pack_on_gpu_module_from_cpu_quantizer_outputs_and_device_mismatch_error
     bad.g_idx = (torch.arange(256, dtype=torch.int32) % 5).to(DEV)         # group 4 does not exist (G = 4)
     with pytest.raises(_lib.GptqError, match="outside"):
         bad.post_init()
+
+
+# ------------------------------------------------------------------------- streamed GEMV (LDS DMA) + gptq_forward_multi
+def _stream_tuning(ln, waves, u, ksplit):
+    t = _tuning(path=6, lanes_n=ln, waves=waves, ksplit=ksplit)
+    t.reserved[0] = u
+    return t
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("ln,waves,u,ksplit", [(4, 4, 2, 1), (4, 8, 4, 1), (4, 16, 8, 1), (16, 8, 4, 2), (16, 16, 8, 3), (4, 8, 2, 4), (16, 4, 2, 1)])
+@pytest.mark.parametrize("K,N,gs,M", [(1024, 512, 128, 1), (2048, 96, 64, 3), (4096, 1056, 128, 4), (512, 2048, 128, 2)])
+def test_streamed_gemv_vs_oracle(K, N, gs, M, ln, waves, u, ksplit, dtype):
+    """gemv_q4_stream_kernel (tuning.path = 6): every launch geometry, incl. ragged last strips (N = 96, 1056 with 64-column
+    strips), several passes over K (small waves x u), the in-launch K-split combine, bias, both zero conventions."""
+    if u > gs // 8:
+        pytest.skip("u rows of a lane must lie in one group")
+    L = O.random_quant_layer(K, N, 4, gs, dtype=dtype, seed=K + N + M, bias=True)
+    for zm in ("wrap", "nowrap"):
+        q = _module_from(L["qweight"], L["qzeros"], L["scales"], None, L["bias"], 4, gs, zero_mode=zm)
+        x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype)
+        t = _stream_tuning(ln, waves, u, ksplit)
+        q.post_init()
+        d = _lib.describe_plan(q._layer, M, t)
+        assert d["kernel"] == "stream" and d["ln"] == ln and d["waves"] == waves and d["u"] == u, d
+        with torch.no_grad():
+            y1 = q(x.to(DEV), tuning=t)
+            y2 = q(x.to(DEV), tuning=t)                       # second launch: tickets were reset by the first
+        assert torch.equal(y1, y2)
+        mode = O.ZERO_WRAP if zm == "wrap" else O.ZERO_NOWRAP
+        ref = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], None, L["bias"], 4, mode)
+        _assert_close(y1, ref, ref, dtype, K, f"streamed gemv ln={ln} waves={waves} u={u} ksplit={ksplit}")
+
+
+@pytest.mark.parametrize("M", [1, 2, 4, 5, 40])
+@pytest.mark.parametrize("act", [False, True])
+def test_forward_multi_equals_layer_by_layer(M, act):
+    """gptq_forward_multi: q/k/v-like (3 layers, different widths) and gate/up-like (2 layers) groups give exactly the
+    outputs of separate forward calls -- one streamed launch for M <= 4 plain layers, layer by layer otherwise (act-order,
+    M > 4)."""
+    from autogptq_amd.qlinear_mi355x import forward_multi
+    K = 2048
+    Ls = [O.random_quant_layer(K, n, 4, 128, act_order=act, seed=31 + i, bias=(i == 1)) for i, n in enumerate((512, 160, 1024))]
+    qs = [_module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"] if act else None, L["bias"], 4, 128) for L in Ls]
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).half().to(DEV)
+    with torch.no_grad():
+        ys = forward_multi(qs, x)
+        ys2 = forward_multi(qs, x)
+        sep = [q(x) for q in qs]
+    mode = O.reference_zero_mode(act, 4)
+    for y, y2, s, L in zip(ys, ys2, sep, Ls):
+        assert torch.equal(y, y2)
+        ref = O.forward_f64(x.cpu(), L["qweight"], L["qzeros"], L["scales"], L["g_idx"] if act else None, L["bias"], 4, mode)
+        _assert_close(y, ref, ref, torch.float16, K, "forward_multi vs oracle")
+        _assert_close(y, s, ref, torch.float16, K, "forward_multi vs separate")
+    if M <= 4 and not act:                       # the single-layer streamed kernel (its own K split: same values within rounding)
+        t = _tuning(path=6)
+        with torch.no_grad():
+            one = [q(x, tuning=t) for q in qs]
+        for y, o, L in zip(ys, one, Ls):
+            _assert_close(o, y, y.double(), torch.float16, K, "single-layer streamed vs multi")
+    # inside a hipGraph, with a K split (narrow layers): tickets survive capture + replays
+    narrow = [O.random_quant_layer(4096, n, 4, 128, seed=77 + n) for n in (128, 256)]
+    qn = [_module_from(L["qweight"], L["qzeros"], L["scales"], None, None, 4, 128) for L in narrow]
+    xn = (torch.rand(1, 4096) - 0.5).half().to(DEV)
+    with torch.no_grad():
+        eager = forward_multi(qn, xn)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), torch.no_grad():
+        cap = forward_multi(qn, xn)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(eager, cap):
+        assert torch.equal(a, b)
