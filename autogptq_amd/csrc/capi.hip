@@ -251,6 +251,9 @@ static int forward_impl(const gptq_layer_t* L, const void* x, void* out, int M, 
         void* outs[1] = {out};
         return stream_call(one, 1, plan_stream(one, 1, M, tune), x, outs, M, ws, ws_bytes, stream);
     }
+    if (tune && tune->path == 6)
+        return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 6: the streamed GEMV needs M <= 4, a plain 4-bit fp16/bf16 layer (no act-order, no epilogue) "
+                                          "and a launch shape with rows-per-lane in {2, 4, 8} dividing the rows of a group");
     if (want_gemm(L, M, tune)) return gptq_gemm(L, x, out, M, ws, ws_bytes, stream, tune);
     return gptq_gemv(L, x, out, M, ws, ws_bytes, stream, tune);
 }

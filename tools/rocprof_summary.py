@@ -74,16 +74,16 @@ def main():
               f"({r[6]},{r[7]},{r[8]})/{r[9]} = {r[6] // max(1, r[9]) * r[7] * r[8]}  {r[10]}  {r[11]} {r[12]} {r[13]}  {short(r[0])}")
     try:
         pmc = cur.execute(
-            "select k.name, p.counter_name, avg(p.counter_value), count(*) from pmc_events p join kernels k "
-            "on p.dispatch_id = k.dispatch_id group by k.name, p.counter_name order by k.name").fetchall()
+            "select k.name, p.counter_name, avg(p.counter_value), count(*), k.grid_x / k.workgroup_x from pmc_events p join kernels k "
+            "on p.dispatch_id = k.dispatch_id group by k.name, k.grid_x, k.workgroup_x, p.counter_name order by k.name, k.grid_x").fetchall()
     except sqlite3.Error:
         pmc = []
     if pmc:
         print("# PMC (mean per dispatch)")
-        for name, ctr, val, cnt in pmc:
+        for name, ctr, val, cnt, blocks in pmc:
             if args.match and args.match not in name:
                 continue
-            print(f"  {ctr:28s} {val:16.1f}  n={cnt:5d}  {short(name, 80)}")
+            print(f"  {ctr:28s} {val:16.1f}  n={cnt:5d}  blocks={blocks:5d}  {short(name, 80)}")
 
 
 if __name__ == "__main__":

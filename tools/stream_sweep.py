@@ -56,15 +56,13 @@ def main():
         base, ref = timed(lambda: [q(x) for q in layers])
         res.append((base / nl, "register kernel (default plan)"))
         rows = K // 8
-        for ln in (4, 16):
+        for ln in (4, 8, 16):
             wr = 64 // ln
-            for waves, u in ((4, 2), (4, 4), (4, 8), (8, 2), (8, 4), (8, 8), (16, 2), (16, 4), (16, 8)):
-                for ks in ((1,) if ln == 4 else (1, 2, 4, 8)):
-                    if ln == 16 and N // 64 * ks < 128:
+            for waves, u in ((4, 2), (4, 4), (8, 2), (8, 4), (8, 8), (16, 2), (16, 4), (16, 8)):
+                for ks in ((1,) if ln == 4 else (1, 2, 4)):
+                    if N // (4 * ln) * ks < 128:
                         continue
                     passes = -(-(rows // ks) // (waves * wr * u))
-                    if passes > 3:
-                        continue
                     t = tune(path=6, lanes_n=ln, waves=waves, ksplit=ks, u=u)
                     try:
                         s, out = timed(lambda: [q(x, tuning=t) for q in layers])
@@ -74,7 +72,7 @@ def main():
                     res.append((s / nl, f"stream ln={ln} waves={waves} u={u} ksplit={ks} passes={passes}{'' if ok else '  MISMATCH'}"))
         res.sort()
         print(f"== {K}x{N} M={M} {args.dtype}: {nl} layers, {ab} B/launch")
-        for s, name in res[:14]:
+        for s, name in res[:18]:
             print(f"   {s*1e6:7.2f} us {ab/s/1e9:7.0f} GB/s  {name}")
         print(f"   (register kernel: {base/nl*1e6:.2f} us)")
         del layers
@@ -88,10 +86,8 @@ def main():
         res = []
         base, ref = timed(lambda: [[q(x) for q in grp] for grp in groups])
         res.append((base / ng, "separate launches (register kernel)"))
-        for ln in (4, 16):
-            for waves, u in ((4, 2), (4, 4), (8, 2), (8, 4), (16, 2), (16, 4), (4, 8), (8, 8)):
-                if (K // 8) > waves * (64 // ln) * u * 2:
-                    continue
+        for ln in (4, 8, 16):
+            for waves, u in ((4, 2), (4, 4), (8, 2), (8, 4), (16, 2), (16, 4), (8, 8), (16, 8)):
                 t = tune(path=6, lanes_n=ln, waves=waves, ksplit=1, u=u)
                 try:
                     s, out = timed(lambda: [forward_multi(grp, x, t) for grp in groups])
@@ -103,7 +99,7 @@ def main():
         res.append((s / ng, "forward_multi (default plan)"))
         res.sort()
         print(f"== {name} K={K} N={Ns} M={M}: {ng} groups, {ab} B per group")
-        for s, nm in res[:10]:
+        for s, nm in res[:14]:
             print(f"   {s*1e6:7.2f} us {ab/s/1e9:7.0f} GB/s  {nm}")
         del groups
         torch.cuda.empty_cache()
