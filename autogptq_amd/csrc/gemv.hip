@@ -815,17 +815,16 @@ __global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && (!PE
     }
 }
 
-// ---- streamed matrix-core GEMV: everything by LDS DMA, software-pipelined, up to 4 layers that share x in ONE launch -----
+// ---- streamed matrix-core GEMV: weights by LDS DMA, up to 4 layers that share x in ONE launch ------------------
 // Same lane decomposition and arithmetic as gemv_q4_f16_mfma_kernel (plain layers: no act-order, no fused epilogue,
-// M <= 4), restructured around what the profile of that kernel shows on the long-K layers: per packed row it spends 71-87 VALU
-// instructions (36 of them the dequant itself; the rest is address arithmetic, per-pass group constants, x permutes, tail
-// masks) and every pass is a dependent load -> wait -> compute round trip with ONE 16-byte load per lane in flight.
-//  * Every global read is an LDS DMA (global_load_lds, no VGPR destination) issued from inline asm and waited for with
-//    hand-counted s_waitcnt vmcnt: the weights of pass p+2 are requested before pass p+1 is computed (two landing buffers
-//    per wave, each wave reads back only what it requested itself: no barrier in the K loop), so compute overlaps the stream.
-//  * x (the slice of K this workgroup walks), the scales and the zero-points of the strip are fetched ONCE per workgroup,
-//    then turned into what the inner loop wants: x in the k-slot order of the magic-number unpack, per (group, column)
-//    half2 constants -(1024 + z) and fp32 scales.  The loop body is then 2 ds_read_b128 + the dequant + 8 MFMA per row.
+// M <= 4), with two structural changes aimed at what bounds a one-shot decode launch -- bytes in flight and fixed cost
+// per launch:
+//  * the packed rows go global -> LDS by DMA (global_load_lds_dwordx4, nontemporal: 1 KiB per wave instruction, no VGPR
+//    destination), each wave into its own U KiB region, and are read back by the SAME lanes (ds_read_b128, lane-linear:
+//    conflict free) -- no barrier, the wave's own vmcnt orders DMA before read.  Bytes in flight per CU are bounded by the
+//    160 KiB of LDS instead of the VGPR budget: U = 8 with 16 waves puts a whole 11008-row strip (88 KB) in flight from the
+//    first cycle, where the register version walked it in 5.4 dependent iterations of 16 KB;  U = 4 with 8 waves stays
+//    under 64 VGPRs, so the 688 strips of a 4096 x 11008 layer are all resident at once (3 workgroups per CU).
 //  * the workgroup grid runs over the strips of up to four layers that read the same x (q/k/v, gate/up): one launch
 //    boundary, one ramp and one drain for 25 / 45 MB instead of three / two (gptq_forward_multi).  The reference gets this
 //    by concatenating the packed tensors (fused_llama_attn.py:171-186); here the checkpoint tensors stay where they are.
@@ -834,30 +833,16 @@ __global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && (!PE
 //    index order with sc1 loads (bit-reproducible: fixed order, no float atomics) and resets the ticket.  Correct for any
 //    placement of the slices over XCDs / CUs.  Tickets live at the front of the workspace, which the caller hands over
 //    zeroed once (gptq_mi355x.h).
-// LDS DMA from inline asm on purpose: with the builtin, hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) behind EVERY DMA of a
-// burst (it cannot prove that two DMA writes into the one __shared__ array do not overlap), which serialises the burst into
-// dependent round trips.  The kernel therefore has NO compiler-visible VMEM load in flight next to the DMAs (the compiler's
-// own vmcnt bookkeeping would over-wait: vmcnt retires in order and counts the hidden DMAs).
-__device__ __forceinline__ void dma16_nt(const void* gsrc, unsigned lds_dst_) {      // 16 B / lane, nontemporal: streamed once
-    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);   // wave-uniform by construction; makes it an SGPR for the compiler too
+// 16 bytes per lane, global -> LDS (destination = lds_dst + lane * 16), nontemporal.  Inline asm on purpose: with the
+// builtin, hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) behind EVERY LDS-DMA instruction of a burst (it cannot prove that two
+// DMA writes into the one __shared__ array do not overlap), which serialises the burst into dependent round trips.  Hidden
+// in asm the instruction is not counted by the compiler's own vmcnt bookkeeping -- that only ever makes its waits for
+// ordinary loads longer, never shorter (vmcnt retires in order) -- and the kernel waits for the DMA data explicitly.
+__device__ __forceinline__ void dma16_nt(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst_) {         // 16 B / lane, default policy: re-read by every workgroup
-    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);   // wave-uniform by construction; makes it an SGPR for the compiler too
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_dst_) {          // 4 B / lane
-    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);   // wave-uniform by construction; makes it an SGPR for the compiler too
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct GemvSeg {
     const unsigned* qweight;
@@ -876,27 +861,10 @@ struct GemvStreamParams {
     float* partial;      // [ksplit][M][nsum]
     unsigned* tickets;   // [strips_total]
     int nseg, M, K, zero_mode, units_total, units_per_split, ksplit, gu_shift, nsum;
-    int xs_stride;       // bytes per x row in LDS (multiple of 1024)
-    int gmax;            // groups a slice can touch (LDS table rows)
 };
-__host__ __device__ constexpr int round_up_i(int v, int a) { return (v + a - 1) / a * a; }
-// LDS carve-up, shared by the kernel and the host-side size computation
-struct StreamLds { int wbuf, xs, raw_s, raw_z, cz, cs, red, total; };
-__host__ __device__ inline StreamLds stream_lds(int W, int U, int MT, int CT, int xs_stride, int gmax) {
-    StreamLds o;
-    o.wbuf = 0;
-    o.xs = W * 2 * U * 1024;
-    o.raw_s = o.xs + MT * xs_stride;
-    o.raw_z = o.raw_s + round_up_i(gmax * CT * 2, 256);
-    o.cz = o.raw_z + round_up_i(gmax * (CT / 8) * 4, 256);
-    o.cs = o.cz + gmax * CT * 4;
-    o.red = o.cs + gmax * CT * 4;
-    o.total = o.red + W * MT * CT * 4 + 16;
-    return o;
-}
 
-template <int LN, int MT, int U, typename T>
-__global__ void __launch_bounds__(1024, 4) gemv_q4_stream_kernel(GemvStreamParams p) {
+template <int LN, int MT, int U, typename T, int WPS>
+__global__ void __launch_bounds__(1024, WPS) gemv_q4_stream_kernel(GemvStreamParams p) {
     constexpr bool BF = std::is_same_v<T, bf16>;
     unsigned m_lo, m_hi, magic;
     asm("s_mov_b32 %0, 0x000f000f" : "=s"(m_lo));
@@ -904,10 +872,11 @@ __global__ void __launch_bounds__(1024, 4) gemv_q4_stream_kernel(GemvStreamParam
     asm("v_mov_b32 %0, 0x64006400" : "=v"(magic));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WR = 64 / LN, CT = LN * 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6, NT = blockDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
     const int cl = lane % LN, rs = lane / LN;
-    const StreamLds lo = stream_lds(W, U, MT, CT, p.xs_stride, p.gmax);
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+    char* const wq = smem + (size_t)wave * (U * 1024);                        // this wave's DMA landing area
+    const unsigned wq_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)wq);   // its LDS byte address (SGPR)
+    float* const red = (float*)(smem + (size_t)W * (U * 1024));               // [W][MT][CT] cross-wave sums, + 1 word
     // logical block -> (strip over all layers, K slice); slices of one strip are adjacent logical ids (same XCD after the remap)
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int sidx = L / p.ksplit, ks = L - sidx * p.ksplit;
@@ -921,153 +890,98 @@ __global__ void __launch_bounds__(1024, 4) gemv_q4_stream_kernel(GemvStreamParam
     const int nload = col_ok ? n0 : 0;
     const int ub = ks * p.units_per_split;
     const int ue = min(ub + p.units_per_split, p.units_total);
-    const int nrows = ue - ub;
-    const int gshift = p.gu_shift;
-    const int g0 = ub >> gshift, Gs = ((ue - 1) >> gshift) - g0 + 1;
+    const T* xrow = (const T*)p.x + (size_t)min(lane & 3, p.M - 1) * p.K;     // A operand: lane i of a 4-lane group carries x row i
+    const T* __restrict__ scales = (const T*)sg.scales;
     const unsigned* __restrict__ qweight = sg.qweight;
+    const int zrow_words = N >> 3;
     const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
-    const int rows_per_pass = W * WR * U;
-    const int npass = (nrows + rows_per_pass - 1) / rows_per_pass;
-    const int lane_row = (wave * WR + rs) * U;                                // this lane's first row inside a pass
+    const int gshift = p.gu_shift;
 
-    // ---- 1. request: x slice, scales, zero-points of the strip (spread over the waves), then the first two weight passes ----
-    {
-        const int x_per_m = (nrows * 16 + 1023) / 1024;                       // 1 KiB DMA instructions per x row
-        const int n_x = MT * x_per_m;
-        const int s_pieces = Gs * (CT / 2), n_s = (s_pieces + 63) / 64;       // 4-byte pieces: 2 scales each
-        const int z_pieces = Gs * (CT / 8), n_z = (z_pieces + 63) / 64;       // 4-byte pieces: 8 zero-points each
-        const int zrow_words = N >> 3;
-        for (int i = wave; i < n_x + n_s + n_z; i += W) {
-            if (i < n_x) {
-                const int m = i / x_per_m, c = i - m * x_per_m;
-                const int pc = c * 64 + lane;
-                if (pc < nrows)
-                    dma16((const char*)p.x + ((size_t)min(m, p.M - 1) * p.K + (size_t)(ub + pc) * 8) * 2, lds0 + lo.xs + m * p.xs_stride + c * 1024);
-            } else if (i < n_x + n_s) {
-                const int c = i - n_x, q = c * 64 + lane;
-                const int g = q / (CT / 2), i2 = q - g * (CT / 2);
-                if (q < s_pieces && strip * CT + i2 * 2 < N)
-                    dma4((const char*)sg.scales + ((size_t)(g0 + g) * N + strip * CT + i2 * 2) * 2, lds0 + lo.raw_s + c * 256);
-            } else {
-                const int c = i - n_x - n_s, q = c * 64 + lane;
-                const int g = q / (CT / 8), i2 = q - g * (CT / 8);
-                if (q < z_pieces && strip * CT + i2 * 8 < N)
-                    dma4(sg.qzeros + (size_t)(g0 + g) * zrow_words + (strip * CT) / 8 + i2, lds0 + lo.raw_z + c * 256);
-            }
-        }
-    }
-    auto issue_pass = [&](int pass) {
-        const int u0 = ub + pass * rows_per_pass + lane_row;
-        const unsigned dst = lds0 + lo.wbuf + ((wave * 2 + (pass & 1)) * U) * 1024;
-#pragma unroll
-        for (int j = 0; j < U; ++j)
-            dma16_nt(qweight + (size_t)min(u0 + j, ue - 1) * N + nload, dst + j * 1024);
-    };
-    issue_pass(0);
-    if (npass > 1) issue_pass(1);
-    // ---- 2. constants have landed (they are older than the weight DMAs): derive the loop's tables ---------------------------
-    if (npass > 1) wait_vm<2 * U>(); else wait_vm<U>();
-    lds_barrier();
-    {
-        const unsigned short* raw_s = (const unsigned short*)(smem + lo.raw_s);
-        const unsigned* raw_z = (const unsigned*)(smem + lo.raw_z);
-        unsigned* cz = (unsigned*)(smem + lo.cz);
-        float* cs = (float*)(smem + lo.cs);
-        for (int idx = tid; idx < Gs * CT; idx += NT) {
-            const int g = idx / CT, c = idx - g * CT;
-            const unsigned z = (((raw_z[g * (CT / 8) + (c >> 3)] >> (4 * (c & 7))) & 15u) + 1u) & zmask;
-            cz[idx] = z * 0x00010001u + 0xE400E400u;                                        // half2 -(1024 + z)
-            cs[idx] = DType<T>::to_f32(__builtin_bit_cast(T, raw_s[idx]));
-        }
-        for (int idx = tid; idx < MT * nrows; idx += NT) {                                  // x: natural -> k-slot order (k0,k4)(k1,k5)(k2,k6)(k3,k7)
-            const int m = idx / nrows, r = idx - m * nrows;
-            u32x4* px = (u32x4*)(smem + lo.xs + m * p.xs_stride + r * 16);
-            const u32x4 t = *px;
-            *px = u32x4{__builtin_amdgcn_perm(t[2], t[0], 0x05040100u), __builtin_amdgcn_perm(t[2], t[0], 0x07060302u),
-                        __builtin_amdgcn_perm(t[3], t[1], 0x05040100u), __builtin_amdgcn_perm(t[3], t[1], 0x07060302u)};
-        }
-    }
-    lds_barrier();
-
-    // ---- 3. the stream: pass p is computed while p+1 is landing and p+2 is requested behind it ------------------------------
     float acc[4][MT];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[c][m] = 0.f;
-    const char* const xlane = smem + lo.xs + min(lane & 3, MT - 1) * p.xs_stride;       // A operand: lane i of a 4-lane group carries x row i
-    const f16x2 k960 = {(f16)960.f, (f16)960.f};
-    const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
-    auto compute_pass = [&](int pass, auto masked_c) {
-        constexpr bool MASKED = decltype(masked_c)::value;
-        const int u0 = ub + pass * rows_per_pass + lane_row;
-        const int gl = (min(u0, ue - 1) >> gshift) - g0;
-        const u32x4 c1v = *(const u32x4*)(smem + lo.cz + (gl * CT + cl * 4) * 4);
-        const f32x4 scv = *(const f32x4*)(smem + lo.cs + (gl * CT + cl * 4) * 4);
+
+    const int rows_per_iter = W * WR * U;
+    for (int base = ub; base < ue; base += rows_per_iter) {
+        const int u0 = base + (wave * WR + rs) * U;
+        const int g = min(u0, ue - 1) >> gshift;
+        // small L2-resident loads first (they return first), then the DMA burst
+        const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * N + nload);
+        const unsigned zw = sg.qzeros[(size_t)g * zrow_words + (nload >> 3)] >> ((nload & 7) * 4);
+        u32x4 xr[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) xr[j] = *(const u32x4*)(xrow + (size_t)min(u0 + j, ue - 1) * 8);
+        if (base != ub) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // WAR: last iteration's ds_reads are done
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int ul = min(u0 + j, ue - 1);
+            dma16_nt(qweight + (size_t)ul * N + nload, wq_lds + j * 1024);
+        }
         f16x2 c1[4], c2[4];
+        const f16x2 k960 = {(f16)960.f, (f16)960.f};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            c1[c] = as_f16x2(c1v[c]);
-            c2[c] = c1[c] + k960;                                   // -(64 + z), exact
+            const unsigned z = (((zw >> (4 * c)) & 15u) + 1u) & zmask;
+            c1[c] = as_f16x2(z * 0x00010001u + 0xE400E400u);        // -(1024+z)
+            c2[c] = c1[c] + k960;                                   // -(64+z)
         }
         f32x4 accg[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) accg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const char* wq = smem + lo.wbuf + ((wave * 2 + (pass & 1)) * U) * 1024 + lane * 16;
+        const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+        // row j is consumed as soon as DMA j has landed: vmcnt retires in order and the U DMAs are the youngest VMEM
+        // operations of the wave, so "at most U-1-j outstanding" means DMAs 0..j (and every older load) are complete
+        [&]<int... J>(std::integer_sequence<int, J...>) {
+            (([&] {
+                 constexpr int j = J;
+                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(U - 1 - j) : "memory");
+                 const u32x4 qv = *(const u32x4*)(wq + j * 1024 + lane * 16);
+                 const bool live = (u0 + j < ue);
+                 const u32x4 t = xr[j];
+                 u32x2 a01 = u32x2{__builtin_amdgcn_perm(t[2], t[0], 0x05040100u), __builtin_amdgcn_perm(t[2], t[0], 0x07060302u)};
+                 u32x2 a23 = u32x2{__builtin_amdgcn_perm(t[3], t[1], 0x05040100u), __builtin_amdgcn_perm(t[3], t[1], 0x07060302u)};
+                 if (!live) { a01 = u32x2{0u, 0u}; a23 = u32x2{0u, 0u}; }
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const u32x4 qv = *(const u32x4*)(wq + j * 1024);
-            const int r = MASKED ? min(u0 + j, ue - 1) - ub : u0 + j - ub;
-            u32x4 t = *(const u32x4*)(xlane + r * 16);
-            if constexpr (MASKED) {
-                if (u0 + j >= ue) t = u32x4{0u, 0u, 0u, 0u};
-            }
-            const u32x2 a01 = {t[0], t[1]}, a23 = {t[2], t[3]};
+                 for (int c = 0; c < 4; ++c) {
+                     const unsigned qw = qv[c], q8 = qw >> 8;
+                     const f16x2 h0 = as_f16x2((qw & m_lo) | magic) + c1[c];             // k0,k4
+                     const f16x2 h1 = as_f16x2((qw & m_hi) | magic) * r16 + c2[c];       // k1,k5
+                     const f16x2 h2 = as_f16x2((q8 & m_lo) | magic) + c1[c];             // k2,k6
+                     const f16x2 h3 = as_f16x2((q8 & m_hi) | magic) * r16 + c2[c];       // k3,k7
+                     u32x2 b01, b23;
+                     if constexpr (BF) {
+                         auto to_bf = [&](f16x2 hv) -> unsigned {
+                             const bf16x2 o = {(bf16)(float)hv[0], (bf16)(float)hv[1]};
+                             return __builtin_bit_cast(unsigned, o);
+                         };
+                         b01 = u32x2{to_bf(h0), to_bf(h1)};
+                         b23 = u32x2{to_bf(h2), to_bf(h3)};
+                     } else {
+                         b01 = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+                         b23 = u32x2{__builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
+                     }
+                     accg[c] = Mma4<T>::run(a01, b01, accg[c]);
+                     accg[c] = Mma4<T>::run(a23, b23, accg[c]);
+                 }
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, U>{});
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const unsigned qw = qv[c], q8 = qw >> 8;
-                const f16x2 h0 = as_f16x2((qw & m_lo) | magic) + c1[c];             // k0,k4
-                const f16x2 h1 = as_f16x2((qw & m_hi) | magic) * r16 + c2[c];       // k1,k5
-                const f16x2 h2 = as_f16x2((q8 & m_lo) | magic) + c1[c];             // k2,k6
-                const f16x2 h3 = as_f16x2((q8 & m_hi) | magic) * r16 + c2[c];       // k3,k7
-                u32x2 b01, b23;
-                if constexpr (BF) {
-                    auto to_bf = [&](f16x2 hv) -> unsigned {
-                        const bf16x2 o = {(bf16)(float)hv[0], (bf16)(float)hv[1]};
-                        return __builtin_bit_cast(unsigned, o);
-                    };
-                    b01 = u32x2{to_bf(h0), to_bf(h1)};
-                    b23 = u32x2{to_bf(h2), to_bf(h3)};
-                } else {
-                    b01 = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
-                    b23 = u32x2{__builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
-                }
-                accg[c] = Mma4<T>::run(a01, b01, accg[c]);
-                accg[c] = Mma4<T>::run(a23, b23, accg[c]);
-            }
-        }
+        for (int c = 0; c < 4; ++c) {
+            const unsigned sh = (c & 1) ? (sraw[c >> 1] >> 16) : (sraw[c >> 1] & 0xffffu);
+            const float sc = DType<T>::to_f32(__builtin_bit_cast(T, (unsigned short)sh));
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[c][m] = fmaf(scv[c], accg[c][m], acc[c][m]);
-    };
-    for (int pass = 0; pass < npass; ++pass) {
-        // vmcnt retires in order: "at most U outstanding" = everything but the youngest pass (p+1) has landed
-        if (pass + 1 < npass) wait_vm<U>(); else wait_vm<0>();
-        if (ub + (pass + 1) * rows_per_pass <= ue) compute_pass(pass, std::false_type{});
-        else compute_pass(pass, std::true_type{});
-        if (pass + 2 < npass) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // WAR: this pass's ds_reads are done before its buffer is refilled
-            issue_pass(pass + 2);
+            for (int m = 0; m < MT; ++m) acc[c][m] = fmaf(sc, accg[c][m], acc[c][m]);
         }
     }
-    // ---- 4. row slots (DPP / bpermute), waves (LDS), then write or publish -------------------------------------------------
+    // ---- row slots (DPP / bpermute), waves (LDS, the only barrier), then write or publish ------------------------------
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c][m] = row_slot_sum<LN>(acc[c][m]);
     constexpr int E = MT * CT;
-    float* const red = (float*)(smem + lo.red);
     if (lane < LN) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -1078,7 +992,7 @@ __global__ void __launch_bounds__(1024, 4) gemv_q4_stream_kernel(GemvStreamParam
     __syncthreads();
     unsigned* const flag = (unsigned*)(red + W * E);                          // one word behind the slabs (same LDS array)
     const size_t slab = (size_t)p.M * p.nsum;
-    for (int e = tid; e < E; e += NT) {
+    for (int e = tid; e < E; e += blockDim.x) {
         const int m = e / CT, c = e % CT;
         float t = 0.f;
         for (int w = 0; w < W; ++w) t += red[w * E + e];
@@ -1097,7 +1011,7 @@ __global__ void __launch_bounds__(1024, 4) gemv_q4_stream_kernel(GemvStreamParam
         if (tid == 0) *flag = __hip_atomic_fetch_add(p.tickets + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (*flag != (unsigned)(p.ksplit - 1)) return;                        // not the last slice of this strip
-        for (int e = tid; e < E; e += NT) {
+        for (int e = tid; e < E; e += blockDim.x) {
             const int m = e / CT, c = e % CT;
             const int n = strip * CT + c;
             if (n >= N || m >= p.M) continue;
@@ -1653,12 +1567,11 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     if (tune && tune->waves && tune->reserved[0]) {
         waves = tune->waves; u = tune->reserved[0];
     } else {
-        // default: the pass size that gives the slice about four passes (two in flight, compute overlapping the stream)
         static const int cand[][2] = {{4, 2}, {8, 2}, {8, 4}, {16, 4}, {16, 8}};
         for (auto& c : cand) {
             if (c[1] > ucap) continue;
             waves = c[0]; u = c[1];
-            if (c[0] * wr * c[1] * 4 >= ups) break;
+            if (c[0] * wr * c[1] >= ups) break;
         }
     }
     if (waves < 1 || waves > 16 || (u != 2 && u != 4 && u != 8) || u > ucap || pl.units_total % u) return pl;
@@ -1667,18 +1580,21 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     pl.ksplit = (pl.units_total + ups - 1) / ups;       // no empty slices
     pl.waves = waves;
     pl.u = u;
-    pl.xs_stride = round_up_i(ups * 16, 1024);
-    pl.gmax = (ups + gu - 1) / gu + 1;
-    pl.lds_bytes = (size_t)stream_lds(waves, u, pl.mt, ct, pl.xs_stride, pl.gmax).total;
+    pl.lds_bytes = (size_t)waves * u * 1024 + (size_t)waves * pl.mt * ct * sizeof(float) + 16;
     if (pl.lds_bytes > 160 * 1024) return pl;
     pl.partial_bytes = pl.ksplit > 1 ? (size_t)pl.ksplit * M * nsum * sizeof(float) : 0;
     pl.ok = true;
     return pl;
 }
 
+// minimum waves per SIMD the kernel is compiled for (= VGPR cap 64 / 80 / 128): no spills at these pairings
+template <int LN, int MT, int U, typename T>
+static constexpr int stream_wps() { return (U <= 2 && MT == 1) ? 8 : ((U <= 2 || (U == 4 && MT <= 2)) ? 6 : 4); }
+
 template <int LN, int MT, int U, typename T>
 static hipError_t launch_stream_one(const StreamPlan& pl, const GemvStreamParams& p, hipStream_t st) {
-    hipLaunchKernelGGL((gemv_q4_stream_kernel<LN, MT, U, T>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+    hipLaunchKernelGGL((gemv_q4_stream_kernel<LN, MT, U, T, stream_wps<LN, MT, U, T>()>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64),
+                       pl.lds_bytes, st, p);
     return hipGetLastError();
 }
 template <int LN, int MT, typename T>
@@ -1729,31 +1645,24 @@ hipError_t launch_stream(const gptq_layer_t* const* Ls, const StreamPlan& pl, co
     p.units_total = pl.units_total; p.units_per_split = pl.units_per_split; p.ksplit = pl.ksplit;
     p.gu_shift = __builtin_ctz((unsigned)(A.group_size / 8));
     p.nsum = pl.nsum;
-    p.xs_stride = pl.xs_stride;
-    p.gmax = pl.gmax;
     return A.dtype == GPTQ_BF16 ? launch_stream_t<bf16>(pl, p, st) : launch_stream_t<f16>(pl, p, st);
 }
 
-// Per-device, once (gptq_init): the streamed kernel's dynamic LDS (landing buffers + x slice + tables) can exceed the 64 KiB default.
+// Per-device, once (gptq_init): instantiations whose dynamic LDS can exceed the 64 KiB default (16 waves x U = 8).
 template <int LN, int MT, typename T>
 static hipError_t grant_stream() {
-    hipError_t e = hipFuncSetAttribute((const void*)gemv_q4_stream_kernel<LN, MT, 2, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemv_q4_stream_kernel<LN, MT, 4, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemv_q4_stream_kernel<LN, MT, 8, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return e;
-}
-template <typename T>
-static hipError_t grant_stream_t() {
-    hipError_t e = hipSuccess;
-    auto acc = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    acc(grant_stream<4, 1, T>()); acc(grant_stream<4, 2, T>()); acc(grant_stream<4, 4, T>());
-    acc(grant_stream<8, 1, T>()); acc(grant_stream<8, 2, T>()); acc(grant_stream<8, 4, T>());
-    acc(grant_stream<16, 1, T>()); acc(grant_stream<16, 2, T>()); acc(grant_stream<16, 4, T>());
-    return e;
+    return hipFuncSetAttribute((const void*)gemv_q4_stream_kernel<LN, MT, 8, T, stream_wps<LN, MT, 8, T>()>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 hipError_t init_gemv_device() {
-    hipError_t e = grant_stream_t<f16>();
-    if (e == hipSuccess) e = grant_stream_t<bf16>();
+    hipError_t e = hipSuccess;
+    auto acc = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    acc(grant_stream<4, 1, f16>()); acc(grant_stream<4, 2, f16>()); acc(grant_stream<4, 4, f16>());
+    acc(grant_stream<16, 1, f16>()); acc(grant_stream<16, 2, f16>()); acc(grant_stream<16, 4, f16>());
+    acc(grant_stream<8, 1, f16>()); acc(grant_stream<8, 2, f16>()); acc(grant_stream<8, 4, f16>());
+    acc(grant_stream<8, 1, bf16>()); acc(grant_stream<8, 2, bf16>()); acc(grant_stream<8, 4, bf16>());
+    acc(grant_stream<4, 1, bf16>()); acc(grant_stream<4, 2, bf16>()); acc(grant_stream<4, 4, bf16>());
+    acc(grant_stream<16, 1, bf16>()); acc(grant_stream<16, 2, bf16>()); acc(grant_stream<16, 4, bf16>());
     return e;
 }
 
