@@ -1524,8 +1524,33 @@ static bool stream_layer_ok(const gptq_layer_t& L) {
            L.group_size % 8 == 0 && gu >= 2 && (gu & (gu - 1)) == 0 && L.K % 8 == 0;
 }
 
-// Measured preferences (bench.py roofline.us_per_launch_by_shape, tools/gemv_sweep.py --stream): see DESIGN.md section 4.1.
-bool stream_preferred(const gptq_layer_t& L, int M) { return false; }
+// Measured preferences (tools/stream_sweep.py on MI355X, rotating HBM-cold weights inside a hipGraph, M = 1, us per launch;
+// gpurun_out/r2d/sweep.log, summarised in DESIGN.md section 4.1):
+//   4096 x 4096    register kernel 5.02 | streamed 16-col 5.10, 32-col 5.57 (64 WGs of 64 columns cannot fill the chip, and the in-launch K split costs ~1.5-2 us)
+//   4096 x 11008   register 9.64 | streamed 64-col strips, 16 waves x 8 rows, one pass: 8.22 (172 workgroups of 256-byte row segments)
+//   11008 x 4096   register 9.70 | streamed 9.42 at best -> not worth a second code path
+//   q|k|v   (3 x 4096 x 4096 in one launch)    8.81 with 64-col strips (192 WGs) | 15.0 as three launches
+//   gate|up (2 x 4096 x 11008 in one launch)  13.47 with 32-col strips (688 WGs) | 19.0 as two launches
+// Strip width follows s16 = number of 64-column strips of the whole launch: 128..256 -> 64 columns, 257..512 -> 32 columns
+// (344 wide workgroups leave the second round of a 256-CU chip a third full), more -> 64 columns again.
+static int stream_strips64(const gptq_layer_t* const* Ls, int n) {
+    int s16 = 0;
+    for (int i = 0; i < n; ++i) s16 += (Ls[i]->N + 63) / 64;
+    return s16;
+}
+static int stream_default_ln(const gptq_layer_t* const* Ls, int n) {
+    const int s16 = stream_strips64(Ls, n);
+    if (s16 >= 128 && (s16 <= 256 || s16 > 512)) return 16;
+    if (s16 > 256) return 8;
+    return (s16 * 2 >= 128) ? 8 : 4;
+}
+bool stream_preferred(const gptq_layer_t& L, int M) {
+    const gptq_layer_t* one[1] = {&L};
+    const int s16 = stream_strips64(one, 1);
+    // only where it was measured against the register kernel: wider than 8192 columns (128 strips of 64 fill too little of the chip)
+    // and narrower than 12288 (from there on the register kernel itself runs 64-column strips)
+    return s16 > 128 && s16 < 192 && L.K <= 8192 && M <= 2;
+}
 bool multi_preferred(const gptq_layer_t* const* layers, int n, int M) { return n >= 2; }
 
 StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* tune) {
@@ -1541,7 +1566,7 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     pl.mt = M >= 3 ? 4 : M;
     pl.units_total = A.K / 8;
     const int gu = A.group_size / 8;
-    int ln = (tune && tune->lanes_n) ? tune->lanes_n : 4;
+    int ln = (tune && tune->lanes_n) ? tune->lanes_n : stream_default_ln(Ls, n);
     if (ln != 4 && ln != 8 && ln != 16) return pl;
     const int ct = ln * 4, wr = 64 / ln;
     int strips = 0, nsum = 0;
@@ -1555,7 +1580,7 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     int ks = (tune && tune->ksplit) ? tune->ksplit : 0;
     if (!ks) {
         ks = 1;
-        while (strips * ks < 192 && pl.units_total / (ks * 2) >= wr * 4) ks *= 2;
+        while (strips * ks < 128 && pl.units_total / (ks * 2) >= wr * 4) ks *= 2;   // the in-launch combine costs ~1.5-2 us: 172 unsplit workgroups beat 344 split ones
     }
     if (ks > pl.units_total) ks = pl.units_total;
     int ups = (pl.units_total + ks - 1) / ks;
@@ -1567,11 +1592,16 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     if (tune && tune->waves && tune->reserved[0]) {
         waves = tune->waves; u = tune->reserved[0];
     } else {
-        static const int cand[][2] = {{4, 2}, {8, 2}, {8, 4}, {16, 4}, {16, 8}};
-        for (auto& c : cand) {
-            if (c[1] > ucap) continue;
-            waves = c[0]; u = c[1];
-            if (c[0] * wr * c[1] >= ups) break;
+        if (ln == 16) {            // one pass of 16 waves x 8 rows where the slice allows it (measured best for 64-column strips)
+            static const int cand[][2] = {{4, 2}, {8, 2}, {8, 4}, {16, 4}, {16, 8}};
+            for (auto& c : cand) {
+                if (c[1] > ucap) continue;
+                waves = c[0]; u = c[1];
+                if (c[0] * wr * c[1] >= ups) break;
+            }
+        } else {                   // narrower strips: small workgroups (8 waves x 2 rows), several per CU, a few passes each
+            waves = 8; u = 2;
+            while (waves > 1 && (waves / 2) * wr * u >= ups) waves /= 2;
         }
     }
     if (waves < 1 || waves > 16 || (u != 2 && u != 4 && u != 8) || u > ucap || pl.units_total % u) return pl;

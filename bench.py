@@ -79,6 +79,41 @@ def build_stack(device, n_blocks, M, act_order, dtype=torch.float16):
     return layers, xs
 
 
+def group_stack(layers):
+    """The same layers, grouped the way a decoder block calls them: [q, k, v] and [gate, up] read the same activations and go
+    through gptq_forward_multi (ONE launch per group for decode rows, the checkpoint tensors untouched); o and down stay single
+    calls.  Entries: (name, K, N_total, layer | [layers])."""
+    out, i = [], 0
+    while i < len(layers):
+        name = layers[i][0]
+        if name == "q_proj" and i + 2 < len(layers) and layers[i + 2][0] == "v_proj":
+            grp = layers[i:i + 3]
+            out.append(("qkv", grp[0][1], sum(g[2] for g in grp), [g[3] for g in grp]))
+            i += 3
+        elif name == "gate_proj" and i + 1 < len(layers) and layers[i + 1][0] == "up_proj":
+            grp = layers[i:i + 2]
+            out.append(("gate_up", grp[0][1], sum(g[2] for g in grp), [g[3] for g in grp]))
+            i += 2
+        else:
+            out.append(layers[i])
+            i += 1
+    return out
+
+
+def call(q, x):
+    if isinstance(q, list):
+        from autogptq_amd.qlinear_mi355x import forward_multi
+        return forward_multi(q, x)
+    return q(x)
+
+
+def entry_bytes(ent, M, act_order=False):
+    name, K, N, q = ent
+    if isinstance(q, list):
+        return sum(algorithmic_bytes(K, l.outfeatures, M, act_order=act_order) for l in q)
+    return algorithmic_bytes(K, N, M, act_order=act_order)
+
+
 def make_fused_block(device, seed):
     """The same Llama-7B block as four launches: [q|k|v] (4096 -> 12288), o, [gate|up] with the SiLU*mul epilogue
     (4096 -> 22016, output 11008) and down -- the reference's fused attention / fused MLP callers."""
@@ -119,22 +154,18 @@ def capture(layers, xs, device):
     import ctypes
     from autogptq_amd import _lib
 
-    need = 0
-    for _, K, N, q in layers:
-        need = max(need, int(_lib.load().gptq_workspace_bytes(ctypes.byref(q._layer), xs[K].shape[0])))
-    reserve_workspace(device, max(need, 1))
     side = torch.cuda.Stream(device=device)
     side.wait_stream(torch.cuda.current_stream(device))
-    with torch.cuda.stream(side), torch.no_grad():       # warm-up run (allocator, lazy init)
+    with torch.cuda.stream(side), torch.no_grad():       # warm-up run (allocator, lazy init, scratch of the largest need)
         for _, K, N, q in layers:
-            q(xs[K])
+            call(q, xs[K])
     torch.cuda.current_stream(device).wait_stream(side)
     torch.cuda.synchronize(device)
     g = torch.cuda.CUDAGraph()
     outs = []
     with torch.cuda.graph(g), torch.no_grad():
         for _, K, N, q in layers:
-            outs.append(q(xs[K]))
+            outs.append(call(q, xs[K]))
     return g, outs
 
 
@@ -230,6 +261,17 @@ def bench_prefill(device, steps):
     return out
 
 
+def _kernel_of(ent, M):
+    """Name of the kernel a stack entry launches (host-side plan query)."""
+    from autogptq_amd import _lib
+    q = ent[3]
+    if isinstance(q, list):
+        return "gptq::gemv_q4_stream_kernel"          # gptq_forward_multi: plain 4-bit layers, M <= 4
+    d = _lib.describe_plan(q._layer, M)
+    return {"stream": "gptq::gemv_q4_stream_kernel", "mfma": "gptq::gemv_q4_f16_mfma_kernel", "mfma_generic": "gptq::gemv_mfma_generic_kernel",
+            "tiled": "gptq::gemm_kernel"}.get(d.get("kernel"), "gptq::" + str(d.get("kernel")))
+
+
 def _plan_of(layers, K, N, M):
     import ctypes
     from autogptq_amd import _lib
@@ -265,20 +307,21 @@ def bench_eager(layers, xs, device, steps):
     with torch.no_grad():
         for _ in range(2):
             for _, K, N, q in layers:
-                q(xs[K])
+                call(q, xs[K])
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         for _ in range(steps):
             for _, K, N, q in layers:
-                q(xs[K])
+                call(q, xs[K])
         t_issue = time.perf_counter() - t0
         torch.cuda.synchronize(device)
         t = time.perf_counter() - t0
     M = next(iter(xs.values())).shape[0]
-    bytes_step = sum(algorithmic_bytes(K, N, M) for _, K, N, _ in layers)
-    return {"us_per_call": round(1e6 * t / (steps * len(layers)), 2), "host_us_per_call": round(1e6 * t_issue / (steps * len(layers)), 2),
+    bytes_step = sum(entry_bytes(e, M) for e in layers)
+    return {"calls_per_step": len(layers), "us_per_call": round(1e6 * t / (steps * len(layers)), 2),
+            "host_us_per_call": round(1e6 * t_issue / (steps * len(layers)), 2),
             "GB_per_s": round(bytes_step * steps / t / 1e9, 1), "tokens_per_s": round(M * steps / t, 1),
-            "note": "eager QuantLinear.forward per layer (torch.empty + ctypes + launch), no hipGraph"}
+            "note": "eager calls (torch.empty + ctypes + launch per call), no hipGraph"}
 
 
 def cpu_baseline(M, act_order, budget_s=20.0):
@@ -373,6 +416,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for launcher smoke tests)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--no-fused", action="store_true", help="skip the extra fused-callers measurement (decode, 1 GPU only)")
+    ap.add_argument("--per-layer", action="store_true", help="decode: 224 separate launches per step (no gptq_forward_multi grouping)")
     ap.add_argument("--no-extras", action="store_true", help="decode, 1 GPU: skip the prefill / config5 / eager blocks of the default line")
     args = ap.parse_args()
 
@@ -400,7 +444,9 @@ def main():
     M = args.m or (2048 if prefill else 1)
     act_order = prefill                      # BASELINE config 3: desc_act=True on the prefill path
     n_blocks = args.blocks if not prefill else min(args.blocks, 4)
-    layers, xs = build_stack(device, n_blocks, M, act_order)
+    flat_layers, xs = build_stack(device, n_blocks, M, act_order)
+    # decode: the block's q/k/v and gate/up go through gptq_forward_multi (one launch per group); --per-layer keeps 224 launches
+    layers = flat_layers if (prefill or args.per_layer) else group_stack(flat_layers)
     g, outs = capture(layers, xs, device)
 
     for _ in range(args.warmup):
@@ -411,7 +457,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = t.item()
 
-    bytes_step = sum(algorithmic_bytes(K, N, M, act_order=act_order) for _, K, N, _ in layers)
+    bytes_step = sum(entry_bytes(e, M, act_order) for e in layers)
     flops_step = sum(2 * M * K * N for _, K, N, _ in layers)
     launches = len(layers)
 
@@ -420,11 +466,11 @@ def main():
     if rank == 0:
       try:
         by_type = {}
-        for name, K, N, q in layers:
-            by_type.setdefault((K, N), []).append((name, K, N, q))
+        for ent in layers:
+            by_type.setdefault((ent[0] if isinstance(ent[3], list) else "", ent[1], ent[2]), []).append(ent)
         best = None
         per_type = {}
-        for (K, N), ls in by_type.items():
+        for (gname, K, N), ls in by_type.items():
             gg, oo = capture(ls, xs, device)
             for _ in range(3):
                 gg.replay()
@@ -432,8 +478,9 @@ def main():
             _, evt = time_graph(gg, reps, device)
             per = evt / (reps * len(ls))
             share = per * len(ls)
-            ent = dict(K=K, N=N, per_launch_s=per, share=share, n=len(ls))
-            per_type[f"{K}x{N}"] = round(per * 1e6, 3)
+            ent = dict(K=K, N=N, per_launch_s=per, share=share, n=len(ls), gname=gname, bytes=entry_bytes(ls[0], M, act_order),
+                       kernel=_kernel_of(ls[0], M))
+            per_type[(gname + ":" if gname else "") + f"{K}x{N}"] = round(per * 1e6, 3)
             if best is None or share > best["share"]:
                 best = ent
             del gg, oo
@@ -443,15 +490,15 @@ def main():
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None}
         else:
-            ach = algorithmic_bytes(K, N, M, act_order=act_order) / best["per_launch_s"] / 1e9
+            ach = best["bytes"] / best["per_launch_s"] / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
-        roof["kernel"] = "gptq::gemm_kernel<4, f16, 4, 64>" if prefill else "gptq::gemv_q4_f16_mfma_kernel"
+        roof["kernel"] = "gptq::gemm_kernel<4, f16, 4, 64>" if prefill else best["kernel"]
         roof["traffic"] = pmc_traffic(roof["kernel"], K, N, M)
-        roof["shape"] = f"K={K} N={N} M={M}"
+        roof["shape"] = (f"{best['gname']}: " if best["gname"] else "") + f"K={K} N={N} M={M}" + (" (layers of one gptq_forward_multi launch)" if best["gname"] else "")
         roof["us_per_launch_events"] = round(best["per_launch_s"] * 1e6, 3)
         roof["us_per_launch_by_shape"] = per_type
-        roof["algorithmic_bytes_per_launch"] = algorithmic_bytes(K, N, M, act_order=act_order)
+        roof["algorithmic_bytes_per_launch"] = best["bytes"]
         if prefill and act_order:
             roof["note"] = "per-launch time includes the x column-permute launch of act-order layers (rocprof splits them: profiles/)"
       except Exception as e:
@@ -475,12 +522,13 @@ def main():
             "metric": metric, "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": ("Llama-7B linear shapes (4096->4096 x4, 4096->11008 x2, 11008->4096) x %d blocks, int4 g128 %s, "
-                                    "M=%d rows per step, %d launches/step in one hipGraph" %
-                                    (n_blocks, "desc_act=True" if act_order else "no act-order", M, launches)),
-                       "rows_per_step": M, "layers": launches, "parallelism": f"dp{world}" if world > 1 else "single"},
+            "config": {"workload": ("Llama-7B linear shapes (4096->4096 x4, 4096->11008 x2, 11008->4096) x %d blocks = %d layers, int4 g128 %s, "
+                                    "M=%d rows per step, %d launches/step in one hipGraph%s" %
+                                    (n_blocks, len(flat_layers), "desc_act=True" if act_order else "no act-order", M, launches,
+                                     "" if launches == len(flat_layers) else " (q|k|v and gate|up of a block: one gptq_forward_multi launch each)")),
+                       "rows_per_step": M, "layers": len(flat_layers), "launches": launches, "parallelism": f"dp{world}" if world > 1 else "single"},
             "tokens_per_s": round(M * args.steps * world / wall, 1),
-            "tokens_per_s_note": "linear-only (the %d quantized linears of the stack; no attention/norm)" % launches,
+            "tokens_per_s_note": "linear-only (the %d quantized linears of the stack; no attention/norm)" % len(flat_layers),
             "event_ms_per_step_rank0": round(1e3 * ev / args.steps, 4),
             "algorithmic_bytes_per_step": bytes_step,
             "roofline": roof,
@@ -490,11 +538,21 @@ def main():
         if not prefill and world == 1 and not args.no_extras:
             try:
                 out["eager"] = bench_eager(layers, xs, device, max(3, args.steps // 4))
+                if launches != len(flat_layers):
+                    # the r1 headline for comparison: one launch per layer, same graph / timing protocol
+                    g2, o2 = capture(flat_layers, xs, device)
+                    for _ in range(3):
+                        g2.replay()
+                    _, ev2 = time_graph(g2, args.steps, device)
+                    out["per_layer_launches"] = {"launches_per_step": len(flat_layers), "ms_per_step": round(1e3 * ev2 / args.steps, 4),
+                                                 "GB_per_s": round(bytes_step * args.steps / ev2 / 1e9, 1), "tokens_per_s": round(M * args.steps / ev2, 1)}
+                    del g2, o2
+                    out["eager_per_layer"] = bench_eager(flat_layers, xs, device, max(3, args.steps // 4))
             except Exception as e:
                 out["eager"] = {"error": repr(e)[:300]}
         if not prefill and world == 1 and not args.no_fused:
             try:
-                del g, outs, layers
+                del g, outs, layers, flat_layers
                 torch.cuda.empty_cache()
                 out["fused_callers"] = bench_fused(device, n_blocks, args.steps)
             except Exception as e:

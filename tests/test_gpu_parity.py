@@ -951,7 +951,7 @@ def _stream_tuning(ln, waves, u, ksplit):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("ln,waves,u,ksplit", [(4, 4, 2, 1), (4, 8, 4, 1), (4, 16, 8, 1), (16, 8, 4, 2), (16, 16, 8, 3), (4, 8, 2, 4), (16, 4, 2, 1)])
+@pytest.mark.parametrize("ln,waves,u,ksplit", [(4, 4, 2, 1), (4, 8, 4, 1), (4, 16, 8, 1), (16, 8, 4, 2), (16, 16, 8, 3), (4, 8, 2, 4), (16, 4, 2, 1), (8, 8, 2, 1), (8, 4, 4, 2)])
 @pytest.mark.parametrize("K,N,gs,M", [(1024, 512, 128, 1), (2048, 96, 64, 3), (4096, 1056, 128, 4), (512, 2048, 128, 2)])
 def test_streamed_gemv_vs_oracle(K, N, gs, M, ln, waves, u, ksplit, dtype):
     """gemv_q4_stream_kernel (tuning.path = 6): every launch geometry, incl. ragged last strips (N = 96, 1056 with 64-column

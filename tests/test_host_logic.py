@@ -262,10 +262,15 @@ def test_dispatch_rules_are_the_measured_ones():
     """gptq_describe_plan (host only): the kernel / geometry gptq_forward_ex picks.  These are the crossovers DESIGN.md §4
     reports measurements for -- pinned here so a planner edit that moves one shows up without a GPU."""
     # decode, Llama-7B shapes: matrix-core GEMV, 16-column strips, one launch
-    for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
+    for K, N in ((4096, 4096), (11008, 4096)):
         p = _plan(K, N, 1)
         assert (p["path"], p["kernel"], p["ln"], p["ksplit"], p["waves"]) == ("gemv", "mfma", 4, 1, 16), p
-    assert _plan(4096, 4096, 1)["strips"] == 256 and _plan(4096, 11008, 1)["strips"] == 688
+    assert _plan(4096, 4096, 1)["strips"] == 256
+    # 4096 x 11008: the streamed (LDS-DMA) kernel with 64-column strips, one pass of 16 waves x 8 rows (8.2 vs 9.6 us); M = 1..2 only
+    p = _plan(4096, 11008, 1)
+    assert (p["kernel"], p["ln"], p["waves"], p["u"], p["ksplit"], p["strips"]) == ("stream", 16, 16, 8, 1, 172), p
+    assert _plan(4096, 11008, 3)["kernel"] == "mfma" and _plan(4096, 11008, 3)["strips"] == 688
+    assert _plan(4096, 11008, 1, dtype=1)["kernel"] == "stream"
     # wider plain fp16 layers: 64- / 32-column strips with >= 160 workgroups; bf16 and act-order stay at 16 columns
     assert _plan(4096, 12288, 1)["ln"] == 16 and _plan(5120, 13824, 1)["ln"] == 16 and _plan(8192, 28672, 1)["ln"] == 16
     assert _plan(8192, 8192, 1)["ln"] == 8 and _plan(3584, 8192, 1)["ln"] == 8
