@@ -420,7 +420,7 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
                  sp.u, sp.ksplit, sp.mt, sp.strips_total);
     } else if (want_gemm(&Lc, M, tune)) {
         const GemmPlan g = plan_gemm(Lc, M, tune);
-        const char* kern = g.strip16 ? "strip16" : (g.skinny ? "skinny64" : (g.tall ? "tiled256x128" : "tiled"));
+        const char* kern = g.strip16 ? "strip16" : (g.skinny ? "skinny64" : "tiled");
         snprintf(out, out_bytes, "path=gemm kernel=%s mt=%d bk=%d kg=%d ksplit=%d tiles=%dx%d perm=%d dma=%d epilogue=%s", kern, g.mt, g.bk,
                  g.kg == 2 ? 2 : 1, g.ksplit, g.nbm, g.nbn, g.use_seq ? 1 : 0, g.glds ? 1 : 0, unfused_epilogue ? "separate" : "none");
     } else {

@@ -79,28 +79,25 @@ __device__ __forceinline__ unsigned short t_bits(bf16 v) { return __builtin_bit_
 // column, N apart).  NW = words it has to fetch (per column) to cover 8*BITS bits from B0.
 template <int BITS> struct BWords { static constexpr int n = (BITS == 3 || BITS == 8) ? 2 : 1; };
 
-template <int BITS, int NT = 2>
-struct BRaw {                       // raw words of the lane's NT adjacent columns for one k16 step
-    unsigned w[BWords<BITS>::n][NT];
+template <int BITS>
+struct BRaw {                       // raw words of the lane's 2 columns for one k16 step
+    u32x2 w[BWords<BITS>::n];
 };
-template <int BITS, int NT>
-__device__ __forceinline__ void set_words(BRaw<BITS, NT>& r, int i, u32x2 v) { r.w[i][0] = v[0]; if constexpr (NT == 2) r.w[i][1] = v[1]; }
 
-template <int BITS, int NT>
-__device__ __forceinline__ void load_braw(BRaw<BITS, NT>& r, const unsigned* __restrict__ qcol, int N, int qrows, int k) {
+template <int BITS>
+__device__ __forceinline__ void load_braw(BRaw<BITS>& r, const unsigned* __restrict__ qcol, int N, int qrows, int k) {
     const unsigned bit = (unsigned)k * BITS;
     const int wi = (int)(bit >> 5);
 #pragma unroll
     for (int i = 0; i < BWords<BITS>::n; ++i) {
         const int row = min(wi + i, qrows - 1);     // the clamp only ever triggers for a word that is not used
-        if constexpr (NT == 2) set_words(r, i, *(const u32x2*)(qcol + (size_t)row * N));
-        else r.w[i][0] = qcol[(size_t)row * N];
+        r.w[i] = *(const u32x2*)(qcol + (size_t)row * N);
     }
 }
 
 // 64-bit window of column c holding the lane's 8 fields starting at bit 0
-template <int BITS, int NT>
-__device__ __forceinline__ unsigned long long window(const BRaw<BITS, NT>& r, int c, int k) {
+template <int BITS>
+__device__ __forceinline__ unsigned long long window(const BRaw<BITS>& r, int c, int k) {
     const unsigned sh = ((unsigned)k * BITS) & 31u;
     unsigned long long v = r.w[0][c];
     if constexpr (BWords<BITS>::n == 2) v |= (unsigned long long)r.w[1][c] << 32;
@@ -143,10 +140,9 @@ template <int BITS, typename T> struct Deq {
             z[col] = zero_point<BITS>(c, col, zero_mode);
         }
     }
-    template <int NT>
-    __device__ __forceinline__ u32x4 frag(const BRaw<BITS, NT>& r, int col, int k) const {
+    __device__ __forceinline__ u32x4 frag(const BRaw<BITS>& r, int col, int k) const {
         constexpr unsigned maxq = (1u << BITS) - 1u;
-        const unsigned long long v = window<BITS, NT>(r, col, k);
+        const unsigned long long v = window<BITS>(r, col, k);
         unsigned short e[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -173,8 +169,7 @@ template <> struct Deq<4, f16> {
             c2[col] = c1[col] + k960;                                        // -(64 + z), exact
         }
     }
-    template <int NT>
-    __device__ __forceinline__ u32x4 frag(const BRaw<4, NT>& r, int col, int) const {
+    __device__ __forceinline__ u32x4 frag(const BRaw<4>& r, int col, int) const {
         const unsigned q = r.w[0][col], q8 = q >> 8;
         const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
         const f16x2 h0 = as_f16x2(and_or(q, 0x000f000fu, 0x64006400u)) + c1[col];          // k0,k4 : w - z
@@ -216,8 +211,7 @@ template <> struct Deq<4, bf16> {
         const bf16x2 v = {(bf16)lo, (bf16)hi};
         return __builtin_bit_cast(unsigned, v);
     }
-    template <int NT>
-    __device__ __forceinline__ u32x4 frag(const BRaw<4, NT>& r, int col, int) const {
+    __device__ __forceinline__ u32x4 frag(const BRaw<4>& r, int col, int) const {
         const unsigned q = r.w[0][col], q8 = q >> 8;
         const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
         const f16x2 h0 = as_f16x2(and_or(q, 0x000f000fu, 0x64006400u)) + c1[col];
@@ -249,12 +243,8 @@ template <> struct Deq<4, bf16> {
 // block's K range with their own x buffers, and the two halves are summed through LDS at the end.  Used when the launch
 // has at most one 128x256 tile per CU: a CU then holds two waves per SIMD (what two co-resident workgroups would give a
 // larger problem), so one wave's dequant/LDS work fills the other's MFMA shadows, at the same weight/x traffic per flop.
-// NT = adjacent columns per lane (2: one 8-byte load per packed row, wave = 64 columns, workgroup = 256 columns; 1: wave = 32
-// columns, workgroup = 128 columns).  MT = 8 with NT = 1 is the 256 x 128 tile: every dequantised word feeds EIGHT row tiles
-// instead of four (half the dequant VALU per MFMA), the same 128 accumulator registers per wave, and a Llama-7B layer at
-// M = 2048 still yields >= 256 workgroups.
-template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, bool GLDS = false, int KG = 1, int NT = 2>
-__global__ void __launch_bounds__(256 * KG, (MT * NT > 8) ? 1 : 2 / KG) gemm_kernel(GemmParams p) {
+template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, bool GLDS = false, int KG = 1>
+__global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
     constexpr int KS = BK / 16;                // MFMA k-steps per K-step
     constexpr int BM = 32 * MT;
     static_assert(!GLDS || (XPRE && BK == 64), "the DMA staging needs pre-slotted x and 128-byte rows");
@@ -263,9 +253,7 @@ __global__ void __launch_bounds__(256 * KG, (MT * NT > 8) ? 1 : 2 / KG) gemm_ker
     constexpr int CHUNKS = BM * CPR;
     constexpr int NTHR = 256;
     constexpr int NCH = (CHUNKS + NTHR - 1) / NTHR;
-    static_assert(KG == 1 || (KG == 2 && MT * NT == 8), "K groups: 1, or 2 with 128 accumulator registers per wave");
-    static_assert(NT == 1 || NT == 2, "columns per lane");
-    constexpr int WN = 32 * NT, BN = 4 * WN;   // columns per wave / per workgroup
+    static_assert(KG == 1 || (KG == 2 && MT == 4), "K groups: 1, or 2 with the 128-row tile");
     extern __shared__ __attribute__((aligned(16))) char smem_all[];   // KG x 2 x BM x STRIDE
     const int kg = KG == 1 ? 0 : (int)(threadIdx.x >> 8);
     char* const smem = smem_all + (size_t)kg * (2 * BM * STRIDE);
@@ -290,7 +278,7 @@ __global__ void __launch_bounds__(256 * KG, (MT * NT > 8) ? 1 : 2 / KG) gemm_ker
         }
     }
     const int m0 = bm * BM;
-    const int n = bn * BN + wave * WN + NT * l31;      // this lane's first column (NT = 2: second is n + 1)
+    const int n = bn * 256 + wave * 64 + 2 * l31;      // this lane's first column (second is n + 1)
     const bool col_ok = n < p.N;
     const int nl = col_ok ? n : 0;
     const unsigned* __restrict__ qcol = p.qweight + nl;
@@ -360,41 +348,37 @@ __global__ void __launch_bounds__(256 * KG, (MT * NT > 8) ? 1 : 2 / KG) gemm_ker
     // Addresses are split into a wave-uniform part (K-step / k-step: scalar ALU) and a loop-invariant 32-bit per-lane byte
     // offset, so a load costs no vector address arithmetic inside the K loop (global_load with an SGPR base).
     const unsigned b_lane_off = ((unsigned)nl + (unsigned)half * (BITS == 8 ? 2u : 1u) * (unsigned)p.N) * 4u;
-    using BR = BRaw<BITS, NT>;
     const unsigned s_lane_off = (unsigned)nl * 2u;
     const unsigned z_lane_off = (((unsigned)nl * BITS) >> 5) * 4u, z_lane_sh = ((unsigned)nl * BITS) & 31u;
-    auto load_b = [&](int kt, BR (&b)[KS]) {
+    auto load_b = [&](int kt, BRaw<BITS> (&b)[KS]) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if constexpr (BITS == 4 || BITS == 8) {
                 constexpr int WPH = (BITS == 8) ? 2 : 1;                       // words per 8 k
                 const size_t row_u = (size_t)(kt * (BK / 8) + ks * 2) * WPH;      // uniform packed row of lane-half 0
 #pragma unroll
-                for (int i = 0; i < WPH; ++i) {
-                    if constexpr (NT == 2) set_words(b[ks], i, __builtin_amdgcn_raw_buffer_load_b64(rsrc_q, b_lane_off, (unsigned)((row_u + i) * (size_t)p.N * 4), 0));
-                    else b[ks].w[i][0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_q, b_lane_off, (unsigned)((row_u + i) * (size_t)p.N * 4), 0);
-                }
+                for (int i = 0; i < WPH; ++i)
+                    b[ks].w[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_q, b_lane_off, (unsigned)((row_u + i) * (size_t)p.N * 4), 0);
             } else {
-                load_braw<BITS, NT>(b[ks], qcol, p.N, p.qrows, kt * BK + ks * 16 + half * 8);
+                load_braw<BITS>(b[ks], qcol, p.N, p.qrows, kt * BK + ks * 16 + half * 8);
             }
         }
     };
     auto load_c = [&](int kt, CRaw& c) {
         const int g = (int)(((unsigned long long)(unsigned)kt * p.kpg_inv) >> 32);
         if constexpr (BITS != 3) {
-            if constexpr (NT == 2) c.s = __builtin_amdgcn_raw_buffer_load_b32(rsrc_s, s_lane_off, (unsigned)g * (unsigned)p.N * 2u, 0);
-            else c.s = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsrc_s, s_lane_off, (unsigned)g * (unsigned)p.N * 2u, 0);
+            c.s = __builtin_amdgcn_raw_buffer_load_b32(rsrc_s, s_lane_off, (unsigned)g * (unsigned)p.N * 2u, 0);
             c.z = (unsigned long long)(__builtin_amdgcn_raw_buffer_load_b32(rsrc_z, z_lane_off, (unsigned)(g * zrow_bytes), 0) >> z_lane_sh);
         } else {
             load_craw<BITS>(c, p.scales, p.qzeros, g, p.N, nl);
         }
     };
 
-    f32x16 acc[MT][NT];
+    f32x16 acc[MT][2];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
@@ -402,7 +386,7 @@ __global__ void __launch_bounds__(256 * KG, (MT * NT > 8) ? 1 : 2 / KG) gemm_ker
     // nothing is copied and every LDS offset is an immediate.  Inside a step the A fragments of MFMA k-step
     // ks+1 are read from LDS before the MFMAs of ks are issued (their latency hides behind 8 MFMAs).
     u32x4 a_next[NCH];
-    BR b0[KS], b1[KS];
+    BRaw<BITS> b0[KS], b1[KS];
     CRaw c0, c1;
     if constexpr (GLDS) dma_a(kt0, 0); else load_a(kt0, a_next);
     load_b(kt0, b0);
@@ -413,7 +397,7 @@ __global__ void __launch_bounds__(256 * KG, (MT * NT > 8) ? 1 : 2 / KG) gemm_ker
     const int a_lane_off = GLDS ? l31 * STRIDE : l31 * STRIDE + half * 16;
     const int a_swz = (l31 >> 1) & 7;                  // GLDS: XOR applied to the 16-byte slot index
     // VAR == 3: fragments of the NEXT K-step's first MFMA k-step, produced under the last MFMAs of the current K-step
-    u32x4 a_first[MT], bq_first[NT];
+    u32x4 a_first[MT], bq_first[2];
     Deq<BITS, T> dq_cur;
     auto read_a = [&](int buf, int ks, u32x4 (&dst)[MT]) {
         const char* base = smem + buf * (BM * STRIDE) + a_lane_off;
@@ -425,9 +409,9 @@ __global__ void __launch_bounds__(256 * KG, (MT * NT > 8) ? 1 : 2 / KG) gemm_ker
         dq_cur.setup(c0, p.zero_mode);
         read_a(0, 0, a_first);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bq_first[nt] = dq_cur.frag(b0[0], nt, kt0 * BK + half * 8);
+        for (int nt = 0; nt < 2; ++nt) bq_first[nt] = dq_cur.frag(b0[0], nt, kt0 * BK + half * 8);
     }
-    auto step = [&](int kt, auto bufc, const BR (&b_use)[KS], const CRaw& c_use, BR (&b_fill)[KS], CRaw& c_fill) {
+    auto step = [&](int kt, auto bufc, const BRaw<BITS> (&b_use)[KS], const CRaw& c_use, BRaw<BITS> (&b_fill)[KS], CRaw& c_fill) {
         constexpr int BUF = decltype(bufc)::value;
         const int ktn = min(kt + 1, kt1 - 1);          // last step re-loads itself (no branch in the pipeline)
         if constexpr (GLDS) dma_a(ktn, BUF ^ 1);
@@ -441,11 +425,11 @@ __global__ void __launch_bounds__(256 * KG, (MT * NT > 8) ? 1 : 2 / KG) gemm_ker
             // step (its operands are already in registers), and right behind it the first A fragments of the next step
             // are read and its first B fragments dequantised -- so the 8 MFMAs of that group cover the barrier wait, the
             // LDS latency and the dequant, and a K-step starts with its MFMAs instead of a fragment-production bubble.
-            u32x4 a[2][MT], bq[2][NT];
+            u32x4 a[2][MT], bq[2][2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[0][mt] = a_first[mt];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bq[0][nt] = bq_first[nt];
+            bq[0][0] = bq_first[0];
+            bq[0][1] = bq_first[1];
             Deq<BITS, T> dq_nx;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -459,16 +443,16 @@ __global__ void __launch_bounds__(256 * KG, (MT * NT > 8) ? 1 : 2 / KG) gemm_ker
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks + 1 < KS) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bq[(ks + 1) & 1][nt] = dq_cur.frag(b_use[ks + 1], nt, kt * BK + (ks + 1) * 16 + half * 8);
+                    for (int nt = 0; nt < 2; ++nt) bq[(ks + 1) & 1][nt] = dq_cur.frag(b_use[ks + 1], nt, kt * BK + (ks + 1) * 16 + half * 8);
                 } else {
                     dq_nx.setup(c_fill, p.zero_mode);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bq_first[nt] = dq_nx.frag(b_fill[0], nt, ktn * BK + half * 8);
+                    for (int nt = 0; nt < 2; ++nt) bq_first[nt] = dq_nx.frag(b_fill[0], nt, ktn * BK + half * 8);
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Mma<T>::run(a[ks & 1][mt], bq[ks & 1][nt], acc[mt][nt]);
+                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = Mma<T>::run(a[ks & 1][mt], bq[ks & 1][nt], acc[mt][nt]);
             }
             dq_cur = dq_nx;
             return;
@@ -479,52 +463,18 @@ __global__ void __launch_bounds__(256 * KG, (MT * NT > 8) ? 1 : 2 / KG) gemm_ker
         if constexpr (VAR == 1 || VAR >= 8) {
             // (VAR >= 8: timing ablations of this schedule -- bit 0 skips the dequant math, bit 1 the x staging,
             //  bit 2 the barrier; their results are wrong by construction and only tools/gemmlab selects them)
-            auto frag = [&](const BR& r, int col, int k) -> u32x4 {
+            auto frag = [&](const BRaw<BITS>& r, int col, int k) -> u32x4 {
                 if constexpr (VAR >= 8 && (VAR & 1)) { const unsigned q = r.w[0][col]; return u32x4{q, q ^ 0x11111111u, q ^ 0x22222222u, q ^ 0x44444444u}; }
                 else return dq.frag(r, col, k);
             };
             // explicit software pipeline over the KS MFMA k-steps: the fragments of ks+1 (A from LDS, B dequantised in
             // registers) are produced while the 2*MT MFMAs of ks run; sched_barrier pins the LDS reads at the top of
             // each region (hipcc otherwise sinks them right in front of their first use and exposes the LDS latency)
-            if constexpr (MT == 8) {
-                // 8 row tiles: the A fragments are pipelined in halves (rows 0-127 / 128-255) so that only 8 of them are live
-                // at a time -- while the MFMAs of one half run, the other half's fragments (and the next k-step's B) are fetched
-                constexpr int H = MT / 2;
-                auto a_off_ks = [&](int ks) { return GLDS ? (((ks * 2 + half) ^ a_swz) * 16) : ks * 32; };
-                u32x4 aL[H], aH[H], bq[2][NT];
-#pragma unroll
-                for (int mt = 0; mt < H; ++mt) aL[mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + a_off_ks(0));
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bq[0][nt] = frag(b_use[0], nt, kt * BK + half * 8);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-                    for (int mt = 0; mt < H; ++mt) aH[mt] = *(const u32x4*)(abase + (H + mt) * 32 * STRIDE + a_off_ks(ks));
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (ks + 1 < KS) {
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) bq[(ks + 1) & 1][nt] = frag(b_use[ks + 1], nt, kt * BK + (ks + 1) * 16 + half * 8);
-                    }
-#pragma unroll
-                    for (int mt = 0; mt < H; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Mma<T>::run(aL[mt], bq[ks & 1][nt], acc[mt][nt]);
-                    if (ks + 1 < KS) {
-#pragma unroll
-                        for (int mt = 0; mt < H; ++mt) aL[mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + a_off_ks(ks + 1));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int mt = 0; mt < H; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[H + mt][nt] = Mma<T>::run(aH[mt], bq[ks & 1][nt], acc[H + mt][nt]);
-                }
-            } else {
-            u32x4 a[2][MT], bq[2][NT];
+            u32x4 a[2][MT], bq[2][2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[0][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (GLDS ? ((half ^ a_swz) * 16) : 0));
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bq[0][nt] = frag(b_use[0], nt, kt * BK + half * 8);
+            for (int nt = 0; nt < 2; ++nt) bq[0][nt] = frag(b_use[0], nt, kt * BK + half * 8);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + 1 < KS) {
@@ -535,28 +485,27 @@ __global__ void __launch_bounds__(256 * KG, (MT * NT > 8) ? 1 : 2 / KG) gemm_ker
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks + 1 < KS) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bq[(ks + 1) & 1][nt] = frag(b_use[ks + 1], nt, kt * BK + (ks + 1) * 16 + half * 8);
+                    for (int nt = 0; nt < 2; ++nt) bq[(ks + 1) & 1][nt] = frag(b_use[ks + 1], nt, kt * BK + (ks + 1) * 16 + half * 8);
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Mma<T>::run(a[ks & 1][mt], bq[ks & 1][nt], acc[mt][nt]);
-            }
+                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = Mma<T>::run(a[ks & 1][mt], bq[ks & 1][nt], acc[mt][nt]);
             }
         } else {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                u32x4 a[MT], b[NT];
+                u32x4 a[MT], b[2];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) a[mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (GLDS ? (((ks * 2 + half) ^ a_swz) * 16) : ks * 32));
                 const int k = kt * BK + ks * 16 + half * 8;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) b[nt] = dq.frag(b_use[ks], nt, k);
+                for (int nt = 0; nt < 2; ++nt) b[nt] = dq.frag(b_use[ks], nt, k);
                 if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Mma<T>::run(a[mt], b[nt], acc[mt][nt]);
+                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = Mma<T>::run(a[mt], b[nt], acc[mt][nt]);
                 if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(0);
             }
         }
@@ -572,30 +521,29 @@ __global__ void __launch_bounds__(256 * KG, (MT * NT > 8) ? 1 : 2 / KG) gemm_ker
         // sum the two K halves through LDS (the x buffers are dead after the last barrier): group 1 hands rows 0-63 to
         // group 0, then group 0 hands rows 64-127 to group 1; each group stores the half it completed.
         float4* ex = (float4*)smem_all;        // [(mt, nt, quad)][256 threads] float4: lane-contiguous, conflict free
-        constexpr int MH = MT / 2;             // row tiles each group hands over / completes
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             if (kg != pass) {
 #pragma unroll
-                for (int mt = 0; mt < MH; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
+                    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const f32x16& a = acc[pass * MH + mt][nt];
-                            ex[((mt * NT + nt) * 4 + q) * 256 + tid] = float4{a[q * 4], a[q * 4 + 1], a[q * 4 + 2], a[q * 4 + 3]};
+                            const f32x16& a = acc[pass * 2 + mt][nt];
+                            ex[((mt * 2 + nt) * 4 + q) * 256 + tid] = float4{a[q * 4], a[q * 4 + 1], a[q * 4 + 2], a[q * 4 + 3]};
                         }
             }
             __syncthreads();
             if (kg == pass) {
 #pragma unroll
-                for (int mt = 0; mt < MH; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
+                    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float4 v = ex[((mt * NT + nt) * 4 + q) * 256 + tid];
-                            f32x16& a = acc[pass * MH + mt][nt];
+                            const float4 v = ex[((mt * 2 + nt) * 4 + q) * 256 + tid];
+                            f32x16& a = acc[pass * 2 + mt][nt];
                             a[q * 4] += v.x; a[q * 4 + 1] += v.y; a[q * 4 + 2] += v.z; a[q * 4 + 3] += v.w;
                         }
             }
@@ -608,29 +556,23 @@ __global__ void __launch_bounds__(256 * KG, (MT * NT > 8) ? 1 : 2 / KG) gemm_ker
     float bias0 = 0.f, bias1 = 0.f;
     if (p.bias && p.ksplit == 1) {
         bias0 = DType<T>::to_f32(((const T*)p.bias)[n]);
-        if constexpr (NT == 2) bias1 = DType<T>::to_f32(((const T*)p.bias)[n + 1]);
+        bias1 = DType<T>::to_f32(((const T*)p.bias)[n + 1]);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        if (KG == 2 && (mt / (MT / 2)) != kg) continue;
+        if (KG == 2 && (mt >> 1) != kg) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (m >= p.M) continue;
-            if constexpr (NT == 2) {
-                const float v0 = acc[mt][0][r], v1 = acc[mt][1][r];
-                if (p.ksplit > 1) {
-                    float2 o = {v0, v1};
-                    *(float2*)(p.partial + ((size_t)blockIdx.y * p.M + m) * p.N + n) = o;
-                } else {
-                    const unsigned o = (unsigned)t_bits(DType<T>::from_f32(v0 + bias0)) |
-                                       ((unsigned)t_bits(DType<T>::from_f32(v1 + bias1)) << 16);
-                    *(unsigned*)((unsigned short*)p.out + (size_t)m * p.N + n) = o;
-                }
+            const float v0 = acc[mt][0][r], v1 = acc[mt][1][r];
+            if (p.ksplit > 1) {
+                float2 o = {v0, v1};
+                *(float2*)(p.partial + ((size_t)blockIdx.y * p.M + m) * p.N + n) = o;
             } else {
-                const float v0 = acc[mt][0][r];
-                if (p.ksplit > 1) p.partial[((size_t)blockIdx.y * p.M + m) * p.N + n] = v0;
-                else ((unsigned short*)p.out)[(size_t)m * p.N + n] = t_bits(DType<T>::from_f32(v0 + bias0));
+                const unsigned o = (unsigned)t_bits(DType<T>::from_f32(v0 + bias0)) |
+                                   ((unsigned)t_bits(DType<T>::from_f32(v1 + bias1)) << 16);
+                *(unsigned*)((unsigned short*)p.out + (size_t)m * p.N + n) = o;
             }
         }
     }
@@ -686,7 +628,7 @@ __global__ void __launch_bounds__(512) gemm_skinny_kernel(GemmParams p) {
             for (int mt = 0; mt < MT; ++mt) a[j][mt] = *(const u32x4*)(a_src[mt] + (size_t)sj * 16);
         }
 #pragma unroll
-        for (int j = 0; j < UNR; ++j) load_braw<BITS, 2>(braw[j], qcol, p.N, p.qrows, min(s0 + j, we - 1) * 16 + half * 8);
+        for (int j = 0; j < UNR; ++j) load_braw<BITS>(braw[j], qcol, p.N, p.qrows, min(s0 + j, we - 1) * 16 + half * 8);
         Deq<BITS, T> dq;
         dq.setup(craw, p.zero_mode);
 #pragma unroll
@@ -968,9 +910,9 @@ hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int 
 template <int BITS, typename T, int MT, int BK, int VAR, bool XPRE, bool GLDS, int KG>
 static constexpr size_t gemm_lds_bytes() { return (size_t)KG * 2 * (32 * MT) * (GLDS ? BK * 2 : BK * 2 + 16); }
 
-template <int BITS, typename T, int MT, int BK, int VAR, bool XPRE, bool GLDS, int KG, int NT = 2>
+template <int BITS, typename T, int MT, int BK, int VAR, bool XPRE, bool GLDS, int KG>
 static hipError_t grant_lds() {
-    return hipFuncSetAttribute((const void*)gemm_kernel<BITS, T, MT, BK, VAR, XPRE, GLDS, KG, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    return hipFuncSetAttribute((const void*)gemm_kernel<BITS, T, MT, BK, VAR, XPRE, GLDS, KG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)gemm_lds_bytes<BITS, T, MT, BK, VAR, XPRE, GLDS, KG>());
 }
 
@@ -979,23 +921,10 @@ hipError_t init_gemm_device() {
     hipError_t e = grant_lds<4, f16, 4, 64, 1, true, true, 2>();
     if (e == hipSuccess) e = grant_lds<4, f16, 4, 64, 1, false, false, 2>();
     if (e == hipSuccess) e = grant_lds<4, bf16, 4, 64, 1, false, false, 2>();
-    // 256 x 128 tiles: 64 - 147 KiB of x staging
-    if (e == hipSuccess) e = grant_lds<4, f16, 8, 64, 1, true, true, 2, 1>();
-    if (e == hipSuccess) e = grant_lds<4, f16, 8, 64, 1, false, false, 2, 1>();
-    if (e == hipSuccess) e = grant_lds<4, bf16, 8, 64, 1, false, false, 2, 1>();
-    if (e == hipSuccess) e = grant_lds<4, f16, 8, 64, 1, true, true, 1, 1>();
-    if (e == hipSuccess) e = grant_lds<4, f16, 8, 64, 1, false, false, 1, 1>();
-    if (e == hipSuccess) e = grant_lds<4, bf16, 8, 64, 1, false, false, 1, 1>();
     return e;
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-// 256 x 128 tiles: experiment knob tuning.reserved[3] = 8 (with K groups) / 9 (without) until the measured rule is in place
-static bool tall_preferred(const gptq_layer_t& L, int M, int variant) {
-    if (variant == 8 || variant == 9) return M >= 256;
-    return false;
-}
 
 GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     GemmPlan pl{};
@@ -1066,13 +995,10 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.bk = (L.bits == 4 && pl.mt == 4 && L.K % 64 == 0 && L.group_size % 64 == 0) ? 64 : 32;
     if (tune && tune->reserved[1] == 32) pl.bk = 32;
     pl.variant = tune ? tune->reserved[3] : 0;            // experiment knob: inner-loop schedule variant      // experiment knob: force the 32-deep K-step
-    // 256 x 128 tiles (8 row tiles x 1 column per lane): half the dequant work per MFMA; 4-bit, 64-deep K-steps, M >= 256
-    pl.tall = L.bits == 4 && pl.bk == 64 && pl.mt == 4 && tall_preferred(L, M, pl.variant);
-    if (pl.tall) pl.mt = 8;
     pl.bm = 32 * pl.mt;
-    pl.bn = pl.tall ? 128 : 256;
+    pl.bn = 256;
     pl.nbm = (M + pl.bm - 1) / pl.bm;
-    pl.nbn = (L.N + pl.bn - 1) / pl.bn;
+    pl.nbn = (L.N + 255) / 256;
     pl.ksteps_total = L.K / pl.bk;
     int ks = (tune && tune->ksplit > 0 && tune->path == 3) ? tune->ksplit : 0;
     if (!ks) {
@@ -1085,20 +1011,20 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.ksplit = (pl.ksteps_total + pl.ksteps_per_split - 1) / pl.ksteps_per_split;   // no empty slices
     pl.workspace_bytes = pl.xperm_bytes + (pl.ksplit > 1 ? (size_t)pl.ksplit * M * L.N * sizeof(float) : 0);
     // act-order + the 4-bit fp16 128x256x64 kernel: the permute pre-pass delivers x in k-slot order
-    pl.xslot = pl.use_seq && L.bits == 4 && L.dtype == GPTQ_F16 && pl.mt >= 4 && pl.bk == 64 && (pl.variant == 0 || pl.variant == 3 || pl.variant == 5 || pl.variant == 6 || pl.variant == 7 || pl.tall);
+    pl.xslot = pl.use_seq && L.bits == 4 && L.dtype == GPTQ_F16 && pl.mt == 4 && pl.bk == 64 && (pl.variant == 0 || pl.variant == 3 || pl.variant == 5 || pl.variant == 6 || pl.variant == 7);
     pl.glds = pl.xslot && pl.variant != 5;            // variant 5 (experiment): register-staged x
     // At most one tile per CU: run the tile's K range as two concurrent halves inside the workgroup (8 waves).
     const bool even_slices = pl.ksteps_total % pl.ksteps_per_split == 0 && pl.ksteps_per_split % 2 == 0 && pl.ksteps_per_split >= 4;
-    const bool kg_ok = L.bits == 4 && pl.bk == 64 && pl.mt >= 4 && even_slices && (pl.variant == 0 || pl.variant == 6 || pl.variant == 7 || pl.tall) &&
+    const bool kg_ok = L.bits == 4 && pl.bk == 64 && pl.mt == 4 && even_slices && (pl.variant == 0 || pl.variant == 6 || pl.variant == 7) &&
                        (!pl.use_seq || pl.xslot == pl.glds);
-    pl.kg = (kg_ok && pl.variant != 6 && pl.variant != 9 && ((long)pl.nbm * pl.nbn * pl.ksplit <= 256 || pl.variant == 7)) ? 2 : 1;
+    pl.kg = (kg_ok && pl.variant != 6 && ((long)pl.nbm * pl.nbn * pl.ksplit <= 256 || pl.variant == 7)) ? 2 : 1;
     return pl;
 }
 
-template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, bool GLDS = false, int KG = 1, int NT = 2>
+template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, bool GLDS = false, int KG = 1>
 static hipError_t launch_one(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
     const size_t lds = (size_t)KG * 2 * (32 * MT) * (GLDS ? BK * 2 : BK * 2 + 16);   // KG = 2: >= the 64 KiB exchange area
-    auto* kern = gemm_kernel<BITS, T, MT, BK, VAR, XPRE, GLDS, KG, NT>;
+    auto* kern = gemm_kernel<BITS, T, MT, BK, VAR, XPRE, GLDS, KG>;
     // KG = 2 asks for > 64 KiB of dynamic LDS: granted per function and device by init_gemm_device() (gptq_init), never here --
     // the launch path makes no runtime-API call besides the launch itself, so it is legal under stream capture.
     hipLaunchKernelGGL(kern, dim3(pl.nbm * pl.nbn, pl.ksplit), dim3(256 * KG), lds, st, p);
@@ -1147,18 +1073,6 @@ static hipError_t launch_bits(const GemmPlan& pl, const GemmParams& p, hipStream
     }
     if (pl.skinny) return launch_skinny<BITS, T>(pl, p, st);
     if constexpr (BITS == 4) {
-        if (pl.tall) {                      // 256 x 128 tiles
-            if (pl.kg == 2) {
-                if constexpr (std::is_same_v<T, f16>) {
-                    if (pl.xslot && pl.glds) return launch_one<BITS, T, 8, 64, 1, true, true, 2, 1>(pl, p, st);
-                }
-                return launch_one<BITS, T, 8, 64, 1, false, false, 2, 1>(pl, p, st);
-            }
-            if constexpr (std::is_same_v<T, f16>) {
-                if (pl.xslot && pl.glds) return launch_one<BITS, T, 8, 64, 1, true, true, 1, 1>(pl, p, st);
-            }
-            return launch_one<BITS, T, 8, 64, 1, false, false, 1, 1>(pl, p, st);
-        }
         if (pl.bk == 64) {
             if (pl.kg == 2) {
                 if constexpr (std::is_same_v<T, f16>) {

@@ -1016,38 +1016,3 @@ def test_forward_multi_equals_layer_by_layer(M, act):
     torch.cuda.synchronize()
     for a, b in zip(eager, cap):
         assert torch.equal(a, b)
-
-
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("act", [False, True])
-@pytest.mark.parametrize("variant", [8, 9])
-@pytest.mark.parametrize("K,N,M", [(1024, 512, 300), (2048, 384, 1000), (4096, 4096, 2048)])
-def test_gemm_256x128_tiles(K, N, M, variant, act, dtype):
-    """The 256 x 128 tile form of the MFMA GEMM (8 row tiles per wave, one column per lane; tuning.reserved[3] = 8 with the
-    two-K-group workgroup where a launch has <= 256 tiles, 9 without): fp64 oracle on a row sample, one-hot rows return the
-    exact dequantised weight rows, bit-reproducible; ragged M (300, 1000) and N (384 = 3 column tiles) included."""
-    L = O.random_quant_layer(K, N, 4, 128, act_order=act, seed=K + N + M + variant, bias=True, dtype=dtype)
-    gen = torch.Generator().manual_seed(7)
-    x = (torch.rand(M, K, generator=gen) - 0.5).to(dtype)
-    hot = [0, K - 1, 128, 77]
-    for r, k in enumerate(hot):
-        x[r].zero_()
-        x[r, k] = 1.0
-    x = x.to(DEV)
-    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"] if act else None, None, 4, 128)
-    t = _tuning(path=3)
-    t.reserved[3] = variant
-    q.post_init()
-    d = _lib.describe_plan(q._layer, M, t)
-    assert d["kernel"] == "tiled256x128" and d["mt"] == 8, d
-    with torch.no_grad():
-        y = q(x, tuning=t)
-        yb = q(x, tuning=t)
-        W = q.dequantize()
-    assert torch.equal(y, yb)
-    for r, k in enumerate(hot):
-        assert torch.equal(y[r], W[k]), (r, k)
-    rows = torch.arange(0, M, max(1, M // 53))
-    mode = O.reference_zero_mode(act, 4)
-    y64 = O.forward_f64(x[rows].cpu(), L["qweight"], L["qzeros"], L["scales"], L["g_idx"] if act else None, None, 4, mode)
-    _assert_close(y[rows], y64, y64, dtype, K, f"256x128 tiles variant {variant}")
