@@ -202,7 +202,7 @@ int gptq_gemm(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, 
     GemmPlan pl = plan_gemm(*L, M, tune);
     if (!pl.supported)
         return fail(GPTQ_ERR_UNSUPPORTED,
-                    "MFMA GEMM needs fp16/bf16, sequential or re-sequenced groups and group_size %% 32 == 0 (bits=%d dtype=%d group_size=%d)",
+                    "MFMA GEMM needs sequential or re-sequenced groups made of whole packing units (fp16/bf16: group_size %% 32 == 0) (bits=%d dtype=%d group_size=%d)",
                     L->bits, L->dtype, L->group_size);
     const WsView wv = split_ws(ws, ws_bytes);
     if (pl.workspace_bytes > 0 && wv.body_bytes < pl.workspace_bytes)
@@ -420,7 +420,7 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
                  sp.u, sp.ksplit, sp.mt, sp.strips_total);
     } else if (want_gemm(&Lc, M, tune)) {
         const GemmPlan g = plan_gemm(Lc, M, tune);
-        const char* kern = g.strip16 ? "strip16" : (g.skinny ? "skinny64" : "tiled");
+        const char* kern = g.f32 ? "f32_mfma" : (g.strip16 ? "strip16" : (g.skinny ? "skinny64" : "tiled"));
         snprintf(out, out_bytes, "path=gemm kernel=%s mt=%d bk=%d kg=%d ksplit=%d tiles=%dx%d perm=%d dma=%d epilogue=%s", kern, g.mt, g.bk,
                  g.kg == 2 ? 2 : 1, g.ksplit, g.nbm, g.nbn, g.use_seq ? 1 : 0, g.glds ? 1 : 0, unfused_epilogue ? "separate" : "none");
     } else {

@@ -842,6 +842,123 @@ __global__ void __launch_bounds__(1024) gemm_strip16_kernel(GemmParams p) {
     }
 }
 
+// ---- fp32 I/O: exact-f32 matrix core (v_mfma_f32_32x32x2_f32), any bit width ---------------------------------------------
+// The reference's Python path is dtype-agnostic (qlinear_cuda_old.py:291-355): an fp32 layer (use_cuda_fp16=False, or the
+// act-order natives that force x.float(), qlinear_cuda.py:216-250) dequantises W = scales * (w - z) in fp32 and multiplies in
+// fp32.  Same arithmetic here: every weight is the exact fp32 product the reference forms, the products are accumulated by
+// the f32-input MFMA (an fmaf chain, bitwise) -- 157 TFLOP/s peak, 1/16 of the fp16 rate, but the weights are read once per
+// 128-row tile instead of once per 4 rows of x as in the GEMV this replaces for M > 8.
+//   workgroup = 4 waves (2 x 2), tile 128 x 128, wave 64 x 64 = 2 x 2 MFMA tiles (64 accumulator registers);
+//   x tile [128][32 k] fp32 through LDS (row stride 33 floats: the 32 rows of a ds_read_b32 hit 32 banks), double buffered;
+//   a lane owns column (l & 31) of each of its 2 column tiles: it loads that column's packing unit (1 word = 16/8/4 values,
+//   3 words = 32 values for 3-bit), extracts the fields, forms s * (w - z) and feeds k-pair (2j + (l >> 5)) to MFMA j.
+template <int BITS>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(GemmParams p) {
+    constexpr int KPU = Pack<BITS>::vals, UW = Pack<BITS>::words, BK = 32, UPB = BK / KPU, BM = 128, AS = BK + 1;
+    __shared__ float As[2][BM * AS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
+    const int L = xcd_remap(blockIdx.x, p.nbm * p.nbn);
+    const int bm = L % p.nbm, bn = L / p.nbm;
+    const int m0 = bm * BM;
+    int ncol[2];
+    bool col_ok[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = bn * 128 + wn * 64 + nt * 32 + l31;
+        col_ok[nt] = n < p.N;
+        ncol[nt] = col_ok[nt] ? n : 0;
+    }
+    const float* __restrict__ x = (const float*)p.x;
+    const float* __restrict__ scales = (const float*)p.scales;
+    const int zrow_words = p.N / 32 * BITS;
+    const int ksteps = p.K / BK;
+    // x staging: thread t copies 16 consecutive k of row t >> 1 (4 x 16-byte loads; rows past M are clamped, never stored)
+    const int a_row = tid >> 1, a_c0 = (tid & 1) * 16;
+    const float* a_src = x + (size_t)min(m0 + a_row, p.M - 1) * p.K + a_c0;
+    f32x4 a_next[4];
+    auto load_a = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_next[i] = *(const f32x4*)(a_src + (size_t)kt * BK + 4 * i);
+    };
+    auto store_a = [&](int buf) {
+        float* dst = &As[buf][a_row * AS + a_c0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dst[4 * i + c] = a_next[i][c];
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    load_a(0);
+    store_a(0);
+    __syncthreads();
+    for (int kt = 0; kt < ksteps; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ksteps) load_a(kt + 1);
+        // this K-step's packing units of the lane's two columns, and their group constants
+        unsigned w[UPB][2][UW];
+        float sc[UPB][2];
+        int zp[UPB][2];
+#pragma unroll
+        for (int u = 0; u < UPB; ++u) {
+            const int unit = kt * UPB + u;
+            const int g = (unit * KPU) / p.group_size;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                for (int i = 0; i < UW; ++i) w[u][nt][i] = p.qweight[(size_t)(unit * UW + i) * p.N + ncol[nt]];
+                sc[u][nt] = scales[(size_t)g * p.N + ncol[nt]];
+                const int f = (int)stream_field(p.qzeros + (size_t)g * zrow_words, 1, (unsigned)ncol[nt], BITS) + 1;
+                zp[u][nt] = (p.zero_mode == GPTQ_ZERO_WRAP) ? (f & (int)Pack<BITS>::maxq) : f;
+            }
+        }
+        const float* arow[2] = {&As[buf][(wm * 64 + l31) * AS + half], &As[buf][(wm * 64 + 32 + l31) * AS + half]};
+#pragma unroll
+        for (int u = 0; u < UPB; ++u) {
+            [&]<int... J>(std::integer_sequence<int, J...>) {       // J = k pair inside the unit: MFMA J consumes k = 2J, 2J + 1
+                (([&] {
+                     float b[2];
+#pragma unroll
+                     for (int nt = 0; nt < 2; ++nt) {
+                         const int f0 = (int)unit_field<BITS, 2 * J>(w[u][nt]), f1 = (int)unit_field<BITS, 2 * J + 1>(w[u][nt]);
+                         b[nt] = sc[u][nt] * (float)((half ? f1 : f0) - zp[u][nt]);      // exact integer difference, one fp32 rounding: the reference's W
+                     }
+                     float a[2];
+#pragma unroll
+                     for (int mt = 0; mt < 2; ++mt) a[mt] = arow[mt][u * KPU + 2 * J];
+#pragma unroll
+                     for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                 }()),
+                 ...);
+            }(std::make_integer_sequence<int, KPU / 2>{});
+        }
+        if (kt + 1 < ksteps) store_a(buf ^ 1);
+        __syncthreads();
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        if (!col_ok[nt]) continue;
+        const float bias = p.bias ? ((const float*)p.bias)[ncol[nt]] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < p.M) ((float*)p.out)[(size_t)m * p.N + ncol[nt]] = acc[mt][nt][r] + bias;
+            }
+    }
+}
+
 // out = sum_s partial[s] (+bias), fixed order; 4 columns per thread
 template <typename T>
 __global__ void __launch_bounds__(256) gemm_reduce_kernel(const float* __restrict__ partial, const T* __restrict__ bias,
@@ -930,6 +1047,20 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     GemmPlan pl{};
     const int kpu = unit_vals(L.bits);
     const bool seq = (L.g_idx == nullptr) || (L.qweight_seq != nullptr && L.perm != nullptr);
+    if (L.dtype == GPTQ_F32) {               // exact-f32 matrix core, 128 x 128 tiles, any bit width; groups made of whole packing units
+        pl.f32 = true;
+        pl.supported = seq && (L.group_size % kpu == 0) && (L.K % 32 == 0) && (L.N % 32 == 0);
+        if (!pl.supported) return pl;
+        pl.use_seq = (L.g_idx != nullptr);
+        pl.xperm_bytes = pl.use_seq ? align_up((size_t)M * L.K * 4, 256) : 0;
+        pl.mt = 4; pl.bk = 32; pl.bm = 128; pl.bn = 128; pl.waves = 4; pl.kg = 1;
+        pl.nbm = (M + 127) / 128;
+        pl.nbn = (L.N + 127) / 128;
+        pl.ksplit = 1;
+        pl.ksteps_total = pl.ksteps_per_split = L.K / 32;
+        pl.workspace_bytes = pl.xperm_bytes;
+        return pl;
+    }
     pl.supported = (L.dtype == GPTQ_F16 || L.dtype == GPTQ_BF16) && seq && (L.group_size % 32 == 0) && (L.K % 32 == 0) &&
                    (L.N % 32 == 0) && (L.group_size % kpu == 0) && ((size_t)L.K * 2 <= 64 * 1024 || L.g_idx == nullptr);
     if (!pl.supported) return pl;
@@ -1136,6 +1267,22 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
         p.kpg_inv = ((1ull << 32) + kpg - 1) / kpg;
     }
     hipError_t e;
+    if (pl.f32) {
+        if (pl.use_seq) {
+            e = launch_permute_columns(x, L.perm, M, L.K, GPTQ_F32, workspace, st);
+            if (e != hipSuccess) return e;
+            p.x = workspace;
+        }
+        const dim3 grid(pl.nbm * pl.nbn), block(256);
+        switch (L.bits) {
+            case 2: hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, block, 0, st, p); break;
+            case 3: hipLaunchKernelGGL(gemm_f32_kernel<3>, grid, block, 0, st, p); break;
+            case 4: hipLaunchKernelGGL(gemm_f32_kernel<4>, grid, block, 0, st, p); break;
+            case 8: hipLaunchKernelGGL(gemm_f32_kernel<8>, grid, block, 0, st, p); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (pl.use_seq) {
         e = launch_permute_rows16(x, L.perm, M, L.K, workspace, st, pl.xslot);
         if (e != hipSuccess) return e;

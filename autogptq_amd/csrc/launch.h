@@ -26,6 +26,7 @@ struct GemmPlan {
     bool glds;                // ... and stages it with global_load_lds (DMA) into swizzled, unpadded LDS rows
     bool xslot;               // act-order: the x pre-pass writes k-slot order, the kernel copies x to LDS verbatim
     bool strip16;             // 8 < M <= 64, 4-bit: 16-column strips on v_mfma_f32_16x16x32 (mt = row tiles of 16)
+    bool f32;                 // fp32 I/O: exact-f32 matrix core kernel (128 x 128 tiles)
     bool skinny;              // weight-streaming decomposition for 8 < M <= 128 (64-column strips, waves split K)
     int waves, variant;
     int kg;                   // K groups inside a workgroup (2 = 8 waves, two K halves summed through LDS)

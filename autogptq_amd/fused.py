@@ -65,75 +65,82 @@ def fuse_gate_up(gate: QuantLinear, up: QuantLinear) -> QuantLinear:
 
 
 class _FusedQKVState:
-    """y = [q | k | v](x) computed once per attention call by the q_proj stand-in and handed to the k/v stand-ins."""
+    """y_q, y_k, y_v computed by ONE gptq_forward_multi call when the q_proj stand-in runs, handed to the k/v stand-ins."""
 
-    def __init__(self, fused: QuantLinear, splits):
-        self.fused, self.splits = fused, splits
+    def __init__(self, layers):
+        self.layers = list(layers)
         self.src = None
         self.parts = None
 
 
 class _QKVPart(nn.Module):
     """Stand-in for q_proj / k_proj / v_proj of an attention module whose forward calls them in that order on the same
-    hidden_states (transformers' LlamaAttention.forward does): index 0 runs the fused layer, 1 and 2 return their slices.
-    Keeps the host model's attention code untouched, where the reference replaces the whole attention module
-    (FusedLlamaAttentionForQuantizedModel, auto_gptq/nn_modules/fused_llama_attn.py:18-135)."""
+    hidden_states (transformers' LlamaAttention.forward does): index 0 runs all three projections through
+    ``forward_multi`` -- one launch for decode rows on plain layers, three ordinary calls otherwise (act-order, prefill) --
+    and 1 / 2 return their results.  The three QuantLinears stay what they were: no concatenated copy of the packed tensors
+    (the reference builds one, fused_llama_attn.py:171-203, and therefore cannot fuse act-order projections with different
+    g_idx on its exllama path, :176-183; its cuda path carries a 3K-long g_idx, qlinear_cuda.py:300-312).  The host model's
+    attention code is untouched, where the reference replaces the whole module (fused_llama_attn.py:18-135)."""
 
-    def __init__(self, state: _FusedQKVState, index: int, owner: bool):
+    def __init__(self, state: _FusedQKVState, index: int):
         super().__init__()
         self.index = index
-        self._state = [state]                       # in a list: not registered as a submodule three times
-        if owner:
-            self.fused = state.fused                # registered once, so .to() / state_dict() see it
+        self._state = [state]                       # in a list: the shared state is not a submodule
+        self.proj = state.layers[index]             # each stand-in owns its own projection: .to() / state_dict() keep working
 
     def forward(self, x):
+        from .qlinear_mi355x import forward_multi
         st = self._state[0]
         if self.index == 0:
             st.src = x
-            st.parts = torch.split(st.fused(x), st.splits, dim=-1)
+            st.parts = forward_multi(st.layers, x)
         elif st.src is not x:
             raise RuntimeError("fused q/k/v: k_proj / v_proj called on a different tensor than q_proj")
-        return st.parts[self.index]
+        out = st.parts[self.index]
+        if self.index == 2:
+            st.src = st.parts = None                # do not keep activations alive between calls
+        return out
 
 
 class FusedGateUpMLP(nn.Module):
-    """down(silu(gate(x)) * up(x)) as two launches: the [gate | up] layer with the SiLU*mul epilogue, then down
-    (the role of FusedLlamaMLPForQuantizedModel, auto_gptq/nn_modules/fused_llama_mlp.py:131-306)."""
+    """down(silu(gate(x)) * up(x)) as two launches (the role of FusedLlamaMLPForQuantizedModel, auto_gptq/nn_modules/
+    fused_llama_mlp.py:131-306): the [gate | up] layer with the SiLU*mul epilogue when gate and up share g_idx, else
+    gate and up through ``forward_multi`` and an elementwise SiLU*mul."""
 
-    def __init__(self, gate_up: QuantLinear, down: nn.Module):
+    def __init__(self, gate: QuantLinear, up: QuantLinear, down: nn.Module):
         super().__init__()
-        self.gate_up = gate_up
+        try:
+            self.gate_up = fuse_gate_up(gate, up).to(gate.qweight.device)
+            self.gate_proj = self.up_proj = None
+        except ValueError:                          # per-projection act-order
+            self.gate_up = None
+            self.gate_proj, self.up_proj = gate, up
         self.down_proj = down
 
     def forward(self, x):
-        return self.down_proj(self.gate_up(x))
+        if self.gate_up is not None:
+            return self.down_proj(self.gate_up(x))
+        from .qlinear_mi355x import forward_multi
+        g, u = forward_multi([self.gate_proj, self.up_proj], x)
+        return self.down_proj(torch.nn.functional.silu(g) * u)
 
 
 def inject_fused_llama(model: nn.Module, fuse_attention: bool = True, fuse_mlp: bool = True) -> int:
-    """Fuse q/k/v and gate/up of every Llama-style decoder block whose projections are mi355x QuantLinears with a common g_idx
-    (the reference's inject_to_model entry points, fused_llama_attn.py:137-231 / fused_llama_mlp.py:290-306; like its exllama
-    backend it leaves blocks with per-projection act-order g_idx unfused).  Returns the number of fused modules."""
+    """Fuse q/k/v and gate/up of every Llama-style decoder block whose projections are mi355x QuantLinears (the reference's
+    inject_to_model entry points, fused_llama_attn.py:137-231 / fused_llama_mlp.py:290-306).  Returns the number of fused modules."""
     n = 0
     for mod in list(model.modules()):
         if fuse_attention and all(isinstance(getattr(mod, a, None), QuantLinear) for a in ("q_proj", "k_proj", "v_proj")):
             q, k, v = mod.q_proj, mod.k_proj, mod.v_proj
-            try:
-                f = fuse_qkv(q, k, v)
-            except ValueError:
-                f = None
-            if f is not None:
-                f = f.to(q.qweight.device)
-                st = _FusedQKVState(f, (q.outfeatures, k.outfeatures, v.outfeatures))
-                mod.q_proj, mod.k_proj, mod.v_proj = _QKVPart(st, 0, True), _QKVPart(st, 1, False), _QKVPart(st, 2, False)
+            if q.infeatures == k.infeatures == v.infeatures and q.scales.dtype == k.scales.dtype == v.scales.dtype:
+                st = _FusedQKVState((q, k, v))
+                mod.q_proj, mod.k_proj, mod.v_proj = _QKVPart(st, 0), _QKVPart(st, 1), _QKVPart(st, 2)
                 n += 1
         if fuse_mlp and all(isinstance(getattr(mod, a, None), QuantLinear) for a in ("gate_proj", "up_proj")) and hasattr(mod, "down_proj") \
                 and getattr(getattr(mod, "act_fn", None), "__class__", type(None)).__name__ in ("SiLU", "SiLUActivation"):
-            try:
-                gu = fuse_gate_up(mod.gate_proj, mod.up_proj)
-            except ValueError:
-                gu = None
-            if gu is not None:
-                fm = FusedGateUpMLP(gu.to(mod.gate_proj.qweight.device), mod.down_proj)
+            gate, up = mod.gate_proj, mod.up_proj
+            if gate.infeatures == up.infeatures and gate.outfeatures == up.outfeatures and gate.bits == up.bits:
+                fm = FusedGateUpMLP(gate, up, mod.down_proj)
                 mod.forward = fm.forward
                 mod.fused_mlp = fm
                 del mod.gate_proj, mod.up_proj

@@ -20,6 +20,12 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+def _host_staged(group) -> bool:
+    """gloo has no device collectives for every op used here: with a gloo group the exchange is staged through host memory
+    (CPU control plane, e.g. the 2-ranks-on-one-GPU test); RCCL ("nccl") groups exchange device buffers directly."""
+    return dist.get_backend(group) == "gloo"
+
+
 def shard_bounds(N: int, rank: int, world: int):
     if N % world != 0 or (N // world) % 32 != 0:
         raise ValueError(f"out_features={N} cannot be split over {world} ranks in multiples of 32 columns")
@@ -73,8 +79,13 @@ class ColumnParallelQuantLinear(nn.Module):
         lead = y.shape[:-1]
         y2 = y.reshape(-1, y.shape[-1]).contiguous()         # [M, N/T]
         M, nl = y2.shape
-        buf = torch.empty((self.world * M, nl), dtype=y2.dtype, device=y2.device)    # rank-major concatenation
-        dist.all_gather_into_tensor(buf, y2, group=self.group)
+        if y2.is_cuda and _host_staged(self.group):
+            hb = torch.empty((self.world * M, nl), dtype=y2.dtype)
+            dist.all_gather_into_tensor(hb, y2.cpu(), group=self.group)
+            buf = hb.to(y2.device)
+        else:
+            buf = torch.empty((self.world * M, nl), dtype=y2.dtype, device=y2.device)    # rank-major concatenation
+            dist.all_gather_into_tensor(buf, y2, group=self.group)
         buf = buf.view(self.world, M, nl)
         if M == 1:
             out = buf.reshape(1, self.world * nl)            # rank-major == column-major for one row
@@ -133,7 +144,12 @@ class RowParallelQuantLinear(nn.Module):
         y = self.local(x)
         if self.world > 1:
             y = y.float()                                   # partial sums are reduced in fp32, rounded once
-            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+            if y.is_cuda and _host_staged(self.group):
+                h = y.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                y = h.to(y.device)
+            else:
+                dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
             y = y.to(x.dtype)
         if self.bias is not None:
             y = y + self.bias

@@ -353,37 +353,66 @@ def cpu_baseline(M, act_order, budget_s=20.0):
 
 
 def bench_tp(device, rank, world, steps):
-    """Column-parallel Llama-2-70B shapes (BASELINE config 4), M = 1: local GEMV + one all-gather."""
+    """Column-parallel Llama-2-70B shapes (BASELINE config 4): local kernel + one all-gather, M = 1 (decode) and M = 2048
+    (prefill); and the Megatron pairing of an MLP block -- column-parallel gate / up without gather feeding a row-parallel
+    down projection: ONE all-reduce per block.  Eager calls (RCCL on the layer's stream), HIP events, max over ranks."""
     import torch.distributed as dist
-    from autogptq_amd.tensor_parallel import ColumnParallelQuantLinear
+    from autogptq_amd.tensor_parallel import ColumnParallelQuantLinear, RowParallelQuantLinear
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize(device)
+        return e0.elapsed_time(e1) * 1e-3 / n, out
 
     res = {}
     for name, K, N in LLAMA70B_TP:
         nl = N // world
         local = make_layer(K, nl, device, seed=rank)
         mod = ColumnParallelQuantLinear(local, N)
-        x = (torch.rand(1, K, device=device) - 0.5).half()
-        for _ in range(5):
-            mod(x)
-        torch.cuda.synchronize(device)
-        dist.barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(steps):
-            y = mod(x)
-        e1.record()
-        torch.cuda.synchronize(device)
-        t_all = e0.elapsed_time(e1) * 1e-3 / steps
-        e0.record()
-        for _ in range(steps):
-            local(x)
-        e1.record()
-        torch.cuda.synchronize(device)
-        t_loc = e0.elapsed_time(e1) * 1e-3 / steps
-        t = torch.tensor([t_all, t_loc], device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        res[name] = {"K": K, "N": N, "tp": world, "us_per_layer_with_allgather": round(t[0].item() * 1e6, 2),
-                     "us_local_only": round(t[1].item() * 1e6, 2), "out_cols": int(y.shape[-1])}
+        ent = {"K": K, "N": N, "tp": world}
+        for M, n in ((1, steps), (2048, max(3, steps // 10))):
+            try:
+                x = (torch.rand(M, K, device=device) - 0.5).half()
+                with torch.no_grad():
+                    t_all, y = timed(lambda: mod(x), n)
+                    t_loc, _ = timed(lambda: local(x), n)
+                t = torch.tensor([t_all, t_loc], device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                key = "" if M == 1 else f"_m{M}"
+                ent["us_per_layer_with_allgather" + key] = round(t[0].item() * 1e6, 2)
+                ent["us_local_only" + key] = round(t[1].item() * 1e6, 2)
+                ent["out_cols"] = int(y.shape[-1])
+            except Exception as e:
+                ent[f"error_m{M}"] = repr(e)[:200]
+        res[name] = ent
+        del local, mod
+    try:      # MLP block 8192 -> 28672 -> 8192: gate/up column shards (no gather) -> down row shard (one all-reduce)
+        K, I = 8192, 28672
+        gate = make_layer(K, I // world, device, seed=100 + rank)
+        up = make_layer(K, I // world, device, seed=200 + rank)
+        down = RowParallelQuantLinear(make_layer(I // world, K, device, seed=300 + rank), (rank * (I // world), (rank + 1) * (I // world)))
+        ent = {"K": K, "I": I, "tp": world}
+        for M, n in ((1, steps), (2048, max(3, steps // 10))):
+            x = (torch.rand(M, K, device=device) - 0.5).half()
+
+            def block():
+                return down(torch.nn.functional.silu(gate(x)) * up(x))
+            with torch.no_grad():
+                t_blk, _ = timed(block, n)
+            t = torch.tensor([t_blk], device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ent["us_per_block" + ("" if M == 1 else f"_m{M}")] = round(t[0].item() * 1e6, 2)
+        res["mlp_column_row_pair"] = ent
+    except Exception as e:
+        res["mlp_column_row_pair"] = {"error": repr(e)[:200]}
     return res
 
 

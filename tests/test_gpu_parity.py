@@ -1016,3 +1016,40 @@ def test_forward_multi_equals_layer_by_layer(M, act):
     torch.cuda.synchronize()
     for a, b in zip(eager, cap):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------- fp32 I/O above M = 8: exact-f32 matrix core
+@pytest.mark.parametrize("act", [False, True])
+@pytest.mark.parametrize("bits,gs,K,N,M", [(4, 128, 1024, 512, 9), (4, 32, 512, 160, 40), (3, 32, 1024, 256, 130), (8, 32, 512, 384, 300),
+                                           (2, 16, 256, 96, 64), (4, 128, 4096, 4096, 2048), (8, 128, 2048, 1056, 77)])
+def test_fp32_gemm_vs_oracle(bits, gs, K, N, M, act):
+    """fp32 layers (scales / x / out fp32: the reference's use_cuda_fp16=False and act-order native paths, qlinear_cuda_old.py:
+    251-290, qlinear_cuda.py:216-250) at M > 8 run gemm_f32_kernel: weights are the exact fp32 s*(w-z), accumulation is the
+    f32 MFMA.  fp64 oracle with the fp32 tolerance, one-hot rows exact, bias, ragged N (160, 1056) and M, act-order."""
+    L = O.random_quant_layer(K, N, bits, gs, act_order=act, dtype=torch.float32, seed=bits + K + N + M, bias=True)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"] if act else None, L["bias"], bits, gs)
+    q.post_init()
+    assert _lib.describe_plan(q._layer, M)["kernel"] == "f32_mfma"
+    gen = torch.Generator().manual_seed(M)
+    x = (torch.rand(M, K, generator=gen) - 0.5).float()
+    hot = [0, K - 1, gs, 10]
+    for r, k in enumerate(hot):
+        x[r].zero_()
+        x[r, k] = 1.0
+    with torch.no_grad():
+        y = q(x.to(DEV))
+        yb = q(x.to(DEV))
+        W = q.dequantize()
+    assert y.dtype == torch.float32 and torch.equal(y, yb)
+    for r, k in enumerate(hot):
+        assert torch.equal(y[r], W[k] + q.bias), (r, k)
+    rows = torch.arange(0, M, max(1, M // 37))
+    cols = slice(0, min(N, 512))
+    mode = O.reference_zero_mode(act, bits)
+    y64 = O.forward_f64(x[rows], L["qweight"][:, cols], L["qzeros"][:, : cols.stop * bits // 32], L["scales"][:, cols], L["g_idx"] if act else None,
+                        L["bias"][cols], bits, mode)
+    _assert_close(y[rows][:, cols], y64, y64, torch.float32, K, "fp32 gemm vs f64")
+    # and the GEMV path it replaces gives the same values within the same tolerance (different summation order)
+    with torch.no_grad():
+        yg = q(x[:8].to(DEV))
+    _assert_close(yg, y[:8].double(), y64, torch.float32, K, "fp32 gemv rows vs gemm rows")
