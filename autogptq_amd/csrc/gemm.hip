@@ -1262,7 +1262,7 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
     p.nbm = pl.nbm; p.nbn = pl.nbn; p.ksplit = pl.ksplit;
     p.ksteps_total = pl.ksteps_total; p.ksteps_per_split = pl.ksteps_per_split;
     p.qrows = L.K / 32 * L.bits;
-    {
+    if (!pl.f32) {
         const unsigned long long kpg = (unsigned long long)(L.group_size / pl.bk);       // K-steps per group (>= 1: group_size % bk == 0)
         p.kpg_inv = ((1ull << 32) + kpg - 1) / kpg;
     }
