@@ -103,54 +103,70 @@ __device__ __forceinline__ float round_to(float v, int dt) {
 }
 __host__ __device__ inline int promote(int a, int b) { return (a == b) ? a : GPTQ_F32; }
 
+// W is [N, K] (rows = output features): a workgroup stages a 32-column x 256-k tile through LDS with loads that run along K
+// (512 contiguous bytes per W row for fp16), then every thread quantises and packs whole units for consecutive columns n --
+// so both the W reads and the qweight / scales accesses are coalesced (the first version read W[n, k] with lanes along n,
+// one 16-64 byte piece per lane at stride K).
 template <int BITS>
 __global__ void __launch_bounds__(256) pack_weights_kernel(const void* __restrict__ W, const void* __restrict__ scale_in,
                                                            const void* __restrict__ zero_in, const int* __restrict__ g_idx,
                                                            int K, int N, int group_size, int w_dt, int q_dt,
                                                            unsigned* __restrict__ qweight, void* __restrict__ scales_out) {
-    constexpr int UW = Pack<BITS>::words, KPU = Pack<BITS>::vals;
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    const int u = blockIdx.y;
-    if (n >= N || u >= K / KPU) return;
+    constexpr int UW = Pack<BITS>::words, KPU = Pack<BITS>::vals, TN = 32, TK = 256;
+    __shared__ float tile[TN][TK + 1];
+    const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
+    const int tid = threadIdx.x;
+    for (int r = 0; r < TN; ++r) {
+        const int n = n0 + r, k = k0 + tid;
+        tile[r][tid] = (n < N && k < K) ? load_as_f32(W, (size_t)n * K + k, w_dt) : 0.f;
+    }
+    __syncthreads();
     const int p_dt = promote(w_dt, q_dt);
-    unsigned vals[KPU];
+    for (int idx = tid; idx < TN * (TK / KPU); idx += 256) {
+        const int ul = idx / TN, nl = idx - ul * TN;
+        const int n = n0 + nl, u = k0 / KPU + ul;
+        if (n >= N || u >= K / KPU) continue;
+        unsigned vals[KPU];
 #pragma unroll
-    for (int v = 0; v < KPU; ++v) {
-        const int k = u * KPU + v;
-        const int g = g_idx ? g_idx[k] : k / group_size;
-        const float s_in = load_as_f32(scale_in, (size_t)g * N + n, q_dt);
-        const float z_in = load_as_f32(zero_in, (size_t)g * N + n, q_dt);
-        const float sz = round_to(z_in * s_in, q_dt);                     // scale_zeros = zeros * scales
-        const float s_cast = round_to(s_in, w_dt);                         // self.scales (layer dtype)
-        const float w = load_as_f32(W, (size_t)n * K + k, w_dt);
-        const float sum = round_to(w + sz, p_dt);
-        const float quo = round_to(sum / s_cast, p_dt);
-        vals[v] = (unsigned)(int)rintf(quo);                               // torch.round = half-to-even
+        for (int v = 0; v < KPU; ++v) {
+            const int k = u * KPU + v;
+            const int g = g_idx ? g_idx[k] : k / group_size;
+            const float s_in = load_as_f32(scale_in, (size_t)g * N + n, q_dt);
+            const float z_in = load_as_f32(zero_in, (size_t)g * N + n, q_dt);
+            const float sz = round_to(z_in * s_in, q_dt);                     // scale_zeros = zeros * scales
+            const float s_cast = round_to(s_in, w_dt);                         // self.scales (layer dtype)
+            const float w = tile[nl][ul * KPU + v];
+            const float sum = round_to(w + sz, p_dt);
+            const float quo = round_to(sum / s_cast, p_dt);
+            vals[v] = (unsigned)(int)rintf(quo);                               // torch.round = half-to-even
+        }
+        unsigned w[UW];
+#pragma unroll
+        for (int i = 0; i < UW; ++i) w[i] = 0u;
+        if constexpr (BITS != 3) {
+#pragma unroll
+            for (int v = 0; v < KPU; ++v) w[0] |= vals[v] << (BITS * v);        // unmasked OR, like the reference
+        } else {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) w[0] |= vals[j] << (3 * j);
+            w[0] |= vals[10] << 30;
+            w[1] |= (vals[10] >> 2) & 1u;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) w[1] |= vals[11 + j] << (3 * j + 1);
+            w[1] |= vals[21] << 31;
+            w[2] |= (vals[21] >> 1) & 3u;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) w[2] |= vals[22 + j] << (3 * j + 2);
+        }
+#pragma unroll
+        for (int i = 0; i < UW; ++i) qweight[(size_t)(u * UW + i) * N + n] = w[i];
     }
-    unsigned w[UW];
-#pragma unroll
-    for (int i = 0; i < UW; ++i) w[i] = 0u;
-    if constexpr (BITS != 3) {
-#pragma unroll
-        for (int v = 0; v < KPU; ++v) w[0] |= vals[v] << (BITS * v);        // unmasked OR, like the reference
-    } else {
-#pragma unroll
-        for (int j = 0; j < 10; ++j) w[0] |= vals[j] << (3 * j);
-        w[0] |= vals[10] << 30;
-        w[1] |= (vals[10] >> 2) & 1u;
-#pragma unroll
-        for (int j = 0; j < 10; ++j) w[1] |= vals[11 + j] << (3 * j + 1);
-        w[1] |= vals[21] << 31;
-        w[2] |= (vals[21] >> 1) & 3u;
-#pragma unroll
-        for (int j = 0; j < 10; ++j) w[2] |= vals[22 + j] << (3 * j + 2);
-    }
-#pragma unroll
-    for (int i = 0; i < UW; ++i) qweight[(size_t)(u * UW + i) * N + n] = w[i];
-    // scales_out = scales.to(layer dtype); written once per (g, n) by the unit that starts a group row
-    if (scales_out && u == 0) {
+    // scales_out = scales.to(layer dtype): the workgroups of the first K tile write their 32 columns of every group row
+    if (scales_out && blockIdx.y == 0) {
         const int G = (K + group_size - 1) / group_size;
-        for (int g = 0; g < G; ++g) {
+        for (int idx = tid; idx < G * TN; idx += 256) {
+            const int g = idx / TN, n = n0 + (idx - g * TN);
+            if (n >= N) continue;
             const float s = round_to(load_as_f32(scale_in, (size_t)g * N + n, q_dt), w_dt);
             switch (w_dt) {
                 case GPTQ_F16: ((f16*)scales_out)[(size_t)g * N + n] = (f16)s; break;
@@ -304,7 +320,7 @@ hipError_t launch_dequant(const gptq_layer_t& L, void* W_out, hipStream_t st) {
 hipError_t launch_pack_weights(const void* W, const void* scale_in, const void* zero_in, const int32_t* g_idx,
                                int K, int N, int bits, int group_size, int w_dtype, int qparam_dtype,
                                uint32_t* qweight_out, void* scales_out, hipStream_t st) {
-    dim3 grid((N + 255) / 256, K / unit_vals(bits)), block(256);
+    dim3 grid((N + 31) / 32, (K + 255) / 256), block(256);       // 32-column x 256-k tiles
     GPTQ_BITS_SWITCH(bits, hipLaunchKernelGGL(pack_weights_kernel<B>, grid, block, 0, st, W, scale_in, zero_in, g_idx, K, N,
                                               group_size, w_dtype, qparam_dtype, qweight_out, scales_out));
     return hipGetLastError();

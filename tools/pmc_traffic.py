@@ -49,15 +49,25 @@ def main():
         w = write.get(key)
         ent["WRITE_SIZE_KiB"] = round(w[0], 1) if w else None
         ent["hbm_bytes_per_launch"] = ent["fetch_bytes_x2"] + (int(w[0] * 1024) if w else 0)
-        # label with (K, N, M) when the grid matches a decode strip decomposition (16-column strips)
+        # label with (K, N, M): the launch geometries bench.py produces (decode: M = 1; prefill: --prefill-m rows)
         ent["K"] = ent["N"] = ent["M"] = None
+        if "gemv_q4_stream_kernel" in name:
+            # streamed GEMV: (workgroups, threads) -> launch; multi-layer launches are labelled with the summed width
+            geo = {(192, 1024): (4096, 12288), (688, 512): (4096, 22016), (172, 1024): (4096, 11008)}
+            if (blocks, wg) in geo:
+                ent["K"], ent["N"] = geo[(blocks, wg)]
+                ent["M"] = args.m
         for K, N in shapes:
-            if blocks * 16 == N and "gemv" in name:
+            if blocks * 16 == N and "gemv" in name and "stream" not in name:
                 ent["N"], ent["M"] = N, args.m
                 cands = [k for k, n2 in shapes if n2 == N]
                 ent["K_candidates"] = cands
                 if len(cands) == 1:
                     ent["K"] = cands[0]
+                elif "mfma_kernel<4, 1, 1," in name:      # rows per lane U = 1 <=> K/8 >= 1024 (plan_gemv): the 11008-row layer
+                    ent["K"] = max(cands)
+                elif "mfma_kernel<4, 1, 2," in name:
+                    ent["K"] = min(cands)
             if "gemm_kernel" in name and args.prefill_m:        # 128 x 256 workgroup tiles
                 if blocks == -(-args.prefill_m // 128) * -(-N // 256):
                     ent["N"], ent["M"] = N, args.prefill_m

@@ -32,9 +32,11 @@ def timed(fn, reps=6):
 def tune(**kw):
     t = _lib.GptqTuning()
     u = kw.pop("u", 0)
+    depth = kw.pop("depth", 0)
     for k, v in kw.items():
         setattr(t, k, v)
     t.reserved[0] = u
+    t.reserved[1] = depth
     return t
 
 
@@ -58,7 +60,7 @@ def main():
         rows = K // 8
         for ln in (4, 8, 16):
             wr = 64 // ln
-            for waves, u in ((4, 2), (4, 4), (8, 2), (8, 4), (8, 8), (16, 2), (16, 4), (16, 8)):
+            for waves, u in ((2, 8), (4, 2), (4, 4), (4, 8), (8, 2), (8, 4), (8, 8), (16, 2), (16, 4), (16, 8)):
                 for ks in ((1,) if ln == 4 else (1, 2, 4)):
                     if N // (4 * ln) * ks < 128:
                         continue
@@ -87,7 +89,7 @@ def main():
         base, ref = timed(lambda: [[q(x) for q in grp] for grp in groups])
         res.append((base / ng, "separate launches (register kernel)"))
         for ln in (4, 8, 16):
-            for waves, u in ((4, 2), (4, 4), (8, 2), (8, 4), (16, 2), (16, 4), (8, 8), (16, 8)):
+            for waves, u in ((2, 8), (4, 2), (4, 4), (4, 8), (8, 2), (8, 4), (16, 2), (16, 4), (8, 8), (16, 8)):
                 t = tune(path=6, lanes_n=ln, waves=waves, ksplit=1, u=u)
                 try:
                     s, out = timed(lambda: [forward_multi(grp, x, t) for grp in groups])
