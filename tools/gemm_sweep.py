@@ -16,7 +16,7 @@ def main():
     ap.add_argument("--cases", default="4096x4096x2048a,4096x11008x2048a,11008x4096x2048a,4096x4096x4096,4096x4096x2048,4096x11008x512a,4096x4096x1024a")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    dt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
     for case in args.cases.split(","):
         act = case.endswith("a")
         K, N, M = map(int, case.rstrip("a").split("x"))
