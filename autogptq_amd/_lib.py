@@ -116,7 +116,24 @@ def load() -> ctypes.CDLL:
     if got != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {got}, expected {ABI_VERSION}")
     _lib = lib
+    _bind_fastcall(lib)
     return lib
+
+
+fast = None      # autogptq_amd/_fastcall.so (METH_FASTCALL trampoline), or None: the same entry points through ctypes
+
+
+def _bind_fastcall(lib) -> None:
+    """Hand the addresses of the two per-token entry points to the C trampoline, if it was built (python -c 'import
+    __graft_entry__ as g; g.build()').  It calls the SAME functions of the SAME loaded library; only the argument marshalling differs."""
+    global fast
+    try:
+        from . import _fastcall
+    except ImportError:
+        fast = None
+        return
+    _fastcall.bind(ctypes.cast(lib.gptq_forward_ex, c_void_p).value, ctypes.cast(lib.gptq_forward_multi_ex, c_void_p).value)
+    fast = _fastcall
 
 
 def check(status: int) -> None:

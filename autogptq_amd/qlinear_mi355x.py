@@ -234,6 +234,7 @@ class QuantLinear(nn.Module):
         L.reserved_ = 0
         self._layer = L
         self._layer_ref = ctypes.byref(L)
+        self._layer_addr = ctypes.addressof(L)
         self._fwd = lib.gptq_forward_ex
         self._dev = dev
         self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -296,12 +297,21 @@ class QuantLinear(nn.Module):
             else:
                 ws_ptr, ws_bytes = self._workspace(M, dev, tuning)
             idx = self._dev_index
-            tref = ctypes.byref(tuning) if tuning is not None else None
-            if idx != torch.cuda.current_device():
-                with torch.cuda.device(idx):
-                    rc = self._fwd(self._layer_ref, x2.data_ptr(), out.data_ptr(), M, ws_ptr, ws_bytes, _raw_stream(idx), tref)
+            fast = _lib.fast
+            if fast is not None:           # METH_FASTCALL trampoline: integers only
+                taddr = ctypes.addressof(tuning) if tuning is not None else 0
+                if idx != torch.cuda.current_device():
+                    with torch.cuda.device(idx):
+                        rc = fast.forward(self._layer_addr, x2.data_ptr(), out.data_ptr(), M, ws_ptr or 0, ws_bytes, _raw_stream(idx), taddr)
+                else:
+                    rc = fast.forward(self._layer_addr, x2.data_ptr(), out.data_ptr(), M, ws_ptr or 0, ws_bytes, _raw_stream(idx), taddr)
             else:
-                rc = self._fwd(self._layer_ref, x2.data_ptr(), out.data_ptr(), M, ws_ptr, ws_bytes, _raw_stream(idx), tref)
+                tref = ctypes.byref(tuning) if tuning is not None else None
+                if idx != torch.cuda.current_device():
+                    with torch.cuda.device(idx):
+                        rc = self._fwd(self._layer_ref, x2.data_ptr(), out.data_ptr(), M, ws_ptr, ws_bytes, _raw_stream(idx), tref)
+                else:
+                    rc = self._fwd(self._layer_ref, x2.data_ptr(), out.data_ptr(), M, ws_ptr, ws_bytes, _raw_stream(idx), tref)
             if rc:
                 _lib.check(rc)
         if x_dtype != w_dtype:
@@ -463,8 +473,9 @@ def forward_multi(layers, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = No
         ent = _MULTI.get(key)
         if ent is None:
             arr = (ctypes.POINTER(_lib.GptqLayer) * n)(*[ctypes.pointer(l._layer) for l in layers])
-            ent = _MULTI[key] = (arr, {}, [l._layer for l in layers])
-        arr, need_by_m, _ = ent
+            optr_arr = (ctypes.c_void_p * n)()
+            ent = _MULTI[key] = (arr, {}, [l._layer for l in layers], optr_arr, ctypes.addressof(arr), ctypes.addressof(optr_arr))
+        arr, need_by_m = ent[0], ent[1]
         tref = ctypes.byref(tuning) if tuning is not None else None
         need = need_by_m.get(M) if tuning is None else None
         if need is None:
@@ -475,10 +486,24 @@ def forward_multi(layers, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = No
         if need:
             buf = reserve_workspace(dev, need)
             ws_ptr, ws_bytes = buf.data_ptr(), buf.numel()
-        optrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+        optrs = ent[3]
+        for i in range(n):
+            optrs[i] = outs[i].data_ptr()
         idx = a._dev_index
-        with torch.cuda.device(idx):
-            _lib.check(_lib.load().gptq_forward_multi_ex(arr, n, x2.data_ptr(), optrs, M, ws_ptr, ws_bytes, _raw_stream(idx), tref))
+        fast = _lib.fast
+
+        def launch():
+            if fast is not None:
+                return fast.forward_multi(ent[4], n, x2.data_ptr(), ent[5], M, ws_ptr or 0, ws_bytes, _raw_stream(idx),
+                                          ctypes.addressof(tuning) if tuning is not None else 0)
+            return _lib.load().gptq_forward_multi_ex(arr, n, x2.data_ptr(), optrs, M, ws_ptr, ws_bytes, _raw_stream(idx), tref)
+        if idx != torch.cuda.current_device():
+            with torch.cuda.device(idx):
+                rc = launch()
+        else:
+            rc = launch()
+        if rc:
+            _lib.check(rc)
     if x_dtype != w_dtype:
         outs = [o.to(x_dtype) for o in outs]
     if x.dim() != 2:
