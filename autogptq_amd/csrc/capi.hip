@@ -66,7 +66,11 @@ bool want_gemm(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
     // enough 256-column tiles to fill the chip (4096x11008, M = 8: 22.2 us GEMV, 17.8 us tiled; narrower layers: GEMV wins)
     const bool wide_small_batch = M >= 5 && L->bits == 4 && L->N > 8192 && L->epilogue == GPTQ_EPI_NONE;
     if (M <= 8 && !wide_small_batch) return false;
-    return plan_gemm(*L, M, t).supported;
+    const GemmPlan g = plan_gemm(*L, M, t);
+    // fp32 matrix-core kernel: 128 x 128 tiles and no K split -- with fewer than 64 tiles the 4-rows-per-pass GEMV is faster
+    // (M = 64 on 4096 x 4096: 455 us on 32 tiles; profiles/r02_gemm_f32.log)
+    if (g.supported && g.f32 && M <= 64 && (long)g.nbm * g.nbn < 64 && !(t && t->path == 3)) return false;
+    return g.supported;
 }
 
 // The streamed GEMV (weights by LDS DMA, in-launch K-split combine) for a single layer: forced by tuning.path = 6, else by

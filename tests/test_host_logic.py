@@ -285,7 +285,8 @@ def test_dispatch_rules_are_the_measured_ones():
     assert _plan(4096, 4096, 1, bits=3, gs=32)["kernel"] == "mfma_generic" and _plan(4096, 4096, 1, bits=8, gs=32)["kernel"] == "mfma_generic"
     assert _plan(4096, 4096, 1, dtype=2)["kernel"] == "generic"
     # fp32 above 8 rows: exact-f32 matrix core (128 x 128 tiles), any bit width; the GEMV would re-stream the weights per 4 rows
-    assert _plan(4096, 4096, 2048, dtype=2)["kernel"] == "f32_mfma" and _plan(4096, 4096, 9, dtype=2, bits=3, gs=32)["kernel"] == "f32_mfma"
+    assert _plan(4096, 4096, 2048, dtype=2)["kernel"] == "f32_mfma" and _plan(4096, 11008, 65, dtype=2, bits=3, gs=32)["kernel"] == "f32_mfma"
+    assert _plan(4096, 4096, 64, dtype=2)["path"] == "gemv"          # 32 tiles: the 4-rows-per-pass GEMV is faster
     assert _plan(4096, 4096, 8, dtype=2)["path"] == "gemv"
     # rows of x: GEMV up to 8 (two passes for 5..8), except wide layers where 5..8 rows go to the tiled kernel
     assert _plan(4096, 4096, 4)["mt"] == 4 and _plan(4096, 4096, 8)["mt"] == 8 and _plan(4096, 4096, 8)["path"] == "gemv"
