@@ -1135,7 +1135,10 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     if (!ks) {
         ks = 1;
         const long blocks = (long)pl.nbm * pl.nbn;
-        while (blocks * ks < 192 && ks < 8 && pl.ksteps_total / (ks * 2) >= 4) ks *= 2;
+        // stop doubling once the next step would pass 256 workgroups: up to 256 the workgroup can run two K groups (8 waves), which
+        // beats twice the slices (tools/ksplit_sweep.py, us per layer: 4096x11008 M = 128: 4 slices x 2 groups 30.5 vs 8 slices 35.4;
+        // M = 256: 46.4 vs 50.3; M = 512: 1 x 2 72.6 vs 2 slices 79.0)
+        while (blocks * ks < 192 && ks < 8 && pl.ksteps_total / (ks * 2) >= 4 && blocks * ks * 2 <= 256) ks *= 2;
     }
     if (ks > pl.ksteps_total) ks = pl.ksteps_total;
     pl.ksteps_per_split = (pl.ksteps_total + ks - 1) / ks;
