@@ -97,6 +97,22 @@ __device__ __forceinline__ void zero_points4(const unsigned* __restrict__ zrow, 
     }
 }
 
+// ---- LDS DMA from inline asm ------------------------------------------------------------------------------------------
+// global_load_lds_dwordx4: 16 bytes per lane, global -> LDS at (lds_dst + lane * 16), no VGPR destination.  Issued from asm on
+// purpose: with __builtin_amdgcn_global_load_lds hipcc (ROCm 7.2) protects every later LDS access that might alias the DMA's
+// destination with s_waitcnt vmcnt(0) -- behind EACH DMA of a burst, and in front of the first ds_read of a double-buffered
+// K-step, i.e. right after the next step's loads were issued (the whole memory latency lands on every step).  Hidden in asm the
+// instruction is not part of the compiler's vmcnt bookkeeping, which only ever makes its waits for ordinary loads longer
+// (vmcnt retires in order), never shorter; the kernel waits for the DMA data with a hand-counted s_waitcnt.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst_) {           // default cache policy
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);   // wave-uniform by construction; an SGPR for the compiler too
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // XCD-aware, bijective remap of a linear workgroup id: consecutive logical ids land on the same
 // XCD (observed placement: hardware block b runs on XCD b % 8), so neighbouring column strips
 // share one L2.  Performance only -- correctness never depends on placement.

@@ -105,7 +105,10 @@ __device__ __forceinline__ unsigned long long window(const BRaw<BITS>& r, int c,
 }
 
 // ---- per-column group constants ----------------------------------------------------------------
-struct CRaw { unsigned s; unsigned long long z; };   // 2 scales (T,T) ; qzeros window aligned to the lane's first column
+// 2 scales (T,T) ; the raw qzeros word(s) holding the lane's columns + the bit offset of the first one.  Nothing is computed on the
+// loaded values at load time: a shift issued next to the load pins an s_waitcnt for a load that was requested one instruction ago
+// in front of the step's MFMAs (seen in the two-K-group kernel: a full memory latency every other K-step).
+struct CRaw { unsigned s; unsigned long long z; unsigned sh; };
 
 template <int BITS>
 __device__ __forceinline__ void load_craw(CRaw& c, const void* __restrict__ scales, const unsigned* __restrict__ qzeros,
@@ -118,13 +121,14 @@ __device__ __forceinline__ void load_craw(CRaw& c, const void* __restrict__ scal
     const unsigned* zr = qzeros + (size_t)g * zrow_words;
     unsigned long long v = zr[wi];
     if constexpr (BITS == 3) v |= (unsigned long long)zr[min(wi + 1, zrow_words - 1)] << 32;
-    c.z = v >> sh;
+    c.z = v;
+    c.sh = sh;
 }
 
 template <int BITS>
 __device__ __forceinline__ int zero_point(const CRaw& c, int col, int zero_mode) {
     constexpr unsigned maxq = (1u << BITS) - 1u;
-    const int f = (int)((unsigned)(c.z >> (BITS * col)) & maxq) + 1;
+    const int f = (int)((unsigned)(c.z >> (c.sh + BITS * col)) & maxq) + 1;
     return zero_mode == GPTQ_ZERO_WRAP ? (f & (int)maxq) : f;
 }
 
@@ -255,7 +259,8 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
     constexpr int NCH = (CHUNKS + NTHR - 1) / NTHR;
     static_assert(KG == 1 || (KG == 2 && MT == 4), "K groups: 1, or 2 with the 128-row tile");
     extern __shared__ __attribute__((aligned(16))) char smem_all[];   // KG x 2 x BM x STRIDE
-    const int kg = KG == 1 ? 0 : (int)(threadIdx.x >> 8);
+    // wave-uniform by construction; said so, or every buffer load whose scalar offset depends on the K group turns into a waterfall loop
+    const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
     char* const smem = smem_all + (size_t)kg * (2 * BM * STRIDE);
 
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
@@ -320,8 +325,7 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             char* dst = smem + (size_t)buf * (BM * STRIDE) + (size_t)(i * NTHR + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + (size_t)kt * (BK * 2) + a_off[i]),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            lds_dma16(a_base + (size_t)kt * (BK * 2) + a_off[i], lds_addr_of(dst));
         }
     };
     auto load_a = [&](int kt, u32x4 (&r)[NCH]) {
@@ -368,7 +372,8 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
         const int g = (int)(((unsigned long long)(unsigned)kt * p.kpg_inv) >> 32);
         if constexpr (BITS != 3) {
             c.s = __builtin_amdgcn_raw_buffer_load_b32(rsrc_s, s_lane_off, (unsigned)g * (unsigned)p.N * 2u, 0);
-            c.z = (unsigned long long)(__builtin_amdgcn_raw_buffer_load_b32(rsrc_z, z_lane_off, (unsigned)(g * zrow_bytes), 0) >> z_lane_sh);
+            c.z = (unsigned long long)__builtin_amdgcn_raw_buffer_load_b32(rsrc_z, z_lane_off, (unsigned)(g * zrow_bytes), 0);
+            c.sh = z_lane_sh;
         } else {
             load_craw<BITS>(c, p.scales, p.qzeros, g, p.N, nl);
         }
@@ -392,6 +397,7 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
     load_b(kt0, b0);
     load_c(kt0, c0);
     if constexpr (!GLDS) store_a(0, a_next);
+    if constexpr (GLDS) wait_vmcnt<0>();           // the DMA is invisible to the compiler's own waits
     __syncthreads();
 
     const int a_lane_off = GLDS ? l31 * STRIDE : l31 * STRIDE + half * 16;
@@ -414,6 +420,18 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
     auto step = [&](int kt, auto bufc, const BRaw<BITS> (&b_use)[KS], const CRaw& c_use, BRaw<BITS> (&b_fill)[KS], CRaw& c_fill) {
         constexpr int BUF = decltype(bufc)::value;
         const int ktn = min(kt + 1, kt1 - 1);          // last step re-loads itself (no branch in the pipeline)
+        if constexpr (GLDS) {
+            // The DMAs below are invisible to the compiler's vmcnt bookkeeping; any wait it emits while they are in flight is too
+            // strict by their number (in-order retirement).  So this step's weight words and group constants -- requested a whole
+            // step ago -- are claimed HERE, before anything new is issued: the compiler's exact wait lands on this line, and no
+            // wait of its own follows while the DMAs fly.
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < BWords<BITS>::n; ++i) asm volatile("" ::"v"(b_use[ks].w[i][0]), "v"(b_use[ks].w[i][1]));
+            asm volatile("" ::"v"(c_use.s), "v"((unsigned)c_use.z));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (GLDS) dma_a(ktn, BUF ^ 1);
         else if constexpr (!(VAR >= 8 && (VAR & 2))) load_a(ktn, a_next);
         load_b(ktn, b_fill);
@@ -437,6 +455,7 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
                     read_a(BUF, ks + 1, a[(ks + 1) & 1]);
                 } else {
                     if constexpr (!GLDS) store_a(BUF ^ 1, a_next);
+                    if constexpr (GLDS) wait_vmcnt<KS * (BITS == 8 ? 2 : 1) + 2>();     // this step's DMAs (see the end of step())
                     __syncthreads();
                     read_a(BUF ^ 1, 0, a_first);
                 }
@@ -510,6 +529,9 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
             }
         }
         if constexpr (!GLDS && !(VAR >= 8 && (VAR & 2))) store_a(BUF ^ 1, a_next);
+        // DMA-staged x: the next step's tile must have landed before anybody passes the barrier.  vmcnt retires in order and
+        // the step issued, after its DMAs, KS * (1 or 2) weight loads + 2 group-constant loads: those may stay in flight.
+        if constexpr (GLDS) wait_vmcnt<KS * (BITS == 8 ? 2 : 1) + 2>();
         if constexpr (!(VAR >= 8 && (VAR & 4))) __syncthreads();
     };
     for (int kt = kt0; kt < kt1; kt += 2) {
