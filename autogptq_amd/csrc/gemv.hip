@@ -910,10 +910,10 @@ __global__ void __launch_bounds__(1024, WPS) gemv_q4_stream_kernel(GemvStreamPar
         // small L2-resident loads first (they return first), then the DMA burst
 #if defined(GPTQ_STREAM_ABL) && (GPTQ_STREAM_ABL & 4)
         const u32x2 sraw = {0x14001400u + (unsigned)g, 0x14001400u};
-        const unsigned zw = 0x7777u;
+        const unsigned zw = 0x77777777u;
 #else
         const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * N + nload);
-        const unsigned zw = sg.qzeros[(size_t)g * zrow_words + (nload >> 3)] >> ((nload & 7) * 4);
+        const unsigned zw = sg.qzeros[(size_t)g * zrow_words + (nload >> 3)];       // raw word: nothing is computed on loaded values up here
 #endif
         u32x4 xr[U];
 #if defined(GPTQ_STREAM_ABL) && (GPTQ_STREAM_ABL & 1)
@@ -924,16 +924,23 @@ __global__ void __launch_bounds__(1024, WPS) gemv_q4_stream_kernel(GemvStreamPar
         for (int j = 0; j < U; ++j) xr[j] = *(const u32x4*)(xrow + (size_t)min(u0 + j, ue - 1) * 8);
 #endif
         if (base != ub) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // WAR: last iteration's ds_reads are done
+        // The burst goes out back to back: between the two fences there are only the DMAs and their address arithmetic.  Everything
+        // that CONSUMES a loaded value (the zero-point shift, the x permutes) sits below the second fence in source order -- hipcc
+        // had scheduled both into the burst, with an s_waitcnt for loads issued a few instructions earlier (a full memory latency)
+        // behind the first DMA.
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int ul = min(u0 + j, ue - 1);
             dma16_nt(qweight + (size_t)ul * N + nload, wq_lds + j * 1024);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned zw_ = zw >> ((nload & 7) * 4), s0_ = sraw[0], s1_ = sraw[1];
         f16x2 c1[4], c2[4];
         const f16x2 k960 = {(f16)960.f, (f16)960.f};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const unsigned z = (((zw >> (4 * c)) & 15u) + 1u) & zmask;
+            const unsigned z = (((zw_ >> (4 * c)) & 15u) + 1u) & zmask;
             c1[c] = as_f16x2(z * 0x00010001u + 0xE400E400u);        // -(1024+z)
             c2[c] = c1[c] + k960;                                   // -(64+z)
         }
@@ -987,7 +994,8 @@ __global__ void __launch_bounds__(1024, WPS) gemv_q4_stream_kernel(GemvStreamPar
         }(std::make_integer_sequence<int, U>{});
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const unsigned sh = (c & 1) ? (sraw[c >> 1] >> 16) : (sraw[c >> 1] & 0xffffu);
+            const unsigned sw = (c >> 1) ? s1_ : s0_;
+            const unsigned sh = (c & 1) ? (sw >> 16) : (sw & 0xffffu);
             const float sc = DType<T>::to_f32(__builtin_bit_cast(T, (unsigned short)sh));
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[c][m] = fmaf(sc, accg[c][m], acc[c][m]);
