@@ -321,7 +321,7 @@ def bench_eager(layers, xs, device, steps):
     return {"calls_per_step": len(layers), "us_per_call": round(1e6 * t / (steps * len(layers)), 2),
             "host_us_per_call": round(1e6 * t_issue / (steps * len(layers)), 2),
             "GB_per_s": round(bytes_step * steps / t / 1e9, 1), "tokens_per_s": round(M * steps / t, 1),
-            "note": "eager calls (torch.empty + ctypes + launch per call), no hipGraph"}
+            "note": "eager calls (torch.empty + C-ABI call + launch per call), no hipGraph"}
 
 
 def cpu_baseline(M, act_order, budget_s=20.0):
