@@ -65,8 +65,14 @@ bool want_gemm(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
     // M = 5..8 on wide layers: the GEMV needs two matrix-core passes per weight word there, and a wide N gives the tiled kernel
     // enough 256-column tiles to fill the chip (4096x11008, M = 8: 22.2 us GEMV, 17.8 us tiled; narrower layers: GEMV wins)
     const bool wide_small_batch = M >= 5 && L->bits == 4 && L->N > 8192 && L->epilogue == GPTQ_EPI_NONE;
-    if (M <= 8 && !wide_small_batch) return false;
+    if (M <= 4) return false;
     const GemmPlan g = plan_gemm(*L, M, t);
+    // M = 5..8: the streamed 64-column-strip kernel (one matrix-core pass for up to 16 rows, weights by LDS DMA) where it exists;
+    // layers with a fused epilogue keep the GEMV that applies it
+    // (and the 16-column-strip kernel on narrow layers: 4096x4096 M = 5 / 8: 7.3 / 7.9 us against the GEMV's 8.0 / 8.3)
+    // (28672x1024, M = 8: GEMV 14.8, 16-column strips 17.0 -- long K keeps the GEMV)
+    const bool small_batch_stream = g.supported && (g.stream64 || (g.strip16 && L->K <= 8192)) && L->epilogue == GPTQ_EPI_NONE;
+    if (M <= 8 && !wide_small_batch && !small_batch_stream) return false;
     // fp32 matrix-core kernel: 128 x 128 tiles and no K split -- with fewer than 64 tiles the 4-rows-per-pass GEMV is faster
     // (M = 64 on 4096 x 4096: 455 us on 32 tiles; profiles/r02_gemm_f32.log)
     if (g.supported && g.f32 && M <= 64 && (long)g.nbm * g.nbn < 64 && !(t && t->path == 3)) return false;
@@ -211,7 +217,7 @@ int gptq_gemm(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, 
     const WsView wv = split_ws(ws, ws_bytes);
     if (pl.workspace_bytes > 0 && wv.body_bytes < pl.workspace_bytes)
         return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + pl.workspace_bytes, ws ? ws_bytes : (size_t)0);
-    hipError_t e = launch_gemm(*L, pl, x, out, M, wv.body, (hipStream_t)stream);
+    hipError_t e = launch_gemm(*L, pl, x, out, M, wv.header, wv.body, (hipStream_t)stream);
     if (e != hipSuccess)
         return hip_fail(e, pl.kg == 2 ? "gptq_gemm launch (this kernel needs > 64 KiB of LDS: was gptq_init() called on this device?)"
                                       : "gptq_gemm launch");
@@ -424,9 +430,10 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
                  sp.u, sp.ksplit, sp.mt, sp.strips_total);
     } else if (want_gemm(&Lc, M, tune)) {
         const GemmPlan g = plan_gemm(Lc, M, tune);
-        const char* kern = g.f32 ? "f32_mfma" : (g.strip16 ? "strip16" : (g.skinny ? "skinny64" : "tiled"));
-        snprintf(out, out_bytes, "path=gemm kernel=%s mt=%d bk=%d kg=%d ksplit=%d tiles=%dx%d perm=%d dma=%d epilogue=%s", kern, g.mt, g.bk,
-                 g.kg == 2 ? 2 : 1, g.ksplit, g.nbm, g.nbn, g.use_seq ? 1 : 0, g.glds ? 1 : 0, unfused_epilogue ? "separate" : "none");
+        const char* kern = g.f32 ? "f32_mfma" : (g.stream64 ? "stream64" : (g.strip16 ? "strip16" : (g.skinny ? "skinny64" : "tiled")));
+        snprintf(out, out_bytes, "path=gemm kernel=%s mt=%d bk=%d kg=%d ksplit=%d tiles=%dx%d perm=%d dma=%d waves=%d u=%d epilogue=%s", kern, g.mt, g.bk,
+                 g.kg == 2 ? 2 : 1, g.ksplit, g.nbm, g.nbn, g.use_seq ? 1 : 0, (g.glds || g.stream64) ? 1 : 0, g.waves, g.u,
+                 unfused_epilogue ? "separate" : "none");
     } else {
         const GemvPlan v = plan_gemv(Lc, M, tune);
         const char* kern = v.mfma ? "mfma" : (v.mfmag ? "mfma_generic" : (v.direct ? "direct" : (v.fast ? "lds_staged" : "generic")));

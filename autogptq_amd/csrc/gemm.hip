@@ -46,6 +46,7 @@ struct GemmParams {
     int M, K, N, group_size, zero_mode;
     int nbm, nbn, ksplit, ksteps_total, ksteps_per_split;
     int qrows;        // rows of qweight (K/32*bits)
+    unsigned* tickets; // stream64: arrival tickets of the in-launch K-split combine, one per (strip, row tile)
     unsigned long long kpg_inv;   // ceil(2^32 / (group_size / BK)): group of K-step kt = (kt * kpg_inv) >> 32, exact for kt < 2^16
 };
 
@@ -864,6 +865,196 @@ __global__ void __launch_bounds__(1024) gemm_strip16_kernel(GemmParams p) {
     }
 }
 
+// ---- batched decode, 4 < M <= 64: 64-column strips, weights by LDS DMA, in-launch K-split combine -----------------------
+// The decode stream kernel's structure (gemv.hip: gemv_q4_stream_kernel) on the 16x16x32 matrix core.  One wave DMA
+// (global_load_lds_dwordx4, 1 KiB) is exactly one 32-deep K-step of a 64-column strip: 4 packed rows x 256 B, and lane
+// (j = l & 15, kg = l >> 4) lands -- and later reads back, lane-linear ds_read_b128, no conflict -- packed row kg of columns
+// 4j .. 4j+3.  Word t of those 16 bytes is the lane's B fragment (8 consecutive k of ONE column) of MFMA t, whose "column j"
+// is strip column 4j + t: four MFMAs per K-step and 16-row tile, all four fed by the same A fragment.  Nothing about the
+// weights touches a VGPR before it is consumed, so a workgroup keeps W x U KiB in flight (16 x 4 = 64 KiB) however many
+// accumulators the row tiles need -- which is what the register kernels this replaces ran out of (gemm_strip16_kernel: one dword
+// per lane and load; gemv MT = 8: one workgroup per CU): M = 8..64 on 4096 x 11008 ran at 21..27 us for 22.5 MB.
+//   A fragments: 16-byte loads of x from L2 per (K-step, row tile), requested before the DMA burst (x is M*K*2 bytes; a
+//   64-column strip re-reads it once: N/64 * M * K * 2 bytes of L2 traffic, 22 MB at M = 16 on 4096 x 11008);
+//   group constants: 8 B of scales + one zeros word per K-step, Deq1 set up again only when the wave's group changes;
+//   waves split the K range of the workgroup; cross-wave sum through LDS in fixed order (slabs alias the landing area);
+//   K slices of one tile are combined inside the launch like the decode kernel's: sc1 publish, ticket, last arriver sums
+//   the slices in index order.  Tickets: front of the workspace (gptq_mi355x.h), zero before and after every launch.
+__device__ __forceinline__ void lds_dma16_nt(const void* gsrc, unsigned lds_dst) {     // see common.cuh: lds_dma16 (this one: nontemporal)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <typename T> __device__ __forceinline__ u32x2 pack4(f32x4 v) {
+    struct { T a, b, c, d; } o{DType<T>::from_f32(v[0]), DType<T>::from_f32(v[1]), DType<T>::from_f32(v[2]), DType<T>::from_f32(v[3])};
+    return __builtin_bit_cast(u32x2, o);
+}
+
+template <typename T, int RT, int U>
+__global__ void __launch_bounds__(RT == 1 ? 1024 : 512) gemm_stream64_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, W = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j16 = lane & 15, kg = lane >> 4;
+    char* const wq = smem + (size_t)wave * (U * 1024);                        // this wave's DMA landing area
+    const unsigned wq_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(wq));
+    // logical block -> (tile, K slice): slices of one tile are adjacent logical ids (one XCD after the remap)
+    const int Lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = Lb / p.ksplit, ks = Lb - tile * p.ksplit;
+    const int strip = tile % p.nbn, mtile = tile / p.nbn;
+    const int m0 = mtile * (16 * RT);
+    const int n0 = strip * 64 + j16 * 4;
+    const bool col_ok = n0 < p.N;
+    const int nload = col_ok ? n0 : 0;
+    const int S = p.K >> 5;
+    const int b0 = ks * p.ksteps_per_split, b1 = min(b0 + p.ksteps_per_split, S);
+    const int spw = (b1 - b0 + W - 1) / W;
+    const int ws = b0 + wave * spw, we = min(ws + spw, b1);
+
+    const unsigned* __restrict__ qsrc = p.qweight + (size_t)kg * p.N + nload;          // + step * 4 * N
+    const T* __restrict__ scales = (const T*)p.scales + nload;
+    const unsigned* __restrict__ zsrc = p.qzeros + (nload >> 3);
+    const unsigned z_sh = ((unsigned)nload & 7u) * 4u;                                  // 0 or 16
+    const int zrow_words = p.N >> 3;
+    const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
+    const unsigned gsteps = (unsigned)p.group_size >> 5;                                // K-steps per group (group_size % 32 == 0)
+    const unsigned short* a_src[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+        a_src[rt] = (const unsigned short*)p.x + (size_t)min(m0 + rt * 16 + j16, p.M - 1) * p.K + kg * 8;
+
+    f32x4 acc[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    Deq1<T> dq[4];
+    int g_cur = -1;
+
+    for (int s0 = ws; s0 < we; s0 += U) {
+        u32x2 sraw[U];
+        unsigned zw[U];
+        u32x4 a[U][RT];
+        int gj[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {                             // small L2-resident loads first: they return first
+            const int sj = min(s0 + j, we - 1);
+            gj[j] = (int)((unsigned)sj / gsteps);
+            sraw[j] = *(const u32x2*)(scales + (size_t)gj[j] * p.N);
+            zw[j] = zsrc[(size_t)gj[j] * zrow_words];             // raw word: nothing is computed on loaded values up here
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int sj = min(s0 + j, we - 1);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) a[j][rt] = *(const u32x4*)(a_src[rt] + (size_t)sj * 32);
+        }
+        if (s0 != ws) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // WAR: last pass's ds_reads are done
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int sj = min(s0 + j, we - 1);
+            lds_dma16_nt(qsrc + (size_t)sj * 4 * p.N, wq_lds + j * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // step j is consumed as soon as DMA j has landed: vmcnt retires in order and the U DMAs are the wave's youngest VMEM
+        // operations, so "at most U-1-j outstanding" means DMAs 0..j and every older load are complete
+        [&]<int... J>(std::integer_sequence<int, J...>) {
+            (([&] {
+                 constexpr int j = J;
+                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(U - 1 - j) : "memory");
+                 const u32x4 qv = *(const u32x4*)(wq + j * 1024 + lane * 16);
+                 if (gj[j] != g_cur) {                            // wave-uniform: the step index depends on the wave id only
+                     g_cur = gj[j];
+                     const unsigned zz = zw[j] >> z_sh;
+#pragma unroll
+                     for (int t = 0; t < 4; ++t) {
+                         const unsigned sw = sraw[j][t >> 1];
+                         dq[t].setup((t & 1) ? (sw >> 16) : (sw & 0xffffu), (((zz >> (4 * t)) & 15u) + 1u) & zmask);
+                     }
+                 }
+                 const bool live = s0 + j < we;
+                 u32x4 b[4];
+#pragma unroll
+                 for (int t = 0; t < 4; ++t) b[t] = dq[t].frag(qv[t]);
+#pragma unroll
+                 for (int rt = 0; rt < RT; ++rt) {
+                     const u32x4 x4 = a[j][rt];
+                     u32x4 o;                                     // x in the slot order of the fragments: k0,k4,k1,k5,k2,k6,k3,k7
+                     o[0] = __builtin_amdgcn_perm(x4[2], x4[0], 0x05040100u);
+                     o[1] = __builtin_amdgcn_perm(x4[2], x4[0], 0x07060302u);
+                     o[2] = __builtin_amdgcn_perm(x4[3], x4[1], 0x05040100u);
+                     o[3] = __builtin_amdgcn_perm(x4[3], x4[1], 0x07060302u);
+                     if (!live) o = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                     for (int t = 0; t < 4; ++t) acc[rt][t] = Mma16<T>::run(o, b[t], acc[rt][t]);
+                 }
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, U>{});
+    }
+
+    // ---- cross-wave sum (LDS slabs over the landing area, fixed order), then write or publish ---------------------------
+    // C/D layout of the 16x16 MFMA: column = lane & 15 (-> strip column 4j + t), row = 4 * (lane >> 4) + r.  A lane writes, per
+    // (row tile, r), the float4 over t = its 4 adjacent columns of one row: lane-linear 16-byte LDS accesses both ways.
+    __syncthreads();                                              // every wave is done with its landing area
+    f32x4* const slab = (f32x4*)smem;                             // [W][RT * 4][64]
+    constexpr int E = RT * 4 * 64;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            slab[(size_t)wave * E + (rt * 4 + r) * 64 + lane] = f32x4{acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]};
+    __syncthreads();
+    unsigned* const flag = (unsigned*)(slab + (size_t)W * E);
+    const size_t pslab = (size_t)p.M * p.N;
+    for (int e = tid; e < E; e += blockDim.x) {
+        f32x4 v = slab[e];
+        for (int w = 1; w < W; ++w) v += slab[(size_t)w * E + e];
+        const int ln = e & 63, rr = e >> 6;                       // rr = rt * 4 + r
+        const int m = m0 + (rr >> 2) * 16 + 4 * (ln >> 4) + (rr & 3);
+        const int n = strip * 64 + (ln & 15) * 4;
+        if (m >= p.M || n >= p.N) continue;
+        if (p.ksplit > 1) {
+            float* dst = p.partial + (size_t)ks * pslab + (size_t)m * p.N + n;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) __hip_atomic_store(dst + t, v[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+        } else {
+            if (p.bias) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] += DType<T>::to_f32(((const T*)p.bias)[n + t]);
+            }
+            *(u32x2*)((T*)p.out + (size_t)m * p.N + n) = pack4<T>(v);
+        }
+    }
+    if (p.ksplit > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // every publishing wave drains its stores
+        __syncthreads();
+        if (tid == 0) *flag = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != (unsigned)(p.ksplit - 1)) return;                        // not the last slice of this tile
+        for (int e = tid; e < E; e += blockDim.x) {
+            const int ln = e & 63, rr = e >> 6;
+            const int m = m0 + (rr >> 2) * 16 + 4 * (ln >> 4) + (rr & 3);
+            const int n = strip * 64 + (ln & 15) * 4;
+            if (m >= p.M || n >= p.N) continue;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < p.ksplit; ++k) {                              // fixed order, sc1 loads (bypass this XCD's non-coherent L2 lines)
+                const float* src = p.partial + (size_t)k * pslab + (size_t)m * p.N + n;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] += __hip_atomic_load(src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (p.bias) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] += DType<T>::to_f32(((const T*)p.bias)[n + t]);
+            }
+            *(u32x2*)((T*)p.out + (size_t)m * p.N + n) = pack4<T>(v);
+        }
+        if (tid == 0) __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+}
+
 // ---- fp32 I/O: exact-f32 matrix core (v_mfma_f32_32x32x2_f32), any bit width ---------------------------------------------
 // The reference's Python path is dtype-agnostic (qlinear_cuda_old.py:291-355): an fp32 layer (use_cuda_fp16=False, or the
 // act-order natives that force x.float(), qlinear_cuda.py:216-250) dequantises W = scales * (w - z) in fp32 and multiplies in
@@ -1056,10 +1247,24 @@ static hipError_t grant_lds() {
 }
 
 // Per-device, once, outside any capture (gptq_init): kernels whose dynamic LDS exceeds the 64 KiB default.
+template <typename T, int RT, int U> static hipError_t grant_stream64() {
+    return hipFuncSetAttribute((const void*)gemm_stream64_kernel<T, RT, U>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <typename T> static hipError_t grant_stream64_t() {
+    hipError_t e = hipSuccess;
+    auto acc = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    acc(grant_stream64<T, 1, 2>()); acc(grant_stream64<T, 1, 4>()); acc(grant_stream64<T, 1, 8>());
+    acc(grant_stream64<T, 2, 2>()); acc(grant_stream64<T, 2, 4>());
+    acc(grant_stream64<T, 4, 1>()); acc(grant_stream64<T, 4, 2>()); acc(grant_stream64<T, 4, 4>());
+    return e;
+}
+
 hipError_t init_gemm_device() {
     hipError_t e = grant_lds<4, f16, 4, 64, 1, true, true, 2>();
     if (e == hipSuccess) e = grant_lds<4, f16, 4, 64, 1, false, false, 2>();
     if (e == hipSuccess) e = grant_lds<4, bf16, 4, 64, 1, false, false, 2>();
+    if (e == hipSuccess) e = grant_stream64_t<f16>();
+    if (e == hipSuccess) e = grant_stream64_t<bf16>();
     return e;
 }
 
@@ -1097,6 +1302,54 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     // tiled kernel enough 256-column tiles to fill the chip without help.
     pl.skinny = (force_skinny == 1) || (force_skinny == 0 && M <= 64 && (L.N + 255) / 256 < 32);
     if (pl.skinny && M > 128) pl.skinny = false;
+    // batched decode (4 < M <= 64, 4-bit): 64-column strips, weights by LDS DMA, K slices combined inside the launch
+    // Measured (tools/stream64_sweep.py, profiles/r02_stream64_sweep*.log; us per launch, M = 8 / 16 / 32 / 64, best older kernel -> this one):
+    //   4096x11008  18.2 / 19.0 / 23.4 / 26.5 -> 10.3 / 11.2 / 15.1 / 23.4   (172 strips, no K split)
+    //   11008x4096  16.7 / 20.2 / 22.6 / 27.6 -> 11.7 / 12.1 / 16.7 / 25.7   (64 strips x 4 K slices)
+    //   5120x5120   15.7 / 15.9 / 19.0 / 23.1 ->  9.8 / 10.3 / 13.8 / 19.9   (80 x 3)      8192x3584  13.2 / 15.2 / 17.3 / 21.7 -> 10.4 / 11.1 / 14.1 / 21.2 (56 x 4)
+    //   3584x8192   12.6 / 12.8 / 14.0 / 18.7 ->  9.4 /  9.8 / 13.4 / 19.5   (128 x 2)     8192x28672 51.7 / 54.3 / 65.3 / 72.2 -> 33.5 / 36.5 / 50.2 / 81.0 (448 x 1)
+    //   4096x4096    7.9 /  8.9 / 12.2 / 15.7 ->  8.7 /  9.2 / 12.1 / 16.7   (64 x 4: the 16-column / skinny kernels stay)
+    //   8192x1024    8.9 /  9.3 / 10.8 / 14.2 ->  9.5 / 10.1 / 12.2 / 17.9   (16 x 4..8: too few workgroups; older kernels stay)
+    // K slices: as many as keep strips x slices <= 256 (one 16-wave workgroup per CU: a 257th starts a second round; 8192x3584 with
+    // 5 slices = 280 workgroups: 16.0 us, with 4 = 224: 10.4), none from 160 strips up (the combine costs more than the idle CUs).
+    const long s64_tiles = (L.N + 63) / 64;                       // one row tile (16 / 32 / 64 rows) covers M <= 64
+    int s64_ks = s64_tiles >= 160 ? 1 : (int)(256 / s64_tiles);
+    if (s64_ks > 8) s64_ks = 8;
+    if (s64_ks < 1) s64_ks = 1;
+    while (s64_ks > 1 && (L.K / 32) / s64_ks < 8) --s64_ks;       // at least 8 K-steps per slice
+    const bool s64_small = L.N <= 4096 && L.K <= 4096;            // <= 8.8 MB: one round of 16-column strips / the skinny kernel is as fast
+    const bool s64_pays = s64_tiles * s64_ks >= 160 && !s64_small && (M <= 32 || L.N < 12288);   // 33+ rows on very wide layers: the tiled kernel
+    pl.stream64 = L.bits == 4 && M <= 64 && (force_skinny == 4 || (force_skinny == 0 && M >= 5 && s64_pays)) && s64_tiles <= 16384;
+    if (pl.stream64) {
+        pl.skinny = false;
+        pl.mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);                  // row tiles of 16 per workgroup
+        pl.bk = 32;
+        pl.bm = 16 * pl.mt;
+        pl.bn = 64;
+        pl.nbm = (M + pl.bm - 1) / pl.bm;
+        pl.nbn = (L.N + 63) / 64;
+        int waves = (tune && tune->waves > 0) ? tune->waves : (pl.mt == 1 ? 16 : 8);
+        if (pl.mt > 1 && waves > 8) waves = 8;                    // 2+ row tiles: > 128 registers per lane (__launch_bounds__(512)); slabs W x RT x 4 KiB <= 128 KiB
+        pl.waves = waves;
+        int u = (tune && tune->reserved[0] > 0) ? tune->reserved[0] : 2;      // deeper bursts measured no faster: the strips are not latency bound
+        if (pl.mt == 1) u = u >= 8 ? 8 : (u >= 4 ? 4 : 2);
+        else if (pl.mt == 2) u = u >= 4 ? 4 : 2;
+        else u = u >= 4 ? 4 : (u >= 2 ? 2 : 1);
+        pl.u = u;
+        const int S = L.K / 32;
+        int ks = (tune && tune->ksplit > 0 && tune->path == 3) ? tune->ksplit : 0;
+        if (!ks) {
+            ks = s64_ks;
+            while (ks > 1 && S / ks < waves) --ks;                // every wave gets at least one K-step
+        }
+        if (ks > S) ks = S;
+        if (ks < 1) ks = 1;
+        pl.ksteps_total = S;
+        pl.ksteps_per_split = (S + ks - 1) / ks;
+        pl.ksplit = (S + pl.ksteps_per_split - 1) / pl.ksteps_per_split;
+        pl.workspace_bytes = pl.xperm_bytes + (pl.ksplit > 1 ? (size_t)pl.ksplit * M * L.N * sizeof(float) : 0);
+        return pl;
+    }
     // 16-column strips on the 16x16x32 matrix core: 4-bit fp16/bf16, M <= 64
     const bool strip16_ok = L.bits == 4 && M <= 64 && L.group_size % 32 == 0 && L.K % 32 == 0 && L.N % 16 == 0;
     pl.strip16 = strip16_ok && (force_skinny == 3 || (force_skinny == 0 && M <= 16 && L.N <= 8192));
@@ -1201,6 +1454,29 @@ static hipError_t launch_strip16_one(const GemmPlan& pl, const GemmParams& p, hi
     return hipGetLastError();
 }
 
+template <typename T, int RT, int U>
+static hipError_t launch_stream64_one(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
+    const size_t land = (size_t)pl.waves * U * 1024, slabs = (size_t)pl.waves * RT * 4096;
+    const size_t lds = (land > slabs ? land : slabs) + 16;       // > 64 KiB for most shapes: granted by init_gemm_device() (gptq_init)
+    hipLaunchKernelGGL((gemm_stream64_kernel<T, RT, U>), dim3(pl.nbm * pl.nbn * pl.ksplit), dim3(pl.waves * 64), lds, st, p);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_stream64(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
+    switch (pl.mt * 16 + pl.u) {
+        case 16 + 2: return launch_stream64_one<T, 1, 2>(pl, p, st);
+        case 16 + 4: return launch_stream64_one<T, 1, 4>(pl, p, st);
+        case 16 + 8: return launch_stream64_one<T, 1, 8>(pl, p, st);
+        case 32 + 2: return launch_stream64_one<T, 2, 2>(pl, p, st);
+        case 32 + 4: return launch_stream64_one<T, 2, 4>(pl, p, st);
+        case 64 + 1: return launch_stream64_one<T, 4, 1>(pl, p, st);
+        case 64 + 2: return launch_stream64_one<T, 4, 2>(pl, p, st);
+        case 64 + 4: return launch_stream64_one<T, 4, 4>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 template <typename T>
 static hipError_t launch_strip16(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
     switch (pl.mt) {
@@ -1225,6 +1501,7 @@ static hipError_t launch_skinny(const GemmPlan& pl, const GemmParams& p, hipStre
 template <int BITS, typename T>
 static hipError_t launch_bits(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
     if constexpr (BITS == 4) {
+        if (pl.stream64) return launch_stream64<T>(pl, p, st);
         if (pl.strip16) return launch_strip16<T>(pl, p, st);
     }
     if (pl.skinny) return launch_skinny<BITS, T>(pl, p, st);
@@ -1274,7 +1551,7 @@ static hipError_t launch_t(const gptq_layer_t& L, const GemmPlan& pl, const Gemm
 }
 
 hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x, void* out, int M,
-                       void* workspace, hipStream_t st) {
+                       void* ws_header, void* workspace, hipStream_t st) {
     if (!pl.supported) return hipErrorNotSupported;
     GemmParams p{};
     p.qweight = pl.use_seq ? L.qweight_seq : L.qweight;
@@ -1314,9 +1591,10 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
         p.x = workspace;
     }
     p.partial = (float*)((char*)workspace + pl.xperm_bytes);
+    p.tickets = (unsigned*)ws_header;
     e = (L.dtype == GPTQ_F16) ? launch_t<f16>(L, pl, p, st) : launch_t<bf16>(L, pl, p, st);
     if (e != hipSuccess) return e;
-    if (pl.ksplit > 1) {
+    if (pl.ksplit > 1 && !pl.stream64) {
         const size_t total4 = (size_t)M * L.N / 4;
         int blocks = (int)((total4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;

@@ -513,7 +513,7 @@ template <> struct Mma4<bf16> {
 // kernel here has -- a layer whose fields equal their zero-points gives exactly 0 -- and failed the reference's
 // "range/range/range" value pattern (tests/test_hpu_linear.py:107) with scales ~ 10^4.)
 template <int LN, int MT, int U, bool PAIR = false, bool PERM = false, typename T = f16>
-__global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && (!PERM || MT == 1) && ((U == 1 && MT <= 4) || (U == 2 && MT <= 2))) ? 8 : 4) gemv_q4_f16_mfma_kernel(GemvParams p) {
+__global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && !PERM && ((U == 1 && MT <= 4) || (U == 2 && MT <= 2))) ? 8 : 4) gemv_q4_f16_mfma_kernel(GemvParams p) {
     constexpr bool BF = std::is_same_v<T, bf16>;
     unsigned m_lo, m_hi, magic;                                   // see the dequant below
     asm("s_mov_b32 %0, 0x000f000f" : "=s"(m_lo));
@@ -1309,9 +1309,14 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     pl.ksplit = ks;
     pl.units_per_split = (pl.units_total + ks - 1) / ks;
     int waves = (tune && tune->waves) ? tune->waves : 0;
+    const bool act_m1 = pl.mfma && pl.use_seq && M == 1 && L.epilogue != GPTQ_EPI_SILU_MUL;
     if (!waves) {
         waves = (pl.units_per_split + wr - 1) / wr;   // one unit per lane if possible
         if (waves > 16) waves = 16;
+        // act-order decode: 8 waves with 2-4 rows per lane beat 16 waves with 1-2 on all three Llama-7B shapes (tools/act_ab.py,
+        // profiles/r02_act_order_decode_ab.log: fp16 5.9 / 13.5 / 12.0 -> 5.1 / 9.8 / 9.6 us, bf16 6.5 / 15.5 / 14.8 -> 5.4 / 11.1 / 11.1):
+        // two workgroups share a CU, so one gathers x through perm[] while the other's loads are in flight
+        if (act_m1 && waves > 8) waves = 8;
         if (waves < 1) waves = 1;
     }
     pl.waves = waves;
@@ -1337,8 +1342,8 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
         int want = pl.units_per_split >= 1024 ? 1 : 2;             // long K: more, shorter iterations pipeline better
         // more than one workgroup per CU only fits with <= 64 VGPRs: U = 1 once 3+ rows of x are carried
         if (pl.mfma && pl.mt == 4 && (long)pl.strips * pl.mtiles > 256) want = 1;
-        if (pl.use_seq) want = (M == 1 && !(L.epilogue == GPTQ_EPI_SILU_MUL)) ? (L.dtype == GPTQ_BF16 ? 4 : 8) : 2;   // bf16: U = 8 spills   // act-order: the x gather is a dependent
-                                                                    // round trip per iteration -> as few iterations as possible
+        // act-order: the x gather is a dependent round trip per iteration -> few iterations; bf16 pays conversions per row, U = 2
+        if (pl.use_seq) want = act_m1 ? ((L.dtype == GPTQ_BF16 && L.K <= 8192) ? 2 : 4) : 2;
         int u = 1;
         while (u * 2 <= per_lane && u * 2 <= gu && u * 2 <= 8 && (pl.mfma || u * 2 * pl.mt <= 8) &&
                pl.units_per_split % (u * 2) == 0 && (tune && tune->reserved[0] > 0 ? u * 2 <= tune->reserved[0] : u * 2 <= want))

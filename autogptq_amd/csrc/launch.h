@@ -28,7 +28,8 @@ struct GemmPlan {
     bool strip16;             // 8 < M <= 64, 4-bit: 16-column strips on v_mfma_f32_16x16x32 (mt = row tiles of 16)
     bool f32;                 // fp32 I/O: exact-f32 matrix core kernel (128 x 128 tiles)
     bool skinny;              // weight-streaming decomposition for 8 < M <= 128 (64-column strips, waves split K)
-    int waves, variant;
+    bool stream64;            // batched decode 4 < M <= 64, 4-bit: 64-column strips by LDS DMA, in-launch K-split combine (u = K-steps in flight per wave)
+    int waves, variant, u;
     int kg;                   // K groups inside a workgroup (2 = 8 waves, two K halves summed through LDS)
     int mt, bk, bm, bn;       // row tiles per wave, K-step, workgroup tile
     int nbm, nbn, ksplit, ksteps_total, ksteps_per_split;
@@ -37,7 +38,7 @@ struct GemmPlan {
 };
 GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune);
 hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x, void* out, int M,
-                       void* workspace, hipStream_t st);
+                       void* ws_header, void* workspace, hipStream_t st);
 
 // Streamed GEMV (gemv_q4_stream_kernel): 1..4 plain 4-bit layers that read the same x, one launch.
 constexpr size_t WS_HEADER_BYTES = 65536;      // front of every workspace: arrival tickets of the in-launch K-split combine (kept zero)

@@ -301,6 +301,24 @@ def bench_config5(device, steps):
     return res
 
 
+def bench_batched(device, steps):
+    """Batched decode (the reference's kernel switch sits at 8 / 50 rows: qlinear_cuda.py:34, q_gemm.cu:118): M = 16 and 64 on the
+    three Llama-7B shapes, int4 g128, distinct layers beyond the Infinity Cache, HIP events, algorithmic GB/s."""
+    res = {}
+    for M in (16, 64):
+        for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
+            n = max(4, -(-(320 << 20) // (K * N // 2)))
+            ls = [("b", K, N, make_layer(K, N, device, seed=7000 + i)) for i in range(n)]
+            xs = {K: (torch.rand(M, K, device=device) - 0.5).half()}
+            per = _time_layers(ls, xs, device, max(3, steps // 2))
+            ab = algorithmic_bytes(K, N, M)
+            res[f"M{M}_{K}x{N}"] = {"us": round(per * 1e6, 2), "GB_per_s": round(ab / per / 1e9, 1), "frac": round(ab / per / 1e9 / HBM_PEAK_GBS, 4),
+                                     "TFLOP_s": round(2 * M * K * N / per / 1e12, 1), "plan": _plan_of(ls, K, N, M)}
+            del ls, xs
+            torch.cuda.empty_cache()
+    return res
+
+
 def bench_eager(layers, xs, device, steps):
     """The same 224 layers called one by one through QuantLinear.forward with no graph: what the reference's callers do
     (generate() under inference_mode, auto_gptq/modeling/_base.py:415-418).  Wall clock per call incl. Python + ctypes."""
@@ -588,7 +606,8 @@ def main():
                 out["fused_callers"] = {"error": repr(e)[:300]}
         if not prefill and world == 1 and not args.no_extras:
             for name, fn in (("prefill", lambda: bench_prefill(device, max(3, args.steps // 4))),
-                             ("config5", lambda: bench_config5(device, args.steps))):
+                             ("config5", lambda: bench_config5(device, args.steps)),
+                             ("batched_decode", lambda: bench_batched(device, args.steps))):
                 try:
                     torch.cuda.empty_cache()
                     out[name] = fn()

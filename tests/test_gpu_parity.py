@@ -1055,3 +1055,37 @@ def test_fp32_gemm_vs_oracle(bits, gs, K, N, M, act):
     with torch.no_grad():
         yg = q(x[:8].to(DEV))
     _assert_close(yg, y[:8].double(), y64, torch.float32, K, "fp32 gemv rows vs gemm rows")
+
+
+# ------------------------------------------------------------------------- batched decode: 64-column strips by LDS DMA
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("waves,u,ksplit", [(0, 0, 0), (16, 8, 1), (8, 2, 3), (4, 4, 2), (2, 1, 5), (8, 4, 8)])
+@pytest.mark.parametrize("M,K,N,gs,act", [(5, 512, 96, 128, False), (8, 4096, 1024, 128, True), (16, 1024, 256, 32, False),
+                                          (17, 1024, 160, 64, True), (32, 2048, 512, 128, False), (50, 4096, 1056, 128, True),
+                                          (64, 224, 64, 32, False), (33, 11008, 512, 128, False)])
+def test_stream64_batched_decode_kernel(M, K, N, gs, act, dtype, waves, u, ksplit):
+    """4 < M <= 64, 4-bit: gemm_stream64_kernel (tuning.reserved[2] = 4; the default in that range) against the fp64 oracle for
+    default and forced launch geometries (waves x K-steps in flight x in-launch K split, ragged last strip: N = 96 / 160 / 1056,
+    ragged row tile, K ranges that do not divide by waves x u, groups of one K-step), with one-hot rows (the exact dequantised
+    rows come back: catches any row / column / k-slot mix-up of the fragment layouts), twice (tickets reset) and bit-reproducible."""
+    L = O.random_quant_layer(K, N, 4, gs, act_order=act, seed=M + K + N, bias=True, dtype=dtype)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, gs, zero_mode="wrap")
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype)
+    y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP)
+    t = _tuning(path=3, waves=waves, ksplit=ksplit)
+    t.reserved[0], t.reserved[2] = u, 4
+    q.post_init()
+    d = _lib.describe_plan(q._layer, M, t)
+    assert d["kernel"] == "stream64", d
+    with torch.no_grad():
+        y, yb = q(x.to(DEV), tuning=t), q(x.to(DEV), tuning=t)
+    assert torch.equal(y, yb)
+    _assert_close(y, y64, y64, dtype, K, f"stream64 {d} vs f64")
+    ks = (torch.arange(M) * 37 + 5) % K
+    xo = torch.zeros(M, K, dtype=dtype)
+    xo[torch.arange(M), ks] = 1.0
+    with torch.no_grad():
+        yo = q(xo.to(DEV), tuning=t).cpu()
+    W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], 4, O.ZERO_WRAP)
+    expect = (W[ks].float() + L["bias"].float()).to(dtype)
+    assert torch.equal(yo, expect)

@@ -288,13 +288,26 @@ def test_dispatch_rules_are_the_measured_ones():
     assert _plan(4096, 4096, 2048, dtype=2)["kernel"] == "f32_mfma" and _plan(4096, 11008, 65, dtype=2, bits=3, gs=32)["kernel"] == "f32_mfma"
     assert _plan(4096, 4096, 64, dtype=2)["path"] == "gemv"          # 32 tiles: the 4-rows-per-pass GEMV is faster
     assert _plan(4096, 4096, 8, dtype=2)["path"] == "gemv"
-    # rows of x: GEMV up to 8 (two passes for 5..8), except wide layers where 5..8 rows go to the tiled kernel
-    assert _plan(4096, 4096, 4)["mt"] == 4 and _plan(4096, 4096, 8)["mt"] == 8 and _plan(4096, 4096, 8)["path"] == "gemv"
-    assert _plan(4096, 11008, 8)["path"] == "gemm" and _plan(4096, 11008, 8)["kernel"] == "tiled" and _plan(4096, 11008, 4)["path"] == "gemv"
-    # batched decode: strips up to 16 rows, 64-column skinny up to 64 rows on narrow layers, tiled on wide ones
+    # rows of x: GEMV up to 4; 5..8 rows: one matrix-core pass over 16 rows (16-column strips on narrow layers, the streamed
+    # 64-column-strip kernel elsewhere) unless the layer has a fused epilogue (the GEMV applies it) or K is long and N small
+    assert _plan(4096, 4096, 4)["mt"] == 4 and _plan(4096, 4096, 4)["path"] == "gemv"
+    assert _plan(4096, 4096, 8)["kernel"] == "strip16" and _plan(4096, 11008, 4)["path"] == "gemv"
+    assert _plan(4096, 22016, 8, epilogue=1)["path"] == "gemv" and _plan(28672, 1024, 8)["path"] == "gemv"
+    # batched decode, 4 < M <= 64: the streamed 64-column-strip kernel when strips x K slices fill 160..256 workgroups
+    p = _plan(4096, 11008, 8)
+    assert (p["kernel"], p["ksplit"], p["tiles"], p["waves"], p["mt"]) == ("stream64", 1, "1x172", 16, 1), p
+    p = _plan(11008, 4096, 16)
+    assert (p["kernel"], p["ksplit"], p["tiles"]) == ("stream64", 4, "1x64"), p
+    assert _plan(8192, 3584, 16)["ksplit"] == 4 and _plan(5120, 5120, 16)["ksplit"] == 3 and _plan(3584, 8192, 16)["ksplit"] == 2
+    p = _plan(4096, 11008, 64)
+    assert (p["kernel"], p["mt"], p["waves"]) == ("stream64", 4, 8), p
+    assert _plan(4096, 11008, 32)["mt"] == 2 and _plan(4096, 11008, 16, act=True)["kernel"] == "stream64" and _plan(4096, 11008, 16, dtype=1)["kernel"] == "stream64"
+    assert _plan(8192, 28672, 32)["kernel"] == "stream64" and _plan(8192, 28672, 64)["kernel"] == "tiled"       # 33+ rows on very wide layers
+    # ... small layers keep the older kernels: 16-column strips up to 16 rows, 64-column skinny up to 64 rows
     assert _plan(4096, 4096, 9)["kernel"] == "strip16" and _plan(4096, 4096, 16)["kernel"] == "strip16"
     assert _plan(4096, 4096, 17)["kernel"] == "skinny64" and _plan(4096, 4096, 64)["kernel"] == "skinny64"
-    assert _plan(4096, 11008, 16)["kernel"] == "tiled" and _plan(4096, 11008, 64)["kernel"] == "tiled"
+    assert _plan(8192, 1024, 16)["kernel"] == "strip16"
+    assert _plan(4096, 11008, 16, bits=8, gs=32)["kernel"] == "tiled" and _plan(4096, 11008, 65)["kernel"] == "tiled"
     assert _plan(4096, 4096, 16, bits=8, gs=32)["kernel"] == "skinny64"          # the 16-column-strip kernel is 4-bit only
     # prefill: 128 x 256 tiles, 64-deep K-steps; two K groups per workgroup when there is at most one tile per CU
     p = _plan(4096, 4096, 2048)
