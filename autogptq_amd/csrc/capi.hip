@@ -277,6 +277,17 @@ size_t gptq_workspace_bytes_multi(const gptq_layer_t* const* layers, int n_layer
     return gptq_workspace_bytes_multi_ex(layers, n_layers, M, nullptr);
 }
 
+// Batched decode of 2..4 layers sharing x in ONE gemm_stream64_kernel launch: by the planner's measured preference, or forced
+// with tuning.path = 3 and tuning.reserved[2] = 4.
+static bool want_stream64_multi(const gptq_layer_t* const* layers, int n, int M, const gptq_tuning_t* t) {
+    if (n < 2 || n > 4 || M > 64) return false;
+    const bool forced = t && t->path == 3 && t->reserved[2] == 4;
+    if (t && t->path != 0 && !forced) return false;
+    if (M <= 4 && !forced) return false;                         // up to 4 rows: the streamed GEMV (or layer by layer)
+    const Stream64Plan sp = plan_stream64(layers, n, M, t);
+    return sp.ok && (sp.pays || forced);
+}
+
 size_t gptq_workspace_bytes_multi_ex(const gptq_layer_t* const* layers, int n_layers, int M, const gptq_tuning_t* tune) {
     if (!layers || n_layers <= 0 || M <= 0) return 0;
     for (int i = 0; i < n_layers; ++i)
@@ -285,6 +296,10 @@ size_t gptq_workspace_bytes_multi_ex(const gptq_layer_t* const* layers, int n_la
     if (n_layers <= 4) {
         const StreamPlan sp = plan_stream(layers, n_layers, M, tune);
         if (sp.ok && multi_preferred(layers, n_layers, M)) return sp.partial_bytes ? WS_HEADER_BYTES + sp.partial_bytes : 0;
+    }
+    if (want_stream64_multi(layers, n_layers, M, tune)) {
+        const Stream64Plan sp = plan_stream64(layers, n_layers, M, tune);
+        return sp.partial_bytes ? WS_HEADER_BYTES + sp.partial_bytes : 0;
     }
     for (int i = 0; i < n_layers; ++i) need = std::max(need, gptq_workspace_bytes_ex(layers[i], M, nullptr));
     return need;
@@ -312,6 +327,17 @@ int gptq_forward_multi_ex(const gptq_layer_t* const* layers, int n_layers, const
         if (sp.ok && multi_preferred(layers, n_layers, M)) return stream_call(layers, n_layers, sp, x, outs, M, ws, ws_bytes, stream);
         if (tune && tune->path == 6) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 6: these layers / this launch shape do not fit the streamed GEMV");
     }
+    if (want_stream64_multi(layers, n_layers, M, tune)) {
+        const Stream64Plan sp = plan_stream64(layers, n_layers, M, tune);
+        const WsView wv = split_ws(ws, ws_bytes);
+        if (sp.partial_bytes > 0 && wv.body_bytes < sp.partial_bytes)
+            return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + sp.partial_bytes, ws ? ws_bytes : (size_t)0);
+        hipError_t e = launch_stream64(layers, sp, x, outs, M, wv.header, wv.body, nullptr, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "gptq batched-decode launch (needs > 64 KiB of LDS: was gptq_init() called on this device?)");
+        return GPTQ_OK;
+    }
+    if (tune && tune->path == 3 && tune->reserved[2] == 4)
+        return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 3 / reserved[2] = 4: these layers do not fit one batched-decode launch (2..4 plain 4-bit layers, M <= 64)");
     for (int i = 0; i < n_layers; ++i) {           // anything the one-launch kernel does not cover: the same result, layer by layer
         int rc = gptq_forward_ex(layers[i], x, outs[i], M, ws, ws_bytes, stream, nullptr);
         if (rc) return rc;

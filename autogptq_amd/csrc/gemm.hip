@@ -46,7 +46,6 @@ struct GemmParams {
     int M, K, N, group_size, zero_mode;
     int nbm, nbn, ksplit, ksteps_total, ksteps_per_split;
     int qrows;        // rows of qweight (K/32*bits)
-    unsigned* tickets; // stream64: arrival tickets of the in-launch K-split combine, one per (strip, row tile)
     unsigned long long kpg_inv;   // ceil(2^32 / (group_size / BK)): group of K-step kt = (kt * kpg_inv) >> 32, exact for kt < 2^16
 };
 
@@ -891,32 +890,55 @@ template <typename T> __device__ __forceinline__ u32x2 pack4(f32x4 v) {
     return __builtin_bit_cast(u32x2, o);
 }
 
+struct S64Seg {
+    const unsigned* qweight;
+    const unsigned* qzeros;
+    const void* scales;
+    const void* bias;
+    void* out;
+    int N;         // columns of this layer
+    int blk_end;   // cumulative strip count up to and including this layer
+    int col0;      // first column of this layer in the concatenated partial slab
+    int pad_;
+};
+struct S64Params {
+    S64Seg seg[4];       // up to four layers that read the same x (gptq_forward_multi): the grid runs over all their strips
+    const void* x;
+    float* partial;      // [ksplit][M][nsum] fp32 when ksplit > 1
+    unsigned* tickets;   // one per strip (over all layers)
+    int nseg, M, K, group_size, zero_mode, ksplit, ksteps_per_split, nsum;
+};
+
 template <typename T, int RT, int U>
-__global__ void __launch_bounds__(RT == 1 ? 1024 : 512) gemm_stream64_kernel(GemmParams p) {
+__global__ void __launch_bounds__(RT == 1 ? 1024 : 512) gemm_stream64_kernel(S64Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, W = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j16 = lane & 15, kg = lane >> 4;
     char* const wq = smem + (size_t)wave * (U * 1024);                        // this wave's DMA landing area
     const unsigned wq_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(wq));
-    // logical block -> (tile, K slice): slices of one tile are adjacent logical ids (one XCD after the remap)
+    // logical block -> (strip over all layers, K slice): slices of one strip are adjacent logical ids (one XCD after the remap)
     const int Lb = xcd_remap(blockIdx.x, gridDim.x);
     const int tile = Lb / p.ksplit, ks = Lb - tile * p.ksplit;
-    const int strip = tile % p.nbn, mtile = tile / p.nbn;
-    const int m0 = mtile * (16 * RT);
+    int sI = 0;
+    while (sI + 1 < p.nseg && tile >= p.seg[sI].blk_end) ++sI;                // wave-uniform (kernel arguments only)
+    const S64Seg& sg = p.seg[sI];
+    const int strip = tile - (sI ? p.seg[sI - 1].blk_end : 0);
+    const int N = sg.N;
+    constexpr int m0 = 0;                                                     // one row tile: M <= 16 * RT (planner)
     const int n0 = strip * 64 + j16 * 4;
-    const bool col_ok = n0 < p.N;
+    const bool col_ok = n0 < N;
     const int nload = col_ok ? n0 : 0;
     const int S = p.K >> 5;
     const int b0 = ks * p.ksteps_per_split, b1 = min(b0 + p.ksteps_per_split, S);
     const int spw = (b1 - b0 + W - 1) / W;
     const int ws = b0 + wave * spw, we = min(ws + spw, b1);
 
-    const unsigned* __restrict__ qsrc = p.qweight + (size_t)kg * p.N + nload;          // + step * 4 * N
-    const T* __restrict__ scales = (const T*)p.scales + nload;
-    const unsigned* __restrict__ zsrc = p.qzeros + (nload >> 3);
+    const unsigned* __restrict__ qsrc = sg.qweight + (size_t)kg * N + nload;          // + step * 4 * N
+    const T* __restrict__ scales = (const T*)sg.scales + nload;
+    const unsigned* __restrict__ zsrc = sg.qzeros + (nload >> 3);
     const unsigned z_sh = ((unsigned)nload & 7u) * 4u;                                  // 0 or 16
-    const int zrow_words = p.N >> 3;
+    const int zrow_words = N >> 3;
     const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
     const unsigned gsteps = (unsigned)p.group_size >> 5;                                // K-steps per group (group_size % 32 == 0)
     const unsigned short* a_src[RT];
@@ -941,7 +963,7 @@ __global__ void __launch_bounds__(RT == 1 ? 1024 : 512) gemm_stream64_kernel(Gem
         for (int j = 0; j < U; ++j) {                             // small L2-resident loads first: they return first
             const int sj = min(s0 + j, we - 1);
             gj[j] = (int)((unsigned)sj / gsteps);
-            sraw[j] = *(const u32x2*)(scales + (size_t)gj[j] * p.N);
+            sraw[j] = *(const u32x2*)(scales + (size_t)gj[j] * N);
             zw[j] = zsrc[(size_t)gj[j] * zrow_words];             // raw word: nothing is computed on loaded values up here
         }
 #pragma unroll
@@ -955,7 +977,7 @@ __global__ void __launch_bounds__(RT == 1 ? 1024 : 512) gemm_stream64_kernel(Gem
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int sj = min(s0 + j, we - 1);
-            lds_dma16_nt(qsrc + (size_t)sj * 4 * p.N, wq_lds + j * 1024);
+            lds_dma16_nt(qsrc + (size_t)sj * 4 * N, wq_lds + j * 1024);
         }
         __builtin_amdgcn_sched_barrier(0);
         // step j is consumed as soon as DMA j has landed: vmcnt retires in order and the U DMAs are the wave's youngest VMEM
@@ -1008,24 +1030,24 @@ __global__ void __launch_bounds__(RT == 1 ? 1024 : 512) gemm_stream64_kernel(Gem
             slab[(size_t)wave * E + (rt * 4 + r) * 64 + lane] = f32x4{acc[rt][0][r], acc[rt][1][r], acc[rt][2][r], acc[rt][3][r]};
     __syncthreads();
     unsigned* const flag = (unsigned*)(slab + (size_t)W * E);
-    const size_t pslab = (size_t)p.M * p.N;
+    const size_t pslab = (size_t)p.M * p.nsum;
     for (int e = tid; e < E; e += blockDim.x) {
         f32x4 v = slab[e];
         for (int w = 1; w < W; ++w) v += slab[(size_t)w * E + e];
         const int ln = e & 63, rr = e >> 6;                       // rr = rt * 4 + r
         const int m = m0 + (rr >> 2) * 16 + 4 * (ln >> 4) + (rr & 3);
         const int n = strip * 64 + (ln & 15) * 4;
-        if (m >= p.M || n >= p.N) continue;
+        if (m >= p.M || n >= N) continue;
         if (p.ksplit > 1) {
-            float* dst = p.partial + (size_t)ks * pslab + (size_t)m * p.N + n;
+            float* dst = p.partial + (size_t)ks * pslab + (size_t)m * p.nsum + sg.col0 + n;
 #pragma unroll
             for (int t = 0; t < 4; ++t) __hip_atomic_store(dst + t, v[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
         } else {
-            if (p.bias) {
+            if (sg.bias) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] += DType<T>::to_f32(((const T*)p.bias)[n + t]);
+                for (int t = 0; t < 4; ++t) v[t] += DType<T>::to_f32(((const T*)sg.bias)[n + t]);
             }
-            *(u32x2*)((T*)p.out + (size_t)m * p.N + n) = pack4<T>(v);
+            *(u32x2*)((T*)sg.out + (size_t)m * N + n) = pack4<T>(v);
         }
     }
     if (p.ksplit > 1) {
@@ -1038,18 +1060,18 @@ __global__ void __launch_bounds__(RT == 1 ? 1024 : 512) gemm_stream64_kernel(Gem
             const int ln = e & 63, rr = e >> 6;
             const int m = m0 + (rr >> 2) * 16 + 4 * (ln >> 4) + (rr & 3);
             const int n = strip * 64 + (ln & 15) * 4;
-            if (m >= p.M || n >= p.N) continue;
+            if (m >= p.M || n >= N) continue;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             for (int k = 0; k < p.ksplit; ++k) {                              // fixed order, sc1 loads (bypass this XCD's non-coherent L2 lines)
-                const float* src = p.partial + (size_t)k * pslab + (size_t)m * p.N + n;
+                const float* src = p.partial + (size_t)k * pslab + (size_t)m * p.nsum + sg.col0 + n;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] += __hip_atomic_load(src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (p.bias) {
+            if (sg.bias) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] += DType<T>::to_f32(((const T*)p.bias)[n + t]);
+                for (int t = 0; t < 4; ++t) v[t] += DType<T>::to_f32(((const T*)sg.bias)[n + t]);
             }
-            *(u32x2*)((T*)p.out + (size_t)m * p.N + n) = pack4<T>(v);
+            *(u32x2*)((T*)sg.out + (size_t)m * N + n) = pack4<T>(v);
         }
         if (tid == 0) __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
@@ -1270,6 +1292,118 @@ hipError_t init_gemm_device() {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- batched decode planner (gemm_stream64_kernel), shared by the single-layer path (plan_gemm) and gptq_forward_multi ------
+// Measured (tools/stream64_sweep.py, profiles/r02_stream64_sweep*.log; us per launch, M = 8 / 16 / 32 / 64, best older kernel -> this one):
+//   4096x11008  18.2 / 19.0 / 23.4 / 26.5 -> 10.3 / 11.2 / 15.1 / 23.4   (172 strips, no K split)
+//   11008x4096  16.7 / 20.2 / 22.6 / 27.6 -> 11.7 / 12.1 / 16.7 / 25.7   (64 strips x 4 K slices)
+//   5120x5120   15.7 / 15.9 / 19.0 / 23.1 ->  9.8 / 10.3 / 13.8 / 19.9   (80 x 3)      8192x3584  13.2 / 15.2 / 17.3 / 21.7 -> 10.4 / 11.1 / 14.1 / 21.2 (56 x 4)
+//   3584x8192   12.6 / 12.8 / 14.0 / 18.7 ->  9.4 /  9.8 / 13.4 / 19.5   (128 x 2)     8192x28672 51.7 / 54.3 / 65.3 / 72.2 -> 33.5 / 36.5 / 50.2 / 81.0 (448 x 1)
+//   4096x4096    7.9 /  8.9 / 12.2 / 15.7 ->  8.7 /  9.2 / 12.1 / 16.7   (64 x 4: the 16-column / skinny kernels stay)
+//   8192x1024    8.9 /  9.3 / 10.8 / 14.2 ->  9.5 / 10.1 / 12.2 / 17.9   (16 x 4..8: too few workgroups; older kernels stay)
+// K slices: as many as keep strips x slices <= 256 (one 16-wave workgroup per CU: a 257th starts a second round; 8192x3584 with
+// 5 slices = 280 workgroups: 16.0 us, with 4 = 224: 10.4), none from 160 strips up (the combine costs more than the idle CUs).
+Stream64Plan plan_stream64(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* tune) {
+    Stream64Plan pl{};
+    if (n < 1 || n > 4 || M < 1 || M > 64) return pl;
+    const gptq_layer_t& A = *Ls[0];
+    int strips = 0, nsum = 0, nmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const gptq_layer_t& L = *Ls[i];
+        if (L.bits != 4 || (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16) || L.epilogue != GPTQ_EPI_NONE) return pl;
+        if (L.K % 32 || L.N % 32 || L.group_size % 32) return pl;
+        if (L.g_idx != nullptr && (n > 1 || !L.qweight_seq || !L.perm)) return pl;      // act-order: single layers only (x is permuted per layer)
+        if (L.K != A.K || L.group_size != A.group_size || L.dtype != A.dtype || L.zero_mode != A.zero_mode) return pl;
+        strips += (L.N + 63) / 64;
+        nsum += L.N;
+        nmax = L.N > nmax ? L.N : nmax;
+    }
+    if ((size_t)strips * 4 > WS_HEADER_BYTES) return pl;                              // one ticket per strip
+    pl.nseg = n;
+    pl.strips_total = strips;
+    pl.nsum = nsum;
+    pl.mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);                                          // row tiles of 16 in the one row tile of the launch
+    const int S = A.K / 32;
+    pl.ksteps_total = S;
+    int ks = (tune && tune->ksplit > 0 && tune->path == 3) ? tune->ksplit : 0;
+    if (!ks) {
+        ks = strips >= 160 ? 1 : 256 / strips;
+        if (ks > 8) ks = 8;
+        while (ks > 1 && S / ks < 8) --ks;                                            // at least 8 K-steps per slice
+    }
+    if (ks > S) ks = S;
+    if (ks < 1) ks = 1;
+    pl.ksteps_per_split = (S + ks - 1) / ks;
+    pl.ksplit = (S + pl.ksteps_per_split - 1) / pl.ksteps_per_split;                  // no empty slices
+    // one row tile of 16: 16 waves while the launch is one round of one workgroup per CU, 8 (two or three workgroups per CU) beyond;
+    // 2+ row tiles: > 128 registers per lane (__launch_bounds__(512)), cross-wave slabs W x RT x 4 KiB <= 128 KiB
+    int waves = (tune && tune->waves > 0) ? tune->waves : ((pl.mt == 1 && (long)strips * pl.ksplit <= 256) ? 16 : 8);
+    if (pl.mt > 1 && waves > 8) waves = 8;
+    if (waves > 16) waves = 16;
+    pl.waves = waves;
+    int u = (tune && tune->reserved[0] > 0) ? tune->reserved[0] : 2;                  // deeper bursts measured no faster: the strips are not latency bound
+    if (pl.mt == 1) u = u >= 8 ? 8 : (u >= 4 ? 4 : 2);
+    else if (pl.mt == 2) u = u >= 4 ? 4 : 2;
+    else u = u >= 4 ? 4 : (u >= 2 ? 2 : 1);
+    pl.u = u;
+    const size_t land = (size_t)waves * u * 1024, slabs = (size_t)waves * pl.mt * 4096;
+    pl.lds_bytes = (land > slabs ? land : slabs) + 16;
+    if (pl.lds_bytes > 160 * 1024) return pl;
+    pl.partial_bytes = pl.ksplit > 1 ? (size_t)pl.ksplit * M * nsum * sizeof(float) : 0;
+    const bool small = n == 1 && A.N <= 4096 && A.K <= 4096;      // <= 8.8 MB: one round of 16-column strips / the skinny kernel is as fast
+    pl.pays = (long)strips * pl.ksplit >= 160 && !small && (M <= 32 || nmax < 12288);   // 33+ rows on very wide layers: the tiled kernel
+    pl.ok = true;
+    return pl;
+}
+
+template <typename T, int RT, int U>
+static hipError_t launch_stream64_one(const Stream64Plan& pl, const S64Params& p, hipStream_t st) {
+    // > 64 KiB of LDS for most shapes: granted by init_gemm_device() (gptq_init)
+    hipLaunchKernelGGL((gemm_stream64_kernel<T, RT, U>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_stream64_t(const Stream64Plan& pl, const S64Params& p, hipStream_t st) {
+    switch (pl.mt * 16 + pl.u) {
+        case 16 + 2: return launch_stream64_one<T, 1, 2>(pl, p, st);
+        case 16 + 4: return launch_stream64_one<T, 1, 4>(pl, p, st);
+        case 16 + 8: return launch_stream64_one<T, 1, 8>(pl, p, st);
+        case 32 + 2: return launch_stream64_one<T, 2, 2>(pl, p, st);
+        case 32 + 4: return launch_stream64_one<T, 2, 4>(pl, p, st);
+        case 64 + 1: return launch_stream64_one<T, 4, 1>(pl, p, st);
+        case 64 + 2: return launch_stream64_one<T, 4, 2>(pl, p, st);
+        case 64 + 4: return launch_stream64_one<T, 4, 4>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_stream64(const gptq_layer_t* const* Ls, const Stream64Plan& pl, const void* x, void* const* outs, int M,
+                           void* ws_header, void* partial, const uint32_t* qweight_override, hipStream_t st) {
+    if (!pl.ok) return hipErrorNotSupported;
+    S64Params p{};
+    int blk = 0, col = 0;
+    for (int i = 0; i < pl.nseg; ++i) {
+        const gptq_layer_t& L = *Ls[i];
+        S64Seg& sg = p.seg[i];
+        sg.qweight = (i == 0 && qweight_override) ? qweight_override : L.qweight;
+        sg.qzeros = L.qzeros;
+        sg.scales = L.scales;
+        sg.bias = L.bias;
+        sg.out = outs[i];
+        sg.N = L.N;
+        blk += (L.N + 63) / 64;
+        sg.blk_end = blk;
+        sg.col0 = col;
+        col += L.N;
+    }
+    p.x = x;
+    p.partial = (float*)partial;
+    p.tickets = (unsigned*)ws_header;
+    p.nseg = pl.nseg; p.M = M; p.K = Ls[0]->K; p.group_size = Ls[0]->group_size; p.zero_mode = Ls[0]->zero_mode;
+    p.ksplit = pl.ksplit; p.ksteps_per_split = pl.ksteps_per_split; p.nsum = pl.nsum;
+    return (Ls[0]->dtype == GPTQ_F16) ? launch_stream64_t<f16>(pl, p, st) : launch_stream64_t<bf16>(pl, p, st);
+}
+
 GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     GemmPlan pl{};
     const int kpu = unit_vals(L.bits);
@@ -1303,52 +1437,20 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.skinny = (force_skinny == 1) || (force_skinny == 0 && M <= 64 && (L.N + 255) / 256 < 32);
     if (pl.skinny && M > 128) pl.skinny = false;
     // batched decode (4 < M <= 64, 4-bit): 64-column strips, weights by LDS DMA, K slices combined inside the launch
-    // Measured (tools/stream64_sweep.py, profiles/r02_stream64_sweep*.log; us per launch, M = 8 / 16 / 32 / 64, best older kernel -> this one):
-    //   4096x11008  18.2 / 19.0 / 23.4 / 26.5 -> 10.3 / 11.2 / 15.1 / 23.4   (172 strips, no K split)
-    //   11008x4096  16.7 / 20.2 / 22.6 / 27.6 -> 11.7 / 12.1 / 16.7 / 25.7   (64 strips x 4 K slices)
-    //   5120x5120   15.7 / 15.9 / 19.0 / 23.1 ->  9.8 / 10.3 / 13.8 / 19.9   (80 x 3)      8192x3584  13.2 / 15.2 / 17.3 / 21.7 -> 10.4 / 11.1 / 14.1 / 21.2 (56 x 4)
-    //   3584x8192   12.6 / 12.8 / 14.0 / 18.7 ->  9.4 /  9.8 / 13.4 / 19.5   (128 x 2)     8192x28672 51.7 / 54.3 / 65.3 / 72.2 -> 33.5 / 36.5 / 50.2 / 81.0 (448 x 1)
-    //   4096x4096    7.9 /  8.9 / 12.2 / 15.7 ->  8.7 /  9.2 / 12.1 / 16.7   (64 x 4: the 16-column / skinny kernels stay)
-    //   8192x1024    8.9 /  9.3 / 10.8 / 14.2 ->  9.5 / 10.1 / 12.2 / 17.9   (16 x 4..8: too few workgroups; older kernels stay)
-    // K slices: as many as keep strips x slices <= 256 (one 16-wave workgroup per CU: a 257th starts a second round; 8192x3584 with
-    // 5 slices = 280 workgroups: 16.0 us, with 4 = 224: 10.4), none from 160 strips up (the combine costs more than the idle CUs).
-    const long s64_tiles = (L.N + 63) / 64;                       // one row tile (16 / 32 / 64 rows) covers M <= 64
-    int s64_ks = s64_tiles >= 160 ? 1 : (int)(256 / s64_tiles);
-    if (s64_ks > 8) s64_ks = 8;
-    if (s64_ks < 1) s64_ks = 1;
-    while (s64_ks > 1 && (L.K / 32) / s64_ks < 8) --s64_ks;       // at least 8 K-steps per slice
-    const bool s64_small = L.N <= 4096 && L.K <= 4096;            // <= 8.8 MB: one round of 16-column strips / the skinny kernel is as fast
-    const bool s64_pays = s64_tiles * s64_ks >= 160 && !s64_small && (M <= 32 || L.N < 12288);   // 33+ rows on very wide layers: the tiled kernel
-    pl.stream64 = L.bits == 4 && M <= 64 && (force_skinny == 4 || (force_skinny == 0 && M >= 5 && s64_pays)) && s64_tiles <= 16384;
-    if (pl.stream64) {
-        pl.skinny = false;
-        pl.mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);                  // row tiles of 16 per workgroup
-        pl.bk = 32;
-        pl.bm = 16 * pl.mt;
-        pl.bn = 64;
-        pl.nbm = (M + pl.bm - 1) / pl.bm;
-        pl.nbn = (L.N + 63) / 64;
-        int waves = (tune && tune->waves > 0) ? tune->waves : (pl.mt == 1 ? 16 : 8);
-        if (pl.mt > 1 && waves > 8) waves = 8;                    // 2+ row tiles: > 128 registers per lane (__launch_bounds__(512)); slabs W x RT x 4 KiB <= 128 KiB
-        pl.waves = waves;
-        int u = (tune && tune->reserved[0] > 0) ? tune->reserved[0] : 2;      // deeper bursts measured no faster: the strips are not latency bound
-        if (pl.mt == 1) u = u >= 8 ? 8 : (u >= 4 ? 4 : 2);
-        else if (pl.mt == 2) u = u >= 4 ? 4 : 2;
-        else u = u >= 4 ? 4 : (u >= 2 ? 2 : 1);
-        pl.u = u;
-        const int S = L.K / 32;
-        int ks = (tune && tune->ksplit > 0 && tune->path == 3) ? tune->ksplit : 0;
-        if (!ks) {
-            ks = s64_ks;
-            while (ks > 1 && S / ks < waves) --ks;                // every wave gets at least one K-step
+    // batched decode (4 < M <= 64, 4-bit): 64-column strips, weights by LDS DMA, K slices combined inside the launch
+    {
+        const gptq_layer_t* one[1] = {&L};
+        const Stream64Plan sp = plan_stream64(one, 1, M, tune);
+        pl.stream64 = sp.ok && (force_skinny == 4 || (force_skinny == 0 && M >= 5 && sp.pays));
+        if (pl.stream64) {
+            pl.skinny = false;
+            pl.mt = sp.mt; pl.bk = 32; pl.bm = 16 * sp.mt; pl.bn = 64;
+            pl.nbm = 1; pl.nbn = sp.strips_total;
+            pl.waves = sp.waves; pl.u = sp.u;
+            pl.ksteps_total = sp.ksteps_total; pl.ksteps_per_split = sp.ksteps_per_split; pl.ksplit = sp.ksplit;
+            pl.workspace_bytes = pl.xperm_bytes + sp.partial_bytes;
+            return pl;
         }
-        if (ks > S) ks = S;
-        if (ks < 1) ks = 1;
-        pl.ksteps_total = S;
-        pl.ksteps_per_split = (S + ks - 1) / ks;
-        pl.ksplit = (S + pl.ksteps_per_split - 1) / pl.ksteps_per_split;
-        pl.workspace_bytes = pl.xperm_bytes + (pl.ksplit > 1 ? (size_t)pl.ksplit * M * L.N * sizeof(float) : 0);
-        return pl;
     }
     // 16-column strips on the 16x16x32 matrix core: 4-bit fp16/bf16, M <= 64
     const bool strip16_ok = L.bits == 4 && M <= 64 && L.group_size % 32 == 0 && L.K % 32 == 0 && L.N % 16 == 0;
@@ -1454,29 +1556,6 @@ static hipError_t launch_strip16_one(const GemmPlan& pl, const GemmParams& p, hi
     return hipGetLastError();
 }
 
-template <typename T, int RT, int U>
-static hipError_t launch_stream64_one(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
-    const size_t land = (size_t)pl.waves * U * 1024, slabs = (size_t)pl.waves * RT * 4096;
-    const size_t lds = (land > slabs ? land : slabs) + 16;       // > 64 KiB for most shapes: granted by init_gemm_device() (gptq_init)
-    hipLaunchKernelGGL((gemm_stream64_kernel<T, RT, U>), dim3(pl.nbm * pl.nbn * pl.ksplit), dim3(pl.waves * 64), lds, st, p);
-    return hipGetLastError();
-}
-
-template <typename T>
-static hipError_t launch_stream64(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
-    switch (pl.mt * 16 + pl.u) {
-        case 16 + 2: return launch_stream64_one<T, 1, 2>(pl, p, st);
-        case 16 + 4: return launch_stream64_one<T, 1, 4>(pl, p, st);
-        case 16 + 8: return launch_stream64_one<T, 1, 8>(pl, p, st);
-        case 32 + 2: return launch_stream64_one<T, 2, 2>(pl, p, st);
-        case 32 + 4: return launch_stream64_one<T, 2, 4>(pl, p, st);
-        case 64 + 1: return launch_stream64_one<T, 4, 1>(pl, p, st);
-        case 64 + 2: return launch_stream64_one<T, 4, 2>(pl, p, st);
-        case 64 + 4: return launch_stream64_one<T, 4, 4>(pl, p, st);
-        default: return hipErrorInvalidValue;
-    }
-}
-
 template <typename T>
 static hipError_t launch_strip16(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
     switch (pl.mt) {
@@ -1501,7 +1580,6 @@ static hipError_t launch_skinny(const GemmPlan& pl, const GemmParams& p, hipStre
 template <int BITS, typename T>
 static hipError_t launch_bits(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
     if constexpr (BITS == 4) {
-        if (pl.stream64) return launch_stream64<T>(pl, p, st);
         if (pl.strip16) return launch_strip16<T>(pl, p, st);
     }
     if (pl.skinny) return launch_skinny<BITS, T>(pl, p, st);
@@ -1591,10 +1669,18 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
         p.x = workspace;
     }
     p.partial = (float*)((char*)workspace + pl.xperm_bytes);
-    p.tickets = (unsigned*)ws_header;
+    if (pl.stream64) {
+        const gptq_layer_t* one[1] = {&L};
+        void* outs[1] = {out};
+        Stream64Plan sp = plan_stream64(one, 1, M, nullptr);
+        sp.waves = pl.waves; sp.u = pl.u; sp.ksplit = pl.ksplit; sp.ksteps_per_split = pl.ksteps_per_split;      // the (possibly tuned) geometry of plan_gemm
+        const size_t land = (size_t)sp.waves * sp.u * 1024, slabs = (size_t)sp.waves * sp.mt * 4096;
+        sp.lds_bytes = (land > slabs ? land : slabs) + 16;
+        return launch_stream64(one, sp, p.x, outs, M, ws_header, p.partial, pl.use_seq ? L.qweight_seq : nullptr, st);
+    }
     e = (L.dtype == GPTQ_F16) ? launch_t<f16>(L, pl, p, st) : launch_t<bf16>(L, pl, p, st);
     if (e != hipSuccess) return e;
-    if (pl.ksplit > 1 && !pl.stream64) {
+    if (pl.ksplit > 1) {
         const size_t total4 = (size_t)M * L.N / 4;
         int blocks = (int)((total4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;

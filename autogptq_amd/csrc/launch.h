@@ -51,6 +51,18 @@ struct StreamPlan {
 StreamPlan plan_stream(const gptq_layer_t* const* layers, int n, int M, const gptq_tuning_t* tune);
 hipError_t launch_stream(const gptq_layer_t* const* layers, const StreamPlan& pl, const void* x, void* const* outs, int M,
                          void* ws_header, void* ws_body, hipStream_t st);
+// Batched decode (gemm_stream64_kernel): 1..4 plain 4-bit layers that read the same x, 1 <= M <= 64, one launch.
+struct Stream64Plan {
+    bool ok;                 // every layer qualifies and the geometry fits
+    bool pays;               // measured preference over the per-layer kernels (enough workgroups, not a small layer)
+    int nseg, mt, waves, u, ksplit, ksteps_total, ksteps_per_split, strips_total, nsum;
+    size_t lds_bytes;
+    size_t partial_bytes;    // behind the header (and the permuted x of an act-order layer): [ksplit][M][nsum] fp32 when ksplit > 1
+};
+Stream64Plan plan_stream64(const gptq_layer_t* const* layers, int n, int M, const gptq_tuning_t* tune);
+// qweight_override: the re-sequenced rows of a single act-order layer (x is then the permuted copy), else NULL
+hipError_t launch_stream64(const gptq_layer_t* const* layers, const Stream64Plan& pl, const void* x, void* const* outs, int M,
+                           void* ws_header, void* partial, const uint32_t* qweight_override, hipStream_t st);
 bool stream_preferred(const gptq_layer_t& L, int M);                              // single layer: streamed kernel instead of the register one?
 bool multi_preferred(const gptq_layer_t* const* layers, int n, int M);             // several layers sharing x: one streamed launch?
 hipError_t init_gemv_device();

@@ -1089,3 +1089,31 @@ def test_stream64_batched_decode_kernel(M, K, N, gs, act, dtype, waves, u, kspli
     W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], 4, O.ZERO_WRAP)
     expect = (W[ks].float() + L["bias"].float()).to(dtype)
     assert torch.equal(yo, expect)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("waves,u,ksplit", [(0, 0, 0), (16, 4, 1), (8, 2, 3), (4, 2, 8)])
+@pytest.mark.parametrize("M,K,widths,gs", [(5, 1024, (512, 160, 1024), 128), (16, 2048, (1056, 96), 64), (33, 4096, (256, 256, 256, 64), 128),
+                                           (64, 512, (704, 704), 32)])
+def test_stream64_multi_layer_launch(M, K, widths, gs, dtype, waves, u, ksplit):
+    """gptq_forward_multi at 4 < M <= 64: 2..4 plain layers that share x in ONE gemm_stream64_kernel launch (forced with
+    tuning.path = 3 / reserved[2] = 4, and by default where the planner prefers it) -- every layer against the fp64 oracle and
+    against its own single-layer forward, ragged last strips inside the concatenation, bias on some layers, tickets reset."""
+    from autogptq_amd.qlinear_mi355x import forward_multi
+    Ls = [O.random_quant_layer(K, n, 4, gs, seed=77 + i + M, bias=(i % 2 == 1), dtype=dtype) for i, n in enumerate(widths)]
+    qs = [_module_from(L["qweight"], L["qzeros"], L["scales"], None, L["bias"], 4, gs) for L in Ls]
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype).to(DEV)
+    t = _tuning(path=3, waves=waves, ksplit=ksplit)
+    t.reserved[0], t.reserved[2] = u, 4
+    with torch.no_grad():
+        ys = forward_multi(qs, x, tuning=t)
+        ys2 = forward_multi(qs, x, tuning=t)
+        yd = forward_multi(qs, x)
+        sep = [q(x) for q in qs]
+    mode = O.reference_zero_mode(False, 4)
+    for y, y2, d, s_, L in zip(ys, ys2, yd, sep, Ls):
+        assert torch.equal(y, y2)
+        ref = O.forward_f64(x.cpu(), L["qweight"], L["qzeros"], L["scales"], None, L["bias"], 4, mode)
+        _assert_close(y, ref, ref, dtype, K, "stream64 multi vs oracle")
+        _assert_close(d, ref, ref, dtype, K, "forward_multi default vs oracle")
+        _assert_close(y, s_, ref, dtype, K, "stream64 multi vs separate")

@@ -38,7 +38,7 @@ for tag, kw, dt in (("act-order fp16 M=1", dict(act_order=True), torch.float16),
         del ls
     line(tag, vals)
 for dt, name in ((torch.float16, "fp16"), (torch.bfloat16, "bf16")):
-    for M in (1, 2, 4):
+    for M in (1, 2, 4, 8, 16, 32, 64):
         vals = []
         for K, Ns in ((4096, (4096,) * 3), (4096, (11008,) * 2)):
             ng = max(3, (400 << 20) // (K * sum(Ns) // 2))
