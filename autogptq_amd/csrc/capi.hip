@@ -122,7 +122,30 @@ static size_t epi_scratch_bytes(const gptq_layer_t* L, int M) {
     const size_t b = (size_t)M * L->N * dtype_size(L->dtype);
     return (b + 255) / 256 * 256;
 }
+// A [gate | up] layer with 3..8 rows of x: the GEMV's fused forms for 3+ rows (MT = 4, two passes for 5..8 rows) lose to the streamed
+// 64-column-strip kernel followed by the elementwise pass (4096 x 22016, tools/fused_small_batch.py: M = 4 27.7 -> 19.5 us,
+// M = 5 / 8 47.6 / 50.8 -> 19.3 / 19.5 us; M = 1 / 2 stay fused: 16.7 / 21.2 us).  Returns the tuning the inner (epilogue-stripped)
+// call runs with: the caller's, or -- for 3..4 rows, below the planner's own threshold for that kernel -- a local one that asks for it.
+static bool small_batch_stream_for_epilogue(const gptq_layer_t* L, int M) {
+    if (L->epilogue != GPTQ_EPI_SILU_MUL || M < 3 || M > 8) return false;
+    gptq_layer_t Lc = *L;
+    Lc.epilogue = GPTQ_EPI_NONE;
+    const gptq_layer_t* one[1] = {&Lc};
+    const Stream64Plan sp = plan_stream64(one, 1, M, nullptr);
+    return sp.ok && sp.pays;
+}
+static const gptq_tuning_t* inner_tuning(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, gptq_tuning_t* local) {
+    if (tune) return tune;
+    if (M <= 4 && small_batch_stream_for_epilogue(L, M)) {
+        *local = gptq_tuning_t{};
+        local->path = 3;
+        local->reserved[2] = 4;
+        return local;
+    }
+    return nullptr;
+}
 static bool fused_epilogue_ok(const gptq_layer_t* L, int M, const gptq_tuning_t* tune) {
+    if (!tune && small_batch_stream_for_epilogue(L, M)) return false;
     return L->epilogue == GPTQ_EPI_SILU_MUL && !want_gemm(L, M, tune) && plan_gemv(*L, M, tune).pair;
 }
 
@@ -131,7 +154,8 @@ static size_t body_bytes(const gptq_layer_t* L, int M, const gptq_tuning_t* tune
     if (L->epilogue != GPTQ_EPI_NONE && !fused_epilogue_ok(L, M, tune)) {
         gptq_layer_t Lc = *L;
         Lc.epilogue = GPTQ_EPI_NONE;
-        const size_t inner = body_bytes(&Lc, M, tune);          // the inner call sees a complete workspace: header + body
+        gptq_tuning_t local;
+        const size_t inner = body_bytes(&Lc, M, inner_tuning(L, M, tune, &local));          // the inner call sees a complete workspace: header + body
         return epi_scratch_bytes(L, M) + (inner ? WS_HEADER_BYTES + inner : 0);
     }
     size_t a = plan_gemv(*L, M, tune).workspace_bytes;
@@ -248,7 +272,8 @@ static int forward_impl(const gptq_layer_t* L, const void* x, void* out, int M, 
         // y = [gate | up] at the front of the body; the rest of the body is a complete workspace (header + body) of the inner call
         gptq_layer_t Lc = *L;
         Lc.epilogue = GPTQ_EPI_NONE;
-        rc = forward_impl(&Lc, x, wv.body, M, (char*)wv.body + yb, wv.body_bytes - yb, stream, tune);
+        gptq_tuning_t local;
+        rc = forward_impl(&Lc, x, wv.body, M, (char*)wv.body + yb, wv.body_bytes - yb, stream, inner_tuning(L, M, tune, &local));
         if (rc) return rc;
         hipError_t e = launch_silu_mul(wv.body, out, M, L->N, L->dtype, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "silu_mul launch");
@@ -448,7 +473,11 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
     if (M <= 0) return fail(GPTQ_ERR_SHAPE, "M must be > 0, got %d", M);
     const bool unfused_epilogue = L->epilogue != GPTQ_EPI_NONE && !fused_epilogue_ok(L, M, tune);
     gptq_layer_t Lc = *L;
-    if (unfused_epilogue) Lc.epilogue = GPTQ_EPI_NONE;
+    gptq_tuning_t local;
+    if (unfused_epilogue) {
+        Lc.epilogue = GPTQ_EPI_NONE;
+        tune = inner_tuning(L, M, tune, &local);
+    }
     if (want_stream(&Lc, M, tune)) {
         const gptq_layer_t* one[1] = {&Lc};
         const StreamPlan sp = plan_stream(one, 1, M, tune);

@@ -603,6 +603,42 @@ def test_fused_gate_up_silu_mul(M, dtype, bits, act):
     assert bool((err <= rtol * (ref.abs() + 0.05 * scale)).all()), float(err.max())
 
 
+@pytest.mark.parametrize("M", [2, 3, 4, 5, 8])
+@pytest.mark.parametrize("act", [False, True])
+def test_fused_gate_up_wide_layer_small_batch(M, act):
+    """A [gate | up] layer wide enough for the streamed 64-column-strip kernel (2 x 5632 columns = 176 strips): fused GEMV epilogue
+    up to 2 rows, streamed kernel + elementwise pass from 3 rows (below that kernel's own threshold of 5 rows: the library asks
+    for it through an internal tuning) -- same oracle, plan pinned."""
+    from autogptq_amd.fused import fuse_gate_up
+    K, N = 1024, 5632
+    Lg = O.random_quant_layer(K, N, 4, 128, seed=160, bias=True, act_order=act)
+    Lu = O.random_quant_layer(K, N, 4, 128, seed=161, bias=True, act_order=act)
+    Lu["g_idx"] = Lg["g_idx"].clone()
+    for L in (Lg, Lu):
+        L["scales"] = (L["scales"].float() * 4).half()
+    mg = _module_from(Lg["qweight"], Lg["qzeros"], Lg["scales"], Lg["g_idx"], Lg["bias"], 4, 128)
+    mu = _module_from(Lu["qweight"], Lu["qzeros"], Lu["scales"], Lu["g_idx"], Lu["bias"], 4, 128)
+    fused = fuse_gate_up(mg, mu).to(DEV)
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).half()
+    with torch.no_grad():
+        y = fused(x.to(DEV))
+        y2 = fused(x.to(DEV))
+    q = next(m for m in fused.modules() if isinstance(m, QuantLinear))
+    d = _lib.describe_plan(q._layer, M)
+    if M <= 2:
+        assert d["epilogue"] == "fused", d
+    else:
+        assert (d["kernel"], d["epilogue"]) == ("stream64", "separate"), d
+    assert tuple(y.shape) == (M, N) and torch.equal(y, y2)
+    mode = O.reference_zero_mode(act, 4)
+    g64 = O.forward_f64(x, Lg["qweight"], Lg["qzeros"], Lg["scales"], Lg["g_idx"], Lg["bias"], 4, mode)
+    u64 = O.forward_f64(x, Lu["qweight"], Lu["qzeros"], Lu["scales"], Lu["g_idx"], Lu["bias"], 4, mode)
+    ref = torch.nn.functional.silu(g64) * u64
+    scale = float(ref.abs().max())
+    err = (y.double().cpu() - ref).abs()
+    assert bool((err <= 4e-3 * (ref.abs() + 0.05 * scale)).all()), float(err.max())
+
+
 # ------------------------------------------------------------------------- callers around the path
 def test_model_level_flow_make_quant_pack_post_init_forward():
     """make_quant -> pack_model (device pack) -> autogptq_post_init -> forward on a toy module: the quantized model tracks the

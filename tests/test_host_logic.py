@@ -292,7 +292,13 @@ def test_dispatch_rules_are_the_measured_ones():
     # 64-column-strip kernel elsewhere) unless the layer has a fused epilogue (the GEMV applies it) or K is long and N small
     assert _plan(4096, 4096, 4)["mt"] == 4 and _plan(4096, 4096, 4)["path"] == "gemv"
     assert _plan(4096, 4096, 8)["kernel"] == "strip16" and _plan(4096, 11008, 4)["path"] == "gemv"
-    assert _plan(4096, 22016, 8, epilogue=1)["path"] == "gemv" and _plan(28672, 1024, 8)["path"] == "gemv"
+    assert _plan(28672, 1024, 8)["path"] == "gemv"
+    # [gate | up] with the SiLU*mul epilogue: fused in the GEMV for 1..2 rows, streamed kernel + elementwise pass from 3 rows
+    # (4096 x 22016, M = 4: 27.7 -> 19.5 us, M = 8: 50.8 -> 19.5 us)
+    assert _plan(4096, 22016, 2, epilogue=1)["epilogue"] == "fused"
+    for m in (3, 4, 5, 8, 16):
+        p = _plan(4096, 22016, m, epilogue=1)
+        assert (p["kernel"], p["epilogue"]) == ("stream64", "separate"), (m, p)
     # batched decode, 4 < M <= 64: the streamed 64-column-strip kernel when strips x K slices fill 160..256 workgroups
     p = _plan(4096, 11008, 8)
     assert (p["kernel"], p["ksplit"], p["tiles"], p["waves"], p["mt"]) == ("stream64", 1, "1x172", 16, 1), p
