@@ -793,7 +793,8 @@ __global__ void __launch_bounds__(1024) gemm_strip16_kernel(GemmParams p) {
     const unsigned short* a_src[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
-        a_src[rt] = (const unsigned short*)p.x + (size_t)min(m0 + rt * 16 + c, p.M - 1) * p.K + kg * 8;
+        a_src[rt] = (const unsigned short*)p.x + (size_t)min(m0 + rt * 16 + (lane >> 2), p.M - 1) * p.K + (lane & 3) * 8;
+    const int a_from = ((c << 2) | kg) << 2;                      // coalesced load layout -> MFMA layout by ds_bpermute (see gemm_stream64_kernel)
 
     f32x4 acc[RT];
 #pragma unroll
@@ -830,7 +831,9 @@ __global__ void __launch_bounds__(1024) gemm_strip16_kernel(GemmParams p) {
             const u32x4 b = dq.frag(braw[j]);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const u32x4 t = a[j][rt];
+                u32x4 t;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) t[d] = (unsigned)__builtin_amdgcn_ds_bpermute(a_from, (int)a[j][rt][d]);
                 u32x4 o;                                          // x in the slot order of the fragments: k0,k4,k1,k5,k2,k6,k3,k7
                 o[0] = __builtin_amdgcn_perm(t[2], t[0], 0x05040100u);
                 o[1] = __builtin_amdgcn_perm(t[2], t[0], 0x07060302u);
@@ -944,7 +947,12 @@ __global__ void __launch_bounds__(RT == 1 ? 1024 : 512) gemm_stream64_kernel(S64
     const unsigned short* a_src[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
-        a_src[rt] = (const unsigned short*)p.x + (size_t)min(m0 + rt * 16 + j16, p.M - 1) * p.K + kg * 8;
+        a_src[rt] = (const unsigned short*)p.x + (size_t)min(m0 + rt * 16 + (lane >> 2), p.M - 1) * p.K + (lane & 3) * 8;
+    // A fragments are LOADED with 4 adjacent lanes covering the 64 contiguous bytes (one K-step) of one row -- lane l: row l >> 2,
+    // k-octet l & 3: 16 segments of 64 B per instruction -- and moved to the MFMA's layout (lane (i, kg) holds k-octet kg of row i:
+    // adjacent lanes = different rows, 64 cache-line lookups per instruction) by 4 ds_bpermute per fragment.  Loading in the MFMA
+    // layout directly cost 3-5 us at M = 32 / 64 (timing ablation with coalesced-but-wrong loads: 16.4 -> 13.5, 25.3 -> 20.5 us).
+    const int a_from = ((j16 << 2) | kg) << 2;                    // byte address for ds_bpermute: source lane 4 * i + kg
 
     f32x4 acc[RT][4];
 #pragma unroll
@@ -1002,7 +1010,9 @@ __global__ void __launch_bounds__(RT == 1 ? 1024 : 512) gemm_stream64_kernel(S64
                  for (int t = 0; t < 4; ++t) b[t] = dq[t].frag(qv[t]);
 #pragma unroll
                  for (int rt = 0; rt < RT; ++rt) {
-                     const u32x4 x4 = a[j][rt];
+                     u32x4 x4;
+#pragma unroll
+                     for (int c = 0; c < 4; ++c) x4[c] = (unsigned)__builtin_amdgcn_ds_bpermute(a_from, (int)a[j][rt][c]);
                      u32x4 o;                                     // x in the slot order of the fragments: k0,k4,k1,k5,k2,k6,k3,k7
                      o[0] = __builtin_amdgcn_perm(x4[2], x4[0], 0x05040100u);
                      o[1] = __builtin_amdgcn_perm(x4[2], x4[0], 0x07060302u);

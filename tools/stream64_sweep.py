@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--act", action="store_true")
     ap.add_argument("--quick", action="store_true", help="default plans only")
+    ap.add_argument("--ks", default="", help="K-slice counts to sweep (default 1,2,3,4,6,8)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.float16 if a.dtype == "f16" else torch.bfloat16
@@ -52,14 +53,15 @@ def main():
                 rt = 1 if M <= 16 else (2 if M <= 32 else 4)
                 for waves in ((8, 16) if rt == 1 else (4, 8)):
                     for u in ((2, 4, 8) if rt == 1 else ((2, 4) if rt == 2 else (1, 2, 4))):
-                        for ks in (1, 2, 3, 4, 6, 8):
+                        for ks in ((1, 2, 3, 4, 6, 8) if not a.ks else tuple(map(int, a.ks.split(",")))):
                             t = tun(path=3, waves=waves, ksplit=ks, reserved={0: u, 2: 4})
+                            tag = f"w{waves}u{u}k{ks}"
                             try:
-                                res.append((run(ls, x, t), f"w{waves}u{u}k{ks}"))
+                                res.append((run(ls, x, t), tag))
                             except Exception as e:
-                                res.append((9.9, f"w{waves}u{u}k{ks}:FAIL"))
+                                res.append((9.9, tag + ":FAIL"))
                 res.sort()
-            best = " ".join(f"{n}={s * 1e6:.2f}" for s, n in res[:6])
+            best = " ".join(f"{n}={s * 1e6:.2f}" for s, n in res[:10])
             print(f"{K}x{N} M={M:2d} ({ab / 1e6:.1f} MB; {ab / auto / 1e9:.0f} GB/s auto): " + " ".join(out) + " | " + best, flush=True)
         del ls
 
