@@ -298,6 +298,42 @@ def test_full_size_decode_properties(K, N):
     _assert_close(ys, y1[:, sl], y64, torch.float16, K, "column-sliced layer")
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("K,N,M,act", [(4096, 11008, 16, False), (11008, 4096, 16, True), (4096, 11008, 64, True), (11008, 4096, 40, False),
+                                       (8192, 3584, 8, False), (4096, 4096, 16, False)])
+def test_full_size_batched_decode_properties(K, N, M, act, dtype):
+    """Batched decode (4 < M <= 64) at the BASELINE shapes with the DEFAULT plan -- the streamed 64-column-strip kernel without
+    K split (172 strips), with 4 in-launch K slices (64 / 56 strips), on an act-order layer (permuted x + qweight_seq); 4096^2
+    keeps the 16-column strips: (a) fp64 oracle on a middle and a ragged right-edge column slice, (b) one-hot rows return the
+    exact dequantised rows, (c) bit reproducibility, (d) the plan is the documented one."""
+    L = O.random_quant_layer(K, N, 4, 128, seed=K // 7 + N + M, act_order=act, dtype=dtype, bias=True)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"] if act else None, L["bias"], 4, 128)
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype)
+    with torch.no_grad():
+        y, yb = q(x.to(DEV)), q(x.to(DEV))
+    assert torch.equal(y, yb)
+    d = _lib.describe_plan(q._layer, M)
+    assert d["kernel"] == ("strip16" if (K, N) == (4096, 4096) else "stream64"), d
+    if d["kernel"] == "stream64":
+        assert d["ksplit"] == (1 if N >= 10240 else 4), d
+    mode = O.reference_zero_mode(act, 4)
+    for n0 in ((N // 2) // 32 * 32, N - 96):
+        n1 = min(N, n0 + 96)
+        sl = slice(n0, n1)
+        y64 = O.forward_f64(x, L["qweight"][:, sl], L["qzeros"][:, n0 // 8:n1 // 8], L["scales"][:, sl], L["g_idx"] if act else None,
+                            L["bias"][sl], 4, mode)
+        _assert_close(y[:, sl], y64, y64, dtype, K, f"batched decode full size, columns {n0}:{n1}")
+    ks = (torch.arange(M) * 977 + 13) % K
+    xo = torch.zeros(M, K, dtype=dtype)
+    xo[torch.arange(M), ks] = 1.0
+    with torch.no_grad():
+        yo = q(xo.to(DEV)).cpu()
+    sl = slice(N - 64, N)
+    W = O.dequantize(L["qweight"][:, sl], L["qzeros"][:, (N - 64) // 8:], L["scales"][:, sl], L["g_idx"] if act else None, 4, mode)
+    expect = (W[ks].float() + L["bias"][sl].float()).to(dtype)
+    assert torch.equal(yo[:, sl], expect)
+
+
 # ------------------------------------------------------------------- MFMA prefill path (gptq_gemm)
 GEMM_CASES = [
     # bits, gs, K, N, act, dtype, M
