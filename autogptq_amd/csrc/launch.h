@@ -44,7 +44,7 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
 constexpr size_t WS_HEADER_BYTES = 65536;      // front of every workspace: arrival tickets of the in-launch K-split combine (kept zero)
 struct StreamPlan {
     bool ok;                 // every layer qualifies and the geometry fits
-    int nseg, ln, waves, u, mt, ksplit, units_total, units_per_split, strips_total, nsum, xs_stride, gmax, depth;
+    int nseg, ln, waves, u, mt, ksplit, units_total, units_per_split, strips_total, nsum;
     size_t lds_bytes;
     size_t partial_bytes;    // behind the header: [ksplit][M][nsum] fp32 when ksplit > 1
 };

@@ -109,7 +109,7 @@ typedef struct gptq_tuning_t {
     int32_t waves;       /* waves per workgroup (1..16) */
     int32_t ksplit;      /* workgroups along K (1 = no cross-workgroup reduction) */
     int32_t path;        /* 0 auto, 1 generic GEMV, 2 LDS-staged q4/fp16 GEMV, 3 MFMA GEMM, 4 direct q4/fp16 GEMV, 5 matrix-core q4/fp16 GEMV, 6 streamed (LDS-DMA) q4 GEMV */
-    int32_t reserved[4]; /* [0]: max packed rows per lane and iteration for the register-direct GEMVs, = rows per lane for the streamed one (0 = heuristic); [1]: 32 = force the 32-deep K-step in the MFMA GEMM; [2]: 1 = force the 64-column skinny GEMM, 2 = force the tiled GEMM, 3 = force the 16-column-strip GEMM (4-bit, M <= 64); [3]: tiled-GEMM inner-loop schedule variant */
+    int32_t reserved[4]; /* [0]: max packed rows per lane and iteration for the register-direct GEMVs, = rows per lane for the streamed one, = K-steps per burst for the batched-decode kernel (0 = heuristic); [1]: 32 = force the 32-deep K-step in the MFMA GEMM; [2]: 1 = force the 64-column skinny GEMM, 2 = force the tiled GEMM, 3 = force the 16-column-strip GEMM (4-bit, M <= 64), 4 = force the streamed 64-column-strip batched-decode GEMM (4-bit, M <= 64; waves / ksplit apply); [3]: tiled-GEMM inner-loop schedule variant */
 } gptq_tuning_t;
 
 int         gptq_abi_version(void);
@@ -138,13 +138,16 @@ int gptq_forward(const gptq_layer_t *layer, const void *x, void *out, int M,
 /* n_layers independent layers that read the SAME x[M, K] -- q/k/v of an attention block, gate/up of a gated MLP -- in one
  * call: outs[i] is [M, layers[i]->N].  The reference fuses such layers by concatenating their packed tensors along
  * out_features into one QuantLinear (fused_llama_attn.py:171-203, fused_llama_mlp.py:157-242); this entry point gives the
- * same single launch (M <= 4, plain 4-bit fp16/bf16 layers, <= 4 of them: one streamed GEMV over the strips of all layers)
+ * same single launch (M <= 64, plain 4-bit fp16/bf16 layers, <= 4 of them: one streamed kernel over the column strips of
+ * all layers -- the matrix-core GEMV up to 4 rows, the batched-decode kernel from 5 to 64 rows where the planner prefers it)
  * without touching or copying the checkpoint tensors, and runs the layers one after the other in every other case --
- * results are those of n gptq_forward calls either way.  Workspace: gptq_workspace_bytes_multi. */
+ * results are those of n gptq_forward calls either way (same values within fp rounding: the K split may differ).
+ * Workspace: gptq_workspace_bytes_multi. */
 size_t gptq_workspace_bytes_multi(const gptq_layer_t *const *layers, int n_layers, int M);
 int gptq_forward_multi(const gptq_layer_t *const *layers, int n_layers, const void *x, void *const *outs, int M,
                        void *workspace, size_t workspace_bytes, void *stream);
-/* ... with an explicit launch shape for the one-launch kernel (experiments; tuning.path = 6 makes "does not fit" an error). */
+/* ... with an explicit launch shape for the one-launch kernel (experiments; tuning.path = 6 -- streamed GEMV -- or
+ * tuning.path = 3 with tuning.reserved[2] = 4 -- batched-decode kernel -- make "does not fit" an error). */
 size_t gptq_workspace_bytes_multi_ex(const gptq_layer_t *const *layers, int n_layers, int M, const gptq_tuning_t *tuning);
 int gptq_forward_multi_ex(const gptq_layer_t *const *layers, int n_layers, const void *x, void *const *outs, int M,
                           void *workspace, size_t workspace_bytes, void *stream, const gptq_tuning_t *tuning);
