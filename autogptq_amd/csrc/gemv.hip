@@ -1594,9 +1594,18 @@ static int stream_default_ln(const gptq_layer_t* const* Ls, int n) {
     if (s16 > 256) return 8;
     return (s16 * 2 >= 128) ? 8 : 4;
 }
+// Layers of the larger models (K and N >= 5120: Llama-13B / 33B / 70B projections): the register kernel's geometry was tuned on the
+// Llama-7B shapes and loses 15-35 % there to the streamed kernel with 32-column strips, 8 waves x 4 rows per lane (64-column strips
+// from 16384 columns), at every M <= 4 and for fp16 and bf16 (tools/stream_sweep.py --shapes ..., profiles/r02_stream_sweep_large_shapes.log;
+// us per launch, register -> streamed, M = 1 / 4: 5120x5120 9.6 / 10.9 -> 7.4 / 9.4; 13824x5120 19.1 / 22.6 -> 14.0 / 16.3;
+// 8192x8192 12.3 / 15.4 -> 10.3 / 11.7; 5120x13824 11.5 / 17.2 -> 11.2 / 13.4; 28672x8192 35.8 / 47.3 -> 25.8 / 30.1 = 4.7 TB/s;
+// 17920x6656 25.1 / 29.7 -> 17.4 / 20.6).  Smaller or flatter layers (8192x3584, 3584x8192, 8192x1024, 4096x4096): equal or slower.
+static bool stream_big_single(const gptq_layer_t& L) { return L.K >= 5120 && L.N >= 5120; }
+
 bool stream_preferred(const gptq_layer_t& L, int M) {
     const gptq_layer_t* one[1] = {&L};
     const int s16 = stream_strips64(one, 1);
+    if (stream_big_single(L)) return true;                       // M <= 4 (plan_stream)
     // only where it was measured against the register kernel: wider than 8192 columns (128 strips of 64 fill too little of the chip)
     // and narrower than 12288 (from there on the register kernel itself runs 64-column strips)
     return s16 > 128 && s16 < 192 && L.K <= 8192 && M <= 2;
@@ -1616,7 +1625,8 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     pl.mt = M >= 3 ? 4 : M;
     pl.units_total = A.K / 8;
     const int gu = A.group_size / 8;
-    int ln = (tune && tune->lanes_n) ? tune->lanes_n : stream_default_ln(Ls, n);
+    const bool big1 = n == 1 && stream_big_single(A);
+    int ln = (tune && tune->lanes_n) ? tune->lanes_n : (big1 ? (A.N >= 16384 ? 16 : 8) : stream_default_ln(Ls, n));
     if (ln != 4 && ln != 8 && ln != 16) return pl;
     const int ct = ln * 4, wr = 64 / ln;
     int strips = 0, nsum = 0;
@@ -1641,6 +1651,8 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     int waves = 0, u = 0;
     if (tune && tune->waves && tune->reserved[0]) {
         waves = tune->waves; u = tune->reserved[0];
+    } else if (big1) {
+        waves = 8; u = ucap < 4 ? ucap : 4;
     } else {
         if (ln == 16) {            // one pass of 16 waves x 8 rows where the slice allows it (measured best for 64-column strips)
             static const int cand[][2] = {{4, 2}, {8, 2}, {8, 4}, {16, 4}, {16, 8}};

@@ -262,7 +262,8 @@ def test_permute_columns_and_errors():
 
 
 # ---------------------------------------------------- BASELINE full sizes: size-independent properties
-FULL = [(4096, 4096), (4096, 11008), (11008, 4096), (3584, 8192), (8192, 1024)]   # + Llama-2-70B TP=8 shards (32-column strips / K split)
+FULL = [(4096, 4096), (4096, 11008), (11008, 4096), (3584, 8192), (8192, 1024),   # + Llama-2-70B TP=8 shards (32-column strips / K split)
+        (5120, 5120), (13824, 5120), (8192, 16384)]          # + Llama-13B projections and a 64-column-strip case: streamed kernel by default
 
 
 @pytest.mark.parametrize("K,N", FULL)
@@ -927,6 +928,29 @@ def test_wide_layers_take_wide_strips(K, N, M, dtype):
     assert torch.equal(y, yb)
     for t, what in ((y, "auto"), (y4, "16-column strips"), (y16, "64-column strips")):
         _assert_close(t, y64, y64, dtype, K, what)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("K,N,M", [(5120, 5120, 1), (5120, 5120, 3), (6656, 5152, 2), (5120, 16384, 4), (13824, 5120, 1)])
+def test_large_model_layers_take_the_streamed_gemv(K, N, M, dtype):
+    """K and N >= 5120 (Llama-13B / 33B / 70B projections), M <= 4: the default plan is the streamed (LDS-DMA) GEMV with 32-column
+    strips (64 from 16384 columns), 8 waves x 4 rows per lane -- against the fp64 oracle on two column slices (one at the ragged
+    right edge: N = 5152 is not a multiple of the strip), against the register kernel, twice."""
+    L = O.random_quant_layer(K, N, 4, 128, seed=K // 3 + N + M, bias=True, dtype=dtype)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], None, L["bias"], 4, 128)
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype)
+    with torch.no_grad():
+        y, yb = q(x.to(DEV)), q(x.to(DEV))
+        yr = q(x.to(DEV), tuning=_tuning(path=5))
+    d = _lib.describe_plan(q._layer, M)
+    assert (d["kernel"], d["ln"], d["waves"], d["u"]) == ("stream", 16 if N >= 16384 else 8, 8, 4), d
+    assert torch.equal(y, yb)
+    mode = O.reference_zero_mode(False, 4)
+    for n0 in ((N // 2) // 32 * 32, N - 96):
+        sl = slice(n0, n0 + 96)
+        y64 = O.forward_f64(x, L["qweight"][:, sl], L["qzeros"][:, n0 // 8:(n0 + 96) // 8], L["scales"][:, sl], None, L["bias"][sl], 4, mode)
+        _assert_close(y[:, sl], y64, y64, dtype, K, f"streamed default, columns {n0}:{n0 + 96}")
+        _assert_close(yr[:, sl], y64, y64, dtype, K, "register kernel")
 
 
 @pytest.mark.parametrize("fname", ["marlin_k256_n256_g128.npz", "marlin_k512_n512_g128.npz"])       # (the single-group file: CPU tests)

@@ -272,8 +272,15 @@ def test_dispatch_rules_are_the_measured_ones():
     assert _plan(4096, 11008, 3)["kernel"] == "mfma" and _plan(4096, 11008, 3)["strips"] == 688
     assert _plan(4096, 11008, 1, dtype=1)["kernel"] == "stream"
     # wider plain fp16 layers: 64- / 32-column strips with >= 160 workgroups; bf16 and act-order stay at 16 columns
-    assert _plan(4096, 12288, 1)["ln"] == 16 and _plan(5120, 13824, 1)["ln"] == 16 and _plan(8192, 28672, 1)["ln"] == 16
-    assert _plan(8192, 8192, 1)["ln"] == 8 and _plan(3584, 8192, 1)["ln"] == 8
+    assert _plan(4096, 12288, 1)["ln"] == 16 and _plan(4096, 14336, 1)["ln"] == 16
+    assert _plan(3584, 8192, 1)["ln"] == 8 and _plan(3584, 8192, 1)["kernel"] == "mfma"
+    # K and N >= 5120 (13B / 33B / 70B projections): the streamed kernel, 32-column strips (64 from 16384 columns), 8 waves x 4 rows, M <= 4
+    for (k, n), ln in (((5120, 5120), 8), ((13824, 5120), 8), ((8192, 8192), 8), ((5120, 13824), 8), ((8192, 28672), 16), ((28672, 8192), 8)):
+        for m in (1, 4):
+            p = _plan(k, n, m)
+            assert (p["kernel"], p["ln"], p["waves"], p["u"], p["ksplit"]) == ("stream", ln, 8, 4, 1), (k, n, m, p)
+    assert _plan(5120, 5120, 1, dtype=1)["kernel"] == "stream" and _plan(5120, 5120, 1, act=True)["kernel"] == "mfma"
+    assert _plan(8192, 3584, 1)["kernel"] == "mfma" and _plan(8192, 1024, 1)["kernel"] == "mfma"
     assert _plan(4096, 12288, 1, dtype=1)["ln"] == 4 and _plan(4096, 12288, 1, act=True)["ln"] == 4
     assert _plan(4096, 12288, 1, act=True)["perm"] == 1
     # small N: K split (second, fixed-order reduce launch)

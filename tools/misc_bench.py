@@ -54,6 +54,13 @@ for K, N in ((8192, 1024), (8192, 3584), (28672, 1024), (3584, 8192)):
     vals.append(run(ls, (torch.rand(1, K, device=dev) - 0.5).half(), None))
     del ls
 line("70B TP=8 shards M=1 (8192x1024, 8192x3584, 28672x1024, 3584x8192)", vals)
+for M in (1, 4):
+    vals = []
+    for K, N in ((5120, 5120), (5120, 13824), (13824, 5120), (8192, 8192), (8192, 28672), (28672, 8192)):
+        ls = layers_for(K, N)
+        vals.append(run(ls, (torch.rand(M, K, device=dev) - 0.5).half(), None))
+        del ls
+    line(f"13B / 70B layers M={M} (5120^2, 5120x13824, 13824x5120, 8192^2, 8192x28672, 28672x8192)", vals)
 for M in (9, 16, 32, 64):
     vals = []
     for K, N in SHAPES:

@@ -44,11 +44,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--m", type=int, default=1)
     ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--shapes", default="4096x4096,4096x11008,11008x4096")
+    ap.add_argument("--no-multi", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
     M = args.m
-    for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
+    for K, N in [tuple(map(int, sh.split('x'))) for sh in args.shapes.split(',')]:
         per = K * N // 2
         nl = max(4, min(64, (512 << 20) // per))
         layers = [make_layer(K, N, dev, dtype=dt, seed=i) for i in range(nl)]
@@ -61,8 +63,8 @@ def main():
         for ln in (4, 8, 16):
             wr = 64 // ln
             for waves, u in ((2, 8), (4, 2), (4, 4), (4, 8), (8, 2), (8, 4), (8, 8), (16, 2), (16, 4), (16, 8)):
-                for ks in ((1,) if ln == 4 else (1, 2, 4)):
-                    if N // (4 * ln) * ks < 128:
+                for ks in ((1, 2, 4, 8) if N < 4096 else ((1,) if ln == 4 else (1, 2, 4))):
+                    if N // (4 * ln) * ks < 96 or N // (4 * ln) * ks > 1024:
                         continue
                     passes = -(-(rows // ks) // (waves * wr * u))
                     t = tune(path=6, lanes_n=ln, waves=waves, ksplit=ks, u=u)
@@ -80,7 +82,7 @@ def main():
         del layers
         torch.cuda.empty_cache()
     # multi-layer launches: groups of layers sharing x
-    for name, K, Ns in (("qkv", 4096, (4096, 4096, 4096)), ("gate_up", 4096, (11008, 11008))):
+    for name, K, Ns in () if args.no_multi else (("qkv", 4096, (4096, 4096, 4096)), ("gate_up", 4096, (11008, 11008))):
         ng = max(3, (512 << 20) // (K * sum(Ns) // 2))
         groups = [[make_layer(K, n, dev, dtype=dt, seed=100 * gi + i) for i, n in enumerate(Ns)] for gi in range(ng)]
         x = (torch.rand(M, K, device=dev) - 0.5).to(dt)
