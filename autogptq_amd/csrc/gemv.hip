@@ -1610,7 +1610,14 @@ bool stream_preferred(const gptq_layer_t& L, int M) {
     // and narrower than 12288 (from there on the register kernel itself runs 64-column strips)
     return s16 > 128 && s16 < 192 && L.K <= 8192 && M <= 2;
 }
-bool multi_preferred(const gptq_layer_t* const* layers, int n, int M) { return n >= 2; }
+bool multi_preferred(const gptq_layer_t* const* layers, int n, int M) {
+    // one launch for a group pays while the fixed cost of a launch matters: measured (tools/multi_shapes.py, M = 1, us, one launch vs
+    // separate): 7B q|k|v 8.9 vs 15.1, 13B q|k|v 14.6 vs 22.5, 13B gate|up (71 MB) 20.7 vs 25.6, 70B GQA q|k|v 14.6 vs 22.4,
+    // 70B gate|up (244 MB) 57.7 vs 55.0 -- beyond ~128 MB the layers run one by one (each then takes its own best plan)
+    size_t bytes = 0;
+    for (int i = 0; i < n; ++i) bytes += (size_t)layers[i]->K * layers[i]->N / 2;
+    return n >= 2 && bytes <= ((size_t)128 << 20);
+}
 
 StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* tune) {
     StreamPlan pl{};
