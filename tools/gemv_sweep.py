@@ -58,6 +58,8 @@ def main():
                     if args.bits == 4:
                         cfgs.append(dict(lanes_n=ln, waves=waves, ksplit=ks, path=4))
                         cfgs.append(dict(lanes_n=ln, waves=waves, ksplit=ks, path=5))
+                    elif ln == 4 and not args.act:
+                        cfgs.append(dict(lanes_n=ln, waves=waves, ksplit=ks, path=5))      # matrix-core kernel with field extraction
         cfgs.append(dict(path=1))
         if args.heuristic_only:
             cfgs = [dict(), dict(path=1)] + ([dict(path=2)] if args.bits == 4 and args.dtype == 'f16' else [])
