@@ -493,7 +493,7 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
         const GemvPlan v = plan_gemv(Lc, M, tune);
         const char* kern = v.mfma ? "mfma" : (v.mfmag ? "mfma_generic" : (v.direct ? "direct" : (v.fast ? "lds_staged" : "generic")));
         snprintf(out, out_bytes, "path=gemv kernel=%s ln=%d waves=%d u=%d ksplit=%d mt=%d strips=%d pair=%d perm=%d epilogue=%s", kern, v.ln,
-                 v.waves, v.u, v.ksplit, v.mt, v.strips, v.pair ? 1 : 0, v.use_seq ? 1 : 0,
+                 v.waves, v.u, v.ksplit, v.mt, v.strips, v.pair ? 1 : 0, v.xperm ? 2 : (v.use_seq ? 1 : 0),
                  v.pair ? "fused" : (unfused_epilogue ? "separate" : "none"));
     }
     return GPTQ_OK;

@@ -1222,6 +1222,23 @@ GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
             return pl;
         }
     }
+    // act-order with 2+ rows of x: the in-kernel gather through perm[] (x row in LDS, cooperative per-wave gather) is built for one
+    // row; for MT = 2 / 4 it measured 22-40 us on the 23 MB layers against 9.5-11.5 us for the plain kernel (tools/act_batch.py).
+    // x is permuted ONCE by the column-permute pre-pass (a 2.6 us launch for these sizes) and the plain matrix-core kernel runs on the
+    // re-sequenced rows: 4096x11008 M = 2 / 4: 22.2 / 28.9 -> 12.1 / 14.1 us.
+    if (L.g_idx != nullptr && L.qweight_seq != nullptr && L.perm != nullptr && M >= 2 && L.epilogue == GPTQ_EPI_NONE && L.bits == 4 &&
+        (L.dtype == GPTQ_F16 || L.dtype == GPTQ_BF16) && (!tune || tune->path == 0)) {
+        gptq_layer_t P = L;
+        P.g_idx = nullptr; P.perm = nullptr; P.qweight = L.qweight_seq; P.qweight_seq = nullptr;
+        GemvPlan pp = plan_gemv_n(P, M, tune, L.N);
+        if (pp.mfma) {
+            pp.pair = false;
+            pp.xperm = true;
+            pp.xperm_bytes = ((size_t)M * L.K * 2 + 255) / 256 * 256;
+            pp.workspace_bytes += pp.xperm_bytes;
+            return pp;
+        }
+    }
     GemvPlan pl = plan_gemv_n(L, M, tune, L.N);
     pl.pair = false;
     return pl;
@@ -1768,7 +1785,13 @@ hipError_t init_gemv_device() {
 hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x, void* out, int M,
                        void* workspace, hipStream_t st) {
     GemvParams p{};
-    p.qweight = pl.use_seq ? L.qweight_seq : L.qweight;
+    if (pl.xperm) {                    // act-order, 2+ rows: x[:, perm] once, then the plain kernel on the re-sequenced rows
+        hipError_t pe = launch_permute_columns(x, L.perm, M, L.K, L.dtype, workspace, st);
+        if (pe != hipSuccess) return pe;
+        x = workspace;
+        workspace = (char*)workspace + pl.xperm_bytes;
+    }
+    p.qweight = (pl.use_seq || pl.xperm) ? L.qweight_seq : L.qweight;
     p.qzeros = L.qzeros;
     p.scales = L.scales;
     p.g_idx = pl.perk ? L.g_idx : nullptr;

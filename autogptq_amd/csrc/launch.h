@@ -14,6 +14,8 @@ struct GemvPlan {
     bool mfma;     // direct path with the k-reduction on v_mfma_f32_4x4x4_16b_f16
     bool mfmag;    // matrix-core kernel for the other packings / bf16 (gemv_mfma_generic_kernel)
     bool pair;     // mfma path with the fused SILU_MUL epilogue (gate/up halves walked by the same workgroup)
+    bool xperm;    // act-order, 2+ rows of x: x is permuted once by a pre-pass into the workspace front (xperm_bytes) and the plain kernel streams qweight_seq
+    size_t xperm_bytes;
     int u;         // direct path: consecutive packed rows per lane and iteration
     size_t lds_bytes, workspace_bytes;
 };

@@ -283,6 +283,11 @@ def test_dispatch_rules_are_the_measured_ones():
     assert _plan(8192, 3584, 1)["kernel"] == "mfma" and _plan(8192, 1024, 1)["kernel"] == "mfma"
     assert _plan(4096, 12288, 1, dtype=1)["ln"] == 4 and _plan(4096, 12288, 1, act=True)["ln"] == 4
     assert _plan(4096, 12288, 1, act=True)["perm"] == 1
+    # act-order with 2+ rows: x permuted once by a pre-pass (perm = 2), plain kernel on the re-sequenced rows
+    for m in (2, 3, 4):
+        p = _plan(4096, 11008, m, act=True)
+        assert (p["path"], p["kernel"], p["perm"]) == ("gemv", "mfma", 2), p
+    assert _plan(28672, 1024, 8, act=True)["perm"] == 2 and _plan(4096, 4096, 1, act=True, dtype=1)["perm"] == 1
     # small N: K split (second, fixed-order reduce launch)
     assert _plan(8192, 1024, 1)["ksplit"] > 1
     # fused gate/up epilogue lives in the GEMV for M <= 8, and is a separate elementwise pass behind the GEMM paths
