@@ -65,6 +65,24 @@ bool want_gemm(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
     // M = 5..8 on wide layers: the GEMV needs two matrix-core passes per weight word there, and a wide N gives the tiled kernel
     // enough 256-column tiles to fill the chip (4096x11008, M = 8: 22.2 us GEMV, 17.8 us tiled; narrower layers: GEMV wins)
     const bool wide_small_batch = M >= 5 && L->bits == 4 && L->N > 8192 && L->epilogue == GPTQ_EPI_NONE;
+    if (L->dtype == GPTQ_F32) {
+        // fp32 layers: the exact-f32 matrix-core kernel runs whole 128-row tiles with no K split; up to 64 rows the 4-rows-per-pass GEMV
+        // is faster or equal on every shape (tools/cliff_scan.py --slice D: 4096x11008 M = 8: 517 us against ~60; M = 64: 528 against
+        // ~510; 4096x4096 M = 64 on 32 tiles: 455 against 85)
+        if (M <= 64) return false;
+        const GemmPlan gf = plan_gemm(*L, M, t);
+        return gf.supported && (long)gf.nbm * gf.nbn >= 64;      // fewer tiles than a quarter of the chip: the GEMV still wins (4096x4096 M = 128: ~170 us against 455)
+    }
+    if (L->bits != 4) {
+        // 2/3/8-bit: the matrix-core GEMV handles 4 rows of x per pass over the weights and the generic (act-order) kernel fewer, so the
+        // weight-streaming GEMMs take over early (tools/cliff_scan.py --slice C, 4096x11008, us: int8 M = 8: 47.6 GEMV, 25.6 tiled at
+        // M = 16; int8 act-order M = 4: 43.7 against 29.5; int3 M = 8: 26.2 against 35.8 -- 3-bit keeps the GEMV up to 8 rows)
+        const bool act = L->g_idx != nullptr;
+        const bool big = (size_t)L->K * L->N >= ((size_t)32 << 20);
+        const int min_m = act ? (L->bits == 8 ? 3 : 5) : (L->bits == 8 ? 5 : ((L->bits == 2 && big) ? 5 : 9));
+        if (M < min_m) return false;
+        return plan_gemm(*L, M, t).supported;
+    }
     if (M <= 4) return false;
     const GemmPlan g = plan_gemm(*L, M, t);
     // M = 5..8: the streamed 64-column-strip kernel (one matrix-core pass for up to 16 rows, weights by LDS DMA) where it exists;
@@ -73,9 +91,6 @@ bool want_gemm(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
     // (28672x1024, M = 8: GEMV 14.8, 16-column strips 17.0 -- long K keeps the GEMV)
     const bool small_batch_stream = g.supported && (g.stream64 || (g.strip16 && L->K <= 8192)) && L->epilogue == GPTQ_EPI_NONE;
     if (M <= 8 && !wide_small_batch && !small_batch_stream) return false;
-    // fp32 matrix-core kernel: 128 x 128 tiles and no K split -- with fewer than 64 tiles the 4-rows-per-pass GEMV is faster
-    // (M = 64 on 4096 x 4096: 455 us on 32 tiles; profiles/r02_gemm_f32.log)
-    if (g.supported && g.f32 && M <= 64 && (long)g.nbm * g.nbn < 64 && !(t && t->path == 3)) return false;
     return g.supported;
 }
 
