@@ -106,6 +106,20 @@ bool want_stream(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
     return stream_preferred(*L, M);
 }
 
+// act-order layers on the streamed GEMV: x permuted once by the column-permute pre-pass, the kernel streams the re-sequenced rows of a
+// plain copy of the layer.  Where the streamed kernel is the planner's choice for that copy (tools/cliff_scan.py --slice F, us, in-kernel
+// gather / register kernel -> this: 13824x5120 M = 1 / 2 / 4 19.6 / 24.7 / 26.9 -> ~17 / 17.3 / 19.8; 8192x28672 M = 1 37.0 -> ~31); with
+// one row only from 33 MiB up -- below that the in-kernel gather is cheaper than the 2.6 us pre-pass (5120x5120: 9.7 against 10.1).
+static bool want_stream_seq(const gptq_layer_t* L, int M, const gptq_tuning_t* t, gptq_layer_t* P) {
+    if (t || !L->g_idx || !L->qweight_seq || !L->perm || L->epilogue != GPTQ_EPI_NONE || M > 4) return false;
+    *P = *L;
+    P->g_idx = nullptr; P->perm = nullptr; P->qweight = L->qweight_seq; P->qweight_seq = nullptr;
+    if (!want_stream(P, M, nullptr)) return false;
+    if (M == 1 && (size_t)L->K * L->N / 2 < ((size_t)33 << 20)) return false;
+    return true;
+}
+static size_t xperm16_bytes(const gptq_layer_t* L, int M) { return ((size_t)M * L->K * 2 + 255) / 256 * 256; }
+
 // workspace split: [ticket header | body]
 struct WsView { void* header; void* body; size_t body_bytes; };
 WsView split_ws(void* ws, size_t ws_bytes) {
@@ -180,6 +194,11 @@ static size_t body_bytes(const gptq_layer_t* L, int M, const gptq_tuning_t* tune
     if (want_stream(L, M, tune)) {
         const gptq_layer_t* one[1] = {L};
         c = plan_stream(one, 1, M, tune).partial_bytes;
+    }
+    gptq_layer_t P;
+    if (want_stream_seq(L, M, tune, &P)) {
+        const gptq_layer_t* one[1] = {&P};
+        c = std::max(c, xperm16_bytes(L, M) + plan_stream(one, 1, M, nullptr).partial_bytes);
     }
     return std::max(std::max(a, b), c);
 }
@@ -300,6 +319,25 @@ static int forward_impl(const gptq_layer_t* L, const void* x, void* out, int M, 
         const gptq_layer_t* one[1] = {L};
         void* outs[1] = {out};
         return stream_call(one, 1, plan_stream(one, 1, M, tune), x, outs, M, ws, ws_bytes, stream);
+    }
+    {
+        gptq_layer_t P;
+        if (want_stream_seq(L, M, tune, &P)) {
+            rc = check_io(x, out, M);
+            if (rc) return rc;
+            const gptq_layer_t* one[1] = {&P};
+            void* outs[1] = {out};
+            const StreamPlan sp = plan_stream(one, 1, M, nullptr);
+            const size_t xb = xperm16_bytes(L, M);
+            const WsView wv = split_ws(ws, ws_bytes);
+            if (wv.body_bytes < xb + sp.partial_bytes)
+                return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + xb + sp.partial_bytes, ws ? ws_bytes : (size_t)0);
+            hipError_t e = launch_permute_columns(x, L->perm, M, L->K, L->dtype, wv.body, (hipStream_t)stream);
+            if (e != hipSuccess) return hip_fail(e, "gptq_permute_columns launch");
+            e = launch_stream(one, sp, wv.body, outs, M, wv.header, (char*)wv.body + xb, (hipStream_t)stream);
+            if (e != hipSuccess) return hip_fail(e, "gptq streamed GEMV launch (was gptq_init() called on this device?)");
+            return GPTQ_OK;
+        }
     }
     if (tune && tune->path == 6)
         return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 6: the streamed GEMV needs M <= 4, a plain 4-bit fp16/bf16 layer (no act-order, no epilogue) "
@@ -493,7 +531,13 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
         Lc.epilogue = GPTQ_EPI_NONE;
         tune = inner_tuning(L, M, tune, &local);
     }
-    if (want_stream(&Lc, M, tune)) {
+    gptq_layer_t Pseq;
+    if (!unfused_epilogue && want_stream_seq(L, M, tune, &Pseq)) {
+        const gptq_layer_t* one[1] = {&Pseq};
+        const StreamPlan sp = plan_stream(one, 1, M, nullptr);
+        snprintf(out, out_bytes, "path=gemv kernel=stream ln=%d waves=%d u=%d ksplit=%d mt=%d strips=%d pair=0 perm=2 epilogue=none", sp.ln, sp.waves,
+                 sp.u, sp.ksplit, sp.mt, sp.strips_total);
+    } else if (want_stream(&Lc, M, tune)) {
         const gptq_layer_t* one[1] = {&Lc};
         const StreamPlan sp = plan_stream(one, 1, M, tune);
         snprintf(out, out_bytes, "path=gemv kernel=stream ln=%d waves=%d u=%d ksplit=%d mt=%d strips=%d pair=0 perm=0 epilogue=none", sp.ln, sp.waves,

@@ -1674,7 +1674,10 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
         return hipGetLastError();
     }
     if (pl.use_seq) {
-        e = launch_permute_rows16(x, L.perm, M, L.K, workspace, st, pl.xslot);
+        // k-slot order for the DMA-staged tiled kernel: the LDS-staged row kernel; plain order: whichever permute kernel fits M and K
+        // (a few long rows -- batched decode -- take the flat gather: 11008x4096 M = 8 act-order 16.8 -> ~14.5 us)
+        e = pl.xslot ? launch_permute_rows16(x, L.perm, M, L.K, workspace, st, true)
+                     : launch_permute_columns(x, L.perm, M, L.K, L.dtype, workspace, st);
         if (e != hipSuccess) return e;
         p.x = workspace;
     }

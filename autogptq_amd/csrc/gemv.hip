@@ -1226,7 +1226,8 @@ GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     // row; for MT = 2 / 4 it measured 22-40 us on the 23 MB layers against 9.5-11.5 us for the plain kernel (tools/act_batch.py).
     // x is permuted ONCE by the column-permute pre-pass (a 2.6 us launch for these sizes) and the plain matrix-core kernel runs on the
     // re-sequenced rows: 4096x11008 M = 2 / 4: 22.2 / 28.9 -> 12.1 / 14.1 us.
-    if (L.g_idx != nullptr && L.qweight_seq != nullptr && L.perm != nullptr && M >= 2 && L.epilogue == GPTQ_EPI_NONE && L.bits == 4 &&
+    // (also for ONE row when K is too long for the x row in LDS: 28672x1024 15.8 us on the LDS-staged fallback, 12.1 this way)
+    if (L.g_idx != nullptr && L.qweight_seq != nullptr && L.perm != nullptr && (M >= 2 || L.K > 24576) && L.epilogue == GPTQ_EPI_NONE && L.bits == 4 &&
         (L.dtype == GPTQ_F16 || L.dtype == GPTQ_BF16) && (!tune || tune->path == 0)) {
         gptq_layer_t P = L;
         P.g_idx = nullptr; P.perm = nullptr; P.qweight = L.qweight_seq; P.qweight_seq = nullptr;
@@ -1302,7 +1303,7 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
                         const int strips = (N_cols + cand * 4 - 1) / (cand * 4);
                         if (N_cols % (cand * 4) == 0 && strips * pl.mtiles >= 160) { ln = cand; break; }
                     }
-                } else if (M == 1 && N_cols % 8192 == 0) {
+                } else if (N_cols % 8192 == 0) {                  // M <= 4 (3584x8192, us: M = 2 8.6 -> 7.5, M = 4 9.9 -> 8.7)
                     ln = 8;
                 }
             }

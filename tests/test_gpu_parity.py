@@ -1125,7 +1125,7 @@ def test_fp32_gemm_vs_oracle(bits, gs, K, N, M, act):
     L = O.random_quant_layer(K, N, bits, gs, act_order=act, dtype=torch.float32, seed=bits + K + N + M, bias=True)
     q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"] if act else None, L["bias"], bits, gs)
     q.post_init()
-    few_tiles = M <= 64 and -(-M // 128) * -(-N // 128) < 64          # the planner keeps such launches on the GEMV
+    few_tiles = M <= 64 or -(-M // 128) * -(-N // 128) < 64          # the planner keeps such launches on the GEMV (want_gemm, fp32 branch)
     assert _lib.describe_plan(q._layer, M)["kernel"] == ("generic" if few_tiles else "f32_mfma")
     t_gemm = _tuning(path=3)
     gen = torch.Generator().manual_seed(M)

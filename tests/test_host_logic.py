@@ -286,8 +286,13 @@ def test_dispatch_rules_are_the_measured_ones():
     # act-order with 2+ rows: x permuted once by a pre-pass (perm = 2), plain kernel on the re-sequenced rows
     for m in (2, 3, 4):
         p = _plan(4096, 11008, m, act=True)
-        assert (p["path"], p["kernel"], p["perm"]) == ("gemv", "mfma", 2), p
+        assert (p["path"], p["kernel"], p["perm"]) == ("gemv", "stream" if m == 2 else "mfma", 2), p      # = the plain layer's kernel at that M
     assert _plan(28672, 1024, 8, act=True)["perm"] == 2 and _plan(4096, 4096, 1, act=True, dtype=1)["perm"] == 1
+    # one row: in-kernel gather (perm = 1), except from 33 MiB up on layers that stream (pre-pass + streamed kernel) and for K beyond the LDS row
+    assert _plan(5120, 5120, 1, act=True)["perm"] == 1 and _plan(4096, 11008, 1, act=True)["perm"] == 1
+    p = _plan(13824, 5120, 1, act=True)
+    assert (p["kernel"], p["perm"], p["ln"]) == ("stream", 2, 8), p
+    assert _plan(8192, 28672, 1, act=True)["kernel"] == "stream" and _plan(28672, 1024, 1, act=True)["perm"] == 2
     # small N: K split (second, fixed-order reduce launch)
     assert _plan(8192, 1024, 1)["ksplit"] > 1
     # fused gate/up epilogue lives in the GEMV for M <= 8, and is a separate elementwise pass behind the GEMM paths

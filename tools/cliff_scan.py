@@ -18,6 +18,7 @@ SL = {"A": ([(4, BF16, False, 128), (4, BF16, True, 128)], (1, 2, 3, 4, 5, 8, 16
       "B": ([(4, F16, False, 32), (4, F16, False, 64), (4, F16, True, 32)], (1, 2, 3, 4, 5, 8, 16, 32, 64)),
       "C": ([(3, F16, False, 32), (3, F16, True, 32), (8, F16, False, 32), (8, F16, True, 32), (2, F16, False, 64)], (1, 2, 4, 8, 16, 64)),
       "D": ([(4, F32, False, 128), (4, F32, True, 128), (8, F32, False, 32)], (1, 2, 4, 8, 16, 64)),
+      "F": ([(4, F16, False, 128), (4, F16, True, 128)], (1, 2, 3, 4, 5, 8, 16, 32, 64)),
       "E": ([(4, F16, False, 128), (4, F16, True, 128)], (65, 96, 128, 192, 256, 384, 512, 1024))}
 cfgs, Ms = SL[a.slice]
 for shp in a.shapes.split(","):
