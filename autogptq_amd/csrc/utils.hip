@@ -433,7 +433,7 @@ hipError_t launch_awq_repack(const uint32_t* aq, const uint32_t* az, int K, int 
 hipError_t launch_permute_columns(const void* x, const int32_t* perm, int M, int K, int dtype, void* x_out, hipStream_t st) {
     // the LDS-staged row kernel runs one workgroup per row of x: for a few long rows (decode of act-order layers, M <= 4) the flat
     // one-thread-per-element gather below has K/256 x M workgroups instead (K = 28672, M = 1: ~7 us against ~2.5)
-    if (dtype != GPTQ_F32 && K % 8 == 0 && (size_t)K * 2 <= 64 * 1024 && (M >= 16 || K <= 4096)) return launch_permute_rows16(x, perm, M, K, x_out, st);
+    if (dtype != GPTQ_F32 && K % 8 == 0 && (size_t)K * 2 <= 64 * 1024 && (M >= 64 || K <= 4096)) return launch_permute_rows16(x, perm, M, K, x_out, st);
     dim3 grid((K + 255) / 256, M < 1024 ? M : 1024), block(256);
     if (dtype == GPTQ_F32)
         hipLaunchKernelGGL(permute_columns_kernel<float>, grid, block, 0, st, (const float*)x, perm, M, K, (float*)x_out);
