@@ -83,8 +83,11 @@ bool want_gemm(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
         if (M < min_m) return false;
         return plan_gemm(*L, M, t).supported;
     }
-    if (M <= 4) return false;
+    if (M <= 2) return false;
     const GemmPlan g = plan_gemm(*L, M, t);
+    // M = 3..4: only the unsplit streamed 64-column-strip kernel (160+ strips) beats the GEMVs there (tools/cliff_scan.py, us, M = 3 / 4 / 5:
+    // 4096x11008 11.8 / 12.0 / 10.8, 5120x13824 15.0 / 15.8 / 13.1 -- the M = 5 column is that kernel, whose time barely depends on M up to 16)
+    if (M <= 4 && !(g.supported && g.stream64 && g.ksplit == 1 && L->epilogue == GPTQ_EPI_NONE)) return false;
     // M = 5..8: the streamed 64-column-strip kernel (one matrix-core pass for up to 16 rows, weights by LDS DMA) where it exists;
     // layers with a fused epilogue keep the GEMV that applies it
     // (and the 16-column-strip kernel on narrow layers: 4096x4096 M = 5 / 8: 7.3 / 7.9 us against the GEMV's 8.0 / 8.3)
@@ -103,6 +106,10 @@ bool want_stream(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
     const StreamPlan sp = plan_stream(one, 1, M, t);
     if (!sp.ok) return false;
     if (t && t->path == 6) return true;
+    if (M >= 3) {                                      // 3..4 rows on layers of 160+ strips: the batched-decode kernel (want_gemm)
+        const Stream64Plan s64 = plan_stream64(one, 1, M, nullptr);
+        if (s64.ok && s64.pays && s64.ksplit == 1) return false;
+    }
     return stream_preferred(*L, M);
 }
 

@@ -1451,7 +1451,7 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     {
         const gptq_layer_t* one[1] = {&L};
         const Stream64Plan sp = plan_stream64(one, 1, M, tune);
-        pl.stream64 = sp.ok && (force_skinny == 4 || (force_skinny == 0 && M >= 5 && sp.pays));
+        pl.stream64 = sp.ok && (force_skinny == 4 || (force_skinny == 0 && M >= 3 && sp.pays));      // 3..4 rows: want_gemm takes it only unsplit
         if (pl.stream64) {
             pl.skinny = false;
             pl.mt = sp.mt; pl.bk = 32; pl.bm = 16 * sp.mt; pl.bn = 64;

@@ -943,7 +943,10 @@ def test_large_model_layers_take_the_streamed_gemv(K, N, M, dtype):
         y, yb = q(x.to(DEV)), q(x.to(DEV))
         yr = q(x.to(DEV), tuning=_tuning(path=5))
     d = _lib.describe_plan(q._layer, M)
-    assert (d["kernel"], d["ln"], d["waves"], d["u"]) == ("stream", 16 if N >= 16384 else 8, 8, 4), d
+    if M >= 3 and N >= 10240:                   # 160+ strips of 64 columns and 3..4 rows: the batched-decode kernel, unsplit
+        assert (d["kernel"], d["ksplit"]) == ("stream64", 1), d
+    else:
+        assert (d["kernel"], d["ln"], d["waves"], d["u"]) == ("stream", 16 if N >= 16384 else 8, 8, 4), d
     assert torch.equal(y, yb)
     mode = O.reference_zero_mode(False, 4)
     for n0 in ((N // 2) // 32 * 32, N - 96):

@@ -269,7 +269,9 @@ def test_dispatch_rules_are_the_measured_ones():
     # 4096 x 11008: the streamed (LDS-DMA) kernel with 64-column strips, one pass of 16 waves x 8 rows (8.2 vs 9.6 us); M = 1..2 only
     p = _plan(4096, 11008, 1)
     assert (p["kernel"], p["ln"], p["waves"], p["u"], p["ksplit"], p["strips"]) == ("stream", 16, 16, 8, 1, 172), p
-    assert _plan(4096, 11008, 3)["kernel"] == "mfma" and _plan(4096, 11008, 3)["strips"] == 688
+    assert _plan(4096, 11008, 3)["kernel"] == "stream64" and _plan(4096, 11008, 4)["kernel"] == "stream64"       # 3..4 rows, 160+ strips: batched-decode kernel, unsplit
+    assert _plan(11008, 4096, 3)["kernel"] == "mfma" and _plan(4096, 4096, 3)["kernel"] == "mfma"               # (with K slices / small layers: GEMV)
+    assert _plan(5120, 13824, 3)["kernel"] == "stream64" and _plan(13824, 5120, 3)["kernel"] == "stream"
     assert _plan(4096, 11008, 1, dtype=1)["kernel"] == "stream"
     # wider plain fp16 layers: 64- / 32-column strips with >= 160 workgroups; bf16 and act-order stay at 16 columns
     assert _plan(4096, 12288, 1)["ln"] == 16 and _plan(4096, 14336, 1)["ln"] == 16
@@ -278,15 +280,21 @@ def test_dispatch_rules_are_the_measured_ones():
     for (k, n), ln in (((5120, 5120), 8), ((13824, 5120), 8), ((8192, 8192), 8), ((5120, 13824), 8), ((8192, 28672), 16), ((28672, 8192), 8)):
         for m in (1, 4):
             p = _plan(k, n, m)
-            assert (p["kernel"], p["ln"], p["waves"], p["u"], p["ksplit"]) == ("stream", ln, 8, 4, 1), (k, n, m, p)
+            if m == 4 and n >= 10240:                 # 160+ strips of 64 columns, 3..4 rows: the batched-decode kernel, unsplit
+                assert (p["kernel"], p["ksplit"]) == ("stream64", 1), (k, n, m, p)
+            else:
+                assert (p["kernel"], p["ln"], p["waves"], p["u"], p["ksplit"]) == ("stream", ln, 8, 4, 1), (k, n, m, p)
     assert _plan(5120, 5120, 1, dtype=1)["kernel"] == "stream" and _plan(5120, 5120, 1, act=True)["kernel"] == "mfma"
     assert _plan(8192, 3584, 1)["kernel"] == "mfma" and _plan(8192, 1024, 1)["kernel"] == "mfma"
     assert _plan(4096, 12288, 1, dtype=1)["ln"] == 4 and _plan(4096, 12288, 1, act=True)["ln"] == 4
     assert _plan(4096, 12288, 1, act=True)["perm"] == 1
     # act-order with 2+ rows: x permuted once by a pre-pass (perm = 2), plain kernel on the re-sequenced rows
-    for m in (2, 3, 4):
-        p = _plan(4096, 11008, m, act=True)
-        assert (p["path"], p["kernel"], p["perm"]) == ("gemv", "stream" if m == 2 else "mfma", 2), p      # = the plain layer's kernel at that M
+    p = _plan(4096, 11008, 2, act=True)
+    assert (p["path"], p["kernel"], p["perm"]) == ("gemv", "stream", 2), p                               # = the plain layer's kernel at that M
+    for m in (3, 4):
+        assert _plan(4096, 11008, m, act=True)["kernel"] == "stream64"                                   # (which from 3 rows is the batched-decode kernel)
+        p = _plan(11008, 4096, m, act=True)
+        assert (p["path"], p["kernel"], p["perm"]) == ("gemv", "mfma", 2), p
     assert _plan(28672, 1024, 8, act=True)["perm"] == 2 and _plan(4096, 4096, 1, act=True, dtype=1)["perm"] == 1
     # one row: in-kernel gather (perm = 1), except from 33 MiB up on layers that stream (pre-pass + streamed kernel) and for K beyond the LDS row
     assert _plan(5120, 5120, 1, act=True)["perm"] == 1 and _plan(4096, 11008, 1, act=True)["perm"] == 1
@@ -316,7 +324,7 @@ def test_dispatch_rules_are_the_measured_ones():
     # rows of x: GEMV up to 4; 5..8 rows: one matrix-core pass over 16 rows (16-column strips on narrow layers, the streamed
     # 64-column-strip kernel elsewhere) unless the layer has a fused epilogue (the GEMV applies it) or K is long and N small
     assert _plan(4096, 4096, 4)["mt"] == 4 and _plan(4096, 4096, 4)["path"] == "gemv"
-    assert _plan(4096, 4096, 8)["kernel"] == "strip16" and _plan(4096, 11008, 4)["path"] == "gemv"
+    assert _plan(4096, 4096, 8)["kernel"] == "strip16" and _plan(4096, 11008, 2)["path"] == "gemv" and _plan(11008, 4096, 4)["path"] == "gemv"
     assert _plan(28672, 1024, 8)["path"] == "gemv"
     # [gate | up] with the SiLU*mul epilogue: fused in the GEMV for 1..2 rows, streamed kernel + elementwise pass from 3 rows
     # (4096 x 22016, M = 4: 27.7 -> 19.5 us, M = 8: 50.8 -> 19.5 us)
