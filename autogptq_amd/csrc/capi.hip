@@ -368,8 +368,11 @@ static bool want_stream64_multi(const gptq_layer_t* const* layers, int n, int M,
     if (n < 2 || n > 4 || M > 64) return false;
     const bool forced = t && t->path == 3 && t->reserved[2] == 4;
     if (t && t->path != 0 && !forced) return false;
-    if (M <= 4 && !forced) return false;                         // up to 4 rows: the streamed GEMV (or layer by layer)
+    if (M <= 2 && !forced) return false;                         // up to 2 rows: the streamed GEMV (or layer by layer)
     const Stream64Plan sp = plan_stream64(layers, n, M, t);
+    // 3..4 rows: only one unsplit round of 16-wave workgroups beats the streamed GEMV (tools/misc_bench.py, us, GEMV at M = 4 against this kernel
+    // at M = 8: q|k|v, 192 strips: 12.0 against 11.2; gate|up, 344 strips in 8-wave workgroups: 17.5 against 18.8)
+    if (M <= 4 && !forced && !(sp.ok && sp.ksplit == 1 && sp.strips_total <= 256)) return false;
     return sp.ok && (sp.pays || forced);
 }
 
@@ -378,13 +381,13 @@ size_t gptq_workspace_bytes_multi_ex(const gptq_layer_t* const* layers, int n_la
     for (int i = 0; i < n_layers; ++i)
         if (check_layer(layers[i]) != GPTQ_OK) return 0;
     size_t need = 0;
-    if (n_layers <= 4) {
-        const StreamPlan sp = plan_stream(layers, n_layers, M, tune);
-        if (sp.ok && multi_preferred(layers, n_layers, M)) return sp.partial_bytes ? WS_HEADER_BYTES + sp.partial_bytes : 0;
-    }
     if (want_stream64_multi(layers, n_layers, M, tune)) {
         const Stream64Plan sp = plan_stream64(layers, n_layers, M, tune);
         return sp.partial_bytes ? WS_HEADER_BYTES + sp.partial_bytes : 0;
+    }
+    if (n_layers <= 4) {
+        const StreamPlan sp = plan_stream(layers, n_layers, M, tune);
+        if (sp.ok && multi_preferred(layers, n_layers, M)) return sp.partial_bytes ? WS_HEADER_BYTES + sp.partial_bytes : 0;
     }
     for (int i = 0; i < n_layers; ++i) need = std::max(need, gptq_workspace_bytes_ex(layers[i], M, nullptr));
     return need;
@@ -407,11 +410,6 @@ int gptq_forward_multi_ex(const gptq_layer_t* const* layers, int n_layers, const
         if (layers[i]->K != layers[0]->K) return fail(GPTQ_ERR_SHAPE, "layers of one gptq_forward_multi call read the same x: in_features %d != %d", layers[i]->K, layers[0]->K);
         if (layers[i]->dtype != layers[0]->dtype) return fail(GPTQ_ERR_UNSUPPORTED, "layers of one gptq_forward_multi call share the dtype of x");
     }
-    if (n_layers <= 4 && M <= 4) {
-        const StreamPlan sp = plan_stream(layers, n_layers, M, tune);
-        if (sp.ok && multi_preferred(layers, n_layers, M)) return stream_call(layers, n_layers, sp, x, outs, M, ws, ws_bytes, stream);
-        if (tune && tune->path == 6) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 6: these layers / this launch shape do not fit the streamed GEMV");
-    }
     if (want_stream64_multi(layers, n_layers, M, tune)) {
         const Stream64Plan sp = plan_stream64(layers, n_layers, M, tune);
         const WsView wv = split_ws(ws, ws_bytes);
@@ -420,6 +418,11 @@ int gptq_forward_multi_ex(const gptq_layer_t* const* layers, int n_layers, const
         hipError_t e = launch_stream64(layers, sp, x, outs, M, wv.header, wv.body, nullptr, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "gptq batched-decode launch (needs > 64 KiB of LDS: was gptq_init() called on this device?)");
         return GPTQ_OK;
+    }
+    if (n_layers <= 4 && M <= 4) {
+        const StreamPlan sp = plan_stream(layers, n_layers, M, tune);
+        if (sp.ok && multi_preferred(layers, n_layers, M)) return stream_call(layers, n_layers, sp, x, outs, M, ws, ws_bytes, stream);
+        if (tune && tune->path == 6) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 6: these layers / this launch shape do not fit the streamed GEMV");
     }
     if (tune && tune->path == 3 && tune->reserved[2] == 4)
         return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 3 / reserved[2] = 4: these layers do not fit one batched-decode launch (2..4 plain 4-bit layers, M <= 64)");
