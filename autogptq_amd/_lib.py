@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPTQ_MI355X_LIB", os.path.join(_HERE, "libgptq_mi355x.so"))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 GPTQ_F16, GPTQ_BF16, GPTQ_F32 = 0, 1, 2
 ZERO_WRAP, ZERO_NOWRAP = 0, 1
@@ -31,6 +31,7 @@ EXPORTS = (
     "gptq_awq_unpack", "gptq_awq_repack", "gptq_describe_plan",
     "gptq_init", "gptq_workspace_bytes_max", "gptq_validate_g_idx",
     "gptq_forward_multi", "gptq_workspace_bytes_multi", "gptq_forward_multi_ex", "gptq_workspace_bytes_multi_ex",
+    "gptq_peer_scatter", "gptq_peer_collect", "gptq_peer_gather",
 )
 WS_HEADER_BYTES = 65536
 
@@ -48,6 +49,15 @@ class GptqLayer(Structure):
 class GptqTuning(Structure):
     _fields_ = [("lanes_n", c_int32), ("waves", c_int32), ("ksplit", c_int32), ("path", c_int32),
                 ("reserved", c_int32 * 4)]
+
+
+PEER_MAX = 8
+
+
+class GptqPeerGroup(Structure):
+    """gptq_peer_group_t: the mapped exchange buffers / flags of all ranks, in rank order (include/gptq_mi355x.h)."""
+    _fields_ = [("xbuf", (c_void_p * PEER_MAX) * 2), ("flags", c_void_p * PEER_MAX), ("state", c_void_p),
+                ("world", c_int32), ("rank", c_int32), ("rows_max", c_int32), ("N", c_int32)]
 
 
 class GptqError(RuntimeError):
@@ -108,6 +118,9 @@ def load() -> ctypes.CDLL:
     lib.gptq_describe_plan.argtypes = [POINTER(GptqLayer), c_int, POINTER(GptqTuning), c_char_p, c_size_t]
     lib.gptq_awq_unpack.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.gptq_awq_repack.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    lib.gptq_peer_scatter.argtypes = [POINTER(GptqPeerGroup), c_void_p, c_int, c_int, c_int, c_void_p]
+    lib.gptq_peer_collect.argtypes = [POINTER(GptqPeerGroup), c_void_p, c_int, c_int, ctypes.c_uint32, c_void_p]
+    lib.gptq_peer_gather.argtypes = [POINTER(GptqPeerGroup), c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_uint32, c_void_p]
     for name in EXPORTS:
         if name not in ("gptq_last_error", "gptq_status_string", "gptq_workspace_bytes", "gptq_workspace_bytes_ex",
                         "gptq_workspace_bytes_max", "gptq_workspace_bytes_multi", "gptq_workspace_bytes_multi_ex"):

@@ -561,9 +561,9 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
     } else {
         const GemvPlan v = plan_gemv(Lc, M, tune);
         const char* kern = v.mfma ? "mfma" : (v.mfmag ? "mfma_generic" : (v.direct ? "direct" : (v.fast ? "lds_staged" : "generic")));
-        snprintf(out, out_bytes, "path=gemv kernel=%s ln=%d waves=%d u=%d ksplit=%d mt=%d strips=%d pair=%d perm=%d epilogue=%s", kern, v.ln,
+        snprintf(out, out_bytes, "path=gemv kernel=%s ln=%d waves=%d u=%d ksplit=%d mt=%d strips=%d pair=%d perm=%d epilogue=%s%s", kern, v.ln,
                  v.waves, v.u, v.ksplit, v.mt, v.strips, v.pair ? 1 : 0, v.xperm ? 2 : (v.use_seq ? 1 : 0),
-                 v.pair ? "fused" : (unfused_epilogue ? "separate" : "none"));
+                 v.pair ? "fused" : (unfused_epilogue ? "separate" : "none"), v.magic ? " deq=magic" : "");
     }
     return GPTQ_OK;
 }
@@ -593,6 +593,48 @@ int gptq_awq_repack(const uint32_t* awq_qweight, const uint32_t* awq_qzeros, int
     hipError_t e = launch_awq_repack(awq_qweight, awq_qzeros, K, N, group_size, qweight_out, qzeros_out, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "gptq_awq_repack launch");
     return GPTQ_OK;
+}
+
+
+// ---- direct peer-store all-gather (peer.hip) ---------------------------------------------------------------------------
+static int check_peer_group(const gptq_peer_group_t* pg, int M, int dtype) {
+    if (!pg) return fail(GPTQ_ERR_NULL, "peer group is NULL");
+    if (pg->world < 1 || pg->world > GPTQ_PEER_MAX) return fail(GPTQ_ERR_SHAPE, "peer group world (%d) must be 1..%d", pg->world, GPTQ_PEER_MAX);
+    if (pg->rank < 0 || pg->rank >= pg->world) return fail(GPTQ_ERR_SHAPE, "peer group rank (%d) outside 0..%d", pg->rank, pg->world - 1);
+    if (!pg->state) return fail(GPTQ_ERR_NULL, "peer group state is NULL");
+    for (int r = 0; r < pg->world; ++r)
+        if (!pg->xbuf[0][r] || !pg->xbuf[1][r] || !pg->flags[r]) return fail(GPTQ_ERR_NULL, "peer group: buffers / flags of rank %d are NULL", r);
+    if (!dtype_ok(dtype)) return fail(GPTQ_ERR_UNSUPPORTED, "unsupported dtype enum %d", dtype);
+    if (pg->N <= 0 || pg->N % pg->world || (pg->N / pg->world) % 32)
+        return fail(GPTQ_ERR_SHAPE, "peer group: out_features (%d) must split over %d ranks in multiples of 32 columns", pg->N, pg->world);
+    if (M <= 0 || M > pg->rows_max) return fail(GPTQ_ERR_SHAPE, "M (%d) must be 1..rows_max (%d) of the exchange buffers", M, pg->rows_max);
+    return GPTQ_OK;
+}
+
+int gptq_peer_scatter(const gptq_peer_group_t* pg, const void* y_local, int M, int n_local, int dtype, void* stream) {
+    if (int rc = check_peer_group(pg, M, dtype)) return rc;
+    if (!y_local) return fail(GPTQ_ERR_NULL, "y_local must be non-NULL");
+    if (n_local != pg->N / pg->world) return fail(GPTQ_ERR_SHAPE, "n_local (%d) must be N / world = %d", n_local, pg->N / pg->world);
+    hipError_t e = launch_peer_scatter(*pg, y_local, M, n_local, dtype, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_peer_scatter launch");
+    return GPTQ_OK;
+}
+
+int gptq_peer_collect(const gptq_peer_group_t* pg, void* out, int M, int dtype, uint32_t max_spins, void* stream) {
+    if (int rc = check_peer_group(pg, M, dtype)) return rc;
+    if (!out) return fail(GPTQ_ERR_NULL, "out must be non-NULL");
+    if (max_spins == 0) return fail(GPTQ_ERR_SHAPE, "max_spins must be > 0 (the wait is bounded by design)");
+    hipError_t e = launch_peer_collect(*pg, out, M, dtype, max_spins, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_peer_collect launch");
+    return GPTQ_OK;
+}
+
+int gptq_peer_gather(const gptq_peer_group_t* pg, const void* y_local, void* out, int M, int n_local, int dtype,
+                     uint32_t max_spins, void* stream) {
+    if (!out) return fail(GPTQ_ERR_NULL, "out must be non-NULL");
+    if (max_spins == 0) return fail(GPTQ_ERR_SHAPE, "max_spins must be > 0 (the wait is bounded by design)");
+    if (int rc = gptq_peer_scatter(pg, y_local, M, n_local, dtype, stream)) return rc;
+    return gptq_peer_collect(pg, out, M, dtype, max_spins, stream);
 }
 
 }  // extern "C"

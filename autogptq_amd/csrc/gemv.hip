@@ -1070,14 +1070,91 @@ __global__ void __launch_bounds__(1024, WPS) gemv_q4_stream_kernel(GemvStreamPar
     }
 }
 
+// ---- magic-number field decode for the 3- and 8-bit fp16 matrix-core GEMV ------------------------------------------------------
+// The generic kernel below extracts every field on its own (shift, mask, integer subtract, two conversions: ~5.3 VALU per
+// weight; the 3-bit g32 decode launch is 912 VALU per wave and spends as long on them as on its loads).  For fp16 the same exact
+// w - z comes out of packed arithmetic two fields at a time, like the 4-bit kernels do: (t & (7 << s) * 0x00010001) | 0x64006400 is
+// the half2 (1024 + f_a * 2^s, 1024 + f_b * 2^s) for the two fields sitting at bit s of the two 16-bit halves of t, and ONE
+// v_pk_fma_f16 by 2^-s with -(1024 * 2^-s + z) gives (f_a - z, f_b - z) exactly (s + bits <= 10: the field stays inside the
+// mantissa; every intermediate is an integer below 2048).
+//   8-bit: the word itself pairs (f0, f2) and, shifted by 8, (f1, f3): 1 shift + 2 v_and_or + 2 v_pk_add per 4 weights.
+//   3-bit: 32 fields in 96 bits do not line up with the halves, but 16-bit WINDOWS of the bit stream at multiples of 15 bits do:
+//          t_k = (stream >> 30k)[15:0] | (stream >> (30k + 15))[15:0] << 16 holds fields 10k..10k+4 in the low half and 10k+5..10k+9 in
+//          the high half at the same bit positions 0, 3, 6, 9, 12 (9 and 12 are brought down to 3 and 6 by one shift of the whole
+//          word); fields 30 and 31 are a fourth window pair.  <= 3 VALU per t_k, then 1 v_and_or + 1 v_pk op per pair: 46 VALU per
+//          32 weights instead of ~170.
+// The pairs put the unit's k values into matrix-core slots in the order ka(p), kb(p); x is brought into the same order with one
+// v_perm per pair (shared by the lane's 4 columns).  bf16 has neither the mantissa (7 bits) nor packed arithmetic for this and keeps
+// the field-by-field form, as do 2-bit layers.
+__device__ __forceinline__ unsigned vand_or(unsigned a, unsigned mask, unsigned orv) {      // (a & mask) | orv, ONE VALU op
+    unsigned r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(orv));
+    return r;
+}
+__device__ __forceinline__ unsigned f16x2_bits(f16x2 v) { return __builtin_bit_cast(unsigned, v); }
+
+template <int BITS> struct MagicF16;
+template <> struct MagicF16<8> {
+    static constexpr int NP = 2;                                   // pairs per unit (4 values)
+    static constexpr int ka(int p) { return p; }                  // (0, 2), (1, 3)
+    static constexpr int kb(int p) { return p + 2; }
+    f16x2 c1;
+    __device__ __forceinline__ void setup(int z) { c1 = as_f16x2((unsigned)z * 0x00010001u + 0xE400E400u); }    // -(1024 + z), z <= 256
+    __device__ __forceinline__ void pairs(const unsigned (&w)[1], unsigned magic, unsigned (&bp)[NP]) const {
+        bp[0] = f16x2_bits(as_f16x2(vand_or(w[0], 0x00ff00ffu, magic)) + c1);
+        bp[1] = f16x2_bits(as_f16x2(vand_or(w[0] >> 8, 0x00ff00ffu, magic)) + c1);
+    }
+};
+template <> struct MagicF16<3> {
+    static constexpr int NP = 16;                                  // pairs per unit (32 values in 3 words)
+    static constexpr int ka(int p) { return p < 15 ? 10 * (p / 5) + p % 5 : 30; }
+    static constexpr int kb(int p) { return p < 15 ? ka(p) + 5 : 31; }
+    f16x2 c1, c3, c6;
+    __device__ __forceinline__ void setup(int z) {                 // z <= 8
+        c1 = as_f16x2((unsigned)z * 0x00010001u + 0xE400E400u);   // -(1024 + z)
+        const f16x2 k896 = {(f16)896.f, (f16)896.f}, k1008 = {(f16)1008.f, (f16)1008.f};
+        c3 = c1 + k896;                                            // -(128 + z), exact
+        c6 = c1 + k1008;                                           // -(16 + z), exact
+    }
+    __device__ __forceinline__ void five(unsigned t, unsigned magic, unsigned* bp) const {
+        const f16x2 r8 = {(f16)0.125f, (f16)0.125f}, r64 = {(f16)0.015625f, (f16)0.015625f};
+        const unsigned t6 = t >> 6;
+        bp[0] = f16x2_bits(as_f16x2(vand_or(t, 0x00070007u, magic)) + c1);
+        bp[1] = f16x2_bits(as_f16x2(vand_or(t, 0x00380038u, magic)) * r8 + c3);
+        bp[2] = f16x2_bits(as_f16x2(vand_or(t, 0x01C001C0u, magic)) * r64 + c6);
+        bp[3] = f16x2_bits(as_f16x2(vand_or(t6, 0x00380038u, magic)) * r8 + c3);
+        bp[4] = f16x2_bits(as_f16x2(vand_or(t6, 0x01C001C0u, magic)) * r64 + c6);
+    }
+    __device__ __forceinline__ void pairs(const unsigned (&w)[3], unsigned magic, unsigned (&bp)[NP]) const {
+        // 16-bit windows of the 96-bit stream at bits 0 / 15, 30 / 45, 60 / 75, 90 / 93 (low half / high half of t)
+        const unsigned t0 = __builtin_amdgcn_perm(w[0] >> 15, w[0], 0x05040100u);
+        const unsigned t1 = __builtin_amdgcn_perm(w[1] >> 13, __builtin_amdgcn_alignbit(w[1], w[0], 30), 0x05040100u);
+        const unsigned t2 = __builtin_amdgcn_perm(w[2] >> 11, __builtin_amdgcn_alignbit(w[2], w[1], 28), 0x05040100u);
+        const unsigned t3 = __builtin_amdgcn_perm(w[2] >> 29, w[2] >> 26, 0x05040100u);
+        five(t0, magic, bp);
+        five(t1, magic, bp + 5);
+        five(t2, magic, bp + 10);
+        bp[15] = f16x2_bits(as_f16x2(vand_or(t3, 0x00070007u, magic)) + c1);
+    }
+};
+// x values of one unit (natural order, two per register) -> the register holding (x[ka(P)], x[kb(P)])
+template <int BITS, int P, int NR>
+__device__ __forceinline__ unsigned magic_x_pair(const unsigned (&xr)[NR]) {
+    constexpr int a = MagicF16<BITS>::ka(P), b = MagicF16<BITS>::kb(P);
+    constexpr unsigned sel = ((a & 1) ? 0x0302u : 0x0100u) | (((b & 1) ? 0x0706u : 0x0504u) << 16);
+    return __builtin_amdgcn_perm(xr[b >> 1], xr[a >> 1], sel);
+}
+
 // ---- matrix-core GEMV, any bits, fp16 / bf16 -----------------------------------------------------
 // The same structure for the other packings (2/3/8-bit, and 4-bit with bf16): a lane owns 4 columns and U consecutive
 // packing units (1 word = 16/8/4 values, or 3 words = 32 values for 3-bit) of one group; fields are extracted with
 // v_bfe, w - z is formed in integers and converted exactly to T (|w - z| <= 256 fits both fp16 and bf16), 4 values of
 // the lane's own column feed one 4x4x4 MFMA against the matching 4 x values of up to 4 x rows (natural k order: no x
 // permutation).  out = sum_g s_g * (sum_{k in g} x_k (w_k - z_g)), fp32 sums.
-template <int BITS, typename T, int LN, int MT, int U>
+// MAGIC (3- / 8-bit, fp16): the packed magic-number decode above instead of the field-by-field one; same values, bit for bit.
+template <int BITS, typename T, int LN, int MT, int U, bool MAGIC = false>
 __global__ void __launch_bounds__(1024, 4) gemv_mfma_generic_kernel(GemvParams p) {
+    static_assert(!MAGIC || (std::is_same_v<T, f16> && (BITS == 3 || BITS == 8)), "magic-number decode: 3- / 8-bit fp16 only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;
     constexpr int UW = Pack<BITS>::words, KPU = Pack<BITS>::vals, WR = 64 / LN, CT = LN * 4;
@@ -1135,6 +1212,31 @@ __global__ void __launch_bounds__(1024, 4) gemv_mfma_generic_kernel(GemvParams p
         f32x4 accg[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) accg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (MAGIC) {
+            unsigned magic;
+            asm("v_mov_b32 %0, 0x64006400" : "=v"(magic));     // opaque: keeps (t & mask) | magic one v_and_or_b32
+            MagicF16<BITS> mg[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mg[c].setup(z[c]);
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const bool live = (u0 + j < ue);
+                unsigned xa[KPU / 2];                            // x in the slot order of the pairs, shared by the 4 columns
+                [&]<int... P>(std::integer_sequence<int, P...>) {
+                    ((xa[P] = live ? magic_x_pair<BITS, P>(xr[j]) : 0u), ...);
+                }(std::make_integer_sequence<int, KPU / 2>{});
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    unsigned wds[UW], bp[KPU / 2];
+#pragma unroll
+                    for (int w = 0; w < UW; ++w) wds[w] = q[j][w][c];
+                    mg[c].pairs(wds, magic, bp);
+#pragma unroll
+                    for (int Q = 0; Q < KPU / 4; ++Q)
+                        accg[c] = Mma4<T>::run(u32x2{xa[2 * Q], xa[2 * Q + 1]}, u32x2{bp[2 * Q], bp[2 * Q + 1]}, accg[c]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const bool live = (u0 + j < ue);
@@ -1157,6 +1259,7 @@ __global__ void __launch_bounds__(1024, 4) gemv_mfma_generic_kernel(GemvParams p
                      ...);
                 }(std::make_integer_sequence<int, KPU / 4>{});
             }
+        }
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1342,6 +1445,8 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     const size_t rbytes = (size_t)waves * pl.mt * ln * 4 * sizeof(float);
     pl.workspace_bytes = ks > 1 ? (size_t)ks * M * L.N * sizeof(float) : 0;
     pl.u = 1;
+    // 3- / 8-bit fp16: packed magic-number decode (tuning.reserved[1] = 1 keeps the field-by-field form, for A/B runs)
+    pl.magic = pl.mfmag && L.dtype == GPTQ_F16 && (L.bits == 3 || L.bits == 8) && !(tune && tune->reserved[1] == 1);
     if (pl.mfmag) {
         const int gunits = L.group_size / kpu;
         const int per_lane = (pl.units_per_split + rows_per_iter - 1) / rows_per_iter;
@@ -1533,6 +1638,17 @@ template <int BITS, typename T, int MT>
 static hipError_t launch_mfmag_u(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
     dim3 grid(pl.strips, pl.ksplit, pl.mtiles), block(pl.waves * 64);
     if (pl.ln != 4) return hipErrorInvalidValue;
+    if constexpr (std::is_same_v<T, f16> && (BITS == 3 || BITS == 8)) {
+        if (pl.magic) {
+            switch (pl.u) {
+                case 1: hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 1, true>), grid, block, pl.lds_bytes, st, p); break;
+                case 2: if constexpr (BITS == 8) { hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 2, true>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
+                case 4: if constexpr (BITS == 8) { hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 4, true>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
+                default: return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
+    }
     switch (pl.u) {
         case 1: hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 1>), grid, block, pl.lds_bytes, st, p); break;
         case 2: if constexpr (BITS != 3) { hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 2>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;

@@ -13,6 +13,7 @@ struct GemvPlan {
     bool direct;   // fast path without LDS staging (x / scales / zeros straight from L2)
     bool mfma;     // direct path with the k-reduction on v_mfma_f32_4x4x4_16b_f16
     bool mfmag;    // matrix-core kernel for the other packings / bf16 (gemv_mfma_generic_kernel)
+    bool magic;    // ... with the packed magic-number field decode (3- / 8-bit fp16)
     bool pair;     // mfma path with the fused SILU_MUL epilogue (gate/up halves walked by the same workgroup)
     bool xperm;    // act-order, 2+ rows of x: x is permuted once by a pre-pass into the workspace front (xperm_bytes) and the plain kernel streams qweight_seq
     size_t xperm_bytes;
@@ -84,5 +85,8 @@ hipError_t launch_awq_repack(const uint32_t* aq, const uint32_t* az, int K, int 
 hipError_t launch_silu_mul(const void* y, void* out, int M, int N, int dtype, hipStream_t st);
 hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int K, void* x_out, hipStream_t st, bool slot_order = false);
 hipError_t launch_permute_columns(const void* x, const int32_t* perm, int M, int K, int dtype, void* x_out, hipStream_t st);
+// peer.hip: direct peer-store all-gather (y_local / out may be NULL: scatter-only / collect-only)
+hipError_t launch_peer_scatter(const gptq_peer_group_t& pg, const void* y_local, int M, int n_local, int dtype, hipStream_t st);
+hipError_t launch_peer_collect(const gptq_peer_group_t& pg, void* out, int M, int dtype, unsigned max_spins, hipStream_t st);
 
 }  // namespace gptq

@@ -10,6 +10,10 @@ Rank r of T owns columns [r*N/T, (r+1)*N/T): ``qweight[:, n0:n1]``, ``qzeros[:, 
 ``scales[:, n0:n1]``, ``bias[n0:n1]``; ``g_idx`` and x are replicated.  (N/T) must be a multiple of
 32 (the 3-bit packing unit).  forward = local GEMV/GEMM + ONE all-gather of the [M, N/T] outputs
 (RCCL over xGMI when the process group backend is "nccl").
+
+``exchange="peer_store"`` (experimental, off by default) replaces the collective by the direct peer-store
+exchange of ``csrc/peer.hip``: every rank stores its slice into every rank's exchange buffer (one xGMI link per peer), raises a
+flag, and copies its own gathered rows out -- two launches, graph-capturable, no rank-major -> column-major copy for M > 1.
 """
 from __future__ import annotations
 
@@ -46,16 +50,23 @@ class ColumnParallelQuantLinear(nn.Module):
     """Wraps the rank-local shard (any module mapping [M,K] -> [M,N/T]) and gathers the output."""
 
     def __init__(self, local: Callable[[torch.Tensor], torch.Tensor], outfeatures: int,
-                 group: Optional[dist.ProcessGroup] = None, gather_output: bool = True):
+                 group: Optional[dist.ProcessGroup] = None, gather_output: bool = True,
+                 exchange: str = "all_gather", max_rows: int = 1):
         super().__init__()
+        if exchange not in ("all_gather", "peer_store"):
+            raise ValueError(f"exchange must be 'all_gather' or 'peer_store', got {exchange!r}")
         self.local = local
         self.outfeatures = outfeatures
         self.group = group
         self.gather_output = gather_output
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.exchange = exchange
+        self.max_rows = max_rows
+        self._px = None                     # PeerExchange, built on the first forward (needs the output dtype / device)
 
     @classmethod
-    def from_full(cls, full, rank: int, world: int, group=None, device=None, gather_output=True):
+    def from_full(cls, full, rank: int, world: int, group=None, device=None, gather_output=True,
+                  exchange: str = "all_gather", max_rows: int = 1):
         """Build the rank's shard from a full (unsharded) mi355x QuantLinear."""
         from .qlinear_mi355x import QuantLinear
 
@@ -70,7 +81,7 @@ class ColumnParallelQuantLinear(nn.Module):
             local.bias = b
         if device is not None:
             local = local.to(device)
-        return cls(local, full.outfeatures, group=group, gather_output=gather_output)
+        return cls(local, full.outfeatures, group=group, gather_output=gather_output, exchange=exchange, max_rows=max_rows)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y = self.local(x)                                   # [..., N/T]
@@ -79,6 +90,14 @@ class ColumnParallelQuantLinear(nn.Module):
         lead = y.shape[:-1]
         y2 = y.reshape(-1, y.shape[-1]).contiguous()         # [M, N/T]
         M, nl = y2.shape
+        if self.exchange == "peer_store":
+            if not y2.is_cuda:
+                raise RuntimeError("exchange='peer_store' moves device buffers; the shard output is on the CPU")
+            if self._px is None or self._px.rows_max < M:
+                # collective: every rank reaches this with the same M (the buffers are symmetric)
+                from .peer_exchange import PeerExchange
+                self._px = PeerExchange(max(M, self.max_rows), self.world * nl, y2.dtype, y2.device, group=self.group)
+            return self._px.gather(y2).reshape(lead + (self.world * nl,))
         if y2.is_cuda and _host_staged(self.group):
             hb = torch.empty((self.world * M, nl), dtype=y2.dtype)
             dist.all_gather_into_tensor(hb, y2.cpu(), group=self.group)

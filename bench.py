@@ -370,10 +370,12 @@ def cpu_baseline(M, act_order, budget_s=20.0):
             "ms_per_layer_mean": round(1e3 * total_t / sum(int(r.split('x')[2]) for r in reps_done), 2)}
 
 
-def bench_tp(device, rank, world, steps):
+def bench_tp(device, rank, world, steps, peer_store=False):
     """Column-parallel Llama-2-70B shapes (BASELINE config 4): local kernel + one all-gather, M = 1 (decode) and M = 2048
     (prefill); and the Megatron pairing of an MLP block -- column-parallel gate / up without gather feeding a row-parallel
-    down projection: ONE all-reduce per block.  Eager calls (RCCL on the layer's stream), HIP events, max over ranks."""
+    down projection: ONE all-reduce per block.  Eager calls (RCCL on the layer's stream), HIP events, max over ranks.
+    peer_store (--tp-exchange peer_store, experimental): the M = 1 layers again with the direct peer-store exchange of
+    csrc/peer.hip instead of the collective (never exercised across GPUs by the builder: 1-GPU boxes only)."""
     import torch.distributed as dist
     from autogptq_amd.tensor_parallel import ColumnParallelQuantLinear, RowParallelQuantLinear
 
@@ -410,6 +412,21 @@ def bench_tp(device, rank, world, steps):
                 ent["out_cols"] = int(y.shape[-1])
             except Exception as e:
                 ent[f"error_m{M}"] = repr(e)[:200]
+        if peer_store:
+            try:
+                modp = ColumnParallelQuantLinear(local, N, exchange="peer_store", max_rows=1)
+                x = (torch.rand(1, K, device=device) - 0.5).half()
+                with torch.no_grad():
+                    t_ps, yp = timed(lambda: modp(x), steps)
+                modp._px.check_timeout()
+                t = torch.tensor([t_ps], device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ent["us_per_layer_with_peer_store"] = round(t[0].item() * 1e6, 2)
+                ent["peer_store_equals_allgather"] = bool(torch.equal(yp, mod(x)))
+                dist.barrier()
+                del modp
+            except Exception as e:
+                ent["error_peer_store"] = repr(e)[:200]
         res[name] = ent
         del local, mod
     try:      # MLP block 8192 -> 28672 -> 8192: gate/up column shards (no gather) -> down row shard (one all-reduce)
@@ -465,6 +482,8 @@ def main():
     ap.add_argument("--no-fused", action="store_true", help="skip the extra fused-callers measurement (decode, 1 GPU only)")
     ap.add_argument("--per-layer", action="store_true", help="decode: 224 separate launches per step (no gptq_forward_multi grouping)")
     ap.add_argument("--no-extras", action="store_true", help="decode, 1 GPU: skip the prefill / config5 / eager blocks of the default line")
+    ap.add_argument("--tp-exchange", default="all_gather", choices=["all_gather", "peer_store"],
+                    help="tp block: also time the experimental direct peer-store exchange (csrc/peer.hip) next to the collective")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -554,7 +573,7 @@ def main():
     tp = None
     if world > 1 and not args.no_tp and not prefill:
         try:
-            tp = bench_tp(device, rank, world, 50)
+            tp = bench_tp(device, rank, world, 50, peer_store=(args.tp_exchange == "peer_store"))
         except Exception as e:                       # the headline line must still be printed
             tp = {"error": repr(e)[:300]}
 

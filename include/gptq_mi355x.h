@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define GPTQ_MI355X_ABI_VERSION 3
+#define GPTQ_MI355X_ABI_VERSION 4
 #define GPTQ_WORKSPACE_HEADER_BYTES 65536
 
 typedef enum gptq_status_t {
@@ -109,7 +109,7 @@ typedef struct gptq_tuning_t {
     int32_t waves;       /* waves per workgroup (1..16) */
     int32_t ksplit;      /* workgroups along K (1 = no cross-workgroup reduction) */
     int32_t path;        /* 0 auto, 1 generic GEMV, 2 LDS-staged q4/fp16 GEMV, 3 MFMA GEMM, 4 direct q4/fp16 GEMV, 5 matrix-core q4/fp16 GEMV, 6 streamed (LDS-DMA) q4 GEMV */
-    int32_t reserved[4]; /* [0]: max packed rows per lane and iteration for the register-direct GEMVs, = rows per lane for the streamed one, = K-steps per burst for the batched-decode kernel (0 = heuristic); [1]: 32 = force the 32-deep K-step in the MFMA GEMM; [2]: 1 = force the 64-column skinny GEMM, 2 = force the tiled GEMM, 3 = force the 16-column-strip GEMM (4-bit, M <= 64), 4 = force the streamed 64-column-strip batched-decode GEMM (4-bit, M <= 64; waves / ksplit apply); [3]: tiled-GEMM inner-loop schedule variant */
+    int32_t reserved[4]; /* [0]: max packed rows per lane and iteration for the register-direct GEMVs, = rows per lane for the streamed one, = K-steps per burst for the batched-decode kernel (0 = heuristic); [1]: 32 = force the 32-deep K-step in the MFMA GEMM, 1 = field-by-field decode in the 3- / 8-bit fp16 matrix-core GEMV instead of the packed magic-number one (A/B runs); [2]: 1 = force the 64-column skinny GEMM, 2 = force the tiled GEMM, 3 = force the 16-column-strip GEMM (4-bit, M <= 64), 4 = force the streamed 64-column-strip batched-decode GEMM (4-bit, M <= 64; waves / ksplit apply); [3]: tiled-GEMM inner-loop schedule variant */
 } gptq_tuning_t;
 
 int         gptq_abi_version(void);
@@ -220,6 +220,37 @@ int gptq_awq_unpack(const uint32_t *awq_qweight, const uint32_t *awq_qzeros, con
                     int group_size, void *weight_kn_out, int8_t *zeros_out, void *stream);
 int gptq_awq_repack(const uint32_t *awq_qweight, const uint32_t *awq_qzeros, int K, int N, int group_size,
                     uint32_t *qweight_out, uint32_t *qzeros_out, void *stream);
+
+/* ---- direct peer-store all-gather for out_features-parallel layers; experimental, off by default ----------
+ * The reference runs a layer on one GPU only (tests/test_q4.py:1224-1226: `test_multigpu` is a TODO); the column split is the
+ * property its fused q/k/v caller relies on (fused_llama_attn.py:171-186).  Rank r of T computes out[:, r*N/T : (r+1)*N/T]; the
+ * exchange below replaces the ring all-gather behind it on a point-to-point fabric: every rank stores its [M, N/T] slice into the
+ * exchange buffer of EVERY rank (one xGMI link per peer), raises a flag there, waits for the T flags of its own buffer and copies
+ * the gathered [M, N] rows to `out`.
+ *
+ * The caller owns all memory: per rank two exchange buffers [rows_max, N] (they alternate by call parity), uint32
+ * flags[GPTQ_PEER_MAX] and uint32 state[4], the last two zeroed once; the buffers and flags of the peers are mapped into the
+ * caller's address space (hipIpcOpenMemHandle / the framework's IPC) and listed in gptq_peer_group_t in RANK order (entry `rank` =
+ * the caller's own).  Across GPUs buffers and flags must be fine-grained allocations.  Calls are collective: every rank issues
+ * the same sequence of gathers with the same M.  Two launches per gather, no host state per call (legal under hipGraph capture,
+ * and a captured graph replays: the call epoch lives in state[0]).  state[3] != 0 afterwards = a wait gave up after
+ * `max_spins` polls (a peer never arrived) and `out` is incomplete -- the kernels never spin unbounded. */
+#define GPTQ_PEER_MAX 8
+typedef struct gptq_peer_group_t {
+    void     *xbuf[2][GPTQ_PEER_MAX];  /* xbuf[p][r]: exchange buffer of parity p of rank r, [rows_max, N] dtype */
+    uint32_t *flags[GPTQ_PEER_MAX];    /* flags[r]: rank r's arrival flags, uint32[GPTQ_PEER_MAX] */
+    uint32_t *state;                   /* this rank's uint32[4]: gathers completed, two tickets, timeout raised */
+    int32_t world, rank;               /* 1 <= world <= GPTQ_PEER_MAX */
+    int32_t rows_max, N;               /* geometry of the exchange buffers; N = out_features of the full layer */
+} gptq_peer_group_t;
+
+/* scatter: y_local [M, n_local] (n_local = N / world) -> columns [rank*n_local, (rank+1)*n_local) of every rank's exchange
+ * buffer, then the arrival flags.  collect: wait for all ranks' slices of this call, copy [M, N] to `out`, advance the epoch.
+ * gather = scatter + collect.  Independent work of the caller may be enqueued between scatter and collect. */
+int gptq_peer_scatter(const gptq_peer_group_t *pg, const void *y_local, int M, int n_local, int dtype, void *stream);
+int gptq_peer_collect(const gptq_peer_group_t *pg, void *out, int M, int dtype, uint32_t max_spins, void *stream);
+int gptq_peer_gather(const gptq_peer_group_t *pg, const void *y_local, void *out, int M, int n_local, int dtype,
+                     uint32_t max_spins, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,213 @@
+"""Direct peer-store all-gather (csrc/peer.hip).
+
+CPU (-m "not gpu"): struct layout and the validation of the three entry points (nothing is launched: every case fails before
+the launch).  GPU (-m gpu): T ranks simulated inside one process (each with its own buffers, flags and state on cuda:0;
+scatter for all ranks, then collect for all -- the split entry points exist for exactly this and for overlapping work), a
+captured graph replayed over several epochs, the bounded wait, and two processes sharing cuda:0 through CUDA-IPC mappings with
+the real column-parallel shards (the only multi-process configuration a 1-GPU box offers)."""
+import ctypes
+import os
+import socket
+
+import pytest
+import torch
+
+from autogptq_amd import _lib
+
+
+def _dummy_group(world=2, rank=0, rows_max=4, N=128, null=()):
+    pg = _lib.GptqPeerGroup()
+    for r in range(min(max(world, 0), _lib.PEER_MAX)):
+        pg.xbuf[0][r] = 0x1000
+        pg.xbuf[1][r] = 0x2000
+        pg.flags[r] = 0x3000
+    pg.state = 0x4000
+    pg.world, pg.rank, pg.rows_max, pg.N = world, rank, rows_max, N
+    for name in null:
+        if name == "state":
+            pg.state = None
+        elif name == "flags1":
+            pg.flags[1] = None
+        elif name == "xbuf1":
+            pg.xbuf[1][0] = None
+    return pg
+
+
+def test_peer_group_struct_layout():
+    assert _lib.PEER_MAX == 8
+    assert ctypes.sizeof(_lib.GptqPeerGroup) == 2 * 8 * 8 + 8 * 8 + 8 + 4 * 4
+    assert _lib.GptqPeerGroup.flags.offset == 128 and _lib.GptqPeerGroup.state.offset == 192
+    assert _lib.GptqPeerGroup.world.offset == 200 and _lib.GptqPeerGroup.N.offset == 212
+
+
+@pytest.mark.parametrize("kw,M,nl,status", [
+    (dict(world=0), 1, 64, 2), (dict(world=9), 1, 64, 2), (dict(rank=2), 1, 64, 2), (dict(rank=-1), 1, 64, 2),
+    (dict(null=("state",)), 1, 64, 1), (dict(null=("flags1",)), 1, 64, 1), (dict(null=("xbuf1",)), 1, 64, 1),
+    (dict(N=96), 1, 48, 2),             # 48 columns per rank: not a multiple of 32
+    (dict(N=130), 1, 65, 2),
+    (dict(), 5, 64, 2),                 # M > rows_max
+    (dict(), 0, 64, 2),
+    (dict(), 1, 32, 2),                 # n_local != N / world
+])
+def test_peer_entry_points_validate_before_launching(kw, M, nl, status):
+    lib = _lib.load()
+    pg = _dummy_group(**kw)
+    rc = lib.gptq_peer_scatter(ctypes.byref(pg), 0x5000, M, nl, _lib.GPTQ_F16, None)
+    assert rc == status, lib.gptq_last_error()
+    rc = lib.gptq_peer_gather(ctypes.byref(pg), 0x5000, 0x6000, M, nl, _lib.GPTQ_F16, 16, None)
+    assert rc == status
+    if nl == 64:
+        assert lib.gptq_peer_collect(ctypes.byref(pg), 0x6000, M, _lib.GPTQ_F16, 16, None) == status
+
+
+def test_peer_entry_points_null_and_unbounded_wait_are_errors():
+    lib = _lib.load()
+    pg = _dummy_group()
+    assert lib.gptq_peer_scatter(None, 0x5000, 1, 64, 0, None) == 1
+    assert lib.gptq_peer_scatter(ctypes.byref(pg), None, 1, 64, 0, None) == 1
+    assert lib.gptq_peer_collect(ctypes.byref(pg), None, 1, 0, 16, None) == 1
+    assert lib.gptq_peer_collect(ctypes.byref(pg), 0x6000, 1, 0, 0, None) == 2           # max_spins = 0: the wait is bounded by design
+    assert b"bounded" in lib.gptq_last_error()
+    assert lib.gptq_peer_gather(ctypes.byref(pg), 0x5000, 0x6000, 1, 64, 7, 16, None) == 3   # dtype enum
+
+
+def test_column_parallel_rejects_unknown_exchange():
+    from autogptq_amd.tensor_parallel import ColumnParallelQuantLinear
+    with pytest.raises(ValueError):
+        ColumnParallelQuantLinear(lambda x: x, 64, exchange="ring")
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------
+def _sim_groups(T, rows_max, N, dtype, dev):
+    from autogptq_amd.peer_exchange import make_group
+    x0 = [torch.full((rows_max, N), -7.0, dtype=dtype, device=dev) for _ in range(T)]
+    x1 = [torch.full((rows_max, N), -9.0, dtype=dtype, device=dev) for _ in range(T)]
+    fl = [torch.zeros(_lib.PEER_MAX, dtype=torch.int32, device=dev) for _ in range(T)]
+    st = [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(T)]
+    groups = [make_group(x0, x1, fl, st[r], r, rows_max, N) for r in range(T)]
+    return groups, (x0, x1, fl, st)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [1, 2, 4, 8])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M", [1, 5, 64])
+def test_peer_gather_simulated_ranks(T, dtype, M):
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    nl = 96 if T > 1 else 128
+    N = T * nl
+    groups, keep = _sim_groups(T, 64, N, dtype, dev)
+    st = _lib.current_stream_handle(dev)
+    dt = _lib.DTYPE_ENUM[dtype]
+    for epoch in range(1, 4):                                   # three calls: both parities, and a reuse of parity 1
+        ys = [(torch.rand(M, nl, device=dev) * (epoch + r)).to(dtype) for r in range(T)]
+        outs = [torch.zeros(M, N, dtype=dtype, device=dev) for _ in range(T)]
+        for r in range(T):
+            _lib.check(lib.gptq_peer_scatter(ctypes.byref(groups[r]), ys[r].data_ptr(), M, nl, dt, st))
+        for r in range(T):
+            _lib.check(lib.gptq_peer_collect(ctypes.byref(groups[r]), outs[r].data_ptr(), M, dt, 1 << 16, st))
+        torch.cuda.synchronize()
+        want = torch.cat(ys, dim=1)
+        for r in range(T):
+            assert torch.equal(outs[r], want), (epoch, r)
+            assert keep[3][r].tolist() == [epoch, 0, 0, 0]      # epoch advanced, tickets back to zero, no timeout
+            assert keep[2][r][:T].tolist() == [epoch] * T
+
+
+@pytest.mark.gpu
+def test_peer_gather_replays_inside_a_graph():
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    T, M, nl = 4, 3, 256
+    N = T * nl
+    groups, keep = _sim_groups(T, 8, N, torch.float16, dev)
+    ys = [torch.zeros(M, nl, dtype=torch.float16, device=dev) for _ in range(T)]
+    outs = [torch.zeros(M, N, dtype=torch.float16, device=dev) for _ in range(T)]
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            st = _lib.current_stream_handle(dev)
+            for r in range(T):
+                _lib.check(lib.gptq_peer_scatter(ctypes.byref(groups[r]), ys[r].data_ptr(), M, nl, _lib.GPTQ_F16, st))
+            for r in range(T):
+                _lib.check(lib.gptq_peer_collect(ctypes.byref(groups[r]), outs[r].data_ptr(), M, _lib.GPTQ_F16, 1 << 16, st))
+        for it in range(5):
+            for r in range(T):
+                ys[r].copy_(torch.full((M, nl), float(10 * it + r), device=dev))
+            g.replay()
+            s.synchronize()
+            want = torch.cat(ys, dim=1)
+            for r in range(T):
+                assert torch.equal(outs[r], want), (it, r)
+    assert keep[3][0].tolist() == [5, 0, 0, 0]
+
+
+@pytest.mark.gpu
+def test_peer_collect_gives_up_instead_of_hanging():
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    T, M, nl = 2, 1, 128
+    groups, keep = _sim_groups(T, 4, T * nl, torch.float16, dev)
+    y = torch.ones(M, nl, dtype=torch.float16, device=dev)
+    out = torch.zeros(M, T * nl, dtype=torch.float16, device=dev)
+    st = _lib.current_stream_handle(dev)
+    _lib.check(lib.gptq_peer_scatter(ctypes.byref(groups[0]), y.data_ptr(), M, nl, _lib.GPTQ_F16, st))
+    _lib.check(lib.gptq_peer_collect(ctypes.byref(groups[0]), out.data_ptr(), M, _lib.GPTQ_F16, 64, st))    # rank 1 never scatters
+    torch.cuda.synchronize()
+    assert keep[3][0].tolist() == [1, 0, 0, 1]                  # timeout raised, epoch still advanced, kernel returned
+    assert torch.equal(out[:, :nl], y)                          # own slice is there, the peer's is whatever the buffer held
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _ipc_worker(rank, world, port, M, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from autogptq_amd import QuantLinear
+        from autogptq_amd.tensor_parallel import ColumnParallelQuantLinear
+        from oracle import gptq_oracle as O
+        dev = "cuda:0"
+        K, N = 1024, 2048
+        L = O.random_quant_layer(K, N, 4, 128, act_order=False, seed=11)                 # identical on every rank
+        m = QuantLinear(4, 128, K, N, False)
+        m.qweight, m.qzeros, m.scales, m.g_idx = L["qweight"], L["qzeros"], L["scales"], L["g_idx"]
+        cp = ColumnParallelQuantLinear.from_full(m, rank, world, device=dev, gather_output=True, exchange="peer_store", max_rows=M)
+        errs = []
+        with torch.no_grad():
+            for it in range(3):
+                x = (torch.rand(M, K, generator=torch.Generator().manual_seed(20 + it)) - 0.5).half()
+                y = cp(x.to(dev))
+                cp._px.check_timeout()
+                y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], None, None, 4, O.ZERO_WRAP)
+                errs.append(float((y.double().cpu() - y64).abs().max() / y64.abs().max()))
+        dist.barrier()                                              # nobody unmaps while a peer may still store
+        q.put((rank, tuple(y.shape) == (M, N) and max(errs) < 3e-3, errs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 48])
+def test_two_processes_one_gpu_peer_store_column_parallel(M):
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ipc_worker, args=(r, world, port, M, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
