@@ -252,8 +252,9 @@ int gptq_gemv(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, 
     GemvPlan pl = plan_gemv(*L, M, tune);
     if (L->epilogue != GPTQ_EPI_NONE && !pl.pair)
         return fail(GPTQ_ERR_UNSUPPORTED, "this GEMV kernel has no fused epilogue; call gptq_forward[_ex], which stages y in the workspace");
-    if (tune && tune->path == 5 && !pl.mfma)
-        return fail(GPTQ_ERR_UNSUPPORTED, "matrix-core GEMV needs bits=4, fp16, no act-order and a power-of-two group_size >= 8");
+    if (tune && tune->path == 5 && !pl.mfma && !pl.mfmag)
+        return fail(GPTQ_ERR_UNSUPPORTED, "matrix-core GEMV needs fp16 / bf16, groups of whole packing units (4-bit: a power-of-two group_size >= 8), "
+                                          "16-column strips for 2/3/8-bit and no raw act-order g_idx");
     if (tune && tune->path == 4 && !pl.direct)
         return fail(GPTQ_ERR_UNSUPPORTED, "direct GEMV needs bits=4, fp16, no act-order and a power-of-two group_size >= 8");
     if (tune && tune->path == 2 && (!pl.fast || pl.mfma || pl.direct))

@@ -1086,11 +1086,22 @@ __global__ void __launch_bounds__(1024, WPS) gemv_q4_stream_kernel(GemvStreamPar
 // The pairs put the unit's k values into matrix-core slots in the order ka(p), kb(p); x is brought into the same order with one
 // v_perm per pair (shared by the lane's 4 columns).  bf16 has neither the mantissa (7 bits) nor packed arithmetic for this and keeps
 // the field-by-field form, as do 2-bit layers.
-__device__ __forceinline__ unsigned vand_or(unsigned a, unsigned mask, unsigned orv) {      // (a & mask) | orv, ONE VALU op
-    unsigned r;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(orv));
-    return r;
-}
+// The masks and the magic number reach the expressions as OPAQUE register values (one-instruction asm definitions at kernel start,
+// as in the 4-bit kernels): with literal operands hipcc splits (t & mask) | magic into v_and + v_or (VOP3 takes no literals on gfx9).
+// The expressions themselves stay C on purpose.  A first version issued v_and_or_b32 from inline asm inside the loop and returned
+// garbage / NaN in columns 1 and 2 of every lane at M = 2: with two rows of x the upper half of a 4x4x4 accumulator is dead, the
+// register allocator reuses it for the next column's B fragments, and a VALU write hidden in asm is invisible to the hazard
+// recognizer -- it landed BEFORE the in-flight MFMA's write of the same (dead) register, which then overwrote the fragment.
+struct MagicConsts {
+    unsigned magic, m0, m3, m6, m8;      // 0x64006400 (VGPR); 3-bit field masks at bits 0 / 3 / 6 of both halves, 8-bit mask (SGPRs)
+    __device__ __forceinline__ void init() {
+        asm("v_mov_b32 %0, 0x64006400" : "=v"(magic));
+        asm("s_mov_b32 %0, 0x00070007" : "=s"(m0));
+        asm("s_mov_b32 %0, 0x00380038" : "=s"(m3));
+        asm("s_mov_b32 %0, 0x01c001c0" : "=s"(m6));
+        asm("s_mov_b32 %0, 0x00ff00ff" : "=s"(m8));
+    }
+};
 __device__ __forceinline__ unsigned f16x2_bits(f16x2 v) { return __builtin_bit_cast(unsigned, v); }
 
 template <int BITS> struct MagicF16;
@@ -1100,9 +1111,9 @@ template <> struct MagicF16<8> {
     static constexpr int kb(int p) { return p + 2; }
     f16x2 c1;
     __device__ __forceinline__ void setup(int z) { c1 = as_f16x2((unsigned)z * 0x00010001u + 0xE400E400u); }    // -(1024 + z), z <= 256
-    __device__ __forceinline__ void pairs(const unsigned (&w)[1], unsigned magic, unsigned (&bp)[NP]) const {
-        bp[0] = f16x2_bits(as_f16x2(vand_or(w[0], 0x00ff00ffu, magic)) + c1);
-        bp[1] = f16x2_bits(as_f16x2(vand_or(w[0] >> 8, 0x00ff00ffu, magic)) + c1);
+    __device__ __forceinline__ void pairs(const unsigned (&w)[1], const MagicConsts& k, unsigned (&bp)[NP]) const {
+        bp[0] = f16x2_bits(as_f16x2((w[0] & k.m8) | k.magic) + c1);
+        bp[1] = f16x2_bits(as_f16x2(((w[0] >> 8) & k.m8) | k.magic) + c1);
     }
 };
 template <> struct MagicF16<3> {
@@ -1116,25 +1127,25 @@ template <> struct MagicF16<3> {
         c3 = c1 + k896;                                            // -(128 + z), exact
         c6 = c1 + k1008;                                           // -(16 + z), exact
     }
-    __device__ __forceinline__ void five(unsigned t, unsigned magic, unsigned* bp) const {
+    __device__ __forceinline__ void five(unsigned t, const MagicConsts& k, unsigned* bp) const {
         const f16x2 r8 = {(f16)0.125f, (f16)0.125f}, r64 = {(f16)0.015625f, (f16)0.015625f};
         const unsigned t6 = t >> 6;
-        bp[0] = f16x2_bits(as_f16x2(vand_or(t, 0x00070007u, magic)) + c1);
-        bp[1] = f16x2_bits(as_f16x2(vand_or(t, 0x00380038u, magic)) * r8 + c3);
-        bp[2] = f16x2_bits(as_f16x2(vand_or(t, 0x01C001C0u, magic)) * r64 + c6);
-        bp[3] = f16x2_bits(as_f16x2(vand_or(t6, 0x00380038u, magic)) * r8 + c3);
-        bp[4] = f16x2_bits(as_f16x2(vand_or(t6, 0x01C001C0u, magic)) * r64 + c6);
+        bp[0] = f16x2_bits(as_f16x2((t & k.m0) | k.magic) + c1);
+        bp[1] = f16x2_bits(as_f16x2((t & k.m3) | k.magic) * r8 + c3);
+        bp[2] = f16x2_bits(as_f16x2((t & k.m6) | k.magic) * r64 + c6);
+        bp[3] = f16x2_bits(as_f16x2((t6 & k.m3) | k.magic) * r8 + c3);
+        bp[4] = f16x2_bits(as_f16x2((t6 & k.m6) | k.magic) * r64 + c6);
     }
-    __device__ __forceinline__ void pairs(const unsigned (&w)[3], unsigned magic, unsigned (&bp)[NP]) const {
+    __device__ __forceinline__ void pairs(const unsigned (&w)[3], const MagicConsts& k, unsigned (&bp)[NP]) const {
         // 16-bit windows of the 96-bit stream at bits 0 / 15, 30 / 45, 60 / 75, 90 / 93 (low half / high half of t)
         const unsigned t0 = __builtin_amdgcn_perm(w[0] >> 15, w[0], 0x05040100u);
         const unsigned t1 = __builtin_amdgcn_perm(w[1] >> 13, __builtin_amdgcn_alignbit(w[1], w[0], 30), 0x05040100u);
         const unsigned t2 = __builtin_amdgcn_perm(w[2] >> 11, __builtin_amdgcn_alignbit(w[2], w[1], 28), 0x05040100u);
         const unsigned t3 = __builtin_amdgcn_perm(w[2] >> 29, w[2] >> 26, 0x05040100u);
-        five(t0, magic, bp);
-        five(t1, magic, bp + 5);
-        five(t2, magic, bp + 10);
-        bp[15] = f16x2_bits(as_f16x2(vand_or(t3, 0x00070007u, magic)) + c1);
+        five(t0, k, bp);
+        five(t1, k, bp + 5);
+        five(t2, k, bp + 10);
+        bp[15] = f16x2_bits(as_f16x2((t3 & k.m0) | k.magic) + c1);
     }
 };
 // x values of one unit (natural order, two per register) -> the register holding (x[ka(P)], x[kb(P)])
@@ -1179,6 +1190,8 @@ __global__ void __launch_bounds__(1024, 4) gemv_mfma_generic_kernel(GemvParams p
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[c][m] = 0.f;
 
+    MagicConsts mk;
+    if constexpr (MAGIC) mk.init();
     const int rows_per_iter = W * WR * U;
     for (int base = ub; base < ue; base += rows_per_iter) {
         const int u0 = base + (wave * WR + rs) * U;
@@ -1213,8 +1226,6 @@ __global__ void __launch_bounds__(1024, 4) gemv_mfma_generic_kernel(GemvParams p
 #pragma unroll
         for (int c = 0; c < 4; ++c) accg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (MAGIC) {
-            unsigned magic;
-            asm("v_mov_b32 %0, 0x64006400" : "=v"(magic));     // opaque: keeps (t & mask) | magic one v_and_or_b32
             MagicF16<BITS> mg[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) mg[c].setup(z[c]);
@@ -1230,7 +1241,7 @@ __global__ void __launch_bounds__(1024, 4) gemv_mfma_generic_kernel(GemvParams p
                     unsigned wds[UW], bp[KPU / 2];
 #pragma unroll
                     for (int w = 0; w < UW; ++w) wds[w] = q[j][w][c];
-                    mg[c].pairs(wds, magic, bp);
+                    mg[c].pairs(wds, mk, bp);
 #pragma unroll
                     for (int Q = 0; Q < KPU / 4; ++Q)
                         accg[c] = Mma4<T>::run(u32x2{xa[2 * Q], xa[2 * Q + 1]}, u32x2{bp[2 * Q], bp[2 * Q + 1]}, accg[c]);

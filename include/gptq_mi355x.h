@@ -108,7 +108,7 @@ typedef struct gptq_tuning_t {
     int32_t lanes_n;     /* lanes of a wave laid along N (4,8,16,64); 4 columns per lane */
     int32_t waves;       /* waves per workgroup (1..16) */
     int32_t ksplit;      /* workgroups along K (1 = no cross-workgroup reduction) */
-    int32_t path;        /* 0 auto, 1 generic GEMV, 2 LDS-staged q4/fp16 GEMV, 3 MFMA GEMM, 4 direct q4/fp16 GEMV, 5 matrix-core q4/fp16 GEMV, 6 streamed (LDS-DMA) q4 GEMV */
+    int32_t path;        /* 0 auto, 1 generic GEMV, 2 LDS-staged q4/fp16 GEMV, 3 MFMA GEMM, 4 direct q4/fp16 GEMV, 5 matrix-core GEMV (4-bit fp16 / bf16 kernel, or the 2/3/8-bit one), 6 streamed (LDS-DMA) q4 GEMV */
     int32_t reserved[4]; /* [0]: max packed rows per lane and iteration for the register-direct GEMVs, = rows per lane for the streamed one, = K-steps per burst for the batched-decode kernel (0 = heuristic); [1]: 32 = force the 32-deep K-step in the MFMA GEMM, 1 = field-by-field decode in the 3- / 8-bit fp16 matrix-core GEMV instead of the packed magic-number one (A/B runs); [2]: 1 = force the 64-column skinny GEMM, 2 = force the tiled GEMM, 3 = force the 16-column-strip GEMM (4-bit, M <= 64), 4 = force the streamed 64-column-strip batched-decode GEMM (4-bit, M <= 64; waves / ksplit apply); [3]: tiled-GEMM inner-loop schedule variant */
 } gptq_tuning_t;
 

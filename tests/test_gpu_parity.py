@@ -184,6 +184,37 @@ def test_forward_random_words_vs_oracle(bits, gs, K, N, act, dtype, M):
             _assert_close(y, y64, y64, dtype, K, f"path={path} zero={zm} vs f64")
 
 
+@pytest.mark.parametrize("bits,gs,K,N", [(3, 32, 1024, 512), (3, 128, 256, 64), (3, 128, 2048, 160), (3, 64, 11008, 96),
+                                          (8, 32, 1024, 512), (8, 128, 512, 64), (8, 64, 2048, 160), (8, 32, 11008, 96)])
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8])
+def test_magic_number_decode_3_and_8_bit(bits, gs, K, N, M):
+    """3- / 8-bit fp16 matrix-core GEMV with the packed magic-number field decode (default) == the field-by-field form
+    (tuning.reserved[1] = 1) == the oracle, for every row-tile instantiation (M = 1, 2, 3..4, two passes at 5..8 where the planner
+    keeps the GEMV), both zero conventions, K tails (11008 = 344 units: the last pass of a workgroup is partly dead); one-hot rows
+    of x return the dequantised rows bit for bit.  M = 2 is the case that caught a WAW hazard between an in-flight MFMA's write of a
+    dead accumulator half and a VALU write hidden in inline asm (csrc/gemv.hip, MagicConsts)."""
+    L = O.random_quant_layer(K, N, bits, gs, act_order=False, dtype=torch.float16, seed=3 * K + N + bits + M, bias=True)
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).half()
+    hot = torch.zeros(M, K, dtype=torch.float16)
+    rows = [(37 * (m + 1) + K // 2 * (m & 1)) % K for m in range(M)]
+    for m, r in enumerate(rows):
+        hot[m, r] = 1.0
+    for zm, mode in (("wrap", O.ZERO_WRAP), ("nowrap", O.ZERO_NOWRAP)):
+        q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], bits, gs, zero_mode=zm)
+        y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], bits, mode)
+        t_old = _tuning(path=5)
+        t_old.reserved[1] = 1
+        with torch.no_grad():
+            y_new = q(x.to(DEV), tuning=_tuning(path=5))
+            y_old = q(x.to(DEV), tuning=t_old)
+            h_new = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], None, bits, gs, zero_mode=zm)(hot.to(DEV), tuning=_tuning(path=5))
+        _assert_close(y_new, y64, y64, torch.float16, K, f"magic zero={zm} vs f64")
+        _assert_close(y_old, y64, y64, torch.float16, K, f"field-by-field zero={zm} vs f64")
+        _assert_close(y_new, y_old, y64, torch.float16, K, f"magic vs field-by-field zero={zm}")
+        W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], bits, mode)             # [K, N] fp16, one rounding
+        assert torch.equal(h_new.cpu(), torch.stack([W[r] for r in rows])), f"one-hot rows zero={zm}"
+
+
 @pytest.mark.parametrize("ln,waves,ksplit", [(4, 16, 1), (4, 4, 1), (8, 8, 2), (16, 16, 4), (64, 4, 8), (64, 1, 1), (4, 2, 3)])
 @pytest.mark.parametrize("path", [1, 2, 4, 5])
 def test_forward_launch_shapes_agree(ln, waves, ksplit, path):

@@ -7,7 +7,9 @@ captured graph replayed over several epochs, the bounded wait, and two processes
 the real column-parallel shards (the only multi-process configuration a 1-GPU box offers)."""
 import ctypes
 import os
+import queue
 import socket
+import time
 
 import pytest
 import torch
@@ -206,7 +208,17 @@ def test_two_processes_one_gpu_peer_store_column_parallel(M):
     procs = [ctx.Process(target=_ipc_worker, args=(r, world, port, M, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
+    res, deadline = [], time.time() + 150
+    while len(res) < world:                        # a crashed worker fails the test at once instead of sitting out a queue timeout
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() > deadline:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                pytest.fail(f"peer-store workers: exit codes {[p.exitcode for p in procs]}, results so far {res}")
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
