@@ -1449,6 +1449,9 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
         // profiles/r02_act_order_decode_ab.log: fp16 5.9 / 13.5 / 12.0 -> 5.1 / 9.8 / 9.6 us, bf16 6.5 / 15.5 / 14.8 -> 5.4 / 11.1 / 11.1):
         // two workgroups share a CU, so one gathers x through perm[] while the other's loads are in flight
         if (act_m1 && waves > 8) waves = 8;
+        // 3-bit fp16 (magic-number decode), one row of x: 8 waves (two workgroups per CU) also on long-K layers -- tools/magic_ab.py sweep,
+        // profiles/r02_magic_decode_ab.log: 11008x4096 g32 10.6 us with 16 waves x 2 passes, 9.6 with 8 x 3; 4096x4096 / 4096x11008 already run 8
+        if (pl.mfmag && L.bits == 3 && L.dtype == GPTQ_F16 && M == 1 && !(tune && tune->reserved[1] == 1) && waves > 8) waves = 8;
         if (waves < 1) waves = 1;
     }
     pl.waves = waves;
