@@ -77,9 +77,11 @@ bool want_gemm(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
         // 2/3/8-bit: the matrix-core GEMV handles 4 rows of x per pass over the weights and the generic (act-order) kernel fewer, so the
         // weight-streaming GEMMs take over early (tools/cliff_scan.py --slice C, 4096x11008, us: int8 M = 8: 47.6 GEMV, 25.6 tiled at
         // M = 16; int8 act-order M = 4: 43.7 against 29.5; int3 M = 8: 26.2 against 35.8 -- 3-bit keeps the GEMV up to 8 rows)
-        const bool act = L->g_idx != nullptr;
+        // (act-order layers with the re-sequenced side copy run the same kernels on a permuted x -- GEMV and GEMM alike pay one 2.6 us
+        // pre-pass -- so they share the plain layers' crossovers; only raw act-order layers, which sit on the fp32 generic GEMV, leave early)
+        const bool raw_act = L->g_idx != nullptr && !(L->qweight_seq != nullptr && L->perm != nullptr);
         const bool big = (size_t)L->K * L->N >= ((size_t)32 << 20);
-        const int min_m = act ? (L->bits == 8 ? 3 : 5) : (L->bits == 8 ? 5 : ((L->bits == 2 && big) ? 5 : 9));
+        const int min_m = raw_act ? (L->bits == 8 ? 3 : 5) : (L->bits == 8 ? 5 : ((L->bits == 2 && big) ? 5 : 9));
         if (M < min_m) return false;
         return plan_gemm(*L, M, t).supported;
     }

@@ -189,6 +189,72 @@ template <> struct Deq<4, f16> {
     }
 };
 
+// 8-bit and 3-bit fp16: the same exact packed form (csrc/gemv.hip, MagicF16, explains the arithmetic).  Both come out in the 4-bit slot
+// order k0,k4,k1,k5,k2,k6,k3,k7, so the x staging is shared.  Plain C with literal masks on purpose -- no VALU instruction hidden in
+// inline asm next to the matrix core (the hazard recognizer does not see it); hipcc spends v_and + v_or on it.
+//   8-bit: the lane's 8 values are two words; v_perm joins their low halves (f0 f1 | f4 f5) and their high halves (f2 f3 | f6 f7), a
+//          byte mask pairs (f0, f4), (f2, f6) and, shifted by 8, (f1, f5), (f3, f7): ~20 VALU per 8 weights instead of ~48.
+//   3-bit: the lane's 8 values are a 24-bit window of the column's bit stream; low half = bits 0..15 (f0..f4 at 0, 3, 6, 9, 12), high
+//          half = bits 12..27 (f4..f7 at 0, 3, 6, 9): pairs (f0, f4), (f1, f5), (f2, f6) at bits 0 / 3 / 6 and (f3, f7) at bit 3 of t >> 6.
+template <> struct Deq<8, f16> {
+    f16x2 s2[2], c1[2];
+    __device__ __forceinline__ void setup(const CRaw& c, int zero_mode) {
+#pragma unroll
+        for (int col = 0; col < 2; ++col) {
+            const unsigned sb = col ? (c.s >> 16) : (c.s & 0xffffu);
+            s2[col] = as_f16x2(sb * 0x00010001u);
+            const unsigned z = (unsigned)zero_point<8>(c, col, zero_mode);   // 0..256
+            c1[col] = as_f16x2(z * 0x00010001u + 0xE400E400u);               // -(1024 + z)
+        }
+    }
+    __device__ __forceinline__ u32x4 frag(const BRaw<8>& r, int col, int) const {
+        const unsigned w0 = r.w[0][col], w1 = r.w[1][col];                   // k0..k3, k4..k7
+        const unsigned lo = __builtin_amdgcn_perm(w1, w0, 0x05040100u);      // f0 f1 | f4 f5
+        const unsigned hi = __builtin_amdgcn_perm(w1, w0, 0x07060302u);      // f2 f3 | f6 f7
+        const f16x2 h0 = as_f16x2((lo & 0x00ff00ffu) | 0x64006400u) + c1[col];            // k0,k4 : w - z
+        const f16x2 h1 = as_f16x2(((lo >> 8) & 0x00ff00ffu) | 0x64006400u) + c1[col];     // k1,k5
+        const f16x2 h2 = as_f16x2((hi & 0x00ff00ffu) | 0x64006400u) + c1[col];            // k2,k6
+        const f16x2 h3 = as_f16x2(((hi >> 8) & 0x00ff00ffu) | 0x64006400u) + c1[col];     // k3,k7
+        u32x4 o;
+        o[0] = f16x2_bits(h0 * s2[col]);
+        o[1] = f16x2_bits(h1 * s2[col]);
+        o[2] = f16x2_bits(h2 * s2[col]);
+        o[3] = f16x2_bits(h3 * s2[col]);
+        return o;
+    }
+};
+template <> struct Deq<3, f16> {
+    f16x2 s2[2], c1[2], c3[2], c6[2];
+    __device__ __forceinline__ void setup(const CRaw& c, int zero_mode) {
+#pragma unroll
+        for (int col = 0; col < 2; ++col) {
+            const unsigned sb = col ? (c.s >> 16) : (c.s & 0xffffu);
+            s2[col] = as_f16x2(sb * 0x00010001u);
+            const unsigned z = (unsigned)zero_point<3>(c, col, zero_mode);   // 0..8
+            c1[col] = as_f16x2(z * 0x00010001u + 0xE400E400u);               // -(1024 + z)
+            const f16x2 k896 = {(f16)896.f, (f16)896.f}, k1008 = {(f16)1008.f, (f16)1008.f};
+            c3[col] = c1[col] + k896;                                        // -(128 + z), exact
+            c6[col] = c1[col] + k1008;                                       // -(16 + z), exact
+        }
+    }
+    __device__ __forceinline__ u32x4 frag(const BRaw<3>& r, int col, int k) const {
+        const unsigned v = (unsigned)window<3>(r, col, k);                   // 24 bits: f0..f7 at bits 3i
+        const unsigned t = __builtin_amdgcn_perm(v >> 12, v, 0x05040100u);
+        const unsigned t6 = t >> 6;
+        const f16x2 r8 = {(f16)0.125f, (f16)0.125f}, r64 = {(f16)0.015625f, (f16)0.015625f};
+        const f16x2 h0 = as_f16x2((t & 0x00070007u) | 0x64006400u) + c1[col];             // k0,k4 : w - z
+        const f16x2 h1 = as_f16x2((t & 0x00380038u) | 0x64006400u) * r8 + c3[col];        // k1,k5
+        const f16x2 h2 = as_f16x2((t & 0x01C001C0u) | 0x64006400u) * r64 + c6[col];       // k2,k6
+        const f16x2 h3 = as_f16x2((t6 & 0x00380038u) | 0x64006400u) * r8 + c3[col];       // k3,k7
+        u32x4 o;
+        o[0] = f16x2_bits(h0 * s2[col]);
+        o[1] = f16x2_bits(h1 * s2[col]);
+        o[2] = f16x2_bits(h2 * s2[col]);
+        o[3] = f16x2_bits(h3 * s2[col]);
+        return o;
+    }
+};
+
 // 4-bit bf16: w - z is formed exactly with the fp16 magic numbers (gfx950 has no packed bf16 arithmetic), each value is
 // multiplied by the scale in fp32 (exact product) and rounded once to bf16 by v_cvt_pk_bf16_f32 -- the reference's
 // scales * (weight - zeros) in bf16, bit for bit -- at about 21-29 VALU per word instead of ~40 for the per-field path.

@@ -1341,12 +1341,16 @@ GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     // x is permuted ONCE by the column-permute pre-pass (a 2.6 us launch for these sizes) and the plain matrix-core kernel runs on the
     // re-sequenced rows: 4096x11008 M = 2 / 4: 22.2 / 28.9 -> 12.1 / 14.1 us.
     // (also for ONE row when K is too long for the x row in LDS: 28672x1024 15.8 us on the LDS-staged fallback, 12.1 this way)
-    if (L.g_idx != nullptr && L.qweight_seq != nullptr && L.perm != nullptr && (M >= 2 || L.K > 24576) && L.epilogue == GPTQ_EPI_NONE && L.bits == 4 &&
-        (L.dtype == GPTQ_F16 || L.dtype == GPTQ_BF16) && (!tune || tune->path == 0)) {
+    // 2/3/8-bit act-order layers (round 2): the same, from ONE row on -- their matrix-core kernel has no in-kernel gather at all, so the
+    // alternative is the fp32 generic kernel (tools/cliff_scan.py, us, M = 1 / 4: int3 g32 11008x4096 18.5 / 30.2, int8 23.1 / 39.7 against
+    // 9.6 / 12.7 and 16.3 / 19.3 for the plain layer + the 2.6 us pre-pass)
+    const bool q4_rows = L.bits == 4 && (M >= 2 || L.K > 24576);
+    if (L.g_idx != nullptr && L.qweight_seq != nullptr && L.perm != nullptr && (q4_rows || L.bits != 4) && L.epilogue == GPTQ_EPI_NONE &&
+        (L.dtype == GPTQ_F16 || L.dtype == GPTQ_BF16) && (!tune || tune->path == 0 || (tune->path == 5 && L.bits != 4))) {
         gptq_layer_t P = L;
         P.g_idx = nullptr; P.perm = nullptr; P.qweight = L.qweight_seq; P.qweight_seq = nullptr;
         GemvPlan pp = plan_gemv_n(P, M, tune, L.N);
-        if (pp.mfma) {
+        if (L.bits == 4 ? pp.mfma : pp.mfmag) {
             pp.pair = false;
             pp.xperm = true;
             pp.xperm_bytes = ((size_t)M * L.K * 2 + 255) / 256 * 256;

@@ -316,10 +316,17 @@ def test_dispatch_rules_are_the_measured_ones():
     # ... and up to 64 rows everywhere (4096 x 11008 M = 8: 517 us on the fp32 GEMM, 48 on the GEMV), beyond that from 64 tiles up
     assert _plan(4096, 11008, 8, dtype=2)["path"] == "gemv" and _plan(4096, 11008, 64, dtype=2)["path"] == "gemv"
     assert _plan(4096, 11008, 65, dtype=2)["kernel"] == "f32_mfma" and _plan(4096, 4096, 128, dtype=2)["path"] == "gemv"
-    # 2/3/8-bit: the weight-streaming GEMMs take over from 5 rows (int8), 3 rows (int8 act-order), 5 rows (int3 act-order); int3 keeps the GEMV to 8
+    # 2/3/8-bit: the weight-streaming GEMMs take over from 5 rows (int8); int3 keeps the GEMV to 8.  Act-order layers with the re-sequenced
+    # side copy run the SAME kernels on a permuted x (perm = 2: one pre-pass, GEMV and GEMM alike), so they share those crossovers
     assert _plan(4096, 11008, 4, bits=8, gs=32)["path"] == "gemv" and _plan(4096, 11008, 8, bits=8, gs=32)["path"] == "gemm"
-    assert _plan(4096, 11008, 2, bits=8, gs=32, act=True)["path"] == "gemv" and _plan(4096, 11008, 4, bits=8, gs=32, act=True)["path"] == "gemm"
-    assert _plan(4096, 11008, 8, bits=3, gs=32)["path"] == "gemv" and _plan(4096, 11008, 8, bits=3, gs=32, act=True)["path"] == "gemm"
+    for m in (1, 2, 4):
+        p = _plan(4096, 11008, m, bits=8, gs=32, act=True)
+        assert (p["path"], p["kernel"], p["perm"], p.get("deq")) == ("gemv", "mfma_generic", 2, "magic"), (m, p)
+    assert _plan(4096, 11008, 8, bits=8, gs=32, act=True)["path"] == "gemm"
+    p = _plan(4096, 11008, 8, bits=3, gs=32, act=True)
+    assert _plan(4096, 11008, 8, bits=3, gs=32)["path"] == "gemv" and (p["path"], p["kernel"], p["perm"]) == ("gemv", "mfma_generic", 2), p
+    assert _plan(4096, 11008, 16, bits=3, gs=32, act=True)["path"] == "gemm"
+    assert _plan(4096, 4096, 1, bits=3, gs=32, act=True, dtype=1)["perm"] == 2 and _plan(4096, 4096, 1, bits=3, gs=32, act=True, dtype=1).get("deq") is None
     assert _plan(4096, 11008, 8, bits=2, gs=64)["path"] == "gemm" and _plan(4096, 4096, 8, bits=2, gs=64)["path"] == "gemv"
     # rows of x: GEMV up to 4; 5..8 rows: one matrix-core pass over 16 rows (16-column strips on narrow layers, the streamed
     # 64-column-strip kernel elsewhere) unless the layer has a fused epilogue (the GEMV applies it) or K is long and N small
