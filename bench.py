@@ -284,7 +284,8 @@ def _plan_of(layers, K, N, M):
 
 def bench_config5(device, steps):
     """BASELINE config 5: int3 / int8, group_size 32, Llama-7B shapes, M = 1 decode.  Per shape: a graph of distinct layers whose
-    packed weights exceed the 256 MiB Infinity Cache, HIP events, algorithmic GB/s (SURVEY App. C formula)."""
+    packed weights exceed the 256 MiB Infinity Cache, HIP events, algorithmic GB/s (SURVEY App. C formula).  On 4096 x 11008 also the
+    act-order (desc_act=True) decode and the M = 2048 prefill of the same packing."""
     res = {}
     for bits in (3, 8):
         for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
@@ -296,6 +297,20 @@ def bench_config5(device, steps):
             ab = algorithmic_bytes(K, N, 1, bits=bits, gs=32)
             res[f"int{bits}_g32_{K}x{N}"] = {"us": round(per * 1e6, 2), "GB_per_s": round(ab / per / 1e9, 1), "frac": round(ab / per / 1e9 / HBM_PEAK_GBS, 4),
                                               "plan": _plan_of(ls, K, N, 1)}
+            if (K, N) == (4096, 11008):
+                # the same packing on the other two paths of the config: act-order decode (desc_act=True) and M = 2048 prefill
+                xp = {K: (torch.rand(2048, K, device=device) - 0.5).half()}
+                perp = _time_layers(ls[:4], xp, device, 3)
+                res[f"int{bits}_g32_{K}x{N}_prefill_M2048"] = {"us": round(perp * 1e6, 1), "TFLOP_s": round(2 * 2048 * K * N / perp / 1e12, 1),
+                                                               "frac": round(2 * 2048 * K * N / perp / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                                               "plan": _plan_of(ls, K, N, 2048)}
+                del xp
+                la = [(f"b{bits}a", K, N, make_layer(K, N, device, bits=bits, gs=32, act_order=True, seed=6000 + i)) for i in range(n)]
+                pera = _time_layers(la, xs, device, max(3, steps // 2))
+                aba = algorithmic_bytes(K, N, 1, bits=bits, gs=32, act_order=True)
+                res[f"int{bits}_g32_{K}x{N}_desc_act"] = {"us": round(pera * 1e6, 2), "GB_per_s": round(aba / pera / 1e9, 1),
+                                                          "frac": round(aba / pera / 1e9 / HBM_PEAK_GBS, 4), "plan": _plan_of(la, K, N, 1)}
+                del la
             del ls, xs
             torch.cuda.empty_cache()
     return res
