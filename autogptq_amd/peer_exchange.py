@@ -34,9 +34,17 @@ def _share(t: torch.Tensor):
 
 
 def _map(args, device):
+    """Map a peer's allocation (the argument tuple of torch's CUDA-IPC reduction) into this process, on OUR device: the kernels of
+    this rank store into it, so the mapping has to live in this rank's address space whichever GPU owns the memory."""
+    import inspect
     from torch.multiprocessing.reductions import rebuild_cuda_tensor
+    names = list(inspect.signature(rebuild_cuda_tensor).parameters)
+    if len(args) != len(names) or "storage_device" not in names:
+        raise RuntimeError("torch.multiprocessing.reductions.rebuild_cuda_tensor changed its signature; "
+                           "pass pre-mapped buffers to PeerExchange(buffers=...) instead")
     args = list(args)
-    args[6] = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()   # storage_device: ours
+    idx = torch.device(device).index
+    args[names.index("storage_device")] = idx if idx is not None else torch.cuda.current_device()
     return rebuild_cuda_tensor(*args)
 
 

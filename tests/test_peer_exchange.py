@@ -79,6 +79,17 @@ def test_column_parallel_rejects_unknown_exchange():
         ColumnParallelQuantLinear(lambda x: x, 64, exchange="ring")
 
 
+def test_ipc_mapping_helper_checks_the_torch_signature_it_patches():
+    """_map overrides `storage_device` in the argument tuple of torch's CUDA-IPC reduction: by NAME, and a tuple of another arity
+    (a different torch) is an error, not a silently wrong index."""
+    import inspect
+    from torch.multiprocessing.reductions import rebuild_cuda_tensor
+    from autogptq_amd.peer_exchange import _map
+    assert "storage_device" in inspect.signature(rebuild_cuda_tensor).parameters
+    with pytest.raises(RuntimeError, match="signature"):
+        _map((1, 2, 3), "cuda:0")
+
+
 # ---- GPU ---------------------------------------------------------------------------------------------------------------
 def _sim_groups(T, rows_max, N, dtype, dev):
     from autogptq_amd.peer_exchange import make_group
