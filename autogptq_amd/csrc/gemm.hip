@@ -22,7 +22,8 @@
 //     reference's  scales * (weight - zeros)  (qlinear_cuda_old.py:348).  The words therefore come out in
 //     slot order k0,k4,k1,k5,k2,k6,k3,k7 -- x is written to LDS in the same slot order (4 v_perm per 16 B), which
 //     is all the MFMA needs (A and B only have to agree on which k sits in which slot).
-//     Every other (bits, dtype) uses fp32 math per field: T(float(s) * float(w - z)) -- also exactly the reference's W.
+//     3- and 8-bit fp16 use the same packed form (Deq<3, f16>, Deq<8, f16>: same slot order); every other (bits, dtype) uses fp32 math
+//     per field: T(float(s) * float(w - z)) -- also exactly the reference's W.
 //   * group_size % BK == 0, so one (scale, zero) pair per column per K-step, fetched one step ahead.
 //   * act-order: weights come from the group-sorted side copy (qweight_seq) and x is permuted once per call
 //     into the workspace by a small LDS-staged gather kernel (the column_remap of exllama, column_remap.cu:9-63).

@@ -18,7 +18,9 @@
 //    on the matrix core: v_mfma_f32_4x4x4_16b_f16 is 16 independent 4x4x4 products, one per aligned 4-lane
 //    group = one packed row x 16 columns, so up to 4 rows of x cost the same as one.  The scale multiplies
 //    the fp32 group sums once per (lane, group).  No fp16 accumulation anywhere.
-//  * Other packings (2/3/8-bit, fp16/bf16): gemv_mfma_generic_kernel, same structure, fields by v_bfe.
+//  * Other packings (2/3/8-bit, fp16/bf16): gemv_mfma_generic_kernel, same structure; 3- and 8-bit fp16 fields are decoded two at a
+//    time with the fp16 magic number (MagicF16: 16-bit windows of the 3-bit stream at multiples of 15 bits line up in both halves of a
+//    register), everything else field by field.  Act-order layers of these packings: x permuted once by the column-permute pre-pass.
 //    fp32 I/O, raw (non-uniform) act-order g_idx, odd group sizes: gemv_generic_kernel (fp32 FMA, x in LDS).
 //    gemv_q4_f16_direct_kernel (v_dot2 reduction) and gemv_q4_f16_kernel (LDS-staged x / group constants,
 //    the first working path of round 1) are kept as comparison variants behind tuning.path = 4 / 2.
