@@ -39,6 +39,13 @@ def _worker(rank, world, port, bits, gs, K, N, M, act, q):
         ok = tuple(y.shape) == (M, N) and torch.allclose(y, ref, rtol=1e-5, atol=1e-6)
         y3 = mod(x.reshape(1, M, K))                      # leading dims preserved
         ok = ok and tuple(y3.shape) == (1, M, N) and torch.equal(y3[0], y)
+        # the direct peer-store exchange moves device buffers through IPC mappings: host tensors are refused, on every rank, before
+        # anything collective happens (the GPU side is tests/test_peer_exchange.py)
+        try:
+            ColumnParallelQuantLinear(local, N, exchange="peer_store")(x)
+            ok = False
+        except RuntimeError as e:
+            ok = ok and "peer_store" in str(e)
         q.put((rank, bool(ok), float((y - ref).abs().max())))
     finally:
         dist.destroy_process_group()
