@@ -1,5 +1,5 @@
 // gemmlab.hip -- timing harness for the PRODUCT MFMA prefill kernel (measurement tool, not product).
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++20 -I autogptq_amd/csrc -I include tools/gemmlab.hip -o tools/gemmlab
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++20 -I autogptq_amd/csrc -I include -c tools/gemmlab.hip -o /tmp/gemmlab.o && hipcc --offload-arch=gfx950 /tmp/gemmlab.o autogptq_amd/csrc/utils.o -o tools/gemmlab
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -30,6 +30,7 @@ __global__ void iota_perm(int* p, int K) {   // a fixed pseudo-random permutatio
 
 int main(int argc, char** argv) {
     hipStream_t st; CK(hipStreamCreate(&st));
+    CK(init_gemm_device());                        // dynamic LDS above 64 KiB (two-K-group workgroups)
     struct Shape { int M, K, N; };
     std::vector<Shape> shapes = {{2048, 4096, 4096}, {4096, 4096, 4096}, {2048, 4096, 11008}, {2048, 11008, 4096}, {512, 4096, 4096}, {128, 4096, 4096}, {64, 4096, 4096}, {32, 4096, 4096}, {16, 4096, 4096}, {16, 4096, 11008}, {64, 11008, 4096}, {128, 4096, 11008}};
     int only_variant = -1, reps = 5;
@@ -43,8 +44,9 @@ int main(int argc, char** argv) {
         unsigned *qw, *qz; f16 *sc, *x, *out; char* ws; int* perm;
         CK(hipMalloc(&qw, qw_b * nl)); CK(hipMalloc(&qz, qz_b * nl)); CK(hipMalloc(&sc, sc_b * nl));
         CK(hipMalloc(&x, (size_t)M * K * 2)); CK(hipMalloc(&out, (size_t)M * N * 2)); CK(hipMalloc(&perm, (size_t)K * 4));
-        const size_t ws_b = (size_t)M * K * 2 + (size_t)8 * M * N * 4 + 4096;
+        const size_t ws_b = WS_HEADER_BYTES + (size_t)M * K * 2 + (size_t)8 * M * N * 4 + 4096;
         CK(hipMalloc(&ws, ws_b));
+        CK(hipMemset(ws, 0, WS_HEADER_BYTES));       // arrival tickets of the in-launch combines start at zero
         fill<<<2048, 256, 0, st>>>(qw, qw_b * nl / 4, 1u);
         fill<<<256, 256, 0, st>>>(qz, qz_b * nl / 4, 2u);
         fill_f16<<<256, 256, 0, st>>>(sc, sc_b * nl / 2, 0.002f, 0.0022f);
@@ -89,7 +91,7 @@ int main(int argc, char** argv) {
                 gptq_layer_t L = v.L;
                 L.qweight = qw + (size_t)i * qw_b / 4; L.qzeros = qz + (size_t)i * qz_b / 4; L.scales = sc + (size_t)i * sc_b / 2;
                 L.qweight_seq = (v.id == 2 || v.id == 12 || v.id == 15 || v.id >= 18) ? L.qweight : nullptr;
-                hipError_t e = launch_gemm(L, v.pl, x, out, M, ws, st);
+                hipError_t e = launch_gemm(L, v.pl, x, out, M, ws, ws + WS_HEADER_BYTES, st);
                 if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); exit(1); }
             }
         };
