@@ -27,14 +27,16 @@ def main():
     ap.add_argument("--gs", type=int, default=32)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--bits", default="3,8")
+    ap.add_argument("--sweep-only", action="store_true", help="skip the magic / field-by-field A/B, only the waves x K-split sweep")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    for bits in (3, 8):
+    for bits in [int(b) for b in args.bits.split(',')]:
         for K, N in SHAPES:
             per = K * N * bits // 8
             nl = max(4, min(48, (512 << 20) // per))
             layers = [make_layer(K, N, dev, bits=bits, gs=args.gs, seed=i) for i in range(nl)]
-            for M in (1, 4):
+            for M in (() if args.sweep_only else (1, 4)):
                 x = (torch.rand(M, K, device=dev) - 0.5).half()
                 ab = algorithmic_bytes(K, N, M, bits=bits, gs=args.gs)
                 with torch.no_grad():
@@ -50,7 +52,7 @@ def main():
                 print(f"int{bits} g{args.gs} {K}x{N} M={M}: magic {best['magic']*1e6:7.2f} us ({ab/best['magic']/1e9:7.1f} GB/s)  "
                       f"field-by-field {best['bfe']*1e6:7.2f} us ({ab/best['bfe']/1e9:7.1f} GB/s)  rel diff {diff:.2e}  "
                       f"{plan.get('kernel')} waves={plan.get('waves')} u={plan.get('u')} deq={plan.get('deq')}", flush=True)
-            if bits == 3 and not args.no_sweep:
+            if not args.no_sweep:
                 x = (torch.rand(1, K, device=dev) - 0.5).half()
                 res = []
                 for waves in (4, 8, 16):
