@@ -1,0 +1,135 @@
+"""CPU (-m "not gpu"): the bit algebra of the packed magic-number field decode (csrc/gemv.hip MagicF16<3 / 8>, csrc/gemm.hip
+Deq<3 / 8, f16>) restated in numpy, instruction for instruction (v_perm_b32, v_alignbit_b32, shifts, masks, fp16 arithmetic), and
+checked against the plain field extraction of the reference layout (qlinear_cuda_old.py:317-344: 32 three-bit values in 3 words,
+fields 10 and 21 straddle; :295-316: four 8-bit values per word).  This is what was run before the first GPU session; it pins
+  * which field lands in which half of which pair (ka / kb: the k order of the matrix-core slots, which x has to follow),
+  * that every intermediate is exactly representable in fp16 (the decode is exact, not merely close),
+  * the zero-point range of both conventions (wrap: 0..maxq, no-wrap: 1..maxq + 1)."""
+import numpy as np
+import pytest
+
+MAGIC = 0x64006400
+
+
+def perm(s0, s1, sel):
+    """v_perm_b32 D, S0, S1, sel: result byte i = byte sel[i] of {S0 (bytes 4-7), S1 (bytes 0-3)}."""
+    b = [(s1 >> (8 * i)) & 0xff for i in range(4)] + [(s0 >> (8 * i)) & 0xff for i in range(4)]
+    return sum(b[(sel >> (8 * i)) & 0xff] << (8 * i) for i in range(4))
+
+
+def alignbit(hi, lo, sh):
+    """v_alignbit_b32: low 32 bits of {hi, lo} >> sh."""
+    return (((hi << 32) | lo) >> sh) & 0xffffffff
+
+
+def halves(u):
+    return np.array([u & 0xffff, (u >> 16) & 0xffff], dtype=np.uint16).view(np.float16)
+
+
+def pk_fma(t, mask, scale, c):
+    """as_f16x2((t & mask) | magic) * scale + c with ONE rounding (v_pk_fma_f16); asserts the result is exact in fp16."""
+    v = halves((t & mask) | MAGIC).astype(np.float64)
+    r = v * scale + c
+    r16 = r.astype(np.float16)
+    assert np.all(r16.astype(np.float64) == r), "intermediate not exact in fp16"
+    return r16
+
+
+def five(t, z):
+    t6 = t >> 6
+    return [pk_fma(t, 0x00070007, 1.0, -(1024 + z)), pk_fma(t, 0x00380038, 0.125, -(128 + z)), pk_fma(t, 0x01C001C0, 1 / 64, -(16 + z)),
+            pk_fma(t6, 0x00380038, 0.125, -(128 + z)), pk_fma(t6, 0x01C001C0, 1 / 64, -(16 + z))]
+
+
+def gemv_pairs_3bit(w, z):
+    """MagicF16<3>::pairs: 16-bit windows of the 96-bit stream at bits 0/15, 30/45, 60/75, 90/93."""
+    t0 = perm(w[0] >> 15, w[0], 0x05040100)
+    t1 = perm(w[1] >> 13, alignbit(w[1], w[0], 30), 0x05040100)
+    t2 = perm(w[2] >> 11, alignbit(w[2], w[1], 28), 0x05040100)
+    t3 = perm(w[2] >> 29, w[2] >> 26, 0x05040100)
+    return five(t0, z) + five(t1, z) + five(t2, z) + [pk_fma(t3, 0x00070007, 1.0, -(1024 + z))]
+
+
+def ka3(p):
+    return 10 * (p // 5) + p % 5 if p < 15 else 30
+
+
+def kb3(p):
+    return ka3(p) + 5 if p < 15 else 31
+
+
+@pytest.mark.parametrize("zero_mode", ["wrap", "nowrap"])
+def test_3bit_unit_pairs_match_plain_field_extraction(zero_mode):
+    rng = np.random.default_rng(3)
+    for _ in range(500):
+        f = rng.integers(0, 8, 32)
+        bits = sum(int(v) << (3 * i) for i, v in enumerate(f))
+        w = [(bits >> (32 * j)) & 0xffffffff for j in range(3)]
+        zf = int(rng.integers(0, 8))                                  # stored field = zero - 1
+        z = ((zf + 1) & 7) if zero_mode == "wrap" else zf + 1       # qlinear_cuda_old.py:301-304 / qlinear_cuda.py:262-264
+        for p, pair in enumerate(gemv_pairs_3bit(w, z)):
+            assert float(pair[0]) == f[ka3(p)] - z and float(pair[1]) == f[kb3(p)] - z, (p, ka3(p), kb3(p))
+    assert sorted([ka3(p) for p in range(16)] + [kb3(p) for p in range(16)]) == list(range(32))      # every k exactly once
+
+
+def test_x_pair_selectors_pick_the_same_k_as_the_weight_pairs():
+    """magic_x_pair: x of a unit sits two values per register in natural order; pair p needs (x[ka], x[kb]) in one register."""
+    x = np.arange(32, dtype=np.uint16) + 100                        # value = 100 + k
+    regs = [int(x[2 * r]) | (int(x[2 * r + 1]) << 16) for r in range(16)]
+    for p in range(16):
+        a, b = ka3(p), kb3(p)
+        sel = (0x0302 if a & 1 else 0x0100) | ((0x0706 if b & 1 else 0x0504) << 16)
+        r = perm(regs[b >> 1], regs[a >> 1], sel)
+        assert (r & 0xffff, r >> 16) == (100 + a, 100 + b)
+    regs8 = [int(x[0]) | (int(x[1]) << 16), int(x[2]) | (int(x[3]) << 16)]        # 8-bit: pairs (0, 2), (1, 3)
+    assert perm(regs8[1], regs8[0], 0x0100 | (0x0504 << 16)) == (100 | (102 << 16))
+    assert perm(regs8[1], regs8[0], 0x0302 | (0x0706 << 16)) == (101 | (103 << 16))
+
+
+@pytest.mark.parametrize("zero_mode", ["wrap", "nowrap"])
+def test_8bit_word_pairs(zero_mode):
+    rng = np.random.default_rng(8)
+    for _ in range(500):
+        f = rng.integers(0, 256, 4)
+        w = sum(int(v) << (8 * i) for i, v in enumerate(f))
+        zf = int(rng.integers(0, 256))
+        z = ((zf + 1) & 255) if zero_mode == "wrap" else zf + 1      # up to 256
+        p0 = pk_fma(w, 0x00ff00ff, 1.0, -(1024 + z))                 # MagicF16<8>::pairs
+        p1 = pk_fma(w >> 8, 0x00ff00ff, 1.0, -(1024 + z))
+        assert (float(p0[0]), float(p0[1]), float(p1[0]), float(p1[1])) == (f[0] - z, f[2] - z, f[1] - z, f[3] - z)
+
+
+def test_gemm_fragments_come_out_in_the_4bit_slot_order():
+    """Deq<3, f16> / Deq<8, f16>::frag: a lane's 8 consecutive k of one column -> 4 registers (k0,k4), (k1,k5), (k2,k6), (k3,k7)."""
+    rng = np.random.default_rng(11)
+    for _ in range(500):
+        f = rng.integers(0, 8, 8)
+        z = int(rng.integers(0, 9))
+        junk = int(rng.integers(0, 1 << 30))                         # the window's upper bits belong to the next fields
+        v = (sum(int(x) << (3 * i) for i, x in enumerate(f)) | (junk << 24)) & 0xffffffff
+        t = perm(v >> 12, v, 0x05040100)
+        t6 = t >> 6
+        h = [pk_fma(t, 0x00070007, 1.0, -(1024 + z)), pk_fma(t, 0x00380038, 0.125, -(128 + z)),
+             pk_fma(t, 0x01C001C0, 1 / 64, -(16 + z)), pk_fma(t6, 0x00380038, 0.125, -(128 + z))]
+        for i in range(4):
+            assert (float(h[i][0]), float(h[i][1])) == (f[i] - z, f[i + 4] - z)
+        f8 = rng.integers(0, 256, 8)
+        z8 = int(rng.integers(0, 257))
+        w0 = sum(int(x) << (8 * i) for i, x in enumerate(f8[:4]))
+        w1 = sum(int(x) << (8 * i) for i, x in enumerate(f8[4:]))
+        lo, hi = perm(w1, w0, 0x05040100), perm(w1, w0, 0x07060302)
+        h8 = [pk_fma(lo, 0x00ff00ff, 1.0, -(1024 + z8)), pk_fma(lo >> 8, 0x00ff00ff, 1.0, -(1024 + z8)),
+              pk_fma(hi, 0x00ff00ff, 1.0, -(1024 + z8)), pk_fma(hi >> 8, 0x00ff00ff, 1.0, -(1024 + z8))]
+        for i in range(4):
+            assert (float(h8[i][0]), float(h8[i][1])) == (f8[i] - z8, f8[i + 4] - z8)
+
+
+def test_zero_point_constants_are_exact_fp16_bit_patterns():
+    """setup(): -(1024 + z) is built as an integer add on the fp16 bit pattern 0xE400 (ulp 1 in [1024, 2048)); -(128 + z) and
+    -(16 + z) by one exact fp16 addition each."""
+    for z in range(0, 257):
+        c1 = np.array([0xE400 + z], dtype=np.uint16).view(np.float16)[0]
+        assert float(c1) == -(1024 + z)
+        if z <= 8:
+            c3, c6 = np.float16(c1) + np.float16(896.0), np.float16(c1) + np.float16(1008.0)
+            assert float(c3) == -(128 + z) and float(c6) == -(16 + z)
