@@ -550,3 +550,41 @@ def test_tensor_parallel_wrappers_refuse_fused_epilogue_layers():
         ColumnParallelQuantLinear.from_full(f, 0, 2)
     with pytest.raises(ValueError, match="fused epilogue"):
         RowParallelQuantLinear.from_full(f, 0, 2)
+
+
+def test_planner_fuzz_every_configuration_plans_or_refuses_cleanly():
+    """gptq_describe_plan / gptq_workspace_bytes[_max] over a few thousand random (bits, group size, K, N, M, dtype, act-order flavour,
+    epilogue) configurations: a status code and a parsable plan or a clean refusal, never a crash (a division by zero for
+    group_size < 32 on the fp32 GEMM path was found this way in round 2), a workspace need that covers the plan's K split, and
+    gptq_workspace_bytes_max >= the need at every M it covers."""
+    import random
+    lib = _lib.load()
+    rnd = random.Random(20260923)
+    Ks = [32, 64, 96, 128, 160, 256, 320, 512, 1024, 1536, 2048, 4096, 5120, 8192, 11008, 13824, 28672]
+    Ns = [32, 64, 96, 128, 256, 320, 512, 1024, 3584, 4096, 5120, 8192, 11008, 12288, 22016, 28672]
+    Ms = [1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 32, 33, 64, 65, 100, 128, 200, 512, 2048, 4096]
+    seen = set()
+    for _ in range(6000):
+        K, N, bits = rnd.choice(Ks), rnd.choice(Ns), rnd.choice((2, 3, 4, 8))
+        gs = rnd.choice((16, 32, 64, 128, 256, 1024, K))
+        L = _layer(K=K, N=N, bits=bits, group_size=gs, dtype=rnd.choice((0, 1, 2)), zero_mode=rnd.choice((0, 1)), epilogue=rnd.choice((0, 0, 0, 1)))
+        act = rnd.choice((0, 0, 1, 2))
+        if act:
+            L.g_idx = 0x1000                              # raw act-order ...
+            if act == 2:
+                L.qweight_seq = L.perm = 0x1000           # ... or with the re-sequenced side copy
+        M = rnd.choice(Ms)
+        buf = ctypes.create_string_buffer(512)
+        rc = lib.gptq_describe_plan(ctypes.byref(L), M, None, buf, len(buf))
+        assert rc in (0, 2, 3), (rc, K, N, bits, gs, M)
+        need = lib.gptq_workspace_bytes(ctypes.byref(L), M)
+        if rc != 0:
+            continue
+        plan = dict(kv.split("=", 1) for kv in buf.value.decode().split())
+        seen.add(plan["kernel"])
+        assert plan["path"] in ("gemv", "gemm") and int(plan["ksplit"]) >= 1
+        if int(plan["ksplit"]) > 1 and plan["kernel"] not in ("stream", "stream64"):      # fp32 slabs [ksplit, M, N] behind the header
+            assert need >= int(plan["ksplit"]) * M * (N // (2 if L.epilogue and plan.get("pair") == "1" else 1)) * 4 // 2, (plan, need)
+        assert need < (1 << 34)
+        assert lib.gptq_workspace_bytes_max(ctypes.byref(L), M) >= need
+    assert {"mfma", "mfma_generic", "generic", "tiled", "skinny64", "stream64", "strip16", "f32_mfma"} <= seen, seen
