@@ -1165,9 +1165,13 @@ __device__ __forceinline__ unsigned magic_x_pair(const unsigned (&xr)[NR]) {
 // the lane's own column feed one 4x4x4 MFMA against the matching 4 x values of up to 4 x rows (natural k order: no x
 // permutation).  out = sum_g s_g * (sum_{k in g} x_k (w_k - z_g)), fp32 sums.
 // MAGIC (3- / 8-bit, fp16): the packed magic-number decode above instead of the field-by-field one; same values, bit for bit.
+// MT = 8 (MAGIC only): 5..8 rows of x in ONE pass over the weights -- a second A operand (rows 4..7) and a second MFMA per fragment, as the
+// 4-bit kernel does; 8 waves at most (<= 256 VGPRs).  Without it 5..8 rows are two passes (blockIdx.z) that unpack every word twice.
 template <int BITS, typename T, int LN, int MT, int U, bool MAGIC = false>
-__global__ void __launch_bounds__(1024, 4) gemv_mfma_generic_kernel(GemvParams p) {
+__global__ void __launch_bounds__(MT == 8 ? 512 : 1024, MT == 8 ? 2 : 4) gemv_mfma_generic_kernel(GemvParams p) {
     static_assert(!MAGIC || (std::is_same_v<T, f16> && (BITS == 3 || BITS == 8)), "magic-number decode: 3- / 8-bit fp16 only");
+    static_assert(MT <= 4 || (MT == 8 && MAGIC), "8 rows per pass: magic-number variants only");
+    constexpr int RP = MT == 8 ? 8 : 4;                 // rows of x per pass (blockIdx.z)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;
     constexpr int UW = Pack<BITS>::words, KPU = Pack<BITS>::vals, WR = 64 / LN, CT = LN * 4;
@@ -1178,10 +1182,11 @@ __global__ void __launch_bounds__(1024, 4) gemv_mfma_generic_kernel(GemvParams p
     const int n0 = strip * CT + cl * 4;
     const bool col_ok = n0 < p.N;
     const int nload = col_ok ? n0 : 0;
-    const int m0 = blockIdx.z * 4;
+    const int m0 = blockIdx.z * RP;
     const int ub = blockIdx.y * p.units_per_split;
     const int ue = min(ub + p.units_per_split, p.units_total);
     const T* __restrict__ xrow = (const T*)p.x + (size_t)min(m0 + (lane & 3), p.M - 1) * p.K;
+    const T* __restrict__ xrow2 = (const T*)p.x + (size_t)min(m0 + 4 + (lane & 3), p.M - 1) * p.K;     // MT = 8: rows 4..7
     const T* __restrict__ scales = (const T*)p.scales;
     const int zrow_words = p.N / 32 * BITS;
     const int gunits = p.group_size / KPU;              // units per group (>= 1, the launcher checks divisibility)
@@ -1217,6 +1222,23 @@ __global__ void __launch_bounds__(1024, 4) gemv_mfma_generic_kernel(GemvParams p
                 }
             }
         }
+        unsigned xr2[MT == 8 ? U : 1][KPU / 2];
+        if constexpr (MT == 8) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const T* xp = xrow2 + (size_t)min(u0 + j, ue - 1) * KPU;
+                if constexpr (KPU == 4) {
+                    const u32x2 t = *(const u32x2*)xp;
+                    xr2[j][0] = t[0]; xr2[j][1] = t[1];
+                } else {
+#pragma unroll
+                    for (int v = 0; v < XV; ++v) {
+                        const u32x4 t = *(const u32x4*)(xp + 8 * v);
+                        xr2[j][4 * v] = t[0]; xr2[j][4 * v + 1] = t[1]; xr2[j][4 * v + 2] = t[2]; xr2[j][4 * v + 3] = t[3];
+                    }
+                }
+            }
+        }
         u32x4 q[U][UW];
 #pragma unroll
         for (int j = 0; j < U; ++j)
@@ -1224,9 +1246,13 @@ __global__ void __launch_bounds__(1024, 4) gemv_mfma_generic_kernel(GemvParams p
             for (int w = 0; w < UW; ++w)
                 q[j][w] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)(min(u0 + j, ue - 1) * UW + w) * p.N + nload));
 
-        f32x4 accg[4];
+        f32x4 accg[4], accg2[MT == 8 ? 4 : 1];
 #pragma unroll
         for (int c = 0; c < 4; ++c) accg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (MT == 8) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) accg2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         if constexpr (MAGIC) {
             MagicF16<BITS> mg[4];
 #pragma unroll
@@ -1234,9 +1260,10 @@ __global__ void __launch_bounds__(1024, 4) gemv_mfma_generic_kernel(GemvParams p
 #pragma unroll
             for (int j = 0; j < U; ++j) {
                 const bool live = (u0 + j < ue);
-                unsigned xa[KPU / 2];                            // x in the slot order of the pairs, shared by the 4 columns
+                unsigned xa[KPU / 2], xa2[MT == 8 ? KPU / 2 : 1];   // x in the slot order of the pairs, shared by the 4 columns
                 [&]<int... P>(std::integer_sequence<int, P...>) {
                     ((xa[P] = live ? magic_x_pair<BITS, P>(xr[j]) : 0u), ...);
+                    if constexpr (MT == 8) ((xa2[P] = live ? magic_x_pair<BITS, P>(xr2[j]) : 0u), ...);
                 }(std::make_integer_sequence<int, KPU / 2>{});
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -1245,8 +1272,11 @@ __global__ void __launch_bounds__(1024, 4) gemv_mfma_generic_kernel(GemvParams p
                     for (int w = 0; w < UW; ++w) wds[w] = q[j][w][c];
                     mg[c].pairs(wds, mk, bp);
 #pragma unroll
-                    for (int Q = 0; Q < KPU / 4; ++Q)
+                    for (int Q = 0; Q < KPU / 4; ++Q) {
                         accg[c] = Mma4<T>::run(u32x2{xa[2 * Q], xa[2 * Q + 1]}, u32x2{bp[2 * Q], bp[2 * Q + 1]}, accg[c]);
+                        if constexpr (MT == 8)
+                            accg2[c] = Mma4<T>::run(u32x2{xa2[2 * Q], xa2[2 * Q + 1]}, u32x2{bp[2 * Q], bp[2 * Q + 1]}, accg2[c]);
+                    }
                 }
             }
         } else {
@@ -1279,7 +1309,11 @@ __global__ void __launch_bounds__(1024, 4) gemv_mfma_generic_kernel(GemvParams p
             const unsigned sh = (c & 1) ? (sraw[c >> 1] >> 16) : (sraw[c >> 1] & 0xffffu);
             const float sc = DType<T>::to_f32(__builtin_bit_cast(T, (unsigned short)sh));
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[c][m] = fmaf(sc, accg[c][m], acc[c][m]);
+            for (int m = 0; m < (MT == 8 ? 4 : MT); ++m) acc[c][m] = fmaf(sc, accg[c][m], acc[c][m]);
+            if constexpr (MT == 8) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[c][4 + m] = fmaf(sc, accg2[c][m], acc[c][4 + m]);
+            }
         }
     }
 #pragma unroll
@@ -1393,8 +1427,15 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
         pl.mt = M >= 5 ? 8 : (M >= 3 ? 4 : M);         // 8 = two groups of 4 rows in one pass
         pl.mtiles = M >= 5 ? (M + 7) / 8 : 1;
     } else if (pl.mfmag) {
-        pl.mt = M >= 3 ? 4 : M;
-        pl.mtiles = (M + 3) / 4;
+        // 3- / 8-bit fp16 (magic-number decode): 5..8 rows in one pass (two matrix-core sets per fragment), else 4 rows per pass
+        const bool magic_ok = L.dtype == GPTQ_F16 && (L.bits == 3 || L.bits == 8) && !(tune && tune->reserved[1] == 1);
+        if (magic_ok && M >= 5) {
+            pl.mt = 8;
+            pl.mtiles = (M + 7) / 8;
+        } else {
+            pl.mt = M >= 3 ? 4 : M;
+            pl.mtiles = (M + 3) / 4;
+        }
     } else {
         pl.mt = pick_mt(M);
         if (pl.direct && pl.mt > 4) pl.mt = 4;
@@ -1460,6 +1501,7 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
         if (pl.mfmag && L.bits == 3 && L.dtype == GPTQ_F16 && M == 1 && !(tune && tune->reserved[1] == 1) && waves > 8) waves = 8;
         if (waves < 1) waves = 1;
     }
+    if (pl.mfmag && pl.mt == 8 && waves > 8) waves = 8;      // 8 rows per pass: 512-thread workgroups (register budget), also when forced
     pl.waves = waves;
     const int rows_per_iter = wr * waves;
     const size_t rbytes = (size_t)waves * pl.mt * ln * 4 * sizeof(float);
@@ -1669,13 +1711,17 @@ static hipError_t launch_mfmag_u(const GemvPlan& pl, const GemvParams& p, hipStr
             return hipGetLastError();
         }
     }
-    switch (pl.u) {
-        case 1: hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 1>), grid, block, pl.lds_bytes, st, p); break;
-        case 2: if constexpr (BITS != 3) { hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 2>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
-        case 4: if constexpr (BITS == 4 || BITS == 8) { hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 4>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
-        default: return hipErrorInvalidValue;
+    if constexpr (MT <= 4) {
+        switch (pl.u) {
+            case 1: hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 1>), grid, block, pl.lds_bytes, st, p); break;
+            case 2: if constexpr (BITS != 3) { hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 2>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
+            case 4: if constexpr (BITS == 4 || BITS == 8) { hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 4>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;                       // 8 rows per pass exist for the magic-number variants only
     }
-    return hipGetLastError();
 }
 
 template <int BITS, typename T>
@@ -1684,6 +1730,11 @@ static hipError_t launch_mfmag_mt(const GemvPlan& pl, const GemvParams& p, hipSt
         case 1: return launch_mfmag_u<BITS, T, 1>(pl, p, st);
         case 2: return launch_mfmag_u<BITS, T, 2>(pl, p, st);
         case 4: return launch_mfmag_u<BITS, T, 4>(pl, p, st);
+        case 8:
+            if constexpr (std::is_same_v<T, f16> && (BITS == 3 || BITS == 8)) {
+                if (pl.magic && pl.waves <= 8) return launch_mfmag_u<BITS, T, 8>(pl, p, st);
+            }
+            return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }

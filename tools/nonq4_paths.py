@@ -22,11 +22,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gs", type=int, default=32)
     ap.add_argument("--ms", default="1,2,4,8,16,64,2048")
+    ap.add_argument("--plain-only", action="store_true", help="skip the act-order layers")
     args = ap.parse_args()
     ms = [int(v) for v in args.ms.split(",")]
     dev = torch.device("cuda:0")
     for bits in (3, 8):
-        for act in (False, True):
+        for act in ((False,) if args.plain_only else (False, True)):
             for K, N in SHAPES:
                 per = K * N * bits // 8
                 nl = max(4, min(32, (320 << 20) // per))
