@@ -81,7 +81,10 @@ bool want_gemm(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
         // pre-pass -- so they share the plain layers' crossovers; only raw act-order layers, which sit on the fp32 generic GEMV, leave early)
         const bool raw_act = L->g_idx != nullptr && !(L->qweight_seq != nullptr && L->perm != nullptr);
         const bool big = (size_t)L->K * L->N >= ((size_t)32 << 20);
-        const int min_m = raw_act ? (L->bits == 8 ? 3 : 5) : (L->bits == 8 ? 5 : ((L->bits == 2 && big) ? 5 : 9));
+        // int8 fp16 on layers of at most 256 strips: the one-pass 8-row GEMV beats the GEMMs up to 8 rows (us at M = 8, GEMV / GEMM: 4096x4096
+        // 12.5 / 16.6, 11008x4096 27.2 / 32.4; 4096x11008 26.0 / 23.6 keeps the GEMM from 5 rows)
+        const bool int8_rows8 = L->bits == 8 && L->dtype == GPTQ_F16 && L->N <= 4096 && L->epilogue == GPTQ_EPI_NONE && !raw_act;
+        const int min_m = raw_act ? (L->bits == 8 ? 3 : 5) : (L->bits == 8 ? (int8_rows8 ? 9 : 5) : ((L->bits == 2 && big) ? 5 : 9));
         if (M < min_m) return false;
         return plan_gemm(*L, M, t).supported;
     }

@@ -1429,7 +1429,9 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     } else if (pl.mfmag) {
         // 3- / 8-bit fp16 (magic-number decode): 5..8 rows in one pass (two matrix-core sets per fragment), else 4 rows per pass
         const bool magic_ok = L.dtype == GPTQ_F16 && (L.bits == 3 || L.bits == 8) && !(tune && tune->reserved[1] == 1);
-        if (magic_ok && M >= 5) {
+        // ... on layers of at most 256 strips (tools/nonq4_paths.py, profiles/r02_nonq4_paths.log, us at M = 8, two passes -> one: int3 11008x4096
+        // 22.8 -> 16.8, 4096x4096 8.6 -> 8.9; on 4096x11008 -- 688 strips, three 8-wave workgroups per CU at 137 VGPRs -- 17.7 -> 21.6: stays two passes)
+        if (magic_ok && M >= 5 && (N_cols <= 4096 || (tune && tune->path == 5))) {
             pl.mt = 8;
             pl.mtiles = (M + 7) / 8;
         } else {

@@ -326,6 +326,14 @@ def test_dispatch_rules_are_the_measured_ones():
     p = _plan(4096, 11008, 8, bits=3, gs=32, act=True)
     assert _plan(4096, 11008, 8, bits=3, gs=32)["path"] == "gemv" and (p["path"], p["kernel"], p["perm"]) == ("gemv", "mfma_generic", 2), p
     assert _plan(4096, 11008, 16, bits=3, gs=32, act=True)["path"] == "gemm"
+    # 5..8 rows, 3- / 8-bit fp16, at most 256 strips: ONE pass of the 8-row matrix-core GEMV (8 waves); wider layers keep two 4-row passes
+    # (int3) or the GEMM (int8) -- profiles/r02_nonq4_paths.log
+    for K, N in ((4096, 4096), (11008, 4096)):
+        for bits in (3, 8):
+            p = _plan(K, N, 8, bits=bits, gs=32)
+            assert (p["path"], p["kernel"], p["mt"], p["waves"]) == ("gemv", "mfma_generic", 8, 8), (K, N, bits, p)
+        assert _plan(K, N, 9, bits=8, gs=32)["path"] == "gemm" and _plan(K, N, 8, bits=8, gs=32, dtype=1)["path"] == "gemm"
+    assert _plan(4096, 11008, 8, bits=3, gs=32)["mt"] == 4 and _plan(4096, 11008, 5, bits=8, gs=32)["path"] == "gemm"
     assert _plan(4096, 4096, 1, bits=3, gs=32, act=True, dtype=1)["perm"] == 2 and _plan(4096, 4096, 1, bits=3, gs=32, act=True, dtype=1).get("deq") is None
     assert _plan(4096, 11008, 8, bits=2, gs=64)["path"] == "gemm" and _plan(4096, 4096, 8, bits=2, gs=64)["path"] == "gemv"
     # rows of x: GEMV up to 4; 5..8 rows: one matrix-core pass over 16 rows (16-column strips on narrow layers, the streamed
