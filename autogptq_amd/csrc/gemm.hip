@@ -454,6 +454,12 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+    // VAR == 16 (tools/gemmlab only, -DGPTQ_GEMM_ABLATIONS): the default schedule with s_memtime stamps at the phase boundaries of every
+    // K-step; per wave the cycle sums of the five phases go to p.partial[wave * 8 ..] of workgroup 0 (the stamps cost ~10 % themselves).
+    constexpr bool STAMP = (VAR == 16);
+    [[maybe_unused]] unsigned tsum[5] = {0u, 0u, 0u, 0u, 0u};
+    auto clk = [] { __builtin_amdgcn_sched_barrier(0); const unsigned t = (unsigned)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); return t; };
+
     // Two K-steps per loop trip, ping-ponging between register sets (b0,c0)/(b1,c1) and LDS buffers 0/1, so
     // nothing is copied and every LDS offset is an immediate.  Inside a step the A fragments of MFMA k-step
     // ks+1 are read from LDS before the MFMAs of ks are issued (their latency hides behind 8 MFMAs).
@@ -487,6 +493,8 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
     auto step = [&](int kt, auto bufc, const BRaw<BITS> (&b_use)[KS], const CRaw& c_use, BRaw<BITS> (&b_fill)[KS], CRaw& c_fill) {
         constexpr int BUF = decltype(bufc)::value;
         const int ktn = min(kt + 1, kt1 - 1);          // last step re-loads itself (no branch in the pipeline)
+        [[maybe_unused]] unsigned T0 = 0, T1 = 0, T2 = 0, T3 = 0, T4 = 0;
+        if constexpr (STAMP) T0 = clk();
         if constexpr (GLDS) {
             // The DMAs below are invisible to the compiler's vmcnt bookkeeping; any wait it emits while they are in flight is too
             // strict by their number (in-order retirement).  So this step's weight words and group constants -- requested a whole
@@ -504,6 +512,7 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
         load_b(ktn, b_fill);
         load_c(ktn, c_fill);
         __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of this step's MFMAs
+        if constexpr (STAMP) T1 = clk();
 
         if constexpr (VAR == 3) {
             // One continuous software pipeline across K-steps: the barrier sits in front of the LAST MFMA group of the
@@ -561,6 +570,10 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
             for (int mt = 0; mt < MT; ++mt) a[0][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (GLDS ? ((half ^ a_swz) * 16) : 0));
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) bq[0][nt] = frag(b_use[0], nt, kt * BK + half * 8);
+            if constexpr (STAMP) {                         // first fragments in registers: this step's weight words and LDS tile have arrived
+                asm volatile("" ::"v"(a[0][0][0]), "v"(bq[0][0][0]), "v"(bq[0][1][3]));
+                T2 = clk();
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + 1 < KS) {
@@ -595,17 +608,31 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
                 if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(0);
             }
         }
+        if constexpr (STAMP) T3 = clk();               // all MFMAs of the step issued
         if constexpr (!GLDS && !(VAR >= 8 && (VAR & 2))) store_a(BUF ^ 1, a_next);
         // DMA-staged x: the next step's tile must have landed before anybody passes the barrier.  vmcnt retires in order and
         // the step issued, after its DMAs, KS * (1 or 2) weight loads + 2 group-constant loads: those may stay in flight.
         if constexpr (GLDS) wait_vmcnt<KS * (BITS == 8 ? 2 : 1) + 2>();
+        if constexpr (STAMP) T4 = clk();               // next x tile written to LDS
         if constexpr (!(VAR >= 8 && (VAR & 4))) __syncthreads();
+        if constexpr (STAMP) {
+            const unsigned T5 = clk();                     // barrier released
+            tsum[0] += T1 - T0; tsum[1] += T2 - T1; tsum[2] += T3 - T2; tsum[3] += T4 - T3; tsum[4] += T5 - T4;
+        }
     };
     for (int kt = kt0; kt < kt1; kt += 2) {
         step(kt, std::integral_constant<int, 0>{}, b0, c0, b1, c1);
         if (kt + 1 < kt1) step(kt + 1, std::integral_constant<int, 1>{}, b1, c1, b0, c0);
     }
 
+    if constexpr (STAMP) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && p.partial != nullptr) {
+            unsigned* o = (unsigned*)p.partial + (threadIdx.x >> 6) * 8;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) o[i] = tsum[i];
+            o[5] = (unsigned)(kt1 - kt0);
+        }
+    }
     if constexpr (KG == 2) {
         // sum the two K halves through LDS (the x buffers are dead after the last barrier): group 1 hands rows 0-63 to
         // group 0, then group 0 hands rows 64-127 to group 1; each group stores the half it completed.
@@ -1362,6 +1389,9 @@ hipError_t init_gemm_device() {
     hipError_t e = grant_lds<4, f16, 4, 64, 1, true, true, 2>();
     if (e == hipSuccess) e = grant_lds<4, f16, 4, 64, 1, false, false, 2>();
     if (e == hipSuccess) e = grant_lds<4, bf16, 4, 64, 1, false, false, 2>();
+#ifdef GPTQ_GEMM_ABLATIONS
+    if (e == hipSuccess) e = grant_lds<4, f16, 4, 64, 16, false, false, 2>();
+#endif
     if (e == hipSuccess) e = grant_stream64_t<f16>();
     if (e == hipSuccess) e = grant_stream64_t<bf16>();
     return e;
@@ -1603,9 +1633,9 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.glds = pl.xslot && pl.variant != 5;            // variant 5 (experiment): register-staged x
     // At most one tile per CU: run the tile's K range as two concurrent halves inside the workgroup (8 waves).
     const bool even_slices = pl.ksteps_total % pl.ksteps_per_split == 0 && pl.ksteps_per_split % 2 == 0 && pl.ksteps_per_split >= 4;
-    const bool kg_ok = L.bits == 4 && pl.bk == 64 && pl.mt == 4 && even_slices && (pl.variant == 0 || pl.variant == 6 || pl.variant == 7) &&
+    const bool kg_ok = L.bits == 4 && pl.bk == 64 && pl.mt == 4 && even_slices && (pl.variant == 0 || pl.variant == 6 || pl.variant == 7 || pl.variant == 16 || pl.variant == 17) &&
                        (!pl.use_seq || pl.xslot == pl.glds);
-    pl.kg = (kg_ok && pl.variant != 6 && ((long)pl.nbm * pl.nbn * pl.ksplit <= 256 || pl.variant == 7)) ? 2 : 1;
+    pl.kg = (kg_ok && pl.variant != 6 && pl.variant != 16 && ((long)pl.nbm * pl.nbn * pl.ksplit <= 256 || pl.variant == 7 || pl.variant == 17)) ? 2 : 1;   // 16 / 17: gemmlab timeline variants (one / two K groups)
     return pl;
 }
 
@@ -1663,6 +1693,11 @@ static hipError_t launch_bits(const GemmPlan& pl, const GemmParams& p, hipStream
     if constexpr (BITS == 4) {
         if (pl.bk == 64) {
             if (pl.kg == 2) {
+#ifdef GPTQ_GEMM_ABLATIONS
+                if constexpr (std::is_same_v<T, f16>) {
+                    if (pl.variant == 17) return launch_one<BITS, T, 4, 64, 16, false, false, 2>(pl, p, st);    // s_memtime timeline
+                }
+#endif
                 if constexpr (std::is_same_v<T, f16>) {
                     if (pl.xslot && pl.glds) return launch_one<BITS, T, 4, 64, 1, true, true, 2>(pl, p, st);
                 }
@@ -1681,6 +1716,7 @@ static hipError_t launch_bits(const GemmPlan& pl, const GemmParams& p, hipStream
                 if (pl.variant == 11) return launch_one<BITS, T, 4, 64, 11>(pl, p, st);
                 if (pl.variant == 12) return launch_one<BITS, T, 4, 64, 12>(pl, p, st);
                 if (pl.variant == 15) return launch_one<BITS, T, 4, 64, 15>(pl, p, st);
+                if (pl.variant == 16) return launch_one<BITS, T, 4, 64, 16>(pl, p, st);                               // s_memtime timeline
 #endif
             }
             return launch_one<BITS, T, 4, 64>(pl, p, st);

@@ -1,5 +1,5 @@
 // gemmlab.hip -- timing harness for the PRODUCT MFMA prefill kernel (measurement tool, not product).
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++20 -I autogptq_amd/csrc -I include -c tools/gemmlab.hip -o /tmp/gemmlab.o && hipcc --offload-arch=gfx950 /tmp/gemmlab.o autogptq_amd/csrc/utils.o -o tools/gemmlab
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++20 -DGPTQ_GEMM_ABLATIONS -I autogptq_amd/csrc -I include -c tools/gemmlab.hip -o /tmp/gemmlab.o && hipcc --offload-arch=gfx950 /tmp/gemmlab.o autogptq_amd/csrc/utils.o -o tools/gemmlab
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
         printf("== M=%d K=%d N=%d : %.2f GFLOP per launch\n", M, K, N, 2.0 * M * K * N / 1e9);
         struct V { int id; const char* name; gptq_layer_t L; gptq_tuning_t tu; GemmPlan pl; double us; };
         std::vector<V> vs;
-        for (int variant = 0; variant < 20; ++variant) {
+        for (int variant = 0; variant < 22; ++variant) {
             if (only_variant >= 0 && variant != only_variant) continue;
             V v{}; v.id = variant; v.us = 1e30;
             gptq_layer_t& L = v.L;
@@ -81,6 +81,8 @@ int main(int argc, char** argv) {
             if (variant == 18) { if (M < 128) continue; L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.tu.reserved[3] = 6; v.name = "KG=1 forced, act-order + DMA"; }
             if (variant == 19) { if (M < 128) continue; L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.tu.reserved[3] = 7; v.name = "KG=2 forced, act-order + DMA"; }
             if (variant == 13) { if (M < 512) continue; L.dtype = GPTQ_BF16; v.name = "bf16 (bit patterns reused: timing only)"; }
+            if (variant == 20) { if (M < 128) continue; v.tu.reserved[3] = 16; v.name = "timeline (s_memtime stamps), one K group"; }
+            if (variant == 21) { if (M < 128) continue; v.tu.reserved[3] = 17; v.name = "timeline (s_memtime stamps), two K groups"; }
             if (variant == 2) { L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.name = "act-order (x permute + qweight_seq)"; }
             v.pl = plan_gemm(L, M, &v.tu);
             if (!v.pl.supported) { printf("  unsupported\n"); continue; }
@@ -111,6 +113,23 @@ int main(int argc, char** argv) {
         for (auto& v : vs)
             printf("  %9.2f us  %8.1f TFLOP/s  %7.1f GB/s(w)  %-38s %s mt=%d bk=%d grid=%dx%d ksplit=%d\n", v.us, 2.0 * M * K * N / v.us / 1e6, qw_b / v.us / 1e3, v.name,
                    v.pl.skinny ? "skinny" : "tiled", v.pl.mt, v.pl.bk, v.pl.nbm, v.pl.nbn, v.pl.ksplit);
+        for (auto& v : vs) {
+            if (v.id != 20 && v.id != 21) continue;
+            // one more launch with a clean stamp area: per wave of workgroup 0 the cycle sums of the five phases of a K-step
+            CK(hipMemsetAsync(ws + WS_HEADER_BYTES, 0, 16 * 8 * 4, st));
+            gptq_layer_t L = v.L; L.qweight = qw; L.qzeros = qz; L.scales = sc;
+            if (launch_gemm(L, v.pl, x, out, M, ws, ws + WS_HEADER_BYTES, st) != hipSuccess) { printf("timeline launch failed\n"); continue; }
+            CK(hipStreamSynchronize(st));
+            unsigned hst[16 * 8];
+            CK(hipMemcpy(hst, ws + WS_HEADER_BYTES, sizeof(hst), hipMemcpyDeviceToHost));
+            printf("  %s: shader cycles per K-step, workgroup 0 (issue loads | first fragments ready | MFMA groups issued | x tile stored | barrier released)\n", v.name);
+            for (int w = 0; w < (v.pl.kg == 2 ? 8 : 4); ++w) {
+                const unsigned* o = hst + w * 8;
+                const double n = o[5] ? (double)o[5] : 1.0;
+                printf("    wave %d (%u steps): %7.0f | %7.0f | %7.0f | %7.0f | %7.0f   = %7.0f cycles per step\n", w, o[5], o[0] / n, o[1] / n, o[2] / n, o[3] / n, o[4] / n,
+                       (o[0] + o[1] + o[2] + o[3] + o[4]) / n);
+            }
+        }
         CK(hipFree(qw)); CK(hipFree(qz)); CK(hipFree(sc)); CK(hipFree(x)); CK(hipFree(out)); CK(hipFree(ws)); CK(hipFree(perm));
     }
     return 0;
