@@ -457,6 +457,9 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
     // VAR == 16 (tools/gemmlab only, -DGPTQ_GEMM_ABLATIONS): the default schedule with s_memtime stamps at the phase boundaries of every
     // K-step; per wave the cycle sums of the five phases go to p.partial[wave * 8 ..] of workgroup 0 (the stamps cost ~10 % themselves).
     constexpr bool STAMP = (VAR == 16);
+    // VAR == 24 (tools/gemmlab only): the next step's loads are not issued in a block at the top of the step but between the MFMA groups
+    // (weights + constants behind group 0, x behind group 1, the x tile goes to LDS behind group 2) -- what the timeline suggests
+    constexpr bool ILV = (VAR == 24);
     [[maybe_unused]] unsigned tsum[5] = {0u, 0u, 0u, 0u, 0u};
     auto clk = [] { __builtin_amdgcn_sched_barrier(0); const unsigned t = (unsigned)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); return t; };
 
@@ -507,10 +510,12 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
             asm volatile("" ::"v"(c_use.s), "v"((unsigned)c_use.z));
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (GLDS) dma_a(ktn, BUF ^ 1);
-        else if constexpr (!(VAR >= 8 && (VAR & 2))) load_a(ktn, a_next);
-        load_b(ktn, b_fill);
-        load_c(ktn, c_fill);
+        if constexpr (!ILV) {
+            if constexpr (GLDS) dma_a(ktn, BUF ^ 1);
+            else if constexpr (!(VAR >= 8 && (VAR & 2))) load_a(ktn, a_next);
+            load_b(ktn, b_fill);
+            load_c(ktn, c_fill);
+        }
         __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of this step's MFMAs
         if constexpr (STAMP) T1 = clk();
 
@@ -590,6 +595,13 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = Mma<T>::run(a[ks & 1][mt], bq[ks & 1][nt], acc[mt][nt]);
+                if constexpr (ILV && !GLDS) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks == 0) { load_b(ktn, b_fill); load_c(ktn, c_fill); }
+                    if (ks == 1) load_a(ktn, a_next);
+                    if (ks == KS - 2 && KS >= 4) store_a(BUF ^ 1, a_next);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         } else {
 #pragma unroll
@@ -609,7 +621,7 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
             }
         }
         if constexpr (STAMP) T3 = clk();               // all MFMAs of the step issued
-        if constexpr (!GLDS && !(VAR >= 8 && (VAR & 2))) store_a(BUF ^ 1, a_next);
+        if constexpr (!GLDS && !(VAR >= 8 && (VAR & 2)) && !ILV) store_a(BUF ^ 1, a_next);
         // DMA-staged x: the next step's tile must have landed before anybody passes the barrier.  vmcnt retires in order and
         // the step issued, after its DMAs, KS * (1 or 2) weight loads + 2 group-constant loads: those may stay in flight.
         if constexpr (GLDS) wait_vmcnt<KS * (BITS == 8 ? 2 : 1) + 2>();
@@ -1717,6 +1729,7 @@ static hipError_t launch_bits(const GemmPlan& pl, const GemmParams& p, hipStream
                 if (pl.variant == 12) return launch_one<BITS, T, 4, 64, 12>(pl, p, st);
                 if (pl.variant == 15) return launch_one<BITS, T, 4, 64, 15>(pl, p, st);
                 if (pl.variant == 16) return launch_one<BITS, T, 4, 64, 16>(pl, p, st);                               // s_memtime timeline
+                if (pl.variant == 24) return launch_one<BITS, T, 4, 64, 24>(pl, p, st);                               // loads interleaved with the MFMA groups
 #endif
             }
             return launch_one<BITS, T, 4, 64>(pl, p, st);

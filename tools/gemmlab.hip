@@ -35,7 +35,11 @@ int main(int argc, char** argv) {
     std::vector<Shape> shapes = {{2048, 4096, 4096}, {4096, 4096, 4096}, {2048, 4096, 11008}, {2048, 11008, 4096}, {512, 4096, 4096}, {128, 4096, 4096}, {64, 4096, 4096}, {32, 4096, 4096}, {16, 4096, 4096}, {16, 4096, 11008}, {64, 11008, 4096}, {128, 4096, 11008}};
     int only_variant = -1, reps = 5;
     if (argc >= 4) { shapes = {{atoi(argv[1]), atoi(argv[2]), atoi(argv[3])}}; }
-    if (argc >= 5) only_variant = atoi(argv[4]);
+    std::vector<int> only_list;
+    if (argc >= 5) {
+        only_variant = atoi(argv[4]);
+        for (const char* c = argv[4]; *c;) { only_list.push_back(atoi(c)); while (*c && *c != ',') ++c; if (*c == ',') ++c; }
+    }
     if (argc >= 6) reps = atoi(argv[5]);
     for (auto s : shapes) {
         const int M = s.M, K = s.K, N = s.N;
@@ -56,8 +60,8 @@ int main(int argc, char** argv) {
         printf("== M=%d K=%d N=%d : %.2f GFLOP per launch\n", M, K, N, 2.0 * M * K * N / 1e9);
         struct V { int id; const char* name; gptq_layer_t L; gptq_tuning_t tu; GemmPlan pl; double us; };
         std::vector<V> vs;
-        for (int variant = 0; variant < 22; ++variant) {
-            if (only_variant >= 0 && variant != only_variant) continue;
+        for (int variant = 0; variant < 24; ++variant) {
+            if (only_variant >= 0 && std::find(only_list.begin(), only_list.end(), variant) == only_list.end()) continue;
             V v{}; v.id = variant; v.us = 1e30;
             gptq_layer_t& L = v.L;
             L.K = K; L.N = N; L.bits = 4; L.group_size = 128; L.dtype = GPTQ_F16; L.zero_mode = GPTQ_ZERO_WRAP;
@@ -81,6 +85,8 @@ int main(int argc, char** argv) {
             if (variant == 18) { if (M < 128) continue; L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.tu.reserved[3] = 6; v.name = "KG=1 forced, act-order + DMA"; }
             if (variant == 19) { if (M < 128) continue; L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.tu.reserved[3] = 7; v.name = "KG=2 forced, act-order + DMA"; }
             if (variant == 13) { if (M < 512) continue; L.dtype = GPTQ_BF16; v.name = "bf16 (bit patterns reused: timing only)"; }
+            if (variant == 22) { if (M < 512) continue; v.tu.reserved[3] = 24; v.name = "loads interleaved with the MFMA groups (KG = 1)"; }
+            if (variant == 23) { if (M < 512) continue; v.tu.reserved[3] = 6; v.name = "default schedule, KG = 1 forced"; }
             if (variant == 20) { if (M < 128) continue; v.tu.reserved[3] = 16; v.name = "timeline (s_memtime stamps), one K group"; }
             if (variant == 21) { if (M < 128) continue; v.tu.reserved[3] = 17; v.name = "timeline (s_memtime stamps), two K groups"; }
             if (variant == 2) { L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.name = "act-order (x permute + qweight_seq)"; }
