@@ -460,6 +460,24 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
     // VAR == 24 (tools/gemmlab only): the next step's loads are not issued in a block at the top of the step but between the MFMA groups
     // (weights + constants behind group 0, x behind group 1, the x tile goes to LDS behind group 2) -- what the timeline suggests
     constexpr bool ILV = (VAR == 24);
+    // VAR == 32 (tools/gemmlab only, KG = 2): PING-PONG between the two K groups.  Waves w (group 0) and w + 4 (group 1) share a SIMD; a token
+    // word per pair in LDS says whose turn the MFMA half of a step is, so one wave's load / unpack half runs under the other's MFMA half instead of
+    // both sitting in the same phase (the K-step timeline).  The per-step barrier becomes per group (an LDS counter): the groups share
+    // nothing until the final reduction.  Every spin is bounded (a lost token ends in wrong numbers, never in a hung queue).
+    constexpr bool PP = (VAR == 32) && KG == 2;
+    unsigned* const pp_sync = (unsigned*)(smem_all + (size_t)KG * 2 * BM * STRIDE);      // [0..3] pair tokens, [4..5] group barrier counters
+    [[maybe_unused]] unsigned pp_step = 0, pp_epoch = 0;
+    if constexpr (PP) {
+        if (threadIdx.x < 8) pp_sync[threadIdx.x] = 0u;                                 // published by the prologue barrier below
+    }
+    auto pp_spin_until = [&](const unsigned* w, unsigned want) {                          // wave-uniform LDS poll, bounded
+        __builtin_amdgcn_sched_barrier(0);
+        for (int spins = 0; spins < (1 << 16); ++spins) {
+            if ((int)(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - want) >= 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     [[maybe_unused]] unsigned tsum[5] = {0u, 0u, 0u, 0u, 0u};
     auto clk = [] { __builtin_amdgcn_sched_barrier(0); const unsigned t = (unsigned)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); return t; };
 
@@ -579,6 +597,10 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
                 asm volatile("" ::"v"(a[0][0][0]), "v"(bq[0][0][0]), "v"(bq[0][1][3]));
                 T2 = clk();
             }
+            if constexpr (PP) {                            // my turn on the matrix core?  (group 0 owns the even half steps)
+                asm volatile("" ::"v"(a[0][0][0]), "v"(bq[0][0][0]), "v"(bq[0][1][3]));
+                pp_spin_until(pp_sync + wave, 2u * pp_step + (unsigned)kg);
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + 1 < KS) {
@@ -620,13 +642,23 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
                 if constexpr (VAR == 2) __builtin_amdgcn_s_setprio(0);
             }
         }
+        if constexpr (PP) {                            // all MFMAs of the step issued: the sibling wave on this SIMD may start its own
+            __builtin_amdgcn_sched_barrier(0);
+            if (lane == 0) __hip_atomic_store(pp_sync + wave, 2u * pp_step + (unsigned)kg + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ++pp_step;
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (STAMP) T3 = clk();               // all MFMAs of the step issued
         if constexpr (!GLDS && !(VAR >= 8 && (VAR & 2)) && !ILV) store_a(BUF ^ 1, a_next);
         // DMA-staged x: the next step's tile must have landed before anybody passes the barrier.  vmcnt retires in order and
         // the step issued, after its DMAs, KS * (1 or 2) weight loads + 2 group-constant loads: those may stay in flight.
         if constexpr (GLDS) wait_vmcnt<KS * (BITS == 8 ? 2 : 1) + 2>();
         if constexpr (STAMP) T4 = clk();               // next x tile written to LDS
-        if constexpr (!(VAR >= 8 && (VAR & 4))) __syncthreads();
+        if constexpr (PP) {                            // per-group barrier: this group's 4 waves only (LDS operations of a wave execute in order, so
+            ++pp_epoch;                                    // the counter increment is behind this wave's x-tile writes)
+            if (lane == 0) __hip_atomic_fetch_add(pp_sync + 4 + kg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pp_spin_until(pp_sync + 4 + kg, 4u * pp_epoch);
+        } else if constexpr (!(VAR >= 8 && (VAR & 4))) __syncthreads();
         if constexpr (STAMP) {
             const unsigned T5 = clk();                     // barrier released
             tsum[0] += T1 - T0; tsum[1] += T2 - T1; tsum[2] += T3 - T2; tsum[3] += T4 - T3; tsum[4] += T5 - T4;
@@ -645,6 +677,7 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
             o[5] = (unsigned)(kt1 - kt0);
         }
     }
+    if constexpr (PP) __syncthreads();                   // the groups ran unsynchronised: both must be out of their K loops before the exchange area is written
     if constexpr (KG == 2) {
         // sum the two K halves through LDS (the x buffers are dead after the last barrier): group 1 hands rows 0-63 to
         // group 0, then group 0 hands rows 64-127 to group 1; each group stores the half it completed.
@@ -1376,7 +1409,7 @@ hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int 
 
 // ---- host side ----------------------------------------------------------------------------------
 template <int BITS, typename T, int MT, int BK, int VAR, bool XPRE, bool GLDS, int KG>
-static constexpr size_t gemm_lds_bytes() { return (size_t)KG * 2 * (32 * MT) * (GLDS ? BK * 2 : BK * 2 + 16); }
+static constexpr size_t gemm_lds_bytes() { return (size_t)KG * 2 * (32 * MT) * (GLDS ? BK * 2 : BK * 2 + 16) + (VAR == 32 ? 64 : 0); }
 
 template <int BITS, typename T, int MT, int BK, int VAR, bool XPRE, bool GLDS, int KG>
 static hipError_t grant_lds() {
@@ -1403,6 +1436,8 @@ hipError_t init_gemm_device() {
     if (e == hipSuccess) e = grant_lds<4, bf16, 4, 64, 1, false, false, 2>();
 #ifdef GPTQ_GEMM_ABLATIONS
     if (e == hipSuccess) e = grant_lds<4, f16, 4, 64, 16, false, false, 2>();
+    if (e == hipSuccess) e = grant_lds<4, f16, 4, 64, 32, false, false, 2>();
+    if (e == hipSuccess) e = grant_lds<4, f16, 4, 64, 32, true, true, 2>();
 #endif
     if (e == hipSuccess) e = grant_stream64_t<f16>();
     if (e == hipSuccess) e = grant_stream64_t<bf16>();
@@ -1641,19 +1676,19 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.ksplit = (pl.ksteps_total + pl.ksteps_per_split - 1) / pl.ksteps_per_split;   // no empty slices
     pl.workspace_bytes = pl.xperm_bytes + (pl.ksplit > 1 ? (size_t)pl.ksplit * M * L.N * sizeof(float) : 0);
     // act-order + the 4-bit fp16 128x256x64 kernel: the permute pre-pass delivers x in k-slot order
-    pl.xslot = pl.use_seq && L.bits == 4 && L.dtype == GPTQ_F16 && pl.mt == 4 && pl.bk == 64 && (pl.variant == 0 || pl.variant == 3 || pl.variant == 5 || pl.variant == 6 || pl.variant == 7);
+    pl.xslot = pl.use_seq && L.bits == 4 && L.dtype == GPTQ_F16 && pl.mt == 4 && pl.bk == 64 && (pl.variant == 0 || pl.variant == 3 || pl.variant == 5 || pl.variant == 6 || pl.variant == 7 || pl.variant == 32);
     pl.glds = pl.xslot && pl.variant != 5;            // variant 5 (experiment): register-staged x
     // At most one tile per CU: run the tile's K range as two concurrent halves inside the workgroup (8 waves).
     const bool even_slices = pl.ksteps_total % pl.ksteps_per_split == 0 && pl.ksteps_per_split % 2 == 0 && pl.ksteps_per_split >= 4;
-    const bool kg_ok = L.bits == 4 && pl.bk == 64 && pl.mt == 4 && even_slices && (pl.variant == 0 || pl.variant == 6 || pl.variant == 7 || pl.variant == 16 || pl.variant == 17) &&
+    const bool kg_ok = L.bits == 4 && pl.bk == 64 && pl.mt == 4 && even_slices && (pl.variant == 0 || pl.variant == 6 || pl.variant == 7 || pl.variant == 16 || pl.variant == 17 || pl.variant == 32) &&
                        (!pl.use_seq || pl.xslot == pl.glds);
-    pl.kg = (kg_ok && pl.variant != 6 && pl.variant != 16 && ((long)pl.nbm * pl.nbn * pl.ksplit <= 256 || pl.variant == 7 || pl.variant == 17)) ? 2 : 1;   // 16 / 17: gemmlab timeline variants (one / two K groups)
+    pl.kg = (kg_ok && pl.variant != 6 && pl.variant != 16 && ((long)pl.nbm * pl.nbn * pl.ksplit <= 256 || pl.variant == 7 || pl.variant == 17 || pl.variant == 32)) ? 2 : 1;   // 16 / 17: gemmlab timeline variants (one / two K groups); 32: ping-pong
     return pl;
 }
 
 template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, bool GLDS = false, int KG = 1>
 static hipError_t launch_one(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
-    const size_t lds = (size_t)KG * 2 * (32 * MT) * (GLDS ? BK * 2 : BK * 2 + 16);   // KG = 2: >= the 64 KiB exchange area
+    const size_t lds = gemm_lds_bytes<BITS, T, MT, BK, VAR, XPRE, GLDS, KG>();       // KG = 2: >= the 64 KiB exchange area
     auto* kern = gemm_kernel<BITS, T, MT, BK, VAR, XPRE, GLDS, KG>;
     // KG = 2 asks for > 64 KiB of dynamic LDS: granted per function and device by init_gemm_device() (gptq_init), never here --
     // the launch path makes no runtime-API call besides the launch itself, so it is legal under stream capture.
@@ -1708,6 +1743,8 @@ static hipError_t launch_bits(const GemmPlan& pl, const GemmParams& p, hipStream
 #ifdef GPTQ_GEMM_ABLATIONS
                 if constexpr (std::is_same_v<T, f16>) {
                     if (pl.variant == 17) return launch_one<BITS, T, 4, 64, 16, false, false, 2>(pl, p, st);    // s_memtime timeline
+                    if (pl.variant == 32) return (pl.xslot && pl.glds) ? launch_one<BITS, T, 4, 64, 32, true, true, 2>(pl, p, st)
+                                                                       : launch_one<BITS, T, 4, 64, 32, false, false, 2>(pl, p, st);   // ping-pong
                 }
 #endif
                 if constexpr (std::is_same_v<T, f16>) {

@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
         printf("== M=%d K=%d N=%d : %.2f GFLOP per launch\n", M, K, N, 2.0 * M * K * N / 1e9);
         struct V { int id; const char* name; gptq_layer_t L; gptq_tuning_t tu; GemmPlan pl; double us; };
         std::vector<V> vs;
-        for (int variant = 0; variant < 24; ++variant) {
+        for (int variant = 0; variant < 26; ++variant) {
             if (only_variant >= 0 && std::find(only_list.begin(), only_list.end(), variant) == only_list.end()) continue;
             V v{}; v.id = variant; v.us = 1e30;
             gptq_layer_t& L = v.L;
@@ -87,6 +87,8 @@ int main(int argc, char** argv) {
             if (variant == 13) { if (M < 512) continue; L.dtype = GPTQ_BF16; v.name = "bf16 (bit patterns reused: timing only)"; }
             if (variant == 22) { if (M < 512) continue; v.tu.reserved[3] = 24; v.name = "loads interleaved with the MFMA groups (KG = 1)"; }
             if (variant == 23) { if (M < 512) continue; v.tu.reserved[3] = 6; v.name = "default schedule, KG = 1 forced"; }
+            if (variant == 24) { if (M < 128) continue; v.tu.reserved[3] = 32; v.name = "ping-pong between the two K groups (KG = 2 forced)"; }
+            if (variant == 25) { if (M < 128) continue; L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.tu.reserved[3] = 32; v.name = "ping-pong, act-order + DMA (KG = 2 forced)"; }
             if (variant == 20) { if (M < 128) continue; v.tu.reserved[3] = 16; v.name = "timeline (s_memtime stamps), one K group"; }
             if (variant == 21) { if (M < 128) continue; v.tu.reserved[3] = 17; v.name = "timeline (s_memtime stamps), two K groups"; }
             if (variant == 2) { L.g_idx = perm; L.perm = perm; L.qweight_seq = qw; v.name = "act-order (x permute + qweight_seq)"; }
@@ -98,7 +100,7 @@ int main(int argc, char** argv) {
             for (int i = 0; i < nl; ++i) {
                 gptq_layer_t L = v.L;
                 L.qweight = qw + (size_t)i * qw_b / 4; L.qzeros = qz + (size_t)i * qz_b / 4; L.scales = sc + (size_t)i * sc_b / 2;
-                L.qweight_seq = (v.id == 2 || v.id == 12 || v.id == 15 || v.id >= 18) ? L.qweight : nullptr;
+                L.qweight_seq = (v.id == 2 || v.id == 12 || v.id == 15 || v.id == 18 || v.id == 19 || v.id == 25) ? L.qweight : nullptr;
                 hipError_t e = launch_gemm(L, v.pl, x, out, M, ws, ws + WS_HEADER_BYTES, st);
                 if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); exit(1); }
             }
