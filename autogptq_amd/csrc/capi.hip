@@ -196,8 +196,8 @@ static size_t body_bytes(const gptq_layer_t* L, int M, const gptq_tuning_t* tune
         gptq_layer_t Lc = *L;
         Lc.epilogue = GPTQ_EPI_NONE;
         gptq_tuning_t local;
-        const size_t inner = body_bytes(&Lc, M, inner_tuning(L, M, tune, &local));          // the inner call sees a complete workspace: header + body
-        return epi_scratch_bytes(L, M) + (inner ? WS_HEADER_BYTES + inner : 0);
+        const size_t inner = body_bytes(&Lc, M, inner_tuning(L, M, tune, &local));          // the inner call shares the ONE zeroed ticket header; its body starts behind y
+        return epi_scratch_bytes(L, M) + inner;
     }
     size_t a = plan_gemv(*L, M, tune).workspace_bytes;
     GemmPlan g = plan_gemm(*L, M, tune);
@@ -245,8 +245,9 @@ int gptq_validate_g_idx(const int32_t* g_idx, int K, int G) {
     return GPTQ_OK;
 }
 
-int gptq_gemv(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream,
-              const gptq_tuning_t* tune) {
+// The kernels see the workspace as (ticket header, body): the header is the caller's zeroed first 64 KiB and is NEVER relocated -- a call
+// that nests another one (the unfused SILU_MUL epilogue) hands the inner call the same header and the rest of its body.
+static int gemv_core(const gptq_layer_t* L, const void* x, void* out, int M, const WsView& wv, void* stream, const gptq_tuning_t* tune) {
     int rc = check_layer(L);
     if (rc) return rc;
     rc = check_io(x, out, M);
@@ -264,16 +265,18 @@ int gptq_gemv(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, 
         return fail(GPTQ_ERR_UNSUPPORTED, "direct GEMV needs bits=4, fp16, no act-order and a power-of-two group_size >= 8");
     if (tune && tune->path == 2 && (!pl.fast || pl.mfma || pl.direct))
         return fail(GPTQ_ERR_UNSUPPORTED, "fast GEMV needs bits=4, fp16 and sequential (or re-sequenced) groups");
-    const WsView wv = split_ws(ws, ws_bytes);
     if (pl.workspace_bytes > 0 && wv.body_bytes < pl.workspace_bytes)
-        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + pl.workspace_bytes, ws ? ws_bytes : (size_t)0);
+        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + pl.workspace_bytes, wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0);
     hipError_t e = launch_gemv(*L, pl, x, out, M, wv.body, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "gptq_gemv launch");
     return GPTQ_OK;
 }
-
-int gptq_gemm(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream,
+int gptq_gemv(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream,
               const gptq_tuning_t* tune) {
+    return gemv_core(L, x, out, M, split_ws(ws, ws_bytes), stream, tune);
+}
+
+static int gemm_core(const gptq_layer_t* L, const void* x, void* out, int M, const WsView& wv, void* stream, const gptq_tuning_t* tune) {
     int rc = check_layer(L);
     if (rc) return rc;
     rc = check_io(x, out, M);
@@ -285,42 +288,45 @@ int gptq_gemm(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, 
         return fail(GPTQ_ERR_UNSUPPORTED,
                     "MFMA GEMM needs sequential or re-sequenced groups made of whole packing units (fp16/bf16: group_size %% 32 == 0) (bits=%d dtype=%d group_size=%d)",
                     L->bits, L->dtype, L->group_size);
-    const WsView wv = split_ws(ws, ws_bytes);
     if (pl.workspace_bytes > 0 && wv.body_bytes < pl.workspace_bytes)
-        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + pl.workspace_bytes, ws ? ws_bytes : (size_t)0);
+        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + pl.workspace_bytes, wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0);
     hipError_t e = launch_gemm(*L, pl, x, out, M, wv.header, wv.body, (hipStream_t)stream);
     if (e != hipSuccess)
         return hip_fail(e, pl.kg == 2 ? "gptq_gemm launch (this kernel needs > 64 KiB of LDS: was gptq_init() called on this device?)"
                                       : "gptq_gemm launch");
     return GPTQ_OK;
 }
+int gptq_gemm(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream,
+              const gptq_tuning_t* tune) {
+    return gemm_core(L, x, out, M, split_ws(ws, ws_bytes), stream, tune);
+}
 
-static int stream_call(const gptq_layer_t* const* Ls, int n, const StreamPlan& sp, const void* x, void* const* outs, int M, void* ws,
-                       size_t ws_bytes, void* stream) {
-    const WsView wv = split_ws(ws, ws_bytes);
+static int stream_call(const gptq_layer_t* const* Ls, int n, const StreamPlan& sp, const void* x, void* const* outs, int M, const WsView& wv,
+                       void* stream) {
     if (sp.partial_bytes > 0 && wv.body_bytes < sp.partial_bytes)
-        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + sp.partial_bytes, ws ? ws_bytes : (size_t)0);
+        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + sp.partial_bytes, wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0);
     hipError_t e = launch_stream(Ls, sp, x, outs, M, wv.header, wv.body, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "gptq streamed GEMV launch (16 waves x U = 8 needs > 64 KiB of LDS: was gptq_init() called on this device?)");
     return GPTQ_OK;
 }
 
-static int forward_impl(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream,
+static int forward_impl(const gptq_layer_t* L, const void* x, void* out, int M, const WsView& wv, void* stream,
                         const gptq_tuning_t* tune) {
     int rc = check_layer(L);
     if (rc) return rc;
+    const size_t have = wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0;
     if (L->epilogue != GPTQ_EPI_NONE && !fused_epilogue_ok(L, M, tune)) {
         rc = check_io(x, out, M);
         if (rc) return rc;
         const size_t yb = epi_scratch_bytes(L, M);
-        const WsView wv = split_ws(ws, ws_bytes);
         if (wv.body_bytes < yb)
-            return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", gptq_workspace_bytes_ex(L, M, tune), ws ? ws_bytes : (size_t)0);
-        // y = [gate | up] at the front of the body; the rest of the body is a complete workspace (header + body) of the inner call
+            return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", gptq_workspace_bytes_ex(L, M, tune), have);
+        // y = [gate | up] at the front of the body; the inner call gets the SAME zeroed ticket header and the body behind y (a header carved
+        // out of the body would sit on whatever an earlier, larger call left there: its tickets would never reach ksplit - 1)
         gptq_layer_t Lc = *L;
         Lc.epilogue = GPTQ_EPI_NONE;
         gptq_tuning_t local;
-        rc = forward_impl(&Lc, x, wv.body, M, (char*)wv.body + yb, wv.body_bytes - yb, stream, inner_tuning(L, M, tune, &local));
+        rc = forward_impl(&Lc, x, wv.body, M, WsView{wv.header, (char*)wv.body + yb, wv.body_bytes - yb}, stream, inner_tuning(L, M, tune, &local));
         if (rc) return rc;
         hipError_t e = launch_silu_mul(wv.body, out, M, L->N, L->dtype, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "silu_mul launch");
@@ -331,7 +337,7 @@ static int forward_impl(const gptq_layer_t* L, const void* x, void* out, int M, 
         if (rc) return rc;
         const gptq_layer_t* one[1] = {L};
         void* outs[1] = {out};
-        return stream_call(one, 1, plan_stream(one, 1, M, tune), x, outs, M, ws, ws_bytes, stream);
+        return stream_call(one, 1, plan_stream(one, 1, M, tune), x, outs, M, wv, stream);
     }
     {
         gptq_layer_t P;
@@ -342,9 +348,8 @@ static int forward_impl(const gptq_layer_t* L, const void* x, void* out, int M, 
             void* outs[1] = {out};
             const StreamPlan sp = plan_stream(one, 1, M, nullptr);
             const size_t xb = xperm16_bytes(L, M);
-            const WsView wv = split_ws(ws, ws_bytes);
             if (wv.body_bytes < xb + sp.partial_bytes)
-                return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + xb + sp.partial_bytes, ws ? ws_bytes : (size_t)0);
+                return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + xb + sp.partial_bytes, have);
             hipError_t e = launch_permute_columns(x, L->perm, M, L->K, L->dtype, wv.body, (hipStream_t)stream);
             if (e != hipSuccess) return hip_fail(e, "gptq_permute_columns launch");
             e = launch_stream(one, sp, wv.body, outs, M, wv.header, (char*)wv.body + xb, (hipStream_t)stream);
@@ -355,13 +360,13 @@ static int forward_impl(const gptq_layer_t* L, const void* x, void* out, int M, 
     if (tune && tune->path == 6)
         return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 6: the streamed GEMV needs M <= 4, a plain 4-bit fp16/bf16 layer (no act-order, no epilogue) "
                                           "and a launch shape with rows-per-lane in {2, 4, 8} dividing the rows of a group");
-    if (want_gemm(L, M, tune)) return gptq_gemm(L, x, out, M, ws, ws_bytes, stream, tune);
-    return gptq_gemv(L, x, out, M, ws, ws_bytes, stream, tune);
+    if (want_gemm(L, M, tune)) return gemm_core(L, x, out, M, wv, stream, tune);
+    return gemv_core(L, x, out, M, wv, stream, tune);
 }
 
 int gptq_forward_ex(const gptq_layer_t* L, const void* x, void* out, int M, void* ws, size_t ws_bytes, void* stream,
                     const gptq_tuning_t* tune) {
-    return forward_impl(L, x, out, M, ws, ws_bytes, stream, tune);
+    return forward_impl(L, x, out, M, split_ws(ws, ws_bytes), stream, tune);
 }
 
 size_t gptq_workspace_bytes_multi(const gptq_layer_t* const* layers, int n_layers, int M) {
@@ -427,7 +432,7 @@ int gptq_forward_multi_ex(const gptq_layer_t* const* layers, int n_layers, const
     }
     if (n_layers <= 4 && M <= 4) {
         const StreamPlan sp = plan_stream(layers, n_layers, M, tune);
-        if (sp.ok && multi_preferred(layers, n_layers, M)) return stream_call(layers, n_layers, sp, x, outs, M, ws, ws_bytes, stream);
+        if (sp.ok && multi_preferred(layers, n_layers, M)) return stream_call(layers, n_layers, sp, x, outs, M, split_ws(ws, ws_bytes), stream);
         if (tune && tune->path == 6) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 6: these layers / this launch shape do not fit the streamed GEMV");
     }
     if (tune && tune->path == 3 && tune->reserved[2] == 4)

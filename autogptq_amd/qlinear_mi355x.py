@@ -154,6 +154,12 @@ class QuantLinear(nn.Module):
         return out
 
     def _invalidate(self):
+        if self._layer is not None and _MULTI:
+            # forward_multi caches ctypes argument arrays keyed by the layer structs they point at: drop every group this
+            # layer was part of (a .to() / reload builds new structs; stale entries would pin the old ones for ever)
+            lid = id(self._layer)
+            for key in [k for k in _MULTI if lid in k]:
+                del _MULTI[key]
         self._layer = None
         self._keepalive = ()
         self._ws_need = {}

@@ -150,6 +150,47 @@ def dequantize(qweight, qzeros, scales: torch.Tensor, g_idx, bits: int, zero_mod
     return s * diff.to(s.dtype)                                   # int -> float is exact
 
 
+def dequantize_torch(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor, g_idx, bits: int, zero_mode: str) -> torch.Tensor:
+    """Same result as dequantize() for 2/4/8-bit layers, computed the way the reference computes it -- ONE broadcast
+    shift + mask over [K/P, P, N] and [G, N/P, P] in multithreaded torch CPU ops (qlinear_cuda_old.py:295-312,
+    qlinear_cuda.py:257-277) instead of one numpy pass per field: what bench.py's cpu_baseline times, so that the port runs
+    at the reference class's own speed.  3-bit layers (their unpack is a three-word splice, :313-344) take dequantize().
+    Pinned bit-identical to dequantize() on every 2/4/8-bit fixture (tests/test_oracle_golden.py)."""
+    if bits == 3:
+        return dequantize(qweight, qzeros, scales, g_idx, bits, zero_mode)
+    P, maxq = 32 // bits, (1 << bits) - 1
+    wf = torch.arange(0, 32, bits, dtype=torch.int32)
+    qw, qz, sc = qweight.cpu(), qzeros.cpu(), scales.cpu()
+    w = torch.bitwise_and(torch.bitwise_right_shift(qw.unsqueeze(1).expand(-1, P, -1), wf.unsqueeze(-1)), maxq)   # [K/P, P, N] (arithmetic shift + mask = the field)
+    K, N = w.shape[0] * P, w.shape[2]
+    w = w.reshape(K, N)
+    z = torch.bitwise_and(torch.bitwise_right_shift(qz.unsqueeze(2).expand(-1, -1, P), wf.unsqueeze(0)), maxq) + 1  # [G, N/P, P]
+    if zero_mode == ZERO_WRAP:
+        z = torch.bitwise_and(z, maxq)
+    elif zero_mode != ZERO_NOWRAP:
+        raise ValueError(f"unknown zero_mode {zero_mode!r}")
+    z = z.reshape(z.shape[0], N)
+    if g_idx is None:
+        G = z.shape[0]
+        gs = -(-K // G)
+        if K == G * gs:                                            # sequential groups: broadcast instead of a gather (qlinear_cuda_old.py:346-349)
+            diff = (w.reshape(G, gs, N) - z.unsqueeze(1)).to(sc.dtype)
+            return (sc.unsqueeze(1) * diff).reshape(K, N)
+        g = torch.from_numpy(default_g_idx(K, gs).astype(np.int64))
+    else:
+        g = torch.as_tensor(np.asarray(g_idx.cpu() if isinstance(g_idx, torch.Tensor) else g_idx), dtype=torch.long)
+    return sc[g] * (w - z[g]).to(sc.dtype)
+
+
+def forward_fast(x: torch.Tensor, qweight, qzeros, scales, g_idx, bias, bits: int, zero_mode: str) -> torch.Tensor:
+    """forward() on dequantize_torch(): identical values, reference-speed unpack."""
+    W = dequantize_torch(qweight, qzeros, scales, g_idx, bits, zero_mode)
+    y = torch.matmul(x.reshape(-1, x.shape[-1]).cpu(), W).to(x.dtype).reshape(x.shape[:-1] + (W.shape[1],))
+    if bias is not None:
+        y = y + bias.cpu()
+    return y
+
+
 def forward(x: torch.Tensor, qweight, qzeros, scales, g_idx, bias, bits: int, zero_mode: str) -> torch.Tensor:
     """out = (x.reshape(-1,K) @ W).to(x.dtype).reshape(...) + bias  (qlinear_cuda_old.py:202-355)."""
     W = dequantize(qweight, qzeros, scales, g_idx, bits, zero_mode)

@@ -72,3 +72,11 @@ def pytest_generate_tests(metafunc):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Run count of the every-output full-size parity checks (tests/test_gpu_baseline_configs.py), for the round's log."""
+    mod = sys.modules.get("test_gpu_baseline_configs") or sys.modules.get("tests.test_gpu_baseline_configs")
+    if mod is not None and getattr(mod, "CHECKED", {}).get("cases"):
+        terminalreporter.write_line("full-size parity: %d (layer, M) cases, %d outputs compared one by one with the fp64 oracle product"
+                                    % (mod.CHECKED["cases"], mod.CHECKED["outputs"]))

@@ -5,14 +5,17 @@ config 4  Llama-2-70B TP=8 shards: column shards 8192->1024, 8192->3584, 28672->
 config 5  int3 / int8 group_size=32 on the Llama-7B shapes, decode (GEMV, M = 1/4/8), batched decode
           (M = 16/64) and prefill (tiled MFMA GEMM, M = 2048), fp16 and bf16, act-order on and off
 
-Every case is checked three ways, all against the oracle / the bit-exact dequantised weights (not against
-another kernel of this library):
-  (a) fp64 oracle (oracle/gptq_oracle.py: the reference's unpack + dequant, accumulated in fp64) on two
-      column slices -- one in the middle, one at the ragged right edge of the layer -- for a row subset;
-  (b) one-hot rows of x return the dequantised weight rows EXACTLY (bit for bit the reference's
-      scales * (weight - zeros), qlinear_cuda_old.py:348 / qlinear_cuda.py:302) through whatever kernel the
-      planner picks for that M;
+Every case is checked four ways, all against the ORACLE (oracle/gptq_oracle.py: the reference's unpack + dequant),
+never against another kernel of this library:
+  (0) the library's full-size dequantize() equals the oracle's dequantised weight bit for bit;
+  (a) EVERY one of the M x N outputs against x (fp64) @ W_oracle (fp64) -- the oracle's weight, multiplied in fp64 on
+      the GPU by torch (plumbing: milliseconds), so every row tile x column tile of every launch geometry is compared;
+  (b) one-hot rows of x -- at least one in every 32-row tile -- return the oracle's dequantised weight rows EXACTLY
+      (bit for bit the reference's scales * (weight - zeros), qlinear_cuda_old.py:348 / qlinear_cuda.py:302) through
+      whatever kernel the planner picks for that M;
   (c) bit reproducibility of a repeated call.
+Tolerance (a): |y - ref| <= atol * max|ref| + rtol * |ref| with (rtol, atol) = (1e-3, 1e-3) fp16, (8e-3, 8e-3) bf16 -- the scale of
+the reference's own atol = 2e-2 on O(7) outputs (tests/test_q4.py:1120,1802), with no sqrt(K) allowance.
 Reference test this mirrors in spirit: tests/test_hpu_linear.py:102-181 (shape x dtype x pattern grid) and
 tests/test_q4.py:1060-1122 (kernel output vs the Python path).
 """
@@ -25,7 +28,8 @@ from oracle import gptq_oracle as O
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
-TOL = {torch.float16: (2e-3, 2e-3), torch.bfloat16: (1.6e-2, 1.6e-2)}      # (rtol, atol relative to the output scale)
+TOL = {torch.float16: (1e-3, 1e-3), torch.bfloat16: (8e-3, 8e-3)}          # (rtol, atol relative to the output scale)
+CHECKED = {"cases": 0, "outputs": 0}                                       # run count, printed at session end (conftest)
 LLAMA7B = [(4096, 4096), (4096, 11008), (11008, 4096)]
 
 _LAYERS = {}
@@ -40,9 +44,14 @@ def _layer(bits, gs, K, N, act, dtype):
         q.qweight, q.qzeros, q.scales, q.g_idx = L["qweight"].clone(), L["qzeros"].clone(), L["scales"].clone(), L["g_idx"].clone()
         q = q.to(DEV)
         q.post_init()
+        mode = O.reference_zero_mode(act, bits)
+        W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], bits, mode)      # the ORACLE's weight, CPU, [K, N] dtype
         with torch.no_grad():
-            W = q.dequantize()                # [K, N] dtype; bit-exact vs the reference (test_gpu_parity.py::test_dequant_*)
-        _LAYERS[key] = (L, q, W)
+            Wlib = q.dequantize()
+        assert torch.equal(Wlib.cpu(), W), f"full-size dequantize() differs from the oracle (bits={bits} {K}x{N} act={act} {dtype})"    # (0)
+        del Wlib
+        Wd = W.to(DEV)
+        _LAYERS[key] = (L, q, Wd, Wd.double())
     return _LAYERS[key]
 
 
@@ -51,15 +60,24 @@ def _slice_cols(L, bits, n0, n1):
     return L["qweight"][:, n0:n1], L["qzeros"][:, z0:z1], L["scales"][:, n0:n1]
 
 
+def _hot_rows(M, K, gs):
+    """(row of x, k) pairs: one one-hot row in every 32-row tile (all of them for M <= 4), k spread over K with the
+    edge cases first (first / last k, a group edge, a 3-bit straddler)."""
+    if M == 1:
+        return []
+    rows = list(range(min(M, 4))) if M <= 32 else [t * 32 + (t * 7) % 32 for t in range(M // 32)]
+    special = [0, K - 1, gs, 10]
+    return [(r, special[i] if i < 4 else (i * 2654435761) % K) for i, r in enumerate(rows)]
+
+
 def _check(bits, gs, K, N, M, act, dtype):
-    L, q, W = _layer(bits, gs, K, N, act, dtype)
+    L, q, W, W64 = _layer(bits, gs, K, N, act, dtype)
     mode = O.reference_zero_mode(act, bits)
     assert q.resolved_zero_mode() == int(mode == O.ZERO_NOWRAP)
     gen = torch.Generator().manual_seed(M * 7 + bits)
     x = (torch.rand(M, K, generator=gen) - 0.5).to(dtype)
-    # (b) one-hot rows: rows 0 .. min(M, 4) - 1 of x select weight rows spread over K (first, last, a group edge, a 3-bit straddler)
-    hot = [0, K - 1, gs, 10][:min(M, 4)] if M > 1 else []
-    for r, k in enumerate(hot):
+    hot = _hot_rows(M, K, gs)
+    for r, k in hot:
         x[r].zero_()
         x[r, k] = 1.0
     xd = x.to(DEV)
@@ -67,20 +85,21 @@ def _check(bits, gs, K, N, M, act, dtype):
         y, yb = q(xd), q(xd)
     assert y.shape == (M, N) and y.dtype == dtype
     assert torch.equal(y, yb), "not bit-reproducible"                       # (c)
-    for r, k in enumerate(hot):
-        assert torch.equal(y[r], W[k]), f"one-hot row {k}: output is not the exact dequantised weight row (M={M})"
-    # (a) fp64 oracle on a row subset x two column slices (middle, ragged right edge)
-    rows = sorted(set([0, 1, M // 2, M - 2, M - 1]) & set(range(M)))
-    mid = (N // 2) // 32 * 32
+    for r, k in hot:                                                        # (b)
+        assert torch.equal(y[r], W[k]), f"one-hot row {r} -> k={k}: output is not the oracle's exact dequantised weight row (M={M})"
+    # (a) every output against the oracle's weight in fp64
+    ref = xd.double() @ W64
     rtol, atol = TOL[dtype]
-    for n0, n1 in ((mid, mid + 256), (N - 96, N)):
-        qw, qz, sc = _slice_cols(L, bits, n0, n1)
-        y64 = O.forward_f64(x[rows], qw, qz, sc, L["g_idx"] if act else None, None, bits, mode)
-        got = y[rows][:, n0:n1].double().cpu()
-        scale = max(1e-6, float(y64.abs().max()))
-        bad = (got - y64).abs() > atol * scale * max(1.0, (K / 1024) ** 0.5) + rtol * y64.abs()
-        assert not bad.any(), (f"bits={bits} g={gs} {K}x{N} M={M} act={act} {dtype} cols[{n0}:{n1}]: {int(bad.sum())}/{bad.numel()} "
-                               f"out of tolerance, max abs diff {float((got - y64).abs().max())} (scale {scale})")
+    scale = max(1e-6, float(ref.abs().max()))
+    diff = (y.double() - ref).abs()
+    bad = diff > atol * scale + rtol * ref.abs()
+    nbad = int(bad.sum())
+    if nbad:
+        idx = torch.nonzero(bad)[0].tolist()
+        raise AssertionError(f"bits={bits} g={gs} {K}x{N} M={M} act={act} {dtype}: {nbad}/{bad.numel()} outputs out of tolerance, first at "
+                             f"[{idx[0]}, {idx[1]}], max abs diff {float(diff.max())} (scale {scale})")
+    CHECKED["cases"] += 1
+    CHECKED["outputs"] += M * N
 
 
 # ------------------------------------------------------------------------------------------ config 5

@@ -707,6 +707,44 @@ def test_fused_gate_up_wide_layer_small_batch(M, act):
     assert bool((err <= 4e-3 * (ref.abs() + 0.05 * scale)).all()), float(err.max())
 
 
+@pytest.mark.parametrize("M_first,M_then", [(16, 4), (8, 3), (32, 5)])
+def test_unfused_epilogue_inner_k_split_uses_the_real_ticket_header(M_first, M_then):
+    """Regression (round-2 advisor finding): a [gate | up] layer whose inner (epilogue-stripped) call splits K inside the launch.
+    The inner call must take its arrival tickets from the workspace's real zeroed header, not from a header carved out of the
+    body behind the staged y -- that region holds whatever an earlier, larger call left there (here: made certain by filling the
+    whole body with 0xFF), so its tickets never reached ksplit - 1, the combine never ran and silu_mul saw stale y."""
+    from autogptq_amd.fused import fuse_gate_up
+    from autogptq_amd.qlinear_mi355x import reserve_workspace
+    K, N = 4096, 4096                                  # [gate | up] = 8192 columns = 128 strips of 64: the planner splits K
+    Lg = O.random_quant_layer(K, N, 4, 128, seed=260, bias=True)
+    Lu = O.random_quant_layer(K, N, 4, 128, seed=261, bias=True)
+    for L in (Lg, Lu):
+        L["scales"] = (L["scales"].float() * 4).half()
+    mg = _module_from(Lg["qweight"], Lg["qzeros"], Lg["scales"], Lg["g_idx"], Lg["bias"], 4, 128)
+    mu = _module_from(Lu["qweight"], Lu["qzeros"], Lu["scales"], Lu["g_idx"], Lu["bias"], 4, 128)
+    fused = fuse_gate_up(mg, mu).to(DEV)
+    q = next(m for m in fused.modules() if isinstance(m, QuantLinear))
+    q.post_init()
+    plans = {M: _lib.describe_plan(q._layer, M) for M in (M_first, M_then)}
+    assert any(int(d.get("ksplit", 1)) > 1 and d.get("epilogue") == "separate" for d in plans.values()), plans
+    mode = O.reference_zero_mode(False, 4)
+    for M in (M_first, M_then, M_first):
+        x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).half()
+        with torch.no_grad():
+            fused(x.to(DEV))                          # sizes the workspace for this M
+            buf = reserve_workspace(torch.device(DEV), 1)
+            torch.cuda.synchronize()
+            buf[65536:].fill_(0xFF)                   # everything behind the ticket header is garbage before the call
+            y = fused(x.to(DEV))
+        g64 = O.forward_f64(x, Lg["qweight"], Lg["qzeros"], Lg["scales"], Lg["g_idx"], Lg["bias"], 4, mode)
+        u64 = O.forward_f64(x, Lu["qweight"], Lu["qzeros"], Lu["scales"], Lu["g_idx"], Lu["bias"], 4, mode)
+        ref = torch.nn.functional.silu(g64) * u64
+        scale = float(ref.abs().max())
+        err = (y.double().cpu() - ref).abs()
+        assert bool((err <= 4e-3 * (ref.abs() + 0.05 * scale)).all()), (M, float(err.max()), plans)
+        assert int(buf[:65536].count_nonzero()) == 0, "the ticket header must be left zero by every launch"
+
+
 # ------------------------------------------------------------------------- callers around the path
 def test_model_level_flow_make_quant_pack_post_init_forward():
     """make_quant -> pack_model (device pack) -> autogptq_post_init -> forward on a toy module: the quantized model tracks the

@@ -68,6 +68,20 @@ def test_dequant_bit_exact(ref_case):
         assert torch.allclose(Wdq.float(), c.Wdq.float(), rtol=2e-3, atol=2e-3)
 
 
+def test_reference_speed_port_is_the_same_function(ref_case):
+    """dequantize_torch / forward_fast (the broadcast shift + mask form bench.py's cpu_baseline times) are bit-identical to
+    the field-by-field restatement on every fixture, with the fixture's g_idx and with the sequential-groups shortcut."""
+    c = ref_case
+    mode = O.reference_zero_mode(c.desc_act_class, c.bits)
+    assert torch.equal(O.dequantize_torch(c.qweight, c.qzeros, c.scales, c.g_idx, c.bits, mode),
+                       O.dequantize(c.qweight, c.qzeros, c.scales, c.g_idx, c.bits, mode))
+    if not c.act_order:
+        assert torch.equal(O.dequantize_torch(c.qweight, c.qzeros, c.scales, None, c.bits, mode),
+                           O.dequantize(c.qweight, c.qzeros, c.scales, None, c.bits, mode))
+    assert torch.equal(O.forward_fast(c.x, c.qweight, c.qzeros, c.scales, c.g_idx, c.bias, c.bits, mode),
+                       O.forward(c.x, c.qweight, c.qzeros, c.scales, c.g_idx, c.bias, c.bits, mode))
+
+
 def test_forward_matches_reference(ref_case):
     c = ref_case
     mode = O.reference_zero_mode(c.desc_act_class, c.bits)
