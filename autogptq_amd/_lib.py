@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPTQ_MI355X_LIB", os.path.join(_HERE, "libgptq_mi355x.so"))
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 GPTQ_F16, GPTQ_BF16, GPTQ_F32 = 0, 1, 2
 ZERO_WRAP, ZERO_NOWRAP = 0, 1
@@ -32,6 +32,7 @@ EXPORTS = (
     "gptq_init", "gptq_workspace_bytes_max", "gptq_validate_g_idx",
     "gptq_forward_multi", "gptq_workspace_bytes_multi", "gptq_forward_multi_ex", "gptq_workspace_bytes_multi_ex",
     "gptq_peer_scatter", "gptq_peer_collect", "gptq_peer_gather",
+    "gptq_mlp_forward", "gptq_mlp_forward_ex", "gptq_workspace_bytes_mlp", "gptq_workspace_bytes_mlp_ex", "gptq_describe_mlp_plan",
 )
 WS_HEADER_BYTES = 65536
 
@@ -118,12 +119,21 @@ def load() -> ctypes.CDLL:
     lib.gptq_describe_plan.argtypes = [POINTER(GptqLayer), c_int, POINTER(GptqTuning), c_char_p, c_size_t]
     lib.gptq_awq_unpack.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.gptq_awq_repack.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    LP = POINTER(GptqLayer)
+    lib.gptq_workspace_bytes_mlp.restype = c_size_t
+    lib.gptq_workspace_bytes_mlp.argtypes = [LP, LP, LP, c_int]
+    lib.gptq_workspace_bytes_mlp_ex.restype = c_size_t
+    lib.gptq_workspace_bytes_mlp_ex.argtypes = [LP, LP, LP, c_int, POINTER(GptqTuning)]
+    lib.gptq_mlp_forward.argtypes = [LP, LP, LP, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]
+    lib.gptq_mlp_forward_ex.argtypes = lib.gptq_mlp_forward.argtypes + [POINTER(GptqTuning)]
+    lib.gptq_describe_mlp_plan.argtypes = [LP, LP, LP, c_int, POINTER(GptqTuning), c_char_p, c_size_t]
     lib.gptq_peer_scatter.argtypes = [POINTER(GptqPeerGroup), c_void_p, c_int, c_int, c_int, c_void_p]
     lib.gptq_peer_collect.argtypes = [POINTER(GptqPeerGroup), c_void_p, c_int, c_int, ctypes.c_uint32, c_void_p]
     lib.gptq_peer_gather.argtypes = [POINTER(GptqPeerGroup), c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_uint32, c_void_p]
     for name in EXPORTS:
         if name not in ("gptq_last_error", "gptq_status_string", "gptq_workspace_bytes", "gptq_workspace_bytes_ex",
-                        "gptq_workspace_bytes_max", "gptq_workspace_bytes_multi", "gptq_workspace_bytes_multi_ex"):
+                        "gptq_workspace_bytes_max", "gptq_workspace_bytes_multi", "gptq_workspace_bytes_multi_ex",
+                        "gptq_workspace_bytes_mlp", "gptq_workspace_bytes_mlp_ex"):
             getattr(lib, name).restype = c_int
     got = lib.gptq_abi_version()
     if got != ABI_VERSION:
@@ -145,7 +155,8 @@ def _bind_fastcall(lib) -> None:
     except ImportError:
         fast = None
         return
-    _fastcall.bind(ctypes.cast(lib.gptq_forward_ex, c_void_p).value, ctypes.cast(lib.gptq_forward_multi_ex, c_void_p).value)
+    _fastcall.bind(ctypes.cast(lib.gptq_forward_ex, c_void_p).value, ctypes.cast(lib.gptq_forward_multi_ex, c_void_p).value,
+                   ctypes.cast(lib.gptq_mlp_forward, c_void_p).value)
     fast = _fastcall
 
 
@@ -162,6 +173,19 @@ def describe_plan(layer: "GptqLayer", M: int, tuning: "GptqTuning | None" = None
     lib = load()
     buf = ctypes.create_string_buffer(512)
     check(lib.gptq_describe_plan(ctypes.byref(layer), M, ctypes.byref(tuning) if tuning is not None else None, buf, len(buf)))
+    out = {}
+    for kv in buf.value.decode().split():
+        k, v = kv.split("=", 1)
+        out[k] = int(v) if v.lstrip("-").isdigit() else v
+    return out
+
+
+def describe_mlp_plan(gate: "GptqLayer", up: "GptqLayer", down: "GptqLayer", M: int, tuning: "GptqTuning | None" = None) -> dict:
+    """What gptq_mlp_forward[_ex] would run for these three layers (host-only query)."""
+    lib = load()
+    buf = ctypes.create_string_buffer(512)
+    check(lib.gptq_describe_mlp_plan(ctypes.byref(gate), ctypes.byref(up), ctypes.byref(down), M,
+                                     ctypes.byref(tuning) if tuning is not None else None, buf, len(buf)))
     out = {}
     for kv in buf.value.decode().split():
         k, v = kv.split("=", 1)

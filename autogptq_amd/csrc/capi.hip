@@ -232,6 +232,7 @@ size_t gptq_workspace_bytes_max(const gptq_layer_t* L, int max_M) {
 int gptq_init(void) {
     hipError_t e = init_gemm_device();
     if (e == hipSuccess) e = init_gemv_device();
+    if (e == hipSuccess) e = init_mlp_device();
     if (e != hipSuccess) return hip_fail(e, "gptq_init (hipFuncSetAttribute)");
     return GPTQ_OK;
 }
@@ -409,8 +410,8 @@ int gptq_forward_multi(const gptq_layer_t* const* layers, int n_layers, const vo
     return gptq_forward_multi_ex(layers, n_layers, x, outs, M, ws, ws_bytes, stream, nullptr);
 }
 
-int gptq_forward_multi_ex(const gptq_layer_t* const* layers, int n_layers, const void* x, void* const* outs, int M, void* ws,
-                          size_t ws_bytes, void* stream, const gptq_tuning_t* tune) {
+static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, const void* x, void* const* outs, int M, const WsView& wv,
+                              void* stream, const gptq_tuning_t* tune) {
     if (!layers || !outs) return fail(GPTQ_ERR_NULL, "layers/outs must be non-NULL");
     if (n_layers <= 0) return fail(GPTQ_ERR_SHAPE, "n_layers must be > 0, got %d", n_layers);
     for (int i = 0; i < n_layers; ++i) {
@@ -423,24 +424,121 @@ int gptq_forward_multi_ex(const gptq_layer_t* const* layers, int n_layers, const
     }
     if (want_stream64_multi(layers, n_layers, M, tune)) {
         const Stream64Plan sp = plan_stream64(layers, n_layers, M, tune);
-        const WsView wv = split_ws(ws, ws_bytes);
         if (sp.partial_bytes > 0 && wv.body_bytes < sp.partial_bytes)
-            return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + sp.partial_bytes, ws ? ws_bytes : (size_t)0);
+            return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + sp.partial_bytes, wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0);
         hipError_t e = launch_stream64(layers, sp, x, outs, M, wv.header, wv.body, nullptr, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "gptq batched-decode launch (needs > 64 KiB of LDS: was gptq_init() called on this device?)");
         return GPTQ_OK;
     }
     if (n_layers <= 4 && M <= 4) {
         const StreamPlan sp = plan_stream(layers, n_layers, M, tune);
-        if (sp.ok && multi_preferred(layers, n_layers, M)) return stream_call(layers, n_layers, sp, x, outs, M, split_ws(ws, ws_bytes), stream);
+        if (sp.ok && multi_preferred(layers, n_layers, M)) return stream_call(layers, n_layers, sp, x, outs, M, wv, stream);
         if (tune && tune->path == 6) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 6: these layers / this launch shape do not fit the streamed GEMV");
     }
     if (tune && tune->path == 3 && tune->reserved[2] == 4)
         return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 3 / reserved[2] = 4: these layers do not fit one batched-decode launch (2..4 plain 4-bit layers, M <= 64)");
     for (int i = 0; i < n_layers; ++i) {           // anything the one-launch kernel does not cover: the same result, layer by layer
-        int rc = gptq_forward_ex(layers[i], x, outs[i], M, ws, ws_bytes, stream, nullptr);
+        int rc = forward_impl(layers[i], x, outs[i], M, wv, stream, nullptr);
         if (rc) return rc;
     }
+    return GPTQ_OK;
+}
+
+int gptq_forward_multi_ex(const gptq_layer_t* const* layers, int n_layers, const void* x, void* const* outs, int M, void* ws,
+                          size_t ws_bytes, void* stream, const gptq_tuning_t* tune) {
+    return forward_multi_core(layers, n_layers, x, outs, M, split_ws(ws, ws_bytes), stream, tune);
+}
+
+// ---- fused gated MLP (mlp.hip) -----------------------------------------------------------------------------------------
+static int check_mlp(const gptq_layer_t* gate, const gptq_layer_t* up, const gptq_layer_t* down) {
+    int rc = check_layer(gate);
+    if (rc) return rc;
+    if ((rc = check_layer(up))) return rc;
+    if ((rc = check_layer(down))) return rc;
+    if (gate->K != up->K || gate->N != up->N)
+        return fail(GPTQ_ERR_SHAPE, "gate (%d -> %d) and up (%d -> %d) must have the same shape", gate->K, gate->N, up->K, up->N);
+    if (down->K != gate->N)
+        return fail(GPTQ_ERR_SHAPE, "down reads the intermediate activation: its in_features (%d) must be gate's out_features (%d)", down->K, gate->N);
+    if (gate->dtype != up->dtype || gate->dtype != down->dtype) return fail(GPTQ_ERR_UNSUPPORTED, "the three layers of an MLP share the dtype of x");
+    if (gate->epilogue != GPTQ_EPI_NONE || up->epilogue != GPTQ_EPI_NONE || down->epilogue != GPTQ_EPI_NONE)
+        return fail(GPTQ_ERR_UNSUPPORTED, "gptq_mlp_forward takes plain layers (the SiLU * mul is its own)");
+    return GPTQ_OK;
+}
+static size_t mlp_stage_bytes(const gptq_layer_t* gate, int M) { return ((size_t)M * gate->N * dtype_size(gate->dtype) + 255) / 256 * 256; }
+
+// The one-launch kernel is OPT-IN (tuning.path = 7): measured on MI355X it is slower than the steps below (tools/mlplab, Llama-7B MLP, M = 1:
+// 27.9 - 31.3 us per call against 22.9 us for gptq_forward_multi(gate, up) + gptq_forward(down) and 26.7 us for the three unfused steps;
+// profiles/r03_mlp_ring_timeline.log) -- kept as the measured experiment it is, not as the default.
+static bool mlp_ring_wanted(const gptq_tuning_t* t) { return t && t->path == 7; }
+
+size_t gptq_workspace_bytes_mlp(const gptq_layer_t* gate, const gptq_layer_t* up, const gptq_layer_t* down, int M) {
+    return gptq_workspace_bytes_mlp_ex(gate, up, down, M, nullptr);
+}
+
+size_t gptq_workspace_bytes_mlp_ex(const gptq_layer_t* gate, const gptq_layer_t* up, const gptq_layer_t* down, int M, const gptq_tuning_t* tune) {
+    if (check_mlp(gate, up, down) != GPTQ_OK || M <= 0) return 0;
+    const MlpPlan mp = mlp_ring_wanted(tune) ? plan_mlp(*gate, *up, *down, M, 0) : MlpPlan{};
+    if (mp.ok) return WS_HEADER_BYTES + mp.exchange_bytes;
+    const gptq_layer_t* gu[2] = {gate, up};
+    size_t inner = gptq_workspace_bytes_multi_ex(gu, 2, M, nullptr);
+    inner = std::max(inner, gptq_workspace_bytes_ex(down, M, nullptr));
+    inner = inner > WS_HEADER_BYTES ? inner - WS_HEADER_BYTES : 0;
+    return WS_HEADER_BYTES + 2 * mlp_stage_bytes(gate, M) + inner;
+}
+
+int gptq_mlp_forward(const gptq_layer_t* gate, const gptq_layer_t* up, const gptq_layer_t* down, const void* x, void* out, int M,
+                     void* ws, size_t ws_bytes, void* stream) {
+    return gptq_mlp_forward_ex(gate, up, down, x, out, M, ws, ws_bytes, stream, nullptr);
+}
+
+int gptq_mlp_forward_ex(const gptq_layer_t* gate, const gptq_layer_t* up, const gptq_layer_t* down, const void* x, void* out, int M,
+                        void* ws, size_t ws_bytes, void* stream, const gptq_tuning_t* tune) {
+    int rc = check_mlp(gate, up, down);
+    if (rc) return rc;
+    if ((rc = check_io(x, out, M))) return rc;
+    const WsView wv = split_ws(ws, ws_bytes);
+    const size_t have = wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0;
+    const MlpPlan mp = mlp_ring_wanted(tune) ? plan_mlp(*gate, *up, *down, M, 0) : MlpPlan{};
+    if (mlp_ring_wanted(tune) && !mp.ok)
+        return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 7: the one-launch MLP kernel needs M = 1, three plain 4-bit fp16/bf16 layers of one group size "
+                                          "(I <= 16384, K <= 8192, at least one 16-byte column chunk per CU) and gptq_init() on this device");
+    if (mp.ok) {
+        if (wv.body_bytes < mp.exchange_bytes)
+            return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + mp.exchange_bytes, have);
+        hipError_t e = launch_mlp(*gate, *up, *down, mp, x, out, wv.header, wv.body, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "gptq_mlp_forward launch (needs > 64 KiB of LDS: was gptq_init() called on this device?)");
+        return GPTQ_OK;
+    }
+    // Every other case (more than one row of x, act-order or non-4-bit layers, shapes the one-launch kernel does not cover): the same
+    // function as three steps -- gate and up through the multi-layer entry point into two staging buffers at the front of the body,
+    // SiLU * mul in place, down -- each inner call on the ONE ticket header and the body behind the staging buffers.
+    const size_t sb = mlp_stage_bytes(gate, M);
+    if (wv.body_bytes < 2 * sb)
+        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", gptq_workspace_bytes_mlp_ex(gate, up, down, M, tune), have);
+    void* hg = wv.body;
+    void* hu = (char*)wv.body + sb;
+    const WsView inner{wv.header, (char*)wv.body + 2 * sb, wv.body_bytes - 2 * sb};
+    const gptq_layer_t* gu[2] = {gate, up};
+    void* outs[2] = {hg, hu};
+    if ((rc = forward_multi_core(gu, 2, x, outs, M, inner, stream, nullptr))) return rc;
+    hipError_t e = launch_silu_mul2(hg, hu, hg, (size_t)M * gate->N, gate->dtype, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "silu_mul launch");
+    return forward_impl(down, hg, out, M, inner, stream, nullptr);
+}
+
+int gptq_describe_mlp_plan(const gptq_layer_t* gate, const gptq_layer_t* up, const gptq_layer_t* down, int M, const gptq_tuning_t* tune, char* out,
+                           size_t out_bytes) {
+    if (!out || out_bytes == 0) return fail(GPTQ_ERR_NULL, "out must be non-NULL");
+    out[0] = 0;
+    int rc = check_mlp(gate, up, down);
+    if (rc) return rc;
+    if (M <= 0) return fail(GPTQ_ERR_SHAPE, "M must be > 0, got %d", M);
+    const MlpPlan mp = mlp_ring_wanted(tune) ? plan_mlp(*gate, *up, *down, M, 0) : MlpPlan{};
+    if (mp.ok)
+        snprintf(out, out_bytes, "kernel=mlp_ring launches=1 workgroups=%d waves=16 ring_slots=%d rows_per_dma=%d/%d lds=%zu exchange=%zu", mp.nwg, mp.ns,
+                 1 << mp.lrpiA, 1 << mp.lrpiB, mp.lds_bytes, mp.exchange_bytes);
+    else
+        snprintf(out, out_bytes, "kernel=unfused launches=3+ steps=forward_multi(gate,up)|silu_mul|forward(down)");
     return GPTQ_OK;
 }
 

@@ -1858,7 +1858,7 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     }
     if (ks > pl.units_total) ks = pl.units_total;
     int ups = (pl.units_total + ks - 1) / ks;
-    if ((size_t)strips * 4 > WS_HEADER_BYTES) return pl;
+    if ((size_t)strips * 4 > WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES) return pl;
     // (waves, U): the smallest capacity that holds a slice in ONE pass -- everything in flight from the first cycle;
     // U rows of a lane lie in one group (U <= rows per group)
     const int ucap = gu < 8 ? gu : 8;

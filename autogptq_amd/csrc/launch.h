@@ -45,6 +45,7 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
 
 // Streamed GEMV (gemv_q4_stream_kernel): 1..4 plain 4-bit layers that read the same x, one launch.
 constexpr size_t WS_HEADER_BYTES = 65536;      // front of every workspace: arrival tickets of the in-launch K-split combine (kept zero)
+constexpr size_t WS_HEADER_TAIL_BYTES = 64;    // ... except its last 64 bytes: launch epoch / arrival count / sticky error word of the fused MLP exchange (mlp.hip)
 struct StreamPlan {
     bool ok;                 // every layer qualifies and the geometry fits
     int nseg, ln, waves, u, mt, ksplit, units_total, units_per_split, strips_total, nsum;
@@ -68,6 +69,22 @@ hipError_t launch_stream64(const gptq_layer_t* const* layers, const Stream64Plan
                            void* ws_header, void* partial, const uint32_t* qweight_override, hipStream_t st);
 bool stream_preferred(const gptq_layer_t& L, int M);                              // single layer: streamed kernel instead of the register one?
 bool multi_preferred(const gptq_layer_t* const* layers, int n, int M);             // several layers sharing x: one streamed launch?
+// Fused gated MLP (mlp.hip): gate | up -> SiLU * mul -> down in ONE persistent launch, one row of x.
+struct MlpPlan {
+    bool ok;                 // the three layers qualify (plain 4-bit fp16/bf16, shared group size, M = 1) and the geometry fits one workgroup per CU
+    int ns, nwg, gshift;     // ring slots per wave, workgroups (= CUs of the device), log2(packed rows per group)
+    int qA, rA, qB, rB;      // column chunks per workgroup: q (+ 1 for the first r workgroups), gate/up and down
+    int lrpiA, lrpiB;        // log2(packed rows per DMA instruction) in the gate/up and the down panels
+    int lspA, lszA, lspB, lszB;   // log2 of the padded LDS table rows (scales, zero-point words)
+    int off_x, off_cst, off_red, off_ctr;
+    size_t lds_bytes;
+    size_t exchange_bytes;   // behind the header: the activation granules [I / 2] x 8 bytes
+};
+MlpPlan plan_mlp(const gptq_layer_t& gate, const gptq_layer_t& up, const gptq_layer_t& down, int M, int nwg_override);
+hipError_t launch_mlp(const gptq_layer_t& gate, const gptq_layer_t& up, const gptq_layer_t& down, const MlpPlan& pl, const void* x, void* out,
+                      void* ws_header, void* exchange, hipStream_t st);
+hipError_t launch_silu_mul2(const void* g, const void* u, void* out, size_t total, int dtype, hipStream_t st);
+hipError_t init_mlp_device();
 hipError_t init_gemv_device();
 hipError_t init_gemm_device();
 

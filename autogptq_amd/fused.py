@@ -120,6 +120,9 @@ class FusedGateUpMLP(nn.Module):
     def forward(self, x):
         if self.gate_up is not None:
             return self.down_proj(self.gate_up(x))
+        if isinstance(self.down_proj, QuantLinear):               # three mi355x layers: one C-ABI call (gptq_mlp_forward)
+            from .qlinear_mi355x import mlp_forward
+            return mlp_forward(self.gate_proj, self.up_proj, self.down_proj, x)
         from .qlinear_mi355x import forward_multi
         g, u = forward_multi([self.gate_proj, self.up_proj], x)
         return self.down_proj(torch.nn.functional.silu(g) * u)

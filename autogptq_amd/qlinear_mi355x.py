@@ -520,4 +520,79 @@ def forward_multi(layers, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = No
 _MULTI: dict = {}
 
 
-__all__ = ["QuantLinear", "reserve_workspace", "forward_multi"]
+def mlp_forward(gate: QuantLinear, up: QuantLinear, down: QuantLinear, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = None):
+    """``down(silu(gate(x)) * up(x))`` for three mi355x QuantLinears through ONE C-ABI call (gptq_mlp_forward): the role of the
+    reference's FusedLlamaMLPForQuantizedModel.forward (auto_gptq/nn_modules/fused_llama_mlp.py:157-242).  gate and up run as one
+    multi-layer launch for decode rows, the SiLU * mul on fp32, then down -- any bits / act-order / row count the single layers take,
+    checkpoint tensors untouched, one Python -> C transition instead of three.  ``tuning.path = 7`` selects the experimental
+    one-launch persistent kernel (M = 1, plain 4-bit layers; measured slower than the default)."""
+    for l in (gate, up, down):
+        if l._layer is None:
+            l.post_init()
+    dev = gate._dev
+    if x.device != dev:
+        raise RuntimeError(f"mi355x mlp_forward: input is on {x.device}, the layers on {dev}")
+    K = gate.infeatures
+    if x.shape[-1] != K or up.infeatures != K or up.outfeatures != gate.outfeatures or down.infeatures != gate.outfeatures:
+        raise RuntimeError("mlp_forward: gate / up must be [K -> I] on the input's K features and down [I -> N]")
+    w_dtype = gate._w_dtype
+    if up._w_dtype != w_dtype or down._w_dtype != w_dtype:
+        raise RuntimeError("mlp_forward: the three layers must share the weight dtype")
+    x_dtype = x.dtype
+    x2 = x.to(w_dtype) if x_dtype != w_dtype else x
+    if x2.dim() != 2:
+        x2 = x2.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    out = torch.empty((M, down.outfeatures), dtype=w_dtype, device=dev)
+    if M:
+        lib = _lib.load()
+        key = (id(gate._layer), id(up._layer), id(down._layer), "mlp")
+        need_by_m = _MULTI.get(key)
+        if need_by_m is None:
+            need_by_m = _MULTI[key] = {}
+        tref = ctypes.byref(tuning) if tuning is not None else None
+        need = need_by_m.get(M) if tuning is None else None
+        if need is None:
+            need = int(lib.gptq_workspace_bytes_mlp_ex(gate._layer_ref, up._layer_ref, down._layer_ref, M, tref))
+            if tuning is None:
+                need_by_m[M] = need
+        buf = reserve_workspace(dev, max(need, 1))
+        idx = gate._dev_index
+        fast = _lib.fast
+
+        def launch():
+            if fast is not None and tuning is None and hasattr(fast, "mlp_forward"):
+                return fast.mlp_forward(gate._layer_addr, up._layer_addr, down._layer_addr, x2.data_ptr(), out.data_ptr(), M,
+                                        buf.data_ptr(), buf.numel(), _raw_stream(idx))
+            return lib.gptq_mlp_forward_ex(gate._layer_ref, up._layer_ref, down._layer_ref, x2.data_ptr(), out.data_ptr(), M,
+                                           buf.data_ptr(), buf.numel(), _raw_stream(idx), tref)
+        if idx != torch.cuda.current_device():
+            with torch.cuda.device(idx):
+                rc = launch()
+        else:
+            rc = launch()
+        if rc:
+            _lib.check(rc)
+    if x_dtype != w_dtype:
+        out = out.to(x_dtype)
+    if x.dim() != 2:
+        out = out.reshape(x.shape[:-1] + (out.shape[-1],))
+    return out
+
+
+def mlp_exchange_error(device=None) -> bool:
+    """True if a bounded wait of the one-launch MLP kernel (tuning.path = 7) ever gave up on this device's current-stream workspace:
+    the sticky error word in the workspace header's tail (gptq_mi355x.h).  Synchronises the stream."""
+    device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ent = _WORKSPACE.get((idx, int(torch.cuda.current_stream(device).cuda_stream)))
+    if ent is None:
+        return False
+    torch.cuda.synchronize(device)
+    tail = ent[0][_lib.WS_HEADER_BYTES - 64:_lib.WS_HEADER_BYTES].view(torch.int32)
+    return bool(tail[2].item() != 0)
+
+
+__all__ = ["QuantLinear", "reserve_workspace", "forward_multi", "mlp_forward", "mlp_exchange_error"]

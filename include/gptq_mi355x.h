@@ -39,13 +39,17 @@
  *   - nothing allocates or frees device memory; scratch is caller-provided and sized by
  *     gptq_workspace_bytes().  The first GPTQ_WORKSPACE_HEADER_BYTES of a workspace hold the arrival
  *     tickets of the in-launch K-split combine: they must be ZERO when the buffer is first handed to
- *     the library (one hipMemset at allocation) and the library leaves them zero after every launch.
+ *     the library (one hipMemset at allocation) and the library leaves them zero after every launch --
+ *     except the header's last 64 bytes, which carry the launch epoch / arrival count / sticky error word
+ *     of the fused MLP's activation exchange from one launch to the next (gptq_mlp_forward).
  *     One workspace serves one stream at a time (launches that may overlap need their own).  Kernels are enqueued on the caller's stream, never synchronise,
  *     and are legal inside hipGraph capture: the forward entry points make no runtime-API call
  *     besides the kernel launches.  No global mutable state in the library; the one per-device
  *     setting it needs (kernels with > 64 KiB of dynamic LDS) is applied by gptq_init(), which the
  *     caller runs once per device, outside any capture, before the first forward.
- *   - results are run-to-run deterministic (no floating-point atomics).
+ *   - results are run-to-run deterministic (no floating-point atomics, fixed summation orders).  The one exception is the opt-in
+ *     experimental kernel of gptq_mlp_forward_ex (tuning.path = 7): its waves draw their work from a counter, so the fp32 summation
+ *     order may differ between launches (last-bit differences).
  */
 #ifndef GPTQ_MI355X_H
 #define GPTQ_MI355X_H
@@ -57,7 +61,7 @@
 extern "C" {
 #endif
 
-#define GPTQ_MI355X_ABI_VERSION 4
+#define GPTQ_MI355X_ABI_VERSION 5
 #define GPTQ_WORKSPACE_HEADER_BYTES 65536
 
 typedef enum gptq_status_t {
@@ -108,7 +112,7 @@ typedef struct gptq_tuning_t {
     int32_t lanes_n;     /* lanes of a wave laid along N (4,8,16,64); 4 columns per lane */
     int32_t waves;       /* waves per workgroup (1..16) */
     int32_t ksplit;      /* workgroups along K (1 = no cross-workgroup reduction) */
-    int32_t path;        /* 0 auto, 1 generic GEMV, 2 LDS-staged q4/fp16 GEMV, 3 MFMA GEMM, 4 direct q4/fp16 GEMV, 5 matrix-core GEMV (4-bit fp16 / bf16 kernel, or the 2/3/8-bit one), 6 streamed (LDS-DMA) q4 GEMV */
+    int32_t path;        /* 0 auto, 1 generic GEMV, 2 LDS-staged q4/fp16 GEMV, 3 MFMA GEMM, 4 direct q4/fp16 GEMV, 5 matrix-core GEMV (4-bit fp16 / bf16 kernel, or the 2/3/8-bit one), 6 streamed (LDS-DMA) q4 GEMV, 7 (gptq_mlp_forward_ex only) the one-launch persistent MLP kernel */
     int32_t reserved[4]; /* [0]: max packed rows per lane and iteration for the register-direct GEMVs, = rows per lane for the streamed one, = K-steps per burst for the batched-decode kernel (0 = heuristic); [1]: 32 = force the 32-deep K-step in the MFMA GEMM, 1 = field-by-field decode in the 3- / 8-bit fp16 matrix-core GEMV instead of the packed magic-number one (A/B runs); [2]: 1 = force the 64-column skinny GEMM, 2 = force the tiled GEMM, 3 = force the 16-column-strip GEMM (4-bit, M <= 64), 4 = force the streamed 64-column-strip batched-decode GEMM (4-bit, M <= 64; waves / ksplit apply); [3]: tiled-GEMM inner-loop schedule variant */
 } gptq_tuning_t;
 
@@ -151,6 +155,26 @@ int gptq_forward_multi(const gptq_layer_t *const *layers, int n_layers, const vo
 size_t gptq_workspace_bytes_multi_ex(const gptq_layer_t *const *layers, int n_layers, int M, const gptq_tuning_t *tuning);
 int gptq_forward_multi_ex(const gptq_layer_t *const *layers, int n_layers, const void *x, void *const *outs, int M,
                           void *workspace, size_t workspace_bytes, void *stream, const gptq_tuning_t *tuning);
+
+/* The gated MLP of a decoder block, out[M, N] = down( silu(gate(x)) * up(x) ), as ONE call: replaces the reference's fused MLP caller
+ * (auto_gptq/nn_modules/fused_llama_mlp.py:157-242: FusedLlamaMLPForQuantizedModel.forward = one fused gate|up kernel with the SiLU * mul
+ * inside + c_proj).  gate and up are [K -> I], down is [I -> N]; plain layers (epilogue NONE), checkpoint tensors untouched; any bits / dtype /
+ * act-order the single-layer entry points take.  Default: gate and up through gptq_forward_multi (one launch for decode rows) into two staging
+ * buffers in the workspace, SiLU * mul (silu and the product on fp32, rounded once to the layer dtype, as fused_llama_mlp.py:237-239), down.
+ * tuning.path = 7 (gptq_mlp_forward_ex; EXPERIMENTAL, measured slower than the default on MI355X -- kept opt-in): M = 1 with three plain 4-bit
+ * fp16/bf16 layers of one group size (I <= 16384, K <= 8192) as ONE persistent launch -- one workgroup per CU streams its share of gate and up
+ * through an LDS ring that runs on into its rows of `down` while the activation is exchanged through the workspace as self-validating 8-byte
+ * granules (no grid barrier, every wait bounded: if a wait ever gives up, word [2] of the header's last 64 bytes is set and stays set).  It needs
+ * every workgroup resident at once: gptq_init() records the device's CU count and nothing else may pin whole CUs for the duration of the call. */
+size_t gptq_workspace_bytes_mlp(const gptq_layer_t *gate, const gptq_layer_t *up, const gptq_layer_t *down, int M);
+size_t gptq_workspace_bytes_mlp_ex(const gptq_layer_t *gate, const gptq_layer_t *up, const gptq_layer_t *down, int M, const gptq_tuning_t *tuning);
+int gptq_mlp_forward(const gptq_layer_t *gate, const gptq_layer_t *up, const gptq_layer_t *down, const void *x, void *out, int M,
+                     void *workspace, size_t workspace_bytes, void *stream);
+int gptq_mlp_forward_ex(const gptq_layer_t *gate, const gptq_layer_t *up, const gptq_layer_t *down, const void *x, void *out, int M,
+                        void *workspace, size_t workspace_bytes, void *stream, const gptq_tuning_t *tuning);
+/* Host-only: "kernel=mlp_ring launches=1 workgroups=256 ..." or "kernel=unfused ..." for (gate, up, down, M, tuning); as gptq_describe_plan. */
+int gptq_describe_mlp_plan(const gptq_layer_t *gate, const gptq_layer_t *up, const gptq_layer_t *down, int M, const gptq_tuning_t *tuning, char *out,
+                           size_t out_bytes);
 
 /* Same, with an explicit launch shape / path (tuning may be NULL). */
 int gptq_forward_ex(const gptq_layer_t *layer, const void *x, void *out, int M,
