@@ -85,6 +85,11 @@ hipError_t launch_mlp(const gptq_layer_t& gate, const gptq_layer_t& up, const gp
                       void* ws_header, void* exchange, hipStream_t st);
 hipError_t launch_silu_mul2(const void* g, const void* u, void* out, size_t total, int dtype, hipStream_t st);
 hipError_t init_mlp_device();
+// gemm_ldsb.hip: prefill kernel with the dequantised weights shared through LDS (4-bit fp16/bf16, 256 x 128 tiles)
+bool ldsb_supported(const gptq_layer_t& L, int M);
+hipError_t init_gemm_ldsb_device();
+hipError_t launch_gemm_ldsb(const gptq_layer_t& L, const uint32_t* qweight, const void* x, void* out, int M, hipStream_t st, int bk = 0, int kgroups = 0,
+                            int abl = 0);
 hipError_t init_gemv_device();
 hipError_t init_gemm_device();
 

@@ -7,8 +7,11 @@ to map a peer's allocation -- the exchange itself is the two launches of ``csrc/
 
 The reference has nothing to mirror here: it runs a layer on one GPU (tests/test_q4.py:1224-1226 ``test_multigpu`` is a
 TODO).  What was exercised: ranks sharing ONE device (in-process groups and 2 processes through IPC, tests/).  Across
-GPUs the flags and buffers have to be fine-grained allocations, which the caching allocator does not hand out: pass them
-in through ``buffers=`` in that case.
+GPUs the flags and buffers have to be FINE-GRAINED allocations for the system-scope fences of csrc/peer.hip to order
+anything; the caching allocator only hands out coarse-grained memory, so by default the buffers come from
+``hipExtMallocWithFlags(hipDeviceMallocFinegrained)`` (``FineGrainedBuffer``: ctypes on libamdhip64, wrapped as tensors
+through ``__cuda_array_interface__``, shared between processes with ``hipIpcGetMemHandle`` / ``hipIpcOpenMemHandle``).
+A group that spans several devices refuses coarse-grained buffers unless ``allow_coarse=True`` says otherwise.
 """
 from __future__ import annotations
 
@@ -23,8 +26,105 @@ from . import _lib
 DEFAULT_MAX_SPINS = 1 << 22          # bounded wait: ~seconds of polling, then state[3] is raised instead of hanging the queue
 
 
+_HIP = None
+
+
+def _hip():
+    """libamdhip64 through ctypes (the runtime torch itself is linked against: same device context, same streams)."""
+    global _HIP
+    if _HIP is None:
+        for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+            try:
+                _HIP = ctypes.CDLL(name)
+                break
+            except OSError:
+                continue
+        if _HIP is None:
+            raise OSError("libamdhip64.so not found")
+        _HIP.hipExtMallocWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+        _HIP.hipFree.argtypes = [ctypes.c_void_p]
+        _HIP.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+        _HIP.hipIpcGetMemHandle.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        _HIP.hipIpcOpenMemHandle.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_char * 64, ctypes.c_uint]
+        _HIP.hipIpcCloseMemHandle.argtypes = [ctypes.c_void_p]
+    return _HIP
+
+
+_TYPESTR = {torch.float16: "<f2", torch.bfloat16: "<u2", torch.float32: "<f4", torch.int32: "<i4", torch.uint8: "|u1"}
+
+
+class _RawDeviceArray:
+    """Just enough of __cuda_array_interface__ for torch.as_tensor to alias a raw device pointer (no copy, no ownership)."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class FineGrainedBuffer:
+    """One fine-grained device allocation (hipExtMallocWithFlags, hipDeviceMallocFinegrained = 0x1) or the mapping of a peer's:
+    coherent at system scope, which is what stores + flags crossing xGMI need.  Owns the pointer; ``tensor()`` aliases it."""
+
+    FINEGRAINED = 0x1
+
+    def __init__(self, nbytes: int = 0, device=None, ipc_handle: bytes = None):
+        hip = _hip()
+        self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+        self.nbytes = int(nbytes)
+        self._ptr = ctypes.c_void_p()
+        self._mapped = ipc_handle is not None
+        with torch.cuda.device(self.device):
+            if self._mapped:
+                h = (ctypes.c_char * 64).from_buffer_copy(ipc_handle)
+                rc = hip.hipIpcOpenMemHandle(ctypes.byref(self._ptr), h, 1)      # hipIpcMemLazyEnablePeerAccess
+                if rc != 0:
+                    raise RuntimeError(f"hipIpcOpenMemHandle failed ({rc})")
+            else:
+                rc = hip.hipExtMallocWithFlags(ctypes.byref(self._ptr), max(self.nbytes, 256), self.FINEGRAINED)
+                if rc != 0:
+                    raise RuntimeError(f"hipExtMallocWithFlags(finegrained) failed ({rc})")
+                hip.hipMemset(self._ptr, 0, max(self.nbytes, 256))
+                torch.cuda.synchronize(self.device)
+
+    @property
+    def ptr(self) -> int:
+        return int(self._ptr.value)
+
+    def tensor(self, shape, dtype: torch.dtype) -> torch.Tensor:
+        if dtype == torch.bfloat16:                                              # no typestr for bf16: alias as u16 bits and view
+            t = torch.as_tensor(_RawDeviceArray(self.ptr, shape, "<i2"), device=self.device)
+            t = t.view(torch.bfloat16)
+        else:
+            t = torch.as_tensor(_RawDeviceArray(self.ptr, shape, _TYPESTR[dtype]), device=self.device)
+        t._gptq_owner = self                                                     # the allocation lives as long as a tensor on it does
+        return t
+
+    def ipc_handle(self) -> bytes:
+        h = (ctypes.c_char * 64)()
+        with torch.cuda.device(self.device):
+            rc = _hip().hipIpcGetMemHandle(h, self._ptr)
+        if rc != 0:
+            raise RuntimeError(f"hipIpcGetMemHandle failed ({rc})")
+        return bytes(h.raw)
+
+    def __del__(self):
+        try:
+            if self._ptr.value:
+                if self._mapped:
+                    _hip().hipIpcCloseMemHandle(self._ptr)
+                else:
+                    _hip().hipFree(self._ptr)
+                self._ptr = ctypes.c_void_p()
+        except Exception:            # interpreter shutdown
+            pass
+
+
 class PeerTimeout(RuntimeError):
     """A collect gave up waiting for a peer's slice (``state[3]`` raised by the kernel)."""
+
+
+def _host_id() -> str:
+    import socket
+    return socket.gethostname()
 
 
 def _share(t: torch.Tensor):
@@ -52,7 +152,8 @@ class PeerExchange:
     """Symmetric exchange buffers of one process group for gathers of up to ``rows_max`` rows of ``N`` columns."""
 
     def __init__(self, rows_max: int, N: int, dtype: torch.dtype, device, group: Optional[dist.ProcessGroup] = None,
-                 buffers: Optional[dict] = None, max_spins: int = DEFAULT_MAX_SPINS):
+                 buffers: Optional[dict] = None, max_spins: int = DEFAULT_MAX_SPINS, fine_grained: Optional[bool] = None,
+                 allow_coarse: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -60,18 +161,64 @@ class PeerExchange:
             raise ValueError(f"peer-store exchange supports up to {_lib.PEER_MAX} ranks, got {self.world}")
         self.rows_max, self.N, self.dtype, self.device = rows_max, N, dtype, torch.device(device)
         self.max_spins = max_spins
+        # which physical devices does the group span?  (system-scope fences only order fine-grained memory across GPUs)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        me = (_host_id(), idx)
+        if self.world > 1:
+            everyone_dev: List = [None] * self.world
+            dist.all_gather_object(everyone_dev, me, group=group)
+            self.multi_device = len(set(everyone_dev)) > 1
+        else:
+            self.multi_device = False
+        self.fine_grained = False
+        fg = None
+        if buffers is None and fine_grained is not False:
+            try:
+                esz = torch.empty(0, dtype=dtype).element_size()
+                fg = dict(xbuf0=FineGrainedBuffer(rows_max * N * esz, self.device), xbuf1=FineGrainedBuffer(rows_max * N * esz, self.device),
+                          flags=FineGrainedBuffer(_lib.PEER_MAX * 4, self.device))
+                buffers = dict(xbuf0=fg["xbuf0"].tensor((rows_max, N), dtype), xbuf1=fg["xbuf1"].tensor((rows_max, N), dtype),
+                               flags=fg["flags"].tensor((_lib.PEER_MAX,), torch.int32))
+                self.fine_grained = True
+            except Exception as e:                       # no libamdhip64 / allocation refused: coarse-grained memory, one device only
+                if fine_grained:
+                    raise
+                fg = None
+                self._fg_error = repr(e)
         if buffers is None:
             buffers = dict(xbuf0=torch.empty((rows_max, N), dtype=dtype, device=device),
                            xbuf1=torch.empty((rows_max, N), dtype=dtype, device=device),
                            flags=torch.zeros(_lib.PEER_MAX, dtype=torch.int32, device=device))
+        elif not self.fine_grained:
+            self.fine_grained = bool(buffers.get("fine_grained", False))      # caller-provided buffers may say what they are
+            buffers = {k: v for k, v in buffers.items() if k != "fine_grained"}
+        if self.multi_device and not self.fine_grained and not allow_coarse:
+            raise RuntimeError("PeerExchange: the group spans several GPUs but the exchange buffers are coarse-grained (caching-allocator) memory: "
+                               "the system-scope fences of the exchange do not order it.  Let PeerExchange allocate (fine_grained=True), pass "
+                               "fine-grained buffers, or allow_coarse=True to try anyway." + (f"  ({getattr(self, '_fg_error', '')})" if fg is None else ""))
         self.state = torch.zeros(4, dtype=torch.int32, device=device)
         self._own = buffers
+        self._fg = fg
         torch.cuda.synchronize(self.device)
         if self.world == 1:
             mapped = [buffers]
+        elif fg is not None:
+            mine = {k: v.ipc_handle() for k, v in fg.items()}
+            everyone: List = [None] * self.world
+            dist.all_gather_object(everyone, mine, group=group)
+            esz = torch.empty(0, dtype=dtype).element_size()
+            mapped, self._peer_fg = [], []
+            for r in range(self.world):
+                if r == self.rank:
+                    mapped.append(buffers)
+                    continue
+                pf = {k: FineGrainedBuffer(device=self.device, ipc_handle=h) for k, h in everyone[r].items()}
+                self._peer_fg.append(pf)
+                mapped.append(dict(xbuf0=pf["xbuf0"].tensor((rows_max, N), dtype), xbuf1=pf["xbuf1"].tensor((rows_max, N), dtype),
+                                   flags=pf["flags"].tensor((_lib.PEER_MAX,), torch.int32)))
         else:
             mine = {k: _share(v) for k, v in buffers.items()}
-            everyone: List = [None] * self.world
+            everyone = [None] * self.world
             dist.all_gather_object(everyone, mine, group=group)
             mapped = [buffers if r == self.rank else {k: _map(a, self.device) for k, a in everyone[r].items()}
                       for r in range(self.world)]
@@ -110,4 +257,4 @@ def make_group(xbuf0: Sequence[torch.Tensor], xbuf1: Sequence[torch.Tensor], fla
     return pg
 
 
-__all__ = ["PeerExchange", "PeerTimeout", "make_group", "DEFAULT_MAX_SPINS"]
+__all__ = ["PeerExchange", "PeerTimeout", "FineGrainedBuffer", "make_group", "DEFAULT_MAX_SPINS"]

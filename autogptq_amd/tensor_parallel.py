@@ -51,7 +51,7 @@ class ColumnParallelQuantLinear(nn.Module):
 
     def __init__(self, local: Callable[[torch.Tensor], torch.Tensor], outfeatures: int,
                  group: Optional[dist.ProcessGroup] = None, gather_output: bool = True,
-                 exchange: str = "all_gather", max_rows: int = 1):
+                 exchange: str = "all_gather", max_rows: int = 1, check_timeout_every: int = 256):
         super().__init__()
         if exchange not in ("all_gather", "peer_store"):
             raise ValueError(f"exchange must be 'all_gather' or 'peer_store', got {exchange!r}")
@@ -62,11 +62,13 @@ class ColumnParallelQuantLinear(nn.Module):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.exchange = exchange
         self.max_rows = max_rows
+        self.check_timeout_every = check_timeout_every
+        self._calls = 0
         self._px = None                     # PeerExchange, built on the first forward (needs the output dtype / device)
 
     @classmethod
     def from_full(cls, full, rank: int, world: int, group=None, device=None, gather_output=True,
-                  exchange: str = "all_gather", max_rows: int = 1):
+                  exchange: str = "all_gather", max_rows: int = 1, check_timeout_every: int = 256):
         """Build the rank's shard from a full (unsharded) mi355x QuantLinear."""
         from .qlinear_mi355x import QuantLinear
 
@@ -81,7 +83,8 @@ class ColumnParallelQuantLinear(nn.Module):
             local.bias = b
         if device is not None:
             local = local.to(device)
-        return cls(local, full.outfeatures, group=group, gather_output=gather_output, exchange=exchange, max_rows=max_rows)
+        return cls(local, full.outfeatures, group=group, gather_output=gather_output, exchange=exchange, max_rows=max_rows,
+                   check_timeout_every=check_timeout_every)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y = self.local(x)                                   # [..., N/T]
@@ -94,10 +97,17 @@ class ColumnParallelQuantLinear(nn.Module):
             if not y2.is_cuda:
                 raise RuntimeError("exchange='peer_store' moves device buffers; the shard output is on the CPU")
             if self._px is None or self._px.rows_max < M:
-                # collective: every rank reaches this with the same M (the buffers are symmetric)
+                # collective: every rank reaches this with the same M (the buffers are symmetric).  PeerExchange allocates fine-grained
+                # buffers itself and refuses a multi-GPU group on coarse-grained memory.
                 from .peer_exchange import PeerExchange
                 self._px = PeerExchange(max(M, self.max_rows), self.world * nl, y2.dtype, y2.device, group=self.group)
-            return self._px.gather(y2).reshape(lead + (self.world * nl,))
+            out = self._px.gather(y2).reshape(lead + (self.world * nl,))
+            # a collect that gave up on a peer leaves a partially stale row and raises state[3]: look at it every `check_timeout_every`
+            # calls (a device -> host read: a sync point, hence not on every token by default; 1 = every call, 0 = never)
+            self._calls += 1
+            if self.check_timeout_every and self._calls % self.check_timeout_every == 0:
+                self._px.check_timeout()
+            return out
         if y2.is_cuda and _host_staged(self.group):
             hb = torch.empty((self.world * M, nl), dtype=y2.dtype)
             dist.all_gather_into_tensor(hb, y2.cpu(), group=self.group)
@@ -138,6 +148,7 @@ class RowParallelQuantLinear(nn.Module):
         self.group = group
         self.input_is_parallel = input_is_parallel
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.fp32_reduce_max_elems = 64 * 16384             # outputs up to 64 rows x 16 K columns take the fp32 reduction
 
     @classmethod
     def from_full(cls, full, rank: int, world: int, group=None, device=None, input_is_parallel=True):
@@ -161,8 +172,12 @@ class RowParallelQuantLinear(nn.Module):
         if not self.input_is_parallel:
             x = x[..., self.k0:self.k1].contiguous()
         y = self.local(x)
-        if self.world > 1:
-            y = y.float()                                   # partial sums are reduced in fp32, rounded once
+        if self.world > 1 and y.numel() > self.fp32_reduce_max_elems and not (y.is_cuda and _host_staged(self.group)):
+            # prefill-sized outputs: reduce in the layer dtype (what Megatron's row-parallel linear does) -- ONE pass over [M, N] instead
+            # of cast-up, fp32 all-reduce (twice the bytes on xGMI) and cast-down; the T partial sums are each rounded once more
+            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+        elif self.world > 1:
+            y = y.float()                                   # decode-sized outputs: partial sums are reduced in fp32, rounded once
             if y.is_cuda and _host_staged(self.group):
                 h = y.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)

@@ -173,6 +173,30 @@ def test_peer_collect_gives_up_instead_of_hanging():
     assert torch.equal(out[:, :nl], y)                          # own slice is there, the peer's is whatever the buffer held
 
 
+@pytest.mark.gpu
+def test_fine_grained_buffer_is_plain_device_memory_for_torch():
+    """hipExtMallocWithFlags(finegrained) memory wrapped as a tensor: zeroed, writable by torch kernels, visible through a second alias of
+    the same pointer, and PeerExchange uses it by default (one rank: nothing to map)."""
+    from autogptq_amd.peer_exchange import FineGrainedBuffer, PeerExchange
+    dev = torch.device("cuda:0")
+    fb = FineGrainedBuffer(4096 * 2, dev)
+    t = fb.tensor((4, 1024), torch.float16)
+    assert t.device == dev and int(t.count_nonzero()) == 0
+    t.copy_(torch.arange(4096, dtype=torch.float32, device=dev).reshape(4, 1024).half())
+    u = fb.tensor((4096,), torch.float16)
+    torch.cuda.synchronize()
+    assert float(u[1025]) == 1025.0 and u.data_ptr() == fb.ptr
+    b = fb.tensor((2048,), torch.bfloat16)
+    assert b.dtype == torch.bfloat16 and b.data_ptr() == fb.ptr
+    assert len(fb.ipc_handle()) == 64
+    px = PeerExchange(4, 256, torch.float16, dev)
+    assert px.fine_grained and not px.multi_device
+    y = torch.ones(2, 256, dtype=torch.float16, device=dev)
+    out = px.gather(y)
+    px.check_timeout()
+    assert torch.equal(out, y)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -203,7 +227,7 @@ def _ipc_worker(rank, world, port, M, q):
                 y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], None, None, 4, O.ZERO_WRAP)
                 errs.append(float((y.double().cpu() - y64).abs().max() / y64.abs().max()))
         dist.barrier()                                              # nobody unmaps while a peer may still store
-        q.put((rank, tuple(y.shape) == (M, N) and max(errs) < 3e-3, errs))
+        q.put((rank, tuple(y.shape) == (M, N) and max(errs) < 3e-3 and cp._px.fine_grained, errs + [("fine_grained", cp._px.fine_grained)]))
     finally:
         dist.destroy_process_group()
 
