@@ -1051,13 +1051,17 @@ struct S64Params {
     int nseg, M, K, group_size, zero_mode, ksplit, ksteps_per_split, nsum;
 };
 
-template <typename T, int RT, int U>
+// PIPE (2+ row tiles, M > 16): two landing areas and two register sets per wave -- pass i + 1 (its x fragments, group constants and U KiB of
+// weights) is requested BEFORE pass i is computed on.  Without it a wave of the M = 33..64 form alternates "request" and "compute 2 K-steps x
+// 16 MFMAs" with nothing in flight while it computes: 8 passes x ~2 us on 4096 x 11008 (the round-2 diagnosis).
+template <typename T, int RT, int U, bool PIPE = false>
 __global__ void __launch_bounds__(RT == 1 ? 1024 : 512) gemm_stream64_kernel(S64Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, W = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j16 = lane & 15, kg = lane >> 4;
-    char* const wq = smem + (size_t)wave * (U * 1024);                        // this wave's DMA landing area
+    constexpr int STAGES = PIPE ? 2 : 1;
+    char* const wq = smem + (size_t)wave * (STAGES * U * 1024);               // this wave's DMA landing area(s)
     const unsigned wq_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(wq));
     // logical block -> (strip over all layers, K slice): slices of one strip are adjacent logical ids (one XCD after the remap)
     const int Lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -1101,6 +1105,105 @@ __global__ void __launch_bounds__(RT == 1 ? 1024 : 512) gemm_stream64_kernel(S64
     Deq1<T> dq[4];
     int g_cur = -1;
 
+    if constexpr (PIPE) {
+        struct Pass { u32x2 sraw[U]; unsigned zw[U]; u32x4 a[U][RT]; int gj[U]; };
+        auto issue = [&](int s0, int stage, Pass& P) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {                         // small L2-resident loads first: they return first
+                const int sj = min(s0 + j, we - 1);
+                P.gj[j] = (int)((unsigned)sj / gsteps);
+                P.sraw[j] = *(const u32x2*)(scales + (size_t)P.gj[j] * N);
+                P.zw[j] = zsrc[(size_t)P.gj[j] * zrow_words];
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int sj = min(s0 + j, we - 1);
+#pragma unroll
+#if defined(GPTQ_S64_ABL) && (GPTQ_S64_ABL & 1)
+                for (int rt = 0; rt < RT; ++rt) P.a[j][rt] = u32x4{0x3c003c00u + (unsigned)sj, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u + (unsigned)rt};
+#else
+                for (int rt = 0; rt < RT; ++rt) P.a[j][rt] = *(const u32x4*)(a_src[rt] + (size_t)sj * 32);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int sj = min(s0 + j, we - 1);
+                lds_dma16_nt(qsrc + (size_t)sj * 4 * N, wq_lds + (stage * U + j) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto consume = [&](int s0, int stage, const Pass& P) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const u32x4 qv = *(const u32x4*)(wq + (stage * U + j) * 1024 + lane * 16);
+                if (P.gj[j] != g_cur) {                           // wave-uniform: the step index depends on the wave id only
+                    g_cur = P.gj[j];
+                    const unsigned zz = P.zw[j] >> z_sh;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const unsigned sw = P.sraw[j][t >> 1];
+                        dq[t].setup((t & 1) ? (sw >> 16) : (sw & 0xffffu), (((zz >> (4 * t)) & 15u) + 1u) & zmask);
+                    }
+                }
+                const bool live = s0 + j < we;
+                u32x4 b[4];
+#pragma unroll
+#if defined(GPTQ_S64_ABL) && (GPTQ_S64_ABL & 4)
+                for (int t = 0; t < 4; ++t) b[t] = u32x4{qv[t], qv[t] ^ 0x11111111u, qv[t] ^ 0x22222222u, qv[t] ^ 0x44444444u};
+#else
+                for (int t = 0; t < 4; ++t) b[t] = dq[t].frag(qv[t]);
+#endif
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    u32x4 x4;
+#if defined(GPTQ_S64_ABL) && (GPTQ_S64_ABL & 2)
+                    x4 = P.a[j][rt];
+                    u32x4 o = x4;
+#else
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x4[c] = (unsigned)__builtin_amdgcn_ds_bpermute(a_from, (int)P.a[j][rt][c]);
+                    u32x4 o;                                      // x in the slot order of the fragments: k0,k4,k1,k5,k2,k6,k3,k7
+                    o[0] = __builtin_amdgcn_perm(x4[2], x4[0], 0x05040100u);
+                    o[1] = __builtin_amdgcn_perm(x4[2], x4[0], 0x07060302u);
+                    o[2] = __builtin_amdgcn_perm(x4[3], x4[1], 0x05040100u);
+                    o[3] = __builtin_amdgcn_perm(x4[3], x4[1], 0x07060302u);
+#endif
+                    if (!live) o = u32x4{0u, 0u, 0u, 0u};
+#if defined(GPTQ_S64_ABL) && (GPTQ_S64_ABL & 8)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[rt][t][0] += as_f32((o[t] ^ b[t][t]) & 0x3fffffffu);
+#else
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[rt][t] = Mma16<T>::run(o, b[t], acc[rt][t]);
+#endif
+                }
+            }
+        };
+        // the newer pass leaves 2 U + U RT loads and U DMAs outstanding behind the pass that is about to be computed on
+        constexpr int NEWER = 3 * U + U * RT;
+        Pass P0, P1;
+        if (ws < we) issue(ws, 0, P0);
+        for (int s0 = ws; s0 < we; s0 += 2 * U) {
+            if (s0 + U < we) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // WAR: the reads of stage 1 two passes ago are done
+                issue(s0 + U, 1, P1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            consume(s0, 0, P0);
+            if (s0 + U >= we) break;
+            if (s0 + 2 * U < we) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                issue(s0 + 2 * U, 0, P0);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            consume(s0 + U, 1, P1);
+        }
+    } else {
     for (int s0 = ws; s0 < we; s0 += U) {
         u32x2 sraw[U];
         unsigned zw[U];
@@ -1164,6 +1267,8 @@ __global__ void __launch_bounds__(RT == 1 ? 1024 : 512) gemm_stream64_kernel(S64
              }()),
              ...);
         }(std::make_integer_sequence<int, U>{});
+    }
+
     }
 
     // ---- cross-wave sum (LDS slabs over the landing area, fixed order), then write or publish ---------------------------
@@ -1419,7 +1524,7 @@ static hipError_t grant_lds() {
 
 // Per-device, once, outside any capture (gptq_init): kernels whose dynamic LDS exceeds the 64 KiB default.
 template <typename T, int RT, int U> static hipError_t grant_stream64() {
-    return hipFuncSetAttribute((const void*)gemm_stream64_kernel<T, RT, U>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return hipFuncSetAttribute((const void*)gemm_stream64_kernel<T, RT, U, (RT > 1)>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 template <typename T> static hipError_t grant_stream64_t() {
     hipError_t e = hipSuccess;
@@ -1494,12 +1599,12 @@ Stream64Plan plan_stream64(const gptq_layer_t* const* Ls, int n, int M, const gp
     if (pl.mt > 1 && waves > 8) waves = 8;
     if (waves > 16) waves = 16;
     pl.waves = waves;
-    int u = (tune && tune->reserved[0] > 0) ? tune->reserved[0] : 2;                  // deeper bursts measured no faster: the strips are not latency bound
+    int u = (tune && tune->reserved[0] > 0) ? tune->reserved[0] : (pl.mt == 4 ? 1 : 2);   // 4 row tiles: two pipelined passes of ONE K-step each (U = 2 spills 44 registers)
     if (pl.mt == 1) u = u >= 8 ? 8 : (u >= 4 ? 4 : 2);
     else if (pl.mt == 2) u = u >= 4 ? 4 : 2;
     else u = u >= 4 ? 4 : (u >= 2 ? 2 : 1);
     pl.u = u;
-    const size_t land = (size_t)waves * u * 1024, slabs = (size_t)waves * pl.mt * 4096;
+    const size_t land = (size_t)waves * u * 1024 * (pl.mt > 1 ? 2 : 1), slabs = (size_t)waves * pl.mt * 4096;     // 2+ row tiles: pipelined passes, two landing areas
     pl.lds_bytes = (land > slabs ? land : slabs) + 16;
     if (pl.lds_bytes > 160 * 1024) return pl;
     pl.partial_bytes = pl.ksplit > 1 ? (size_t)pl.ksplit * M * nsum * sizeof(float) : 0;
@@ -1512,7 +1617,7 @@ Stream64Plan plan_stream64(const gptq_layer_t* const* Ls, int n, int M, const gp
 template <typename T, int RT, int U>
 static hipError_t launch_stream64_one(const Stream64Plan& pl, const S64Params& p, hipStream_t st) {
     // > 64 KiB of LDS for most shapes: granted by init_gemm_device() (gptq_init)
-    hipLaunchKernelGGL((gemm_stream64_kernel<T, RT, U>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+    hipLaunchKernelGGL((gemm_stream64_kernel<T, RT, U, (RT > 1)>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
     return hipGetLastError();
 }
 

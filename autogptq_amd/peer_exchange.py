@@ -29,6 +29,10 @@ DEFAULT_MAX_SPINS = 1 << 22          # bounded wait: ~seconds of polling, then s
 _HIP = None
 
 
+class _IpcHandle(ctypes.Structure):          # hipIpcMemHandle_t: 64 opaque bytes, passed BY VALUE to hipIpcOpenMemHandle
+    _fields_ = [("reserved", ctypes.c_char * 64)]
+
+
 def _hip():
     """libamdhip64 through ctypes (the runtime torch itself is linked against: same device context, same streams)."""
     global _HIP
@@ -44,8 +48,8 @@ def _hip():
         _HIP.hipExtMallocWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
         _HIP.hipFree.argtypes = [ctypes.c_void_p]
         _HIP.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
-        _HIP.hipIpcGetMemHandle.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-        _HIP.hipIpcOpenMemHandle.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_char * 64, ctypes.c_uint]
+        _HIP.hipIpcGetMemHandle.argtypes = [ctypes.POINTER(_IpcHandle), ctypes.c_void_p]
+        _HIP.hipIpcOpenMemHandle.argtypes = [ctypes.POINTER(ctypes.c_void_p), _IpcHandle, ctypes.c_uint]
         _HIP.hipIpcCloseMemHandle.argtypes = [ctypes.c_void_p]
     return _HIP
 
@@ -74,7 +78,7 @@ class FineGrainedBuffer:
         self._mapped = ipc_handle is not None
         with torch.cuda.device(self.device):
             if self._mapped:
-                h = (ctypes.c_char * 64).from_buffer_copy(ipc_handle)
+                h = _IpcHandle.from_buffer_copy(ipc_handle)
                 rc = hip.hipIpcOpenMemHandle(ctypes.byref(self._ptr), h, 1)      # hipIpcMemLazyEnablePeerAccess
                 if rc != 0:
                     raise RuntimeError(f"hipIpcOpenMemHandle failed ({rc})")
@@ -99,12 +103,12 @@ class FineGrainedBuffer:
         return t
 
     def ipc_handle(self) -> bytes:
-        h = (ctypes.c_char * 64)()
+        h = _IpcHandle()
         with torch.cuda.device(self.device):
-            rc = _hip().hipIpcGetMemHandle(h, self._ptr)
+            rc = _hip().hipIpcGetMemHandle(ctypes.byref(h), self._ptr)
         if rc != 0:
             raise RuntimeError(f"hipIpcGetMemHandle failed ({rc})")
-        return bytes(h.raw)
+        return bytes(ctypes.string_at(ctypes.addressof(h), 64))
 
     def __del__(self):
         try:

@@ -363,7 +363,10 @@ def cpu_baseline(M, act_order, budget_s=20.0):
     distinct Llama-7B layer shapes, a few repetitions each."""
     from oracle import gptq_oracle as O
 
-    threads = torch.get_num_threads()
+    # the reference class was timed on 8 threads in the build container (BASELINE.md section 5); 128 threads make these small tensor ops
+    # slower, not faster (measured here: 4096 x 4096 77 ms on 128 threads against ~35 ms on 8-16)
+    threads = min(16, torch.get_num_threads())
+    torch.set_num_threads(threads)
     total_b, total_t, reps_done = 0, 0.0, []
     per_shape = budget_s / 3
     for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
