@@ -1576,7 +1576,7 @@ Stream64Plan plan_stream64(const gptq_layer_t* const* Ls, int n, int M, const gp
         nsum += L.N;
         nmax = L.N > nmax ? L.N : nmax;
     }
-    if ((size_t)strips * 4 > WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES) return pl;                              // one ticket per strip
+    if ((size_t)strips * 4 > WS_HEADER_EPOCH_OFFSET) return pl;                              // one ticket per strip
     pl.nseg = n;
     pl.strips_total = strips;
     pl.nsum = nsum;

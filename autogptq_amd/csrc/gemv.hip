@@ -860,9 +860,11 @@ struct GemvSeg {
 struct GemvStreamParams {
     GemvSeg seg[4];
     const void* x;
-    float* partial;      // [ksplit][M][nsum]
-    unsigned* tickets;   // [strips_total]
+    unsigned long long* gran;   // [ksplit - 1][M][nsum] exchange granules {fp32 partial sum, tag} of K slices 1 .. ksplit - 1
+    unsigned* epochs;           // [strips_total] per-strip launch epoch (header bytes 32768 ..): bumped by the strip's owner slice, never reset
+    unsigned* err;              // sticky error word (header tail): a bounded wait gave up
     int nseg, M, K, zero_mode, units_total, units_per_split, ksplit, gu_shift, nsum;
+    unsigned max_spins;
 };
 
 template <int LN, int MT, int U, typename T, int WPS>
@@ -1021,18 +1023,50 @@ __global__ void __launch_bounds__(1024, WPS) gemv_q4_stream_kernel(GemvStreamPar
         }
     }
     __syncthreads();
-    unsigned* const flag = (unsigned*)(red + W * ES);                         // one word behind the slabs (same LDS array)
+    // K split: slice ks >= 1 PUBLISHES its partial sums as 8-byte {fp32, tag} granules (one write-through store each) and is done; slice 0,
+    // the strip's OWNER, polls the granules of the other slices for its entries, takes each the moment its tag is this launch's, adds them in
+    // slice order (fixed order: bit-reproducible) and writes the result -- ONE memory hop after the last slice has published, where the
+    // ticket scheme this replaces (publish, drain, draw a ticket, last arriver reads everything back) was three (~3 us).
+    // tag = the strip's epoch word + 1 in a NaN pattern; the owner bumps the word when all its waves are through (by then every producer
+    // wave has read it), so the next launch on this workspace -- any layer -- uses a tag that no stale granule carries.
+    unsigned tag = 0;
+    if (p.ksplit > 1) {
+        unsigned ep;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ep) : "s"(p.epochs + sidx) : "memory");
+        tag = 0x7FE00000u | ((ep + 1u) & 0x1FFFFFu);
+    }
     const size_t slab = (size_t)p.M * p.nsum;
+    bool gave_up = false;
     auto emit = [&](int e, float t) {
         const int m = e / CT, c = e % CT;
         const int n = strip * CT + c;
         if (n >= N || m >= p.M) return;
         if (p.ksplit > 1) {
-            __hip_atomic_store(p.partial + (size_t)ks * slab + (size_t)m * p.nsum + sg.col0 + n, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
-        } else {
-            if (sg.bias) t += DType<T>::to_f32(((const T*)sg.bias)[n]);
-            ((T*)sg.out)[(size_t)m * N + n] = DType<T>::from_f32(t);
+            const size_t at = (size_t)m * p.nsum + sg.col0 + n;
+            if (ks != 0) {
+                const unsigned long long g8 = (unsigned long long)as_u32(t) | ((unsigned long long)tag << 32);
+                __hip_atomic_store(p.gran + (size_t)(ks - 1) * slab + at, g8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            constexpr int KMAX = 8;                                           // planner: ksplit <= 8
+            unsigned long long v[KMAX - 1];
+            unsigned pending = (1u << (p.ksplit - 1)) - 1u;
+            for (unsigned spins = 0; pending; ++spins) {
+#pragma unroll
+                for (int k = 0; k < KMAX - 1; ++k)
+                    if (pending & (1u << k)) v[k] = __hip_atomic_load(p.gran + (size_t)k * slab + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int k = 0; k < KMAX - 1; ++k)
+                    if ((pending & (1u << k)) && (unsigned)(v[k] >> 32) == tag) pending &= ~(1u << k);
+                if (pending && spins > p.max_spins) { gave_up = true; break; }
+                if (pending) __builtin_amdgcn_s_sleep(2);
+            }
+#pragma unroll
+            for (int k = 0; k < KMAX - 1; ++k)
+                if (k < p.ksplit - 1) t += as_f32((unsigned)(v[k] & 0xffffffffu));
         }
+        if (sg.bias) t += DType<T>::to_f32(((const T*)sg.bias)[n]);
+        ((T*)sg.out)[(size_t)m * N + n] = DType<T>::from_f32(t);
     };
     if ((W & (W - 1)) == 0) {
         // every wave takes 64 / W entries per round; its lanes are (entry, partial w) pairs: one LDS read each, then a fixed
@@ -1052,23 +1086,10 @@ __global__ void __launch_bounds__(1024, WPS) gemv_q4_stream_kernel(GemvStreamPar
             emit(e, t);
         }
     }
-    if (p.ksplit > 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // every publishing wave drains its stores
-        __syncthreads();
-        if (tid == 0) *flag = __hip_atomic_fetch_add(p.tickets + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (*flag != (unsigned)(p.ksplit - 1)) return;                        // not the last slice of this strip
-        for (int e = tid; e < E; e += blockDim.x) {
-            const int m = e / CT, c = e % CT;
-            const int n = strip * CT + c;
-            if (n >= N || m >= p.M) continue;
-            float t = 0.f;
-            for (int k = 0; k < p.ksplit; ++k)                                // fixed order, sc1 loads (bypass this XCD's non-coherent L2 lines)
-                t += __hip_atomic_load(p.partial + (size_t)k * slab + (size_t)m * p.nsum + sg.col0 + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (sg.bias) t += DType<T>::to_f32(((const T*)sg.bias)[n]);
-            ((T*)sg.out)[(size_t)m * N + n] = DType<T>::from_f32(t);
-        }
-        if (tid == 0) __hip_atomic_store(p.tickets + sidx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    if (p.ksplit > 1 && ks == 0) {
+        if (gave_up) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                                      // every wave of the owner has its granules: every producer wave has read the epoch
+        if (tid == 0) __hip_atomic_store(p.epochs + sidx, (tag & 0x1FFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1858,7 +1879,7 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     }
     if (ks > pl.units_total) ks = pl.units_total;
     int ups = (pl.units_total + ks - 1) / ks;
-    if ((size_t)strips * 4 > WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES) return pl;
+    if ((size_t)strips * 4 > WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES - WS_HEADER_EPOCH_OFFSET) return pl;   // one epoch word per strip
     // (waves, U): the smallest capacity that holds a slice in ONE pass -- everything in flight from the first cycle;
     // U rows of a lane lie in one group (U <= rows per group)
     const int ucap = gu < 8 ? gu : 8;
@@ -1875,8 +1896,11 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
                 waves = c[0]; u = c[1];
                 if (c[0] * wr * c[1] >= ups) break;
             }
-        } else {                   // narrower strips: small workgroups (8 waves x 2 rows), several per CU, a few passes each
+        } else {                   // narrower strips: small workgroups, several per CU, a few passes each
             waves = 8; u = 2;
+            // 32-column strips of a multi-layer launch (gate|up: 688 workgroups): 4 waves x 4 rows -- the same 16 KiB per workgroup, half the
+            // waves to start and to join per workgroup (round-3 sweep, profiles/r03_stream_sweep_one_hop_combine.log: 13.48 against 14.07 us)
+            if (ln == 8 && n >= 2 && ucap >= 4 && pl.units_total % 4 == 0) { waves = 4; u = 4; }
             while (waves > 1 && (waves / 2) * wr * u >= ups) waves /= 2;
         }
     }
@@ -1888,7 +1912,8 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     pl.u = u;
     pl.lds_bytes = (size_t)waves * u * 1024 + (size_t)waves * (pl.mt * ct + 4) * sizeof(float) + 16;
     if (pl.lds_bytes > 160 * 1024) return pl;
-    pl.partial_bytes = pl.ksplit > 1 ? (size_t)pl.ksplit * M * nsum * sizeof(float) : 0;
+    if (pl.ksplit > 8) return pl;                          // the owner's poll is unrolled over at most 7 other slices
+    pl.partial_bytes = pl.ksplit > 1 ? (size_t)(pl.ksplit - 1) * M * nsum * 8 : 0;      // {fp32, tag} granules of slices 1 ..
     pl.ok = true;
     return pl;
 }
@@ -1945,8 +1970,10 @@ hipError_t launch_stream(const gptq_layer_t* const* Ls, const StreamPlan& pl, co
     }
     const gptq_layer_t& A = *Ls[0];
     p.x = x;
-    p.partial = (float*)ws_body;
-    p.tickets = (unsigned*)ws_header;
+    p.gran = (unsigned long long*)ws_body;
+    p.epochs = (unsigned*)((char*)ws_header + WS_HEADER_EPOCH_OFFSET);
+    p.err = (unsigned*)((char*)ws_header + WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES) + 2;
+    p.max_spins = 1u << 20;
     p.nseg = pl.nseg; p.M = M; p.K = A.K; p.zero_mode = A.zero_mode;
     p.units_total = pl.units_total; p.units_per_split = pl.units_per_split; p.ksplit = pl.ksplit;
     p.gu_shift = __builtin_ctz((unsigned)(A.group_size / 8));

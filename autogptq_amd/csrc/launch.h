@@ -45,6 +45,7 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
 
 // Streamed GEMV (gemv_q4_stream_kernel): 1..4 plain 4-bit layers that read the same x, one launch.
 constexpr size_t WS_HEADER_BYTES = 65536;      // front of every workspace: arrival tickets of the in-launch K-split combine (kept zero)
+constexpr size_t WS_HEADER_EPOCH_OFFSET = 32768; // second half of the header: per-strip launch epochs of the streamed GEMV's one-hop K-split combine (monotonic, never reset)
 constexpr size_t WS_HEADER_TAIL_BYTES = 64;    // ... except its last 64 bytes: launch epoch / arrival count / sticky error word of the fused MLP exchange (mlp.hip)
 struct StreamPlan {
     bool ok;                 // every layer qualifies and the geometry fits

@@ -32,7 +32,7 @@
 
 namespace gptq {
 
-namespace {
+namespace mlpk {      // named (not anonymous) so that rocprof traces show gptq::mlpk::mlp_ring_kernel instead of gptq::_GLOBAL__N_1
 
 constexpr int MLP_W = 16;          // waves per workgroup (1024 threads: one workgroup per CU)
 constexpr int MLP_CWMAX = 16;      // column chunks (of 4 columns) per workgroup and panel: a DMA instruction covers 64 / cw rows
@@ -498,7 +498,8 @@ int g_cu_count[64] = {0};          // per device ordinal, filled by init_mlp_dev
 
 constexpr int mlp_ns_options[] = {8, 7, 6, 4};
 
-}  // namespace
+}  // namespace mlpk
+using namespace mlpk;
 
 hipError_t launch_silu_mul2(const void* g, const void* u, void* out, size_t total, int dtype, hipStream_t st) {
     int blocks = (int)((total + 255) / 256);

@@ -148,6 +148,48 @@ def bench_fused(device, n_blocks, steps):
             "note": "same weights volume as the headline run, 4 launches per block: [q|k|v], o, [gate|up]+SiLU*mul epilogue, down"}
 
 
+def bench_mlp_call(flat_layers, xs, device, steps):
+    """The gated MLP of every block through gptq_mlp_forward (ONE C-ABI call per block: gate|up launch, SiLU*mul, down) and through its
+    opt-in one-launch persistent kernel (tuning.path = 7), each as a hipGraph over all blocks (rotating, HBM-cold weights).  The activation
+    really flows from gate/up into down here (the headline stack feeds down an independent x)."""
+    from autogptq_amd import _lib
+    from autogptq_amd.qlinear_mi355x import mlp_forward, mlp_exchange_error
+    blocks, i = [], 0
+    while i + 2 < len(flat_layers):
+        if flat_layers[i][0] == "gate_proj" and flat_layers[i + 1][0] == "up_proj" and flat_layers[i + 2][0] == "down_proj":
+            blocks.append((flat_layers[i][3], flat_layers[i + 1][3], flat_layers[i + 2][3]))
+            i += 3
+        else:
+            i += 1
+    x = xs[4096]
+    res = {"blocks": len(blocks)}
+    wbytes = sum(algorithmic_bytes(4096, 11008, 1) * 2 + algorithmic_bytes(11008, 4096, 1) for _ in blocks[:1])
+    for name, tun in (("default_three_steps", None), ("one_launch_ring_kernel_path7", "ring")):
+        try:
+            t = None
+            if tun:
+                t = _lib.GptqTuning()
+                t.path = 7
+            with torch.no_grad():
+                for g_, u_, d_ in blocks:
+                    mlp_forward(g_, u_, d_, x, tuning=t)
+            torch.cuda.synchronize(device)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr), torch.no_grad():
+                keep = [mlp_forward(g_, u_, d_, x, tuning=t) for g_, u_, d_ in blocks]
+            for _ in range(3):
+                gr.replay()
+            _, ev = time_graph(gr, max(3, steps // 2), device)
+            per = ev / (max(3, steps // 2) * len(blocks))
+            res[name] = {"us_per_mlp": round(per * 1e6, 2), "GB_per_s": round(wbytes / per / 1e9, 1), "frac": round(wbytes / per / 1e9 / HBM_PEAK_GBS, 4)}
+            if tun:
+                res[name]["bounded_wait_gave_up"] = bool(mlp_exchange_error(device))
+            del gr, keep
+        except Exception as e:
+            res[name] = {"error": repr(e)[:200]}
+    return res
+
+
 def capture(layers, xs, device):
     """Capture one forward of every layer into a graph; returns (graph, keepalive outputs)."""
     from autogptq_amd.qlinear_mi355x import reserve_workspace
@@ -636,6 +678,11 @@ def main():
                     out["eager_per_layer"] = bench_eager(flat_layers, xs, device, max(3, args.steps // 4))
             except Exception as e:
                 out["eager"] = {"error": repr(e)[:300]}
+        if not prefill and world == 1 and not args.no_extras:
+            try:
+                out["mlp_call"] = bench_mlp_call(flat_layers, xs, device, args.steps)
+            except Exception as e:
+                out["mlp_call"] = {"error": repr(e)[:300]}
         if not prefill and world == 1 and not args.no_fused:
             try:
                 del g, outs, layers, flat_layers
@@ -674,6 +721,11 @@ def main():
                 for k, v in bd.items():
                     if isinstance(v, dict) and "frac" in v:
                         byc["batched_decode:" + k] = {"frac": v["frac"], "us": v["us"], "bound": "hbm"}
+            mc = out.get("mlp_call")
+            if isinstance(mc, dict):
+                for k, v in mc.items():
+                    if isinstance(v, dict) and "frac" in v:
+                        byc["mlp_call:" + k] = {"frac": v["frac"], "us": v["us_per_mlp"], "bound": "hbm"}
             if byc:
                 roof["by_config"] = byc
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (bounded sample, ~25 s of host time)

@@ -39,9 +39,11 @@
  *   - nothing allocates or frees device memory; scratch is caller-provided and sized by
  *     gptq_workspace_bytes().  The first GPTQ_WORKSPACE_HEADER_BYTES of a workspace hold the arrival
  *     tickets of the in-launch K-split combine: they must be ZERO when the buffer is first handed to
- *     the library (one hipMemset at allocation) and the library leaves them zero after every launch --
- *     except the header's last 64 bytes, which carry the launch epoch / arrival count / sticky error word
- *     of the fused MLP's activation exchange from one launch to the next (gptq_mlp_forward).
+ *     the library (one hipMemset at allocation).  Its first half (32 KiB: arrival tickets) is left zero by
+ *     every launch; its second half carries state from one launch to the next and is NOT zero afterwards: one
+ *     launch-epoch word per column strip for the streamed GEMV's K-split combine (partial sums travel as
+ *     {value, tag} granules through the body and are validated by their tag), and in the last 64 bytes the
+ *     launch epoch / arrival count / sticky error word ([2]: a bounded wait gave up) of the exchanges.
  *     One workspace serves one stream at a time (launches that may overlap need their own).  Kernels are enqueued on the caller's stream, never synchronise,
  *     and are legal inside hipGraph capture: the forward entry points make no runtime-API call
  *     besides the kernel launches.  No global mutable state in the library; the one per-device

@@ -743,7 +743,7 @@ def test_unfused_epilogue_inner_k_split_uses_the_real_ticket_header(M_first, M_t
         err = (y.double().cpu() - ref).abs()
         # (y = [gate | up] is staged in fp16 on this path: a large negative gate value amplifies its rounding ~ |g| x through silu)
         assert bool((err <= 8e-3 * (ref.abs() + 0.05 * scale)).all()), (M, float(err.max()), scale, plans)
-        assert int(buf[:65536 - 64].count_nonzero()) == 0, "the ticket header must be left zero by every launch"
+        assert int(buf[:32768].count_nonzero()) == 0, "the ticket half of the header must be left zero by every launch"
 
 
 def _mlp_layers(K, I, N, bits, gs, dtype, act, seed):
