@@ -53,7 +53,7 @@ def main():
         ent["K"] = ent["N"] = ent["M"] = None
         if "gemv_q4_stream_kernel" in name:
             # streamed GEMV: (workgroups, threads) -> launch; multi-layer launches are labelled with the summed width
-            geo = {(192, 1024): (4096, 12288), (688, 512): (4096, 22016), (172, 1024): (4096, 11008)}
+            geo = {(192, 1024): (4096, 12288), (688, 512): (4096, 22016), (688, 256): (4096, 22016), (172, 1024): (4096, 11008)}
             if (blocks, wg) in geo:
                 ent["K"], ent["N"] = geo[(blocks, wg)]
                 ent["M"] = args.m
