@@ -92,10 +92,15 @@ class _QKVPart(nn.Module):
         from .qlinear_mi355x import forward_multi
         st = self._state[0]
         if self.index == 0:
-            st.src = x
+            st.src = (x.data_ptr(), tuple(x.shape), x.dtype, x._version)
             st.parts = forward_multi(st.layers, x)
-        elif st.src is not x:
-            raise RuntimeError("fused q/k/v: k_proj / v_proj called on a different tensor than q_proj")
+            return st.parts[0]
+        # k_proj / v_proj: the same activation as q_proj saw?  Compared by storage, shape, dtype and version counter, not by object identity:
+        # wrappers that re-wrap or move the input per call (accelerate's AlignDevicesHook, autocast) hand every projection its own tensor object.
+        same = st.parts is not None and st.src == (x.data_ptr(), tuple(x.shape), x.dtype, x._version)
+        if not same:                                # a different input (or q_proj was never called): this projection on its own
+            st.src = st.parts = None
+            return self.proj(x)
         out = st.parts[self.index]
         if self.index == 2:
             st.src = st.parts = None                # do not keep activations alive between calls
@@ -103,18 +108,22 @@ class _QKVPart(nn.Module):
 
 
 class FusedGateUpMLP(nn.Module):
-    """down(silu(gate(x)) * up(x)) as two launches (the role of FusedLlamaMLPForQuantizedModel, auto_gptq/nn_modules/
-    fused_llama_mlp.py:131-306): the [gate | up] layer with the SiLU*mul epilogue when gate and up share g_idx, else
-    gate and up through ``forward_multi`` and an elementwise SiLU*mul."""
+    """down(silu(gate(x)) * up(x)) (the role of FusedLlamaMLPForQuantizedModel, auto_gptq/nn_modules/fused_llama_mlp.py:131-306).
+    Three mi355x QuantLinears: ONE C-ABI call (gptq_mlp_forward: gate and up in one launch for decode rows, SiLU*mul on fp32, down) over the
+    three checkpoint layers as they are -- no concatenated copy of the packed tensors (the reference builds one), so nothing is held twice and
+    per-projection act-order is allowed.  A non-quantized down projection: the [gate | up] layer with the SiLU*mul epilogue when gate and up
+    share g_idx, else gate and up through ``forward_multi`` and an elementwise SiLU*mul."""
 
     def __init__(self, gate: QuantLinear, up: QuantLinear, down: nn.Module):
         super().__init__()
-        try:
-            self.gate_up = fuse_gate_up(gate, up).to(gate.qweight.device)
-            self.gate_proj = self.up_proj = None
-        except ValueError:                          # per-projection act-order
-            self.gate_up = None
-            self.gate_proj, self.up_proj = gate, up
+        self.gate_up = None
+        self.gate_proj, self.up_proj = gate, up
+        if not isinstance(down, QuantLinear):
+            try:
+                self.gate_up = fuse_gate_up(gate, up).to(gate.qweight.device)
+                self.gate_proj = self.up_proj = None
+            except ValueError:                      # per-projection act-order
+                pass
         self.down_proj = down
 
     def forward(self, x):
@@ -145,8 +154,13 @@ def inject_fused_llama(model: nn.Module, fuse_attention: bool = True, fuse_mlp: 
             if gate.infeatures == up.infeatures and gate.outfeatures == up.outfeatures and gate.bits == up.bits:
                 fm = FusedGateUpMLP(gate, up, mod.down_proj)
                 mod.forward = fm.forward
-                mod.fused_mlp = fm
-                del mod.gate_proj, mod.up_proj
+                if fm.gate_up is None:
+                    # the fused caller only REFERENCES the three projections: it is kept out of the module tree (object.__setattr__), they stay
+                    # registered once under their checkpoint names, and state_dict() of a fused model round-trips with the checkpoint layout
+                    object.__setattr__(mod, "fused_mlp", fm)
+                else:                               # non-quantized down: the concatenated [gate | up] copy replaces the two originals
+                    mod.fused_mlp = fm
+                    del mod.gate_proj, mod.up_proj
                 n += 1
     return n
 
