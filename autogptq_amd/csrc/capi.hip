@@ -233,6 +233,7 @@ int gptq_init(void) {
     hipError_t e = init_gemm_device();
     if (e == hipSuccess) e = init_gemv_device();
     if (e == hipSuccess) e = init_mlp_device();
+    if (e == hipSuccess) e = init_gemm_mid_device();
     if (e != hipSuccess) return hip_fail(e, "gptq_init (hipFuncSetAttribute)");
     return GPTQ_OK;
 }
@@ -388,11 +389,25 @@ static bool want_stream64_multi(const gptq_layer_t* const* layers, int n, int M,
     return sp.ok && (sp.pays || forced);
 }
 
+// 17 .. 128 rows, 2..4 layers sharing x in ONE gemm_mid_kernel launch: by the planner's measured preference, or forced with tuning.path = 3 and
+// tuning.reserved[2] = 5.
+static bool want_mid_multi(const gptq_layer_t* const* layers, int n, int M, const gptq_tuning_t* t) {
+    if (n < 2 || n > 4 || M > 128) return false;
+    const bool forced = t && t->path == 3 && t->reserved[2] == 5;
+    if (t && t->path != 0 && !forced) return false;
+    const MidPlan mp = plan_mid(layers, n, M, t);
+    return mp.ok && (mp.pays || forced);
+}
+
 size_t gptq_workspace_bytes_multi_ex(const gptq_layer_t* const* layers, int n_layers, int M, const gptq_tuning_t* tune) {
     if (!layers || n_layers <= 0 || M <= 0) return 0;
     for (int i = 0; i < n_layers; ++i)
         if (check_layer(layers[i]) != GPTQ_OK) return 0;
     size_t need = 0;
+    if (want_mid_multi(layers, n_layers, M, tune)) {
+        const MidPlan mp = plan_mid(layers, n_layers, M, tune);
+        return mp.partial_bytes ? WS_HEADER_BYTES + mp.partial_bytes : 0;
+    }
     if (want_stream64_multi(layers, n_layers, M, tune)) {
         const Stream64Plan sp = plan_stream64(layers, n_layers, M, tune);
         return sp.partial_bytes ? WS_HEADER_BYTES + sp.partial_bytes : 0;
@@ -422,6 +437,14 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
         if (layers[i]->K != layers[0]->K) return fail(GPTQ_ERR_SHAPE, "layers of one gptq_forward_multi call read the same x: in_features %d != %d", layers[i]->K, layers[0]->K);
         if (layers[i]->dtype != layers[0]->dtype) return fail(GPTQ_ERR_UNSUPPORTED, "layers of one gptq_forward_multi call share the dtype of x");
     }
+    if (want_mid_multi(layers, n_layers, M, tune)) {
+        const MidPlan mp = plan_mid(layers, n_layers, M, tune);
+        if (mp.partial_bytes > 0 && wv.body_bytes < mp.partial_bytes)
+            return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + mp.partial_bytes, wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0);
+        hipError_t e = launch_mid(layers, mp, x, outs, M, wv.header, wv.body, nullptr, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "gptq 17..128-row launch (needs > 64 KiB of LDS: was gptq_init() called on this device?)");
+        return GPTQ_OK;
+    }
     if (want_stream64_multi(layers, n_layers, M, tune)) {
         const Stream64Plan sp = plan_stream64(layers, n_layers, M, tune);
         if (sp.partial_bytes > 0 && wv.body_bytes < sp.partial_bytes)
@@ -437,6 +460,8 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
     }
     if (tune && tune->path == 3 && tune->reserved[2] == 4)
         return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 3 / reserved[2] = 4: these layers do not fit one batched-decode launch (2..4 plain 4-bit layers, M <= 64)");
+    if (tune && tune->path == 3 && tune->reserved[2] == 5)
+        return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 3 / reserved[2] = 5: these layers do not fit one gemm_mid_kernel launch (2..4 plain 4-bit layers, N %% 64 == 0, M <= 128)");
     for (int i = 0; i < n_layers; ++i) {           // anything the one-launch kernel does not cover: the same result, layer by layer
         int rc = forward_impl(layers[i], x, outs[i], M, wv, stream, nullptr);
         if (rc) return rc;
@@ -663,9 +688,9 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
                  sp.u, sp.ksplit, sp.mt, sp.strips_total);
     } else if (want_gemm(&Lc, M, tune)) {
         const GemmPlan g = plan_gemm(Lc, M, tune);
-        const char* kern = g.f32 ? "f32_mfma" : (g.stream64 ? "stream64" : (g.strip16 ? "strip16" : (g.skinny ? "skinny64" : "tiled")));
+        const char* kern = g.f32 ? "f32_mfma" : g.mid ? "mid" : (g.stream64 ? "stream64" : (g.strip16 ? "strip16" : (g.skinny ? "skinny64" : "tiled")));
         snprintf(out, out_bytes, "path=gemm kernel=%s mt=%d bk=%d kg=%d ksplit=%d tiles=%dx%d perm=%d dma=%d waves=%d u=%d epilogue=%s", kern, g.mt, g.bk,
-                 g.kg == 2 ? 2 : 1, g.ksplit, g.nbm, g.nbn, g.use_seq ? 1 : 0, (g.glds || g.stream64) ? 1 : 0, g.waves, g.u,
+                 g.kg == 2 ? 2 : 1, g.ksplit, g.nbm, g.nbn, g.use_seq ? 1 : 0, (g.glds || g.stream64 || g.mid) ? 1 : 0, g.waves, g.u,
                  unfused_epilogue ? "separate" : "none");
     } else {
         const GemvPlan v = plan_gemv(Lc, M, tune);

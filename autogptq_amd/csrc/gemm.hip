@@ -1695,6 +1695,22 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     // tiled kernel enough 256-column tiles to fill the chip without help.
     pl.skinny = (force_skinny == 1) || (force_skinny == 0 && M <= 64 && (L.N + 255) / 256 < 32);
     if (pl.skinny && M > 128) pl.skinny = false;
+    // 17 .. 128 rows: everything by LDS DMA (gemm_mid.hip)
+    {
+        const gptq_layer_t* one[1] = {&L};
+        const MidPlan mp = plan_mid(one, 1, M, tune);
+        pl.mid = mp.ok && (force_skinny == 5 || (force_skinny == 0 && mp.pays));
+        if (pl.mid) {
+            pl.skinny = false;
+            pl.midp = mp;
+            pl.mt = mp.rt; pl.bk = 32; pl.bm = 16 * mp.rt; pl.bn = 64;
+            pl.nbm = 1; pl.nbn = mp.strips_total;
+            pl.waves = mp.waves; pl.u = mp.stages;
+            pl.ksteps_total = mp.ksteps_total; pl.ksteps_per_split = mp.ksteps_per_split; pl.ksplit = mp.ksplit;
+            pl.workspace_bytes = pl.xperm_bytes + mp.partial_bytes;
+            return pl;
+        }
+    }
     // batched decode (4 < M <= 64, 4-bit): 64-column strips, weights by LDS DMA, K slices combined inside the launch
     // batched decode (4 < M <= 64, 4-bit): 64-column strips, weights by LDS DMA, K slices combined inside the launch
     {
@@ -1940,6 +1956,11 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
         p.x = workspace;
     }
     p.partial = (float*)((char*)workspace + pl.xperm_bytes);
+    if (pl.mid) {
+        const gptq_layer_t* one[1] = {&L};
+        void* outs[1] = {out};
+        return launch_mid(one, pl.midp, p.x, outs, M, ws_header, p.partial, pl.use_seq ? L.qweight_seq : nullptr, st);
+    }
     if (pl.stream64) {
         const gptq_layer_t* one[1] = {&L};
         void* outs[1] = {out};

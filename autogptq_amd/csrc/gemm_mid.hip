@@ -1,0 +1,504 @@
+// gemm_mid.hip -- 4-bit fp16 / bf16 QuantLinear forward for 17 .. 128 rows of x ("batched decode" and small prefill chunks).
+//
+// Role in the reference: the regime between the one-row kernels and the dequantise-then-GEMM fallbacks -- exllamav2's MAX_Q_GEMM_ROWS = 50
+// (autogptq_extension/exllamav2/cuda/q_gemm.cu:118, config.h:4), qlinear_cuda.py:34,212 (kernel_switch_threshold) and the batch > 1 rows of
+// the reference's own benchmark table.  Nothing is derived from those kernels.
+//
+// Why another kernel: gemm_stream64_kernel (gemm.hip) brings x to the matrix core through registers -- 16-byte loads of 64-byte row
+// segments from L2 per (K-step, row tile), then 4 ds_bpermute to reach the MFMA's lane layout -- and that path, not the weights, is what
+// its time grows with beyond 32 rows (profiles/r03_stream64_ablation.log: 22.8 us at M = 64 on 4096 x 11008, 18.0 without the x loads; the
+// weights alone stream in 8.6).  Here NOTHING a wave consumes passes through a VGPR before it is used:
+//   * weights: one LDS DMA (global_load_lds_dwordx4, 1 KiB, nontemporal) per 32-deep K-step of the 64-column strip, as in stream64;
+//   * x: one LDS DMA per (K-step, 16-row tile) -- lanes 4q .. 4q+3 fetch the 64 contiguous bytes of row q (coalesced), their four 16-byte
+//     octets rotated by q >> 2 so that the MFMA's lane (row i, k-octet kg) reads slot 4 i + ((kg + (i >> 2)) & 3) with ONE conflict-free
+//     ds_read_b128 (the 16 lanes of a quarter-wave hit 16 different 16-byte bank groups);
+//   * group constants: the (scales, zero-point) rows of all the groups a wave will touch are DMA'd once, up front, into a per-wave LDS
+//     table (256 B per group) -- the K loop's only VMEM instructions are its own DMAs, so `s_waitcnt vmcnt(newer stages x (1 + RT))` is exact;
+//   * D stages of (1 + RT) KiB per wave are in flight; waves split the workgroup's K range (no barrier in the K loop); addresses are
+//     scalar base (+ K-step) + a fixed 32-bit lane offset: no vector address arithmetic per DMA.
+// K slices of a strip are combined inside the launch: slices 1.. write their fp32 partial tile with 16-byte write-through (sc1) stores,
+// drain them and set ONE flag word each; slice 0 (the owner) polls the flags (bounded), adds the partials in slice order (bit-reproducible)
+// and clears the flags.  Flags live in the zeroed ticket half of the workspace header (gptq_mi355x.h): zero before and after every launch.
+#include <type_traits>
+#include <utility>
+
+#include "common.cuh"
+#include "launch.h"
+
+namespace gptq {
+
+namespace midk {
+
+struct MidSeg {
+    const unsigned* qweight;
+    const unsigned* qzeros;
+    const void* scales;
+    const void* bias;
+    void* out;
+    int N;         // columns of this layer (multiple of 64)
+    int blk_end;   // cumulative strip count up to and including this layer
+    int col0;      // first column of this layer in the concatenated partial slab
+    int pad_;
+};
+struct MidParams {
+    MidSeg seg[4];       // up to four layers that read the same x: the grid runs over all their strips
+    const void* x;
+    float* partial;      // [ksplit - 1][M][nsum] fp32 partial tiles of K slices 1 .. ksplit - 1
+    unsigned* flags;     // workspace header, ticket half: word [strip * 8 + slice], zero before and after every launch
+    unsigned* err;       // sticky error word (header tail): a bounded wait gave up
+    int nseg, M, K, zero_mode, ksplit, ksteps_per_split, nsum;
+    int lg_gsteps;       // log2(group_size / 32)
+    int tab_bytes;       // per-wave group-constant table (256 B per group the wave can touch)
+    unsigned max_spins;
+};
+
+__device__ __forceinline__ unsigned and_or(unsigned q, unsigned mask, unsigned magic) { return (q & mask) | magic; }
+__device__ __forceinline__ unsigned f16x2_bits(f16x2 v) { return __builtin_bit_cast(unsigned, v); }
+
+// 16 bytes per lane global -> LDS (lds_dst + lane * 16); source = scalar base + 32-bit per-lane byte offset
+__device__ __forceinline__ void dma16_sv(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma16_sv_nt(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void store16_sc1(void* dst, f32x4 v) {      // write-through: visible to every XCD once drained
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+}
+
+// one column: (scale bits, zero-point) -> fragment of one 4-bit word = 8 consecutive k in the slot order k0,k4,k1,k5,k2,k6,k3,k7;
+// exact w - z in packed fp16 (magic number 0x6400), then x scale: the reference's scales * (w - z), bit for bit
+template <typename T> struct Deq1;
+template <> struct Deq1<f16> {
+    f16x2 s2, c1, c2;
+    __device__ __forceinline__ void setup(unsigned sbits, unsigned z) {
+        s2 = as_f16x2(sbits * 0x00010001u);
+        c1 = as_f16x2(z * 0x00010001u + 0xE400E400u);
+        const f16x2 k960 = {(f16)960.f, (f16)960.f};
+        c2 = c1 + k960;
+    }
+    __device__ __forceinline__ u32x4 frag(unsigned q) const {
+        const unsigned q8 = q >> 8;
+        const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+        u32x4 o;
+        o[0] = f16x2_bits((as_f16x2(and_or(q, 0x000f000fu, 0x64006400u)) + c1) * s2);
+        o[1] = f16x2_bits((as_f16x2(and_or(q, 0x00f000f0u, 0x64006400u)) * r16 + c2) * s2);
+        o[2] = f16x2_bits((as_f16x2(and_or(q8, 0x000f000fu, 0x64006400u)) + c1) * s2);
+        o[3] = f16x2_bits((as_f16x2(and_or(q8, 0x00f000f0u, 0x64006400u)) * r16 + c2) * s2);
+        return o;
+    }
+};
+template <> struct Deq1<bf16> {
+    f16x2 c1, c2;
+    float s;
+    __device__ __forceinline__ void setup(unsigned sbits, unsigned z) {
+        s = (float)__builtin_bit_cast(bf16, (unsigned short)sbits);
+        c1 = as_f16x2(z * 0x00010001u + 0xE400E400u);
+        const f16x2 k960 = {(f16)960.f, (f16)960.f};
+        c2 = c1 + k960;
+    }
+    static __device__ __forceinline__ unsigned scaled_pair(f16x2 h, float sc) {      // exact fp32 product, one rounding to bf16
+        const unsigned hb = __builtin_bit_cast(unsigned, h);
+        float lo, hi;
+        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hb), "v"(sc));
+        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(hb), "v"(sc));
+        const bf16x2 v = {(bf16)lo, (bf16)hi};
+        return __builtin_bit_cast(unsigned, v);
+    }
+    __device__ __forceinline__ u32x4 frag(unsigned q) const {
+        const unsigned q8 = q >> 8;
+        const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+        u32x4 o;
+        o[0] = scaled_pair(as_f16x2(and_or(q, 0x000f000fu, 0x64006400u)) + c1, s);
+        o[1] = scaled_pair(as_f16x2(and_or(q, 0x00f000f0u, 0x64006400u)) * r16 + c2, s);
+        o[2] = scaled_pair(as_f16x2(and_or(q8, 0x000f000fu, 0x64006400u)) + c1, s);
+        o[3] = scaled_pair(as_f16x2(and_or(q8, 0x00f000f0u, 0x64006400u)) * r16 + c2, s);
+        return o;
+    }
+};
+template <typename T> struct Mma16;
+template <> struct Mma16<f16> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma16<bf16> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <typename T> __device__ __forceinline__ u32x2 pack4(f32x4 v) {
+    struct { T a, b, c, d; } o{DType<T>::from_f32(v[0]), DType<T>::from_f32(v[1]), DType<T>::from_f32(v[2]), DType<T>::from_f32(v[3])};
+    return __builtin_bit_cast(u32x2, o);
+}
+
+// RT = row tiles of 16 (M <= 16 RT); D = stages of one K-step in flight per wave.  512 threads: 8 waves split the K range.
+// XREG (experiment, tuning.reserved[1] = 1): x fragments by ordinary 16-byte loads (same coalesced lane layout) into registers, written to the
+// stage with ds_write_b128 when the stage is consumed -- the L1 path (64 B/clk per CU) instead of the LDS-DMA path (~17 B/clk measured).
+template <typename T, int RT, int D, bool XREG = false>
+__global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SB = (1 + RT) * 1024;                           // bytes of one stage: [weights 1 KiB][x row tile 0] .. [x row tile RT-1]
+    constexpr int OPS = XREG ? 1 : 1 + RT;                        // asm-issued (compiler-invisible) VMEM instructions per stage; XREG: the x loads are the compiler's
+    constexpr int VOPS = 1 + RT;                                  // all VMEM instructions per stage
+    static_assert((D - 1) * VOPS <= 63, "vmcnt is a 6-bit counter");
+    const int tid = threadIdx.x, lane = tid & 63, W = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j16 = lane & 15, kg = lane >> 4;
+    const int wave_bytes = D * SB + p.tab_bytes;
+    char* const wbase = smem + (size_t)wave * wave_bytes;         // this wave's stages, then its group-constant table
+    const unsigned w_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(wbase));
+    // logical block -> (strip over all layers, K slice): slices of one strip are adjacent logical ids (one XCD after the remap)
+    const int Lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = Lb / p.ksplit, ks = Lb - tile * p.ksplit;
+    int sI = 0;
+    while (sI + 1 < p.nseg && tile >= p.seg[sI].blk_end) ++sI;    // wave-uniform (kernel arguments only)
+    const MidSeg& sg = p.seg[sI];
+    const int strip = tile - (sI ? p.seg[sI - 1].blk_end : 0);
+    const int N = sg.N;
+    const int S = p.K >> 5;
+    const int b0 = ks * p.ksteps_per_split, b1 = min(b0 + p.ksteps_per_split, S);
+    const int spw = (b1 - b0 + W - 1) / W;
+    const int ws = b0 + wave * spw, we = min(ws + spw, b1);
+    const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
+
+    f32x4 acc[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (ws < we) {
+        const int g_first = ws >> p.lg_gsteps, g_last = (we - 1) >> p.lg_gsteps;
+        {   // group constants of every group this wave touches -> table (256 B per group: scales of the 64 columns, then the 32 B of zero-points)
+            const int sub = lane >> 4, w16 = lane & 15;
+            const unsigned tab_lds = w_lds + D * SB;
+            for (int it = 0; g_first + it * 4 <= g_last; ++it) {
+                const int gg = min(g_first + it * 4 + sub, g_last);
+                const char* src = (w16 < 8) ? (const char*)((const T*)sg.scales + (size_t)gg * N + strip * 64 + w16 * 8)
+                                            : (const char*)(sg.qzeros + (size_t)gg * (N >> 3) + strip * 8 + (w16 == 8 ? 0 : 4));
+                lds_dma16(src, tab_lds + it * 1024);
+            }
+        }
+        // fixed per-lane source offsets (bytes)
+        const unsigned woff = (unsigned)(((size_t)kg * N + strip * 64 + j16 * 4) * 4);
+        unsigned xoff[RT];
+        {
+            const int q = lane >> 2, a = lane & 3, oct = (a - (q >> 2)) & 3;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) xoff[rt] = (unsigned)(((size_t)min(rt * 16 + q, p.M - 1) * p.K + oct * 8) * 2);
+        }
+        const unsigned a_slot = (unsigned)((4 * j16 + ((kg + (j16 >> 2)) & 3)) * 16);   // where the MFMA lane (row j16, k-octet kg) finds its 16 bytes
+        const char* const qw = (const char*)sg.qweight;
+        const char* const xb = (const char*)p.x;
+        const size_t wstep = (size_t)N * 16;                      // bytes of 4 packed rows
+
+        u32x4 xr[XREG ? D : 1][XREG ? RT : 1];
+        auto issue = [&](int s, int stage) __attribute__((always_inline)) {
+            const unsigned dst = w_lds + stage * SB;
+            const char* xs = xb + (size_t)s * 64;
+            if constexpr (XREG) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) xr[stage][rt] = *(const u32x4*)(xs + xoff[rt]);
+            }
+            dma16_sv_nt(qw + (size_t)s * wstep, woff, dst);
+            if constexpr (!XREG) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) dma16_sv(xs, xoff[rt], dst + (1 + rt) * 1024);
+            }
+        };
+        Deq1<T> dq[4];
+        int g_cur = -1;
+        auto consume = [&](int s, int stage) __attribute__((always_inline)) {
+            const char* st = wbase + stage * SB;
+            const u32x4 qv = *(const u32x4*)(st + lane * 16);
+            const int g = s >> p.lg_gsteps;
+            if (g != g_cur) {                                     // wave-uniform
+                g_cur = g;
+                const char* tb = wbase + D * SB + (g - g_first) * 256;
+                const u32x2 sraw = *(const u32x2*)(tb + j16 * 8);
+                const unsigned zz = *(const unsigned short*)(tb + 128 + j16 * 2);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const unsigned sw = sraw[t >> 1];
+                    dq[t].setup((t & 1) ? (sw >> 16) : (sw & 0xffffu), (((zz >> (4 * t)) & 15u) + 1u) & zmask);
+                }
+            }
+            u32x4 b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[t] = dq[t].frag(qv[t]);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                if constexpr (XREG) *(u32x4*)(wbase + stage * SB + (1 + rt) * 1024 + lane * 16) = xr[stage][rt];
+                const u32x4 x4 = *(const u32x4*)(st + (1 + rt) * 1024 + a_slot);
+                u32x4 o;                                          // x in the slot order of the fragments: k0,k4,k1,k5,k2,k6,k3,k7
+                o[0] = __builtin_amdgcn_perm(x4[2], x4[0], 0x05040100u);
+                o[1] = __builtin_amdgcn_perm(x4[2], x4[0], 0x07060302u);
+                o[2] = __builtin_amdgcn_perm(x4[3], x4[1], 0x05040100u);
+                o[3] = __builtin_amdgcn_perm(x4[3], x4[1], 0x07060302u);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[rt][t] = Mma16<T>::run(o, b[t], acc[rt][t]);
+            }
+        };
+        auto wait_newer = [&](int newer) __attribute__((always_inline)) {     // stages issued after the one about to be consumed (wave-uniform)
+            if constexpr (D >= 3) {
+                if (newer >= 2) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * VOPS) : "memory"); return; }
+            }
+            if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VOPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (ws + d < we) issue(ws + d, d);
+        for (int s0 = ws; s0 < we; s0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int s = s0 + d;
+                if (s < we) {
+                    wait_newer(min(D - 1, we - 1 - s));
+                    consume(s, d);
+                    if (s + D < we) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // WAR: this stage's ds_reads are done
+                        issue(s + D, d);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- cross-wave sum (LDS slabs over the landing areas, fixed order), CH row tiles at a time, then write / publish / combine ----------
+    // C/D layout of the 16x16 MFMA: column = lane & 15 (-> strip column 4 j + t), row = 4 * (lane >> 4) + r.  A lane writes, per
+    // (row tile, r), the float4 over t = its 4 adjacent columns of one row: lane-linear 16-byte LDS accesses both ways.
+    constexpr int CH = RT < 4 ? RT : 4;
+    constexpr int E = CH * 4 * 64;                                // float4 entries per chunk and wave
+    f32x4* const slab = (f32x4*)smem;                             // [W][CH * 4][64]
+    const size_t pslab = (size_t)p.M * p.nsum;
+    bool partials_ready = (p.ksplit == 1 || ks != 0);
+    __syncthreads();                                              // every wave is done with its landing area
+#pragma unroll
+    for (int c0 = 0; c0 < RT; c0 += CH) {
+        if (c0) __syncthreads();                                  // the previous chunk's slabs have been read
+#pragma unroll
+        for (int rt = 0; rt < CH; ++rt) {
+            if (c0 + rt < RT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    slab[(size_t)wave * E + (rt * 4 + r) * 64 + lane] =
+                        f32x4{acc[(c0 + rt) % RT][0][r], acc[(c0 + rt) % RT][1][r], acc[(c0 + rt) % RT][2][r], acc[(c0 + rt) % RT][3][r]};
+            }
+        }
+        __syncthreads();
+        if (!partials_ready) {                                    // owner slice, first chunk: every other slice of this strip has published
+            if (tid < p.ksplit - 1) {
+                const unsigned* f = p.flags + (size_t)tile * 8 + 1 + tid;
+                unsigned v = 0;
+                for (unsigned spins = 0;; ++spins) {
+                    v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v != 0u) break;
+                    if (spins > p.max_spins) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            __syncthreads();
+            partials_ready = true;
+        }
+        for (int e = tid; e < E; e += blockDim.x) {
+            const int ln = e & 63, rr = e >> 6;                   // rr = rt * 4 + r inside the chunk
+            const int rt = c0 + (rr >> 2);
+            if (rt >= RT) continue;
+            f32x4 v = slab[e];
+            for (int w = 1; w < W; ++w) v += slab[(size_t)w * E + e];
+            const int m = rt * 16 + 4 * (ln >> 4) + (rr & 3);
+            const int n = strip * 64 + (ln & 15) * 4;
+            if (m >= p.M) continue;
+            if (p.ksplit > 1) {
+                const size_t at = (size_t)m * p.nsum + sg.col0 + n;
+                if (ks != 0) {
+                    store16_sc1(p.partial + (size_t)(ks - 1) * pslab + at, v);
+                    continue;
+                }
+                for (int k = 0; k + 1 < p.ksplit; ++k) {          // fixed order; sc1 loads bypass this XCD's non-coherent L2 lines
+                    const unsigned long long* src = (const unsigned long long*)(p.partial + (size_t)k * pslab + at);
+                    const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v[0] += as_f32((unsigned)lo); v[1] += as_f32((unsigned)(lo >> 32));
+                    v[2] += as_f32((unsigned)hi); v[3] += as_f32((unsigned)(hi >> 32));
+                }
+            }
+            if (sg.bias) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] += DType<T>::to_f32(((const T*)sg.bias)[n + t]);
+            }
+            *(u32x2*)((T*)sg.out + (size_t)m * N + n) = pack4<T>(v);
+        }
+    }
+    if (p.ksplit > 1) {
+        if (ks != 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every publishing wave drains its write-through stores
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(p.flags + (size_t)tile * 8 + ks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __syncthreads();                                      // every partial has been read
+            if (tid < p.ksplit - 1) __hip_atomic_store(p.flags + (size_t)tile * 8 + 1 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace midk
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+static int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* tune) {
+    MidPlan pl{};
+    if (n < 1 || n > 4 || M < 1 || M > 128) return pl;
+    const gptq_layer_t& A = *Ls[0];
+    int strips = 0, nsum = 0;
+    for (int i = 0; i < n; ++i) {
+        const gptq_layer_t& L = *Ls[i];
+        if (L.bits != 4 || (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16) || L.epilogue != GPTQ_EPI_NONE) return pl;
+        if (L.K % 32 || L.N % 64 || L.group_size % 32) return pl;
+        if (L.g_idx != nullptr && (n > 1 || !L.qweight_seq || !L.perm)) return pl;      // act-order: single layers only (x is permuted per layer)
+        if (L.K != A.K || L.group_size != A.group_size || L.dtype != A.dtype || L.zero_mode != A.zero_mode) return pl;
+        strips += L.N / 64;
+        nsum += L.N;
+    }
+    const int lg = ilog2_exact(A.group_size / 32);
+    if (lg < 0) return pl;
+    if ((size_t)strips * 8 * 4 > WS_HEADER_EPOCH_OFFSET) return pl;                     // 8 flag words per strip in the ticket half of the header
+    if ((size_t)M * A.K * 2 >= ((size_t)1 << 31)) return pl;                            // 32-bit lane offsets into x
+    pl.nseg = n;
+    pl.strips_total = strips;
+    pl.nsum = nsum;
+    const int rt = (M + 15) / 16;
+    pl.rt = rt <= 2 ? 2 : (rt <= 4 ? 4 : (rt <= 6 ? 6 : 8));
+    pl.lg_gsteps = lg;
+    const int S = A.K / 32;
+    pl.ksteps_total = S;
+    pl.waves = 8;
+    int ks = (tune && tune->ksplit > 0 && tune->path == 3) ? tune->ksplit : 0;
+    if (!ks) {
+        ks = strips >= 160 ? 1 : 256 / strips;                                          // one workgroup per CU is one round
+        if (ks > 8) ks = 8;
+        while (ks > 1 && S / ks < 2 * pl.waves) --ks;                                   // at least two K-steps per wave
+    }
+    if (ks > 8) ks = 8;
+    while (ks > 1 && (long)strips * ks > 256) --ks;                                     // the owner slice WAITS for the others: every workgroup of the launch must be resident (one per CU, 256 CUs)
+    if (ks > S) ks = S;
+    if (ks < 1) ks = 1;
+    pl.ksteps_per_split = (S + ks - 1) / ks;
+    pl.ksplit = (S + pl.ksteps_per_split - 1) / pl.ksteps_per_split;                    // no empty slices
+    int stages = (tune && tune->reserved[0] > 0) ? tune->reserved[0] : ((pl.rt == 2 && strips >= 160) ? 3 : 2);   // tools/mid_sweep.py: two, except two row tiles on wide layers (4096 x 11008, M = 17: 12.3 against 12.8 us)
+    if (stages > 3) stages = 3;
+    if (stages < 2) stages = 2;
+    const int ch = pl.rt < 4 ? pl.rt : 4;
+    // LDS: waves x (stages x (1 + rt) KiB + group table); the table grows with a wave's K range, so when 8 waves do not fit first drop the third
+    // stage, then waves (8 row tiles with one long K slice: 7 waves)
+    for (;;) {
+        const int spw = (pl.ksteps_per_split + pl.waves - 1) / pl.waves;                // K-steps per wave
+        const int groups = ((spw - 1) >> lg) + 2;                                       // groups a wave's range can touch (unaligned start)
+        pl.tab_bytes = ((groups + 3) / 4) * 1024;                                       // the table DMA writes whole KiB
+        const size_t land = (size_t)pl.waves * ((size_t)stages * (1 + pl.rt) * 1024 + pl.tab_bytes);
+        const size_t slabs = (size_t)pl.waves * ch * 4096;
+        pl.lds_bytes = (land > slabs ? land : slabs) + 16;
+        if (pl.lds_bytes <= 160 * 1024) break;
+        if (stages > 2) --stages;
+        else if (pl.waves > 4) --pl.waves;
+        else break;
+    }
+    pl.stages = stages;
+    pl.xreg = tune && tune->reserved[1] == 1;
+    if (pl.lds_bytes > 160 * 1024) return pl;
+    pl.partial_bytes = pl.ksplit > 1 ? (size_t)(pl.ksplit - 1) * M * nsum * sizeof(float) : 0;
+    // Measured preference (tools/mid_sweep.py, us per launch, planner's previous choice -> this kernel; M = 17 / 33 / 64 / 96 / 128):
+    //   4096x4096   11.7 / 13.5 / 15.7 / 22.5 / 24.7 ->  9.8 / 12.2 / 14.0 / 18.4 / 22.2
+    //   4096x11008  14.5 / 19.3 / 22.6 / 26.5 / 27.9 -> 12.3 / 16.5 / 21.1 / 26.7 / 27.1      (172 strips: the tiled kernel keeps 65+ rows)
+    //   11008x4096  15.7 / 20.4 / 24.5 / 33.8 / 35.6 -> 13.4 / 17.5 / 21.3 / 27.5 / 33.3
+    // Up to 16 rows gemm_stream64_kernel's one-row-tile form (16 waves) stays.
+    int nmax = 0;
+    for (int i = 0; i < n; ++i) nmax = Ls[i]->N > nmax ? Ls[i]->N : nmax;
+    // Other shapes (profiles/r03_mid_kernel_more_shapes.log): 17..64 rows win on 5120^2, 8192^2, 3584x8192, 8192x3584, 13824x5120, 28672x8192 (5-20 %);
+    // 97..128 rows only on the 64-strip layers above (5120^2: 26.4 against 23.1, 8192x3584: 28.8 against 25.6); layers of < 32 strips keep
+    // the skinny kernel from 33 rows (8192x1024 M = 64: 15.9 against 14.0); very wide layers keep the tiled kernel from 33 rows.
+    pl.pays = M >= 17 && !(M > 64 && strips >= 160) && !(M > 32 && nmax >= 12288) && !(M > 32 && strips < 32) && !(M > 96 && strips != 64);
+    pl.ok = true;
+    return pl;
+}
+
+template <typename T, int RT, int D>
+static hipError_t launch_mid_one(const MidPlan& pl, const midk::MidParams& p, hipStream_t st) {
+    if (pl.xreg) hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, D, true>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+    else hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, D, false>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+    return hipGetLastError();
+}
+template <typename T>
+static hipError_t launch_mid_t(const MidPlan& pl, const midk::MidParams& p, hipStream_t st) {
+    switch (pl.rt * 4 + pl.stages) {
+        case 2 * 4 + 2: return launch_mid_one<T, 2, 2>(pl, p, st);
+        case 2 * 4 + 3: return launch_mid_one<T, 2, 3>(pl, p, st);
+        case 4 * 4 + 2: return launch_mid_one<T, 4, 2>(pl, p, st);
+        case 4 * 4 + 3: return launch_mid_one<T, 4, 3>(pl, p, st);
+        case 6 * 4 + 2: return launch_mid_one<T, 6, 2>(pl, p, st);
+        case 8 * 4 + 2: return launch_mid_one<T, 8, 2>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_mid(const gptq_layer_t* const* Ls, const MidPlan& pl, const void* x, void* const* outs, int M, void* ws_header, void* partial,
+                      const uint32_t* qweight_override, hipStream_t st) {
+    if (!pl.ok) return hipErrorNotSupported;
+    if (pl.ksplit > 1 && (!ws_header || !partial)) return hipErrorInvalidValue;
+    midk::MidParams p{};
+    int blk = 0, col = 0;
+    for (int i = 0; i < pl.nseg; ++i) {
+        const gptq_layer_t& L = *Ls[i];
+        midk::MidSeg& sg = p.seg[i];
+        sg.qweight = (i == 0 && qweight_override) ? qweight_override : L.qweight;
+        sg.qzeros = L.qzeros;
+        sg.scales = L.scales;
+        sg.bias = L.bias;
+        sg.out = outs[i];
+        sg.N = L.N;
+        blk += L.N / 64;
+        sg.blk_end = blk;
+        sg.col0 = col;
+        col += L.N;
+    }
+    p.x = x;
+    p.partial = (float*)partial;
+    p.flags = (unsigned*)ws_header;
+    p.err = ws_header ? (unsigned*)((char*)ws_header + WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES) + 2 : nullptr;
+    p.nseg = pl.nseg; p.M = M; p.K = Ls[0]->K; p.zero_mode = Ls[0]->zero_mode;
+    p.ksplit = pl.ksplit; p.ksteps_per_split = pl.ksteps_per_split; p.nsum = pl.nsum;
+    p.lg_gsteps = pl.lg_gsteps; p.tab_bytes = pl.tab_bytes;
+    p.max_spins = 1u << 22;
+    return (Ls[0]->dtype == GPTQ_F16) ? launch_mid_t<f16>(pl, p, st) : launch_mid_t<bf16>(pl, p, st);
+}
+
+template <typename T, int RT, int D> static hipError_t grant_mid() {
+    hipError_t e = hipFuncSetAttribute((const void*)midk::gemm_mid_kernel<T, RT, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)midk::gemm_mid_kernel<T, RT, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e;
+}
+template <typename T> static hipError_t grant_mid_t() {
+    hipError_t e = hipSuccess;
+    auto acc = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    acc(grant_mid<T, 2, 2>()); acc(grant_mid<T, 2, 3>()); acc(grant_mid<T, 4, 2>()); acc(grant_mid<T, 4, 3>());
+    acc(grant_mid<T, 6, 2>()); acc(grant_mid<T, 8, 2>());
+    return e;
+}
+hipError_t init_gemm_mid_device() {
+    hipError_t e = grant_mid_t<f16>();
+    if (e == hipSuccess) e = grant_mid_t<bf16>();
+    return e;
+}
+
+}  // namespace gptq

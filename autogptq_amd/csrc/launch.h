@@ -24,8 +24,25 @@ GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune);
 hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x, void* out, int M,
                        void* workspace, hipStream_t st);
 
+// 17 .. 128 rows (gemm_mid.hip: gemm_mid_kernel): 1..4 plain 4-bit layers that read the same x, one launch; weights, x and group constants by LDS DMA.
+struct MidPlan {
+    bool ok;                 // every layer qualifies and the geometry fits
+    bool pays;               // measured preference over the other kernels
+    bool xreg;               // experiment: x through registers (ordinary loads + ds_write) instead of LDS DMA
+    int nseg, rt, waves, stages, ksplit, ksteps_total, ksteps_per_split, strips_total, nsum, lg_gsteps, tab_bytes;
+    size_t lds_bytes;
+    size_t partial_bytes;    // behind the header (and the permuted x of an act-order layer): [ksplit - 1][M][nsum] fp32 when ksplit > 1
+};
+MidPlan plan_mid(const gptq_layer_t* const* layers, int n, int M, const gptq_tuning_t* tune);
+// qweight_override: the re-sequenced rows of a single act-order layer (x is then the permuted copy), else NULL
+hipError_t launch_mid(const gptq_layer_t* const* layers, const MidPlan& pl, const void* x, void* const* outs, int M, void* ws_header, void* partial,
+                      const uint32_t* qweight_override, hipStream_t st);
+hipError_t init_gemm_mid_device();
+
 struct GemmPlan {
     bool supported, use_seq;
+    bool mid;                 // 17 .. 128 rows, 4-bit: gemm_mid_kernel (midp holds its geometry)
+    MidPlan midp;
     bool glds;                // ... and stages it with global_load_lds (DMA) into swizzled, unpadded LDS rows
     bool xslot;               // act-order: the x pre-pass writes k-slot order, the kernel copies x to LDS verbatim
     bool strip16;             // 8 < M <= 64, 4-bit: 16-column strips on v_mfma_f32_16x16x32 (mt = row tiles of 16)

@@ -345,8 +345,8 @@ def test_full_size_batched_decode_properties(K, N, M, act, dtype):
         y, yb = q(x.to(DEV)), q(x.to(DEV))
     assert torch.equal(y, yb)
     d = _lib.describe_plan(q._layer, M)
-    assert d["kernel"] == ("strip16" if (K, N) == (4096, 4096) else "stream64"), d
-    if d["kernel"] == "stream64":
+    assert d["kernel"] == ("strip16" if (K, N) == (4096, 4096) else ("mid" if M > 16 else "stream64")), d
+    if d["kernel"] in ("stream64", "mid"):
         assert d["ksplit"] == (1 if N >= 10240 else 4), d
     mode = O.reference_zero_mode(act, 4)
     for n0 in ((N // 2) // 32 * 32, N - 96):
@@ -364,6 +364,75 @@ def test_full_size_batched_decode_properties(K, N, M, act, dtype):
     W = O.dequantize(L["qweight"][:, sl], L["qzeros"][:, (N - 64) // 8:], L["scales"][:, sl], L["g_idx"] if act else None, 4, mode)
     expect = (W[ks].float() + L["bias"][sl].float()).to(dtype)
     assert torch.equal(yo[:, sl], expect)
+
+
+# ------------------------------------------------------------------------- 17 .. 128 rows: everything by LDS DMA (gemm_mid_kernel)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("stages,ksplit,xreg", [(0, 0, 0), (2, 1, 0), (3, 3, 0), (2, 8, 0), (3, 2, 1), (2, 5, 1)])
+@pytest.mark.parametrize("M,K,N,gs,act", [(17, 1024, 128, 64, False), (32, 2048, 512, 128, True), (33, 4096, 1024, 128, False), (50, 4096, 1088, 128, True),
+                                          (64, 224, 64, 32, False), (65, 1024, 256, 32, True), (96, 11008, 256, 128, False), (100, 2048, 192, 256, False),
+                                          (128, 4096, 512, 128, True), (128, 512, 64, 512, False), (5, 512, 128, 128, False)])
+def test_mid_kernel(M, K, N, gs, act, dtype, stages, ksplit, xreg):
+    """17 .. 128 rows (and fewer, forced), 4-bit: gemm_mid_kernel (tuning.path = 3, reserved[2] = 5; the default in most of that range) against
+    the fp64 oracle for default and forced launch geometries (stages in flight x in-launch K slices x the register variant of the x path; 2 / 4 / 6 /
+    8 row tiles, ragged last row tile, K ranges that do not divide by waves, one K-step per group and one group per layer, act-order through the
+    permuted-x pre-pass), with one-hot rows (the exact dequantised rows come back: catches any row / column / k-slot mix-up of the DMA lane
+    layouts), twice (flags cleared) and bit-reproducible."""
+    L = O.random_quant_layer(K, N, 4, gs, act_order=act, seed=M + K + N, bias=True, dtype=dtype)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, gs, zero_mode="wrap")
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype)
+    y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP)
+    t = _tuning(path=3, ksplit=ksplit)
+    t.reserved[0], t.reserved[1], t.reserved[2] = stages, xreg, 5
+    q.post_init()
+    d = _lib.describe_plan(q._layer, M, t)
+    assert d["kernel"] == "mid", d
+    with torch.no_grad():
+        y, yb = q(x.to(DEV), tuning=t), q(x.to(DEV), tuning=t)
+    assert torch.equal(y, yb)
+    _assert_close(y, y64, y64, dtype, K, f"mid {d} vs f64")
+    ks = (torch.arange(M) * 37 + 5) % K
+    xo = torch.zeros(M, K, dtype=dtype)
+    xo[torch.arange(M), ks] = 1.0
+    with torch.no_grad():
+        yo = q(xo.to(DEV), tuning=t).cpu()
+    W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], 4, O.ZERO_WRAP)
+    expect = (W[ks].float() + L["bias"].float()).to(dtype)
+    assert torch.equal(yo, expect)
+    # the ticket half of the workspace header is zero again (flags cleared by the owner slices)
+    from autogptq_amd.qlinear_mi355x import _WORKSPACE
+    torch.cuda.synchronize()
+    for ent in _WORKSPACE.values():
+        if ent[0].numel() >= 65536:
+            assert int(ent[0][:32768].count_nonzero()) == 0, "the ticket half of the header must be left zero by every launch"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("stages,ksplit", [(0, 0), (2, 3), (3, 8)])
+@pytest.mark.parametrize("M,K,widths,gs", [(17, 1024, (512, 192, 1024), 128), (40, 2048, (1088, 128), 64), (64, 4096, (256, 256, 256, 64), 128),
+                                           (128, 512, (704, 704), 32), (96, 4096, (4096, 1024, 1024), 128)])
+def test_mid_multi_layer_launch(M, K, widths, gs, dtype, stages, ksplit):
+    """gptq_forward_multi at 17 .. 128 rows: 2..4 plain layers that share x in ONE gemm_mid_kernel launch (forced with tuning.path = 3 /
+    reserved[2] = 5, and by default where the planner prefers it) -- every layer against the fp64 oracle and against its own single-layer forward,
+    bias on some layers, flags cleared."""
+    from autogptq_amd.qlinear_mi355x import forward_multi
+    Ls = [O.random_quant_layer(K, n, 4, gs, seed=177 + i + M, bias=(i % 2 == 1), dtype=dtype) for i, n in enumerate(widths)]
+    qs = [_module_from(L["qweight"], L["qzeros"], L["scales"], None, L["bias"], 4, gs) for L in Ls]
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype).to(DEV)
+    t = _tuning(path=3, ksplit=ksplit)
+    t.reserved[0], t.reserved[2] = stages, 5
+    with torch.no_grad():
+        ys = forward_multi(qs, x, tuning=t)
+        ys2 = forward_multi(qs, x, tuning=t)
+        yd = forward_multi(qs, x)
+        sep = [q(x) for q in qs]
+    mode = O.reference_zero_mode(False, 4)
+    for y, y2, d, s_, L in zip(ys, ys2, yd, sep, Ls):
+        assert torch.equal(y, y2)
+        ref = O.forward_f64(x.cpu(), L["qweight"], L["qzeros"], L["scales"], None, L["bias"], 4, mode)
+        _assert_close(y, ref, ref, dtype, K, "mid multi vs oracle")
+        _assert_close(d, ref, ref, dtype, K, "forward_multi default vs oracle")
+        _assert_close(y, s_, ref, dtype, K, "mid multi vs separate")
 
 
 # ------------------------------------------------------------------- MFMA prefill path (gptq_gemm)

@@ -353,15 +353,25 @@ def test_dispatch_rules_are_the_measured_ones():
     p = _plan(11008, 4096, 16)
     assert (p["kernel"], p["ksplit"], p["tiles"]) == ("stream64", 4, "1x64"), p
     assert _plan(8192, 3584, 16)["ksplit"] == 4 and _plan(5120, 5120, 16)["ksplit"] == 3 and _plan(3584, 8192, 16)["ksplit"] == 2
+    assert _plan(4096, 11008, 16, act=True)["kernel"] == "stream64" and _plan(4096, 11008, 16, dtype=1)["kernel"] == "stream64"
+    # 17 .. 128 rows: gemm_mid_kernel (weights, x and group constants by LDS DMA; row tiles of 16: 2 / 4 / 6 / 8; in-launch K slices with flags)
     p = _plan(4096, 11008, 64)
-    assert (p["kernel"], p["mt"], p["waves"]) == ("stream64", 4, 8), p
-    assert _plan(4096, 11008, 32)["mt"] == 2 and _plan(4096, 11008, 16, act=True)["kernel"] == "stream64" and _plan(4096, 11008, 16, dtype=1)["kernel"] == "stream64"
-    assert _plan(8192, 28672, 32)["kernel"] == "stream64" and _plan(8192, 28672, 64)["kernel"] == "tiled"       # 33+ rows on very wide layers
-    # ... small layers keep the older kernels: 16-column strips up to 16 rows, 64-column skinny up to 64 rows
+    assert (p["kernel"], p["mt"], p["waves"], p["ksplit"], p["tiles"]) == ("mid", 4, 8, 1, "1x172"), p
+    assert _plan(4096, 11008, 17)["kernel"] == "mid" and _plan(4096, 11008, 17)["u"] == 3 and _plan(4096, 11008, 32)["mt"] == 2
+    p = _plan(11008, 4096, 96)
+    assert (p["kernel"], p["mt"], p["ksplit"], p["u"]) == ("mid", 6, 4, 2), p
+    assert _plan(4096, 4096, 17)["kernel"] == "mid" and _plan(4096, 4096, 128)["kernel"] == "mid" and _plan(4096, 4096, 128)["mt"] == 8
+    assert _plan(4096, 11008, 64, act=True)["kernel"] == "mid" and _plan(4096, 11008, 64, dtype=1)["kernel"] == "mid"
+    # ... except: 65+ rows on layers of 160+ strips and 33+ rows on very wide layers (tiled kernel), 97+ rows off the 64-strip layers,
+    # 33+ rows on layers of < 32 strips (skinny kernel), other bit widths, N % 64 != 0
+    assert _plan(4096, 11008, 65)["kernel"] == "tiled" and _plan(8192, 28672, 64)["kernel"] == "tiled" and _plan(8192, 28672, 32)["kernel"] == "mid"
+    assert _plan(5120, 5120, 96)["kernel"] == "mid" and _plan(5120, 5120, 128)["kernel"] == "tiled"
+    assert _plan(8192, 1024, 32)["kernel"] == "mid" and _plan(8192, 1024, 64)["kernel"] == "skinny64"
+    assert _plan(4096, 4128, 64)["kernel"] != "mid"
+    # ... up to 16 rows small layers keep the 16-column strips
     assert _plan(4096, 4096, 9)["kernel"] == "strip16" and _plan(4096, 4096, 16)["kernel"] == "strip16"
-    assert _plan(4096, 4096, 17)["kernel"] == "skinny64" and _plan(4096, 4096, 64)["kernel"] == "skinny64"
     assert _plan(8192, 1024, 16)["kernel"] == "strip16"
-    assert _plan(4096, 11008, 16, bits=8, gs=32)["kernel"] == "tiled" and _plan(4096, 11008, 65)["kernel"] == "tiled"
+    assert _plan(4096, 11008, 16, bits=8, gs=32)["kernel"] == "tiled"
     assert _plan(4096, 4096, 16, bits=8, gs=32)["kernel"] == "skinny64"          # the 16-column-strip kernel is 4-bit only
     # prefill: 128 x 256 tiles, 64-deep K-steps; two K groups per workgroup when there is at most one tile per CU
     p = _plan(4096, 4096, 2048)
