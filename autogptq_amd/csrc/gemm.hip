@@ -1699,11 +1699,13 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     {
         const gptq_layer_t* one[1] = {&L};
         const MidPlan mp = plan_mid(one, 1, M, tune);
-        pl.mid = mp.ok && (force_skinny == 5 || (force_skinny == 0 && mp.pays));
+        // by default only without kernel-specific experiment knobs: tuning.reserved[0..3] mean different things to the tiled / stream64 kernels
+        const bool plain_tuning = !tune || (tune->reserved[0] == 0 && tune->reserved[1] == 0 && tune->reserved[3] == 0);
+        pl.mid = mp.ok && (force_skinny == 5 || (force_skinny == 0 && mp.pays && plain_tuning));
         if (pl.mid) {
             pl.skinny = false;
             pl.midp = mp;
-            pl.mt = mp.rt; pl.bk = 32; pl.bm = 16 * mp.rt; pl.bn = 64;
+            pl.mt = mp.rt; pl.bk = 32; pl.bm = 16 * mp.rt; pl.bn = 64 * mp.cw;
             pl.nbm = 1; pl.nbn = mp.strips_total;
             pl.waves = mp.waves; pl.u = mp.stages;
             pl.ksteps_total = mp.ksteps_total; pl.ksteps_per_split = mp.ksteps_per_split; pl.ksplit = mp.ksplit;

@@ -44,8 +44,11 @@ struct MidParams {
     MidSeg seg[4];       // up to four layers that read the same x: the grid runs over all their strips
     const void* x;
     float* partial;      // [ksplit - 1][M][nsum] fp32 partial tiles of K slices 1 .. ksplit - 1
-    unsigned* flags;     // workspace header, ticket half: word [strip * 8 + slice], zero before and after every launch
+    unsigned* flags;     // workspace header, ticket half: word [strip * 8 + slice], zero before and after every launch (flag combine)
+    unsigned* epochs;    // workspace header, second half: per-strip launch epoch (granule combine; monotonic, bumped by the owner slice, never reset)
     unsigned* err;       // sticky error word (header tail): a bounded wait gave up
+    int gran;            // 1: K slices 1.. publish {fp32, tag} granules (8 bytes per value) that the owner validates itself -- ONE memory hop;
+                         // 0: fp32 partial tiles + one flag word per slice (publish, drain, flag, read: three)
     int nseg, M, K, zero_mode, ksplit, ksteps_per_split, nsum;
     int lg_gsteps;       // log2(group_size / 32)
     int tab_bytes;       // per-wave group-constant table (256 B per group the wave can touch)
@@ -139,12 +142,16 @@ template <typename T> __device__ __forceinline__ u32x2 pack4(f32x4 v) {
 // RT = row tiles of 16 (M <= 16 RT); D = stages of one K-step in flight per wave.  512 threads: 8 waves split the K range.
 // XREG (experiment, tuning.reserved[1] = 1): x fragments by ordinary 16-byte loads (same coalesced lane layout) into registers, written to the
 // stage with ds_write_b128 when the stage is consumed -- the L1 path (64 B/clk per CU) instead of the LDS-DMA path (~17 B/clk measured).
-template <typename T, int RT, int D, bool XREG = false>
+// CW = 64-column halves per strip (1: 64-column strips; 2: 128-column strips -- every x fragment feeds 8 MFMAs instead of 4, which halves
+// the x bytes a CU pulls from L2 per flop: what bounds this kernel is the ~50 GB/s a CU gets out of the L2 when every CU reads the same x
+// (tools/xfetch_lab.hip, profiles/r03_xfetch_lab.log), by DMA or through registers alike).  CW = 2 needs RT <= 4 (128 accumulator registers).
+template <typename T, int RT, int D, bool XREG = false, int CW = 1>
 __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SB = (1 + RT) * 1024;                           // bytes of one stage: [weights 1 KiB][x row tile 0] .. [x row tile RT-1]
-    constexpr int OPS = XREG ? 1 : 1 + RT;                        // asm-issued (compiler-invisible) VMEM instructions per stage; XREG: the x loads are the compiler's
-    constexpr int VOPS = 1 + RT;                                  // all VMEM instructions per stage
+    constexpr int SB = (CW + RT) * 1024;                          // bytes of one stage: [weights CW x 1 KiB][x row tile 0] .. [x row tile RT-1]
+    constexpr int OPS = XREG ? CW : CW + RT;                      // asm-issued (compiler-invisible) VMEM instructions per stage; XREG: the x loads are the compiler's
+    constexpr int VOPS = CW + RT;                                 // all VMEM instructions per stage
+    constexpr int SC = 64 * CW;                                   // columns of a strip
     static_assert((D - 1) * VOPS <= 63, "vmcnt is a 6-bit counter");
     const int tid = threadIdx.x, lane = tid & 63, W = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,26 +173,46 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
     const int ws = b0 + wave * spw, we = min(ws + spw, b1);
     const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
 
-    f32x4 acc[RT][4];
+#ifdef GPTQ_MID_TL
+    // lab build: per-wave s_memtime stamps in the last 1 KiB of the wave's table area (plan_mid adds it), dumped to the buffer whose address the
+    // host put into header-tail words 4..5 (tools/mid_timeline.py)
+    unsigned long long* const tl_lds = (unsigned long long*)(wbase + wave_bytes - 1024);
+    int tl_n = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && tl_n < 126) tl_lds[tl_n] = t;
+        ++tl_n;
+    };
+    stamp();
+#else
+    auto stamp = [&]() __attribute__((always_inline)) {};
+#endif
+    f32x4 acc[RT][CW][4];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < CW; ++h)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[rt][h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (ws < we) {
         const int g_first = ws >> p.lg_gsteps, g_last = (we - 1) >> p.lg_gsteps;
-        {   // group constants of every group this wave touches -> table (256 B per group: scales of the 64 columns, then the 32 B of zero-points)
+        {   // group constants of every group this wave touches -> table (256 B per (group, 64-column half): scales of the 64 columns, then the 32 B of zero-points)
             const int sub = lane >> 4, w16 = lane & 15;
             const unsigned tab_lds = w_lds + D * SB;
-            for (int it = 0; g_first + it * 4 <= g_last; ++it) {
-                const int gg = min(g_first + it * 4 + sub, g_last);
-                const char* src = (w16 < 8) ? (const char*)((const T*)sg.scales + (size_t)gg * N + strip * 64 + w16 * 8)
-                                            : (const char*)(sg.qzeros + (size_t)gg * (N >> 3) + strip * 8 + (w16 == 8 ? 0 : 4));
+            const int units = (g_last - g_first + 1) * CW;
+            for (int it = 0; it * 4 < units; ++it) {
+                const int u = min(it * 4 + sub, units - 1);
+                const int gg = g_first + u / CW, c0 = strip * SC + (u % CW) * 64;
+                const char* src = (w16 < 8) ? (const char*)((const T*)sg.scales + (size_t)gg * N + c0 + w16 * 8)
+                                            : (const char*)(sg.qzeros + (size_t)gg * (N >> 3) + (c0 >> 3) + (w16 == 8 ? 0 : 4));
                 lds_dma16(src, tab_lds + it * 1024);
             }
         }
         // fixed per-lane source offsets (bytes)
-        const unsigned woff = (unsigned)(((size_t)kg * N + strip * 64 + j16 * 4) * 4);
+        unsigned woff[CW];
+#pragma unroll
+        for (int h = 0; h < CW; ++h) woff[h] = (unsigned)(((size_t)kg * N + strip * SC + h * 64 + j16 * 4) * 4);
         unsigned xoff[RT];
         {
             const int q = lane >> 2, a = lane & 3, oct = (a - (q >> 2)) & 3;
@@ -205,43 +232,54 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) xr[stage][rt] = *(const u32x4*)(xs + xoff[rt]);
             }
-            dma16_sv_nt(qw + (size_t)s * wstep, woff, dst);
+            const char* wsrc = qw + (size_t)s * wstep;
+#pragma unroll
+            for (int h = 0; h < CW; ++h) dma16_sv_nt(wsrc, woff[h], dst + h * 1024);
             if constexpr (!XREG) {
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) dma16_sv(xs, xoff[rt], dst + (1 + rt) * 1024);
+                for (int rt = 0; rt < RT; ++rt) dma16_sv(xs, xoff[rt], dst + (CW + rt) * 1024);
             }
         };
-        Deq1<T> dq[4];
+        Deq1<T> dq[CW][4];
         int g_cur = -1;
         auto consume = [&](int s, int stage) __attribute__((always_inline)) {
             const char* st = wbase + stage * SB;
-            const u32x4 qv = *(const u32x4*)(st + lane * 16);
+            u32x4 qv[CW];
+#pragma unroll
+            for (int h = 0; h < CW; ++h) qv[h] = *(const u32x4*)(st + h * 1024 + lane * 16);
             const int g = s >> p.lg_gsteps;
             if (g != g_cur) {                                     // wave-uniform
                 g_cur = g;
-                const char* tb = wbase + D * SB + (g - g_first) * 256;
-                const u32x2 sraw = *(const u32x2*)(tb + j16 * 8);
-                const unsigned zz = *(const unsigned short*)(tb + 128 + j16 * 2);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const unsigned sw = sraw[t >> 1];
-                    dq[t].setup((t & 1) ? (sw >> 16) : (sw & 0xffffu), (((zz >> (4 * t)) & 15u) + 1u) & zmask);
+                for (int h = 0; h < CW; ++h) {
+                    const char* tb = wbase + D * SB + ((g - g_first) * CW + h) * 256;
+                    const u32x2 sraw = *(const u32x2*)(tb + j16 * 8);
+                    const unsigned zz = *(const unsigned short*)(tb + 128 + j16 * 2);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const unsigned sw = sraw[t >> 1];
+                        dq[h][t].setup((t & 1) ? (sw >> 16) : (sw & 0xffffu), (((zz >> (4 * t)) & 15u) + 1u) & zmask);
+                    }
                 }
             }
-            u32x4 b[4];
+            u32x4 b[CW][4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) b[t] = dq[t].frag(qv[t]);
+            for (int h = 0; h < CW; ++h)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[h][t] = dq[h][t].frag(qv[h][t]);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                if constexpr (XREG) *(u32x4*)(wbase + stage * SB + (1 + rt) * 1024 + lane * 16) = xr[stage][rt];
-                const u32x4 x4 = *(const u32x4*)(st + (1 + rt) * 1024 + a_slot);
+                if constexpr (XREG) *(u32x4*)(wbase + stage * SB + (CW + rt) * 1024 + lane * 16) = xr[stage][rt];
+                const u32x4 x4 = *(const u32x4*)(st + (CW + rt) * 1024 + a_slot);
                 u32x4 o;                                          // x in the slot order of the fragments: k0,k4,k1,k5,k2,k6,k3,k7
                 o[0] = __builtin_amdgcn_perm(x4[2], x4[0], 0x05040100u);
                 o[1] = __builtin_amdgcn_perm(x4[2], x4[0], 0x07060302u);
                 o[2] = __builtin_amdgcn_perm(x4[3], x4[1], 0x05040100u);
                 o[3] = __builtin_amdgcn_perm(x4[3], x4[1], 0x07060302u);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[rt][t] = Mma16<T>::run(o, b[t], acc[rt][t]);
+                for (int h = 0; h < CW; ++h)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[rt][h][t] = Mma16<T>::run(o, b[h][t], acc[rt][h][t]);
             }
         };
         auto wait_newer = [&](int newer) __attribute__((always_inline)) {     // stages issued after the one about to be consumed (wave-uniform)
@@ -251,24 +289,50 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
             if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VOPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
+        stamp();
 #pragma unroll
         for (int d = 0; d < D; ++d)
             if (ws + d < we) issue(ws + d, d);
+        stamp();
         for (int s0 = ws; s0 < we; s0 += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const int s = s0 + d;
                 if (s < we) {
                     wait_newer(min(D - 1, we - 1 - s));
+                    stamp();
                     consume(s, d);
                     if (s + D < we) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // WAR: this stage's ds_reads are done
                         issue(s + D, d);
                     }
+                    stamp();
                 }
             }
         }
     }
+#ifdef GPTQ_MID_TL
+    {   // dump before the landing areas are reused as slabs: [workgroup][wave][128] = count, then the stamps
+        stamp();
+        unsigned long long* const tl_out = *(unsigned long long* const*)((const char*)p.err - 8 + 16);
+        if (tl_out && lane == 0) {
+            unsigned long long* o = tl_out + ((size_t)blockIdx.x * 8 + wave) * 128;
+            o[0] = (unsigned long long)tl_n | ((unsigned long long)(we - ws) << 32);
+            o[1] = __builtin_amdgcn_s_memrealtime();
+            for (int i = 0; i < tl_n && i < 126; ++i) o[2 + i] = tl_lds[i];
+        }
+    }
+    // epilogue stamps go straight to the buffer: entries [100 ..) of the wave's row
+    unsigned long long* const tl_epi = *(unsigned long long* const*)((const char*)p.err - 8 + 16);
+    int epi_n = 0;
+    auto estamp = [&]() __attribute__((always_inline)) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (tl_epi && lane == 0 && epi_n < 20) tl_epi[((size_t)blockIdx.x * 8 + wave) * 128 + 100 + epi_n] = t;
+        ++epi_n;
+    };
+#else
+    auto estamp = [&]() __attribute__((always_inline)) {};
+#endif
 
     // ---- cross-wave sum (LDS slabs over the landing areas, fixed order), CH row tiles at a time, then write / publish / combine ----------
     // C/D layout of the 16x16 MFMA: column = lane & 15 (-> strip column 4 j + t), row = 4 * (lane >> 4) + r.  A lane writes, per
@@ -277,18 +341,26 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
     constexpr int E = CH * 4 * 64;                                // float4 entries per chunk and wave
     f32x4* const slab = (f32x4*)smem;                             // [W][CH * 4][64]
     const size_t pslab = (size_t)p.M * p.nsum;
-    bool partials_ready = (p.ksplit == 1 || ks != 0);
+    bool partials_ready = (p.ksplit == 1 || ks != 0 || p.gran);
+    unsigned tag = 0, ep = 0;
+    if (p.ksplit > 1 && p.gran) {                                 // tag = the strip's epoch + 1 in a NaN pattern: no stale granule (older epoch) and no fp32 partial carries it
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ep) : "s"(p.epochs + tile) : "memory");
+        tag = 0x7FE00000u | ((ep + 1u) & 0x1FFFFFu);
+    }
+    bool gave_up = false;
     __syncthreads();                                              // every wave is done with its landing area
+    estamp();                                                     // E0: first barrier passed
 #pragma unroll
-    for (int c0 = 0; c0 < RT; c0 += CH) {
-        if (c0) __syncthreads();                                  // the previous chunk's slabs have been read
+    for (int cc = 0; cc < ((RT + CH - 1) / CH) * CW; ++cc) {      // chunks: CH row tiles of one 64-column half
+        const int c0 = (cc / CW) * CH, hh = cc % CW;
+        if (cc) __syncthreads();                                  // the previous chunk's slabs have been read
 #pragma unroll
         for (int rt = 0; rt < CH; ++rt) {
             if (c0 + rt < RT) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     slab[(size_t)wave * E + (rt * 4 + r) * 64 + lane] =
-                        f32x4{acc[(c0 + rt) % RT][0][r], acc[(c0 + rt) % RT][1][r], acc[(c0 + rt) % RT][2][r], acc[(c0 + rt) % RT][3][r]};
+                        f32x4{acc[(c0 + rt) % RT][hh][0][r], acc[(c0 + rt) % RT][hh][1][r], acc[(c0 + rt) % RT][hh][2][r], acc[(c0 + rt) % RT][hh][3][r]};
             }
         }
         __syncthreads();
@@ -305,6 +377,7 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
             }
             __syncthreads();
             partials_ready = true;
+            estamp();                                             // (owner) E: flags seen
         }
         for (int e = tid; e < E; e += blockDim.x) {
             const int ln = e & 63, rr = e >> 6;                   // rr = rt * 4 + r inside the chunk
@@ -313,9 +386,39 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
             f32x4 v = slab[e];
             for (int w = 1; w < W; ++w) v += slab[(size_t)w * E + e];
             const int m = rt * 16 + 4 * (ln >> 4) + (rr & 3);
-            const int n = strip * 64 + (ln & 15) * 4;
+            const int n = strip * SC + hh * 64 + (ln & 15) * 4;
             if (m >= p.M) continue;
-            if (p.ksplit > 1) {
+            if (p.ksplit > 1 && p.gran) {
+                const size_t at = (size_t)m * p.nsum + sg.col0 + n;
+                unsigned long long* const gbase = (unsigned long long*)p.partial;
+                if (ks != 0) {
+                    unsigned long long* g = gbase + (size_t)(ks - 1) * pslab + at;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        __hip_atomic_store(g + t, (unsigned long long)as_u32(v[t]) | ((unsigned long long)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    continue;
+                }
+                for (int k = 0; k + 1 < p.ksplit; ++k) {          // fixed order: bit-reproducible; each granule is taken the moment its tag is this launch's
+                    const unsigned long long* g = gbase + (size_t)k * pslab + at;
+                    unsigned long long a[4];
+                    for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) a[t] = __hip_atomic_load(g + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const bool ok = (unsigned)(a[0] >> 32) == tag && (unsigned)(a[1] >> 32) == tag && (unsigned)(a[2] >> 32) == tag && (unsigned)(a[3] >> 32) == tag;
+                        if (ok) break;
+                        if (spins > p.max_spins) { gave_up = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] += as_f32((unsigned)a[t]);
+                    // consumed granules are cleared: between launches the exchange area holds NO valid tag, so a tag that is valid now was written
+                    // by this launch -- per-strip epochs alone would let a strip whose epoch lags (it is used by fewer layers) accept what another
+                    // layer published at the same address under the same number
+                    unsigned long long* gw = gbase + (size_t)k * pslab + at;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) __hip_atomic_store(gw + t, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else if (p.ksplit > 1) {
                 const size_t at = (size_t)m * p.nsum + sg.col0 + n;
                 if (ks != 0) {
                     store16_sc1(p.partial + (size_t)(ks - 1) * pslab + at, v);
@@ -336,7 +439,14 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
             *(u32x2*)((T*)sg.out + (size_t)m * N + n) = pack4<T>(v);
         }
     }
-    if (p.ksplit > 1) {
+    estamp();                                                     // E: all chunks reduced and written
+    if (p.ksplit > 1 && p.gran) {
+        if (gave_up) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ks == 0) {
+            __syncthreads();                                      // every granule of this strip has been taken (so every producer has read the epoch)
+            if (tid == 0) __hip_atomic_store(p.epochs + tile, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (p.ksplit > 1) {
         if (ks != 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every publishing wave drains its write-through stores
             __syncthreads();
@@ -346,6 +456,7 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
             if (tid < p.ksplit - 1) __hip_atomic_store(p.flags + (size_t)tile * 8 + 1 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    estamp();                                                     // E: end
 }
 
 }  // namespace midk
@@ -357,29 +468,48 @@ static int ilog2_exact(int v) {
     return (1 << l) == v ? l : -1;
 }
 
+// 128-column strips by default?  (filled in from tools/mid_sweep.py; s128 = strips of 128 columns over all layers of the launch)
+static bool mid_prefers_wide_strips(int M, int s128) {
+    (void)M; (void)s128;
+    return false;
+}
+
 MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* tune) {
     MidPlan pl{};
     if (n < 1 || n > 4 || M < 1 || M > 128) return pl;
     const gptq_layer_t& A = *Ls[0];
     int strips = 0, nsum = 0;
+    const int rt16 = (M + 15) / 16;
+    const int rt_ = rt16 <= 2 ? 2 : (rt16 <= 4 ? 4 : (rt16 <= 6 ? 6 : 8));
+    bool all128 = true;
+    for (int i = 0; i < n; ++i) all128 = all128 && Ls[i]->N % 128 == 0;
+    // 128-column strips (two 64-column halves per wave): forced by tuning.reserved[3] = 2 (1 forces 64), else by measurement (below)
+    const int want_cw = (tune && tune->reserved[3] > 0) ? tune->reserved[3] : 0;
+    int cw = (want_cw == 2 && rt_ <= 4 && all128) ? 2 : 1;
+    if (want_cw == 0 && rt_ <= 4 && all128) {
+        int s128 = 0;
+        for (int i = 0; i < n; ++i) s128 += Ls[i]->N / 128;
+        if (mid_prefers_wide_strips(M, s128)) cw = 2;
+    }
     for (int i = 0; i < n; ++i) {
         const gptq_layer_t& L = *Ls[i];
         if (L.bits != 4 || (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16) || L.epilogue != GPTQ_EPI_NONE) return pl;
         if (L.K % 32 || L.N % 64 || L.group_size % 32) return pl;
         if (L.g_idx != nullptr && (n > 1 || !L.qweight_seq || !L.perm)) return pl;      // act-order: single layers only (x is permuted per layer)
         if (L.K != A.K || L.group_size != A.group_size || L.dtype != A.dtype || L.zero_mode != A.zero_mode) return pl;
-        strips += L.N / 64;
+        strips += L.N / (64 * cw);
         nsum += L.N;
     }
     const int lg = ilog2_exact(A.group_size / 32);
     if (lg < 0) return pl;
     if ((size_t)strips * 8 * 4 > WS_HEADER_EPOCH_OFFSET) return pl;                     // 8 flag words per strip in the ticket half of the header
+    if ((size_t)strips * 4 > WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES - WS_HEADER_EPOCH_OFFSET) return pl;   // one epoch word per strip in the second half
     if ((size_t)M * A.K * 2 >= ((size_t)1 << 31)) return pl;                            // 32-bit lane offsets into x
     pl.nseg = n;
     pl.strips_total = strips;
     pl.nsum = nsum;
-    const int rt = (M + 15) / 16;
-    pl.rt = rt <= 2 ? 2 : (rt <= 4 ? 4 : (rt <= 6 ? 6 : 8));
+    pl.rt = rt_;
+    pl.cw = cw;
     pl.lg_gsteps = lg;
     const int S = A.K / 32;
     pl.ksteps_total = S;
@@ -405,8 +535,11 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     for (;;) {
         const int spw = (pl.ksteps_per_split + pl.waves - 1) / pl.waves;                // K-steps per wave
         const int groups = ((spw - 1) >> lg) + 2;                                       // groups a wave's range can touch (unaligned start)
-        pl.tab_bytes = ((groups + 3) / 4) * 1024;                                       // the table DMA writes whole KiB
-        const size_t land = (size_t)pl.waves * ((size_t)stages * (1 + pl.rt) * 1024 + pl.tab_bytes);
+        pl.tab_bytes = ((groups * cw + 3) / 4) * 1024;                                  // 256 B per (group, 64-column half); the table DMA writes whole KiB
+#ifdef GPTQ_MID_TL
+        pl.tab_bytes += 1024;                                                           // lab build: the wave's stamp area
+#endif
+        const size_t land = (size_t)pl.waves * ((size_t)stages * (cw + pl.rt) * 1024 + pl.tab_bytes);
         const size_t slabs = (size_t)pl.waves * ch * 4096;
         pl.lds_bytes = (land > slabs ? land : slabs) + 16;
         if (pl.lds_bytes <= 160 * 1024) break;
@@ -417,7 +550,14 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     pl.stages = stages;
     pl.xreg = tune && tune->reserved[1] == 1;
     if (pl.lds_bytes > 160 * 1024) return pl;
-    pl.partial_bytes = pl.ksplit > 1 ? (size_t)(pl.ksplit - 1) * M * nsum * sizeof(float) : 0;
+    // experiment knob: reserved[1] = 3 -> the granule combine.  One hop instead of three, but 8-byte write-through stores and polls for every VALUE of a
+    // 16..128 x 64 tile: 4096^2 M = 64 27.7 us against 14.8 with flags, M = 128 46 against 23 (profiles/r03_mid_kernel_granules_vs_flags.log).  What pays
+    // for the one to four rows of the streamed GEMV (64 values per strip) does not scale to a tile.
+    pl.gran = tune && tune->reserved[1] == 3;
+    pl.partial_bytes = pl.ksplit > 1 ? (size_t)(pl.ksplit - 1) * M * nsum * (pl.gran ? 8 : 4) : 0;
+#ifdef GPTQ_MID_TL
+    if (!pl.partial_bytes) pl.partial_bytes = 256;                                      // lab build: always a workspace (its header tail carries the timeline pointer)
+#endif
     // Measured preference (tools/mid_sweep.py, us per launch, planner's previous choice -> this kernel; M = 17 / 33 / 64 / 96 / 128):
     //   4096x4096   11.7 / 13.5 / 15.7 / 22.5 / 24.7 ->  9.8 / 12.2 / 14.0 / 18.4 / 22.2
     //   4096x11008  14.5 / 19.3 / 22.6 / 26.5 / 27.9 -> 12.3 / 16.5 / 21.1 / 26.7 / 27.1      (172 strips: the tiled kernel keeps 65+ rows)
@@ -435,8 +575,15 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
 
 template <typename T, int RT, int D>
 static hipError_t launch_mid_one(const MidPlan& pl, const midk::MidParams& p, hipStream_t st) {
-    if (pl.xreg) hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, D, true>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
-    else hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, D, false>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+    const dim3 grid(pl.strips_total * pl.ksplit), block(pl.waves * 64);
+    if constexpr (RT <= 4) {
+        if (pl.cw == 2) {
+            hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, D, false, 2>), grid, block, pl.lds_bytes, st, p);
+            return hipGetLastError();
+        }
+    }
+    if (pl.xreg) hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, D, true>), grid, block, pl.lds_bytes, st, p);
+    else hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, D, false>), grid, block, pl.lds_bytes, st, p);
     return hipGetLastError();
 }
 template <typename T>
@@ -467,7 +614,7 @@ hipError_t launch_mid(const gptq_layer_t* const* Ls, const MidPlan& pl, const vo
         sg.bias = L.bias;
         sg.out = outs[i];
         sg.N = L.N;
-        blk += L.N / 64;
+        blk += L.N / (64 * pl.cw);
         sg.blk_end = blk;
         sg.col0 = col;
         col += L.N;
@@ -475,6 +622,8 @@ hipError_t launch_mid(const gptq_layer_t* const* Ls, const MidPlan& pl, const vo
     p.x = x;
     p.partial = (float*)partial;
     p.flags = (unsigned*)ws_header;
+    p.epochs = ws_header ? (unsigned*)((char*)ws_header + WS_HEADER_EPOCH_OFFSET) : nullptr;
+    p.gran = pl.gran ? 1 : 0;
     p.err = ws_header ? (unsigned*)((char*)ws_header + WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES) + 2 : nullptr;
     p.nseg = pl.nseg; p.M = M; p.K = Ls[0]->K; p.zero_mode = Ls[0]->zero_mode;
     p.ksplit = pl.ksplit; p.ksteps_per_split = pl.ksteps_per_split; p.nsum = pl.nsum;
@@ -486,6 +635,9 @@ hipError_t launch_mid(const gptq_layer_t* const* Ls, const MidPlan& pl, const vo
 template <typename T, int RT, int D> static hipError_t grant_mid() {
     hipError_t e = hipFuncSetAttribute((const void*)midk::gemm_mid_kernel<T, RT, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)midk::gemm_mid_kernel<T, RT, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (RT <= 4) {
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)midk::gemm_mid_kernel<T, RT, D, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     return e;
 }
 template <typename T> static hipError_t grant_mid_t() {

@@ -1064,6 +1064,12 @@ __global__ void __launch_bounds__(1024, WPS) gemv_q4_stream_kernel(GemvStreamPar
 #pragma unroll
             for (int k = 0; k < KMAX - 1; ++k)
                 if (k < p.ksplit - 1) t += as_f32((unsigned)(v[k] & 0xffffffffu));
+            // consumed granules are cleared: between launches the exchange area holds NO valid tag, so a tag that is valid now was written by
+            // this launch -- per-strip epochs alone would let a strip whose epoch lags (it is used by fewer layers of the model) accept what
+            // another layer published at the same address under the same number
+#pragma unroll
+            for (int k = 0; k < KMAX - 1; ++k)
+                if (k < p.ksplit - 1) __hip_atomic_store(p.gran + (size_t)k * slab + at, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (sg.bias) t += DType<T>::to_f32(((const T*)sg.bias)[n]);
         ((T*)sg.out)[(size_t)m * N + n] = DType<T>::from_f32(t);

@@ -368,7 +368,7 @@ def test_full_size_batched_decode_properties(K, N, M, act, dtype):
 
 # ------------------------------------------------------------------------- 17 .. 128 rows: everything by LDS DMA (gemm_mid_kernel)
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("stages,ksplit,xreg", [(0, 0, 0), (2, 1, 0), (3, 3, 0), (2, 8, 0), (3, 2, 1), (2, 5, 1)])
+@pytest.mark.parametrize("stages,ksplit,xreg", [(0, 0, 0), (2, 1, 0), (3, 3, 0), (2, 8, 0), (3, 2, 1), (2, 5, 3), (2, 4, 10), (3, 1, 10)])
 @pytest.mark.parametrize("M,K,N,gs,act", [(17, 1024, 128, 64, False), (32, 2048, 512, 128, True), (33, 4096, 1024, 128, False), (50, 4096, 1088, 128, True),
                                           (64, 224, 64, 32, False), (65, 1024, 256, 32, True), (96, 11008, 256, 128, False), (100, 2048, 192, 256, False),
                                           (128, 4096, 512, 128, True), (128, 512, 64, 512, False), (5, 512, 128, 128, False)])
@@ -383,10 +383,15 @@ def test_mid_kernel(M, K, N, gs, act, dtype, stages, ksplit, xreg):
     x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype)
     y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP)
     t = _tuning(path=3, ksplit=ksplit)
-    t.reserved[0], t.reserved[1], t.reserved[2] = stages, xreg, 5
+    # xreg: 1 = x through registers, 3 = granule combine instead of flags, 10 = 128-column strips (two 64-column halves per wave; <= 64 rows, N % 128 == 0)
+    if xreg == 10 and (M > 64 or N % 128):
+        pytest.skip("128-column strips: up to 64 rows, N a multiple of 128")
+    t.reserved[0], t.reserved[1], t.reserved[2], t.reserved[3] = stages, (xreg if xreg < 10 else 0), 5, (2 if xreg == 10 else 0)
     q.post_init()
     d = _lib.describe_plan(q._layer, M, t)
     assert d["kernel"] == "mid", d
+    if xreg == 10:
+        assert d["tiles"] == f"1x{N // 128}", d
     with torch.no_grad():
         y, yb = q(x.to(DEV), tuning=t), q(x.to(DEV), tuning=t)
     assert torch.equal(y, yb)
@@ -405,6 +410,9 @@ def test_mid_kernel(M, K, N, gs, act, dtype, stages, ksplit, xreg):
     for ent in _WORKSPACE.values():
         if ent[0].numel() >= 65536:
             assert int(ent[0][:32768].count_nonzero()) == 0, "the ticket half of the header must be left zero by every launch"
+            # granule combine: every consumed {fp32, tag} granule was cleared -- no word of the body carries the tag pattern (0x7FE.....) any more
+            body = ent[0][65536:65536 + (ent[0].numel() - 65536) // 4 * 4].view(torch.int32)
+            assert int(((body & -0x200000) == 0x7FE00000).sum()) == 0, "valid-looking granule tags left behind in the exchange area"
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

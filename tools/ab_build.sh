@@ -12,9 +12,9 @@ W=$(mktemp -d)/a/b; mkdir -p "$W"                       # two levels deep: the s
 mkdir -p "$W/../../include"; cp "$ROOT/include/gptq_mi355x.h" "$W/../../include/"
 cp "$CS/common.cuh" "$CS/launch.h" "$W/"
 if [ -n "$REF" ]; then UNIT=$(basename "$SRC"); git -C "$ROOT" show "$REF:autogptq_amd/csrc/$UNIT" > "$W/$UNIT"
-else UNIT=gemv.hip; case "$(basename "$SRC")" in gemm*.hip) UNIT=gemm.hip;; utils*.hip) UNIT=utils.hip;; capi*.hip) UNIT=capi.hip;; esac; cp "$SRC" "$W/$UNIT"; fi
+else UNIT=gemv.hip; case "$(basename "$SRC")" in gemm_mid*.hip) UNIT=gemm_mid.hip;; gemm*.hip) UNIT=gemm.hip;; utils*.hip) UNIT=utils.hip;; capi*.hip) UNIT=capi.hip;; esac; cp "$SRC" "$W/$UNIT"; fi
 OBJ=${UNIT%.hip}.o
 (cd "$W" && /opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-pass-failed -fno-strict-aliasing -c "$UNIT" -o "$OBJ")
-OTHERS=""; for o in capi.o gemv.o gemm.o utils.o peer.o mlp.o; do [ "$o" = "$OBJ" ] && OTHERS="$OTHERS $W/$OBJ" || OTHERS="$OTHERS $CS/$o"; done
+OTHERS=""; for o in capi.o gemv.o gemm.o utils.o peer.o mlp.o gemm_mid.o; do [ "$o" = "$OBJ" ] && OTHERS="$OTHERS $W/$OBJ" || OTHERS="$OTHERS $CS/$o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/tools/libgptq_$NAME.so" $OTHERS
 ls -la "$ROOT/tools/libgptq_$NAME.so"
