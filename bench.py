@@ -359,10 +359,11 @@ def bench_config5(device, steps):
 
 
 def bench_batched(device, steps):
-    """Batched decode (the reference's kernel switch sits at 8 / 50 rows: qlinear_cuda.py:34, q_gemm.cu:118): M = 16 and 64 on the
-    three Llama-7B shapes, int4 g128, distinct layers beyond the Infinity Cache, HIP events, algorithmic GB/s."""
+    """Batched decode (the reference's kernel switch sits at 8 / 50 rows: qlinear_cuda.py:34, q_gemm.cu:118): M = 16, 64 and 128 on the
+    three Llama-7B shapes, int4 g128, distinct layers beyond the Infinity Cache, HIP events, algorithmic GB/s (and the MFMA fraction: at 128 rows
+    the two rooflines cross)."""
     res = {}
-    for M in (16, 64):
+    for M in (16, 64, 128):
         for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
             n = max(4, -(-(320 << 20) // (K * N // 2)))
             ls = [("b", K, N, make_layer(K, N, device, seed=7000 + i)) for i in range(n)]
@@ -370,7 +371,8 @@ def bench_batched(device, steps):
             per = _time_layers(ls, xs, device, max(3, steps // 2))
             ab = algorithmic_bytes(K, N, M)
             res[f"M{M}_{K}x{N}"] = {"us": round(per * 1e6, 2), "GB_per_s": round(ab / per / 1e9, 1), "frac": round(ab / per / 1e9 / HBM_PEAK_GBS, 4),
-                                     "TFLOP_s": round(2 * M * K * N / per / 1e12, 1), "plan": _plan_of(ls, K, N, M)}
+                                     "TFLOP_s": round(2 * M * K * N / per / 1e12, 1), "mfma_frac": round(2 * M * K * N / per / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                     "plan": _plan_of(ls, K, N, M)}
             del ls, xs
             torch.cuda.empty_cache()
     return res
