@@ -127,7 +127,7 @@ static bool want_stream_seq(const gptq_layer_t* L, int M, const gptq_tuning_t* t
     *P = *L;
     P->g_idx = nullptr; P->perm = nullptr; P->qweight = L->qweight_seq; P->qweight_seq = nullptr;
     if (!want_stream(P, M, nullptr)) return false;
-    if (M == 1 && (size_t)L->K * L->N / 2 < ((size_t)33 << 20)) return false;
+    if (M == 1 && (size_t)L->K * L->N * L->bits / 8 < ((size_t)33 << 20)) return false;
     return true;
 }
 static size_t xperm16_bytes(const gptq_layer_t* L, int M) { return ((size_t)M * L->K * 2 + 255) / 256 * 256; }

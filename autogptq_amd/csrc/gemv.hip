@@ -817,6 +817,92 @@ __global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && !PER
     }
 }
 
+// ---- magic-number field decode for the 3- and 8-bit fp16 matrix-core GEMV ------------------------------------------------------
+// The generic kernel below extracts every field on its own (shift, mask, integer subtract, two conversions: ~5.3 VALU per
+// weight; the 3-bit g32 decode launch is 912 VALU per wave and spends as long on them as on its loads).  For fp16 the same exact
+// w - z comes out of packed arithmetic two fields at a time, like the 4-bit kernels do: (t & (7 << s) * 0x00010001) | 0x64006400 is
+// the half2 (1024 + f_a * 2^s, 1024 + f_b * 2^s) for the two fields sitting at bit s of the two 16-bit halves of t, and ONE
+// v_pk_fma_f16 by 2^-s with -(1024 * 2^-s + z) gives (f_a - z, f_b - z) exactly (s + bits <= 10: the field stays inside the
+// mantissa; every intermediate is an integer below 2048).
+//   8-bit: the word itself pairs (f0, f2) and, shifted by 8, (f1, f3): 1 shift + 2 v_and_or + 2 v_pk_add per 4 weights.
+//   3-bit: 32 fields in 96 bits do not line up with the halves, but 16-bit WINDOWS of the bit stream at multiples of 15 bits do:
+//          t_k = (stream >> 30k)[15:0] | (stream >> (30k + 15))[15:0] << 16 holds fields 10k..10k+4 in the low half and 10k+5..10k+9 in
+//          the high half at the same bit positions 0, 3, 6, 9, 12 (9 and 12 are brought down to 3 and 6 by one shift of the whole
+//          word); fields 30 and 31 are a fourth window pair.  <= 3 VALU per t_k, then 1 v_and_or + 1 v_pk op per pair: 46 VALU per
+//          32 weights instead of ~170.
+// The pairs put the unit's k values into matrix-core slots in the order ka(p), kb(p); x is brought into the same order with one
+// v_perm per pair (shared by the lane's 4 columns).  bf16 has neither the mantissa (7 bits) nor packed arithmetic for this and keeps
+// the field-by-field form, as do 2-bit layers.
+// The masks and the magic number reach the expressions as OPAQUE register values (one-instruction asm definitions at kernel start,
+// as in the 4-bit kernels): with literal operands hipcc splits (t & mask) | magic into v_and + v_or (VOP3 takes no literals on gfx9).
+// The expressions themselves stay C on purpose.  A first version issued v_and_or_b32 from inline asm inside the loop and returned
+// garbage / NaN in columns 1 and 2 of every lane at M = 2: with two rows of x the upper half of a 4x4x4 accumulator is dead, the
+// register allocator reuses it for the next column's B fragments, and a VALU write hidden in asm is invisible to the hazard
+// recognizer -- it landed BEFORE the in-flight MFMA's write of the same (dead) register, which then overwrote the fragment.
+struct MagicConsts {
+    unsigned magic, m0, m3, m6, m8;      // 0x64006400 (VGPR); 3-bit field masks at bits 0 / 3 / 6 of both halves, 8-bit mask (SGPRs)
+    __device__ __forceinline__ void init() {
+        asm("v_mov_b32 %0, 0x64006400" : "=v"(magic));
+        asm("s_mov_b32 %0, 0x00070007" : "=s"(m0));
+        asm("s_mov_b32 %0, 0x00380038" : "=s"(m3));
+        asm("s_mov_b32 %0, 0x01c001c0" : "=s"(m6));
+        asm("s_mov_b32 %0, 0x00ff00ff" : "=s"(m8));
+    }
+};
+__device__ __forceinline__ unsigned f16x2_bits(f16x2 v) { return __builtin_bit_cast(unsigned, v); }
+
+template <int BITS> struct MagicF16;
+template <> struct MagicF16<8> {
+    static constexpr int NP = 2;                                   // pairs per unit (4 values)
+    static constexpr int ka(int p) { return p; }                  // (0, 2), (1, 3)
+    static constexpr int kb(int p) { return p + 2; }
+    f16x2 c1;
+    __device__ __forceinline__ void setup(int z) { c1 = as_f16x2((unsigned)z * 0x00010001u + 0xE400E400u); }    // -(1024 + z), z <= 256
+    __device__ __forceinline__ void pairs(const unsigned (&w)[1], const MagicConsts& k, unsigned (&bp)[NP]) const {
+        bp[0] = f16x2_bits(as_f16x2((w[0] & k.m8) | k.magic) + c1);
+        bp[1] = f16x2_bits(as_f16x2(((w[0] >> 8) & k.m8) | k.magic) + c1);
+    }
+};
+template <> struct MagicF16<3> {
+    static constexpr int NP = 16;                                  // pairs per unit (32 values in 3 words)
+    static constexpr int ka(int p) { return p < 15 ? 10 * (p / 5) + p % 5 : 30; }
+    static constexpr int kb(int p) { return p < 15 ? ka(p) + 5 : 31; }
+    f16x2 c1, c3, c6;
+    __device__ __forceinline__ void setup(int z) {                 // z <= 8
+        c1 = as_f16x2((unsigned)z * 0x00010001u + 0xE400E400u);   // -(1024 + z)
+        const f16x2 k896 = {(f16)896.f, (f16)896.f}, k1008 = {(f16)1008.f, (f16)1008.f};
+        c3 = c1 + k896;                                            // -(128 + z), exact
+        c6 = c1 + k1008;                                           // -(16 + z), exact
+    }
+    __device__ __forceinline__ void five(unsigned t, const MagicConsts& k, unsigned* bp) const {
+        const f16x2 r8 = {(f16)0.125f, (f16)0.125f}, r64 = {(f16)0.015625f, (f16)0.015625f};
+        const unsigned t6 = t >> 6;
+        bp[0] = f16x2_bits(as_f16x2((t & k.m0) | k.magic) + c1);
+        bp[1] = f16x2_bits(as_f16x2((t & k.m3) | k.magic) * r8 + c3);
+        bp[2] = f16x2_bits(as_f16x2((t & k.m6) | k.magic) * r64 + c6);
+        bp[3] = f16x2_bits(as_f16x2((t6 & k.m3) | k.magic) * r8 + c3);
+        bp[4] = f16x2_bits(as_f16x2((t6 & k.m6) | k.magic) * r64 + c6);
+    }
+    __device__ __forceinline__ void pairs(const unsigned (&w)[3], const MagicConsts& k, unsigned (&bp)[NP]) const {
+        // 16-bit windows of the 96-bit stream at bits 0 / 15, 30 / 45, 60 / 75, 90 / 93 (low half / high half of t)
+        const unsigned t0 = __builtin_amdgcn_perm(w[0] >> 15, w[0], 0x05040100u);
+        const unsigned t1 = __builtin_amdgcn_perm(w[1] >> 13, __builtin_amdgcn_alignbit(w[1], w[0], 30), 0x05040100u);
+        const unsigned t2 = __builtin_amdgcn_perm(w[2] >> 11, __builtin_amdgcn_alignbit(w[2], w[1], 28), 0x05040100u);
+        const unsigned t3 = __builtin_amdgcn_perm(w[2] >> 29, w[2] >> 26, 0x05040100u);
+        five(t0, k, bp);
+        five(t1, k, bp + 5);
+        five(t2, k, bp + 10);
+        bp[15] = f16x2_bits(as_f16x2((t3 & k.m0) | k.magic) + c1);
+    }
+};
+// x values of one unit (natural order, two per register) -> the register holding (x[ka(P)], x[kb(P)])
+template <int BITS, int P, int NR>
+__device__ __forceinline__ unsigned magic_x_pair(const unsigned (&xr)[NR]) {
+    constexpr int a = MagicF16<BITS>::ka(P), b = MagicF16<BITS>::kb(P);
+    constexpr unsigned sel = ((a & 1) ? 0x0302u : 0x0100u) | (((b & 1) ? 0x0706u : 0x0504u) << 16);
+    return __builtin_amdgcn_perm(xr[b >> 1], xr[a >> 1], sel);
+}
+
 // ---- streamed matrix-core GEMV: weights by LDS DMA, up to 4 layers that share x in ONE launch ------------------
 // Same lane decomposition and arithmetic as gemv_q4_f16_mfma_kernel (plain layers: no act-order, no fused epilogue,
 // M <= 4), with two structural changes aimed at what bounds a one-shot decode launch -- bytes in flight and fixed cost
@@ -866,6 +952,103 @@ struct GemvStreamParams {
     int nseg, M, K, zero_mode, units_total, units_per_split, ksplit, gu_shift, nsum;
     unsigned max_spins;
 };
+
+// Shared tail of the streamed GEMV kernels: row slots (DPP / bpermute), waves (LDS, the kernel's only barrier), then write -- or, with a K split,
+// publish / combine through {fp32, tag} granules.
+template <int LN, int MT, typename T>
+__device__ __forceinline__ void stream_epilogue(float (&acc)[4][MT], const GemvStreamParams& p, const GemvSeg& sg, int strip, int sidx, int ks, int N,
+                                                float* red) {
+    constexpr int CT = LN * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
+    // ---- row slots (DPP / bpermute), waves (LDS, the only barrier), then write or publish ------------------------------
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c][m] = row_slot_sum<LN>(acc[c][m]);
+    constexpr int E = MT * CT, ES = E + 4;                                    // slab stride padded by 16 B: the W partials of an entry spread over banks
+    if (lane < LN) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f32x4 v = {acc[0][m], acc[1][m], acc[2][m], acc[3][m]};
+            *(f32x4*)(red + wave * ES + m * CT + lane * 4) = v;
+        }
+    }
+    __syncthreads();
+    // K split: slice ks >= 1 PUBLISHES its partial sums as 8-byte {fp32, tag} granules (one write-through store each) and is done; slice 0,
+    // the strip's OWNER, polls the granules of the other slices for its entries, takes each the moment its tag is this launch's, adds them in
+    // slice order (fixed order: bit-reproducible) and writes the result -- ONE memory hop after the last slice has published, where the
+    // ticket scheme this replaces (publish, drain, draw a ticket, last arriver reads everything back) was three (~3 us, DESIGN.md 4.1b).
+    // tag = the strip's epoch word + 1 in a NaN pattern; the owner bumps the word when all its waves are through (by then every producer
+    // wave has read it), so the next launch on this workspace -- any layer -- uses a tag that no stale granule carries.
+    unsigned tag = 0;
+    if (p.ksplit > 1) {
+        unsigned ep;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ep) : "s"(p.epochs + sidx) : "memory");
+        tag = 0x7FE00000u | ((ep + 1u) & 0x1FFFFFu);
+    }
+    const size_t slab = (size_t)p.M * p.nsum;
+    bool gave_up = false;
+    auto emit = [&](int e, float t) {
+        const int m = e / CT, c = e % CT;
+        const int n = strip * CT + c;
+        if (n >= N || m >= p.M) return;
+        if (p.ksplit > 1) {
+            const size_t at = (size_t)m * p.nsum + sg.col0 + n;
+            if (ks != 0) {
+                const unsigned long long g8 = (unsigned long long)as_u32(t) | ((unsigned long long)tag << 32);
+                __hip_atomic_store(p.gran + (size_t)(ks - 1) * slab + at, g8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            constexpr int KMAX = 8;                                           // planner: ksplit <= 8
+            unsigned long long v[KMAX - 1];
+            unsigned pending = (1u << (p.ksplit - 1)) - 1u;
+            for (unsigned spins = 0; pending; ++spins) {
+#pragma unroll
+                for (int k = 0; k < KMAX - 1; ++k)
+                    if (pending & (1u << k)) v[k] = __hip_atomic_load(p.gran + (size_t)k * slab + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int k = 0; k < KMAX - 1; ++k)
+                    if ((pending & (1u << k)) && (unsigned)(v[k] >> 32) == tag) pending &= ~(1u << k);
+                if (pending && spins > p.max_spins) { gave_up = true; break; }
+                if (pending) __builtin_amdgcn_s_sleep(2);
+            }
+#pragma unroll
+            for (int k = 0; k < KMAX - 1; ++k)
+                if (k < p.ksplit - 1) t += as_f32((unsigned)(v[k] & 0xffffffffu));
+            // consumed granules are cleared: between launches the exchange area holds NO valid tag, so a tag that is valid now was written by
+            // this launch -- per-strip epochs alone would let a strip whose epoch lags (it is used by fewer layers of the model) accept what
+            // another layer published at the same address under the same number
+#pragma unroll
+            for (int k = 0; k < KMAX - 1; ++k)
+                if (k < p.ksplit - 1) __hip_atomic_store(p.gran + (size_t)k * slab + at, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (sg.bias) t += DType<T>::to_f32(((const T*)sg.bias)[n]);
+        ((T*)sg.out)[(size_t)m * N + n] = DType<T>::from_f32(t);
+    };
+    if ((W & (W - 1)) == 0) {
+        // every wave takes 64 / W entries per round; its lanes are (entry, partial w) pairs: one LDS read each, then a fixed
+        // xor tree over the W lanes of an entry (deterministic order) -- instead of one thread walking W slabs per entry
+        const int lw = __builtin_ctz((unsigned)W);
+        const int w_of_lane = lane & (W - 1), e_of_lane = lane >> lw;
+        for (int e0 = 0; e0 < E; e0 += 64) {
+            const int e = e0 + wave * (64 >> lw) + e_of_lane;
+            float t = (e < E) ? red[w_of_lane * ES + e] : 0.f;
+            for (int off = 1; off < W; off <<= 1) t += __shfl_xor(t, off, 64);
+            if (w_of_lane == 0 && e < E) emit(e, t);
+        }
+    } else {
+        for (int e = tid; e < E; e += blockDim.x) {
+            float t = 0.f;
+            for (int w = 0; w < W; ++w) t += red[w * ES + e];
+            emit(e, t);
+        }
+    }
+    if (p.ksplit > 1 && ks == 0) {
+        if (gave_up) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                                      // every wave of the owner has its granules: every producer wave has read the epoch
+        if (tid == 0) __hip_atomic_store(p.epochs + sidx, (tag & 0x1FFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 template <int LN, int MT, int U, typename T, int WPS>
 __global__ void __launch_bounds__(1024, WPS) gemv_q4_stream_kernel(GemvStreamParams p) {
@@ -1009,180 +1192,135 @@ __global__ void __launch_bounds__(1024, WPS) gemv_q4_stream_kernel(GemvStreamPar
     if (acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] == 1.2345f) ((T*)sg.out)[n0] = DType<T>::from_f32(acc[0][0]);
     return;
 #endif
-    // ---- row slots (DPP / bpermute), waves (LDS, the only barrier), then write or publish ------------------------------
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c][m] = row_slot_sum<LN>(acc[c][m]);
-    constexpr int E = MT * CT, ES = E + 4;                                    // slab stride padded by 16 B: the W partials of an entry spread over banks
-    if (lane < LN) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            f32x4 v = {acc[0][m], acc[1][m], acc[2][m], acc[3][m]};
-            *(f32x4*)(red + wave * ES + m * CT + lane * 4) = v;
-        }
-    }
-    __syncthreads();
-    // K split: slice ks >= 1 PUBLISHES its partial sums as 8-byte {fp32, tag} granules (one write-through store each) and is done; slice 0,
-    // the strip's OWNER, polls the granules of the other slices for its entries, takes each the moment its tag is this launch's, adds them in
-    // slice order (fixed order: bit-reproducible) and writes the result -- ONE memory hop after the last slice has published, where the
-    // ticket scheme this replaces (publish, drain, draw a ticket, last arriver reads everything back) was three (~3 us, DESIGN.md 4.1b).
-    // tag = the strip's epoch word + 1 in a NaN pattern; the owner bumps the word when all its waves are through (by then every producer
-    // wave has read it), so the next launch on this workspace -- any layer -- uses a tag that no stale granule carries.
-    unsigned tag = 0;
-    if (p.ksplit > 1) {
-        unsigned ep;
-        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ep) : "s"(p.epochs + sidx) : "memory");
-        tag = 0x7FE00000u | ((ep + 1u) & 0x1FFFFFu);
-    }
-    const size_t slab = (size_t)p.M * p.nsum;
-    bool gave_up = false;
-    auto emit = [&](int e, float t) {
-        const int m = e / CT, c = e % CT;
-        const int n = strip * CT + c;
-        if (n >= N || m >= p.M) return;
-        if (p.ksplit > 1) {
-            const size_t at = (size_t)m * p.nsum + sg.col0 + n;
-            if (ks != 0) {
-                const unsigned long long g8 = (unsigned long long)as_u32(t) | ((unsigned long long)tag << 32);
-                __hip_atomic_store(p.gran + (size_t)(ks - 1) * slab + at, g8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-            }
-            constexpr int KMAX = 8;                                           // planner: ksplit <= 8
-            unsigned long long v[KMAX - 1];
-            unsigned pending = (1u << (p.ksplit - 1)) - 1u;
-            for (unsigned spins = 0; pending; ++spins) {
-#pragma unroll
-                for (int k = 0; k < KMAX - 1; ++k)
-                    if (pending & (1u << k)) v[k] = __hip_atomic_load(p.gran + (size_t)k * slab + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int k = 0; k < KMAX - 1; ++k)
-                    if ((pending & (1u << k)) && (unsigned)(v[k] >> 32) == tag) pending &= ~(1u << k);
-                if (pending && spins > p.max_spins) { gave_up = true; break; }
-                if (pending) __builtin_amdgcn_s_sleep(2);
-            }
-#pragma unroll
-            for (int k = 0; k < KMAX - 1; ++k)
-                if (k < p.ksplit - 1) t += as_f32((unsigned)(v[k] & 0xffffffffu));
-            // consumed granules are cleared: between launches the exchange area holds NO valid tag, so a tag that is valid now was written by
-            // this launch -- per-strip epochs alone would let a strip whose epoch lags (it is used by fewer layers of the model) accept what
-            // another layer published at the same address under the same number
-#pragma unroll
-            for (int k = 0; k < KMAX - 1; ++k)
-                if (k < p.ksplit - 1) __hip_atomic_store(p.gran + (size_t)k * slab + at, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (sg.bias) t += DType<T>::to_f32(((const T*)sg.bias)[n]);
-        ((T*)sg.out)[(size_t)m * N + n] = DType<T>::from_f32(t);
-    };
-    if ((W & (W - 1)) == 0) {
-        // every wave takes 64 / W entries per round; its lanes are (entry, partial w) pairs: one LDS read each, then a fixed
-        // xor tree over the W lanes of an entry (deterministic order) -- instead of one thread walking W slabs per entry
-        const int lw = __builtin_ctz((unsigned)W);
-        const int w_of_lane = lane & (W - 1), e_of_lane = lane >> lw;
-        for (int e0 = 0; e0 < E; e0 += 64) {
-            const int e = e0 + wave * (64 >> lw) + e_of_lane;
-            float t = (e < E) ? red[w_of_lane * ES + e] : 0.f;
-            for (int off = 1; off < W; off <<= 1) t += __shfl_xor(t, off, 64);
-            if (w_of_lane == 0 && e < E) emit(e, t);
-        }
-    } else {
-        for (int e = tid; e < E; e += blockDim.x) {
-            float t = 0.f;
-            for (int w = 0; w < W; ++w) t += red[w * ES + e];
-            emit(e, t);
-        }
-    }
-    if (p.ksplit > 1 && ks == 0) {
-        if (gave_up) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();                                                      // every wave of the owner has its granules: every producer wave has read the epoch
-        if (tid == 0) __hip_atomic_store(p.epochs + sidx, (tag & 0x1FFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    stream_epilogue<LN, MT, T>(acc, p, sg, strip, sidx, ks, N, red);
 }
 
-// ---- magic-number field decode for the 3- and 8-bit fp16 matrix-core GEMV ------------------------------------------------------
-// The generic kernel below extracts every field on its own (shift, mask, integer subtract, two conversions: ~5.3 VALU per
-// weight; the 3-bit g32 decode launch is 912 VALU per wave and spends as long on them as on its loads).  For fp16 the same exact
-// w - z comes out of packed arithmetic two fields at a time, like the 4-bit kernels do: (t & (7 << s) * 0x00010001) | 0x64006400 is
-// the half2 (1024 + f_a * 2^s, 1024 + f_b * 2^s) for the two fields sitting at bit s of the two 16-bit halves of t, and ONE
-// v_pk_fma_f16 by 2^-s with -(1024 * 2^-s + z) gives (f_a - z, f_b - z) exactly (s + bits <= 10: the field stays inside the
-// mantissa; every intermediate is an integer below 2048).
-//   8-bit: the word itself pairs (f0, f2) and, shifted by 8, (f1, f3): 1 shift + 2 v_and_or + 2 v_pk_add per 4 weights.
-//   3-bit: 32 fields in 96 bits do not line up with the halves, but 16-bit WINDOWS of the bit stream at multiples of 15 bits do:
-//          t_k = (stream >> 30k)[15:0] | (stream >> (30k + 15))[15:0] << 16 holds fields 10k..10k+4 in the low half and 10k+5..10k+9 in
-//          the high half at the same bit positions 0, 3, 6, 9, 12 (9 and 12 are brought down to 3 and 6 by one shift of the whole
-//          word); fields 30 and 31 are a fourth window pair.  <= 3 VALU per t_k, then 1 v_and_or + 1 v_pk op per pair: 46 VALU per
-//          32 weights instead of ~170.
-// The pairs put the unit's k values into matrix-core slots in the order ka(p), kb(p); x is brought into the same order with one
-// v_perm per pair (shared by the lane's 4 columns).  bf16 has neither the mantissa (7 bits) nor packed arithmetic for this and keeps
-// the field-by-field form, as do 2-bit layers.
-// The masks and the magic number reach the expressions as OPAQUE register values (one-instruction asm definitions at kernel start,
-// as in the 4-bit kernels): with literal operands hipcc splits (t & mask) | magic into v_and + v_or (VOP3 takes no literals on gfx9).
-// The expressions themselves stay C on purpose.  A first version issued v_and_or_b32 from inline asm inside the loop and returned
-// garbage / NaN in columns 1 and 2 of every lane at M = 2: with two rows of x the upper half of a 4x4x4 accumulator is dead, the
-// register allocator reuses it for the next column's B fragments, and a VALU write hidden in asm is invisible to the hazard
-// recognizer -- it landed BEFORE the in-flight MFMA's write of the same (dead) register, which then overwrote the fragment.
-struct MagicConsts {
-    unsigned magic, m0, m3, m6, m8;      // 0x64006400 (VGPR); 3-bit field masks at bits 0 / 3 / 6 of both halves, 8-bit mask (SGPRs)
-    __device__ __forceinline__ void init() {
-        asm("v_mov_b32 %0, 0x64006400" : "=v"(magic));
-        asm("s_mov_b32 %0, 0x00070007" : "=s"(m0));
-        asm("s_mov_b32 %0, 0x00380038" : "=s"(m3));
-        asm("s_mov_b32 %0, 0x01c001c0" : "=s"(m6));
-        asm("s_mov_b32 %0, 0x00ff00ff" : "=s"(m8));
-    }
-};
-__device__ __forceinline__ unsigned f16x2_bits(f16x2 v) { return __builtin_bit_cast(unsigned, v); }
+// ---- the streamed kernel for 3- and 8-bit fp16 layers (BASELINE config 5) ----------------------------------------------------------------
+// The structure of gemv_q4_stream_kernel (weights by LDS DMA into per-wave landing areas, up to four layers that share x in one launch,
+// K slices combined through granules) with the packing units and the magic-number decode of gemv_mfma_generic_kernel: a unit is one word
+// of 4 values (8-bit) or three words of 32 values (3-bit), a lane owns 4 adjacent columns and U consecutive units of ONE group, every
+// word of a unit is its own 1 KiB wave DMA (row (unit * UW + w) of the packed matrix), and unit j is consumed as soon as its UW DMAs
+// have landed.  Same values as the register kernel, bit for bit (same pairs, same matrix-core order, fp32 group sums times the scale).
+template <int BITS, int LN, int MT, int U>
+__global__ void __launch_bounds__(1024, 4) gemv_qx_stream_kernel(GemvStreamParams p) {
+    static_assert(BITS == 3 || BITS == 8, "4-bit layers have their own kernel");
+    using T = f16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int UW = Pack<BITS>::words, KPU = Pack<BITS>::vals, WR = 64 / LN, CT = LN * 4;
+    constexpr int XV = KPU / 8;                                               // 16-byte x pieces per unit (8-bit: half a piece)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
+    const int cl = lane % LN, rs = lane / LN;
+    char* const wq = smem + (size_t)wave * (U * UW * 1024);                   // this wave's DMA landing area
+    const unsigned wq_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)wq);
+    float* const red = (float*)(smem + (size_t)W * (U * UW * 1024));          // [W][MT][CT] cross-wave sums, + 1 word
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int sidx = L / p.ksplit, ks = L - sidx * p.ksplit;
+    int s = 0;
+    while (s + 1 < p.nseg && sidx >= p.seg[s].blk_end) ++s;                   // wave-uniform (kernel arguments only)
+    const GemvSeg& sg = p.seg[s];
+    const int strip = sidx - (s ? p.seg[s - 1].blk_end : 0);
+    const int N = sg.N;
+    const int n0 = strip * CT + cl * 4;
+    const bool col_ok = n0 < N;
+    const int nload = col_ok ? n0 : 0;
+    const int ub = ks * p.units_per_split;
+    const int ue = min(ub + p.units_per_split, p.units_total);
+    const T* xrow = (const T*)p.x + (size_t)min(lane & 3, p.M - 1) * p.K;     // A operand: lane i of a 4-lane group carries x row i
+    const T* __restrict__ scales = (const T*)sg.scales;
+    const unsigned* __restrict__ qweight = sg.qweight;
+    const int zrow_words = N / 32 * BITS;
+    const unsigned zbit = (unsigned)BITS * (unsigned)nload;                    // the lane's 4 zero-points: 4 * BITS bits from here (one or two words)
+    const unsigned zwi = zbit >> 5, zsh = zbit & 31;
+    const bool z2 = zsh + 4u * BITS > 32u;
+    const int gshift = p.gu_shift;
+    constexpr unsigned maxq = (1u << BITS) - 1u;
 
-template <int BITS> struct MagicF16;
-template <> struct MagicF16<8> {
-    static constexpr int NP = 2;                                   // pairs per unit (4 values)
-    static constexpr int ka(int p) { return p; }                  // (0, 2), (1, 3)
-    static constexpr int kb(int p) { return p + 2; }
-    f16x2 c1;
-    __device__ __forceinline__ void setup(int z) { c1 = as_f16x2((unsigned)z * 0x00010001u + 0xE400E400u); }    // -(1024 + z), z <= 256
-    __device__ __forceinline__ void pairs(const unsigned (&w)[1], const MagicConsts& k, unsigned (&bp)[NP]) const {
-        bp[0] = f16x2_bits(as_f16x2((w[0] & k.m8) | k.magic) + c1);
-        bp[1] = f16x2_bits(as_f16x2(((w[0] >> 8) & k.m8) | k.magic) + c1);
+    float acc[4][MT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[c][m] = 0.f;
+    MagicConsts mk;
+    mk.init();
+
+    const int rows_per_iter = W * WR * U;
+    for (int base = ub; base < ue; base += rows_per_iter) {
+        const int u0 = base + (wave * WR + rs) * U;
+        const int g = min(u0, ue - 1) >> gshift;
+        // small L2-resident loads first (they return first), then the DMA burst; nothing is computed on loaded values up here
+        const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * N + nload);
+        const unsigned* zrow = sg.qzeros + (size_t)g * zrow_words;
+        const unsigned zlo = zrow[zwi];
+        const unsigned zhi = z2 ? zrow[zwi + 1] : 0u;
+        unsigned xr[U][KPU / 2];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const T* xp = xrow + (size_t)min(u0 + j, ue - 1) * KPU;
+            if constexpr (KPU == 4) {
+                const u32x2 t = *(const u32x2*)xp;
+                xr[j][0] = t[0]; xr[j][1] = t[1];
+            } else {
+#pragma unroll
+                for (int v = 0; v < XV; ++v) {
+                    const u32x4 t = *(const u32x4*)(xp + 8 * v);
+                    xr[j][4 * v] = t[0]; xr[j][4 * v + 1] = t[1]; xr[j][4 * v + 2] = t[2]; xr[j][4 * v + 3] = t[3];
+                }
+            }
+        }
+        if (base != ub) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // WAR: last iteration's ds_reads are done
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int ul = min(u0 + j, ue - 1);
+#pragma unroll
+            for (int w = 0; w < UW; ++w) dma16_nt(qweight + (size_t)(ul * UW + w) * N + nload, wq_lds + (j * UW + w) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long zv = (((unsigned long long)zhi << 32) | zlo) >> zsh;
+        MagicF16<BITS> mg[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int f = (int)((unsigned)(zv >> (BITS * c)) & maxq) + 1;
+            mg[c].setup((p.zero_mode == GPTQ_ZERO_WRAP) ? (f & (int)maxq) : f);
+        }
+        f32x4 accg[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) accg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // unit j is consumed as soon as its UW DMAs have landed (vmcnt retires in order; the U * UW DMAs are the wave's youngest VMEM operations)
+        [&]<int... J>(std::integer_sequence<int, J...>) {
+            (([&] {
+                 constexpr int j = J;
+                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((U - 1 - j) * UW) : "memory");
+                 u32x4 qv[UW];
+#pragma unroll
+                 for (int w = 0; w < UW; ++w) qv[w] = *(const u32x4*)(wq + (j * UW + w) * 1024 + lane * 16);
+                 const bool live = (u0 + j < ue);
+                 unsigned xa[KPU / 2];                                        // x in the slot order of the pairs, shared by the 4 columns
+                 [&]<int... P>(std::integer_sequence<int, P...>) {
+                     ((xa[P] = live ? magic_x_pair<BITS, P>(xr[j]) : 0u), ...);
+                 }(std::make_integer_sequence<int, KPU / 2>{});
+#pragma unroll
+                 for (int c = 0; c < 4; ++c) {
+                     unsigned wds[UW], bp[KPU / 2];
+#pragma unroll
+                     for (int w = 0; w < UW; ++w) wds[w] = qv[w][c];
+                     mg[c].pairs(wds, mk, bp);
+#pragma unroll
+                     for (int Q = 0; Q < KPU / 4; ++Q)
+                         accg[c] = Mma4<T>::run(u32x2{xa[2 * Q], xa[2 * Q + 1]}, u32x2{bp[2 * Q], bp[2 * Q + 1]}, accg[c]);
+                 }
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, U>{});
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned sh = (c & 1) ? (sraw[c >> 1] >> 16) : (sraw[c >> 1] & 0xffffu);
+            const float sc = DType<T>::to_f32(__builtin_bit_cast(T, (unsigned short)sh));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[c][m] = fmaf(sc, accg[c][m], acc[c][m]);
+        }
     }
-};
-template <> struct MagicF16<3> {
-    static constexpr int NP = 16;                                  // pairs per unit (32 values in 3 words)
-    static constexpr int ka(int p) { return p < 15 ? 10 * (p / 5) + p % 5 : 30; }
-    static constexpr int kb(int p) { return p < 15 ? ka(p) + 5 : 31; }
-    f16x2 c1, c3, c6;
-    __device__ __forceinline__ void setup(int z) {                 // z <= 8
-        c1 = as_f16x2((unsigned)z * 0x00010001u + 0xE400E400u);   // -(1024 + z)
-        const f16x2 k896 = {(f16)896.f, (f16)896.f}, k1008 = {(f16)1008.f, (f16)1008.f};
-        c3 = c1 + k896;                                            // -(128 + z), exact
-        c6 = c1 + k1008;                                           // -(16 + z), exact
-    }
-    __device__ __forceinline__ void five(unsigned t, const MagicConsts& k, unsigned* bp) const {
-        const f16x2 r8 = {(f16)0.125f, (f16)0.125f}, r64 = {(f16)0.015625f, (f16)0.015625f};
-        const unsigned t6 = t >> 6;
-        bp[0] = f16x2_bits(as_f16x2((t & k.m0) | k.magic) + c1);
-        bp[1] = f16x2_bits(as_f16x2((t & k.m3) | k.magic) * r8 + c3);
-        bp[2] = f16x2_bits(as_f16x2((t & k.m6) | k.magic) * r64 + c6);
-        bp[3] = f16x2_bits(as_f16x2((t6 & k.m3) | k.magic) * r8 + c3);
-        bp[4] = f16x2_bits(as_f16x2((t6 & k.m6) | k.magic) * r64 + c6);
-    }
-    __device__ __forceinline__ void pairs(const unsigned (&w)[3], const MagicConsts& k, unsigned (&bp)[NP]) const {
-        // 16-bit windows of the 96-bit stream at bits 0 / 15, 30 / 45, 60 / 75, 90 / 93 (low half / high half of t)
-        const unsigned t0 = __builtin_amdgcn_perm(w[0] >> 15, w[0], 0x05040100u);
-        const unsigned t1 = __builtin_amdgcn_perm(w[1] >> 13, __builtin_amdgcn_alignbit(w[1], w[0], 30), 0x05040100u);
-        const unsigned t2 = __builtin_amdgcn_perm(w[2] >> 11, __builtin_amdgcn_alignbit(w[2], w[1], 28), 0x05040100u);
-        const unsigned t3 = __builtin_amdgcn_perm(w[2] >> 29, w[2] >> 26, 0x05040100u);
-        five(t0, k, bp);
-        five(t1, k, bp + 5);
-        five(t2, k, bp + 10);
-        bp[15] = f16x2_bits(as_f16x2((t3 & k.m0) | k.magic) + c1);
-    }
-};
-// x values of one unit (natural order, two per register) -> the register holding (x[ka(P)], x[kb(P)])
-template <int BITS, int P, int NR>
-__device__ __forceinline__ unsigned magic_x_pair(const unsigned (&xr)[NR]) {
-    constexpr int a = MagicF16<BITS>::ka(P), b = MagicF16<BITS>::kb(P);
-    constexpr unsigned sel = ((a & 1) ? 0x0302u : 0x0100u) | (((b & 1) ? 0x0706u : 0x0504u) << 16);
-    return __builtin_amdgcn_perm(xr[b >> 1], xr[a >> 1], sel);
+    stream_epilogue<LN, MT, T>(acc, p, sg, strip, sidx, ks, N, red);
 }
 
 // ---- matrix-core GEMV, any bits, fp16 / bf16 -----------------------------------------------------
@@ -1803,9 +1941,17 @@ static hipError_t launch_fast_mt(const GemvPlan& pl, const GemvParams& p, hipStr
 
 // ---- streamed kernel: plan + launch ------------------------------------------------------------------------------------
 static bool stream_layer_ok(const gptq_layer_t& L) {
-    const int gu = L.group_size / 8;
-    return L.bits == 4 && (L.dtype == GPTQ_F16 || L.dtype == GPTQ_BF16) && L.g_idx == nullptr && L.epilogue == GPTQ_EPI_NONE &&
-           L.group_size % 8 == 0 && gu >= 2 && (gu & (gu - 1)) == 0 && L.K % 8 == 0;
+    if (L.g_idx != nullptr || L.epilogue != GPTQ_EPI_NONE) return false;
+    if (L.bits == 4) {
+        const int gu = L.group_size / 8;
+        return (L.dtype == GPTQ_F16 || L.dtype == GPTQ_BF16) && L.group_size % 8 == 0 && gu >= 2 && (gu & (gu - 1)) == 0 && L.K % 8 == 0;
+    }
+    if ((L.bits == 3 || L.bits == 8) && L.dtype == GPTQ_F16) {       // gemv_qx_stream_kernel: packed magic-number decode, fp16 only
+        const int kpu = unit_vals(L.bits);
+        const int gu = L.group_size / kpu;
+        return L.group_size % kpu == 0 && gu >= 1 && (gu & (gu - 1)) == 0 && L.K % kpu == 0 && L.N % 32 == 0;
+    }
+    return false;
 }
 
 // Measured preferences (tools/stream_sweep.py on MI355X, rotating HBM-cold weights inside a hipGraph, M = 1, us per launch;
@@ -1836,7 +1982,16 @@ static int stream_default_ln(const gptq_layer_t* const* Ls, int n) {
 // 17920x6656 25.1 / 29.7 -> 17.4 / 20.6).  Smaller or flatter layers (8192x3584, 3584x8192, 8192x1024, 4096x4096): equal or slower.
 static bool stream_big_single(const gptq_layer_t& L) { return L.K >= 5120 && L.N >= 5120; }
 
+// 3- / 8-bit fp16 single layers: the streamed kernel instead of gemv_mfma_generic_kernel?  (filled in from tools/stream_sweep.py --bits)
+static bool stream_preferred_qx(const gptq_layer_t& L, int M) {
+    // int8 from ~40 M weights (4096x11008: 17.8 -> 14.0 us, 11008x4096: 16.3 -> 13.9; 4096x4096 stays at 7.7 on the register kernel);
+    // int3 single layers stay on the register kernel (9.7 against 10.0 us): its multi-layer launches are what the streamed form is for
+    (void)M;
+    return L.bits == 8 && (size_t)L.K * L.N >= ((size_t)40 << 20);
+}
+
 bool stream_preferred(const gptq_layer_t& L, int M) {
+    if (L.bits != 4) return stream_preferred_qx(L, M);
     const gptq_layer_t* one[1] = {&L};
     const int s16 = stream_strips64(one, 1);
     if (stream_big_single(L)) return true;                       // M <= 4 (plan_stream)
@@ -1849,7 +2004,7 @@ bool multi_preferred(const gptq_layer_t* const* layers, int n, int M) {
     // separate): 7B q|k|v 8.9 vs 15.1, 13B q|k|v 14.6 vs 22.5, 13B gate|up (71 MB) 20.7 vs 25.6, 70B GQA q|k|v 14.6 vs 22.4,
     // 70B gate|up (244 MB) 57.7 vs 55.0 -- beyond ~128 MB the layers run one by one (each then takes its own best plan)
     size_t bytes = 0;
-    for (int i = 0; i < n; ++i) bytes += (size_t)layers[i]->K * layers[i]->N / 2;
+    for (int i = 0; i < n; ++i) bytes += (size_t)layers[i]->K * layers[i]->N * layers[i]->bits / 8;
     return n >= 2 && bytes <= ((size_t)128 << 20);
 }
 
@@ -1860,15 +2015,19 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     for (int i = 0; i < n; ++i) {
         const gptq_layer_t& L = *Ls[i];
         if (!stream_layer_ok(L)) return pl;
-        if (L.K != A.K || L.group_size != A.group_size || L.dtype != A.dtype || L.zero_mode != A.zero_mode) return pl;
+        if (L.K != A.K || L.group_size != A.group_size || L.dtype != A.dtype || L.zero_mode != A.zero_mode || L.bits != A.bits) return pl;
     }
     pl.nseg = n;
     pl.mt = M >= 3 ? 4 : M;
-    pl.units_total = A.K / 8;
-    const int gu = A.group_size / 8;
-    const bool big1 = n == 1 && stream_big_single(A);
-    int ln = (tune && tune->lanes_n) ? tune->lanes_n : (big1 ? (A.N >= 16384 ? 16 : 8) : stream_default_ln(Ls, n));
+    const int kpu = unit_vals(A.bits), uw = unit_words(A.bits);
+    const bool q4 = A.bits == 4;
+    pl.units_total = A.K / kpu;
+    const int gu = A.group_size / kpu;
+    const bool big1 = q4 && n == 1 && stream_big_single(A);
+    // 3- / 8-bit (tools/stream_sweep.py --bits 8 / 3 --gs 32, profiles/r03_stream_sweep_int{8,3}_g32.log): 32-column strips (128-byte row segments)
+    int ln = (tune && tune->lanes_n) ? tune->lanes_n : (!q4 ? 8 : (big1 ? (A.N >= 16384 ? 16 : 8) : stream_default_ln(Ls, n)));
     if (ln != 4 && ln != 8 && ln != 16) return pl;
+    if (!q4 && ln == 16) return pl;                               // 3- / 8-bit: 16- and 32-column strips
     const int ct = ln * 4, wr = 64 / ln;
     int strips = 0, nsum = 0;
     for (int i = 0; i < n; ++i) {
@@ -1879,9 +2038,15 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     pl.strips_total = strips;
     pl.nsum = nsum;
     int ks = (tune && tune->ksplit) ? tune->ksplit : 0;
+    if (!ks && !q4 && A.bits == 8 && n == 1) {
+        // int8 single layers run best as ~512-700 small workgroups: 4096x11008 (344 strips) x 2 slices 14.0 us, 11008x4096 (128 strips) x 4 slices
+        // 13.9 us, against 17.8 / 16.3 for the register kernel
+        ks = strips >= 256 ? 2 : 1;
+        while (strips * ks < 512 && ks < 8 && pl.units_total / (ks * 2) >= wr * 4) ks *= 2;
+    }
     if (!ks) {
         ks = 1;
-        while (strips * ks < 128 && pl.units_total / (ks * 2) >= wr * 4) ks *= 2;   // the in-launch combine costs ~1.5-2 us: 172 unsplit workgroups beat 344 split ones
+        while (q4 && strips * ks < 128 && pl.units_total / (ks * 2) >= wr * 4) ks *= 2;   // the in-launch combine costs ~1.5-2 us: 172 unsplit workgroups beat 344 split ones
     }
     if (ks > pl.units_total) ks = pl.units_total;
     int ups = (pl.units_total + ks - 1) / ks;
@@ -1892,6 +2057,16 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     int waves = 0, u = 0;
     if (tune && tune->waves && tune->reserved[0]) {
         waves = tune->waves; u = tune->reserved[0];
+    } else if (!q4) {              // 3- / 8-bit: small workgroups, several per CU (int8: 4 waves x 2..4 units = 8-16 KiB in flight each; int3: 8 waves x 1 unit = 24 KiB)
+        if (A.bits == 8) {
+            waves = 4;
+            u = (strips >= 256 && (n == 1 || strips >= 512)) ? 2 : 4;
+            if (u > ucap) u = ucap;
+            while (u > 2 && pl.units_total % u) u /= 2;
+        } else {
+            waves = 8; u = 1;
+        }
+        while (waves > 1 && (waves / 2) * wr * u >= ups) waves /= 2;
     } else if (big1) {
         waves = 8; u = ucap < 4 ? ucap : 4;
     } else {
@@ -1910,13 +2085,14 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
             while (waves > 1 && (waves / 2) * wr * u >= ups) waves /= 2;
         }
     }
-    if (waves < 1 || waves > 16 || (u != 2 && u != 4 && u != 8) || u > ucap || pl.units_total % u) return pl;
+    if (q4 ? (u != 2 && u != 4 && u != 8) : (A.bits == 8 ? (u != 2 && u != 4 && u != 8) : (u != 1 && u != 2))) return pl;
+    if (waves < 1 || waves > 16 || u > ucap || pl.units_total % u) return pl;
     ups = (ups + u - 1) / u * u;                        // a lane's U rows start on a multiple of U: slices do too
     pl.units_per_split = ups;
     pl.ksplit = (pl.units_total + ups - 1) / ups;       // no empty slices
     pl.waves = waves;
     pl.u = u;
-    pl.lds_bytes = (size_t)waves * u * 1024 + (size_t)waves * (pl.mt * ct + 4) * sizeof(float) + 16;
+    pl.lds_bytes = (size_t)waves * u * uw * 1024 + (size_t)waves * (pl.mt * ct + 4) * sizeof(float) + 16;
     if (pl.lds_bytes > 160 * 1024) return pl;
     if (pl.ksplit > 8) return pl;                          // the owner's poll is unrolled over at most 7 other slices
     pl.partial_bytes = pl.ksplit > 1 ? (size_t)(pl.ksplit - 1) * M * nsum * 8 : 0;      // {fp32, tag} granules of slices 1 ..
@@ -1962,6 +2138,47 @@ static hipError_t launch_stream_t(const StreamPlan& pl, const GemvStreamParams& 
     }
 }
 
+// 3- / 8-bit fp16 (gemv_qx_stream_kernel)
+template <int BITS, int LN, int MT, int U>
+static hipError_t launch_qx_one(const StreamPlan& pl, const GemvStreamParams& p, hipStream_t st) {
+    hipLaunchKernelGGL((gemv_qx_stream_kernel<BITS, LN, MT, U>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+    return hipGetLastError();
+}
+template <int BITS, int LN, int MT>
+static hipError_t launch_qx_u(const StreamPlan& pl, const GemvStreamParams& p, hipStream_t st) {
+    if constexpr (BITS == 8) {
+        switch (pl.u) {
+            case 2: return launch_qx_one<8, LN, MT, 2>(pl, p, st);
+            case 4: return launch_qx_one<8, LN, MT, 4>(pl, p, st);
+            case 8: return launch_qx_one<8, LN, MT, 8>(pl, p, st);
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (pl.u) {
+            case 1: return launch_qx_one<3, LN, MT, 1>(pl, p, st);
+            case 2: return launch_qx_one<3, LN, MT, 2>(pl, p, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
+}
+template <int BITS, int LN>
+static hipError_t launch_qx_mt(const StreamPlan& pl, const GemvStreamParams& p, hipStream_t st) {
+    switch (pl.mt) {
+        case 1: return launch_qx_u<BITS, LN, 1>(pl, p, st);
+        case 2: return launch_qx_u<BITS, LN, 2>(pl, p, st);
+        case 4: return launch_qx_u<BITS, LN, 4>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+template <int BITS>
+static hipError_t launch_qx_ln(const StreamPlan& pl, const GemvStreamParams& p, hipStream_t st) {
+    switch (pl.ln) {
+        case 4: return launch_qx_mt<BITS, 4>(pl, p, st);
+        case 8: return launch_qx_mt<BITS, 8>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_stream(const gptq_layer_t* const* Ls, const StreamPlan& pl, const void* x, void* const* outs, int M,
                          void* ws_header, void* ws_body, hipStream_t st) {
     if (!pl.ok) return hipErrorInvalidValue;
@@ -1982,8 +2199,10 @@ hipError_t launch_stream(const gptq_layer_t* const* Ls, const StreamPlan& pl, co
     p.max_spins = 1u << 20;
     p.nseg = pl.nseg; p.M = M; p.K = A.K; p.zero_mode = A.zero_mode;
     p.units_total = pl.units_total; p.units_per_split = pl.units_per_split; p.ksplit = pl.ksplit;
-    p.gu_shift = __builtin_ctz((unsigned)(A.group_size / 8));
+    p.gu_shift = __builtin_ctz((unsigned)(A.group_size / unit_vals(A.bits)));
     p.nsum = pl.nsum;
+    if (A.bits == 8) return launch_qx_ln<8>(pl, p, st);
+    if (A.bits == 3) return launch_qx_ln<3>(pl, p, st);
     return A.dtype == GPTQ_BF16 ? launch_stream_t<bf16>(pl, p, st) : launch_stream_t<f16>(pl, p, st);
 }
 
@@ -2002,6 +2221,11 @@ hipError_t init_gemv_device() {
     acc(grant_stream<8, 1, bf16>()); acc(grant_stream<8, 2, bf16>()); acc(grant_stream<8, 4, bf16>());
     acc(grant_stream<4, 1, bf16>()); acc(grant_stream<4, 2, bf16>()); acc(grant_stream<4, 4, bf16>());
     acc(grant_stream<16, 1, bf16>()); acc(grant_stream<16, 2, bf16>()); acc(grant_stream<16, 4, bf16>());
+    auto grant_qx = [&](auto kern) { acc(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); };
+    grant_qx(gemv_qx_stream_kernel<8, 4, 1, 8>); grant_qx(gemv_qx_stream_kernel<8, 4, 2, 8>); grant_qx(gemv_qx_stream_kernel<8, 4, 4, 8>);
+    grant_qx(gemv_qx_stream_kernel<8, 8, 1, 8>); grant_qx(gemv_qx_stream_kernel<8, 8, 2, 8>); grant_qx(gemv_qx_stream_kernel<8, 8, 4, 8>);
+    grant_qx(gemv_qx_stream_kernel<3, 4, 1, 2>); grant_qx(gemv_qx_stream_kernel<3, 4, 2, 2>); grant_qx(gemv_qx_stream_kernel<3, 4, 4, 2>);
+    grant_qx(gemv_qx_stream_kernel<3, 8, 1, 2>); grant_qx(gemv_qx_stream_kernel<3, 8, 2, 2>); grant_qx(gemv_qx_stream_kernel<3, 8, 4, 2>);
     return e;
 }
 

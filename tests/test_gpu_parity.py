@@ -1301,6 +1301,66 @@ def test_streamed_gemv_vs_oracle(K, N, gs, M, ln, waves, u, ksplit, dtype):
         _assert_close(y1, ref, ref, dtype, K, f"streamed gemv ln={ln} waves={waves} u={u} ksplit={ksplit}")
 
 
+@pytest.mark.parametrize("bits,ln,waves,u,ksplit", [(8, 4, 16, 4, 1), (8, 4, 4, 2, 1), (8, 8, 8, 8, 2), (8, 4, 8, 8, 3), (8, 8, 2, 4, 1),
+                                                    (3, 4, 16, 1, 1), (3, 4, 4, 1, 2), (3, 8, 8, 1, 1), (3, 4, 8, 2, 1), (3, 8, 4, 2, 4)])
+@pytest.mark.parametrize("K,N,gs,M", [(1024, 512, 32, 1), (2048, 96, 64, 3), (4096, 1056, 128, 4), (512, 2048, 32, 2), (11008, 256, 32, 1)])
+def test_streamed_gemv_3_and_8_bit(K, N, gs, M, bits, ln, waves, u, ksplit):
+    """gemv_qx_stream_kernel (tuning.path = 6 on 3- / 8-bit fp16 layers): the packing units (one word of 4 values / three words of 32) by LDS DMA,
+    the packed magic-number decode, every launch geometry incl. ragged last strips, several passes over K, the in-launch K-split combine, bias,
+    both zero conventions (3-bit zero-points straddle words); against the fp64 oracle and BIT-equal to the register kernel with the same geometry
+    where that exists."""
+    kpu = 32 if bits == 3 else 4
+    if u > gs // kpu or (K // kpu) % u:
+        pytest.skip("u units of a lane must lie in one group")
+    L = O.random_quant_layer(K, N, bits, gs, dtype=torch.float16, seed=K + N + M + bits, bias=True)
+    for zm in ("wrap", "nowrap"):
+        q = _module_from(L["qweight"], L["qzeros"], L["scales"], None, L["bias"], bits, gs, zero_mode=zm)
+        x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).half()
+        t = _stream_tuning(ln, waves, u, ksplit)
+        q.post_init()
+        d = _lib.describe_plan(q._layer, M, t)
+        assert d["kernel"] == "stream" and d["ln"] == ln and d["waves"] == waves and d["u"] == u, d
+        with torch.no_grad():
+            y1 = q(x.to(DEV), tuning=t)
+            y2 = q(x.to(DEV), tuning=t)
+        assert torch.equal(y1, y2)
+        mode = O.ZERO_WRAP if zm == "wrap" else O.ZERO_NOWRAP
+        ref = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], None, L["bias"], bits, mode)
+        _assert_close(y1, ref, ref, torch.float16, K, f"streamed {bits}-bit gemv ln={ln} waves={waves} u={u} ksplit={ksplit}")
+        # one-hot rows on the bias-free layer: the exact dequantised rows come back (the scale multiplies the fp32 group sum, one rounding)
+        q0 = _module_from(L["qweight"], L["qzeros"], L["scales"], None, None, bits, gs, zero_mode=zm)
+        ks_ = (torch.arange(M) * 131 + 7) % K
+        xo = torch.zeros(M, K, dtype=torch.float16)
+        xo[torch.arange(M), ks_] = 1.0
+        with torch.no_grad():
+            yo = q0(xo.to(DEV), tuning=t).cpu()
+        W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], None, bits, mode)
+        assert torch.equal(yo, W[ks_])
+
+
+@pytest.mark.parametrize("bits,gs", [(8, 32), (3, 32), (8, 128), (3, 64)])
+@pytest.mark.parametrize("M", [1, 3])
+def test_forward_multi_3_and_8_bit_one_launch(bits, gs, M):
+    """gptq_forward_multi on 3- / 8-bit fp16 layers that share x: one gemv_qx_stream_kernel launch (forced and by default), every layer against
+    the fp64 oracle and equal to its own single-layer forward within the tolerance."""
+    from autogptq_amd.qlinear_mi355x import forward_multi
+    K, widths = 2048, (512, 96, 1024)
+    Ls = [O.random_quant_layer(K, n, bits, gs, seed=31 + i + M + bits, bias=(i == 1), dtype=torch.float16) for i, n in enumerate(widths)]
+    qs = [_module_from(L["qweight"], L["qzeros"], L["scales"], None, L["bias"], bits, gs) for L in Ls]
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).half().to(DEV)
+    t = _tuning(path=6)
+    with torch.no_grad():
+        yf = forward_multi(qs, x, tuning=t)
+        yd = forward_multi(qs, x)
+        sep = [q(x) for q in qs]
+    mode = O.reference_zero_mode(False, bits)
+    for y, d, s_, L in zip(yf, yd, sep, Ls):
+        ref = O.forward_f64(x.cpu(), L["qweight"], L["qzeros"], L["scales"], None, L["bias"], bits, mode)
+        _assert_close(y, ref, ref, torch.float16, K, "qx multi (forced) vs oracle")
+        _assert_close(d, ref, ref, torch.float16, K, "qx multi (default) vs oracle")
+        _assert_close(s_, ref, ref, torch.float16, K, "single layer vs oracle")
+
+
 @pytest.mark.parametrize("M", [1, 2, 4, 5, 40])
 @pytest.mark.parametrize("act", [False, True])
 def test_forward_multi_equals_layer_by_layer(M, act):

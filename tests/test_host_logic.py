@@ -319,9 +319,18 @@ def test_dispatch_rules_are_the_measured_ones():
     # 2/3/8-bit: the weight-streaming GEMMs take over from 5 rows (int8); int3 keeps the GEMV to 8.  Act-order layers with the re-sequenced
     # side copy run the SAME kernels on a permuted x (perm = 2: one pre-pass, GEMV and GEMM alike), so they share those crossovers
     assert _plan(4096, 11008, 4, bits=8, gs=32)["path"] == "gemv" and _plan(4096, 11008, 8, bits=8, gs=32)["path"] == "gemm"
-    for m in (1, 2, 4):
+    for m in (1, 2, 4):                                   # int8 from ~40 M weights: the streamed 3- / 8-bit kernel (gemv_qx_stream_kernel) on a permuted x
         p = _plan(4096, 11008, m, bits=8, gs=32, act=True)
-        assert (p["path"], p["kernel"], p["perm"], p.get("deq")) == ("gemv", "mfma_generic", 2, "magic"), (m, p)
+        assert (p["path"], p["kernel"], p["perm"], p["ln"]) == ("gemv", "stream", 2, 8), (m, p)
+    p = _plan(4096, 4096, 2, bits=8, gs=32, act=True)
+    assert (p["path"], p["kernel"], p["perm"], p.get("deq")) == ("gemv", "mfma_generic", 2, "magic"), p
+    # int8 single layers: streamed from ~40 M weights (32-column strips, 4-wave workgroups, 2..4 in-launch K slices); int3 and small int8 layers: register kernel
+    p = _plan(4096, 11008, 1, bits=8, gs=32)
+    assert (p["kernel"], p["ln"], p["waves"], p["u"], p["ksplit"], p["strips"]) == ("stream", 8, 4, 2, 2, 344), p
+    p = _plan(11008, 4096, 4, bits=8, gs=32)
+    assert (p["kernel"], p["ln"], p["waves"], p["u"], p["ksplit"], p["mt"]) == ("stream", 8, 4, 4, 4, 4), p
+    assert _plan(4096, 4096, 1, bits=8, gs=32)["kernel"] == "mfma_generic" and _plan(4096, 11008, 1, bits=3, gs=32)["kernel"] == "mfma_generic"
+    assert _plan(4096, 11008, 1, bits=8, gs=32, dtype=1)["kernel"] == "mfma_generic"          # bf16: no packed magic-number decode
     assert _plan(4096, 11008, 8, bits=8, gs=32, act=True)["path"] == "gemm"
     p = _plan(4096, 11008, 8, bits=3, gs=32, act=True)
     assert _plan(4096, 11008, 8, bits=3, gs=32)["path"] == "gemv" and (p["path"], p["kernel"], p["perm"]) == ("gemv", "mfma_generic", 2), p

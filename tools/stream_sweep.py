@@ -46,23 +46,25 @@ def main():
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--shapes", default="4096x4096,4096x11008,11008x4096")
     ap.add_argument("--no-multi", action="store_true")
+    ap.add_argument("--bits", type=int, default=4)
+    ap.add_argument("--gs", type=int, default=128)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
     M = args.m
     for K, N in [tuple(map(int, sh.split('x'))) for sh in args.shapes.split(',')]:
-        per = K * N // 2
+        per = K * N * args.bits // 8
         nl = max(4, min(64, (512 << 20) // per))
-        layers = [make_layer(K, N, dev, dtype=dt, seed=i) for i in range(nl)]
+        layers = [make_layer(K, N, dev, bits=args.bits, gs=args.gs, dtype=dt, seed=i) for i in range(nl)]
         x = (torch.rand(M, K, device=dev) - 0.5).to(dt)
-        ab = algorithmic_bytes(K, N, M)
+        ab = algorithmic_bytes(K, N, M, bits=args.bits, gs=args.gs)
         res = []
         base, ref = timed(lambda: [q(x) for q in layers])
         res.append((base / nl, "register kernel (default plan)"))
-        rows = K // 8
+        rows = K // (32 // args.bits if args.bits != 3 else 32)
         for ln in (4, 8, 16):
             wr = 64 // ln
-            for waves, u in ((2, 8), (4, 2), (4, 4), (4, 8), (8, 2), (8, 4), (8, 8), (16, 2), (16, 4), (16, 8)):
+            for waves, u in ((2, 8), (4, 2), (4, 4), (4, 8), (8, 2), (8, 4), (8, 8), (16, 2), (16, 4), (16, 8), (4, 1), (8, 1), (16, 1)):
                 for ks in ((1, 2, 4, 8) if N < 4096 else ((1,) if ln == 4 else (1, 2, 4))):
                     if N // (4 * ln) * ks < 96 or N // (4 * ln) * ks > 1024:
                         continue
@@ -83,15 +85,15 @@ def main():
         torch.cuda.empty_cache()
     # multi-layer launches: groups of layers sharing x
     for name, K, Ns in () if args.no_multi else (("qkv", 4096, (4096, 4096, 4096)), ("gate_up", 4096, (11008, 11008))):
-        ng = max(3, (512 << 20) // (K * sum(Ns) // 2))
-        groups = [[make_layer(K, n, dev, dtype=dt, seed=100 * gi + i) for i, n in enumerate(Ns)] for gi in range(ng)]
+        ng = max(3, (512 << 20) // (K * sum(Ns) * args.bits // 8))
+        groups = [[make_layer(K, n, dev, bits=args.bits, gs=args.gs, dtype=dt, seed=100 * gi + i) for i, n in enumerate(Ns)] for gi in range(ng)]
         x = (torch.rand(M, K, device=dev) - 0.5).to(dt)
-        ab = sum(algorithmic_bytes(K, n, M) for n in Ns)
+        ab = sum(algorithmic_bytes(K, n, M, bits=args.bits, gs=args.gs) for n in Ns)
         res = []
         base, ref = timed(lambda: [[q(x) for q in grp] for grp in groups])
         res.append((base / ng, "separate launches (register kernel)"))
         for ln in (4, 8, 16):
-            for waves, u in ((2, 8), (4, 2), (4, 4), (4, 8), (8, 2), (8, 4), (16, 2), (16, 4), (8, 8), (16, 8)):
+            for waves, u in ((2, 8), (4, 2), (4, 4), (4, 8), (8, 2), (8, 4), (16, 2), (16, 4), (8, 8), (16, 8), (4, 1), (8, 1), (16, 1)):
               for ks in ((1,) if ln == 4 else (1, 2, 4)):
                 t = tune(path=6, lanes_n=ln, waves=waves, ksplit=ks, u=u)
                 try:
