@@ -355,6 +355,18 @@ def bench_config5(device, steps):
                 del la
             del ls, xs
             torch.cuda.empty_cache()
+        # the block's fused callers on this packing: q|k|v and gate|up through gptq_forward_multi (one streamed launch per group)
+        for gname, K, Ns in (("qkv", 4096, (4096, 4096, 4096)), ("gate_up", 4096, (11008, 11008))):
+            wbytes = K * sum(Ns) * bits // 8
+            n = max(3, -(-(320 << 20) // wbytes))
+            gs_ = [(gname, K, sum(Ns), [make_layer(K, nn, device, bits=bits, gs=32, seed=8000 + 10 * i + j) for j, nn in enumerate(Ns)]) for i in range(n)]
+            xs = {K: (torch.rand(1, K, device=device) - 0.5).half()}
+            per = _time_layers(gs_, xs, device, max(3, steps // 2))
+            ab = sum(algorithmic_bytes(K, nn, 1, bits=bits, gs=32) for nn in Ns)
+            res[f"int{bits}_g32_{gname}_one_launch"] = {"us": round(per * 1e6, 2), "GB_per_s": round(ab / per / 1e9, 1), "frac": round(ab / per / 1e9 / HBM_PEAK_GBS, 4),
+                                                        "plan": "gptq_forward_multi: " + " | ".join(f"{K}x{nn}" for nn in Ns)}
+            del gs_, xs
+            torch.cuda.empty_cache()
     return res
 
 
