@@ -392,7 +392,7 @@ static bool want_stream64_multi(const gptq_layer_t* const* layers, int n, int M,
 // 17 .. 128 rows, 2..4 layers sharing x in ONE gemm_mid_kernel launch: by the planner's measured preference, or forced with tuning.path = 3 and
 // tuning.reserved[2] = 5.
 static bool want_mid_multi(const gptq_layer_t* const* layers, int n, int M, const gptq_tuning_t* t) {
-    if (n < 2 || n > 4 || M > 128) return false;
+    if (n < 2 || n > 4 || M > 256) return false;
     const bool forced = t && t->path == 3 && t->reserved[2] == 5;
     if (t && t->path != 0 && !forced) return false;
     const MidPlan mp = plan_mid(layers, n, M, t);
@@ -461,7 +461,7 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
     if (tune && tune->path == 3 && tune->reserved[2] == 4)
         return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 3 / reserved[2] = 4: these layers do not fit one batched-decode launch (2..4 plain 4-bit layers, M <= 64)");
     if (tune && tune->path == 3 && tune->reserved[2] == 5)
-        return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 3 / reserved[2] = 5: these layers do not fit one gemm_mid_kernel launch (2..4 plain 4-bit layers, N %% 64 == 0, M <= 128)");
+        return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 3 / reserved[2] = 5: these layers do not fit one gemm_mid_kernel launch (2..4 plain 4-bit layers, N %% 64 == 0, M <= 256)");
     for (int i = 0; i < n_layers; ++i) {           // anything the one-launch kernel does not cover: the same result, layer by layer
         int rc = forward_impl(layers[i], x, outs[i], M, wv, stream, nullptr);
         if (rc) return rc;

@@ -1706,7 +1706,7 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
             pl.skinny = false;
             pl.midp = mp;
             pl.mt = mp.rt; pl.bk = 32; pl.bm = 16 * mp.rt; pl.bn = 64 * mp.cw;
-            pl.nbm = 1; pl.nbn = mp.strips_total;
+            pl.nbm = mp.row_blocks; pl.nbn = mp.strips_total;
             pl.waves = mp.waves; pl.u = mp.stages;
             pl.ksteps_total = mp.ksteps_total; pl.ksteps_per_split = mp.ksteps_per_split; pl.ksplit = mp.ksplit;
             pl.workspace_bytes = pl.xperm_bytes + mp.partial_bytes;

@@ -50,6 +50,7 @@ struct MidParams {
     int gran;            // 1: K slices 1.. publish {fp32, tag} granules (8 bytes per value) that the owner validates itself -- ONE memory hop;
                          // 0: fp32 partial tiles + one flag word per slice (publish, drain, flag, read: three)
     int nseg, M, K, zero_mode, ksplit, ksteps_per_split, nsum;
+    int strips_total;    // strips over all layers; the grid is strips_total x row_blocks x ksplit
     int lg_gsteps;       // log2(group_size / 32)
     int tab_bytes;       // per-wave group-constant table (256 B per group the wave can touch)
     unsigned max_spins;
@@ -160,12 +161,16 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
     char* const wbase = smem + (size_t)wave * wave_bytes;         // this wave's stages, then its group-constant table
     const unsigned w_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(wbase));
     // logical block -> (strip over all layers, K slice): slices of one strip are adjacent logical ids (one XCD after the remap)
+    // (a workgroup owns 16 RT rows of x: row blocks are what fills the chip on narrow layers WITHOUT K slices and their combine -- the weights of a
+    // strip are then streamed once per row block, out of the L2 after the first)
     const int Lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = Lb / p.ksplit, ks = Lb - tile * p.ksplit;
+    const int tile = Lb / p.ksplit, ks = Lb - tile * p.ksplit;    // tile = (row block, strip): index of the flag words too
+    const int rb = tile / p.strips_total, stile = tile - rb * p.strips_total;
+    const int m0 = rb * (RT * 16);
     int sI = 0;
-    while (sI + 1 < p.nseg && tile >= p.seg[sI].blk_end) ++sI;    // wave-uniform (kernel arguments only)
+    while (sI + 1 < p.nseg && stile >= p.seg[sI].blk_end) ++sI;   // wave-uniform (kernel arguments only)
     const MidSeg& sg = p.seg[sI];
-    const int strip = tile - (sI ? p.seg[sI - 1].blk_end : 0);
+    const int strip = stile - (sI ? p.seg[sI - 1].blk_end : 0);
     const int N = sg.N;
     const int S = p.K >> 5;
     const int b0 = ks * p.ksteps_per_split, b1 = min(b0 + p.ksteps_per_split, S);
@@ -217,7 +222,7 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
         {
             const int q = lane >> 2, a = lane & 3, oct = (a - (q >> 2)) & 3;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) xoff[rt] = (unsigned)(((size_t)min(rt * 16 + q, p.M - 1) * p.K + oct * 8) * 2);
+            for (int rt = 0; rt < RT; ++rt) xoff[rt] = (unsigned)(((size_t)min(m0 + rt * 16 + q, p.M - 1) * p.K + oct * 8) * 2);
         }
         const unsigned a_slot = (unsigned)((4 * j16 + ((kg + (j16 >> 2)) & 3)) * 16);   // where the MFMA lane (row j16, k-octet kg) finds its 16 bytes
         const char* const qw = (const char*)sg.qweight;
@@ -385,7 +390,7 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
             if (rt >= RT) continue;
             f32x4 v = slab[e];
             for (int w = 1; w < W; ++w) v += slab[(size_t)w * E + e];
-            const int m = rt * 16 + 4 * (ln >> 4) + (rr & 3);
+            const int m = m0 + rt * 16 + 4 * (ln >> 4) + (rr & 3);
             const int n = strip * SC + hh * 64 + (ln & 15) * 4;
             if (m >= p.M) continue;
             if (p.ksplit > 1 && p.gran) {
@@ -474,13 +479,30 @@ static bool mid_prefers_wide_strips(int M, int s128) {
     return false;
 }
 
+// Row blocks by default (filled in from tools/mid_sweep.py): 1 = the whole M in every workgroup
+// Row blocks.  Measured (profiles/r03_mid_kernel_row_blocks_sweep.log, ..._more_shapes.log; us, one block -> row blocks): 4096x4096 M = 64 14.7 -> 12.4
+// (2 blocks x 2 K slices), M = 96 19.2 -> 15.5 (3 blocks, no K split), M = 128 23.0 -> 16.4 (4 blocks, no K split): a strip's weights (K x 32 bytes)
+// come out of the L2 for every block after the first, which is cheaper than the K slices' combine while K is short AND the blocks fill the chip
+// (192..256 workgroups with at most 2 K slices): 5120x5120 with 2 blocks (160 workgroups) 16.7 -> 19.8 and with 4 (320) 23 -> 34.7 lose, with 3
+// (240) it wins.  Long K (11008x4096, 8192x3584): two blocks of four row tiles from 128 rows (34.0 -> 32.5), else one.
+static int mid_row_blocks(int M, int strips, int K) {
+    const int t16 = (M + 15) / 16;
+    if (strips >= 160 || t16 < 3) return 1;
+    const int blocks = K <= 5120 ? (t16 + 1) / 2 : ((t16 >= 8 && strips <= 64) ? (t16 + 3) / 4 : 1);     // (8192x8192 with two blocks: 38.5 against 33.9 tiled)
+    if (blocks <= 1) return 1;
+    const int tiles = strips * blocks;
+    const int ks = tiles >= 160 ? 1 : 256 / tiles;
+    const int wgs = tiles * ks;
+    return (wgs >= 192 && wgs <= 256 && ks <= 2) ? blocks : 1;
+}
+
 MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* tune) {
     MidPlan pl{};
-    if (n < 1 || n > 4 || M < 1 || M > 128) return pl;
+    if (n < 1 || n > 4 || M < 1 || M > 256) return pl;
     const gptq_layer_t& A = *Ls[0];
     int strips = 0, nsum = 0;
     const int rt16 = (M + 15) / 16;
-    const int rt_ = rt16 <= 2 ? 2 : (rt16 <= 4 ? 4 : (rt16 <= 6 ? 6 : 8));
+    const int rt_ = rt16 <= 2 ? 2 : (rt16 <= 4 ? 4 : (rt16 <= 6 ? 6 : 8));   // (whole M in one block: what the 128-column-strip experiment is defined for)
     bool all128 = true;
     for (int i = 0; i < n; ++i) all128 = all128 && Ls[i]->N % 128 == 0;
     // 128-column strips (two 64-column halves per wave): forced by tuning.reserved[3] = 2 (1 forces 64), else by measurement (below)
@@ -502,26 +524,38 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     }
     const int lg = ilog2_exact(A.group_size / 32);
     if (lg < 0) return pl;
-    if ((size_t)strips * 8 * 4 > WS_HEADER_EPOCH_OFFSET) return pl;                     // 8 flag words per strip in the ticket half of the header
+    if ((size_t)strips * rt16 * 8 * 4 > WS_HEADER_EPOCH_OFFSET) return pl;              // 8 flag words per (row block, strip) in the ticket half of the header
     if ((size_t)strips * 4 > WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES - WS_HEADER_EPOCH_OFFSET) return pl;   // one epoch word per strip in the second half
     if ((size_t)M * A.K * 2 >= ((size_t)1 << 31)) return pl;                            // 32-bit lane offsets into x
     pl.nseg = n;
     pl.strips_total = strips;
     pl.nsum = nsum;
-    pl.rt = rt_;
+    // row blocks: tuning.lanes_n (unused by this kernel otherwise) forces the count; default by measurement (mid_row_blocks)
+    int rbs = (tune && tune->lanes_n > 0 && tune->path == 3) ? tune->lanes_n : mid_row_blocks(M, strips, A.K);
+    if (rbs < 1) rbs = 1;
+    if (rbs > rt16) rbs = rt16;
+    {
+        const int per = (rt16 + rbs - 1) / rbs;                                         // row tiles per block
+        if (per > 8) return pl;                                                         // 129+ rows need row blocks
+        const int rtb = per <= 1 ? 1 : (per <= 2 ? 2 : (per <= 4 ? 4 : (per <= 6 ? 6 : 8)));
+        if (cw == 2 && rtb > 4) return pl;
+        pl.rt = rtb;
+        pl.row_blocks = (rt16 + rtb - 1) / rtb;                                         // no empty block
+    }
     pl.cw = cw;
     pl.lg_gsteps = lg;
     const int S = A.K / 32;
     pl.ksteps_total = S;
     pl.waves = 8;
     int ks = (tune && tune->ksplit > 0 && tune->path == 3) ? tune->ksplit : 0;
+    const int tiles = strips * pl.row_blocks;
     if (!ks) {
-        ks = strips >= 160 ? 1 : 256 / strips;                                          // one workgroup per CU is one round
+        ks = tiles >= 160 ? 1 : 256 / tiles;                                            // one workgroup per CU is one round
         if (ks > 8) ks = 8;
         while (ks > 1 && S / ks < 2 * pl.waves) --ks;                                   // at least two K-steps per wave
     }
     if (ks > 8) ks = 8;
-    while (ks > 1 && (long)strips * ks > 256) --ks;                                     // the owner slice WAITS for the others: every workgroup of the launch must be resident (one per CU, 256 CUs)
+    while (ks > 1 && (long)tiles * ks > 256) --ks;                                     // the owner slice WAITS for the others: every workgroup of the launch must be resident (one per CU, 256 CUs)
     if (ks > S) ks = S;
     if (ks < 1) ks = 1;
     pl.ksteps_per_split = (S + ks - 1) / ks;
@@ -568,14 +602,15 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     // Other shapes (profiles/r03_mid_kernel_more_shapes.log): 17..64 rows win on 5120^2, 8192^2, 3584x8192, 8192x3584, 13824x5120, 28672x8192 (5-20 %);
     // 97..128 rows only on the 64-strip layers above (5120^2: 26.4 against 23.1, 8192x3584: 28.8 against 25.6); layers of < 32 strips keep
     // the skinny kernel from 33 rows (8192x1024 M = 64: 15.9 against 14.0); very wide layers keep the tiled kernel from 33 rows.
-    pl.pays = M >= 17 && !(M > 64 && strips >= 160) && !(M > 32 && nmax >= 12288) && !(M > 32 && strips < 32) && !(M > 96 && strips != 64);
+    pl.pays = M >= 17 && M <= 128 && !(M > 64 && strips >= 160) && !(M > 32 && nmax >= 12288) && !(M > 32 && strips < 32) &&
+              !(M > 96 && strips != 64 && pl.row_blocks == 1);
     pl.ok = true;
     return pl;
 }
 
 template <typename T, int RT, int D>
 static hipError_t launch_mid_one(const MidPlan& pl, const midk::MidParams& p, hipStream_t st) {
-    const dim3 grid(pl.strips_total * pl.ksplit), block(pl.waves * 64);
+    const dim3 grid(pl.strips_total * pl.row_blocks * pl.ksplit), block(pl.waves * 64);
     if constexpr (RT <= 4) {
         if (pl.cw == 2) {
             hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, D, false, 2>), grid, block, pl.lds_bytes, st, p);
@@ -589,6 +624,8 @@ static hipError_t launch_mid_one(const MidPlan& pl, const midk::MidParams& p, hi
 template <typename T>
 static hipError_t launch_mid_t(const MidPlan& pl, const midk::MidParams& p, hipStream_t st) {
     switch (pl.rt * 4 + pl.stages) {
+        case 1 * 4 + 2: return launch_mid_one<T, 1, 2>(pl, p, st);
+        case 1 * 4 + 3: return launch_mid_one<T, 1, 3>(pl, p, st);
         case 2 * 4 + 2: return launch_mid_one<T, 2, 2>(pl, p, st);
         case 2 * 4 + 3: return launch_mid_one<T, 2, 3>(pl, p, st);
         case 4 * 4 + 2: return launch_mid_one<T, 4, 2>(pl, p, st);
@@ -627,7 +664,7 @@ hipError_t launch_mid(const gptq_layer_t* const* Ls, const MidPlan& pl, const vo
     p.err = ws_header ? (unsigned*)((char*)ws_header + WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES) + 2 : nullptr;
     p.nseg = pl.nseg; p.M = M; p.K = Ls[0]->K; p.zero_mode = Ls[0]->zero_mode;
     p.ksplit = pl.ksplit; p.ksteps_per_split = pl.ksteps_per_split; p.nsum = pl.nsum;
-    p.lg_gsteps = pl.lg_gsteps; p.tab_bytes = pl.tab_bytes;
+    p.lg_gsteps = pl.lg_gsteps; p.tab_bytes = pl.tab_bytes; p.strips_total = pl.strips_total;
     p.max_spins = 1u << 22;
     return (Ls[0]->dtype == GPTQ_F16) ? launch_mid_t<f16>(pl, p, st) : launch_mid_t<bf16>(pl, p, st);
 }
@@ -643,7 +680,7 @@ template <typename T, int RT, int D> static hipError_t grant_mid() {
 template <typename T> static hipError_t grant_mid_t() {
     hipError_t e = hipSuccess;
     auto acc = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    acc(grant_mid<T, 2, 2>()); acc(grant_mid<T, 2, 3>()); acc(grant_mid<T, 4, 2>()); acc(grant_mid<T, 4, 3>());
+    acc(grant_mid<T, 1, 2>()); acc(grant_mid<T, 1, 3>()); acc(grant_mid<T, 2, 2>()); acc(grant_mid<T, 2, 3>()); acc(grant_mid<T, 4, 2>()); acc(grant_mid<T, 4, 3>());
     acc(grant_mid<T, 6, 2>()); acc(grant_mid<T, 8, 2>());
     return e;
 }

@@ -415,6 +415,39 @@ def test_mid_kernel(M, K, N, gs, act, dtype, stages, ksplit, xreg):
             assert int(((body & -0x200000) == 0x7FE00000).sum()) == 0, "valid-looking granule tags left behind in the exchange area"
 
 
+@pytest.mark.parametrize("rbs,ksplit", [(2, 1), (4, 2), (8, 1), (3, 4)])
+@pytest.mark.parametrize("M,K,N,gs,act,dtype", [(33, 2048, 256, 128, False, torch.float16), (64, 4096, 512, 128, True, torch.float16), (100, 1024, 192, 32, False, torch.bfloat16),
+                                               (128, 11008, 128, 128, False, torch.float16), (128, 4096, 1024, 64, True, torch.bfloat16)])
+def test_mid_kernel_row_blocks(M, K, N, gs, act, dtype, rbs, ksplit):
+    """gemm_mid_kernel with workgroups along M (tuning.lanes_n = row blocks): each workgroup owns 16 rt rows of x, the (row block, strip) tiles
+    have their own flag words, ragged last block; fp64 oracle, one-hot rows, bit-reproducible, header left zero."""
+    L = O.random_quant_layer(K, N, 4, gs, act_order=act, seed=M + K + N + rbs, bias=True, dtype=dtype)
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, gs, zero_mode="wrap")
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype)
+    y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP)
+    t = _tuning(path=3, ksplit=ksplit, lanes_n=rbs)
+    t.reserved[2] = 5
+    q.post_init()
+    d = _lib.describe_plan(q._layer, M, t)
+    assert d["kernel"] == "mid" and int(d["tiles"].split("x")[0]) > 1, d
+    with torch.no_grad():
+        y, yb = q(x.to(DEV), tuning=t), q(x.to(DEV), tuning=t)
+    assert torch.equal(y, yb)
+    _assert_close(y, y64, y64, dtype, K, f"mid row blocks {d} vs f64")
+    ks = (torch.arange(M) * 37 + 5) % K
+    xo = torch.zeros(M, K, dtype=dtype)
+    xo[torch.arange(M), ks] = 1.0
+    with torch.no_grad():
+        yo = q(xo.to(DEV), tuning=t).cpu()
+    W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], 4, O.ZERO_WRAP)
+    assert torch.equal(yo, (W[ks].float() + L["bias"].float()).to(dtype))
+    from autogptq_amd.qlinear_mi355x import _WORKSPACE
+    torch.cuda.synchronize()
+    for ent in _WORKSPACE.values():
+        if ent[0].numel() >= 65536:
+            assert int(ent[0][:32768].count_nonzero()) == 0
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("stages,ksplit", [(0, 0), (2, 3), (3, 8)])
 @pytest.mark.parametrize("M,K,widths,gs", [(17, 1024, (512, 192, 1024), 128), (40, 2048, (1088, 128), 64), (64, 4096, (256, 256, 256, 64), 128),

@@ -368,9 +368,17 @@ def test_dispatch_rules_are_the_measured_ones():
     assert (p["kernel"], p["mt"], p["waves"], p["ksplit"], p["tiles"]) == ("mid", 4, 8, 1, "1x172"), p
     assert _plan(4096, 11008, 17)["kernel"] == "mid" and _plan(4096, 11008, 17)["u"] == 3 and _plan(4096, 11008, 32)["mt"] == 2
     p = _plan(11008, 4096, 96)
-    assert (p["kernel"], p["mt"], p["ksplit"], p["u"]) == ("mid", 6, 4, 2), p
-    assert _plan(4096, 4096, 17)["kernel"] == "mid" and _plan(4096, 4096, 128)["kernel"] == "mid" and _plan(4096, 4096, 128)["mt"] == 8
-    assert _plan(4096, 11008, 64, act=True)["kernel"] == "mid" and _plan(4096, 11008, 64, dtype=1)["kernel"] == "mid"
+    assert (p["kernel"], p["mt"], p["ksplit"], p["u"], p["tiles"]) == ("mid", 6, 4, 2, "1x64"), p
+    assert _plan(4096, 4096, 17)["kernel"] == "mid" and _plan(4096, 11008, 64, act=True)["kernel"] == "mid" and _plan(4096, 11008, 64, dtype=1)["kernel"] == "mid"
+    # row blocks (workgroups along M, two row tiles each) instead of K slices where K is short and the blocks fill 192..256 workgroups:
+    # 4096^2 M = 64: 2 blocks x 2 slices, M = 96 / 128: 3 / 4 blocks and no K split; 5120^2 only at 96 rows (3 x 80); long K: two blocks from 128 rows
+    for m, tiles, ks in ((48, "2x64", 2), (64, "2x64", 2), (96, "3x64", 1), (128, "4x64", 1)):
+        p = _plan(4096, 4096, m)
+        assert (p["kernel"], p["tiles"], p["ksplit"], p["mt"]) == ("mid", tiles, ks, 2), (m, p)
+    assert _plan(5120, 5120, 64)["tiles"] == "1x80" and _plan(5120, 5120, 96)["tiles"] == "3x80" and _plan(3584, 8192, 64)["tiles"] == "2x128"
+    p = _plan(11008, 4096, 128)
+    assert (p["kernel"], p["tiles"], p["ksplit"], p["mt"]) == ("mid", "2x64", 2, 4), p
+    assert _plan(11008, 4096, 64)["tiles"] == "1x64" and _plan(8192, 8192, 128)["kernel"] == "tiled"
     # ... except: 65+ rows on layers of 160+ strips and 33+ rows on very wide layers (tiled kernel), 97+ rows off the 64-strip layers,
     # 33+ rows on layers of < 32 strips (skinny kernel), other bit widths, N % 64 != 0
     assert _plan(4096, 11008, 65)["kernel"] == "tiled" and _plan(8192, 28672, 64)["kernel"] == "tiled" and _plan(8192, 28672, 32)["kernel"] == "mid"

@@ -50,12 +50,14 @@ def main():
                 except Exception as e:
                     out.append(f"{name}=n/a")
             res = []
-            cfgs = [(0, 0, 1, 0), (0, 0, 1, 3), (0, 0, 2, 0)] if a.quick else [(st, ks, cw, fl) for fl in (0, 3) for cw in (1, 2) for st in (2, 3) for ks in (0, 2, 3, 4, 8)]
-            for st, ks, cw, fl in cfgs:
+            cfgs = [(0, 0, 1, 0, 0)] if a.quick else [(2, ks, 1, 0, rb) for rb in (1, 2, 4, 8) for ks in (0, 1, 2, 4)]
+            for st, ks, cw, fl, rb in cfgs:
                 if cw == 2 and (M > 64 or N % 128):
                     continue
-                t = tun(path=3, ksplit=ks, reserved={0: st, 1: fl, 2: 5, 3: cw})
-                tag = f"{'w' if cw == 2 else 'd'}{st}k{ks}{'G' if fl else ''}"
+                if rb > (M + 15) // 16:
+                    continue
+                t = tun(path=3, ksplit=ks, lanes_n=rb, reserved={0: st, 1: fl, 2: 5, 3: cw})
+                tag = f"rb{rb}k{ks}"
                 try:
                     with torch.no_grad():
                         y = ls[0](x, tuning=t)
@@ -70,7 +72,7 @@ def main():
                 except Exception as e:
                     res.append((9.9, tag + ":FAIL " + str(e)[:60]))
             res.sort()
-            best = " ".join(f"{n}={s * 1e6:.2f}" for s, n in [r for r in res if r[1][0] != "w"][:5]) + " || " + " ".join(f"{n}={s * 1e6:.2f}" for s, n in [r for r in res if r[1][0] == "w"][:6])
+            best = " ".join(f"{n}={s * 1e6:.2f}" for s, n in res[:10])
             print(f"{K}x{N} M={M:3d} ({ab / 1e6:.1f} MB): " + " ".join(out) + " | mid: " + best, flush=True)
         del ls
     print("WRONG RESULTS:", bad)
