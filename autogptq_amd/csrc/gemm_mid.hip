@@ -51,6 +51,7 @@ struct MidParams {
                          // 0: fp32 partial tiles + one flag word per slice (publish, drain, flag, read: three)
     int nseg, M, K, zero_mode, ksplit, ksteps_per_split, nsum;
     int strips_total;    // strips over all layers; the grid is strips_total x row_blocks x ksplit
+    int row_blocks;
     int lg_gsteps;       // log2(group_size / 32)
     int tab_bytes;       // per-wave group-constant table (256 B per group the wave can touch)
     unsigned max_spins;
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
     // strip are then streamed once per row block, out of the L2 after the first)
     const int Lb = xcd_remap(blockIdx.x, gridDim.x);
     const int tile = Lb / p.ksplit, ks = Lb - tile * p.ksplit;    // tile = (row block, strip): index of the flag words too
-    const int rb = tile / p.strips_total, stile = tile - rb * p.strips_total;
+    const int stile = tile / p.row_blocks, rb = tile - stile * p.row_blocks;   // the row blocks of a strip are adjacent ids: same XCD, same moment -> one HBM fetch of its weights
     const int m0 = rb * (RT * 16);
     int sI = 0;
     while (sI + 1 < p.nseg && stile >= p.seg[sI].blk_end) ++sI;   // wave-uniform (kernel arguments only)
@@ -480,19 +481,24 @@ static bool mid_prefers_wide_strips(int M, int s128) {
 }
 
 // Row blocks by default (filled in from tools/mid_sweep.py): 1 = the whole M in every workgroup
-// Row blocks.  Measured (profiles/r03_mid_kernel_row_blocks_sweep.log, ..._more_shapes.log; us, one block -> row blocks): 4096x4096 M = 64 14.7 -> 12.4
-// (2 blocks x 2 K slices), M = 96 19.2 -> 15.5 (3 blocks, no K split), M = 128 23.0 -> 16.4 (4 blocks, no K split): a strip's weights (K x 32 bytes)
-// come out of the L2 for every block after the first, which is cheaper than the K slices' combine while K is short AND the blocks fill the chip
-// (192..256 workgroups with at most 2 K slices): 5120x5120 with 2 blocks (160 workgroups) 16.7 -> 19.8 and with 4 (320) 23 -> 34.7 lose, with 3
-// (240) it wins.  Long K (11008x4096, 8192x3584): two blocks of four row tiles from 128 rows (34.0 -> 32.5), else one.
+// Row blocks: two row tiles per workgroup, the blocks of a strip on adjacent workgroup ids (same XCD, same moment: the strip's weights are fetched
+// from HBM once and shared through the L2).  Measured (profiles/r03_mid_kernel_row_blocks_adjacent.log; us, one block -> row blocks): 4096x4096 M = 64
+// 14.4 -> 11.5 (2 blocks x 2 K slices), M = 128 23.0 -> 13.7 (4 blocks, no K split); 11008x4096 M = 64 21.7 -> 20.3, M = 128 34.4 -> 29.1.  Only when
+// the blocks fill the chip -- 192..256 workgroups with at most 2 K slices: 5120x5120 with 2 blocks is 160 workgroups (17.2 = no gain) and with 4 is 320
+// (24.7 against 23.0 for the tiled kernel).
 static int mid_row_blocks(int M, int strips, int K) {
     const int t16 = (M + 15) / 16;
     if (strips >= 160 || t16 < 3) return 1;
-    const int blocks = K <= 5120 ? (t16 + 1) / 2 : ((t16 >= 8 && strips <= 64) ? (t16 + 3) / 4 : 1);     // (8192x8192 with two blocks: 38.5 against 33.9 tiled)
-    if (blocks <= 1) return 1;
+    if (t16 > 8) {                                     // 129..256 rows: blocks of four row tiles, short K only (profiles/r03_mid_kernel_row_blocks_192_256.log:
+        if (K > 5120) return 1;                        // 4096x4096 M = 192 / 256 22.6 / 22.9 (tiled) -> 18.5 / 18.9, 5120x5120 M = 192 28.8 -> 23.9; long K: no gain)
+        const int b4 = (t16 + 3) / 4, t4 = strips * b4;
+        return (t4 >= 192 && t4 <= 256) ? b4 : 1;
+    }
+    const int blocks = (t16 + 1) / 2;
     const int tiles = strips * blocks;
     const int ks = tiles >= 160 ? 1 : 256 / tiles;
     const int wgs = tiles * ks;
+    if (wgs < 224 && K > 5120) return 1;               // 11008x4096 M = 96: 3 blocks = 192 workgroups 29.2 against 28.1 with one block x 4 slices
     return (wgs >= 192 && wgs <= 256 && ks <= 2) ? blocks : 1;
 }
 
@@ -602,7 +608,7 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     // Other shapes (profiles/r03_mid_kernel_more_shapes.log): 17..64 rows win on 5120^2, 8192^2, 3584x8192, 8192x3584, 13824x5120, 28672x8192 (5-20 %);
     // 97..128 rows only on the 64-strip layers above (5120^2: 26.4 against 23.1, 8192x3584: 28.8 against 25.6); layers of < 32 strips keep
     // the skinny kernel from 33 rows (8192x1024 M = 64: 15.9 against 14.0); very wide layers keep the tiled kernel from 33 rows.
-    pl.pays = M >= 17 && M <= 128 && !(M > 64 && strips >= 160) && !(M > 32 && nmax >= 12288) && !(M > 32 && strips < 32) &&
+    pl.pays = M >= 17 && (M <= 128 || pl.row_blocks > 1) && !(M > 64 && strips >= 160) && !(M > 32 && nmax >= 12288) && !(M > 32 && strips < 32) &&
               !(M > 96 && strips != 64 && pl.row_blocks == 1);
     pl.ok = true;
     return pl;
@@ -664,7 +670,7 @@ hipError_t launch_mid(const gptq_layer_t* const* Ls, const MidPlan& pl, const vo
     p.err = ws_header ? (unsigned*)((char*)ws_header + WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES) + 2 : nullptr;
     p.nseg = pl.nseg; p.M = M; p.K = Ls[0]->K; p.zero_mode = Ls[0]->zero_mode;
     p.ksplit = pl.ksplit; p.ksteps_per_split = pl.ksteps_per_split; p.nsum = pl.nsum;
-    p.lg_gsteps = pl.lg_gsteps; p.tab_bytes = pl.tab_bytes; p.strips_total = pl.strips_total;
+    p.lg_gsteps = pl.lg_gsteps; p.tab_bytes = pl.tab_bytes; p.strips_total = pl.strips_total; p.row_blocks = pl.row_blocks;
     p.max_spins = 1u << 22;
     return (Ls[0]->dtype == GPTQ_F16) ? launch_mid_t<f16>(pl, p, st) : launch_mid_t<bf16>(pl, p, st);
 }

@@ -128,10 +128,11 @@ def test_config3_int4_g128_desc_act_prefill_2048(K, N, dtype):
 @pytest.mark.parametrize("act", [False, True], ids=["seq", "act"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
 @pytest.mark.parametrize("K,N", LLAMA7B)
-def test_batched_rows_17_to_128_int4_g128_llama7b_shapes(K, N, dtype, act):
+def test_batched_rows_17_to_256_int4_g128_llama7b_shapes(K, N, dtype, act):
     """The row counts between decode and prefill (the reference's kernel switch sits at 8 / 50 rows) on the Llama-7B shapes with the DEFAULT plan:
-    gemm_mid_kernel with 2 / 4 / 6 / 8 row tiles (in-launch K slices on the 4096-wide layers), the tiled kernel where the planner keeps it."""
-    for M in (17, 33, 96, 128):
+    gemm_mid_kernel with 1..8 row tiles per workgroup (row blocks and / or in-launch K slices on the 4096-wide layers), the tiled kernel where the
+    planner keeps it."""
+    for M in (17, 33, 96, 128, 192, 256):
         _check(4, 128, K, N, M, act, dtype)
 
 

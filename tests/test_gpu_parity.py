@@ -346,8 +346,10 @@ def test_full_size_batched_decode_properties(K, N, M, act, dtype):
     assert torch.equal(y, yb)
     d = _lib.describe_plan(q._layer, M)
     assert d["kernel"] == ("strip16" if (K, N) == (4096, 4096) else ("mid" if M > 16 else "stream64")), d
-    if d["kernel"] in ("stream64", "mid"):
+    if d["kernel"] == "stream64":
         assert d["ksplit"] == (1 if N >= 10240 else 4), d
+    if d["kernel"] == "mid":                         # 4096-wide layers: 2 row blocks x 2 K slices at 33..64 rows; 172 strips: neither
+        assert (d["tiles"], d["ksplit"]) == (("1x172", 1) if N >= 10240 else ("2x64", 2)), d
     mode = O.reference_zero_mode(act, 4)
     for n0 in ((N // 2) // 32 * 32, N - 96):
         n1 = min(N, n0 + 96)
@@ -417,7 +419,8 @@ def test_mid_kernel(M, K, N, gs, act, dtype, stages, ksplit, xreg):
 
 @pytest.mark.parametrize("rbs,ksplit", [(2, 1), (4, 2), (8, 1), (3, 4)])
 @pytest.mark.parametrize("M,K,N,gs,act,dtype", [(33, 2048, 256, 128, False, torch.float16), (64, 4096, 512, 128, True, torch.float16), (100, 1024, 192, 32, False, torch.bfloat16),
-                                               (128, 11008, 128, 128, False, torch.float16), (128, 4096, 1024, 64, True, torch.bfloat16)])
+                                               (128, 11008, 128, 128, False, torch.float16), (128, 4096, 1024, 64, True, torch.bfloat16),
+                                               (200, 2048, 128, 128, False, torch.float16), (256, 1024, 256, 128, True, torch.bfloat16)])
 def test_mid_kernel_row_blocks(M, K, N, gs, act, dtype, rbs, ksplit):
     """gemm_mid_kernel with workgroups along M (tuning.lanes_n = row blocks): each workgroup owns 16 rt rows of x, the (row block, strip) tiles
     have their own flag words, ragged last block; fp64 oracle, one-hot rows, bit-reproducible, header left zero."""

@@ -370,15 +370,20 @@ def test_dispatch_rules_are_the_measured_ones():
     p = _plan(11008, 4096, 96)
     assert (p["kernel"], p["mt"], p["ksplit"], p["u"], p["tiles"]) == ("mid", 6, 4, 2, "1x64"), p
     assert _plan(4096, 4096, 17)["kernel"] == "mid" and _plan(4096, 11008, 64, act=True)["kernel"] == "mid" and _plan(4096, 11008, 64, dtype=1)["kernel"] == "mid"
-    # row blocks (workgroups along M, two row tiles each) instead of K slices where K is short and the blocks fill 192..256 workgroups:
-    # 4096^2 M = 64: 2 blocks x 2 slices, M = 96 / 128: 3 / 4 blocks and no K split; 5120^2 only at 96 rows (3 x 80); long K: two blocks from 128 rows
-    for m, tiles, ks in ((48, "2x64", 2), (64, "2x64", 2), (96, "3x64", 1), (128, "4x64", 1)):
-        p = _plan(4096, 4096, m)
-        assert (p["kernel"], p["tiles"], p["ksplit"], p["mt"]) == ("mid", tiles, ks, 2), (m, p)
+    # row blocks (workgroups along M, two row tiles each, the blocks of a strip on adjacent ids) instead of / next to K slices where they fill
+    # 192..256 workgroups: 4096^2 M = 64: 2 blocks x 2 slices, M = 96 / 128: 3 / 4 blocks and no K split; 11008x4096 the same except at 96 rows
+    for K in (4096, 11008):
+        for m, tiles, ks in ((48, "2x64", 2), (64, "2x64", 2), (128, "4x64", 1)):
+            p = _plan(K, 4096, m)
+            assert (p["kernel"], p["tiles"], p["ksplit"], p["mt"]) == ("mid", tiles, ks, 2), (K, m, p)
+    assert _plan(4096, 4096, 96)["tiles"] == "3x64" and _plan(11008, 4096, 96)["tiles"] == "1x64"
     assert _plan(5120, 5120, 64)["tiles"] == "1x80" and _plan(5120, 5120, 96)["tiles"] == "3x80" and _plan(3584, 8192, 64)["tiles"] == "2x128"
-    p = _plan(11008, 4096, 128)
-    assert (p["kernel"], p["tiles"], p["ksplit"], p["mt"]) == ("mid", "2x64", 2, 4), p
-    assert _plan(11008, 4096, 64)["tiles"] == "1x64" and _plan(8192, 8192, 128)["kernel"] == "tiled"
+    assert _plan(8192, 8192, 64)["tiles"] == "2x128" and _plan(8192, 8192, 128)["kernel"] == "tiled"
+    # 129 .. 256 rows: blocks of four row tiles on short-K layers that they fill (4096^2: 3 / 4 blocks; 5120^2 at 192 rows), else the tiled kernel
+    p = _plan(4096, 4096, 256)
+    assert (p["kernel"], p["tiles"], p["ksplit"], p["mt"]) == ("mid", "4x64", 1, 4), p
+    assert _plan(4096, 4096, 192)["tiles"] == "3x64" and _plan(5120, 5120, 192)["kernel"] == "mid" and _plan(5120, 5120, 256)["kernel"] == "tiled"
+    assert _plan(11008, 4096, 192)["kernel"] == "tiled" and _plan(4096, 4096, 257)["kernel"] == "tiled"
     # ... except: 65+ rows on layers of 160+ strips and 33+ rows on very wide layers (tiled kernel), 97+ rows off the 64-strip layers,
     # 33+ rows on layers of < 32 strips (skinny kernel), other bit widths, N % 64 != 0
     assert _plan(4096, 11008, 65)["kernel"] == "tiled" and _plan(8192, 28672, 64)["kernel"] == "tiled" and _plan(8192, 28672, 32)["kernel"] == "mid"
