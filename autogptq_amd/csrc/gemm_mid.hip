@@ -530,7 +530,6 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     }
     const int lg = ilog2_exact(A.group_size / 32);
     if (lg < 0) return pl;
-    if ((size_t)strips * rt16 * 8 * 4 > WS_HEADER_EPOCH_OFFSET) return pl;              // 8 flag words per (row block, strip) in the ticket half of the header
     if ((size_t)strips * 4 > WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES - WS_HEADER_EPOCH_OFFSET) return pl;   // one epoch word per strip in the second half
     if ((size_t)M * A.K * 2 >= ((size_t)1 << 31)) return pl;                            // 32-bit lane offsets into x
     pl.nseg = n;
@@ -563,6 +562,7 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     if (ks > 8) ks = 8;
     while (ks > 1 && (long)tiles * ks > 256) --ks;                                     // the owner slice WAITS for the others: every workgroup of the launch must be resident (one per CU, 256 CUs)
     if (ks > S) ks = S;
+    if (ks > 1 && (size_t)tiles * 8 * 4 > WS_HEADER_EPOCH_OFFSET) ks = 1;             // 8 flag words per (row block, strip) in the ticket half of the header
     if (ks < 1) ks = 1;
     pl.ksteps_per_split = (S + ks - 1) / ks;
     pl.ksplit = (S + pl.ksteps_per_split - 1) / pl.ksteps_per_split;                    // no empty slices
@@ -608,6 +608,16 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     // Other shapes (profiles/r03_mid_kernel_more_shapes.log): 17..64 rows win on 5120^2, 8192^2, 3584x8192, 8192x3584, 13824x5120, 28672x8192 (5-20 %);
     // 97..128 rows only on the 64-strip layers above (5120^2: 26.4 against 23.1, 8192x3584: 28.8 against 25.6); layers of < 32 strips keep
     // the skinny kernel from 33 rows (8192x1024 M = 64: 15.9 against 14.0); very wide layers keep the tiled kernel from 33 rows.
+    if (n >= 2) {
+        // several layers sharing x (tools/mid_multi_ab.py, profiles/r03_mid_kernel_multi_layer_ab.log; us, one launch against layer by layer): q|k|v
+        // M = 33 / 64 / 96 / 128: 17.3 / 22.1 / 28.1 / 35.9 against 34.4 / 35.7 / 40.3 / 42.5; gate|up 32.3 / 41.3 / 51.7 against 34.7 / 43.6 / 53.1, and
+        // 58-68 against 55.9 at 128 rows (its layers are 172 strips each: the tiled kernel's regime)
+        int smax = 0;
+        for (int i = 0; i < n; ++i) smax = Ls[i]->N / (64 * cw) > smax ? Ls[i]->N / (64 * cw) : smax;
+        pl.pays = M >= 17 && M <= 128 && (M <= 96 || smax < 160) && !(M > 32 && nmax >= 12288);
+        pl.ok = true;
+        return pl;
+    }
     pl.pays = M >= 17 && (M <= 128 || pl.row_blocks > 1) && !(M > 64 && strips >= 160) && !(M > 32 && nmax >= 12288) && !(M > 32 && strips < 32) &&
               !(M > 96 && strips != 64 && pl.row_blocks == 1);
     pl.ok = true;
