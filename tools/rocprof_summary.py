@@ -21,6 +21,11 @@ def demangle(name: str) -> str:
     n = int(m.group(1))
     base = name[m.end():m.end() + n]
     rest = name[m.end() + n:]
+    m2 = re.match(r"^(\d+)", rest)                     # nested namespace (gptq::midk::gemm_mid_kernel, gptq::mlpk::...)
+    if m2:
+        n2 = int(m2.group(1))
+        base = base + "::" + rest[m2.end():m2.end() + n2]
+        rest = rest[m2.end() + n2:]
     if not rest.startswith("I"):
         return "gptq::" + base
     args, i = [], 1
