@@ -652,10 +652,20 @@ static hipError_t launch_mid_t(const MidPlan& pl, const midk::MidParams& p, hipS
     }
 }
 
+namespace mlpk { extern int g_cu_count[64]; }     // per device ordinal, filled by gptq_init (mlp.hip)
+
 hipError_t launch_mid(const gptq_layer_t* const* Ls, const MidPlan& pl, const void* x, void* const* outs, int M, void* ws_header, void* partial,
                       const uint32_t* qweight_override, hipStream_t st) {
     if (!pl.ok) return hipErrorNotSupported;
     if (pl.ksplit > 1 && (!ws_header || !partial)) return hipErrorInvalidValue;
+    if (pl.ksplit > 1) {
+        // the owner slice of a strip WAITS (bounded) for the other slices: every workgroup of the launch must be resident at once -- one per CU (its
+        // LDS allows no second).  The planner assumes MI355X's 256 CUs; a device with fewer (partitioned, masked) is refused here, loudly.
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && mlpk::g_cu_count[dev] > 0 &&
+            pl.strips_total * pl.row_blocks * pl.ksplit > mlpk::g_cu_count[dev])
+            return hipErrorLaunchOutOfResources;
+    }
     midk::MidParams p{};
     int blk = 0, col = 0;
     for (int i = 0; i < pl.nseg; ++i) {
