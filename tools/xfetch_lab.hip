@@ -18,7 +18,9 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
 }
 
 // SEG = bytes of one row segment per instruction (64 / 128 / 256); rows per instruction = 1024 / SEG
-template <int SEG, bool DMA>
+// ROT: every workgroup starts its walk along K at a different segment (blockIdx * 37 mod segments per wave) -- do 256 workgroups reading the SAME
+// addresses at the same moment hot-spot the L2 channels?
+template <int SEG, bool DMA, bool ROT = false>
 __global__ void __launch_bounds__(512) xfetch_kernel(const char* x, int M, int K, unsigned* sink, int depth) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
@@ -31,7 +33,11 @@ __global__ void __launch_bounds__(512) xfetch_kernel(const char* x, int M, int K
     const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + wave * 16384));
     u32x4 acc = {0, 0, 0, 0};
     int slot = 0;
-    for (int s = s0; s < s1; ++s) {
+    const int cnt = s1 - s0;
+    const int rot = (ROT && cnt > 0) ? (int)((blockIdx.x * 37u) % (unsigned)cnt) : 0;
+    for (int si = 0; si < cnt; ++si) {
+        int s = s0 + si + rot;
+        if (s >= s1) s -= cnt;
         for (int rb = 0; rb < M; rb += RPI) {
             const char* src = x + (size_t)min(rb + r, M - 1) * rowb + (size_t)s * SEG + o * 16;
             if constexpr (DMA) {
@@ -50,14 +56,14 @@ __global__ void __launch_bounds__(512) xfetch_kernel(const char* x, int M, int K
     if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) sink[blockIdx.x] = acc[0];
 }
 
-template <int SEG, bool DMA>
+template <int SEG, bool DMA, bool ROT = false>
 static void run(const char* name, const char* x, int M, int K, unsigned* sink, int depth) {
-    CK(hipFuncSetAttribute((const void*)xfetch_kernel<SEG, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    CK(hipFuncSetAttribute((const void*)xfetch_kernel<SEG, DMA, ROT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 20;
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((xfetch_kernel<SEG, DMA>), dim3(256), dim3(512), 128 * 1024, 0, x, M, K, sink, depth);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((xfetch_kernel<SEG, DMA, ROT>), dim3(256), dim3(512), 128 * 1024, 0, x, M, K, sink, depth);
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((xfetch_kernel<SEG, DMA>), dim3(256), dim3(512), 128 * 1024, 0, x, M, K, sink, depth);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((xfetch_kernel<SEG, DMA, ROT>), dim3(256), dim3(512), 128 * 1024, 0, x, M, K, sink, depth);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps, bytes = (double)M * K * 2;
@@ -77,6 +83,9 @@ int main() {
         run<64, false>("reg, 16 rows x 64 B", x, M, K, sink, 0);
         run<128, false>("reg,  8 rows x 128 B", x, M, K, sink, 0);
         run<256, false>("reg,  4 rows x 256 B", x, M, K, sink, 0);
+        run<64, true, true>("dma, 16 rows x 64 B, depth 8, ROTATED", x, M, K, sink, 8);
+        run<128, true, true>("dma,  8 rows x 128 B, depth 16, ROTATED", x, M, K, sink, 16);
+        run<128, false, true>("reg,  8 rows x 128 B, ROTATED", x, M, K, sink, 0);
         CK(hipFree(x));
     }
     return 0;
