@@ -125,6 +125,45 @@ template <> struct Deq1<bf16> {
         return o;
     }
 };
+// 8-bit: a lane's 8 consecutive k of one column are two words (packed rows 2 kg and 2 kg + 1); v_perm joins their halves so that a byte mask pairs
+// (f0, f4), (f2, f6) and, shifted by 8, (f1, f5), (f3, f7): the same slot order as the 4-bit fragments, exact w - z with the 0x6400 magic number
+// (|w - z| <= 256), then x scale (fp16: packed multiply; bf16: exact fp32 product, one rounding)
+template <typename T> struct Deq8;
+template <> struct Deq8<f16> {
+    f16x2 s2, c1;
+    __device__ __forceinline__ void setup(unsigned sbits, unsigned z) {
+        s2 = as_f16x2(sbits * 0x00010001u);
+        c1 = as_f16x2(z * 0x00010001u + 0xE400E400u);
+    }
+    __device__ __forceinline__ u32x4 frag(unsigned w0, unsigned w1) const {
+        const unsigned lo = __builtin_amdgcn_perm(w1, w0, 0x05040100u);      // f0 f1 | f4 f5
+        const unsigned hi = __builtin_amdgcn_perm(w1, w0, 0x07060302u);      // f2 f3 | f6 f7
+        u32x4 o;
+        o[0] = f16x2_bits((as_f16x2(and_or(lo, 0x00ff00ffu, 0x64006400u)) + c1) * s2);
+        o[1] = f16x2_bits((as_f16x2(and_or(lo >> 8, 0x00ff00ffu, 0x64006400u)) + c1) * s2);
+        o[2] = f16x2_bits((as_f16x2(and_or(hi, 0x00ff00ffu, 0x64006400u)) + c1) * s2);
+        o[3] = f16x2_bits((as_f16x2(and_or(hi >> 8, 0x00ff00ffu, 0x64006400u)) + c1) * s2);
+        return o;
+    }
+};
+template <> struct Deq8<bf16> {
+    f16x2 c1;
+    float s;
+    __device__ __forceinline__ void setup(unsigned sbits, unsigned z) {
+        s = (float)__builtin_bit_cast(bf16, (unsigned short)sbits);
+        c1 = as_f16x2(z * 0x00010001u + 0xE400E400u);
+    }
+    __device__ __forceinline__ u32x4 frag(unsigned w0, unsigned w1) const {
+        const unsigned lo = __builtin_amdgcn_perm(w1, w0, 0x05040100u);
+        const unsigned hi = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+        u32x4 o;
+        o[0] = Deq1<bf16>::scaled_pair(as_f16x2(and_or(lo, 0x00ff00ffu, 0x64006400u)) + c1, s);
+        o[1] = Deq1<bf16>::scaled_pair(as_f16x2(and_or(lo >> 8, 0x00ff00ffu, 0x64006400u)) + c1, s);
+        o[2] = Deq1<bf16>::scaled_pair(as_f16x2(and_or(hi, 0x00ff00ffu, 0x64006400u)) + c1, s);
+        o[3] = Deq1<bf16>::scaled_pair(as_f16x2(and_or(hi >> 8, 0x00ff00ffu, 0x64006400u)) + c1, s);
+        return o;
+    }
+};
 template <typename T> struct Mma16;
 template <> struct Mma16<f16> {
     static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
@@ -147,12 +186,15 @@ template <typename T> __device__ __forceinline__ u32x2 pack4(f32x4 v) {
 // CW = 64-column halves per strip (1: 64-column strips; 2: 128-column strips -- every x fragment feeds 8 MFMAs instead of 4, which halves
 // the x bytes a CU pulls from L2 per flop: what bounds this kernel is the ~50 GB/s a CU gets out of the L2 when every CU reads the same x
 // (tools/xfetch_lab.hip, profiles/r03_xfetch_lab.log), by DMA or through registers alike).  CW = 2 needs RT <= 4 (128 accumulator registers).
-template <typename T, int RT, int D, bool XREG = false, int CW = 1>
+// BITS = 8 (CW = 1): a 32-deep K-step is 8 packed rows = two weight DMAs; the lane reads its two words per column from them (rows 2 kg, 2 kg + 1).
+template <typename T, int RT, int D, bool XREG = false, int CW = 1, int BITS = 4>
 __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
+    static_assert(BITS == 4 || (BITS == 8 && CW == 1 && !XREG), "8-bit: 64-column strips, x by DMA");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SB = (CW + RT) * 1024;                          // bytes of one stage: [weights CW x 1 KiB][x row tile 0] .. [x row tile RT-1]
-    constexpr int OPS = XREG ? CW : CW + RT;                      // asm-issued (compiler-invisible) VMEM instructions per stage; XREG: the x loads are the compiler's
-    constexpr int VOPS = CW + RT;                                 // all VMEM instructions per stage
+    constexpr int WD = BITS == 8 ? 2 : CW;                        // weight DMAs (KiB) per stage
+    constexpr int SB = (WD + RT) * 1024;                          // bytes of one stage: [weights WD x 1 KiB][x row tile 0] .. [x row tile RT-1]
+    constexpr int OPS = XREG ? WD : WD + RT;                      // asm-issued (compiler-invisible) VMEM instructions per stage; XREG: the x loads are the compiler's
+    constexpr int VOPS = WD + RT;                                 // all VMEM instructions per stage
     constexpr int SC = 64 * CW;                                   // columns of a strip
     static_assert((D - 1) * VOPS <= 63, "vmcnt is a 6-bit counter");
     const int tid = threadIdx.x, lane = tid & 63, W = blockDim.x >> 6;
@@ -177,7 +219,7 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
     const int b0 = ks * p.ksteps_per_split, b1 = min(b0 + p.ksteps_per_split, S);
     const int spw = (b1 - b0 + W - 1) / W;
     const int ws = b0 + wave * spw, we = min(ws + spw, b1);
-    const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
+    const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? (BITS == 8 ? 255u : 15u) : (BITS == 8 ? 511u : 31u);
 
 #ifdef GPTQ_MID_TL
     // lab build: per-wave s_memtime stamps in the last 1 KiB of the wave's table area (plan_mid adds it), dumped to the buffer whose address the
@@ -210,15 +252,18 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
             for (int it = 0; it * 4 < units; ++it) {
                 const int u = min(it * 4 + sub, units - 1);
                 const int gg = g_first + u / CW, c0 = strip * SC + (u % CW) * 64;
+                constexpr int ZL = BITS / 2;                      // 16-byte pieces of zero-points per 64 columns (4-bit: 32 B, 8-bit: 64 B)
                 const char* src = (w16 < 8) ? (const char*)((const T*)sg.scales + (size_t)gg * N + c0 + w16 * 8)
-                                            : (const char*)(sg.qzeros + (size_t)gg * (N >> 3) + (c0 >> 3) + (w16 == 8 ? 0 : 4));
+                                            : (const char*)(sg.qzeros + (size_t)gg * (N * BITS / 32) + (c0 * BITS / 32) + min(w16 - 8, ZL - 1) * 4);
                 lds_dma16(src, tab_lds + it * 1024);
             }
         }
         // fixed per-lane source offsets (bytes)
-        unsigned woff[CW];
+        unsigned woff[WD];
 #pragma unroll
-        for (int h = 0; h < CW; ++h) woff[h] = (unsigned)(((size_t)kg * N + strip * SC + h * 64 + j16 * 4) * 4);
+        for (int h = 0; h < WD; ++h)
+            woff[h] = BITS == 8 ? (unsigned)(((size_t)(4 * h + kg) * N + strip * SC + j16 * 4) * 4)       // DMA h: packed rows 4 h .. 4 h + 3
+                                : (unsigned)(((size_t)kg * N + strip * SC + h * 64 + j16 * 4) * 4);        // DMA h: 64-column half h
         unsigned xoff[RT];
         {
             const int q = lane >> 2, a = lane & 3, oct = (a - (q >> 2)) & 3;
@@ -228,7 +273,8 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
         const unsigned a_slot = (unsigned)((4 * j16 + ((kg + (j16 >> 2)) & 3)) * 16);   // where the MFMA lane (row j16, k-octet kg) finds its 16 bytes
         const char* const qw = (const char*)sg.qweight;
         const char* const xb = (const char*)p.x;
-        const size_t wstep = (size_t)N * 16;                      // bytes of 4 packed rows
+        const size_t wstep = (size_t)N * (BITS == 8 ? 32 : 16);   // bytes of the packed rows of one K-step (4-bit: 4, 8-bit: 8)
+        const unsigned w8_slot = (unsigned)((kg >> 1) * 1024 + ((((2 * kg) & 3) * 16 + j16) * 16));   // 8-bit: packed row 2 kg of the lane's 4 columns (row 2 kg + 1: + 256)
 
         u32x4 xr[XREG ? D : 1][XREG ? RT : 1];
         auto issue = [&](int s, int stage) __attribute__((always_inline)) {
@@ -240,19 +286,25 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
             }
             const char* wsrc = qw + (size_t)s * wstep;
 #pragma unroll
-            for (int h = 0; h < CW; ++h) dma16_sv_nt(wsrc, woff[h], dst + h * 1024);
+            for (int h = 0; h < WD; ++h) dma16_sv_nt(wsrc, woff[h], dst + h * 1024);
             if constexpr (!XREG) {
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) dma16_sv(xs, xoff[rt], dst + (CW + rt) * 1024);
+                for (int rt = 0; rt < RT; ++rt) dma16_sv(xs, xoff[rt], dst + (WD + rt) * 1024);
             }
         };
-        Deq1<T> dq[CW][4];
+        using DQ = std::conditional_t<BITS == 8, Deq8<T>, Deq1<T>>;
+        DQ dq[CW][4];
         int g_cur = -1;
         auto consume = [&](int s, int stage) __attribute__((always_inline)) {
             const char* st = wbase + stage * SB;
-            u32x4 qv[CW];
+            u32x4 qv[WD];
+            if constexpr (BITS == 8) {
+                qv[0] = *(const u32x4*)(st + w8_slot);
+                qv[1] = *(const u32x4*)(st + w8_slot + 256);
+            } else {
 #pragma unroll
-            for (int h = 0; h < CW; ++h) qv[h] = *(const u32x4*)(st + h * 1024 + lane * 16);
+                for (int h = 0; h < CW; ++h) qv[h] = *(const u32x4*)(st + h * 1024 + lane * 16);
+            }
             const int g = s >> p.lg_gsteps;
             if (g != g_cur) {                                     // wave-uniform
                 g_cur = g;
@@ -260,11 +312,14 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
                 for (int h = 0; h < CW; ++h) {
                     const char* tb = wbase + D * SB + ((g - g_first) * CW + h) * 256;
                     const u32x2 sraw = *(const u32x2*)(tb + j16 * 8);
-                    const unsigned zz = *(const unsigned short*)(tb + 128 + j16 * 2);
+                    unsigned zz;
+                    if constexpr (BITS == 8) zz = *(const unsigned*)(tb + 128 + j16 * 4);
+                    else zz = *(const unsigned short*)(tb + 128 + j16 * 2);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const unsigned sw = sraw[t >> 1];
-                        dq[h][t].setup((t & 1) ? (sw >> 16) : (sw & 0xffffu), (((zz >> (4 * t)) & 15u) + 1u) & zmask);
+                        const unsigned zf = BITS == 8 ? ((zz >> (8 * t)) & 255u) : ((zz >> (4 * t)) & 15u);
+                        dq[h][t].setup((t & 1) ? (sw >> 16) : (sw & 0xffffu), (zf + 1u) & zmask);
                     }
                 }
             }
@@ -272,11 +327,14 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
 #pragma unroll
             for (int h = 0; h < CW; ++h)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) b[h][t] = dq[h][t].frag(qv[h][t]);
+                for (int t = 0; t < 4; ++t) {
+                    if constexpr (BITS == 8) b[h][t] = dq[h][t].frag(qv[0][t], qv[1][t]);
+                    else b[h][t] = dq[h][t].frag(qv[h][t]);
+                }
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                if constexpr (XREG) *(u32x4*)(wbase + stage * SB + (CW + rt) * 1024 + lane * 16) = xr[stage][rt];
-                const u32x4 x4 = *(const u32x4*)(st + (CW + rt) * 1024 + a_slot);
+                if constexpr (XREG) *(u32x4*)(wbase + stage * SB + (WD + rt) * 1024 + lane * 16) = xr[stage][rt];
+                const u32x4 x4 = *(const u32x4*)(st + (WD + rt) * 1024 + a_slot);
                 u32x4 o;                                          // x in the slot order of the fragments: k0,k4,k1,k5,k2,k6,k3,k7
                 o[0] = __builtin_amdgcn_perm(x4[2], x4[0], 0x05040100u);
                 o[1] = __builtin_amdgcn_perm(x4[2], x4[0], 0x07060302u);
@@ -502,6 +560,16 @@ static int mid_row_blocks(int M, int strips, int K) {
     return (wgs >= 192 && wgs <= 256 && ks <= 2) ? blocks : 1;
 }
 
+// 8-bit layers by default?  (filled in from tools/nonq4_batched.py)
+// Measured (tools/nonq4_batched.py, profiles/r03_nonq4_batched_int8.log; us, previous default -> this kernel, int8 g32):
+//   4096x4096   M = 8 / 16 / 64 / 128: 12.3 / 16.3 / 17.8 / 26.5 -> 11.1 / 11.3 / 13.5 / 17.3
+//   4096x11008  M = 8 / 16 / 64 / 128: 23.7 / 24.2 / 29.3 / 39.5 -> 15.1 / 16.3 / 26.6 / 41.4 (tiled stays at 128)
+//   11008x4096  M = 8 / 16 / 64 / 128: 27.1 / 32.8 / 32.4 / 44.1 -> 16.1 / 16.7 / 26.4 / 38.0
+static bool mid_pays_int8(int M, int strips, int K) {
+    (void)K;
+    return M >= 5 && M <= 128 && !(M > 64 && strips >= 160);
+}
+
 MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* tune) {
     MidPlan pl{};
     if (n < 1 || n > 4 || M < 1 || M > 256) return pl;
@@ -513,15 +581,15 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     for (int i = 0; i < n; ++i) all128 = all128 && Ls[i]->N % 128 == 0;
     // 128-column strips (two 64-column halves per wave): forced by tuning.reserved[3] = 2 (1 forces 64), else by measurement (below)
     const int want_cw = (tune && tune->reserved[3] > 0) ? tune->reserved[3] : 0;
-    int cw = (want_cw == 2 && rt_ <= 4 && all128) ? 2 : 1;
-    if (want_cw == 0 && rt_ <= 4 && all128) {
+    int cw = (want_cw == 2 && rt_ <= 4 && all128 && A.bits == 4) ? 2 : 1;
+    if (want_cw == 0 && rt_ <= 4 && all128 && A.bits == 4) {
         int s128 = 0;
         for (int i = 0; i < n; ++i) s128 += Ls[i]->N / 128;
         if (mid_prefers_wide_strips(M, s128)) cw = 2;
     }
     for (int i = 0; i < n; ++i) {
         const gptq_layer_t& L = *Ls[i];
-        if (L.bits != 4 || (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16) || L.epilogue != GPTQ_EPI_NONE) return pl;
+        if ((L.bits != 4 && L.bits != 8) || L.bits != A.bits || (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16) || L.epilogue != GPTQ_EPI_NONE) return pl;
         if (L.K % 32 || L.N % 64 || L.group_size % 32) return pl;
         if (L.g_idx != nullptr && (n > 1 || !L.qweight_seq || !L.perm)) return pl;      // act-order: single layers only (x is permuted per layer)
         if (L.K != A.K || L.group_size != A.group_size || L.dtype != A.dtype || L.zero_mode != A.zero_mode) return pl;
@@ -568,7 +636,7 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     pl.ksplit = (S + pl.ksteps_per_split - 1) / pl.ksteps_per_split;                    // no empty slices
     int stages = (tune && tune->reserved[0] > 0) ? tune->reserved[0] : ((pl.rt == 2 && strips >= 160) ? 3 : 2);   // tools/mid_sweep.py: two, except two row tiles on wide layers (4096 x 11008, M = 17: 12.3 against 12.8 us)
     if (stages > 3) stages = 3;
-    if (stages < 2) stages = 2;
+    if (stages < 2 || A.bits == 8) stages = 2;
     const int ch = pl.rt < 4 ? pl.rt : 4;
     // LDS: waves x (stages x (1 + rt) KiB + group table); the table grows with a wave's K range, so when 8 waves do not fit first drop the third
     // stage, then waves (8 row tiles with one long K slice: 7 waves)
@@ -579,7 +647,7 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
 #ifdef GPTQ_MID_TL
         pl.tab_bytes += 1024;                                                           // lab build: the wave's stamp area
 #endif
-        const size_t land = (size_t)pl.waves * ((size_t)stages * (cw + pl.rt) * 1024 + pl.tab_bytes);
+        const size_t land = (size_t)pl.waves * ((size_t)stages * ((A.bits == 8 ? 2 : cw) + pl.rt) * 1024 + pl.tab_bytes);
         const size_t slabs = (size_t)pl.waves * ch * 4096;
         pl.lds_bytes = (land > slabs ? land : slabs) + 16;
         if (pl.lds_bytes <= 160 * 1024) break;
@@ -588,7 +656,8 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
         else break;
     }
     pl.stages = stages;
-    pl.xreg = tune && tune->reserved[1] == 1;
+    pl.xreg = tune && tune->reserved[1] == 1 && A.bits == 4;
+    pl.bits = A.bits;
     if (pl.lds_bytes > 160 * 1024) return pl;
     // experiment knob: reserved[1] = 3 -> the granule combine.  One hop instead of three, but 8-byte write-through stores and polls for every VALUE of a
     // 16..128 x 64 tile: 4096^2 M = 64 27.7 us against 14.8 with flags, M = 128 46 against 23 (profiles/r03_mid_kernel_granules_vs_flags.log).  What pays
@@ -608,6 +677,11 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     // Other shapes (profiles/r03_mid_kernel_more_shapes.log): 17..64 rows win on 5120^2, 8192^2, 3584x8192, 8192x3584, 13824x5120, 28672x8192 (5-20 %);
     // 97..128 rows only on the 64-strip layers above (5120^2: 26.4 against 23.1, 8192x3584: 28.8 against 25.6); layers of < 32 strips keep
     // the skinny kernel from 33 rows (8192x1024 M = 64: 15.9 against 14.0); very wide layers keep the tiled kernel from 33 rows.
+    if (A.bits == 8) {                                 // 8-bit (tools/nonq4_batched.py): measured preference, see plan_gemm
+        pl.pays = mid_pays_int8(M, strips, A.K);
+        pl.ok = true;
+        return pl;
+    }
     if (n >= 2) {
         // several layers sharing x (tools/mid_multi_ab.py, profiles/r03_mid_kernel_multi_layer_ab.log; us, one launch against layer by layer): q|k|v
         // M = 33 / 64 / 96 / 128: 17.3 / 22.1 / 28.1 / 35.9 against 34.4 / 35.7 / 40.3 / 42.5; gate|up 32.3 / 41.3 / 51.7 against 34.7 / 43.6 / 53.1, and
@@ -627,6 +701,14 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
 template <typename T, int RT, int D>
 static hipError_t launch_mid_one(const MidPlan& pl, const midk::MidParams& p, hipStream_t st) {
     const dim3 grid(pl.strips_total * pl.row_blocks * pl.ksplit), block(pl.waves * 64);
+    if (pl.bits == 8) {
+        if constexpr (D == 2) {
+            hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, 2, false, 1, 8>), grid, block, pl.lds_bytes, st, p);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if constexpr (RT <= 4) {
         if (pl.cw == 2) {
             hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, D, false, 2>), grid, block, pl.lds_bytes, st, p);
@@ -700,6 +782,9 @@ template <typename T, int RT, int D> static hipError_t grant_mid() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)midk::gemm_mid_kernel<T, RT, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if constexpr (RT <= 4) {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)midk::gemm_mid_kernel<T, RT, D, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if constexpr (D == 2) {
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)midk::gemm_mid_kernel<T, RT, 2, false, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     return e;
 }

@@ -32,6 +32,7 @@ struct MidPlan {
     bool gran;               // K slices combined through tag-validated {fp32, tag} granules (one hop) instead of partial tiles + flags
     int cw;                  // 64-column halves per strip (2: 128-column strips, M <= 64)
     int row_blocks;          // workgroups along M (each owns 16 rt rows of x)
+    int bits;                // 4 or 8
     int nseg, rt, waves, stages, ksplit, ksteps_total, ksteps_per_split, strips_total, nsum, lg_gsteps, tab_bytes;
     size_t lds_bytes;
     size_t partial_bytes;    // behind the header (and the permuted x of an act-order layer): [ksplit - 1][M][nsum] fp32 when ksplit > 1
