@@ -164,6 +164,47 @@ template <> struct Deq8<bf16> {
         return o;
     }
 };
+// 3-bit: the lane's 8 consecutive k of one column are a 24-bit window of the column's 96-bit K-step (three packed rows); low half = bits 0..15
+// (f0..f4 at 0, 3, 6, 9, 12), high half = bits 12..27 (f4..f7 at 0, 3, 6, 9): pairs (f0, f4), (f1, f5), (f2, f6) at bits 0 / 3 / 6 and (f3, f7) at
+// bit 3 of t >> 6 -- again the 4-bit slot order; exact w - z by the magic number with the shifted constants (gemv.hip: MagicF16<3>)
+template <typename T> struct Deq3;
+template <> struct Deq3<f16> {
+    f16x2 s2, c1, c3, c6;
+    __device__ __forceinline__ void setup(unsigned sbits, unsigned z) {
+        s2 = as_f16x2(sbits * 0x00010001u);
+        c1 = as_f16x2(z * 0x00010001u + 0xE400E400u);             // -(1024 + z)
+        const f16x2 k896 = {(f16)896.f, (f16)896.f}, k1008 = {(f16)1008.f, (f16)1008.f};
+        c3 = c1 + k896;                                           // -(128 + z), exact
+        c6 = c1 + k1008;                                          // -(16 + z), exact
+    }
+    __device__ __forceinline__ void diffs(unsigned v, f16x2 (&h)[4]) const {
+        const unsigned t = __builtin_amdgcn_perm(v >> 12, v, 0x05040100u);
+        const unsigned t6 = t >> 6;
+        const f16x2 r8 = {(f16)0.125f, (f16)0.125f}, r64 = {(f16)0.015625f, (f16)0.015625f};
+        h[0] = as_f16x2(and_or(t, 0x00070007u, 0x64006400u)) + c1;             // k0,k4 : w - z
+        h[1] = as_f16x2(and_or(t, 0x00380038u, 0x64006400u)) * r8 + c3;        // k1,k5
+        h[2] = as_f16x2(and_or(t, 0x01C001C0u, 0x64006400u)) * r64 + c6;       // k2,k6
+        h[3] = as_f16x2(and_or(t6, 0x00380038u, 0x64006400u)) * r8 + c3;       // k3,k7
+    }
+    __device__ __forceinline__ u32x4 frag(unsigned v) const {
+        f16x2 h[4];
+        diffs(v, h);
+        return u32x4{f16x2_bits(h[0] * s2), f16x2_bits(h[1] * s2), f16x2_bits(h[2] * s2), f16x2_bits(h[3] * s2)};
+    }
+};
+template <> struct Deq3<bf16> {
+    Deq3<f16> d;
+    float s;
+    __device__ __forceinline__ void setup(unsigned sbits, unsigned z) {
+        d.setup(0x3c00u, z);
+        s = (float)__builtin_bit_cast(bf16, (unsigned short)sbits);
+    }
+    __device__ __forceinline__ u32x4 frag(unsigned v) const {
+        f16x2 h[4];
+        d.diffs(v, h);
+        return u32x4{Deq1<bf16>::scaled_pair(h[0], s), Deq1<bf16>::scaled_pair(h[1], s), Deq1<bf16>::scaled_pair(h[2], s), Deq1<bf16>::scaled_pair(h[3], s)};
+    }
+};
 template <typename T> struct Mma16;
 template <> struct Mma16<f16> {
     static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
@@ -189,7 +230,7 @@ template <typename T> __device__ __forceinline__ u32x2 pack4(f32x4 v) {
 // BITS = 8 (CW = 1): a 32-deep K-step is 8 packed rows = two weight DMAs; the lane reads its two words per column from them (rows 2 kg, 2 kg + 1).
 template <typename T, int RT, int D, bool XREG = false, int CW = 1, int BITS = 4>
 __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
-    static_assert(BITS == 4 || (BITS == 8 && CW == 1 && !XREG), "8-bit: 64-column strips, x by DMA");
+    static_assert(BITS == 4 || ((BITS == 8 || BITS == 3) && CW == 1 && !XREG), "3- / 8-bit: 64-column strips, x by DMA");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WD = BITS == 8 ? 2 : CW;                        // weight DMAs (KiB) per stage
     constexpr int SB = (WD + RT) * 1024;                          // bytes of one stage: [weights WD x 1 KiB][x row tile 0] .. [x row tile RT-1]
@@ -219,7 +260,7 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
     const int b0 = ks * p.ksteps_per_split, b1 = min(b0 + p.ksteps_per_split, S);
     const int spw = (b1 - b0 + W - 1) / W;
     const int ws = b0 + wave * spw, we = min(ws + spw, b1);
-    const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? (BITS == 8 ? 255u : 15u) : (BITS == 8 ? 511u : 31u);
+    const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? (BITS == 8 ? 255u : (BITS == 3 ? 7u : 15u)) : (BITS == 8 ? 511u : (BITS == 3 ? 15u : 31u));
 
 #ifdef GPTQ_MID_TL
     // lab build: per-wave s_memtime stamps in the last 1 KiB of the wave's table area (plan_mid adds it), dumped to the buffer whose address the
@@ -252,9 +293,19 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
             for (int it = 0; it * 4 < units; ++it) {
                 const int u = min(it * 4 + sub, units - 1);
                 const int gg = g_first + u / CW, c0 = strip * SC + (u % CW) * 64;
-                constexpr int ZL = BITS / 2;                      // 16-byte pieces of zero-points per 64 columns (4-bit: 32 B, 8-bit: 64 B)
-                const char* src = (w16 < 8) ? (const char*)((const T*)sg.scales + (size_t)gg * N + c0 + w16 * 8)
-                                            : (const char*)(sg.qzeros + (size_t)gg * (N * BITS / 32) + (c0 * BITS / 32) + min(w16 - 8, ZL - 1) * 4);
+                const char* src;
+                if constexpr (BITS == 3) {
+                    // 64 columns x 3 bits = 24 bytes at byte 24 * strip of the row: not 16-byte aligned for odd strips -- three aligned pieces from
+                    // floor16 on cover it; a piece that would start beyond the row is never needed and re-reads the row's last 16 bytes
+                    const size_t rowb = (size_t)N * 3 / 8, base16 = ((size_t)strip * 24) & ~(size_t)15;
+                    const size_t pz = base16 + (size_t)min(w16 - 8, 2) * 16;
+                    src = (w16 < 8) ? (const char*)((const T*)sg.scales + (size_t)gg * N + c0 + w16 * 8)
+                                    : (const char*)sg.qzeros + (size_t)gg * rowb + (pz + 16 <= rowb ? pz : rowb - 16);
+                } else {
+                    constexpr int ZL = BITS / 2;                  // 16-byte pieces of zero-points per 64 columns (4-bit: 32 B, 8-bit: 64 B)
+                    src = (w16 < 8) ? (const char*)((const T*)sg.scales + (size_t)gg * N + c0 + w16 * 8)
+                                    : (const char*)(sg.qzeros + (size_t)gg * (N * BITS / 32) + (c0 * BITS / 32) + min(w16 - 8, ZL - 1) * 4);
+                }
                 lds_dma16(src, tab_lds + it * 1024);
             }
         }
@@ -263,7 +314,8 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
 #pragma unroll
         for (int h = 0; h < WD; ++h)
             woff[h] = BITS == 8 ? (unsigned)(((size_t)(4 * h + kg) * N + strip * SC + j16 * 4) * 4)       // DMA h: packed rows 4 h .. 4 h + 3
-                                : (unsigned)(((size_t)kg * N + strip * SC + h * 64 + j16 * 4) * 4);        // DMA h: 64-column half h
+                      : BITS == 3 ? (unsigned)(((size_t)min(kg, 2) * N + strip * SC + j16 * 4) * 4)       // rows 0 .. 2 of the K-step (lanes 48..63 do not take part)
+                                  : (unsigned)(((size_t)kg * N + strip * SC + h * 64 + j16 * 4) * 4);      // DMA h: 64-column half h
         unsigned xoff[RT];
         {
             const int q = lane >> 2, a = lane & 3, oct = (a - (q >> 2)) & 3;
@@ -273,7 +325,10 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
         const unsigned a_slot = (unsigned)((4 * j16 + ((kg + (j16 >> 2)) & 3)) * 16);   // where the MFMA lane (row j16, k-octet kg) finds its 16 bytes
         const char* const qw = (const char*)sg.qweight;
         const char* const xb = (const char*)p.x;
-        const size_t wstep = (size_t)N * (BITS == 8 ? 32 : 16);   // bytes of the packed rows of one K-step (4-bit: 4, 8-bit: 8)
+        const size_t wstep = (size_t)N * (BITS == 8 ? 32 : (BITS == 3 ? 12 : 16));   // bytes of the packed rows of one K-step (4-bit: 4, 8-bit: 8, 3-bit: 3)
+        // 3-bit: the lane's 24-bit window [24 kg, 24 kg + 24) of the 96-bit K-step: words (w0, w1) >> 0 / 24 for kg = 0 / 1, (w1, w2) >> 16 / 40 for kg = 2 / 3
+        const unsigned w3_sh = kg == 0 ? 0u : (kg == 1 ? 24u : (kg == 2 ? 16u : 40u));
+        const int zstart = (int)(((size_t)strip * 24) & 15);      // 3-bit: where the strip's zero-points begin inside the table's zero area (0 or 8)
         const unsigned w8_slot = (unsigned)((kg >> 1) * 1024 + ((((2 * kg) & 3) * 16 + j16) * 16));   // 8-bit: packed row 2 kg of the lane's 4 columns (row 2 kg + 1: + 256)
 
         u32x4 xr[XREG ? D : 1][XREG ? RT : 1];
@@ -286,21 +341,30 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
             }
             const char* wsrc = qw + (size_t)s * wstep;
 #pragma unroll
-            for (int h = 0; h < WD; ++h) dma16_sv_nt(wsrc, woff[h], dst + h * 1024);
+            for (int h = 0; h < WD; ++h) {
+                if constexpr (BITS == 3) {
+                    if (lane < 48) dma16_sv_nt(wsrc, woff[h], dst + h * 1024);          // three packed rows = 768 bytes of the 1 KiB slot
+                } else {
+                    dma16_sv_nt(wsrc, woff[h], dst + h * 1024);
+                }
+            }
             if constexpr (!XREG) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) dma16_sv(xs, xoff[rt], dst + (WD + rt) * 1024);
             }
         };
-        using DQ = std::conditional_t<BITS == 8, Deq8<T>, Deq1<T>>;
+        using DQ = std::conditional_t<BITS == 8, Deq8<T>, std::conditional_t<BITS == 3, Deq3<T>, Deq1<T>>>;
         DQ dq[CW][4];
         int g_cur = -1;
         auto consume = [&](int s, int stage) __attribute__((always_inline)) {
             const char* st = wbase + stage * SB;
-            u32x4 qv[WD];
+            u32x4 qv[BITS == 3 ? 3 : WD];
             if constexpr (BITS == 8) {
                 qv[0] = *(const u32x4*)(st + w8_slot);
                 qv[1] = *(const u32x4*)(st + w8_slot + 256);
+            } else if constexpr (BITS == 3) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) qv[r] = *(const u32x4*)(st + r * 256 + j16 * 16);
             } else {
 #pragma unroll
                 for (int h = 0; h < CW; ++h) qv[h] = *(const u32x4*)(st + h * 1024 + lane * 16);
@@ -314,11 +378,15 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
                     const u32x2 sraw = *(const u32x2*)(tb + j16 * 8);
                     unsigned zz;
                     if constexpr (BITS == 8) zz = *(const unsigned*)(tb + 128 + j16 * 4);
-                    else zz = *(const unsigned short*)(tb + 128 + j16 * 2);
+                    else if constexpr (BITS == 3) {               // 12 bits at bit 8 zstart + 12 j16 of the zero area (two aligned words, funnel shift)
+                        const unsigned bit = 8u * (unsigned)zstart + 12u * (unsigned)j16;
+                        const unsigned* za = (const unsigned*)(tb + 128) + (bit >> 5);
+                        zz = (unsigned)((((unsigned long long)za[1] << 32) | za[0]) >> (bit & 31u));
+                    } else zz = *(const unsigned short*)(tb + 128 + j16 * 2);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const unsigned sw = sraw[t >> 1];
-                        const unsigned zf = BITS == 8 ? ((zz >> (8 * t)) & 255u) : ((zz >> (4 * t)) & 15u);
+                        const unsigned zf = BITS == 8 ? ((zz >> (8 * t)) & 255u) : (BITS == 3 ? ((zz >> (3 * t)) & 7u) : ((zz >> (4 * t)) & 15u));
                         dq[h][t].setup((t & 1) ? (sw >> 16) : (sw & 0xffffu), (zf + 1u) & zmask);
                     }
                 }
@@ -329,7 +397,10 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if constexpr (BITS == 8) b[h][t] = dq[h][t].frag(qv[0][t], qv[1][t]);
-                    else b[h][t] = dq[h][t].frag(qv[h][t]);
+                    else if constexpr (BITS == 3) {
+                        const unsigned lo = kg < 2 ? qv[0][t] : qv[1][t], hi = kg < 2 ? qv[1][t] : qv[2][t];
+                        b[h][t] = dq[h][t].frag((unsigned)((((unsigned long long)hi << 32) | lo) >> w3_sh) & 0xFFFFFFu);
+                    } else b[h][t] = dq[h][t].frag(qv[h][t]);
                 }
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -570,6 +641,16 @@ static bool mid_pays_int8(int M, int strips, int K) {
     return M >= 5 && M <= 128 && !(M > 64 && strips >= 160);
 }
 
+// 3-bit layers by default?  (filled in from tools/nonq4_batched.py)
+// Measured (tools/nonq4_batched.py, profiles/r03_nonq4_batched_int3.log; us, previous default -> this kernel, int3 g32):
+//   4096x4096   M = 8 / 16 / 64 / 128:  9.0 / 10.8 / 15.1 / 29.9 -> 10.4 (GEMV stays) / 10.3 / 13.0 / 17.6
+//   4096x11008  M = 8 / 16 / 64 / 128: 17.7 / 26.9 / 32.9 / 38.6 -> 15.0 / 15.3 / 21.8 / 36.5
+//   11008x4096  M = 8 / 16 / 64 / 128: 16.7 / 21.6 / 30.4 / 44.7 -> 15.1 (GEMV stays: equal) / 15.7 / 24.2 / 38.7
+static bool mid_pays_int3(int M, int strips, int K) {
+    (void)K;
+    return M <= 128 && (M >= 9 || (M >= 5 && strips >= 160));
+}
+
 MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* tune) {
     MidPlan pl{};
     if (n < 1 || n > 4 || M < 1 || M > 256) return pl;
@@ -589,7 +670,7 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     }
     for (int i = 0; i < n; ++i) {
         const gptq_layer_t& L = *Ls[i];
-        if ((L.bits != 4 && L.bits != 8) || L.bits != A.bits || (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16) || L.epilogue != GPTQ_EPI_NONE) return pl;
+        if ((L.bits != 4 && L.bits != 8 && L.bits != 3) || L.bits != A.bits || (L.bits == 3 && L.N % 128) || (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16) || L.epilogue != GPTQ_EPI_NONE) return pl;
         if (L.K % 32 || L.N % 64 || L.group_size % 32) return pl;
         if (L.g_idx != nullptr && (n > 1 || !L.qweight_seq || !L.perm)) return pl;      // act-order: single layers only (x is permuted per layer)
         if (L.K != A.K || L.group_size != A.group_size || L.dtype != A.dtype || L.zero_mode != A.zero_mode) return pl;
@@ -636,7 +717,7 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     pl.ksplit = (S + pl.ksteps_per_split - 1) / pl.ksteps_per_split;                    // no empty slices
     int stages = (tune && tune->reserved[0] > 0) ? tune->reserved[0] : ((pl.rt == 2 && strips >= 160) ? 3 : 2);   // tools/mid_sweep.py: two, except two row tiles on wide layers (4096 x 11008, M = 17: 12.3 against 12.8 us)
     if (stages > 3) stages = 3;
-    if (stages < 2 || A.bits == 8) stages = 2;
+    if (stages < 2 || A.bits != 4) stages = 2;
     const int ch = pl.rt < 4 ? pl.rt : 4;
     // LDS: waves x (stages x (1 + rt) KiB + group table); the table grows with a wave's K range, so when 8 waves do not fit first drop the third
     // stage, then waves (8 row tiles with one long K slice: 7 waves)
@@ -647,7 +728,7 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
 #ifdef GPTQ_MID_TL
         pl.tab_bytes += 1024;                                                           // lab build: the wave's stamp area
 #endif
-        const size_t land = (size_t)pl.waves * ((size_t)stages * ((A.bits == 8 ? 2 : cw) + pl.rt) * 1024 + pl.tab_bytes);
+        const size_t land = (size_t)pl.waves * ((size_t)stages * ((A.bits == 8 ? 2 : cw) + pl.rt) * 1024 + pl.tab_bytes);   // 3-bit: one (768-byte) weight slot as 4-bit
         const size_t slabs = (size_t)pl.waves * ch * 4096;
         pl.lds_bytes = (land > slabs ? land : slabs) + 16;
         if (pl.lds_bytes <= 160 * 1024) break;
@@ -677,8 +758,8 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     // Other shapes (profiles/r03_mid_kernel_more_shapes.log): 17..64 rows win on 5120^2, 8192^2, 3584x8192, 8192x3584, 13824x5120, 28672x8192 (5-20 %);
     // 97..128 rows only on the 64-strip layers above (5120^2: 26.4 against 23.1, 8192x3584: 28.8 against 25.6); layers of < 32 strips keep
     // the skinny kernel from 33 rows (8192x1024 M = 64: 15.9 against 14.0); very wide layers keep the tiled kernel from 33 rows.
-    if (A.bits == 8) {                                 // 8-bit (tools/nonq4_batched.py): measured preference, see plan_gemm
-        pl.pays = mid_pays_int8(M, strips, A.K);
+    if (A.bits != 4) {                                 // 3- / 8-bit (tools/nonq4_batched.py): measured preference, see plan_gemm
+        pl.pays = A.bits == 8 ? mid_pays_int8(M, strips, A.K) : mid_pays_int3(M, strips, A.K);
         pl.ok = true;
         return pl;
     }
@@ -701,9 +782,10 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
 template <typename T, int RT, int D>
 static hipError_t launch_mid_one(const MidPlan& pl, const midk::MidParams& p, hipStream_t st) {
     const dim3 grid(pl.strips_total * pl.row_blocks * pl.ksplit), block(pl.waves * 64);
-    if (pl.bits == 8) {
+    if (pl.bits != 4) {
         if constexpr (D == 2) {
-            hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, 2, false, 1, 8>), grid, block, pl.lds_bytes, st, p);
+            if (pl.bits == 8) hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, 2, false, 1, 8>), grid, block, pl.lds_bytes, st, p);
+            else hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, 2, false, 1, 3>), grid, block, pl.lds_bytes, st, p);
             return hipGetLastError();
         } else {
             return hipErrorInvalidValue;
@@ -785,6 +867,7 @@ template <typename T, int RT, int D> static hipError_t grant_mid() {
     }
     if constexpr (D == 2) {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)midk::gemm_mid_kernel<T, RT, 2, false, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)midk::gemm_mid_kernel<T, RT, 2, false, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     return e;
 }

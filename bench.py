@@ -347,6 +347,14 @@ def bench_config5(device, steps):
                                                                "frac": round(2 * 2048 * K * N / perp / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                                                "plan": _plan_of(ls, K, N, 2048)}
                 del xp
+                # batched decode rows on this packing (int8: the 8-bit form of gemm_mid_kernel; int3: skinny / tiled)
+                for Mb in (16, 64):
+                    xb = {K: (torch.rand(Mb, K, device=device) - 0.5).half()}
+                    perb = _time_layers(ls, xb, device, max(3, steps // 2))
+                    abb = algorithmic_bytes(K, N, Mb, bits=bits, gs=32)
+                    res[f"int{bits}_g32_{K}x{N}_M{Mb}"] = {"us": round(perb * 1e6, 2), "GB_per_s": round(abb / perb / 1e9, 1), "frac": round(abb / perb / 1e9 / HBM_PEAK_GBS, 4),
+                                                         "plan": _plan_of(ls, K, N, Mb)}
+                    del xb
                 la = [(f"b{bits}a", K, N, make_layer(K, N, device, bits=bits, gs=32, act_order=True, seed=6000 + i)) for i in range(n)]
                 pera = _time_layers(la, xs, device, max(3, steps // 2))
                 aba = algorithmic_bytes(K, N, 1, bits=bits, gs=32, act_order=True)

@@ -453,6 +453,42 @@ def test_mid_kernel_int8(M, K, N, gs, act, dtype, rbs, ksplit):
         assert torch.equal(yo, (W[ks].float() + L["bias"].float()).to(dtype))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rbs,ksplit", [(0, 0), (1, 1), (2, 2), (1, 4), (4, 1)])
+@pytest.mark.parametrize("M,K,N,gs,act", [(8, 1024, 128, 32, False), (17, 2048, 256, 32, True), (64, 4096, 384, 128, False), (100, 1024, 640, 64, True),
+                                          (128, 11008, 128, 32, False), (200, 512, 128, 32, False)])
+def test_mid_kernel_int3(M, K, N, gs, act, dtype, rbs, ksplit):
+    """gemm_mid_kernel on 3-bit layers: a K-step is three packed rows (one 48-lane weight DMA), every lane funnels its 24-bit window out of the 96-bit
+    column stream, zero-points are a 24-byte run per strip that is 16-byte aligned only on even strips (N = 384 / 640: odd strips too); fp64 oracle,
+    one-hot rows, bit-reproducible, both zero conventions."""
+    if rbs > (M + 15) // 16 or (M > 128 and rbs * 8 * 16 < M):
+        pytest.skip("row blocks: at most one per row tile; 129+ rows need blocks of <= 8 row tiles")
+    L = O.random_quant_layer(K, N, 3, gs, act_order=act, seed=M + K + N, bias=True, dtype=dtype)
+    for zm in ("wrap", "nowrap"):
+        q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 3, gs, zero_mode=zm)
+        x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype)
+        mode = O.ZERO_WRAP if zm == "wrap" else O.ZERO_NOWRAP
+        y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 3, mode)
+        t = _tuning(path=3, ksplit=ksplit, lanes_n=rbs)
+        t.reserved[2] = 5
+        q.post_init()
+        d = _lib.describe_plan(q._layer, M, t)
+        if d["kernel"] != "mid":
+            assert gs == 32 and K >= 8192 and ksplit <= 1, d
+            pytest.skip("group table too large for this geometry")
+        with torch.no_grad():
+            y, yb = q(x.to(DEV), tuning=t), q(x.to(DEV), tuning=t)
+        assert torch.equal(y, yb)
+        _assert_close(y, y64, y64, dtype, K, f"mid int3 {d} vs f64")
+        ks = (torch.arange(M) * 37 + 5) % K
+        xo = torch.zeros(M, K, dtype=dtype)
+        xo[torch.arange(M), ks] = 1.0
+        with torch.no_grad():
+            yo = q(xo.to(DEV), tuning=t).cpu()
+        W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], 3, mode)
+        assert torch.equal(yo, (W[ks].float() + L["bias"].float()).to(dtype))
+
+
 @pytest.mark.parametrize("rbs,ksplit", [(2, 1), (4, 2), (8, 1), (3, 4)])
 @pytest.mark.parametrize("M,K,N,gs,act,dtype", [(33, 2048, 256, 128, False, torch.float16), (64, 4096, 512, 128, True, torch.float16), (100, 1024, 192, 32, False, torch.bfloat16),
                                                (128, 11008, 128, 128, False, torch.float16), (128, 4096, 1024, 64, True, torch.bfloat16),

@@ -326,7 +326,10 @@ def test_dispatch_rules_are_the_measured_ones():
             assert _plan(K, N, m, bits=8, gs=32)["kernel"] == "mid", (K, N, m)
     assert _plan(4096, 11008, 8, bits=8, gs=32, act=True)["kernel"] == "mid" and _plan(4096, 11008, 16, bits=8, gs=32, dtype=1)["kernel"] == "mid"
     assert _plan(4096, 11008, 128, bits=8, gs=32)["kernel"] == "tiled" and _plan(11008, 4096, 128, bits=8, gs=32)["kernel"] == "mid"
-    assert _plan(4096, 4096, 16, bits=3, gs=32)["kernel"] == "skinny64"
+    # int3 (a K-step = three packed rows = one 48-lane DMA, 24-bit windows funnelled out of the 96-bit stream): from 9 rows, from 5 on 172-strip layers
+    assert _plan(4096, 4096, 16, bits=3, gs=32)["kernel"] == "mid" and _plan(11008, 4096, 64, bits=3, gs=32)["kernel"] == "mid"
+    assert _plan(4096, 11008, 8, bits=3, gs=32)["kernel"] == "mid" and _plan(4096, 4096, 8, bits=3, gs=32)["kernel"] == "mfma_generic"
+    assert _plan(4096, 4128, 16, bits=3, gs=32)["kernel"] != "mid" and _plan(4096, 4096, 16, bits=2, gs=64)["kernel"] != "mid"
     for m in (1, 2, 4):                                   # int8 from ~40 M weights: the streamed 3- / 8-bit kernel (gemv_qx_stream_kernel) on a permuted x
         p = _plan(4096, 11008, m, bits=8, gs=32, act=True)
         assert (p["path"], p["kernel"], p["perm"], p["ln"]) == ("gemv", "stream", 2, 8), (m, p)
@@ -341,7 +344,7 @@ def test_dispatch_rules_are_the_measured_ones():
     assert _plan(4096, 11008, 1, bits=8, gs=32, dtype=1)["kernel"] == "mfma_generic"          # bf16: no packed magic-number decode
     assert _plan(4096, 11008, 8, bits=8, gs=32, act=True)["path"] == "gemm"
     p = _plan(4096, 11008, 8, bits=3, gs=32, act=True)
-    assert _plan(4096, 11008, 8, bits=3, gs=32)["path"] == "gemv" and (p["path"], p["kernel"], p["perm"]) == ("gemv", "mfma_generic", 2), p
+    assert _plan(4096, 11008, 8, bits=3, gs=32)["kernel"] == "mid" and (p["path"], p["kernel"], p["perm"]) == ("gemm", "mid", 1), p
     assert _plan(4096, 11008, 16, bits=3, gs=32, act=True)["path"] == "gemm"
     # 5..8 rows, 3-bit fp16, at most 256 strips: ONE pass of the 8-row matrix-core GEMV (8 waves); wider layers keep two 4-row passes
     # -- profiles/r02_nonq4_paths.log (int8 went to gemm_mid_kernel in round 3; its 8-row GEMV stays reachable through tuning.path = 5)
@@ -349,7 +352,7 @@ def test_dispatch_rules_are_the_measured_ones():
         p = _plan(K, N, 8, bits=3, gs=32)
         assert (p["path"], p["kernel"], p["mt"], p["waves"]) == ("gemv", "mfma_generic", 8, 8), (K, N, p)
         assert _plan(K, N, 9, bits=8, gs=32)["path"] == "gemm" and _plan(K, N, 8, bits=8, gs=32, dtype=1)["path"] == "gemm"
-    assert _plan(4096, 11008, 8, bits=3, gs=32)["mt"] == 4 and _plan(4096, 11008, 5, bits=8, gs=32)["path"] == "gemm"
+    assert _plan(4096, 11008, 5, bits=8, gs=32)["path"] == "gemm"
     assert _plan(4096, 4096, 1, bits=3, gs=32, act=True, dtype=1)["perm"] == 2 and _plan(4096, 4096, 1, bits=3, gs=32, act=True, dtype=1).get("deq") is None
     assert _plan(4096, 11008, 8, bits=2, gs=64)["path"] == "gemm" and _plan(4096, 4096, 8, bits=2, gs=64)["path"] == "gemv"
     # rows of x: GEMV up to 4; 5..8 rows: one matrix-core pass over 16 rows (16-column strips on narrow layers, the streamed
@@ -400,8 +403,8 @@ def test_dispatch_rules_are_the_measured_ones():
     # ... up to 16 rows small layers keep the 16-column strips
     assert _plan(4096, 4096, 9)["kernel"] == "strip16" and _plan(4096, 4096, 16)["kernel"] == "strip16"
     assert _plan(8192, 1024, 16)["kernel"] == "strip16"
-    assert _plan(4096, 11008, 16, bits=3, gs=32)["kernel"] == "tiled"
-    assert _plan(4096, 4096, 16, bits=3, gs=32)["kernel"] == "skinny64"          # the 16-column-strip kernel is 4-bit only
+    assert _plan(4096, 11008, 16, bits=2, gs=64)["kernel"] == "tiled"
+    assert _plan(4096, 4096, 16, bits=2, gs=64)["kernel"] == "skinny64"          # the 16-column-strip kernel is 4-bit only
     # prefill: 128 x 256 tiles, 64-deep K-steps; two K groups per workgroup when there is at most one tile per CU
     p = _plan(4096, 4096, 2048)
     assert (p["kernel"], p["mt"], p["bk"], p["kg"], p["ksplit"], p["tiles"]) == ("tiled", 4, 64, 2, 1, "16x16"), p

@@ -16,7 +16,7 @@ for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
             x = (torch.rand(M, K, device=dev) - 0.5).half()
             t = run(ls, x, None)
             extra = ""
-            if bits == 8:
+            if bits in (8, 3):
                 tn = _lib.GptqTuning(); tn.path = 3; tn.reserved[2] = 5
                 try:
                     extra = f" mid {run(ls, x, tn) * 1e6:6.2f}"
