@@ -489,6 +489,30 @@ def test_mid_kernel_int3(M, K, N, gs, act, dtype, rbs, ksplit):
         assert torch.equal(yo, (W[ks].float() + L["bias"].float()).to(dtype))
 
 
+@pytest.mark.parametrize("bits,gs", [(8, 32), (3, 32), (8, 128), (3, 64)])
+@pytest.mark.parametrize("M", [6, 16, 64])
+def test_mid_multi_layer_launch_3_and_8_bit(bits, gs, M):
+    """gptq_forward_multi on 3- / 8-bit layers that share x at 5..128 rows: one gemm_mid_kernel launch (forced and by default), every layer against the
+    fp64 oracle and against its own single-layer forward."""
+    from autogptq_amd.qlinear_mi355x import forward_multi
+    K, widths = 2048, (512, 128, 1024)
+    Ls = [O.random_quant_layer(K, n, bits, gs, seed=57 + i + M + bits, bias=(i == 1), dtype=torch.float16) for i, n in enumerate(widths)]
+    qs = [_module_from(L["qweight"], L["qzeros"], L["scales"], None, L["bias"], bits, gs) for L in Ls]
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).half().to(DEV)
+    t = _tuning(path=3)
+    t.reserved[2] = 5
+    with torch.no_grad():
+        yf = forward_multi(qs, x, tuning=t)
+        yd = forward_multi(qs, x)
+        sep = [q(x) for q in qs]
+    mode = O.reference_zero_mode(False, bits)
+    for y, d, s_, L in zip(yf, yd, sep, Ls):
+        ref = O.forward_f64(x.cpu(), L["qweight"], L["qzeros"], L["scales"], None, L["bias"], bits, mode)
+        _assert_close(y, ref, ref, torch.float16, K, "mid multi (forced) vs oracle")
+        _assert_close(d, ref, ref, torch.float16, K, "mid multi (default) vs oracle")
+        _assert_close(s_, ref, ref, torch.float16, K, "single layer vs oracle")
+
+
 @pytest.mark.parametrize("rbs,ksplit", [(2, 1), (4, 2), (8, 1), (3, 4)])
 @pytest.mark.parametrize("M,K,N,gs,act,dtype", [(33, 2048, 256, 128, False, torch.float16), (64, 4096, 512, 128, True, torch.float16), (100, 1024, 192, 32, False, torch.bfloat16),
                                                (128, 11008, 128, 128, False, torch.float16), (128, 4096, 1024, 64, True, torch.bfloat16),
