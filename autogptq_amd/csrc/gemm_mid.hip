@@ -679,7 +679,6 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     }
     const int lg = ilog2_exact(A.group_size / 32);
     if (lg < 0) return pl;
-    if ((size_t)strips * 4 > WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES - WS_HEADER_EPOCH_OFFSET) return pl;   // one epoch word per strip in the second half
     if ((size_t)M * A.K * 2 >= ((size_t)1 << 31)) return pl;                            // 32-bit lane offsets into x
     pl.nseg = n;
     pl.strips_total = strips;
@@ -743,7 +742,8 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     // experiment knob: reserved[1] = 3 -> the granule combine.  One hop instead of three, but 8-byte write-through stores and polls for every VALUE of a
     // 16..128 x 64 tile: 4096^2 M = 64 27.7 us against 14.8 with flags, M = 128 46 against 23 (profiles/r03_mid_kernel_granules_vs_flags.log).  What pays
     // for the one to four rows of the streamed GEMV (64 values per strip) does not scale to a tile.
-    pl.gran = tune && tune->reserved[1] == 3;
+    pl.gran = tune && tune->reserved[1] == 3 &&
+              (size_t)strips * pl.row_blocks * 4 <= WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES - WS_HEADER_EPOCH_OFFSET;   // one epoch word per (row block, strip) in the header's second half
     pl.partial_bytes = pl.ksplit > 1 ? (size_t)(pl.ksplit - 1) * M * nsum * (pl.gran ? 8 : 4) : 0;
 #ifdef GPTQ_MID_TL
     if (!pl.partial_bytes) pl.partial_bytes = 256;                                      // lab build: always a workspace (its header tail carries the timeline pointer)
