@@ -633,8 +633,17 @@ def test_planner_fuzz_every_configuration_plans_or_refuses_cleanly():
         plan = dict(kv.split("=", 1) for kv in buf.value.decode().split())
         seen.add(plan["kernel"])
         assert plan["path"] in ("gemv", "gemm") and int(plan["ksplit"]) >= 1
-        if int(plan["ksplit"]) > 1 and plan["kernel"] not in ("stream", "stream64"):      # fp32 slabs [ksplit, M, N] behind the header
+        if int(plan["ksplit"]) > 1 and plan["kernel"] not in ("stream", "stream64", "mid"):      # fp32 slabs [ksplit, M, N] behind the header
             assert need >= int(plan["ksplit"]) * M * (N // (2 if L.epilogue and plan.get("pair") == "1" else 1)) * 4 // 2, (plan, need)
+        if plan["kernel"] == "mid":
+            # gemm_mid_kernel: the owner slices WAIT for the others, so a K-split launch must fit one workgroup per CU (256); (ksplit - 1) fp32 tiles
+            # behind the header (and the permuted x of an act-order layer); row blocks x row tiles cover M; 4 / 8 / 3 bits only
+            rb, strips = map(int, plan["tiles"].split("x"))
+            ks, rt = int(plan["ksplit"]), int(plan["mt"])
+            assert bits in (3, 4, 8) and N % 64 == 0 and strips == N // 64 and rt in (1, 2, 4, 6, 8) and rb * rt * 16 >= M and (rb - 1) * rt * 16 < M, plan
+            assert ks == 1 or rb * strips * ks <= 256, plan
+            assert need >= (ks - 1) * M * N * 4 + (65536 if ks > 1 else 0), (plan, need)
+            assert 2 <= int(plan["u"]) <= 3 and 4 <= int(plan["waves"]) <= 8, plan
         assert need < (1 << 34)
         assert lib.gptq_workspace_bytes_max(ctypes.byref(L), M) >= need
-    assert {"mfma", "mfma_generic", "generic", "tiled", "skinny64", "stream64", "strip16", "f32_mfma"} <= seen, seen
+    assert {"mfma", "mfma_generic", "generic", "tiled", "skinny64", "stream64", "strip16", "f32_mfma", "mid", "stream"} <= seen, seen
