@@ -85,8 +85,8 @@ bool want_gemm(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
         // 12.5 / 16.6, 11008x4096 27.2 / 32.4; 4096x11008 26.0 / 23.6 keeps the GEMM from 5 rows)
         const bool int8_rows8 = L->bits == 8 && L->dtype == GPTQ_F16 && L->N <= 4096 && L->epilogue == GPTQ_EPI_NONE && !raw_act;
         const int min_m = raw_act ? (L->bits == 8 ? 3 : 5) : (L->bits == 8 ? (int8_rows8 ? 9 : 5) : ((L->bits == 2 && big) ? 5 : 9));
-        if (M >= 5 && M < min_m && (L->bits == 8 || L->bits == 3) && L->epilogue == GPTQ_EPI_NONE && !raw_act) {
-            const GemmPlan g8 = plan_gemm(*L, M, t);              // 5..8 rows: the 3- / 8-bit forms of gemm_mid_kernel where the planner takes them (tools/nonq4_batched.py:
+        if (M >= 5 && M < min_m && L->epilogue == GPTQ_EPI_NONE && !raw_act) {
+            const GemmPlan g8 = plan_gemm(*L, M, t);              // 5..8 rows: the 2- / 3- / 8-bit forms of gemm_mid_kernel where the planner takes them (tools/nonq4_batched.py:
             if (g8.supported && g8.mid) return true;              // 11008x4096 M = 8 27.1 -> 16.1 us, 4096x4096 12.3 -> 11.1)
         }
         if (M < min_m) return false;

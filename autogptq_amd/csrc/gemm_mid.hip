@@ -205,6 +205,47 @@ template <> struct Deq3<bf16> {
         return u32x4{Deq1<bf16>::scaled_pair(h[0], s), Deq1<bf16>::scaled_pair(h[1], s), Deq1<bf16>::scaled_pair(h[2], s), Deq1<bf16>::scaled_pair(h[3], s)};
     }
 };
+// 2-bit: the lane's 8 consecutive k of one column are 16 bits of a word (16 values per word: half kg & 1 of packed row kg >> 1); v_perm spreads the two
+// bytes over the halves of a register (f0..f3 at bits 0, 2, 4, 6 of the low half, f4..f7 of the high half): pairs (f0, f4), (f1, f5), (f2, f6), (f3, f7)
+// -- the 4-bit slot order again -- each ONE v_and_or + ONE packed fma by 2^-s with -(1024 * 2^-s + z), exact
+template <typename T> struct Deq2;
+template <> struct Deq2<f16> {
+    f16x2 s2, c1, c2, c4, c6;
+    __device__ __forceinline__ void setup(unsigned sbits, unsigned z) {
+        s2 = as_f16x2(sbits * 0x00010001u);
+        c1 = as_f16x2(z * 0x00010001u + 0xE400E400u);             // -(1024 + z)
+        const f16x2 k768 = {(f16)768.f, (f16)768.f}, k960 = {(f16)960.f, (f16)960.f}, k1008 = {(f16)1008.f, (f16)1008.f};
+        c2 = c1 + k768;                                           // -(256 + z), exact
+        c4 = c1 + k960;                                           // -(64 + z)
+        c6 = c1 + k1008;                                          // -(16 + z)
+    }
+    __device__ __forceinline__ void diffs(unsigned v16, f16x2 (&h)[4]) const {
+        const unsigned t = __builtin_amdgcn_perm(v16, v16, 0x0c010c00u);       // byte 0 -> bits 0..7, byte 1 -> bits 16..23
+        const f16x2 r4 = {(f16)0.25f, (f16)0.25f}, r16 = {(f16)0.0625f, (f16)0.0625f}, r64 = {(f16)0.015625f, (f16)0.015625f};
+        h[0] = as_f16x2(and_or(t, 0x00030003u, 0x64006400u)) + c1;             // k0,k4 : w - z
+        h[1] = as_f16x2(and_or(t, 0x000C000Cu, 0x64006400u)) * r4 + c2;        // k1,k5
+        h[2] = as_f16x2(and_or(t, 0x00300030u, 0x64006400u)) * r16 + c4;       // k2,k6
+        h[3] = as_f16x2(and_or(t, 0x00C000C0u, 0x64006400u)) * r64 + c6;       // k3,k7
+    }
+    __device__ __forceinline__ u32x4 frag(unsigned v) const {
+        f16x2 h[4];
+        diffs(v, h);
+        return u32x4{f16x2_bits(h[0] * s2), f16x2_bits(h[1] * s2), f16x2_bits(h[2] * s2), f16x2_bits(h[3] * s2)};
+    }
+};
+template <> struct Deq2<bf16> {
+    Deq2<f16> d;
+    float s;
+    __device__ __forceinline__ void setup(unsigned sbits, unsigned z) {
+        d.setup(0x3c00u, z);
+        s = (float)__builtin_bit_cast(bf16, (unsigned short)sbits);
+    }
+    __device__ __forceinline__ u32x4 frag(unsigned v) const {
+        f16x2 h[4];
+        d.diffs(v, h);
+        return u32x4{Deq1<bf16>::scaled_pair(h[0], s), Deq1<bf16>::scaled_pair(h[1], s), Deq1<bf16>::scaled_pair(h[2], s), Deq1<bf16>::scaled_pair(h[3], s)};
+    }
+};
 template <typename T> struct Mma16;
 template <> struct Mma16<f16> {
     static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
@@ -230,7 +271,7 @@ template <typename T> __device__ __forceinline__ u32x2 pack4(f32x4 v) {
 // BITS = 8 (CW = 1): a 32-deep K-step is 8 packed rows = two weight DMAs; the lane reads its two words per column from them (rows 2 kg, 2 kg + 1).
 template <typename T, int RT, int D, bool XREG = false, int CW = 1, int BITS = 4>
 __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
-    static_assert(BITS == 4 || ((BITS == 8 || BITS == 3) && CW == 1 && !XREG), "3- / 8-bit: 64-column strips, x by DMA");
+    static_assert(BITS == 4 || ((BITS == 8 || BITS == 3 || BITS == 2) && CW == 1 && !XREG), "2- / 3- / 8-bit: 64-column strips, x by DMA");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WD = BITS == 8 ? 2 : CW;                        // weight DMAs (KiB) per stage
     constexpr int SB = (WD + RT) * 1024;                          // bytes of one stage: [weights WD x 1 KiB][x row tile 0] .. [x row tile RT-1]
@@ -260,7 +301,7 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
     const int b0 = ks * p.ksteps_per_split, b1 = min(b0 + p.ksteps_per_split, S);
     const int spw = (b1 - b0 + W - 1) / W;
     const int ws = b0 + wave * spw, we = min(ws + spw, b1);
-    const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? (BITS == 8 ? 255u : (BITS == 3 ? 7u : 15u)) : (BITS == 8 ? 511u : (BITS == 3 ? 15u : 31u));
+    const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? ((1u << BITS) - 1u) : ((2u << BITS) - 1u);      // stored zero + 1, wrapped to the field or not
 
 #ifdef GPTQ_MID_TL
     // lab build: per-wave s_memtime stamps in the last 1 KiB of the wave's table area (plan_mid adds it), dumped to the buffer whose address the
@@ -302,7 +343,7 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
                     src = (w16 < 8) ? (const char*)((const T*)sg.scales + (size_t)gg * N + c0 + w16 * 8)
                                     : (const char*)sg.qzeros + (size_t)gg * rowb + (pz + 16 <= rowb ? pz : rowb - 16);
                 } else {
-                    constexpr int ZL = BITS / 2;                  // 16-byte pieces of zero-points per 64 columns (4-bit: 32 B, 8-bit: 64 B)
+                    constexpr int ZL = BITS / 2;                  // 16-byte pieces of zero-points per 64 columns (2-bit: 16 B, 4-bit: 32 B, 8-bit: 64 B)
                     src = (w16 < 8) ? (const char*)((const T*)sg.scales + (size_t)gg * N + c0 + w16 * 8)
                                     : (const char*)(sg.qzeros + (size_t)gg * (N * BITS / 32) + (c0 * BITS / 32) + min(w16 - 8, ZL - 1) * 4);
                 }
@@ -315,6 +356,7 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
         for (int h = 0; h < WD; ++h)
             woff[h] = BITS == 8 ? (unsigned)(((size_t)(4 * h + kg) * N + strip * SC + j16 * 4) * 4)       // DMA h: packed rows 4 h .. 4 h + 3
                       : BITS == 3 ? (unsigned)(((size_t)min(kg, 2) * N + strip * SC + j16 * 4) * 4)       // rows 0 .. 2 of the K-step (lanes 48..63 do not take part)
+                      : BITS == 2 ? (unsigned)(((size_t)min(kg, 1) * N + strip * SC + j16 * 4) * 4)       // rows 0 .. 1 (lanes 32..63 do not take part)
                                   : (unsigned)(((size_t)kg * N + strip * SC + h * 64 + j16 * 4) * 4);      // DMA h: 64-column half h
         unsigned xoff[RT];
         {
@@ -325,7 +367,7 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
         const unsigned a_slot = (unsigned)((4 * j16 + ((kg + (j16 >> 2)) & 3)) * 16);   // where the MFMA lane (row j16, k-octet kg) finds its 16 bytes
         const char* const qw = (const char*)sg.qweight;
         const char* const xb = (const char*)p.x;
-        const size_t wstep = (size_t)N * (BITS == 8 ? 32 : (BITS == 3 ? 12 : 16));   // bytes of the packed rows of one K-step (4-bit: 4, 8-bit: 8, 3-bit: 3)
+        const size_t wstep = (size_t)N * BITS * 4;                // bytes of the packed rows of one K-step (32 k = BITS rows)
         // 3-bit: the lane's 24-bit window [24 kg, 24 kg + 24) of the 96-bit K-step: words (w0, w1) >> 0 / 24 for kg = 0 / 1, (w1, w2) >> 16 / 40 for kg = 2 / 3
         const unsigned w3_sh = kg == 0 ? 0u : (kg == 1 ? 24u : (kg == 2 ? 16u : 40u));
         const int zstart = (int)(((size_t)strip * 24) & 15);      // 3-bit: where the strip's zero-points begin inside the table's zero area (0 or 8)
@@ -342,8 +384,8 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
             const char* wsrc = qw + (size_t)s * wstep;
 #pragma unroll
             for (int h = 0; h < WD; ++h) {
-                if constexpr (BITS == 3) {
-                    if (lane < 48) dma16_sv_nt(wsrc, woff[h], dst + h * 1024);          // three packed rows = 768 bytes of the 1 KiB slot
+                if constexpr (BITS == 3 || BITS == 2) {
+                    if (lane < 16 * BITS) dma16_sv_nt(wsrc, woff[h], dst + h * 1024);   // three / two packed rows = 768 / 512 bytes of the 1 KiB slot
                 } else {
                     dma16_sv_nt(wsrc, woff[h], dst + h * 1024);
                 }
@@ -353,18 +395,18 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
                 for (int rt = 0; rt < RT; ++rt) dma16_sv(xs, xoff[rt], dst + (WD + rt) * 1024);
             }
         };
-        using DQ = std::conditional_t<BITS == 8, Deq8<T>, std::conditional_t<BITS == 3, Deq3<T>, Deq1<T>>>;
+        using DQ = std::conditional_t<BITS == 8, Deq8<T>, std::conditional_t<BITS == 3, Deq3<T>, std::conditional_t<BITS == 2, Deq2<T>, Deq1<T>>>>;
         DQ dq[CW][4];
         int g_cur = -1;
         auto consume = [&](int s, int stage) __attribute__((always_inline)) {
             const char* st = wbase + stage * SB;
-            u32x4 qv[BITS == 3 ? 3 : WD];
+            u32x4 qv[BITS == 3 ? 3 : (BITS == 2 ? 2 : WD)];
             if constexpr (BITS == 8) {
                 qv[0] = *(const u32x4*)(st + w8_slot);
                 qv[1] = *(const u32x4*)(st + w8_slot + 256);
-            } else if constexpr (BITS == 3) {
+            } else if constexpr (BITS == 3 || BITS == 2) {
 #pragma unroll
-                for (int r = 0; r < 3; ++r) qv[r] = *(const u32x4*)(st + r * 256 + j16 * 16);
+                for (int r = 0; r < BITS; ++r) qv[r] = *(const u32x4*)(st + r * 256 + j16 * 16);
             } else {
 #pragma unroll
                 for (int h = 0; h < CW; ++h) qv[h] = *(const u32x4*)(st + h * 1024 + lane * 16);
@@ -382,11 +424,12 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
                         const unsigned bit = 8u * (unsigned)zstart + 12u * (unsigned)j16;
                         const unsigned* za = (const unsigned*)(tb + 128) + (bit >> 5);
                         zz = (unsigned)((((unsigned long long)za[1] << 32) | za[0]) >> (bit & 31u));
-                    } else zz = *(const unsigned short*)(tb + 128 + j16 * 2);
+                    } else if constexpr (BITS == 2) zz = *(const unsigned char*)(tb + 128 + j16);
+                    else zz = *(const unsigned short*)(tb + 128 + j16 * 2);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const unsigned sw = sraw[t >> 1];
-                        const unsigned zf = BITS == 8 ? ((zz >> (8 * t)) & 255u) : (BITS == 3 ? ((zz >> (3 * t)) & 7u) : ((zz >> (4 * t)) & 15u));
+                        const unsigned zf = (zz >> (BITS * t)) & ((1u << BITS) - 1u);
                         dq[h][t].setup((t & 1) ? (sw >> 16) : (sw & 0xffffu), (zf + 1u) & zmask);
                     }
                 }
@@ -400,6 +443,9 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
                     else if constexpr (BITS == 3) {
                         const unsigned lo = kg < 2 ? qv[0][t] : qv[1][t], hi = kg < 2 ? qv[1][t] : qv[2][t];
                         b[h][t] = dq[h][t].frag((unsigned)((((unsigned long long)hi << 32) | lo) >> w3_sh) & 0xFFFFFFu);
+                    } else if constexpr (BITS == 2) {
+                        const unsigned wsel = (kg & 2) ? qv[1][t] : qv[0][t];
+                        b[h][t] = dq[h][t].frag((kg & 1) ? (wsel >> 16) : (wsel & 0xFFFFu));
                     } else b[h][t] = dq[h][t].frag(qv[h][t]);
                 }
 #pragma unroll
@@ -641,6 +687,15 @@ static bool mid_pays_int8(int M, int strips, int K) {
     return M >= 5 && M <= 128 && !(M > 64 && strips >= 160);
 }
 
+// 2-bit layers by default?  (filled in from tools/nonq4_batched.py)
+// Measured (tools/nonq4_batched.py, profiles/r03_nonq4_batched_int2.log; us, previous default -> this kernel, int2 g64, M = 8 / 16 / 64 / 128):
+//   4096x4096 10.2 / 11.3 / 15.4 / 33.2 -> 9.0 / 9.0 / 12.1 / 15.8;  4096x11008 24.9 / 26.2 / 33.9 / 43.3 -> 13.3 / 13.1 / 20.3 / 34.0;
+//   11008x4096 23.5 / 23.5 / 28.7 / 50.0 -> 13.6 / 13.9 / 21.6 / 32.7
+static bool mid_pays_int2(int M, int strips, int K) {
+    (void)strips; (void)K;
+    return M >= 5 && M <= 128;
+}
+
 // 3-bit layers by default?  (filled in from tools/nonq4_batched.py)
 // Measured (tools/nonq4_batched.py, profiles/r03_nonq4_batched_int3.log; us, previous default -> this kernel, int3 g32):
 //   4096x4096   M = 8 / 16 / 64 / 128:  9.0 / 10.8 / 15.1 / 29.9 -> 10.4 (GEMV stays) / 10.3 / 13.0 / 17.6
@@ -670,7 +725,7 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     }
     for (int i = 0; i < n; ++i) {
         const gptq_layer_t& L = *Ls[i];
-        if ((L.bits != 4 && L.bits != 8 && L.bits != 3) || L.bits != A.bits || (L.bits == 3 && L.N % 128) || (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16) || L.epilogue != GPTQ_EPI_NONE) return pl;
+        if ((L.bits != 4 && L.bits != 8 && L.bits != 3 && L.bits != 2) || L.bits != A.bits || (L.bits == 3 && L.N % 128) || (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16) || L.epilogue != GPTQ_EPI_NONE) return pl;
         if (L.K % 32 || L.N % 64 || L.group_size % 32) return pl;
         if (L.g_idx != nullptr && (n > 1 || !L.qweight_seq || !L.perm)) return pl;      // act-order: single layers only (x is permuted per layer)
         if (L.K != A.K || L.group_size != A.group_size || L.dtype != A.dtype || L.zero_mode != A.zero_mode) return pl;
@@ -759,7 +814,7 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     // 97..128 rows only on the 64-strip layers above (5120^2: 26.4 against 23.1, 8192x3584: 28.8 against 25.6); layers of < 32 strips keep
     // the skinny kernel from 33 rows (8192x1024 M = 64: 15.9 against 14.0); very wide layers keep the tiled kernel from 33 rows.
     if (A.bits != 4) {                                 // 3- / 8-bit (tools/nonq4_batched.py): measured preference, see plan_gemm
-        pl.pays = A.bits == 8 ? mid_pays_int8(M, strips, A.K) : mid_pays_int3(M, strips, A.K);
+        pl.pays = A.bits == 8 ? mid_pays_int8(M, strips, A.K) : (A.bits == 3 ? mid_pays_int3(M, strips, A.K) : mid_pays_int2(M, strips, A.K));
         pl.ok = true;
         return pl;
     }
@@ -785,7 +840,8 @@ static hipError_t launch_mid_one(const MidPlan& pl, const midk::MidParams& p, hi
     if (pl.bits != 4) {
         if constexpr (D == 2) {
             if (pl.bits == 8) hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, 2, false, 1, 8>), grid, block, pl.lds_bytes, st, p);
-            else hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, 2, false, 1, 3>), grid, block, pl.lds_bytes, st, p);
+            else if (pl.bits == 3) hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, 2, false, 1, 3>), grid, block, pl.lds_bytes, st, p);
+            else hipLaunchKernelGGL((midk::gemm_mid_kernel<T, RT, 2, false, 1, 2>), grid, block, pl.lds_bytes, st, p);
             return hipGetLastError();
         } else {
             return hipErrorInvalidValue;
@@ -868,6 +924,7 @@ template <typename T, int RT, int D> static hipError_t grant_mid() {
     if constexpr (D == 2) {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)midk::gemm_mid_kernel<T, RT, 2, false, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)midk::gemm_mid_kernel<T, RT, 2, false, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)midk::gemm_mid_kernel<T, RT, 2, false, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     return e;
 }

@@ -489,6 +489,38 @@ def test_mid_kernel_int3(M, K, N, gs, act, dtype, rbs, ksplit):
         assert torch.equal(yo, (W[ks].float() + L["bias"].float()).to(dtype))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rbs,ksplit", [(0, 0), (1, 1), (2, 2), (1, 4)])
+@pytest.mark.parametrize("M,K,N,gs,act", [(8, 1024, 128, 32, False), (17, 2048, 256, 64, True), (64, 4096, 320, 128, False), (100, 1024, 192, 64, True), (128, 2048, 64, 2048, False)])
+def test_mid_kernel_int2(M, K, N, gs, act, dtype, rbs, ksplit):
+    """gemm_mid_kernel on 2-bit layers: a K-step is two packed rows (one 32-lane weight DMA), the lane's 8 values are 16 bits of a word spread over the
+    halves of a register by one v_perm, four (v_and_or, packed fma) pairs; fp64 oracle, one-hot rows, bit-reproducible, both zero conventions."""
+    if rbs > (M + 15) // 16:
+        pytest.skip("row blocks: at most one per row tile")
+    L = O.random_quant_layer(K, N, 2, gs, act_order=act, seed=M + K + N, bias=True, dtype=dtype)
+    for zm in ("wrap", "nowrap"):
+        q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 2, gs, zero_mode=zm)
+        x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype)
+        mode = O.ZERO_WRAP if zm == "wrap" else O.ZERO_NOWRAP
+        y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 2, mode)
+        t = _tuning(path=3, ksplit=ksplit, lanes_n=rbs)
+        t.reserved[2] = 5
+        q.post_init()
+        d = _lib.describe_plan(q._layer, M, t)
+        assert d["kernel"] == "mid", d
+        with torch.no_grad():
+            y, yb = q(x.to(DEV), tuning=t), q(x.to(DEV), tuning=t)
+        assert torch.equal(y, yb)
+        _assert_close(y, y64, y64, dtype, K, f"mid int2 {d} vs f64")
+        ks = (torch.arange(M) * 37 + 5) % K
+        xo = torch.zeros(M, K, dtype=dtype)
+        xo[torch.arange(M), ks] = 1.0
+        with torch.no_grad():
+            yo = q(xo.to(DEV), tuning=t).cpu()
+        W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], 2, mode)
+        assert torch.equal(yo, (W[ks].float() + L["bias"].float()).to(dtype))
+
+
 @pytest.mark.parametrize("bits,gs", [(8, 32), (3, 32), (8, 128), (3, 64)])
 @pytest.mark.parametrize("M", [6, 16, 64])
 def test_mid_multi_layer_launch_3_and_8_bit(bits, gs, M):

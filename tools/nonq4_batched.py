@@ -8,7 +8,7 @@ from tools.gemv_sweep import run
 from autogptq_amd import _lib
 dev = torch.device("cuda:0")
 for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
-    for bits, gs in ((4, 128), (4, 32), (8, 32), (3, 32)):
+    for bits, gs in ((4, 128), (4, 32), (8, 32), (3, 32), (2, 64)):
         n = max(4, min(24, (320 << 20) // (K * N * bits // 8)))
         ls = [make_layer(K, N, dev, bits=bits, gs=gs, seed=i) for i in range(n)]
         out = []
@@ -16,7 +16,7 @@ for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
             x = (torch.rand(M, K, device=dev) - 0.5).half()
             t = run(ls, x, None)
             extra = ""
-            if bits in (8, 3):
+            if bits in (8, 3, 2):
                 tn = _lib.GptqTuning(); tn.path = 3; tn.reserved[2] = 5
                 try:
                     extra = f" mid {run(ls, x, tn) * 1e6:6.2f}"
