@@ -841,12 +841,17 @@ __global__ void __launch_bounds__(1024, (std::is_same_v<T, f16> && !PAIR && !PER
 // recognizer -- it landed BEFORE the in-flight MFMA's write of the same (dead) register, which then overwrote the fragment.
 struct MagicConsts {
     unsigned magic, m0, m3, m6, m8;      // 0x64006400 (VGPR); 3-bit field masks at bits 0 / 3 / 6 of both halves, 8-bit mask (SGPRs)
+    unsigned q0, q2, q4, q6;             // 2-bit field masks at bits 0 / 2 / 4 / 6 of both halves (SGPRs)
     __device__ __forceinline__ void init() {
         asm("v_mov_b32 %0, 0x64006400" : "=v"(magic));
         asm("s_mov_b32 %0, 0x00070007" : "=s"(m0));
         asm("s_mov_b32 %0, 0x00380038" : "=s"(m3));
         asm("s_mov_b32 %0, 0x01c001c0" : "=s"(m6));
         asm("s_mov_b32 %0, 0x00ff00ff" : "=s"(m8));
+        asm("s_mov_b32 %0, 0x00030003" : "=s"(q0));
+        asm("s_mov_b32 %0, 0x000c000c" : "=s"(q2));
+        asm("s_mov_b32 %0, 0x00300030" : "=s"(q4));
+        asm("s_mov_b32 %0, 0x00c000c0" : "=s"(q6));
     }
 };
 __device__ __forceinline__ unsigned f16x2_bits(f16x2 v) { return __builtin_bit_cast(unsigned, v); }
@@ -861,6 +866,33 @@ template <> struct MagicF16<8> {
     __device__ __forceinline__ void pairs(const unsigned (&w)[1], const MagicConsts& k, unsigned (&bp)[NP]) const {
         bp[0] = f16x2_bits(as_f16x2((w[0] & k.m8) | k.magic) + c1);
         bp[1] = f16x2_bits(as_f16x2(((w[0] >> 8) & k.m8) | k.magic) + c1);
+    }
+};
+// 2-bit (round 3): 16 values per word; v_perm spreads bytes 0 / 1 (values 0..7) and bytes 2 / 3 (values 8..15) over the halves of a register, so that
+// the fields pair up as (f, f + 4) at bits 0 / 2 / 4 / 6 of both halves: 2 v_perm + 8 (v_and_or, packed add / fma) per 16 weights -- the field-by-field
+// form this replaces made a 2-bit layer SLOWER than the 4-bit layer of twice the bytes (4096 x 11008, M = 1: 13.0 us against 8.4)
+template <> struct MagicF16<2> {
+    static constexpr int NP = 8;                                   // pairs per unit (16 values)
+    static constexpr int ka(int p) { return p < 4 ? p : p + 4; }  // (0,4) (1,5) (2,6) (3,7) | (8,12) (9,13) (10,14) (11,15)
+    static constexpr int kb(int p) { return ka(p) + 4; }
+    f16x2 c1, c2, c4, c6;
+    __device__ __forceinline__ void setup(int z) {                 // z <= 4
+        c1 = as_f16x2((unsigned)z * 0x00010001u + 0xE400E400u);   // -(1024 + z)
+        const f16x2 k768 = {(f16)768.f, (f16)768.f}, k960 = {(f16)960.f, (f16)960.f}, k1008 = {(f16)1008.f, (f16)1008.f};
+        c2 = c1 + k768;                                            // -(256 + z), exact
+        c4 = c1 + k960;                                            // -(64 + z)
+        c6 = c1 + k1008;                                           // -(16 + z)
+    }
+    __device__ __forceinline__ void four(unsigned t, const MagicConsts& k, unsigned* bp) const {
+        const f16x2 r4 = {(f16)0.25f, (f16)0.25f}, r16 = {(f16)0.0625f, (f16)0.0625f}, r64 = {(f16)0.015625f, (f16)0.015625f};
+        bp[0] = f16x2_bits(as_f16x2((t & k.q0) | k.magic) + c1);
+        bp[1] = f16x2_bits(as_f16x2((t & k.q2) | k.magic) * r4 + c2);
+        bp[2] = f16x2_bits(as_f16x2((t & k.q4) | k.magic) * r16 + c4);
+        bp[3] = f16x2_bits(as_f16x2((t & k.q6) | k.magic) * r64 + c6);
+    }
+    __device__ __forceinline__ void pairs(const unsigned (&w)[1], const MagicConsts& k, unsigned (&bp)[NP]) const {
+        four(__builtin_amdgcn_perm(w[0], w[0], 0x0c010c00u), k, bp);          // byte 0 -> bits 0..7, byte 1 -> bits 16..23
+        four(__builtin_amdgcn_perm(w[0], w[0], 0x0c030c02u), k, bp + 4);      // bytes 2, 3
     }
 };
 template <> struct MagicF16<3> {
@@ -1203,7 +1235,7 @@ __global__ void __launch_bounds__(1024, WPS) gemv_q4_stream_kernel(GemvStreamPar
 // have landed.  Same values as the register kernel, bit for bit (same pairs, same matrix-core order, fp32 group sums times the scale).
 template <int BITS, int LN, int MT, int U>
 __global__ void __launch_bounds__(1024, 4) gemv_qx_stream_kernel(GemvStreamParams p) {
-    static_assert(BITS == 3 || BITS == 8, "4-bit layers have their own kernel");
+    static_assert(BITS == 2 || BITS == 3 || BITS == 8, "4-bit layers have their own kernel");
     using T = f16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int UW = Pack<BITS>::words, KPU = Pack<BITS>::vals, WR = 64 / LN, CT = LN * 4;
@@ -1334,7 +1366,7 @@ __global__ void __launch_bounds__(1024, 4) gemv_qx_stream_kernel(GemvStreamParam
 // 4-bit kernel does; 8 waves at most (<= 256 VGPRs).  Without it 5..8 rows are two passes (blockIdx.z) that unpack every word twice.
 template <int BITS, typename T, int LN, int MT, int U, bool MAGIC = false>
 __global__ void __launch_bounds__(MT == 8 ? 512 : 1024, MT == 8 ? 2 : 4) gemv_mfma_generic_kernel(GemvParams p) {
-    static_assert(!MAGIC || (std::is_same_v<T, f16> && (BITS == 3 || BITS == 8)), "magic-number decode: 3- / 8-bit fp16 only");
+    static_assert(!MAGIC || (std::is_same_v<T, f16> && (BITS == 2 || BITS == 3 || BITS == 8)), "magic-number decode: 2- / 3- / 8-bit fp16 only");
     static_assert(MT <= 4 || (MT == 8 && MAGIC), "8 rows per pass: magic-number variants only");
     constexpr int RP = MT == 8 ? 8 : 4;                 // rows of x per pass (blockIdx.z)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1593,7 +1625,7 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
         pl.mtiles = M >= 5 ? (M + 7) / 8 : 1;
     } else if (pl.mfmag) {
         // 3- / 8-bit fp16 (magic-number decode): 5..8 rows in one pass (two matrix-core sets per fragment), else 4 rows per pass
-        const bool magic_ok = L.dtype == GPTQ_F16 && (L.bits == 3 || L.bits == 8) && !(tune && tune->reserved[1] == 1);
+        const bool magic_ok = L.dtype == GPTQ_F16 && (L.bits == 3 || L.bits == 8) && !(tune && tune->reserved[1] == 1);      // (2-bit: 4 rows per pass)
         // ... on layers of at most 256 strips (tools/nonq4_paths.py, profiles/r02_nonq4_paths.log, us at M = 8, two passes -> one: int3 11008x4096
         // 22.8 -> 16.8, 4096x4096 8.6 -> 8.9; on 4096x11008 -- 688 strips, three 8-wave workgroups per CU at 137 VGPRs -- 17.7 -> 21.6: stays two passes)
         if (magic_ok && M >= 5 && (N_cols <= 4096 || (tune && tune->path == 5))) {
@@ -1675,7 +1707,7 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     pl.workspace_bytes = ks > 1 ? (size_t)ks * M * L.N * sizeof(float) : 0;
     pl.u = 1;
     // 3- / 8-bit fp16: packed magic-number decode (tuning.reserved[1] = 1 keeps the field-by-field form, for A/B runs)
-    pl.magic = pl.mfmag && L.dtype == GPTQ_F16 && (L.bits == 3 || L.bits == 8) && !(tune && tune->reserved[1] == 1);
+    pl.magic = pl.mfmag && L.dtype == GPTQ_F16 && (L.bits == 2 || L.bits == 3 || L.bits == 8) && !(tune && tune->reserved[1] == 1);
     if (pl.mfmag) {
         const int gunits = L.group_size / kpu;
         const int per_lane = (pl.units_per_split + rows_per_iter - 1) / rows_per_iter;
@@ -1867,11 +1899,11 @@ template <int BITS, typename T, int MT>
 static hipError_t launch_mfmag_u(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
     dim3 grid(pl.strips, pl.ksplit, pl.mtiles), block(pl.waves * 64);
     if (pl.ln != 4) return hipErrorInvalidValue;
-    if constexpr (std::is_same_v<T, f16> && (BITS == 3 || BITS == 8)) {
+    if constexpr (std::is_same_v<T, f16> && (BITS == 2 || BITS == 3 || BITS == 8) && !(BITS == 2 && MT == 8)) {
         if (pl.magic) {
             switch (pl.u) {
                 case 1: hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 1, true>), grid, block, pl.lds_bytes, st, p); break;
-                case 2: if constexpr (BITS == 8) { hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 2, true>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
+                case 2: if constexpr (BITS == 8 || BITS == 2) { hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 2, true>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
                 case 4: if constexpr (BITS == 8) { hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 4, true>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
                 default: return hipErrorInvalidValue;
             }
@@ -1946,7 +1978,7 @@ static bool stream_layer_ok(const gptq_layer_t& L) {
         const int gu = L.group_size / 8;
         return (L.dtype == GPTQ_F16 || L.dtype == GPTQ_BF16) && L.group_size % 8 == 0 && gu >= 2 && (gu & (gu - 1)) == 0 && L.K % 8 == 0;
     }
-    if ((L.bits == 3 || L.bits == 8) && L.dtype == GPTQ_F16) {       // gemv_qx_stream_kernel: packed magic-number decode, fp16 only
+    if ((L.bits == 2 || L.bits == 3 || L.bits == 8) && L.dtype == GPTQ_F16) {       // gemv_qx_stream_kernel: packed magic-number decode, fp16 only
         const int kpu = unit_vals(L.bits);
         const int gu = L.group_size / kpu;
         return L.group_size % kpu == 0 && gu >= 1 && (gu & (gu - 1)) == 0 && L.K % kpu == 0 && L.N % 32 == 0;
@@ -1987,7 +2019,8 @@ static bool stream_preferred_qx(const gptq_layer_t& L, int M) {
     // int8 from ~40 M weights (4096x11008: 17.8 -> 14.0 us, 11008x4096: 16.3 -> 13.9; 4096x4096 stays at 7.7 on the register kernel);
     // int3 single layers stay on the register kernel (9.7 against 10.0 us): its multi-layer launches are what the streamed form is for
     (void)M;
-    return L.bits == 8 && (size_t)L.K * L.N >= ((size_t)40 << 20);
+    // int2 the same (4096x11008 8.7 -> 8.0 us, 11008x4096 10.2 -> 8.1; 4096x4096 5.0 = equal: register kernel stays)
+    return (L.bits == 8 || L.bits == 2) && (size_t)L.K * L.N >= ((size_t)40 << 20);
 }
 
 bool stream_preferred(const gptq_layer_t& L, int M) {
@@ -2025,7 +2058,10 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     const int gu = A.group_size / kpu;
     const bool big1 = q4 && n == 1 && stream_big_single(A);
     // 3- / 8-bit (tools/stream_sweep.py --bits 8 / 3 --gs 32, profiles/r03_stream_sweep_int{8,3}_g32.log): 32-column strips (128-byte row segments)
-    int ln = (tune && tune->lanes_n) ? tune->lanes_n : (!q4 ? 8 : (big1 ? (A.N >= 16384 ? 16 : 8) : stream_default_ln(Ls, n)));
+    // 2-bit single layers (profiles/r03_stream_sweep_int2_g64.log): 32-column strips x 8 waves x 4 units from 8192 columns (4096x11008: 8.0 us), 16-column
+    // strips x 8 waves x 2 units below (11008x4096: 8.1), no K split
+    const bool q2_single = A.bits == 2 && n == 1;
+    int ln = (tune && tune->lanes_n) ? tune->lanes_n : (q2_single ? (A.N >= 8192 ? 8 : 4) : (!q4 ? 8 : (big1 ? (A.N >= 16384 ? 16 : 8) : stream_default_ln(Ls, n))));
     if (ln != 4 && ln != 8 && ln != 16) return pl;
     if (!q4 && ln == 16) return pl;                               // 3- / 8-bit: 16- and 32-column strips
     const int ct = ln * 4, wr = 64 / ln;
@@ -2038,7 +2074,8 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     pl.strips_total = strips;
     pl.nsum = nsum;
     int ks = (tune && tune->ksplit) ? tune->ksplit : 0;
-    if (!ks && !q4 && A.bits == 8 && n == 1) {
+    if (!ks && q2_single) ks = 1;
+    if (!ks && !q4 && A.bits != 3 && n == 1) {
         // int8 single layers run best as ~512-700 small workgroups: 4096x11008 (344 strips) x 2 slices 14.0 us, 11008x4096 (128 strips) x 4 slices
         // 13.9 us, against 17.8 / 16.3 for the register kernel
         ks = strips >= 256 ? 2 : 1;
@@ -2058,7 +2095,12 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
     if (tune && tune->waves && tune->reserved[0]) {
         waves = tune->waves; u = tune->reserved[0];
     } else if (!q4) {              // 3- / 8-bit: small workgroups, several per CU (int8: 4 waves x 2..4 units = 8-16 KiB in flight each; int3: 8 waves x 1 unit = 24 KiB)
-        if (A.bits == 8) {
+        if (q2_single) {
+            waves = 8;
+            u = ln == 8 ? 4 : 2;
+            if (u > ucap) u = ucap;
+            while (u > 2 && pl.units_total % u) u /= 2;
+        } else if (A.bits != 3) {  // 8-bit, 2-bit groups
             waves = 4;
             u = (strips >= 256 && (n == 1 || strips >= 512)) ? 2 : 4;
             if (u > ucap) u = ucap;
@@ -2085,7 +2127,7 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
             while (waves > 1 && (waves / 2) * wr * u >= ups) waves /= 2;
         }
     }
-    if (q4 ? (u != 2 && u != 4 && u != 8) : (A.bits == 8 ? (u != 2 && u != 4 && u != 8) : (u != 1 && u != 2))) return pl;
+    if (q4 ? (u != 2 && u != 4 && u != 8) : (A.bits != 3 ? (u != 2 && u != 4 && u != 8) : (u != 1 && u != 2))) return pl;
     if (waves < 1 || waves > 16 || u > ucap || pl.units_total % u) return pl;
     ups = (ups + u - 1) / u * u;                        // a lane's U rows start on a multiple of U: slices do too
     pl.units_per_split = ups;
@@ -2146,11 +2188,11 @@ static hipError_t launch_qx_one(const StreamPlan& pl, const GemvStreamParams& p,
 }
 template <int BITS, int LN, int MT>
 static hipError_t launch_qx_u(const StreamPlan& pl, const GemvStreamParams& p, hipStream_t st) {
-    if constexpr (BITS == 8) {
+    if constexpr (BITS == 8 || BITS == 2) {
         switch (pl.u) {
-            case 2: return launch_qx_one<8, LN, MT, 2>(pl, p, st);
-            case 4: return launch_qx_one<8, LN, MT, 4>(pl, p, st);
-            case 8: return launch_qx_one<8, LN, MT, 8>(pl, p, st);
+            case 2: return launch_qx_one<BITS, LN, MT, 2>(pl, p, st);
+            case 4: return launch_qx_one<BITS, LN, MT, 4>(pl, p, st);
+            case 8: return launch_qx_one<BITS, LN, MT, 8>(pl, p, st);
             default: return hipErrorInvalidValue;
         }
     } else {
@@ -2203,6 +2245,7 @@ hipError_t launch_stream(const gptq_layer_t* const* Ls, const StreamPlan& pl, co
     p.nsum = pl.nsum;
     if (A.bits == 8) return launch_qx_ln<8>(pl, p, st);
     if (A.bits == 3) return launch_qx_ln<3>(pl, p, st);
+    if (A.bits == 2) return launch_qx_ln<2>(pl, p, st);
     return A.dtype == GPTQ_BF16 ? launch_stream_t<bf16>(pl, p, st) : launch_stream_t<f16>(pl, p, st);
 }
 
@@ -2224,6 +2267,8 @@ hipError_t init_gemv_device() {
     auto grant_qx = [&](auto kern) { acc(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); };
     grant_qx(gemv_qx_stream_kernel<8, 4, 1, 8>); grant_qx(gemv_qx_stream_kernel<8, 4, 2, 8>); grant_qx(gemv_qx_stream_kernel<8, 4, 4, 8>);
     grant_qx(gemv_qx_stream_kernel<8, 8, 1, 8>); grant_qx(gemv_qx_stream_kernel<8, 8, 2, 8>); grant_qx(gemv_qx_stream_kernel<8, 8, 4, 8>);
+    grant_qx(gemv_qx_stream_kernel<2, 4, 1, 8>); grant_qx(gemv_qx_stream_kernel<2, 4, 2, 8>); grant_qx(gemv_qx_stream_kernel<2, 4, 4, 8>);
+    grant_qx(gemv_qx_stream_kernel<2, 8, 1, 8>); grant_qx(gemv_qx_stream_kernel<2, 8, 2, 8>); grant_qx(gemv_qx_stream_kernel<2, 8, 4, 8>);
     grant_qx(gemv_qx_stream_kernel<3, 4, 1, 2>); grant_qx(gemv_qx_stream_kernel<3, 4, 2, 2>); grant_qx(gemv_qx_stream_kernel<3, 4, 4, 2>);
     grant_qx(gemv_qx_stream_kernel<3, 8, 1, 2>); grant_qx(gemv_qx_stream_kernel<3, 8, 2, 2>); grant_qx(gemv_qx_stream_kernel<3, 8, 4, 2>);
     return e;

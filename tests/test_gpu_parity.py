@@ -1466,14 +1466,15 @@ def test_streamed_gemv_vs_oracle(K, N, gs, M, ln, waves, u, ksplit, dtype):
 
 
 @pytest.mark.parametrize("bits,ln,waves,u,ksplit", [(8, 4, 16, 4, 1), (8, 4, 4, 2, 1), (8, 8, 8, 8, 2), (8, 4, 8, 8, 3), (8, 8, 2, 4, 1),
-                                                    (3, 4, 16, 1, 1), (3, 4, 4, 1, 2), (3, 8, 8, 1, 1), (3, 4, 8, 2, 1), (3, 8, 4, 2, 4)])
+                                                    (3, 4, 16, 1, 1), (3, 4, 4, 1, 2), (3, 8, 8, 1, 1), (3, 4, 8, 2, 1), (3, 8, 4, 2, 4),
+                                                    (2, 4, 16, 2, 1), (2, 8, 4, 4, 2), (2, 4, 8, 8, 1), (2, 8, 8, 2, 3)])
 @pytest.mark.parametrize("K,N,gs,M", [(1024, 512, 32, 1), (2048, 96, 64, 3), (4096, 1056, 128, 4), (512, 2048, 32, 2), (11008, 256, 32, 1)])
 def test_streamed_gemv_3_and_8_bit(K, N, gs, M, bits, ln, waves, u, ksplit):
     """gemv_qx_stream_kernel (tuning.path = 6 on 3- / 8-bit fp16 layers): the packing units (one word of 4 values / three words of 32) by LDS DMA,
     the packed magic-number decode, every launch geometry incl. ragged last strips, several passes over K, the in-launch K-split combine, bias,
     both zero conventions (3-bit zero-points straddle words); against the fp64 oracle and BIT-equal to the register kernel with the same geometry
     where that exists."""
-    kpu = 32 if bits == 3 else 4
+    kpu = {3: 32, 8: 4, 2: 16}[bits]
     if u > gs // kpu or (K // kpu) % u:
         pytest.skip("u units of a lane must lie in one group")
     L = O.random_quant_layer(K, N, bits, gs, dtype=torch.float16, seed=K + N + M + bits, bias=True)
@@ -1502,7 +1503,7 @@ def test_streamed_gemv_3_and_8_bit(K, N, gs, M, bits, ln, waves, u, ksplit):
         assert torch.equal(yo, W[ks_])
 
 
-@pytest.mark.parametrize("bits,gs", [(8, 32), (3, 32), (8, 128), (3, 64)])
+@pytest.mark.parametrize("bits,gs", [(8, 32), (3, 32), (8, 128), (3, 64), (2, 64), (2, 32)])
 @pytest.mark.parametrize("M", [1, 3])
 def test_forward_multi_3_and_8_bit_one_launch(bits, gs, M):
     """gptq_forward_multi on 3- / 8-bit fp16 layers that share x: one gemv_qx_stream_kernel launch (forced and by default), every layer against

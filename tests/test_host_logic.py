@@ -330,6 +330,14 @@ def test_dispatch_rules_are_the_measured_ones():
     assert _plan(4096, 4096, 16, bits=3, gs=32)["kernel"] == "mid" and _plan(11008, 4096, 64, bits=3, gs=32)["kernel"] == "mid"
     assert _plan(4096, 11008, 8, bits=3, gs=32)["kernel"] == "mid" and _plan(4096, 4096, 8, bits=3, gs=32)["kernel"] == "mfma_generic"
     assert _plan(4096, 4128, 16, bits=3, gs=32)["kernel"] != "mid"
+    # int2 decode: packed magic-number decode in the register kernel (4096x11008 13.0 -> 8.7 us), the streamed kernel from ~40 M weights (8.0 / 8.1 us)
+    p = _plan(4096, 11008, 1, bits=2, gs=64)
+    assert (p["kernel"], p["ln"], p["waves"], p["u"], p["ksplit"]) == ("stream", 8, 8, 4, 1), p
+    p = _plan(11008, 4096, 2, bits=2, gs=64)
+    assert (p["kernel"], p["ln"], p["waves"], p["u"], p["ksplit"], p["mt"]) == ("stream", 4, 8, 2, 1, 2), p
+    p = _plan(4096, 4096, 1, bits=2, gs=64)
+    assert (p["kernel"], p.get("deq")) == ("mfma_generic", "magic"), p
+    assert _plan(4096, 11008, 1, bits=2, gs=64, dtype=1).get("deq") is None                  # bf16: field by field
     # int2 (a K-step = two packed rows = one 32-lane DMA): from 5 rows everywhere (4096x11008 M = 8: 24.9 -> 13.3 us)
     assert _plan(4096, 4096, 5, bits=2, gs=64)["kernel"] == "mid" and _plan(4096, 11008, 128, bits=2, gs=64)["kernel"] == "mid"
     assert _plan(4096, 4096, 4, bits=2, gs=64)["path"] == "gemv" and _plan(4096, 4096, 129, bits=2, gs=64)["kernel"] == "tiled"
