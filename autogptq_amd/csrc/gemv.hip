@@ -1366,8 +1366,8 @@ __global__ void __launch_bounds__(1024, 4) gemv_qx_stream_kernel(GemvStreamParam
 // 4-bit kernel does; 8 waves at most (<= 256 VGPRs).  Without it 5..8 rows are two passes (blockIdx.z) that unpack every word twice.
 template <int BITS, typename T, int LN, int MT, int U, bool MAGIC = false>
 __global__ void __launch_bounds__(MT == 8 ? 512 : 1024, MT == 8 ? 2 : 4) gemv_mfma_generic_kernel(GemvParams p) {
-    static_assert(!MAGIC || (std::is_same_v<T, f16> && (BITS == 2 || BITS == 3 || BITS == 8)), "magic-number decode: 2- / 3- / 8-bit fp16 only");
-    static_assert(MT <= 4 || (MT == 8 && MAGIC), "8 rows per pass: magic-number variants only");
+    static_assert(!MAGIC || BITS == 2 || BITS == 3 || BITS == 8, "magic-number decode: 2- / 3- / 8-bit (4-bit has its own kernels)");
+    static_assert(MT <= 4 || (MT == 8 && MAGIC && std::is_same_v<T, f16>), "8 rows per pass: fp16 magic-number variants only");
     constexpr int RP = MT == 8 ? 8 : 4;                 // rows of x per pass (blockIdx.z)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;
@@ -1468,6 +1468,14 @@ __global__ void __launch_bounds__(MT == 8 ? 512 : 1024, MT == 8 ? 2 : 4) gemv_mf
 #pragma unroll
                     for (int w = 0; w < UW; ++w) wds[w] = q[j][w][c];
                     mg[c].pairs(wds, mk, bp);
+                    if constexpr (std::is_same_v<T, bf16>) {          // bf16 (round 3): the exact fp16 w - z, each pair converted once (|w - z| <= 256 is exact in bf16)
+#pragma unroll
+                        for (int i = 0; i < KPU / 2; ++i) {
+                            const f16x2 hv = as_f16x2(bp[i]);
+                            const bf16x2 o = {(bf16)(float)hv[0], (bf16)(float)hv[1]};
+                            bp[i] = __builtin_bit_cast(unsigned, o);
+                        }
+                    }
 #pragma unroll
                     for (int Q = 0; Q < KPU / 4; ++Q) {
                         accg[c] = Mma4<T>::run(u32x2{xa[2 * Q], xa[2 * Q + 1]}, u32x2{bp[2 * Q], bp[2 * Q + 1]}, accg[c]);
@@ -1707,7 +1715,10 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     pl.workspace_bytes = ks > 1 ? (size_t)ks * M * L.N * sizeof(float) : 0;
     pl.u = 1;
     // 3- / 8-bit fp16: packed magic-number decode (tuning.reserved[1] = 1 keeps the field-by-field form, for A/B runs)
-    pl.magic = pl.mfmag && L.dtype == GPTQ_F16 && (L.bits == 2 || L.bits == 3 || L.bits == 8) && !(tune && tune->reserved[1] == 1);
+    // bf16 (tools/bf16_magic_ab.py, profiles/r03_bf16_magic_decode_ab.log): the packed decode + one conversion per pair wins for 2- and 3-bit (int2 4096x11008
+    // 12.7 -> 10.6 us, int3 11008x4096 15.4 -> 13.4) and loses for 8-bit (18.1 -> 19.6: four byte fields per word are cheap to extract one by one)
+    pl.magic = pl.mfmag && (L.dtype == GPTQ_F16 || (L.dtype == GPTQ_BF16 && L.bits != 8)) && (L.bits == 2 || L.bits == 3 || L.bits == 8) &&
+               !(tune && tune->reserved[1] == 1);
     if (pl.mfmag) {
         const int gunits = L.group_size / kpu;
         const int per_lane = (pl.units_per_split + rows_per_iter - 1) / rows_per_iter;
@@ -1899,7 +1910,7 @@ template <int BITS, typename T, int MT>
 static hipError_t launch_mfmag_u(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
     dim3 grid(pl.strips, pl.ksplit, pl.mtiles), block(pl.waves * 64);
     if (pl.ln != 4) return hipErrorInvalidValue;
-    if constexpr (std::is_same_v<T, f16> && (BITS == 2 || BITS == 3 || BITS == 8) && !(BITS == 2 && MT == 8)) {
+    if constexpr ((BITS == 2 || BITS == 3 || BITS == 8) && !(BITS == 2 && MT == 8) && !(std::is_same_v<T, bf16> && MT == 8)) {
         if (pl.magic) {
             switch (pl.u) {
                 case 1: hipLaunchKernelGGL((gemv_mfma_generic_kernel<BITS, T, 4, MT, 1, true>), grid, block, pl.lds_bytes, st, p); break;

@@ -337,7 +337,7 @@ def test_dispatch_rules_are_the_measured_ones():
     assert (p["kernel"], p["ln"], p["waves"], p["u"], p["ksplit"], p["mt"]) == ("stream", 4, 8, 2, 1, 2), p
     p = _plan(4096, 4096, 1, bits=2, gs=64)
     assert (p["kernel"], p.get("deq")) == ("mfma_generic", "magic"), p
-    assert _plan(4096, 11008, 1, bits=2, gs=64, dtype=1).get("deq") is None                  # bf16: field by field
+    assert _plan(4096, 11008, 1, bits=2, gs=64, dtype=1).get("deq") == "magic"               # bf16: the same exact fp16 w - z, pairs converted once (register kernel)
     # int2 (a K-step = two packed rows = one 32-lane DMA): from 5 rows everywhere (4096x11008 M = 8: 24.9 -> 13.3 us)
     assert _plan(4096, 4096, 5, bits=2, gs=64)["kernel"] == "mid" and _plan(4096, 11008, 128, bits=2, gs=64)["kernel"] == "mid"
     assert _plan(4096, 4096, 4, bits=2, gs=64)["path"] == "gemv" and _plan(4096, 4096, 129, bits=2, gs=64)["kernel"] == "tiled"
@@ -364,7 +364,7 @@ def test_dispatch_rules_are_the_measured_ones():
         assert (p["path"], p["kernel"], p["mt"], p["waves"]) == ("gemv", "mfma_generic", 8, 8), (K, N, p)
         assert _plan(K, N, 9, bits=8, gs=32)["path"] == "gemm" and _plan(K, N, 8, bits=8, gs=32, dtype=1)["path"] == "gemm"
     assert _plan(4096, 11008, 5, bits=8, gs=32)["path"] == "gemm"
-    assert _plan(4096, 4096, 1, bits=3, gs=32, act=True, dtype=1)["perm"] == 2 and _plan(4096, 4096, 1, bits=3, gs=32, act=True, dtype=1).get("deq") is None
+    assert _plan(4096, 4096, 1, bits=3, gs=32, act=True, dtype=1)["perm"] == 2 and _plan(4096, 4096, 1, bits=3, gs=32, act=True, dtype=1).get("deq") == "magic"
     assert _plan(4096, 11008, 8, bits=2, gs=64)["path"] == "gemm" and _plan(4096, 4096, 8, bits=2, gs=64)["kernel"] == "mid"
     # rows of x: GEMV up to 4; 5..8 rows: one matrix-core pass over 16 rows (16-column strips on narrow layers, the streamed
     # 64-column-strip kernel elsewhere) unless the layer has a fused epilogue (the GEMV applies it) or K is long and N small
