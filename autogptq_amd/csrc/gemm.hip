@@ -224,6 +224,39 @@ template <> struct Deq<8, f16> {
         return o;
     }
 };
+// 2-bit fp16 (round 3): the lane's 8 values are a 16-bit window; one v_perm spreads its bytes over the halves of a register (f0..f3 | f4..f7 at bits
+// 0, 2, 4, 6), then (f, f + 4) pairs by v_and_or + packed fma with -(1024 * 2^-s + z): the 4-bit slot order, ~14 VALU per 8 weights instead of ~48
+template <> struct Deq<2, f16> {
+    f16x2 s2[2], c1[2], c2[2], c4[2], c6[2];
+    __device__ __forceinline__ void setup(const CRaw& c, int zero_mode) {
+#pragma unroll
+        for (int col = 0; col < 2; ++col) {
+            const unsigned sb = col ? (c.s >> 16) : (c.s & 0xffffu);
+            s2[col] = as_f16x2(sb * 0x00010001u);
+            const unsigned z = (unsigned)zero_point<2>(c, col, zero_mode);   // 0..4
+            c1[col] = as_f16x2(z * 0x00010001u + 0xE400E400u);               // -(1024 + z)
+            const f16x2 k768 = {(f16)768.f, (f16)768.f}, k960 = {(f16)960.f, (f16)960.f}, k1008 = {(f16)1008.f, (f16)1008.f};
+            c2[col] = c1[col] + k768;                                        // -(256 + z), exact
+            c4[col] = c1[col] + k960;                                        // -(64 + z)
+            c6[col] = c1[col] + k1008;                                       // -(16 + z)
+        }
+    }
+    __device__ __forceinline__ u32x4 frag(const BRaw<2>& r, int col, int k) const {
+        const unsigned v = (unsigned)window<2>(r, col, k);                   // 16 bits: f0..f7 at bits 2i
+        const unsigned t = __builtin_amdgcn_perm(v, v, 0x0c010c00u);         // byte 0 -> bits 0..7, byte 1 -> bits 16..23
+        const f16x2 r4 = {(f16)0.25f, (f16)0.25f}, r16 = {(f16)0.0625f, (f16)0.0625f}, r64 = {(f16)0.015625f, (f16)0.015625f};
+        const f16x2 h0 = as_f16x2((t & 0x00030003u) | 0x64006400u) + c1[col];             // k0,k4 : w - z
+        const f16x2 h1 = as_f16x2((t & 0x000C000Cu) | 0x64006400u) * r4 + c2[col];        // k1,k5
+        const f16x2 h2 = as_f16x2((t & 0x00300030u) | 0x64006400u) * r16 + c4[col];       // k2,k6
+        const f16x2 h3 = as_f16x2((t & 0x00C000C0u) | 0x64006400u) * r64 + c6[col];       // k3,k7
+        u32x4 o;
+        o[0] = f16x2_bits(h0 * s2[col]);
+        o[1] = f16x2_bits(h1 * s2[col]);
+        o[2] = f16x2_bits(h2 * s2[col]);
+        o[3] = f16x2_bits(h3 * s2[col]);
+        return o;
+    }
+};
 template <> struct Deq<3, f16> {
     f16x2 s2[2], c1[2], c3[2], c6[2];
     __device__ __forceinline__ void setup(const CRaw& c, int zero_mode) {

@@ -625,6 +625,9 @@ GEMM_CASES = [
     (8, 128, 1024, 256, True, torch.bfloat16, 20),
     (2, 64, 1024, 256, False, torch.float16, 128),
     (2, 32, 512, 128, True, torch.float16, 16),
+    (2, 64, 2048, 512, False, torch.float16, 300),      # 2-bit fp16 on the tiled kernel (packed magic-number decode, round 3)
+    (2, 128, 1024, 320, True, torch.float16, 520),
+    (2, 64, 1024, 256, False, torch.bfloat16, 260),     # 2-bit bf16: field by field
     (4, 1024, 1024, 256, False, torch.float16, 96),     # one group for the whole layer
     (4, 32, 32 * 7, 64, False, torch.float16, 12),      # K = 224: odd number of K-steps
     (4, 128, 512, 8448, False, torch.float16, 6),       # M = 5..8 on a wide layer (N > 8192): auto dispatch takes the tiled kernel
