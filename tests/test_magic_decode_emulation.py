@@ -13,7 +13,7 @@ MAGIC = 0x64006400
 
 def perm(s0, s1, sel):
     """v_perm_b32 D, S0, S1, sel: result byte i = byte sel[i] of {S0 (bytes 4-7), S1 (bytes 0-3)}."""
-    b = [(s1 >> (8 * i)) & 0xff for i in range(4)] + [(s0 >> (8 * i)) & 0xff for i in range(4)]
+    b = [(s1 >> (8 * i)) & 0xff for i in range(4)] + [(s0 >> (8 * i)) & 0xff for i in range(4)] + [None] * 4 + [0x00]     # selector 12 = constant 0x00
     return sum(b[(sel >> (8 * i)) & 0xff] << (8 * i) for i in range(4))
 
 
@@ -133,3 +133,86 @@ def test_zero_point_constants_are_exact_fp16_bit_patterns():
         if z <= 8:
             c3, c6 = np.float16(c1) + np.float16(896.0), np.float16(c1) + np.float16(1008.0)
             assert float(c3) == -(128 + z) and float(c6) == -(16 + z)
+
+
+# ---------------------------------------------------------------------------------------------------- round 3: 2-bit, and the windows of gemm_mid_kernel
+def four2(t, z):
+    """MagicF16<2>::four / Deq2::diffs: fields at bits 0 / 2 / 4 / 6 of both halves."""
+    return [pk_fma(t, 0x00030003, 1.0, -(1024 + z)), pk_fma(t, 0x000C000C, 0.25, -(256 + z)), pk_fma(t, 0x00300030, 1 / 16, -(64 + z)),
+            pk_fma(t, 0x00C000C0, 1 / 64, -(16 + z))]
+
+
+@pytest.mark.parametrize("zero_mode", ["wrap", "nowrap"])
+def test_2bit_word_pairs(zero_mode):
+    """MagicF16<2>::pairs (csrc/gemv.hip): 16 two-bit values per word (qlinear_cuda_old.py:295-316 layout); two v_perm spread bytes 0 / 1 and 2 / 3 over
+    the halves of a register; pair p holds fields (ka(p), kb(p)) = (p, p + 4) for p < 4 and (p + 4, p + 8) above; every intermediate exact in fp16."""
+    rng = np.random.default_rng(2)
+    ka = lambda p: p if p < 4 else p + 4
+    for _ in range(500):
+        f = rng.integers(0, 4, 16)
+        w = sum(int(v) << (2 * i) for i, v in enumerate(f))
+        zf = int(rng.integers(0, 4))
+        z = ((zf + 1) & 3) if zero_mode == "wrap" else zf + 1        # up to 4
+        pairs = four2(perm(w, w, 0x0c010c00), z) + four2(perm(w, w, 0x0c030c02), z)
+        for p in range(8):
+            assert (float(pairs[p][0]), float(pairs[p][1])) == (f[ka(p)] - z, f[ka(p) + 4] - z), p
+    for z in range(0, 5):                                            # setup(): the shifted constants are exact fp16 values
+        c1 = np.array([0xE400 + z], dtype=np.uint16).view(np.float16)[0]
+        assert [float(np.float16(c1) + np.float16(k)) for k in (768.0, 960.0, 1008.0)] == [-(256 + z), -(64 + z), -(16 + z)]
+
+
+def test_mid_kernel_lane_windows():
+    """gemm_mid_kernel (csrc/gemm_mid.hip): what lane (column, k-octet kg) cuts out of the landing area for its 8 consecutive k of a 32-deep K-step.
+    3-bit: 24 bits at bit 24 kg of the column's 96-bit stream (three packed rows) by ONE 64-bit shift of (w0, w1) or (w1, w2); 2-bit: half kg & 1 of word
+    kg >> 1; 8-bit: the words of packed rows 2 kg and 2 kg + 1.  Then Deq3 / Deq2 / Deq8 give (k0,k4), (k1,k5), (k2,k6), (k3,k7)."""
+    rng = np.random.default_rng(33)
+    for _ in range(300):
+        f3 = rng.integers(0, 8, 32)
+        stream = sum(int(v) << (3 * i) for i, v in enumerate(f3))
+        w = [(stream >> (32 * i)) & 0xffffffff for i in range(3)]
+        z = int(rng.integers(0, 9))
+        for kg in range(4):
+            sh = (0, 24, 16, 40)[kg]
+            lo, hi = (w[0], w[1]) if kg < 2 else (w[1], w[2])
+            v = ((((hi << 32) | lo) >> sh) & 0xffffffff) & 0xFFFFFF
+            t = perm(v >> 12, v, 0x05040100)
+            t6 = t >> 6
+            h = [pk_fma(t, 0x00070007, 1.0, -(1024 + z)), pk_fma(t, 0x00380038, 0.125, -(128 + z)), pk_fma(t, 0x01C001C0, 1 / 64, -(16 + z)),
+                 pk_fma(t6, 0x00380038, 0.125, -(128 + z))]
+            for i in range(4):
+                assert (float(h[i][0]), float(h[i][1])) == (f3[8 * kg + i] - z, f3[8 * kg + i + 4] - z), (kg, i)
+        f2 = rng.integers(0, 4, 32)
+        w2 = [sum(int(v) << (2 * i) for i, v in enumerate(f2[16 * r:16 * r + 16])) for r in range(2)]
+        z2 = int(rng.integers(0, 5))
+        for kg in range(4):
+            word = w2[kg >> 1]
+            v16 = (word >> 16) if (kg & 1) else (word & 0xffff)
+            h = four2(perm(v16, v16, 0x0c010c00), z2)
+            for i in range(4):
+                assert (float(h[i][0]), float(h[i][1])) == (f2[8 * kg + i] - z2, f2[8 * kg + i + 4] - z2), (kg, i)
+
+
+def test_mid_kernel_3bit_zero_point_run():
+    """3-bit zero-points of a 64-column strip are a 24-byte run at byte 24 * strip of the qzeros row -- 16-byte aligned only on even strips.  The kernel's
+    table holds three aligned 16-byte pieces from floor16 on; lane j reads 12 bits at bit 8 * zstart + 12 j with two aligned words and a funnel shift."""
+    rng = np.random.default_rng(5)
+    N = 128 * 3                                                      # the 3-bit plan wants N % 128 == 0, so the row is a multiple of 16 bytes
+    zf = rng.integers(0, 8, N)
+    bits = sum(int(v) << (3 * i) for i, v in enumerate(zf))
+    rowb = N * 3 // 8
+    row = bits.to_bytes(rowb, "little")
+    for strip in range(N // 64):
+        start = 24 * strip
+        base16 = start & ~15
+        pieces = b""
+        for i in range(3):
+            pz = base16 + 16 * i
+            pieces += row[pz:pz + 16] if pz + 16 <= rowb else row[rowb - 16:rowb]     # a piece beyond the row is never needed
+        zstart = start & 15
+        words = [int.from_bytes(pieces[4 * i:4 * i + 4], "little") for i in range(12)]
+        for j in range(16):
+            bit = 8 * zstart + 12 * j
+            wi = bit >> 5
+            zz = ((((words[wi + 1] if wi + 1 < 12 else 0) << 32) | words[wi]) >> (bit & 31)) & 0xffffffff
+            for t in range(4):
+                assert (zz >> (3 * t)) & 7 == zf[64 * strip + 4 * j + t], (strip, j, t)
