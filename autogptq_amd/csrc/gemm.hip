@@ -48,6 +48,12 @@ struct GemmParams {
     int nbm, nbn, ksplit, ksteps_total, ksteps_per_split;
     int qrows;        // rows of qweight (K/32*bits)
     unsigned long long kpg_inv;   // ceil(2^32 / (group_size / BK)): group of K-step kt = (kt * kpg_inv) >> 32, exact for kt < 2^16
+    // balanced tail (gemm_kernel<..., TAIL = true>): the last `tail` logical tiles are run as 2^tail_lg K slices by as many workgroups each
+    int tail, tail_lg;
+    unsigned* tail_flags;         // workspace header, ticket half: [16 t] arrival ticket, [16 t + 1 + slice] "slice published"; zero before and after every launch
+    float* tail_partial;          // [tail][2^tail_lg][32][256] float4: the accumulators of the slices that did not arrive last
+    unsigned* err;                // sticky error word of the workspace header (a bounded wait gave up)
+    unsigned max_spins;
 };
 
 __device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
@@ -347,8 +353,17 @@ template <> struct Deq<4, bf16> {
 // block's K range with their own x buffers, and the two halves are summed through LDS at the end.  Used when the launch
 // has at most one 128x256 tile per CU: a CU then holds two waves per SIMD (what two co-resident workgroups would give a
 // larger problem), so one wave's dequant/LDS work fills the other's MFMA shadows, at the same weight/x traffic per flop.
-template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, bool GLDS = false, int KG = 1>
+// TAIL (round 3, KG = 1, one K slice): balanced tail.  While the workgroups of a launch run in lockstep (up to ~4 rounds of one 128 x 256 tile per
+// CU -- a CU's throughput is the same with one or two resident workgroups), T tiles cost ceil(T / 256) tile times: 258 tiles take as long as 512,
+// 516 as long as 768 (measured: 4096x11008 at M = 1536, 516 tiles, 179 us against 137 us of work).  With TAIL the last p.tail = T mod 256 logical
+// tiles are run by 2^tail_lg workgroups each, one per K slice, launched behind the whole tiles.  Every slice takes an arrival ticket when its K
+// loop is done; all but the last arrival write their accumulators to the workspace (write-through stores), raise their "published" flag and
+// leave; the last arrival -- which only ever waits for workgroups that are past their K loops: no residency assumption -- adds the slices IN
+// SLICE ORDER (its own from registers), so the result does not depend on who arrives last, and stores the tile.  It also clears the words
+// (the header stays zero between launches).  The fix-up moves 128 KiB per slice and direction, so it only pays for small tails: plan_gemm.
+template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, bool GLDS = false, int KG = 1, bool TAIL = false>
 __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
+    static_assert(!TAIL || (KG == 1 && MT == 4), "the balanced tail is built for the one-K-group 128-row tile");
     constexpr int KS = BK / 16;                // MFMA k-steps per K-step
     constexpr int BM = 32 * MT;
     static_assert(!GLDS || (XPRE && BK == 64), "the DMA staging needs pre-slotted x and 128-byte rows");
@@ -368,7 +383,16 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
     // Logical tile order: column blocks 8 tiles wide, walked row by row, so the contiguous run of logical ids
     // an XCD receives is a compact (rows x 8 columns) patch: its L2 holds 8 weight panels and a few x panels
     // instead of every x panel (measured: L2 fill traffic was 0.49 GB per 4096^3 launch with a column-major order).
-    const int L = xcd_remap(blockIdx.x, p.nbm * p.nbn);
+    int L, tail_half = -1;                     // tail_half >= 0: this workgroup runs K slice tail_half of tail tile L (wave-uniform: blockIdx only)
+    if constexpr (TAIL) {
+        const int whole = p.nbm * p.nbn - p.tail;
+        if ((int)blockIdx.x < whole) L = xcd_remap(blockIdx.x, whole);
+        else {
+            const int j = xcd_remap((int)blockIdx.x - whole, p.tail << p.tail_lg);      // the slices of a tile are neighbours: same XCD, same L2
+            L = whole + (j >> p.tail_lg);
+            tail_half = j & ((1 << p.tail_lg) - 1);
+        }
+    } else L = xcd_remap(blockIdx.x, p.nbm * p.nbn);
     int bm, bn;
     {
         const int full = p.nbn >> 3, per = p.nbm * 8;
@@ -395,6 +419,13 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
         const int hs = (kt1 - kt0) >> 1;
         kt0 += kg * hs;
         kt1 = kt0 + hs;
+    }
+    if constexpr (TAIL) {
+        if (tail_half >= 0) {                  // the planner only cuts K into slices of equal, whole step counts
+            const int hs = p.ksteps_total >> p.tail_lg;
+            kt0 = tail_half * hs;
+            kt1 = kt0 + hs;
+        }
     }
 
     // A staging assignment: chunk c -> (row, 16-byte column)
@@ -742,6 +773,95 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
                         }
             }
             if (pass == 0) __syncthreads();
+        }
+    }
+
+    if constexpr (TAIL) {
+        if (tail_half >= 0) {
+            const int t = L - (p.nbm * p.nbn - p.tail), nsl = 1 << p.tail_lg;
+            unsigned* const tk = p.tail_flags + 16 * t;                            // [0] arrival ticket, [1 + slice] "slice published"
+            constexpr size_t SLAB = 32 * 256 * 4;                                  // floats: [(mt, nt, quad)][256 threads] float4, lane-contiguous
+            float* const slabs = p.tail_partial + ((size_t)t << p.tail_lg) * SLAB;
+            unsigned* const lw = (unsigned*)smem_all;                              // the x buffers are dead behind the last step's barrier
+            if (threadIdx.x == 0) lw[0] = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const unsigned arrival = (unsigned)__builtin_amdgcn_readfirstlane((int)lw[0]);
+            if (arrival + 1u < (unsigned)nsl) {    // not the last: publish, drain the write-through stores, count, leave
+                float* const mine = slabs + (size_t)tail_half * SLAB;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x16& a = acc[mt][nt];
+                            const f32x4 v = {a[q * 4], a[q * 4 + 1], a[q * 4 + 2], a[q * 4 + 3]};
+                            // s_nop inside the string: hipcc pads nothing behind an asm statement, and the next instruction may overwrite the data
+                            // registers (dead to the compiler) while the store still reads them -- measured: the first 8 bytes of lanes 12..15 of
+                            // every 16 came out as the NEXT store's address (tools/tail_diag.py)
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(mine + ((size_t)((mt * 2 + nt) * 4 + q) * 256 + tid) * 4), "v"(v) : "memory");
+                        }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every publishing wave drains its write-through stores
+                __syncthreads();
+                if (threadIdx.x == 0) __hip_atomic_store(tk + 1 + tail_half, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            if ((int)threadIdx.x < nsl && (int)threadIdx.x != tail_half) {      // last arrival: the others are past their K loops -- short, bounded waits
+                unsigned* const f = tk + 1 + threadIdx.x;
+                for (unsigned spins = 0;; ++spins) {
+                    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                    if (spins > p.max_spins) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            // sums in slice order, straight to the output (the accumulators are only read: a second, modified copy of 128 registers would spill)
+            float bias0 = 0.f, bias1 = 0.f;
+            if (p.bias && col_ok) {
+                bias0 = DType<T>::to_f32(((const T*)p.bias)[n]);
+                bias1 = DType<T>::to_f32(((const T*)p.bias)[n + 1]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float s0[16], s1[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+                for (int sl = 0; sl < nsl; ++sl) {
+                    if (sl == tail_half) {             // wave-uniform
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { s0[r] += acc[mt][0][r]; s1[r] += acc[mt][1][r]; }
+                    } else {
+                        const float* from = slabs + (size_t)sl * SLAB;
+                        unsigned long long pv[2][4][2];
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {      // agent-scope loads: they bypass this XCD's non-coherent L2 lines
+                                const unsigned long long* src = (const unsigned long long*)(from + ((size_t)((mt * 2 + nt) * 4 + q) * 256 + tid) * 4);
+                                pv[nt][q][0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                pv[nt][q][1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const unsigned long long w0 = pv[0][r >> 2][(r >> 1) & 1], w1 = pv[1][r >> 2][(r >> 1) & 1];
+                            s0[r] += __builtin_bit_cast(float, (unsigned)((r & 1) ? (w0 >> 32) : w0));
+                            s1[r] += __builtin_bit_cast(float, (unsigned)((r & 1) ? (w1 >> 32) : w1));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m < p.M && col_ok) {
+                        const unsigned o = (unsigned)t_bits(DType<T>::from_f32(s0[r] + bias0)) | ((unsigned)t_bits(DType<T>::from_f32(s1[r] + bias1)) << 16);
+                        *(unsigned*)((unsigned short*)p.out + (size_t)m * p.N + n) = o;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
         }
     }
 
@@ -1546,6 +1666,9 @@ hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int 
 }
 
 // ---- host side ----------------------------------------------------------------------------------
+// Balanced tail of the tiled kernel by default?  (tuning.reserved[3] = 40 / 41 forces it on / off for A/B runs.)
+constexpr bool GEMM_TAIL_DEFAULT = false;
+
 template <int BITS, typename T, int MT, int BK, int VAR, bool XPRE, bool GLDS, int KG>
 static constexpr size_t gemm_lds_bytes() { return (size_t)KG * 2 * (32 * MT) * (GLDS ? BK * 2 : BK * 2 + 16) + (VAR == 32 ? 64 : 0); }
 
@@ -1812,7 +1935,9 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.mt = M <= 32 ? 1 : (M <= 64 ? 2 : 4);
     pl.bk = (L.bits == 4 && pl.mt == 4 && L.K % 64 == 0 && L.group_size % 64 == 0) ? 64 : 32;
     if (tune && tune->reserved[1] == 32) pl.bk = 32;
-    pl.variant = tune ? tune->reserved[3] : 0;            // experiment knob: inner-loop schedule variant      // experiment knob: force the 32-deep K-step
+    pl.variant = tune ? tune->reserved[3] : 0;            // experiment knob: inner-loop schedule variant
+    const int tail_knob = (pl.variant == 40 || pl.variant == 41) ? pl.variant : 0;      // 40 = balanced tail on, 41 = off (A/B), else the default rule
+    if (tail_knob) pl.variant = 0;
     pl.bm = 32 * pl.mt;
     pl.bn = 256;
     pl.nbm = (M + pl.bm - 1) / pl.bm;
@@ -1838,13 +1963,45 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     const bool even_slices = pl.ksteps_total % pl.ksteps_per_split == 0 && pl.ksteps_per_split % 2 == 0 && pl.ksteps_per_split >= 4;
     const bool kg_ok = L.bits == 4 && pl.bk == 64 && pl.mt == 4 && even_slices && (pl.variant == 0 || pl.variant == 6 || pl.variant == 7 || pl.variant == 16 || pl.variant == 17 || pl.variant == 32) &&
                        (!pl.use_seq || pl.xslot == pl.glds);
-    pl.kg = (kg_ok && pl.variant != 6 && pl.variant != 16 && ((long)pl.nbm * pl.nbn * pl.ksplit <= 256 || pl.variant == 7 || pl.variant == 17 || pl.variant == 32)) ? 2 : 1;   // 16 / 17: gemmlab timeline variants (one / two K groups); 32: ping-pong
+    // Balanced tail (see gemm_kernel, TAIL): the tiles past the last full round of 256 are cut into 2 / 4 / 8 K slices when the time model says
+    // it pays -- a round costs ksteps x ~1.05 us, the tail round shrinks to ceil(tail * s / 256) / s of it, and the fix-up moves 128 KiB per
+    // published slice and direction at ~3 TB/s plus ~1 us per slice on the last arrival.  Above ~4 rounds the workgroups no longer run in
+    // lockstep and the hardware's own dispatch balances the launch (4096x11008 at M = 4096, 1376 tiles: 366 us measured, 364 us of work).
+    pl.tail = 0; pl.tail_lg = 0;
+    {
+        const long tiles = (long)pl.nbm * pl.nbn, rem = tiles % 256;
+        const bool legal = L.bits == 4 && pl.bk == 64 && pl.mt == 4 && pl.ksplit == 1 && pl.variant == 0 &&
+                           (!pl.use_seq || (pl.xslot && pl.glds) || L.dtype == GPTQ_BF16) && L.N % 256 == 0;
+        const bool wanted = tail_knob == 40 || (tail_knob == 0 && GEMM_TAIL_DEFAULT);
+        if (legal && wanted && tiles > 256 && tiles <= 1024 && rem > 0) {
+            const double t_round = 1.05 * pl.ksteps_total;
+            double best = 0.0;
+            for (int lg = 1; lg <= 3; ++lg) {
+                const int s = 1 << lg;
+                if (pl.ksteps_total % s != 0 || pl.ksteps_total / s < 4) break;
+                const double gain = t_round * (1.0 - (double)((rem * s + 255) / 256) / s);
+                const double cost = (double)rem * (s - 1) * (2.0 * 131072.0) / 3.0e6 + 1.0 * (s - 1);      // us
+                if (gain - cost > best + 0.5) { best = gain - cost; pl.tail_lg = lg; }
+            }
+            if (best >= 0.03 * t_round * (double)tiles / 256.0) pl.tail = (int)rem;       // at least 3 % of the launch
+            else pl.tail_lg = 0;
+        }
+        if (pl.tail) pl.workspace_bytes = pl.xperm_bytes + ((size_t)pl.tail << pl.tail_lg) * (32 * 256 * 16);
+    }
+    pl.kg = (kg_ok && pl.tail == 0 && pl.variant != 6 && pl.variant != 16 && ((long)pl.nbm * pl.nbn * pl.ksplit <= 256 || pl.variant == 7 || pl.variant == 17 || pl.variant == 32)) ? 2 : 1;   // 16 / 17: gemmlab timeline variants (one / two K groups); 32: ping-pong
     return pl;
 }
 
 template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, bool GLDS = false, int KG = 1>
 static hipError_t launch_one(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
     const size_t lds = gemm_lds_bytes<BITS, T, MT, BK, VAR, XPRE, GLDS, KG>();       // KG = 2: >= the 64 KiB exchange area
+    if constexpr (BITS == 4 && MT == 4 && BK == 64 && VAR == 1 && KG == 1) {
+        if (pl.tail > 0) {                         // whole tiles first, then the K slices of the tail tiles
+            hipLaunchKernelGGL((gemm_kernel<BITS, T, MT, BK, VAR, XPRE, GLDS, 1, true>), dim3(pl.nbm * pl.nbn - pl.tail + (pl.tail << pl.tail_lg), 1),
+                               dim3(256), lds, st, p);
+            return hipGetLastError();
+        }
+    }
     auto* kern = gemm_kernel<BITS, T, MT, BK, VAR, XPRE, GLDS, KG>;
     // KG = 2 asks for > 64 KiB of dynamic LDS: granted per function and device by init_gemm_device() (gptq_init), never here --
     // the launch path makes no runtime-API call besides the launch itself, so it is legal under stream capture.
@@ -1991,6 +2148,14 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
         p.x = workspace;
     }
     p.partial = (float*)((char*)workspace + pl.xperm_bytes);
+    if (pl.tail > 0) {
+        if (!ws_header || !workspace) return hipErrorInvalidValue;
+        p.tail = pl.tail; p.tail_lg = pl.tail_lg;
+        p.tail_flags = (unsigned*)ws_header;
+        p.tail_partial = p.partial;
+        p.err = (unsigned*)((char*)ws_header + WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES) + 2;
+        p.max_spins = 1u << 22;
+    }
     if (pl.mid) {
         const gptq_layer_t* one[1] = {&L};
         void* outs[1] = {out};

@@ -72,7 +72,9 @@ __device__ __forceinline__ void dma16_sv_nt(const void* sbase, unsigned voff, un
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void store16_sc1(void* dst, f32x4 v) {      // write-through: visible to every XCD once drained
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+    // s_nop inside the string: hipcc pads nothing behind an asm statement, and the data registers are dead to it -- an instruction right behind
+    // the store that overwrites them races with the store's own read of them (seen in the tiled kernel's balanced tail, tools/tail_diag.py)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
 }
 
 // one column: (scale bits, zero-point) -> fragment of one 4-bit word = 8 consecutive k in the slot order k0,k4,k1,k5,k2,k6,k3,k7;

@@ -57,8 +57,9 @@ struct GemmPlan {
     int kg;                   // K groups inside a workgroup (2 = 8 waves, two K halves summed through LDS)
     int mt, bk, bm, bn;       // row tiles per wave, K-step, workgroup tile
     int nbm, nbn, ksplit, ksteps_total, ksteps_per_split;
+    int tail, tail_lg;        // tiled kernel, balanced tail: the last `tail` tiles run as 2^tail_lg K slices (one workgroup each, combined inside the launch)
     size_t xperm_bytes;       // permuted-x scratch for act-order layers (front of the workspace)
-    size_t workspace_bytes;   // xperm + split-K partial slabs
+    size_t workspace_bytes;   // xperm + split-K partial slabs (or the balanced tail's accumulator slabs)
 };
 GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune);
 hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x, void* out, int M,
