@@ -353,9 +353,9 @@ template <> struct Deq<4, bf16> {
 // block's K range with their own x buffers, and the two halves are summed through LDS at the end.  Used when the launch
 // has at most one 128x256 tile per CU: a CU then holds two waves per SIMD (what two co-resident workgroups would give a
 // larger problem), so one wave's dequant/LDS work fills the other's MFMA shadows, at the same weight/x traffic per flop.
-// TAIL (round 3, KG = 1, one K slice): balanced tail.  While the workgroups of a launch run in lockstep (up to ~4 rounds of one 128 x 256 tile per
-// CU -- a CU's throughput is the same with one or two resident workgroups), T tiles cost ceil(T / 256) tile times: 258 tiles take as long as 512,
-// 516 as long as 768 (measured: 4096x11008 at M = 1536, 516 tiles, 179 us against 137 us of work).  With TAIL the last p.tail = T mod 256 logical
+// TAIL (round 3, KG = 1, one K slice): balanced tail.  The workgroups of a launch start together and take the same time, so T tiles cost about
+// ceil(T / 256) tile times: the T mod 256 tiles of the last round keep a few CUs busy while the rest of the chip idles (measured: 4096x11008
+// at M = 1536, 516 tiles, 179 us against 137 us of work; still 5 % at 1376 tiles).  With TAIL the last p.tail = T mod 256 logical
 // tiles are run by 2^tail_lg workgroups each, one per K slice, launched behind the whole tiles.  Every slice takes an arrival ticket when its K
 // loop is done; all but the last arrival write their accumulators to the workspace (write-through stores), raise their "published" flag and
 // leave; the last arrival -- which only ever waits for workgroups that are past their K loops: no residency assumption -- adds the slices IN
@@ -1666,8 +1666,8 @@ hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int 
 }
 
 // ---- host side ----------------------------------------------------------------------------------
-// Balanced tail of the tiled kernel by default?  (tuning.reserved[3] = 40 / 41 forces it on / off for A/B runs.)
-constexpr bool GEMM_TAIL_DEFAULT = false;
+// Balanced tail of the tiled kernel by default?  (tuning.reserved[3] = 40 / 41 forces the rule on / off for A/B runs.)
+constexpr bool GEMM_TAIL_DEFAULT = true;
 
 template <int BITS, typename T, int MT, int BK, int VAR, bool XPRE, bool GLDS, int KG>
 static constexpr size_t gemm_lds_bytes() { return (size_t)KG * 2 * (32 * MT) * (GLDS ? BK * 2 : BK * 2 + 16) + (VAR == 32 ? 64 : 0); }
@@ -1936,7 +1936,7 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.bk = (L.bits == 4 && pl.mt == 4 && L.K % 64 == 0 && L.group_size % 64 == 0) ? 64 : 32;
     if (tune && tune->reserved[1] == 32) pl.bk = 32;
     pl.variant = tune ? tune->reserved[3] : 0;            // experiment knob: inner-loop schedule variant
-    const int tail_knob = (pl.variant == 40 || pl.variant == 41) ? pl.variant : 0;      // 40 = balanced tail on, 41 = off (A/B), else the default rule
+    const int tail_knob = (pl.variant >= 40 && pl.variant <= 42) ? pl.variant : 0;      // 40 / 42 = balanced tail by the rule below, 41 = off (A/B runs)
     if (tail_knob) pl.variant = 0;
     pl.bm = 32 * pl.mt;
     pl.bn = 256;
@@ -1965,15 +1965,17 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
                        (!pl.use_seq || pl.xslot == pl.glds);
     // Balanced tail (see gemm_kernel, TAIL): the tiles past the last full round of 256 are cut into 2 / 4 / 8 K slices when the time model says
     // it pays -- a round costs ksteps x ~1.05 us, the tail round shrinks to ceil(tail * s / 256) / s of it, and the fix-up moves 128 KiB per
-    // published slice and direction at ~3 TB/s plus ~1 us per slice on the last arrival.  Above ~4 rounds the workgroups no longer run in
-    // lockstep and the hardware's own dispatch balances the launch (4096x11008 at M = 4096, 1376 tiles: 366 us measured, 364 us of work).
+    // published slice and direction at ~3 TB/s plus ~1 us per slice on the last arrival; it has to be worth 3 % of the launch.  Measured
+    // (profiles/r03_gemm_balanced_tail_ab.log, us per layer, whole tiles -> balanced): 4096x4096 M = 2176 / 2560 / 2944 / 4224: 111 -> 87,
+    // 124 -> 99, 122 -> 106, 182 -> 153; 4096x11008 M = 768 / 1024 / 1536 / 4096: 106 -> 85, 120 -> 102, 187 -> 161, 375 -> 356 (1037 TFLOP/s);
+    // 11008x4096 M = 2176: 281 -> 221.  A tail the model refuses (4096x11008 at M = 2048: 176 tiles) measured 0.97 - 1.0x with two slices.
     pl.tail = 0; pl.tail_lg = 0;
     {
         const long tiles = (long)pl.nbm * pl.nbn, rem = tiles % 256;
         const bool legal = L.bits == 4 && pl.bk == 64 && pl.mt == 4 && pl.ksplit == 1 && pl.variant == 0 &&
                            (!pl.use_seq || (pl.xslot && pl.glds) || L.dtype == GPTQ_BF16) && L.N % 256 == 0;
-        const bool wanted = tail_knob == 40 || (tail_knob == 0 && GEMM_TAIL_DEFAULT);
-        if (legal && wanted && tiles > 256 && tiles <= 1024 && rem > 0) {
+        const bool wanted = tail_knob == 40 || tail_knob == 42 || (tail_knob == 0 && GEMM_TAIL_DEFAULT);
+        if (legal && wanted && tiles > 256 && rem > 0) {
             const double t_round = 1.05 * pl.ksteps_total;
             double best = 0.0;
             for (int lg = 1; lg <= 3; ++lg) {

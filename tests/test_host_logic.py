@@ -433,6 +433,54 @@ def test_dispatch_rules_are_the_measured_ones():
         _plan(4096, 4096, 0)
 
 
+def test_balanced_tail_rule():
+    """Tiled kernel, 4-bit fp16 / bf16, 128 x 256 x 64 tiles: the tiles past the last full round of 256 run as 2 / 4 / 8 K slices when the planner's
+    time model says it pays (measured in profiles/r03_gemm_balanced_tail_ab.log).  Pinned decisions, the off knob, and the invariants a
+    launch relies on: K steps divide over the slices, the flag words fit the ticket half of the header, the workspace covers the slabs."""
+    lib = _lib.load()
+    off = _lib.GptqTuning()
+    off.path, off.reserved[3] = 3, 41
+    pinned = [  # K, N, M, act, dtype -> (tail, slices)
+        (4096, 11008, 2048, True, 0, (0, 1)),        # 688 tiles: 176 left over, two slices would only move 45 MB around (measured 0.97 - 1.0x)
+        (4096, 11008, 4096, True, 0, (96, 2)),       # 375 -> 356 us
+        (4096, 4096, 4096, False, 0, (0, 1)),        # 512 tiles: nothing left over
+        (4096, 4096, 2048, False, 0, (0, 1)),        # 256 tiles: the 8-wave form
+        (4096, 11008, 768, False, 0, (2, 8)),        # 106 -> 85 us
+        (4096, 11008, 1024, False, 0, (88, 2)),      # 120 -> 102 us
+        (4096, 4096, 2176, False, 1, (16, 4)),       # 111 -> 87 us
+        (11008, 4096, 2176, True, 0, (16, 4)),       # 172 K steps: 4 slices of 43
+        (8192, 28672, 2048, False, 0, (0, 1)),
+    ]
+    for K, N, M, act, dt, want in pinned:
+        d = _plan(K, N, M, act=act, dtype=dt)
+        assert (d["tail"], d["tail_slices"]) == want, (K, N, M, act, dt, d)
+        assert _plan(K, N, M, act=act, dtype=dt, tuning=off)["tail"] == 0
+    rng = np.random.default_rng(40)
+    seen = 0
+    for _ in range(3000):
+        K = int(rng.choice([512, 1024, 2048, 4096, 5120, 8192, 11008]))
+        N = 256 * int(rng.integers(1, 120))
+        M = int(rng.integers(65, 20000))
+        act = bool(rng.integers(0, 2))
+        dt = int(rng.integers(0, 2))
+        L = _layer(K=K, N=N, bits=4, group_size=128, dtype=dt)
+        if act:
+            L.g_idx = L.qweight_seq = L.perm = 0x1000
+        d = _lib.describe_plan(L, M, None)
+        if d.get("kernel") != "tiled" or not d.get("tail"):
+            continue
+        seen += 1
+        nbm, nbn = map(int, d["tiles"].split("x"))
+        s = d["tail_slices"]
+        assert s in (2, 4, 8) and d["tail"] == (nbm * nbn) % 256 and nbm * nbn > 256 and d["ksplit"] == 1 and d["kg"] == 1, d
+        assert (K // 64) % s == 0 and K // 64 // s >= 4, (K, d)
+        assert 16 * d["tail"] * 4 <= 32768, d
+        need = int(lib.gptq_workspace_bytes(ctypes.byref(L), M))
+        xperm = (M * K * 2 + 255) // 256 * 256 if act else 0
+        assert need >= 65536 + xperm + d["tail"] * s * 131072, (K, N, M, act, d, need)
+    assert seen > 100
+
+
 def test_format_round_trips_random():
     """Random layers through the three checkpoint formats: GPTQ -> Marlin -> GPTQ is the identity on symmetric layers, and
     AWQ words -> GPTQ words unpack (oracle) to the integers that were packed, for several shapes and seeds."""

@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", default="4096x11008x768a,4096x4096x2176,4096x4096x2176a,11008x4096x2176a,4096x11008x1024,4096x11008x1536a,4096x11008x1664a,4096x11008x2304,4096x4096x4224,4096x4096x2304ab,4096x11008x2048a")
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--on", type=int, default=40, help="40 = the planner's rule, 42 = the rule without its tile limit")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     for case in args.cases.split(","):
@@ -33,7 +34,7 @@ def main():
         n = 6 if K * N <= 64 << 20 else 3
         layers = [make_layer(K, N, dev, act_order=act, dtype=dt, seed=i) for i in range(n)]
         x = (torch.rand(M, K, device=dev) - 0.5).to(dt)
-        t_on, t_off = tun(40), tun(41)
+        t_on, t_off = tun(args.on), tun(41)
         plan = _lib.describe_plan(layers[0]._layer, M, t_on)
         best = {40: 1e9, 41: 1e9}
         for _ in range(args.rounds):
