@@ -1972,15 +1972,16 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.tail = 0; pl.tail_lg = 0;
     {
         const long tiles = (long)pl.nbm * pl.nbn, rem = tiles % 256;
-        const bool legal = L.bits == 4 && pl.bk == 64 && pl.mt == 4 && pl.ksplit == 1 && pl.variant == 0 &&
-                           (!pl.use_seq || (pl.xslot && pl.glds) || L.dtype == GPTQ_BF16) && L.N % 256 == 0;
+        // every 128-row form of the kernel: 4-bit BK = 64 (act-order fp16 only in its DMA-staged form) and the BK = 32 forms of 2- / 3- / 8-bit and g32 layers
+        const bool legal = pl.mt == 4 && pl.ksplit == 1 && pl.variant == 0 && L.N % 256 == 0 &&
+                           (pl.bk == 32 || !pl.use_seq || (pl.xslot && pl.glds) || L.dtype == GPTQ_BF16);
         const bool wanted = tail_knob == 40 || tail_knob == 42 || (tail_knob == 0 && GEMM_TAIL_DEFAULT);
         if (legal && wanted && tiles > 256 && rem > 0) {
-            const double t_round = 1.05 * pl.ksteps_total;
+            const double t_round = 1.05 * (L.K / 64.0) * (L.bits != 4 ? 1.35 : (pl.bk == 32 ? 1.1 : 1.0));      // 2- / 3- / 8-bit prefill: 660 - 770 TFLOP/s
             double best = 0.0;
             for (int lg = 1; lg <= 3; ++lg) {
                 const int s = 1 << lg;
-                if (pl.ksteps_total % s != 0 || pl.ksteps_total / s < 4) break;
+                if (pl.ksteps_total % s != 0 || (pl.ksteps_total / s) * pl.bk < 256) break;
                 const double gain = t_round * (1.0 - (double)((rem * s + 255) / 256) / s);
                 const double cost = (double)rem * (s - 1) * (2.0 * 131072.0) / 3.0e6 + 1.0 * (s - 1);      // us
                 if (gain - cost > best + 0.5) { best = gain - cost; pl.tail_lg = lg; }
@@ -1997,7 +1998,7 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
 template <int BITS, typename T, int MT, int BK, int VAR = 1, bool XPRE = false, bool GLDS = false, int KG = 1>
 static hipError_t launch_one(const GemmPlan& pl, const GemmParams& p, hipStream_t st) {
     const size_t lds = gemm_lds_bytes<BITS, T, MT, BK, VAR, XPRE, GLDS, KG>();       // KG = 2: >= the 64 KiB exchange area
-    if constexpr (BITS == 4 && MT == 4 && BK == 64 && VAR == 1 && KG == 1) {
+    if constexpr (MT == 4 && VAR == 1 && KG == 1) {
         if (pl.tail > 0) {                         // whole tiles first, then the K slices of the tail tiles
             hipLaunchKernelGGL((gemm_kernel<BITS, T, MT, BK, VAR, XPRE, GLDS, 1, true>), dim3(pl.nbm * pl.nbn - pl.tail + (pl.tail << pl.tail_lg), 1),
                                dim3(256), lds, st, p);

@@ -737,41 +737,56 @@ def test_gemm_k_groups_inside_workgroup(dtype, act, K, N, M, ksplit):
     _assert_close(y7, y6.double(), y64, dtype, K, "8-wave vs 4-wave")
 
 
-@pytest.mark.parametrize("dtype,act,K,N,M,slices", [
-    (torch.float16, False, 512, 2304, 7424, 2), (torch.float16, True, 512, 2304, 7300, 2), (torch.bfloat16, False, 2048, 2304, 7424, 4),
-    (torch.bfloat16, True, 1024, 2304, 3800, 2), (torch.float16, True, 4096, 11008, 768, 8), (torch.float16, False, 4096, 4096, 2176, 4)])
-def test_tiled_gemm_balanced_tail(dtype, act, K, N, M, slices):
-    """Balanced tail of the big-tile kernel (tuning.reserved[3] = 40 / 41 = the planner's rule / off): the tiles past the last full round of 256 run
-    as 2 / 4 / 8 K slices by as many workgroups each, combined inside the launch (arrival ticket, write-through partials, published count, sum in
-    slice order by the last arrival).  Every output against the whole-tile form; a row / column sample that covers the split tiles against the
-    fp64 oracle; bit-reproducible over repeated launches (the sum does not depend on who arrives last); ticket / count words zero and the sticky
-    error word clear afterwards."""
+def _check_balanced_tail(bits, gs, dtype, act, K, N, M, slices=None):
     from autogptq_amd import qlinear_mi355x as QM
-    L = O.random_quant_layer(K, N, 4, 128, act_order=act, seed=K + N + M, bias=True, dtype=dtype)
+    L = O.random_quant_layer(K, N, bits, gs, act_order=act, seed=K + N + M + bits, bias=True, dtype=dtype)
     x = (torch.rand(M, K, generator=torch.Generator().manual_seed(40)) - 0.5).to(dtype).to(DEV)
-    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, 128, zero_mode="wrap")
+    q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], bits, gs, zero_mode="wrap")
     t_on, t_off = _tuning(path=3), _tuning(path=3)
     t_on.reserved[3], t_off.reserved[3] = 40, 41
     with torch.no_grad():
         y_off = q(x, tuning=t_off)
         ys = [q(x, tuning=t_on) for _ in range(4)]
+        y_auto = q(x)
     plan = _lib.describe_plan(q._layer, M, t_on)
     tiles = ((M + 127) // 128) * (N // 256)
-    assert plan["kernel"] == "tiled" and plan["tail"] == tiles % 256 and plan["tail_slices"] == slices, plan
+    assert plan["kernel"] == "tiled" and plan["tail"] == tiles % 256 and plan["tail_slices"] in ((slices,) if slices else (2, 4, 8)), plan
     assert _lib.describe_plan(q._layer, M, t_off)["tail"] == 0
     for y in ys[1:]:
         assert torch.equal(ys[0], y)
+    assert torch.equal(ys[0], y_auto), "the rule is the default"
     torch.cuda.synchronize()
     for ent in QM._WORKSPACE.values():
         hdr = ent[0][:_lib.WS_HEADER_BYTES].view(torch.int32)
-        assert int(hdr[:8192].abs().max().item()) == 0, "ticket / count words must be zero between launches"
+        assert int(hdr[:8192].abs().max().item()) == 0, "ticket / flag words must be zero between launches"
         assert int(hdr[_lib.WS_HEADER_BYTES // 4 - 16 + 2].item()) == 0, "a bounded wait gave up"
     rows = torch.cat([torch.arange(0, M, max(1, M // 53)), torch.arange(max(0, M - 130), M, 7)]).unique()
     cols = slice(N - 512, N)                      # the last column tiles: the split tiles sit at the end of the tile order
-    y64 = O.forward_f64(x[rows].cpu(), L["qweight"][:, cols], L["qzeros"][:, cols.start * 4 // 32: cols.stop * 4 // 32], L["scales"][:, cols],
-                        L["g_idx"], L["bias"][cols], 4, O.ZERO_WRAP)
+    y64 = O.forward_f64(x[rows].cpu(), L["qweight"][:, cols], L["qzeros"][:, cols.start * bits // 32: cols.stop * bits // 32], L["scales"][:, cols],
+                        L["g_idx"], L["bias"][cols], bits, O.ZERO_WRAP)
     _assert_close(ys[0][rows][:, cols], y64, y64, dtype, K, "balanced tail vs f64")
     _assert_close(ys[0], y_off.double(), y64, dtype, K, "balanced tail vs whole tiles")
+
+
+@pytest.mark.parametrize("dtype,act,K,N,M,slices", [
+    (torch.float16, False, 512, 2304, 7424, 2), (torch.float16, True, 512, 2304, 7300, 2), (torch.bfloat16, False, 2048, 2304, 7424, 4),
+    (torch.bfloat16, True, 1024, 2304, 3800, 2), (torch.float16, True, 4096, 11008, 768, 8), (torch.float16, False, 4096, 4096, 2176, 4)])
+def test_tiled_gemm_balanced_tail(dtype, act, K, N, M, slices):
+    """Balanced tail of the big-tile kernel (the default; tuning.reserved[3] = 40 / 41 = the planner's rule / off): the tiles past the last full round
+    of 256 run as 2 / 4 / 8 K slices by as many workgroups each, combined inside the launch (arrival ticket, write-through partials, per-slice
+    flags, sum in slice order by the last arrival).  Every output against the whole-tile form; a row / column sample that covers the split tiles
+    against the fp64 oracle; bit-reproducible over repeated launches (the sum does not depend on who arrives last); ticket / flag words zero and
+    the sticky error word clear afterwards."""
+    _check_balanced_tail(4, 128, dtype, act, K, N, M, slices)
+
+
+@pytest.mark.parametrize("bits,gs,dtype,act,K,N,M", [
+    (8, 32, torch.float16, False, 1024, 2304, 3800), (8, 128, torch.bfloat16, True, 2048, 2304, 7424), (3, 32, torch.float16, True, 2048, 2304, 3800),
+    (3, 128, torch.bfloat16, False, 1024, 2304, 7424), (2, 64, torch.float16, False, 2048, 2304, 3800), (2, 32, torch.bfloat16, True, 1024, 2304, 7300),
+    (4, 32, torch.float16, True, 2048, 2304, 7424), (4, 32, torch.bfloat16, False, 1024, 2304, 3800)])
+def test_tiled_gemm_balanced_tail_other_packings(bits, gs, dtype, act, K, N, M):
+    """The same on the 32-deep K-step forms of the kernel: 2- / 3- / 8-bit layers and 4-bit layers with 32-wide groups."""
+    _check_balanced_tail(bits, gs, dtype, act, K, N, M)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

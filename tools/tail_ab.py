@@ -22,6 +22,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", default="4096x11008x768a,4096x4096x2176,4096x4096x2176a,11008x4096x2176a,4096x11008x1024,4096x11008x1536a,4096x11008x1664a,4096x11008x2304,4096x4096x4224,4096x4096x2304ab,4096x11008x2048a")
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--bits", type=int, default=4)
+    ap.add_argument("--gs", type=int, default=128)
     ap.add_argument("--on", type=int, default=40, help="40 = the planner's rule, 42 = the rule without its tile limit")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -32,7 +34,7 @@ def main():
         K, N, M = map(int, c.rstrip("a").split("x"))
         dt = torch.bfloat16 if bf else torch.float16
         n = 6 if K * N <= 64 << 20 else 3
-        layers = [make_layer(K, N, dev, act_order=act, dtype=dt, seed=i) for i in range(n)]
+        layers = [make_layer(K, N, dev, bits=args.bits, gs=args.gs, act_order=act, dtype=dt, seed=i) for i in range(n)]
         x = (torch.rand(M, K, device=dev) - 0.5).to(dt)
         t_on, t_off = tun(args.on), tun(41)
         plan = _lib.describe_plan(layers[0]._layer, M, t_on)
@@ -53,7 +55,7 @@ def main():
             hdr_ok &= int(h[:8192].abs().max().item()) == 0
             err |= int(h[_lib.WS_HEADER_BYTES // 4 - 14].item())
         fl = 2 * M * K * N
-        print(f"{K}x{N} M={M} act={int(act)} {'bf16' if bf else 'f16'} tiles={plan['tiles']} tail={plan['tail']}x{plan['tail_slices']}: whole {best[41] * 1e6:7.1f} us {fl / best[41] / 1e12:6.0f} TF | "
+        print(f"int{args.bits} g{args.gs} {K}x{N} M={M} act={int(act)} {'bf16' if bf else 'f16'} tiles={plan['tiles']} tail={plan['tail']}x{plan['tail_slices']}: whole {best[41] * 1e6:7.1f} us {fl / best[41] / 1e12:6.0f} TF | "
               f"balanced {best[40] * 1e6:7.1f} us {fl / best[40] / 1e12:6.0f} TF ({best[41] / best[40]:.3f}x)  max|diff| {float(d.max()):.3g} of {scale:.3g}, "
               f"differing {int((d > 0).sum())}/{d.numel()}, repeat-identical={same} header_zero={hdr_ok} err={err}", flush=True)
         del layers, x, y_off, y_on
