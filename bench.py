@@ -300,6 +300,40 @@ def bench_prefill(device, steps):
                                "plan": _plan_of(ls, 4096, 4096, M2)}}
     del ls, xs2
     torch.cuda.empty_cache()
+    # row counts that leave a remainder round of 128 x 256 tiles (balanced tail): the planner's default against whole tiles only
+    try:
+        from autogptq_amd import _lib
+        off = _lib.GptqTuning()
+        off.path, off.reserved[3] = 3, 41
+        rem = {}
+        for (K, N, Mx, act) in ((4096, 11008, 2304, True), (4096, 11008, 1536, True), (4096, 4096, 2176, False)):
+            ls = [("q", K, N, make_layer(K, N, device, act_order=act, seed=950 + i)) for i in range(6)]
+            x = (torch.rand(Mx, K, device=device) - 0.5).half()
+            graphs = []
+            for tn in (None, off):                      # the planner's default, then whole tiles only
+                gg = torch.cuda.CUDAGraph()
+                with torch.no_grad():
+                    ls[0][3](x, tuning=tn)
+                    torch.cuda.synchronize(device)
+                    with torch.cuda.graph(gg):
+                        keep = [q(x, tuning=tn) for _, _, _, q in ls]
+                graphs.append((gg, keep))
+            reps = max(2, steps // 6)
+            best = [1e9, 1e9]
+            for _ in range(2):                          # interleaved, minimum of two rounds each
+                for i, (gg, _) in enumerate(graphs):
+                    gg.replay()
+                    _, evt = time_graph(gg, reps, device)
+                    best[i] = min(best[i], evt / (reps * len(ls)))
+            per, per_off = best
+            rem[f"{K}x{N}_M{Mx}" + ("_desc_act" if act else "")] = {
+                "us": round(per * 1e6, 2), "TFLOP_s": round(2 * Mx * K * N / per / 1e12, 1), "frac": round(2 * Mx * K * N / per / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                "us_whole_tiles_only": round(per_off * 1e6, 2), "plan": _plan_of(ls, K, N, Mx)}
+            del graphs, gg, keep, ls, x
+            torch.cuda.empty_cache()
+        out["remainder_rounds"] = rem
+    except Exception as e:
+        out["remainder_rounds"] = {"error": repr(e)[:200]}
     return out
 
 

@@ -442,7 +442,9 @@ def test_balanced_tail_rule():
     off.path, off.reserved[3] = 3, 41
     pinned = [  # K, N, M, act, dtype -> (tail, slices)
         (4096, 11008, 2048, True, 0, (0, 1)),        # 688 tiles: 176 left over, two slices would only move 45 MB around (measured 0.97 - 1.0x)
-        (4096, 11008, 4096, True, 0, (96, 2)),       # 375 -> 356 us
+        (4096, 11008, 4096, True, 0, (0, 1)),        # 1376 tiles, 96 left over: 6.7 % predicted = noise level measured (+5 % / -5 % in two sessions)
+        (4096, 11008, 3072, True, 0, (0, 1)),        # 1032 tiles: beyond ~4 rounds the gain is within the harness-to-harness spread
+        (4096, 11008, 2304, False, 0, (6, 8)),       # 242 -> 221 us
         (4096, 4096, 4096, False, 0, (0, 1)),        # 512 tiles: nothing left over
         (4096, 4096, 2048, False, 0, (0, 1)),        # 256 tiles: the 8-wave form
         (4096, 11008, 768, False, 0, (2, 8)),        # 106 -> 85 us
@@ -472,7 +474,7 @@ def test_balanced_tail_rule():
         seen += 1
         nbm, nbn = map(int, d["tiles"].split("x"))
         s = d["tail_slices"]
-        assert s in (2, 4, 8) and d["tail"] == (nbm * nbn) % 256 and nbm * nbn > 256 and d["ksplit"] == 1 and d["kg"] == 1, d
+        assert s in (2, 4, 8) and d["tail"] == (nbm * nbn) % 256 and 256 < nbm * nbn <= 1024 and d["ksplit"] == 1 and d["kg"] == 1, d
         assert (K // 64) % s == 0 and K // 64 // s >= 4, (K, d)
         assert 16 * d["tail"] * 4 <= 32768, d
         need = int(lib.gptq_workspace_bytes(ctypes.byref(L), M))
