@@ -491,7 +491,8 @@ def cpu_baseline(M, act_order, budget_s=20.0):
 def bench_tp(device, rank, world, steps, peer_store=False):
     """Column-parallel Llama-2-70B shapes (BASELINE config 4): local kernel + one all-gather, M = 1 (decode) and M = 2048
     (prefill); and the Megatron pairing of an MLP block -- column-parallel gate / up without gather feeding a row-parallel
-    down projection: ONE all-reduce per block.  Eager calls (RCCL on the layer's stream), HIP events, max over ranks.
+    down projection: ONE all-reduce per block.  Eager calls (RCCL on the layer's stream), HIP events, max over ranks; the M = 1
+    entries again as hipGraph replays (`*_graph`: eight calls per graph, the collective captured with the kernels).
     peer_store (--tp-exchange peer_store, experimental): the M = 1 layers again with the direct peer-store exchange of
     csrc/peer.hip instead of the collective (never exercised across GPUs by the builder: 1-GPU boxes only)."""
     import torch.distributed as dist
@@ -509,6 +510,51 @@ def bench_tp(device, rank, world, steps, peer_store=False):
         e1.record()
         torch.cuda.synchronize(device)
         return e0.elapsed_time(e1) * 1e-3 / n, out
+
+    def graphed(fn, calls=8, reps=10):
+        """`calls` forward calls captured in ONE hipGraph (the collective included: RCCL captures like any other stream work), `reps` replays
+        between HIP events; (seconds per call, None) or (None, reason).  Every rank replays or none does: the capture verdicts are reduced first."""
+        ok, why, g, keep = 1, None, None, None
+        try:
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side), torch.no_grad():
+                fn()                                  # workspace / communicator / exchange buffers exist before the capture
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize(device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side), torch.no_grad():
+                keep = [fn() for _ in range(calls)]
+        except Exception as e:
+            ok, why = 0, "capture: " + repr(e)[:160]
+        flag = torch.tensor([ok], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            return None, why or "capture failed on another rank"
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize(device)
+        del keep
+        return e0.elapsed_time(e1) * 1e-3 / (reps * calls), None
+
+    def put_graphed(ent, key, fn):
+        try:
+            t_g, why = graphed(fn)
+            if t_g is None:
+                ent[key + "_error"] = why
+            else:
+                t = torch.tensor([t_g], device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ent[key] = round(t.item() * 1e6, 2)
+        except Exception as e:
+            ent[key + "_error"] = repr(e)[:200]
 
     res = {}
     for name, K, N in LLAMA70B_TP:
@@ -528,6 +574,9 @@ def bench_tp(device, rank, world, steps, peer_store=False):
                 ent["us_per_layer_with_allgather" + key] = round(t[0].item() * 1e6, 2)
                 ent["us_local_only" + key] = round(t[1].item() * 1e6, 2)
                 ent["out_cols"] = int(y.shape[-1])
+                if M == 1:                            # decode is launch-bound: the number that matters is the graph-captured one
+                    put_graphed(ent, "us_per_layer_with_allgather_graph", lambda: mod(x))
+                    put_graphed(ent, "us_local_only_graph", lambda: local(x))
             except Exception as e:
                 ent[f"error_m{M}"] = repr(e)[:200]
         if peer_store:
@@ -541,6 +590,8 @@ def bench_tp(device, rank, world, steps, peer_store=False):
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 ent["us_per_layer_with_peer_store"] = round(t[0].item() * 1e6, 2)
                 ent["peer_store_equals_allgather"] = bool(torch.equal(yp, mod(x)))
+                put_graphed(ent, "us_per_layer_with_peer_store_graph", lambda: modp(x))      # kernels only: two launches per call
+                modp._px.check_timeout()
                 dist.barrier()
                 del modp
             except Exception as e:
@@ -563,6 +614,8 @@ def bench_tp(device, rank, world, steps, peer_store=False):
             t = torch.tensor([t_blk], device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ent["us_per_block" + ("" if M == 1 else f"_m{M}")] = round(t[0].item() * 1e6, 2)
+            if M == 1:
+                put_graphed(ent, "us_per_block_graph", block)
         res["mlp_column_row_pair"] = ent
     except Exception as e:
         res["mlp_column_row_pair"] = {"error": repr(e)[:200]}
@@ -582,6 +635,31 @@ def _watchdog(seconds: float):
     t.daemon = True
     t.start()
     return t
+
+
+def _deadline(seconds: float, on_expire):
+    """Run `on_expire` on a timer thread unless the returned finish() is called first; finish() says whether it won the race."""
+    import threading
+    lock, state = threading.Lock(), {"done": False}
+
+    def fire():
+        with lock:
+            if state["done"]:
+                return
+            state["done"] = True
+        on_expire()
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+
+    def finish():
+        with lock:
+            if state["done"]:
+                return False
+            state["done"] = True
+        t.cancel()
+        return True
+    return finish
 
 
 def main():
@@ -688,13 +766,7 @@ def main():
       except Exception as e:
         roof = {"error": repr(e)[:300]}
 
-    tp = None
-    if world > 1 and not args.no_tp and not prefill:
-        try:
-            tp = bench_tp(device, rank, world, 50, peer_store=(args.tp_exchange == "peer_store"))
-        except Exception as e:                       # the headline line must still be printed
-            tp = {"error": repr(e)[:300]}
-
+    out = None
     if rank == 0:
         if prefill:
             value, unit, metric = flops_step * args.steps * world / wall / 1e12, "TFLOP/s", \
@@ -717,8 +789,28 @@ def main():
             "algorithmic_bytes_per_step": bytes_step,
             "roofline": roof,
         }
-        if tp is not None:
+    # The tensor-parallel block is extra information: it runs with the headline already built, under a deadline of its own -- a hung or failed
+    # collective (one rank raising inside a capture while the others wait) costs the `tp` object, never the line the driver reads.
+    if world > 1 and not args.no_tp and not prefill:
+        tp_limit = float(os.environ.get("BENCH_TP_DEADLINE_S", "300"))
+
+        def tp_expired():
+            if rank == 0:
+                out["tp"] = {"error": f"tp block did not finish within {tp_limit:.0f} s (a rank hung or a collective failed); skipped"}
+                print(json.dumps(out))
+                sys.stdout.flush()
+            os._exit(0)
+        finish = _deadline(tp_limit, tp_expired)
+        try:
+            tp = bench_tp(device, rank, world, 50, peer_store=(args.tp_exchange == "peer_store"))
+        except Exception as e:                       # the headline line must still be printed
+            tp = {"error": repr(e)[:300]}
+        if not finish():
+            time.sleep(3600)                          # the timer thread is printing the line and ending the process
+        if rank == 0:
             out["tp"] = tp
+
+    if rank == 0:
         if not prefill and world == 1 and not args.no_extras:
             try:
                 out["eager"] = bench_eager(layers, xs, device, max(3, args.steps // 4))
@@ -766,6 +858,8 @@ def main():
                 roof["prefill_m4096_4096x4096"] = dict(bound="mfma", unit="TFLOP/s", peak=MFMA_PEAK_TFLOPS, achieved=pf["m4096_4096x4096"]["TFLOP_s"],
                                                        frac=pf["m4096_4096x4096"]["frac"], us_per_launch_events=pf["m4096_4096x4096"]["us_per_launch_events"])
                 roof["prefill_stack_TFLOP_s"] = pf.get("TFLOP_s")
+                if isinstance(pf.get("remainder_rounds"), dict):
+                    roof["prefill_remainder_rounds"] = pf["remainder_rounds"]
             byc = {}
             c5 = out.get("config5")
             if isinstance(c5, dict):
