@@ -1936,7 +1936,8 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.bk = (L.bits == 4 && pl.mt == 4 && L.K % 64 == 0 && L.group_size % 64 == 0) ? 64 : 32;
     if (tune && tune->reserved[1] == 32) pl.bk = 32;
     pl.variant = tune ? tune->reserved[3] : 0;            // experiment knob: inner-loop schedule variant
-    const int tail_knob = (pl.variant >= 40 && pl.variant <= 42) ? pl.variant : 0;      // 40 = balanced tail by the rule below, 41 = off, 42 = the rule without its tile limit (A/B runs)
+    const int tail_knob = (pl.variant >= 40 && pl.variant <= 43) ? pl.variant : 0;      // 40 = balanced tail by the rule below, 41 = off, 42 = the rule without its tile limit (A/B runs),
+                                                                                         // 43 = unrun experiment: a K-split launch combined in the launch (every tile a tail tile) instead of slabs + reduce launch
     if (tail_knob) pl.variant = 0;
     pl.bm = 32 * pl.mt;
     pl.bn = 256;
@@ -1970,6 +1971,15 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     // 124 -> 99, 122 -> 106, 182 -> 153; 4096x11008 M = 768 / 1024 / 1536 / 2304: 106 -> 85, 120 -> 102, 187 -> 161, 242 -> 221;
     // 11008x4096 M = 2176: 281 -> 221.  A tail the model refuses (4096x11008 at M = 2048: 176 tiles) measured 0.97 - 1.0x with two slices.
     pl.tail = 0; pl.tail_lg = 0;
+    if (tail_knob == 43 && pl.ksplit > 1 && pl.mt == 4 && L.N % 256 == 0 && (pl.ksplit & (pl.ksplit - 1)) == 0 && pl.ksplit <= 8 &&
+        pl.ksteps_total % pl.ksplit == 0 && (long)pl.nbm * pl.nbn * 16 * 4 <= (long)WS_HEADER_EPOCH_OFFSET &&
+        (pl.bk == 32 || !pl.use_seq || (pl.xslot && pl.glds) || L.dtype == GPTQ_BF16)) {
+        pl.tail = pl.nbm * pl.nbn;
+        while ((1 << pl.tail_lg) < pl.ksplit) ++pl.tail_lg;
+        pl.ksplit = 1;
+        pl.ksteps_per_split = pl.ksteps_total;
+        pl.workspace_bytes = pl.xperm_bytes + ((size_t)pl.tail << pl.tail_lg) * (32 * 256 * 16);
+    } else
     {
         const long tiles = (long)pl.nbm * pl.nbn, rem = tiles % 256;
         // every 128-row form of the kernel: 4-bit BK = 64 (act-order fp16 only in its DMA-staged form) and the BK = 32 forms of 2- / 3- / 8-bit and g32 layers
