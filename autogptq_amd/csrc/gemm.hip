@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(256 * KG, 2 / KG) gemm_kernel(GemmParams p) {
         const int whole = p.nbm * p.nbn - p.tail;
         if ((int)blockIdx.x < whole) L = xcd_remap(blockIdx.x, whole);
         else {
-            const int j = xcd_remap((int)blockIdx.x - whole, p.tail << p.tail_lg);      // the slices of a tile are neighbours: same XCD, same L2
+            const int j = xcd_remap((int)blockIdx.x - whole, p.tail << p.tail_lg);      // the slices of a tile are neighbours (one XCD when the tail is a multiple of 8; speed only)
             L = whole + (j >> p.tail_lg);
             tail_half = j & ((1 << p.tail_lg) - 1);
         }

@@ -116,7 +116,7 @@ typedef struct gptq_tuning_t {
     int32_t waves;       /* waves per workgroup (1..16) */
     int32_t ksplit;      /* workgroups along K (1 = no cross-workgroup reduction) */
     int32_t path;        /* 0 auto, 1 generic GEMV, 2 LDS-staged q4/fp16 GEMV, 3 MFMA GEMM, 4 direct q4/fp16 GEMV, 5 matrix-core GEMV (4-bit fp16 / bf16 kernel, or the 2/3/8-bit one), 6 streamed (LDS-DMA) q4 GEMV, 7 (gptq_mlp_forward_ex only) the one-launch persistent MLP kernel */
-    int32_t reserved[4]; /* [0]: max packed rows per lane and iteration for the register-direct GEMVs, = rows per lane for the streamed one, = K-steps per burst for the batched-decode kernel (0 = heuristic); [1]: 32 = force the 32-deep K-step in the MFMA GEMM, 1 = field-by-field decode in the 3- / 8-bit fp16 matrix-core GEMV instead of the packed magic-number one (A/B runs); [2]: 1 = force the 64-column skinny GEMM, 2 = force the tiled GEMM, 3 = force the 16-column-strip GEMM (4-bit, M <= 64), 4 = force the streamed 64-column-strip batched-decode GEMM (4-bit, M <= 64; waves / ksplit apply), 5 = force the 17..128-row kernel (gemm_mid_kernel: 4-bit, N % 64 == 0, M <= 128; ksplit applies, [0] = stages in flight 2..3, [1] = 1: x through registers instead of LDS DMA, 3: granule instead of flag combine, [3] = 2: 128-column strips for M <= 64); [3]: tiled-GEMM inner-loop schedule variant */
+    int32_t reserved[4]; /* [0]: max packed rows per lane and iteration for the register-direct GEMVs, = rows per lane for the streamed one, = K-steps per burst for the batched-decode kernel (0 = heuristic); [1]: 32 = force the 32-deep K-step in the MFMA GEMM, 1 = field-by-field decode in the 3- / 8-bit fp16 matrix-core GEMV instead of the packed magic-number one (A/B runs); [2]: 1 = force the 64-column skinny GEMM, 2 = force the tiled GEMM, 3 = force the 16-column-strip GEMM (4-bit, M <= 64), 4 = force the streamed 64-column-strip batched-decode GEMM (4-bit, M <= 64; waves / ksplit apply), 5 = force the 17..128-row kernel (gemm_mid_kernel: 4-bit, N % 64 == 0, M <= 128; ksplit applies, [0] = stages in flight 2..3, [1] = 1: x through registers instead of LDS DMA, 3: granule instead of flag combine, [3] = 2: 128-column strips for M <= 64); [3]: tiled-GEMM inner-loop schedule variant; 40 / 41 = balanced tail of the tiled GEMM by the planner's rule / off (the rule is the default), 42 = the rule without its 1024-tile limit, 43 = experiment: a K-split launch combined inside the launch */
 } gptq_tuning_t;
 
 int         gptq_abi_version(void);

@@ -216,3 +216,53 @@ def test_mid_kernel_3bit_zero_point_run():
             zz = ((((words[wi + 1] if wi + 1 < 12 else 0) << 32) | words[wi]) >> (bit & 31)) & 0xffffffff
             for t in range(4):
                 assert (zz >> (3 * t)) & 7 == zf[64 * strip + 4 * j + t], (strip, j, t)
+
+
+# ---------------------------------------------------------------------------------------------------- round 3: the balanced tail's block -> work mapping
+def _xcd_remap(b, n):
+    """common.cuh xcd_remap: hardware block b runs on XCD b % 8; consecutive logical ids land on one XCD."""
+    q, r = n >> 3, n & 7
+    xcd, idx = b & 7, b >> 3
+    base = xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q
+    return base + idx
+
+
+def _tile_of(L, nbm, nbn):
+    """gemm_kernel: logical tile -> (bm, bn): column blocks 8 tiles wide walked row by row, then the narrower last block."""
+    full, per = nbn >> 3, nbm * 8
+    if L < full * per:
+        cb, r = divmod(L, per)
+        return r >> 3, cb * 8 + (r & 7)
+    w = nbn & 7
+    r = L - full * per
+    bm = r // w
+    return bm, full * 8 + (r - bm * w)
+
+
+@pytest.mark.parametrize("nbm,nbn,tail,lg", [(17, 16, 16, 2), (12, 43, 4, 3), (8, 43, 88, 1), (6, 43, 2, 3), (58, 9, 10, 1), (13, 43, 47, 2), (4, 16, 64, 2),
+                                             (18, 16, 32, 2), (30, 9, 14, 1)])
+def test_balanced_tail_block_mapping_is_a_bijection(nbm, nbn, tail, lg):
+    """gemm_kernel<..., TAIL>: blocks [0, whole) are whole tiles, blocks behind them are the K slices of the last `tail` logical tiles.  Every whole
+    tile exactly once, every (tail tile, slice) exactly once, every (bm, bn) of the grid covered, the slices of a tile on one XCD whenever whole tiles
+    and tail tiles are multiples of 8 (speed only: the exchange is placement-independent), and the flag words of a tile inside its 16."""
+    tiles, s = nbm * nbn, 1 << lg
+    whole = tiles - tail
+    grid = whole + tail * s
+    seen_whole, seen_piece, xcds = set(), set(), {}
+    for b in range(grid):
+        if b < whole:
+            L = _xcd_remap(b, whole)
+            assert 0 <= L < whole and L not in seen_whole
+            seen_whole.add(L)
+        else:
+            j = _xcd_remap(b - whole, tail << lg)
+            L, sl = whole + (j >> lg), j & (s - 1)
+            assert whole <= L < tiles and (L, sl) not in seen_piece
+            seen_piece.add((L, sl))
+            xcds.setdefault(L, set()).add(b & 7)
+    assert len(seen_whole) == whole and len(seen_piece) == tail * s
+    assert {_tile_of(L, nbm, nbn) for L in range(tiles)} == {(bm, bn) for bm in range(nbm) for bn in range(nbn)}
+    if whole % 8 == 0 and tail % 8 == 0:                 # (fewer than 8 tail tiles: an XCD's share of the pieces is less than one tile's slices)
+        assert all(len(v) == 1 for v in xcds.values())
+    assert all(len(v) <= 2 for v in xcds.values()) or tail < 8
+    assert 1 + s <= 16 and 16 * tail * 4 <= 32768
