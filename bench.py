@@ -792,7 +792,7 @@ def main():
     # The tensor-parallel block is extra information: it runs with the headline already built, under a deadline of its own -- a hung or failed
     # collective (one rank raising inside a capture while the others wait) costs the `tp` object, never the line the driver reads.
     if world > 1 and not args.no_tp and not prefill:
-        tp_limit = float(os.environ.get("BENCH_TP_DEADLINE_S", "300"))
+        tp_limit = float(os.environ.get("BENCH_TP_DEADLINE_S", "150"))
 
         def tp_expired():
             if rank == 0:
