@@ -797,6 +797,8 @@ def main():
         def tp_expired():
             if rank == 0:
                 out["tp"] = {"error": f"tp block did not finish within {tp_limit:.0f} s (a rank hung or a collective failed); skipped"}
+                if isinstance(roof, dict):
+                    roof["tp"] = out["tp"]
                 print(json.dumps(out))
                 sys.stdout.flush()
             os._exit(0)
@@ -809,6 +811,8 @@ def main():
             time.sleep(3600)                          # the timer thread is printing the line and ending the process
         if rank == 0:
             out["tp"] = tp
+            if isinstance(roof, dict):
+                roof["tp"] = tp                       # the driver keeps `roofline` whole and drops unknown top-level keys
 
     if rank == 0:
         if not prefill and world == 1 and not args.no_extras:
