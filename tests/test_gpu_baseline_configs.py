@@ -163,3 +163,134 @@ def test_config4_llama70b_row_shard_and_act_order_refusal():
     full.qweight, full.qzeros, full.scales, full.g_idx = L["qweight"], L["qzeros"], L["scales"], L["g_idx"]
     with pytest.raises(ValueError, match="sequential groups"):
         RowParallelQuantLinear.from_full(full, 0, 8)
+
+
+# ------------------------------------------------------------------------------------------ config 2 (the headline)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("K,N", LLAMA7B)
+def test_config2_int4_g128_decode(K, N, dtype):
+    """BASELINE config 2 -- the headline: int4 g128, NO act-order, decode row counts on the three Llama-7B shapes, every output
+    of the planner's own kernel (register GEMV, streamed GEMV, 16-column strips / batched-decode kernels at 8 / 16 rows) against the
+    fp64 oracle product.  Mirrors tests/test_q4.py:1060-1122 (kernel output vs the Python path on the layer's real shape)."""
+    for M in (1, 2, 3, 4, 8, 16):
+        _check(4, 128, K, N, M, False, dtype)
+
+
+def _plain_layer(K, N, dtype, seed):
+    L = O.random_quant_layer(K, N, 4, 128, act_order=False, dtype=dtype, seed=seed)
+    q = QuantLinear(4, 128, K, N, False, weight_dtype=dtype)
+    q.qweight, q.qzeros, q.scales, q.g_idx = L["qweight"].clone(), L["qzeros"].clone(), L["scales"].clone(), L["g_idx"].clone()
+    q = q.to(DEV)
+    q.post_init()
+    W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], 4, O.reference_zero_mode(False, 4))
+    return q, W.to(DEV)
+
+
+def _assert_all_outputs(y, xd, W, dtype, what):
+    ref = xd.double() @ W.double()
+    rtol, atol = TOL[dtype]
+    scale = max(1e-6, float(ref.abs().max()))
+    diff = (y.double() - ref).abs()
+    bad = diff > atol * scale + rtol * ref.abs()
+    nbad = int(bad.sum())
+    if nbad:
+        idx = torch.nonzero(bad)[0].tolist()
+        raise AssertionError(f"{what}: {nbad}/{bad.numel()} outputs out of tolerance, first at [{idx[0]}, {idx[1]}], max abs diff "
+                             f"{float(diff.max())} (scale {scale})")
+    CHECKED["cases"] += 1
+    CHECKED["outputs"] += y.numel()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("group", ["qkv", "gate_up"])
+def test_headline_forward_multi_full_size(group, dtype):
+    """The two multi-layer launches bench.py's headline times -- gptq_forward_multi on q|k|v (3 x 4096 -> 4096) and on gate|up
+    (2 x 4096 -> 11008) -- at their real size: EVERY output of EVERY layer against x (fp64) @ W_oracle (fp64), a one-hot row returning the
+    oracle's exact weight row, bit-reproducible, and the same again replayed from a captured hipGraph (what the bench times).
+    The three / two layers are DIFFERENT random layers, so a strip that lands in the wrong layer or column cannot cancel out."""
+    from autogptq_amd.qlinear_mi355x import forward_multi
+
+    K, N, n = (4096, 4096, 3) if group == "qkv" else (4096, 11008, 2)
+    layers, Ws = [], []
+    for i in range(n):
+        q, W = _plain_layer(K, N, dtype, seed=1000 + 17 * i + N // 64)
+        layers.append(q)
+        Ws.append(W)
+    for M in (1, 2, 4):
+        gen = torch.Generator().manual_seed(M * 11 + n)
+        x = (torch.rand(M, K, generator=gen) - 0.5).to(dtype)
+        hot_k = (K - 1, 129, 0, 2047)[:M]
+        if M > 1:                                                           # row M-1 one-hot (M = 1 keeps its dense row)
+            x[M - 1].zero_()
+            x[M - 1, hot_k[M - 1]] = 1.0
+        xd = x.to(DEV)
+        with torch.no_grad():
+            ys = forward_multi(layers, xd)
+            ys2 = forward_multi(layers, xd)
+        for i in range(n):
+            assert ys[i].shape == (M, N) and ys[i].dtype == dtype
+            assert torch.equal(ys[i], ys2[i]), f"{group}[{i}] M={M}: not bit-reproducible"
+            if M > 1:
+                assert torch.equal(ys[i][M - 1], Ws[i][hot_k[M - 1]]), f"{group}[{i}] M={M}: one-hot row is not the oracle's weight row"
+            _assert_all_outputs(ys[i], xd, Ws[i], dtype, f"forward_multi {group}[{i}] {K}x{N} M={M} {dtype}")
+        # the same launch replayed from a hipGraph, on fresh x (the graph holds the pointers: x is rewritten in place)
+        xs = xd.clone()
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s), torch.no_grad():
+            forward_multi(layers, xs)                                       # workspace of this stream allocated before capture
+            s.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                yg = forward_multi(layers, xs)
+        for rep in range(3):
+            xs.copy_((torch.rand(M, K, generator=gen) - 0.5).to(dtype))
+            g.replay()
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                ye = forward_multi(layers, xs)
+            for i in range(n):
+                assert torch.equal(yg[i], ye[i]), f"{group}[{i}] M={M}: graph replay {rep} differs from the eager call"
+            if rep == 0:
+                for i in range(n):
+                    _assert_all_outputs(yg[i], xs, Ws[i], dtype, f"forward_multi graph replay {group}[{i}] M={M} {dtype}")
+    del layers, Ws
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_headline_mlp_forward_full_size_with_intermediate(dtype):
+    """The default gptq_mlp_forward (gate | up in one launch, SiLU * mul, down) on the Llama-7B MLP 4096 -> 11008 -> 4096: the INTERMEDIATE
+    silu(g) * u (read back from the call's staging buffer at the front of the workspace body) is checked entry by entry against the fp64 oracle
+    products of gate and up -- a handful of wrong gate / up columns cannot hide in the down projection's tolerance -- and the final
+    output against down applied, in fp64, to the intermediate the kernel really produced."""
+    from autogptq_amd import _lib
+    from autogptq_amd import qlinear_mi355x as qm
+
+    K, I = 4096, 11008
+    gate, Wg = _plain_layer(K, I, dtype, seed=2001)
+    up, Wu = _plain_layer(K, I, dtype, seed=2002)
+    down, Wd = _plain_layer(I, K, dtype, seed=2003)
+    esz = 2
+    for M in (1, 4, 16):
+        gen = torch.Generator().manual_seed(M + 5)
+        xd = ((torch.rand(M, K, generator=gen) - 0.5) * 4).to(dtype).to(DEV)      # |gate| up to ~1: the SiLU is exercised off its linear part
+        with torch.no_grad():
+            y = qm.mlp_forward(gate, up, down, xd)
+            y2 = qm.mlp_forward(gate, up, down, xd)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2), "mlp_forward: not bit-reproducible"
+        ws = qm._WORKSPACE[(torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))][0]
+        h = ws[_lib.WS_HEADER_BYTES:_lib.WS_HEADER_BYTES + M * I * esz].view(dtype).reshape(M, I).clone()
+        g64 = xd.double() @ Wg.double()
+        u64 = xd.double() @ Wu.double()
+        href = torch.nn.functional.silu(g64) * u64
+        rtol, atol = TOL[dtype]
+        scale = max(1e-6, float(href.abs().max()))
+        # silu(g) * u from fp32 sums rounded once to the layer dtype: the product of two results each within (rtol, atol) of its reference
+        bad = (h.double() - href).abs() > 2 * atol * scale + 2 * rtol * href.abs()
+        assert not bool(bad.any()), (f"mlp intermediate M={M} {dtype}: {int(bad.sum())}/{bad.numel()} entries out of tolerance, first at "
+                                      f"{torch.nonzero(bad)[0].tolist()}")
+        CHECKED["cases"] += 1
+        CHECKED["outputs"] += h.numel()
+        _assert_all_outputs(y, h, Wd, dtype, f"mlp_forward down M={M} {dtype}")
+    del gate, up, down
