@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPTQ_MI355X_LIB", os.path.join(_HERE, "libgptq_mi355x.so"))
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 GPTQ_F16, GPTQ_BF16, GPTQ_F32 = 0, 1, 2
 ZERO_WRAP, ZERO_NOWRAP = 0, 1
@@ -27,7 +27,7 @@ EXPORTS = (
     "gptq_abi_version", "gptq_last_error", "gptq_status_string", "gptq_workspace_bytes", "gptq_workspace_bytes_ex",
     "gptq_forward", "gptq_forward_ex", "gptq_gemv", "gptq_gemm", "gptq_dequant",
     "gptq_unpack_weights", "gptq_unpack_zeros", "gptq_pack_weights", "gptq_pack_zeros",
-    "gptq_make_sequential", "gptq_resequence_qweight", "gptq_permute_columns",
+    "gptq_make_sequential", "gptq_resequence_qweight", "gptq_permute_columns", "gptq_prepack_decode", "gptq_prepack_decode_bytes",
     "gptq_awq_unpack", "gptq_awq_repack", "gptq_describe_plan",
     "gptq_init", "gptq_workspace_bytes_max", "gptq_validate_g_idx",
     "gptq_forward_multi", "gptq_workspace_bytes_multi", "gptq_forward_multi_ex", "gptq_workspace_bytes_multi_ex",
@@ -35,6 +35,7 @@ EXPORTS = (
     "gptq_mlp_forward", "gptq_mlp_forward_ex", "gptq_workspace_bytes_mlp", "gptq_workspace_bytes_mlp_ex", "gptq_describe_mlp_plan",
 )
 WS_HEADER_BYTES = 65536
+STRIP_COLS = 16          # GPTQ_STRIP_COLS: columns per strip of the decode copy (gptq_prepack_decode)
 
 
 class GptqLayer(Structure):
@@ -43,7 +44,8 @@ class GptqLayer(Structure):
         ("K", c_int32), ("N", c_int32), ("bits", c_int32), ("group_size", c_int32),
         ("dtype", c_int32), ("zero_mode", c_int32),
         ("qweight_seq", c_void_p), ("perm", c_void_p),
-        ("epilogue", c_int32), ("reserved_", c_int32),
+        ("epilogue", c_int32), ("tiled_cols", c_int32),
+        ("qweight_tiled", c_void_p), ("qconst_tiled", c_void_p),
     ]
 
 
@@ -116,6 +118,8 @@ def load() -> ctypes.CDLL:
     lib.gptq_make_sequential.argtypes = [c_void_p, c_int, c_int, c_void_p, POINTER(c_int)]
     lib.gptq_resequence_qweight.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.gptq_permute_columns.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.gptq_prepack_decode_bytes.argtypes = [POINTER(GptqLayer), POINTER(c_size_t), POINTER(c_size_t)]
+    lib.gptq_prepack_decode.argtypes = [POINTER(GptqLayer), c_void_p, c_void_p, c_void_p]
     lib.gptq_describe_plan.argtypes = [POINTER(GptqLayer), c_int, POINTER(GptqTuning), c_char_p, c_size_t]
     lib.gptq_awq_unpack.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.gptq_awq_repack.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
@@ -155,8 +159,12 @@ def _bind_fastcall(lib) -> None:
     except ImportError:
         fast = None
         return
-    _fastcall.bind(ctypes.cast(lib.gptq_forward_ex, c_void_p).value, ctypes.cast(lib.gptq_forward_multi_ex, c_void_p).value,
-                   ctypes.cast(lib.gptq_mlp_forward, c_void_p).value)
+    try:
+        _fastcall.bind(ctypes.cast(lib.gptq_forward_ex, c_void_p).value, ctypes.cast(lib.gptq_forward_multi_ex, c_void_p).value,
+                       ctypes.cast(lib.gptq_mlp_forward, c_void_p).value)
+    except TypeError:          # a _fastcall.so built from an older revision (two-argument bind): use ctypes rather than fail the load
+        fast = None
+        return
     fast = _fastcall
 
 

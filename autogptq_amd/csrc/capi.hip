@@ -46,6 +46,9 @@ int check_layer(const gptq_layer_t* L) {
     if (L->group_size <= 0) return fail(GPTQ_ERR_SHAPE, "group_size must be > 0 (resolve -1 to in_features), got %d", L->group_size);
     if ((L->qweight_seq == nullptr) != (L->perm == nullptr))
         return fail(GPTQ_ERR_NULL, "qweight_seq and perm must be given together");
+    if ((L->qweight_tiled != nullptr) != (L->tiled_cols != 0) || (L->qweight_tiled != nullptr) != (L->qconst_tiled != nullptr) ||
+        (L->tiled_cols != 0 && L->tiled_cols != GPTQ_STRIP_COLS))
+        return fail(GPTQ_ERR_UNSUPPORTED, "qweight_tiled, qconst_tiled and tiled_cols (%d) must be given together, tiled_cols = %d", L->tiled_cols, GPTQ_STRIP_COLS);
     if (L->epilogue != GPTQ_EPI_NONE && L->epilogue != GPTQ_EPI_SILU_MUL)
         return fail(GPTQ_ERR_UNSUPPORTED, "unknown epilogue %d", L->epilogue);
     if (L->epilogue == GPTQ_EPI_SILU_MUL && L->N % 64)
@@ -120,6 +123,16 @@ bool want_stream(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
         if (s64.ok && s64.pays && s64.ksplit == 1) return false;
     }
     return stream_preferred(*L, M);
+}
+
+// Decode from the strip-major side copy (gemv_tiled.hip): plain 4-bit fp16 / bf16 layers that carry qweight_tiled, M <= 4.  tuning.path = 8 forces it
+// ("does not fit" is then an error), any other explicit path keeps the checkpoint-layout kernels (A/B runs).
+bool want_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* t) {
+    if (M > 4 || n < 1 || n > 4) return false;
+    if (t && t->path != 0 && t->path != 8) return false;
+    for (int i = 0; i < n; ++i)
+        if (Ls[i]->g_idx != nullptr) return false;                 // act-order layers: the tiled copy holds qweight_seq; x has to be permuted first (not wired yet)
+    return plan_tiled(Ls, n, M, t).ok;
 }
 
 // act-order layers on the streamed GEMV: x permuted once by the column-permute pre-pass, the kernel streams the re-sequenced rows of a
@@ -207,6 +220,10 @@ static size_t body_bytes(const gptq_layer_t* L, int M, const gptq_tuning_t* tune
     GemmPlan g = plan_gemm(*L, M, tune);
     size_t b = g.supported ? g.workspace_bytes : 0;
     size_t c = 0;
+    {
+        const gptq_layer_t* one[1] = {L};
+        if (want_tiled(one, 1, M, tune)) return plan_tiled(one, 1, M, tune).partial_bytes;
+    }
     if (want_stream(L, M, tune)) {
         const gptq_layer_t* one[1] = {L};
         c = plan_stream(one, 1, M, tune).partial_bytes;
@@ -238,6 +255,7 @@ int gptq_init(void) {
     if (e == hipSuccess) e = init_gemv_device();
     if (e == hipSuccess) e = init_mlp_device();
     if (e == hipSuccess) e = init_gemm_mid_device();
+    if (e == hipSuccess) e = init_gemv_tiled_device();
     if (e != hipSuccess) return hip_fail(e, "gptq_init (hipFuncSetAttribute)");
     return GPTQ_OK;
 }
@@ -316,11 +334,32 @@ static int stream_call(const gptq_layer_t* const* Ls, int n, const StreamPlan& s
     return GPTQ_OK;
 }
 
+static int tiled_call(const gptq_layer_t* const* Ls, int n, const void* x, void* const* outs, int M, const WsView& wv, void* stream, const gptq_tuning_t* tune) {
+    const TiledPlan tp = plan_tiled(Ls, n, M, tune);
+    if (tp.partial_bytes > 0 && wv.body_bytes < tp.partial_bytes)
+        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + tp.partial_bytes, wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0);
+    hipError_t e = launch_tiled(Ls, tp, x, outs, M, wv.header, wv.body, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq strip-major decode launch (was gptq_init() called on this device?)");
+    return GPTQ_OK;
+}
+
 static int forward_impl(const gptq_layer_t* L, const void* x, void* out, int M, const WsView& wv, void* stream,
                         const gptq_tuning_t* tune) {
     int rc = check_layer(L);
     if (rc) return rc;
     const size_t have = wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0;
+    if (L->epilogue == GPTQ_EPI_NONE) {
+        const gptq_layer_t* one[1] = {L};
+        if (want_tiled(one, 1, M, tune)) {
+            rc = check_io(x, out, M);
+            if (rc) return rc;
+            void* outs[1] = {out};
+            return tiled_call(one, 1, x, outs, M, wv, stream, tune);
+        }
+        if (tune && tune->path == 8)
+            return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: the decode-copy kernel needs M <= 4 and a plain 4-bit fp16/bf16 layer that carries qweight_tiled / qconst_tiled "
+                                              "(gptq_prepack_decode; tiled_cols = %d)", GPTQ_STRIP_COLS);
+    }
     if (L->epilogue != GPTQ_EPI_NONE && !fused_epilogue_ok(L, M, tune)) {
         rc = check_io(x, out, M);
         if (rc) return rc;
@@ -416,6 +455,10 @@ size_t gptq_workspace_bytes_multi_ex(const gptq_layer_t* const* layers, int n_la
         const Stream64Plan sp = plan_stream64(layers, n_layers, M, tune);
         return sp.partial_bytes ? WS_HEADER_BYTES + sp.partial_bytes : 0;
     }
+    if (want_tiled(layers, n_layers, M, tune) && multi_preferred(layers, n_layers, M)) {
+        const TiledPlan tp = plan_tiled(layers, n_layers, M, tune);
+        return tp.partial_bytes ? WS_HEADER_BYTES + tp.partial_bytes : 0;
+    }
     if (n_layers <= 4) {
         const StreamPlan sp = plan_stream(layers, n_layers, M, tune);
         if (sp.ok && multi_preferred(layers, n_layers, M)) return sp.partial_bytes ? WS_HEADER_BYTES + sp.partial_bytes : 0;
@@ -457,6 +500,9 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
         if (e != hipSuccess) return hip_fail(e, "gptq batched-decode launch (needs > 64 KiB of LDS: was gptq_init() called on this device?)");
         return GPTQ_OK;
     }
+    if (want_tiled(layers, n_layers, M, tune) && (multi_preferred(layers, n_layers, M) || (tune && tune->path == 8)))
+        return tiled_call(layers, n_layers, x, outs, M, wv, stream, tune);
+    if (tune && tune->path == 8) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: these layers do not fit one strip-major decode launch (1..4 plain 4-bit layers with qweight_tiled, M <= 4)");
     if (n_layers <= 4 && M <= 4) {
         const StreamPlan sp = plan_stream(layers, n_layers, M, tune);
         if (sp.ok && multi_preferred(layers, n_layers, M)) return stream_call(layers, n_layers, sp, x, outs, M, wv, stream);
@@ -657,6 +703,43 @@ int gptq_resequence_qweight(const uint32_t* qweight, const int32_t* perm, int K,
     return GPTQ_OK;
 }
 
+// the layer as the decode copy sees it: plain 4-bit, source rows = qweight_seq when the layer has one
+static int decode_copy_source(const gptq_layer_t* L, gptq_layer_t* S) {
+    int rc = check_layer(L);
+    if (rc) return rc;
+    *S = *L;
+    S->qweight_tiled = (const uint32_t*)(uintptr_t)16;       // placeholders: tiled_layer_ok() only asks whether the copy COULD exist
+    S->qconst_tiled = (const void*)(uintptr_t)16;
+    S->tiled_cols = GPTQ_STRIP_COLS;
+    S->epilogue = GPTQ_EPI_NONE;                             // a [gate | up] layer with the fused epilogue has no decode copy of its own (its halves do)
+    if (L->epilogue != GPTQ_EPI_NONE || !tiled_layer_ok(*S))
+        return fail(GPTQ_ERR_UNSUPPORTED, "the decode copy needs a plain 4-bit fp16/bf16 layer, group_size %% 32 == 0 with group_size / 32 a power of two (or group_size >= K), "
+                                          "and no raw act-order g_idx (bits=%d dtype=%d group_size=%d)", L->bits, L->dtype, L->group_size);
+    return GPTQ_OK;
+}
+
+int gptq_prepack_decode_bytes(const gptq_layer_t* L, size_t* tiled_bytes, size_t* const_bytes) {
+    if (tiled_bytes) *tiled_bytes = 0;
+    if (const_bytes) *const_bytes = 0;
+    if (!tiled_bytes || !const_bytes) return fail(GPTQ_ERR_NULL, "tiled_bytes/const_bytes must be non-NULL");
+    gptq_layer_t S;
+    if (int rc = decode_copy_source(L, &S)) return rc;
+    *tiled_bytes = (size_t)((L->K + 127) / 128) * 1024 * (size_t)(L->N / GPTQ_STRIP_COLS);
+    *const_bytes = (size_t)((L->K + L->group_size - 1) / L->group_size) * 48 * (size_t)(L->N / GPTQ_STRIP_COLS);
+    return GPTQ_OK;
+}
+
+int gptq_prepack_decode(const gptq_layer_t* L, uint32_t* tiled_out, void* const_out, void* stream) {
+    if (!tiled_out || !const_out) return fail(GPTQ_ERR_NULL, "qweight_tiled_out/qconst_tiled_out must be non-NULL");
+    gptq_layer_t S;
+    if (int rc = decode_copy_source(L, &S)) return rc;
+    const uint32_t* src = L->qweight_seq ? L->qweight_seq : L->qweight;
+    if (tiled_out == src || tiled_out == L->qweight) return fail(GPTQ_ERR_UNSUPPORTED, "gptq_prepack_decode does not work in place (the checkpoint tensors are never rewritten)");
+    hipError_t e = launch_prepack_decode(src, L->qzeros, L->scales, L->K, L->N, L->group_size, L->zero_mode, tiled_out, const_out, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_prepack_decode launch");
+    return GPTQ_OK;
+}
+
 int gptq_permute_columns(const void* x, const int32_t* perm, int M, int K, int dtype, void* x_out, void* stream) {
     if (!x || !perm || !x_out) return fail(GPTQ_ERR_NULL, "x/perm/x_out must be non-NULL");
     if (!dtype_ok(dtype)) return fail(GPTQ_ERR_UNSUPPORTED, "unsupported dtype enum %d", dtype);
@@ -680,7 +763,12 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
         tune = inner_tuning(L, M, tune, &local);
     }
     gptq_layer_t Pseq;
-    if (!unfused_epilogue && want_stream_seq(L, M, tune, &Pseq)) {
+    const gptq_layer_t* one_t[1] = {&Lc};
+    if (!unfused_epilogue && Lc.epilogue == GPTQ_EPI_NONE && want_tiled(one_t, 1, M, tune)) {
+        const TiledPlan tp = plan_tiled(one_t, 1, M, tune);
+        snprintf(out, out_bytes, "path=gemv kernel=tiled ln=4 waves=%d u=%d ksplit=%d mt=%d strips=%d pair=0 perm=0 epilogue=none", tp.waves, tp.u, tp.ksplit, tp.mt,
+                 tp.strips_total);
+    } else if (!unfused_epilogue && want_stream_seq(L, M, tune, &Pseq)) {
         const gptq_layer_t* one[1] = {&Pseq};
         const StreamPlan sp = plan_stream(one, 1, M, nullptr);
         snprintf(out, out_bytes, "path=gemv kernel=stream ln=%d waves=%d u=%d ksplit=%d mt=%d strips=%d pair=0 perm=2 epilogue=none", sp.ln, sp.waves,

@@ -1,0 +1,325 @@
+// gemv_tiled.hip -- decode (M <= 4) from the load-time DECODE COPY of a 4-bit layer (round 4).
+//
+// What the reference does at load time in every fast backend -- exllamav2 shuffle_kernel (autogptq_extension/exllamav2/cuda/q_matrix.cu:19-42,
+// called from :149), exllama make_sequential (exllama/cuda_func/q4_matrix.cu:105-169), Marlin gptq_repack + its scale permutation
+// (marlin/marlin_repack.cu:8-92, qlinear_marlin.py:133-176) -- is a re-layout of the packed weights for the kernel that streams them.  Here the
+// re-layout goes into NON-PERSISTENT side buffers (gptq_prepack_decode, csrc/utils.hip); the checkpoint tensors stay intact:
+//
+//   qweight_tiled  [strip s = 16 output columns][chunk c = 16 packed rows = 128 k][k-slot kb = 0..3][column 0..15][word w = 0..3]
+//                  word (c, kb, col, w) = nibble_shuffle( qweight[16 c + 4 kb + w][16 s + col] ),  stored nibbles = k0 k2 k4 k6 k1 k3 k5 k7
+//                  -> a strip is ONE contiguous run; a chunk is one contiguous KiB = one wave load; LANE (kb, col) of that load holds 4 consecutive
+//                  packed rows (32 k) of ONE column; the magic-number extraction (q & 0x000f000f etc.) yields the k pairs (k0,k1)(k2,k3)(k4,k5)(k6,k7),
+//                  the order x lies in memory (no v_perm on the activations).  Rows past K/8 are zero words (whole chunks).
+//   qconst_tiled   [strip][group g][48 bytes] = 16 scales (layer dtype) + 16 one-byte zero-points AS USED (zero_mode applied): the constants of a
+//                  strip are one contiguous run (1.5 KiB for K = 4096, g128) instead of 32-byte / 8-byte pieces of row-major [G, N] arrays.
+//
+// tools/membench2.hip (profiles/r04_membench_stripmajor.log): reading the same bytes as contiguous strips instead of 64-byte row segments 16 KiB apart
+// takes 2.74 instead of 3.40 us (4096^2), 4.93 / 6.75 (11008x4096), 5.13 / 6.82 (q|k|v), 8.09 / 11.14 (gate|up) -- the rate of a flat stream.
+// tools/declab.hip (profiles/r04_declab_*.log) then compared lane decompositions on that stream: 4 columns x 1 row per lane (every row its own group:
+// a constant set per 32 weights, x re-read from L2 per row) against this one, us per launch: 4.37 -> 4.13, 7.90 -> 6.84, 8.12 -> 6.95, 12.95 -> 10.70.
+//
+// Kernel (one strip, or one K slice of it, per workgroup; W waves x U chunks in flight per wave):
+//   * x (M rows, the slice's k range) and the strip's constants go global -> LDS by DMA FIRST (they return first), the wave's U weight loads behind them;
+//     one barrier, by which time the weights are in flight;
+//   * per chunk and lane: 16 bytes of weights (registers, nontemporal), x fragments by 4 ds_read_b128 (lane i of a 4-lane group reads x row i: the A
+//     operand of v_mfma_f32_4x4x4), scale + zero-point by ds_read_u16 / ds_read_u8; w - z exactly in packed fp16, 8 matrix-core steps into one fp32
+//     group sum, times the scale: the arithmetic of every other decode kernel here (one-hot rows return the reference's exact scales * (w - z));
+//   * a lane owns ONE column: k-slots by two shuffles, waves through LDS, K slices through {fp32, tag} granules (stream_finish, gemv_shared.cuh);
+//   * up to four layers that share x in one launch (gptq_forward_multi).
+#include "gemv_shared.cuh"
+
+namespace gptq {
+
+// Kernel arguments, laid out for a short prologue: everything a workgroup needs to find its layer sits in the first bytes (loaded with the other scalars
+// at kernel entry), the layer's pointers are ONE dependent scalar load.  (The first version walked GemvStreamParams::seg[] with a dependent kernarg load per
+// step and divided by ksplit: ~230 instructions and five scalar-load round trips before the first weight load, ~1 us per launch against the lab kernel.)
+struct TiledSeg {
+    const unsigned* tq;      // qweight_tiled
+    const void* cst;         // qconst_tiled
+    const void* bias;
+    void* out;
+    int N, col0;             // columns of this layer; its first column in the concatenated partial slab
+    int pad_[2];
+};
+struct TiledParams {
+    int blk_end[4];          // cumulative strip count up to and including layer i (unused entries: INT_MAX)
+    const void* x;
+    unsigned long long* gran;   // K-split exchange granules (stream_finish)
+    unsigned* epochs;
+    unsigned* err;
+    int nseg, M, K, chunks, chunks_per_split, ksplit, gu_shift, nsum, groups, xstride, waves;
+    unsigned max_spins;
+    TiledSeg seg[4];
+};
+
+template <int MT, int U, typename T, int MAXW>
+__global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_q4_tiled_kernel(TiledParams p) {
+    constexpr bool BF = std::is_same_v<T, bf16>;
+    unsigned m_lo, m_hi, magic;                                                   // opaque constants: (q & mask) | magic is ONE v_and_or_b32 (gemv.hip)
+    asm("s_mov_b32 %0, 0x000f000f" : "=s"(m_lo));
+    asm("s_mov_b32 %0, 0x00f000f0" : "=s"(m_hi));
+    asm("v_mov_b32 %0, 0x64006400" : "=v"(magic));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                    // scalar: the staging loops below are scalar loops
+    const int col = lane & 15, kb = lane >> 4;                                    // lane = kb * 16 + col: lane-linear inside the chunk
+    // every scalar argument in ONE batch of kernarg loads (the empty asm pins them here: left to itself the compiler loads them one dependent step at a time)
+    int ksplit = p.ksplit, be0 = p.blk_end[0], be1 = p.blk_end[1], be2 = p.blk_end[2], nchunks = p.chunks, cps = p.chunks_per_split, K = p.K, Mrows = p.M,
+        G = p.groups, xstride = p.xstride, gshift = p.gu_shift, W = p.waves;
+    const char* xg = (const char*)p.x;
+    asm volatile("" : "+s"(ksplit), "+s"(be0), "+s"(be1), "+s"(be2), "+s"(nchunks), "+s"(cps), "+s"(K), "+s"(Mrows), "+s"(G), "+s"(xstride), "+s"(gshift), "+s"(W), "+s"(xg));
+    // workgroup -> (strip over all layers, K slice); no XCD remap: strips share nothing but x, which every L2 holds
+    int sidx = blockIdx.x, ks = 0;
+    if (ksplit != 1) { sidx = (int)blockIdx.x / ksplit; ks = (int)blockIdx.x - sidx * ksplit; }      // uniform branch: the division only where slices exist
+    const int s = (sidx >= be0) + (sidx >= be1) + (sidx >= be2);                  // scalar compares on entry-loaded words
+    const TiledSeg sg = p.seg[s];                                                 // one dependent kernarg load
+    const int strip = sidx - (s == 0 ? 0 : (s == 1 ? be0 : (s == 2 ? be1 : be2)));
+    const int N = sg.N;
+    const int cb = ks * cps, ce = min(cb + cps, nchunks);                         // this slice's chunks
+    const int kbeg = cb * 128, kend = min(ce * 128, K);                          // ... and its k range: what is staged of x
+    // LDS: [x: MT rows of (kend - kbeg) values, row stride + 16 B][constants: G x 48 B][cross-wave sums]
+    char* const xs = smem;                                                        // row stride xstride = chunks_per_split * 256 + 16 bytes: the 4 rows of a 4-lane group hit different banks
+    char* const cs = smem + (size_t)MT * xstride;
+    float* const red = (float*)(cs + (size_t)G * 48);
+    const char* const cg = (const char*)sg.cst + (size_t)strip * G * 48;          // this strip's constants: one contiguous run
+    const char* const tb = (const char*)(sg.tq + (size_t)strip * nchunks * 256);  // this strip's weights: one contiguous run
+    const unsigned t_lane = (unsigned)lane * 16u;
+    // ---- stage x and the constants by LDS DMA: no VGPRs, issued FIRST (loads return in issue order), waited for behind the first weight burst
+    {
+        const unsigned xs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)xs, cs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cs;
+        const int pieces = (kend - kbeg) >> 3;                                    // 16-byte pieces per x row
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const char* xr = xg + ((size_t)min(m, Mrows - 1) * K + kbeg) * 2;
+            for (int pc0 = wave * 64; pc0 < pieces; pc0 += W * 64)                // wave-uniform trip count
+                if (pc0 + lane < pieces) lds_dma16(xr + (size_t)(pc0 + lane) * 16, xs_lds + m * xstride + pc0 * 16);      // default cache policy: every workgroup reads x
+        }
+        const int cpieces = G * 3;
+        for (int pc0 = wave * 64; pc0 < cpieces; pc0 += W * 64)
+            if (pc0 + lane < cpieces) dma16_nt(cg + (size_t)(pc0 + lane) * 16, __builtin_amdgcn_readfirstlane(cs_lds + pc0 * 16));
+    }
+    const char* const xl = xs + (size_t)min(lane & 3, MT - 1) * xstride + kb * 64;    // A operand: lane i of a 4-lane group carries x row i
+    float acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+    const f16x2 k960 = {(f16)960.f, (f16)960.f};
+    const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+    bool staged = false;
+    for (int cbase = cb; cbase < ce; cbase += W * U) {
+        const int c0 = cbase + wave * U;
+        u32x4 q[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) q[j] = __builtin_nontemporal_load((const u32x4*)(tb + ((unsigned)min(c0 + j, ce - 1) * 1024u + t_lane)));
+        if (!staged) {                                                            // first pass only (uniform): the staging DMAs are OLDER than the U loads just issued
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(U) : "memory");
+            __syncthreads();
+            staged = true;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int cc = min(c0 + j, ce - 1);
+            const int k0 = cc * 128 + kb * 32;                                    // first k of this lane's 4 words
+            const bool live = (c0 + j < ce) && (k0 < K);                          // a ragged last chunk (K % 128 != 0): whole k-slots are missing
+            const int g = min(k0 >> 5 >> gshift, G - 1);
+            const char* cp = cs + g * 48;
+            const unsigned short sraw = *(const unsigned short*)(cp + col * 2);
+            const unsigned z = *(const unsigned char*)(cp + 32 + col);
+            u32x4 xa[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) xa[w] = *(const u32x4*)(xl + ((unsigned)(cc - cb) * 256u + w * 16u));
+            const f16x2 c1 = as_f16x2(z * 0x00010001u + 0xE400E400u);            // -(1024 + z)
+            const f16x2 c2 = c1 + k960;                                           // -(64 + z)
+            const u32x4 qv = q[j];
+            f32x4 accg = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const unsigned qw = qv[w], q8 = qw >> 8;
+                const f16x2 h0 = as_f16x2((qw & m_lo) | magic) + c1;              // k0,k1  (stored nibbles 0 and 4)
+                const f16x2 h1 = as_f16x2((qw & m_hi) | magic) * r16 + c2;        // k2,k3  (1 and 5)
+                const f16x2 h2 = as_f16x2((q8 & m_lo) | magic) + c1;              // k4,k5  (2 and 6)
+                const f16x2 h3 = as_f16x2((q8 & m_hi) | magic) * r16 + c2;        // k6,k7  (3 and 7)
+                u32x2 b01, b23;
+                if constexpr (BF) {
+                    // fp16 -> fp32 -> bf16 per pair (exact: integers in [-16, 15]); gfx950 has no packed bf16 arithmetic
+                    auto to_bf = [&](f16x2 hv) -> unsigned {
+                        const bf16x2 o = {(bf16)(float)hv[0], (bf16)(float)hv[1]};
+                        return __builtin_bit_cast(unsigned, o);
+                    };
+                    b01 = u32x2{to_bf(h0), to_bf(h1)};
+                    b23 = u32x2{to_bf(h2), to_bf(h3)};
+                } else {
+                    b01 = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+                    b23 = u32x2{__builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
+                }
+                accg = Mma4<T>::run(u32x2{xa[w][0], xa[w][1]}, b01, accg);
+                accg = Mma4<T>::run(u32x2{xa[w][2], xa[w][3]}, b23, accg);
+            }
+            const float sc = DType<T>::to_f32(__builtin_bit_cast(T, sraw));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = live ? fmaf(sc, accg[m], acc[m]) : acc[m];   // a select, not a product by 0: a dead slot's x is whatever the LDS holds
+        }
+    }
+    // ---- k-slots (two shuffles: a lane owns one column), waves (LDS), then write / publish ---------------------------------------------------
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        float v = acc[m];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        acc[m] = v;
+    }
+    if (!staged) __syncthreads();                                                 // (an empty slice never took the staging barrier; the planner makes none)
+    constexpr int ES = MT * 16 + 4;
+    if (lane < 16) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) red[wave * ES + m * 16 + lane] = acc[m];
+    }
+    __syncthreads();
+    stream_finish<16, MT, T, TiledParams, TiledSeg>(p, sg, strip, sidx, ks, N, red);
+}
+
+// ---- plan + launch ---------------------------------------------------------------------------------------------------------------------
+bool tiled_layer_ok(const gptq_layer_t& L) {
+    if (!L.qweight_tiled || !L.qconst_tiled || L.tiled_cols != GPTQ_STRIP_COLS || L.epilogue != GPTQ_EPI_NONE || L.bits != 4) return false;
+    if (L.g_idx != nullptr && !(L.qweight_seq && L.perm)) return false;           // raw act-order: per-k groups
+    if (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16) return false;
+    if (L.K % 32 || L.N % GPTQ_STRIP_COLS) return false;
+    const int gu = L.group_size / 32;                                             // a lane's 32 k lie in one group
+    return L.group_size % 32 == 0 && (L.group_size >= L.K || (gu & (gu - 1)) == 0);
+}
+
+TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* tune) {
+    TiledPlan pl{};
+    if (n < 1 || n > 4 || M < 1 || M > 4) return pl;
+    const gptq_layer_t& A = *Ls[0];
+    int strips = 0, nsum = 0;
+    for (int i = 0; i < n; ++i) {
+        const gptq_layer_t& L = *Ls[i];
+        if (!tiled_layer_ok(L)) return pl;
+        if (L.K != A.K || L.group_size != A.group_size || L.dtype != A.dtype) return pl;
+        strips += L.N / GPTQ_STRIP_COLS;
+        nsum += L.N;
+    }
+    pl.nseg = n;
+    pl.mt = M >= 3 ? 4 : M;
+    const int chunks = (A.K + 127) / 128;
+    pl.chunks_total = chunks;
+    pl.strips_total = strips;
+    pl.nsum = nsum;
+    pl.groups = (A.K + A.group_size - 1) / A.group_size;
+    // K slices: narrow layers (TP shards: fewer than 128 strips) fill the chip with them, and a slice's part of x (MT rows) has to fit the LDS next to
+    // the constants -- combined inside the launch through granules (stream_finish)
+    int ks = (tune && tune->ksplit) ? tune->ksplit : 0;
+    if (!ks) {
+        ks = 1;
+        while (strips * ks < 128 && chunks / (ks * 2) >= 8) ks *= 2;
+    }
+    const size_t lds_cap = 96 * 1024;
+    auto lds_need = [&](int k_slices, int waves) {
+        const int cps = (chunks + k_slices - 1) / k_slices;
+        return (size_t)pl.mt * ((size_t)cps * 256 + 16) + (size_t)pl.groups * 48 + (size_t)waves * (pl.mt * 16 + 4) * sizeof(float) + 16;
+    };
+    while (ks < 8 && ks < chunks && lds_need(ks, 16) > lds_cap) ks *= 2;
+    if (ks > chunks) ks = chunks;
+    if (ks > 8) ks = 8;                                                           // the owner's poll is unrolled over at most 7 other slices
+    const int cps = (chunks + ks - 1) / ks;
+    pl.chunks_per_split = cps;
+    pl.ksplit = (chunks + cps - 1) / cps;                                         // no empty slices
+    if ((size_t)strips * 4 > WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES - WS_HEADER_EPOCH_OFFSET) return pl;   // one epoch word per strip
+    int waves, u;
+    if (tune && tune->waves && tune->reserved[0]) {
+        waves = tune->waves; u = tune->reserved[0];
+    } else {
+        // tools/tiled_sweep.py on MI355X (profiles/r04_tiled_sweep_*.log, us per launch, rotating HBM-cold layers in a hipGraph): one 16-wave workgroup per CU
+        // with 2 chunks per wave in flight for the <= 256-strip launches (4096^2 4.43, 11008x4096 7.41; 8 waves x 4: 4.50 / 7.68), 4 waves x 4 chunks where
+        // several workgroups share a CU (4096x11008 7.13, q|k|v 7.50, gate|up 11.11; 8 waves x 4: 7.69 / 8.21 / 12.44)
+        const int wgs = strips * pl.ksplit;
+        if (wgs <= 320) { waves = 16; u = 2; }
+        else { waves = 4; u = 4; }
+        while (waves > 1 && (waves / 2) * u >= cps) waves /= 2;
+    }
+    if (waves < 1 || waves > 16 || (u != 1 && u != 2 && u != 4 && u != 8)) return pl;
+    pl.waves = waves;
+    pl.u = u;
+    pl.xstride = cps * 256 + 16;
+    pl.lds_bytes = lds_need(pl.ksplit, waves);
+    if (pl.lds_bytes > 160 * 1024) return pl;
+    pl.partial_bytes = pl.ksplit > 1 ? (size_t)(pl.ksplit - 1) * M * nsum * 8 : 0;
+    pl.ok = true;
+    return pl;
+}
+
+// Two compilations per (MT, U, T): workgroups of up to 16 waves (<= 128 VGPRs) and of up to 8 waves.
+template <int MT, int U, typename T>
+static hipError_t launch_tiled_one(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
+    if (pl.waves > 8)
+        hipLaunchKernelGGL((gemv_q4_tiled_kernel<MT, U, T, 16>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+    else
+        hipLaunchKernelGGL((gemv_q4_tiled_kernel<MT, U, T, 8>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+    return hipGetLastError();
+}
+template <int MT, typename T>
+static hipError_t launch_tiled_u(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
+    switch (pl.u) {
+        case 1: return launch_tiled_one<MT, 1, T>(pl, p, st);
+        case 2: return launch_tiled_one<MT, 2, T>(pl, p, st);
+        case 4: return launch_tiled_one<MT, 4, T>(pl, p, st);
+        case 8: return launch_tiled_one<MT, 8, T>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+template <typename T>
+static hipError_t launch_tiled_mt(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
+    switch (pl.mt) {
+        case 1: return launch_tiled_u<1, T>(pl, p, st);
+        case 2: return launch_tiled_u<2, T>(pl, p, st);
+        case 4: return launch_tiled_u<4, T>(pl, p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_tiled(const gptq_layer_t* const* Ls, const TiledPlan& pl, const void* x, void* const* outs, int M, void* ws_header, void* ws_body,
+                        hipStream_t st) {
+    if (!pl.ok) return hipErrorInvalidValue;
+    TiledParams p{};
+    int blk = 0, col = 0;
+    for (int i = 0; i < 4; ++i) p.blk_end[i] = 0x7fffffff;
+    for (int i = 0; i < pl.nseg; ++i) {
+        const gptq_layer_t& L = *Ls[i];
+        blk += L.N / GPTQ_STRIP_COLS;
+        p.blk_end[i] = blk;
+        p.seg[i] = TiledSeg{L.qweight_tiled, L.qconst_tiled, L.bias, outs[i], L.N, col, {0, 0}};
+        col += L.N;
+    }
+    p.blk_end[3] = 0x7fffffff;                                                    // the selector adds three compares: a fourth layer is reached by the first three
+    const gptq_layer_t& A = *Ls[0];
+    p.x = x;
+    p.gran = (unsigned long long*)ws_body;
+    p.epochs = ws_header ? (unsigned*)((char*)ws_header + WS_HEADER_EPOCH_OFFSET) : nullptr;
+    p.err = ws_header ? (unsigned*)((char*)ws_header + WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES) + 2 : nullptr;
+    p.max_spins = 1u << 20;
+    p.nseg = pl.nseg; p.M = M; p.K = A.K;
+    p.chunks = pl.chunks_total; p.chunks_per_split = pl.chunks_per_split; p.ksplit = pl.ksplit;
+    p.gu_shift = A.group_size >= A.K ? 26 : __builtin_ctz((unsigned)(A.group_size / 32));   // group_size == K: every k maps to group 0
+    p.nsum = pl.nsum;
+    p.groups = pl.groups;
+    p.xstride = pl.xstride;
+    p.waves = pl.waves;
+    return A.dtype == GPTQ_BF16 ? launch_tiled_mt<bf16>(pl, p, st) : launch_tiled_mt<f16>(pl, p, st);
+}
+
+hipError_t init_gemv_tiled_device() {
+    hipError_t e = hipSuccess;
+    auto grant = [&](auto kern) { hipError_t r = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e == hipSuccess) e = r; };
+    // long K at 4 rows of x: the staged activations can pass the 64 KiB default
+    auto grant_mt = [&](auto mt) {
+        constexpr int MT = decltype(mt)::value;
+        grant(gemv_q4_tiled_kernel<MT, 1, f16, 16>); grant(gemv_q4_tiled_kernel<MT, 2, f16, 16>); grant(gemv_q4_tiled_kernel<MT, 4, f16, 16>); grant(gemv_q4_tiled_kernel<MT, 8, f16, 16>);
+        grant(gemv_q4_tiled_kernel<MT, 1, f16, 8>); grant(gemv_q4_tiled_kernel<MT, 2, f16, 8>); grant(gemv_q4_tiled_kernel<MT, 4, f16, 8>); grant(gemv_q4_tiled_kernel<MT, 8, f16, 8>);
+        grant(gemv_q4_tiled_kernel<MT, 1, bf16, 16>); grant(gemv_q4_tiled_kernel<MT, 2, bf16, 16>); grant(gemv_q4_tiled_kernel<MT, 4, bf16, 16>); grant(gemv_q4_tiled_kernel<MT, 8, bf16, 16>);
+        grant(gemv_q4_tiled_kernel<MT, 1, bf16, 8>); grant(gemv_q4_tiled_kernel<MT, 2, bf16, 8>); grant(gemv_q4_tiled_kernel<MT, 4, bf16, 8>); grant(gemv_q4_tiled_kernel<MT, 8, bf16, 8>);
+    };
+    grant_mt(std::integral_constant<int, 1>{}); grant_mt(std::integral_constant<int, 2>{}); grant_mt(std::integral_constant<int, 4>{});
+    return e;
+}
+
+}  // namespace gptq

@@ -241,6 +241,37 @@ __global__ void __launch_bounds__(256) resequence_kernel(const unsigned* __restr
     }
 }
 
+// ---- the decode copy of a 4-bit layer (layouts: include/gptq_mi355x.h, gptq_layer_t.qweight_tiled / qconst_tiled; consumer: gemv_tiled.hip) ----------
+// Load time only.  One workgroup = one 1 KiB chunk (16 packed rows x 16 columns): thread t reads word (row 4 kb + w, column col) with col = t & 15 fastest
+// (64-byte row pieces), shuffles its nibbles into pair order and writes it to slot (kb, col, w) of the chunk.
+// Stored nibble p holds source nibble {0, 2, 4, 6, 1, 3, 5, 7}[p]: (q & 0x000f000f) then picks (k0, k1), (q & 0x00f000f0) (k2, k3), and the same on q >> 8
+// (k4, k5), (k6, k7) -- the order x lies in memory.
+__device__ __forceinline__ unsigned nibble_pair_order(unsigned v) {
+    // even source nibbles k0 k2 k4 k6 -> stored nibbles 0..3, odd ones k1 k3 k5 k7 -> stored nibbles 4..7
+    const unsigned e = v & 0x0f0f0f0fu, o = (v >> 4) & 0x0f0f0f0fu;                  // bytes: k0,k2,k4,k6 / k1,k3,k5,k7 (one nibble per byte)
+    auto squeeze = [](unsigned b) { b = (b | (b >> 4)) & 0x00ff00ffu; return (b | (b >> 8)) & 0x0000ffffu; };   // 4 nibble-bytes -> 16 bits
+    return squeeze(e) | (squeeze(o) << 16);
+}
+__global__ void __launch_bounds__(256) prepack_decode_weights_kernel(const unsigned* __restrict__ q, int R, int N, int chunks, unsigned* __restrict__ out) {
+    const int c = blockIdx.x, s = blockIdx.y;
+    const int t = threadIdx.x, col = t & 15, w = (t >> 4) & 3, kb = t >> 6;
+    const int r = c * 16 + kb * 4 + w;
+    const unsigned v = r < R ? q[(size_t)r * N + s * 16 + col] : 0u;
+    out[((size_t)s * chunks + c) * 256 + kb * 64 + col * 4 + w] = nibble_pair_order(v);
+}
+// one thread = one (strip, group, column): 2 bytes of scale (bit copy) + 1 byte of zero-point as used
+__global__ void __launch_bounds__(256) prepack_decode_consts_kernel(const unsigned* __restrict__ qzeros, const unsigned short* __restrict__ scales, int G, int N,
+                                                                    int zero_mode, unsigned char* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (n >= N) return;
+    const int s = n >> 4, col = n & 15;
+    const unsigned f = (qzeros[(size_t)g * (N >> 3) + (n >> 3)] >> ((n & 7) * 4)) & 15u;
+    const unsigned z = zero_mode == GPTQ_ZERO_WRAP ? ((f + 1u) & 15u) : f + 1u;
+    unsigned char* rec = out + ((size_t)s * G + g) * 48;
+    *(unsigned short*)(rec + col * 2) = scales[(size_t)g * N + n];
+    rec[32 + col] = (unsigned char)z;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) permute_columns_kernel(const T* __restrict__ x, const int* __restrict__ perm, int M, int K,
                                                               T* __restrict__ out) {
@@ -329,6 +360,17 @@ hipError_t launch_pack_weights(const void* W, const void* scale_in, const void* 
 hipError_t launch_pack_zeros(const void* zero_in, int G, int N, int bits, int qparam_dtype, uint32_t* qzeros_out, hipStream_t st) {
     dim3 grid((N / unit_vals(bits) + 255) / 256, G), block(256);
     GPTQ_BITS_SWITCH(bits, hipLaunchKernelGGL(pack_zeros_kernel<B>, grid, block, 0, st, zero_in, G, N, qparam_dtype, qzeros_out));
+    return hipGetLastError();
+}
+
+hipError_t launch_prepack_decode(const uint32_t* qweight, const uint32_t* qzeros, const void* scales, int K, int N, int group_size, int zero_mode,
+                                 uint32_t* tiled_out, void* const_out, hipStream_t st) {
+    const int R = K / 8, chunks = (K + 127) / 128, G = (K + group_size - 1) / group_size;
+    hipLaunchKernelGGL(prepack_decode_weights_kernel, dim3(chunks, N / 16), dim3(256), 0, st, qweight, R, N, chunks, tiled_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(prepack_decode_consts_kernel, dim3((N + 255) / 256, G), dim3(256), 0, st, qzeros, (const unsigned short*)scales, G, N, zero_mode,
+                       (unsigned char*)const_out);
     return hipGetLastError();
 }
 

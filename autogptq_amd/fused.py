@@ -88,16 +88,24 @@ class _QKVPart(nn.Module):
         self._state = [state]                       # in a list: the shared state is not a submodule
         self.proj = state.layers[index]             # each stand-in owns its own projection: .to() / state_dict() keep working
 
+    @staticmethod
+    def _key(x):
+        # Inference tensors (torch.inference_mode(): what the reference's generate() runs under, auto_gptq/modeling/_base.py:415-418) do not
+        # track a version counter -- reading ._version raises there.  They cannot be modified in place outside inference mode either, so
+        # storage + shape + dtype identifies the activation for the three back-to-back projection calls.
+        ver = None if x.is_inference() else x._version
+        return (x.data_ptr(), tuple(x.shape), x.dtype, ver)
+
     def forward(self, x):
         from .qlinear_mi355x import forward_multi
         st = self._state[0]
         if self.index == 0:
-            st.src = (x.data_ptr(), tuple(x.shape), x.dtype, x._version)
+            st.src = self._key(x)
             st.parts = forward_multi(st.layers, x)
             return st.parts[0]
         # k_proj / v_proj: the same activation as q_proj saw?  Compared by storage, shape, dtype and version counter, not by object identity:
         # wrappers that re-wrap or move the input per call (accelerate's AlignDevicesHook, autocast) hand every projection its own tensor object.
-        same = st.parts is not None and st.src == (x.data_ptr(), tuple(x.shape), x.dtype, x._version)
+        same = st.parts is not None and st.src == self._key(x)
         if not same:                                # a different input (or q_proj was never called): this projection on its own
             st.src = st.parts = None
             return self.proj(x)

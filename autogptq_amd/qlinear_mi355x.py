@@ -86,6 +86,7 @@ def _is_sequential_g_idx(g_idx: torch.Tensor, group_size: int) -> bool:
 
 class QuantLinear(nn.Module):
     QUANT_TYPE = "mi355x"
+    TILED_DECODE = True       # post_init derives the strip-major side copy of qweight for the decode kernels (a second copy of the packed weights)
 
     def __init__(
         self,
@@ -144,6 +145,7 @@ class QuantLinear(nn.Module):
         # derived, non-persistent state (never part of state_dict; checkpoint tensors stay intact)
         self._layer = None            # ctypes GptqLayer
         self._keepalive = ()          # tensors the raw pointers in _layer refer to
+        self._qweight_tiled = self._qconst_tiled = None    # the decode copy (post_init), never part of state_dict
         self._ws_need = {}            # M -> workspace bytes
         self.act_order = None         # resolved by post_init
 
@@ -162,6 +164,7 @@ class QuantLinear(nn.Module):
                 del _MULTI[key]
         self._layer = None
         self._keepalive = ()
+        self._qweight_tiled = self._qconst_tiled = None
         self._ws_need = {}
 
     def _load_from_state_dict(self, *args, **kwargs):
@@ -180,7 +183,7 @@ class QuantLinear(nn.Module):
         return _lib.ZERO_WRAP
 
     # ------------------------------------------------------------------ post_init
-    def post_init(self, temp_dq=None):
+    def post_init(self, temp_dq=None, tiled=None):
         """Snapshot device pointers and, for act-order layers, derive the group-sorted copy of
         qweight plus the x permutation (side buffers; qweight itself is never modified -- the
         reference's exllama backends overwrite it in place, q4_matrix.cu:160)."""
@@ -237,7 +240,22 @@ class QuantLinear(nn.Module):
         L.qweight_seq = _lib.ptr(qweight_seq)
         L.perm = _lib.ptr(perm)
         L.epilogue = _lib.EPI_SILU_MUL if self.epilogue == "silu_mul" else _lib.EPI_NONE
-        L.reserved_ = 0
+        L.qweight_tiled = L.qconst_tiled = None
+        L.tiled_cols = 0
+        # Decode copy (plain 4-bit fp16 / bf16 layers): what exllamav2's shuffle / Marlin's repack do at load time (q_matrix.cu:19-42,149;
+        # marlin_repack.cu:8-92) -- into NON-PERSISTENT storage, the checkpoint tensors stay as they are.  Costs a second copy of the packed weights in
+        # HBM; QuantLinear.TILED_DECODE = False (or post_init(tiled=False)) turns it off.
+        qweight_tiled = qconst_tiled = None
+        if tiled is None:
+            tiled = self.TILED_DECODE
+        if tiled and self.bits == 4 and not self.act_order and self.epilogue == "none":
+            tb, cb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+            if lib.gptq_prepack_decode_bytes(ctypes.byref(L), ctypes.byref(tb), ctypes.byref(cb)) == 0:      # a layer that does not qualify simply has none
+                qweight_tiled = torch.empty(tb.value, dtype=torch.uint8, device=dev)
+                qconst_tiled = torch.empty(cb.value, dtype=torch.uint8, device=dev)
+                with torch.cuda.device(dev):
+                    _lib.check(lib.gptq_prepack_decode(ctypes.byref(L), qweight_tiled.data_ptr(), qconst_tiled.data_ptr(), _lib.current_stream_handle(dev)))
+                L.qweight_tiled, L.qconst_tiled, L.tiled_cols = qweight_tiled.data_ptr(), qconst_tiled.data_ptr(), _lib.STRIP_COLS
         self._layer = L
         self._layer_ref = ctypes.byref(L)
         self._layer_addr = ctypes.addressof(L)
@@ -247,7 +265,8 @@ class QuantLinear(nn.Module):
         self._dev = torch.device("cuda", self._dev_index)
         self._w_dtype = self.scales.dtype
         self._n_out = self.outfeatures // 2 if self.epilogue == "silu_mul" else self.outfeatures
-        self._keepalive = (self.qweight, self.qzeros, self.scales, self.g_idx, self.bias, qweight_seq, perm)
+        self._keepalive = (self.qweight, self.qzeros, self.scales, self.g_idx, self.bias, qweight_seq, perm, qweight_tiled, qconst_tiled)
+        self._qweight_tiled, self._qconst_tiled = qweight_tiled, qconst_tiled
         self._ws_need = {}
         return self
 

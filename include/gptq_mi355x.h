@@ -20,6 +20,11 @@
  *          exllamav2_kernels.make_q_matrix                            exllamav2/ext.cpp:26-93, cuda/q_matrix.cu:502-627
  *          column_remap_cuda                                          exllama/cuda_func/column_remap.cu:9-63
  *       (unlike those, never mutates qweight in place: results go to caller-owned side buffers)
+ *   gptq_prepack_decode / gptq_prepack_decode_bytes
+ *       <- the load-time weight re-layouts: exllamav2 shuffle_kernel   exllamav2/cuda/q_matrix.cu:19-42,149
+ *          exllama Q4Matrix::make_sequential's row rewrite             exllama/cuda_func/q4_matrix.cu:105-169
+ *          Marlin's repack kernel                                      marlin/marlin_repack.cu:8-92
+ *       (into a caller-owned side buffer; the checkpoint tensor stays as it is)
  *   gptq_pack_weights / gptq_pack_zeros
  *       <- QuantLinear.pack (CPU-only in the reference)               auto_gptq/nn_modules/qlinear/qlinear_cuda.py:108-203
  *   gptq_unpack_weights / gptq_unpack_zeros
@@ -64,7 +69,7 @@
 extern "C" {
 #endif
 
-#define GPTQ_MI355X_ABI_VERSION 5
+#define GPTQ_MI355X_ABI_VERSION 6
 #define GPTQ_WORKSPACE_HEADER_BYTES 65536
 
 typedef enum gptq_status_t {
@@ -107,8 +112,21 @@ typedef struct gptq_layer_t {
     const uint32_t *qweight_seq;  /* [K/32*bits, N] or NULL */
     const int32_t  *perm;         /* [K] or NULL */
     int32_t epilogue;             /* gptq_epilogue_t; with SILU_MUL `out` is [M, N/2] */
-    int32_t reserved_;            /* must be 0 */
+    int32_t tiled_cols;           /* GPTQ_STRIP_COLS when the two side buffers below are given, else 0 */
+    /* Optional derived (post_init) DECODE COPY of a 4-bit layer, built by gptq_prepack_decode (sizes: gptq_prepack_decode_bytes); both NULL = decode
+     * streams the checkpoint layout.  With W = qweight_seq when the layer has one (act-order), else qweight:
+     *   qweight_tiled [strip s of 16 columns][chunk c of 16 packed rows][k-slot kb 0..3][column 0..15][word w 0..3]
+     *                 = nibble_shuffle(W[16 c + 4 kb + w][16 s + col]), stored nibble order k0 k2 k4 k6 k1 k3 k5 k7; rows past K/8 are zero words
+     *                 (ceil(K / 128) whole chunks) -- a strip is one contiguous run, a chunk one contiguous KiB = one wave load, a lane of that load
+     *                 holds 32 consecutive k of ONE column;
+     *   qconst_tiled  [strip][group g][48 bytes] = 16 scales (layer dtype) + 16 uint8 zero-points AS USED (zero_mode applied).
+     * The reference re-lays its weights at load time in every fast backend (exllamav2 q_matrix.cu:19-42,149; exllama q4_matrix.cu:105-169;
+     * marlin_repack.cu:8-92 + the scale permutation of qlinear_marlin.py:133-176), in place; here the checkpoint tensors are left as they are. */
+    const uint32_t *qweight_tiled;
+    const void     *qconst_tiled;
 } gptq_layer_t;
+
+#define GPTQ_STRIP_COLS 16
 
 /* Optional launch-shape override for experiments; NULL / zero fields = built-in heuristic. */
 typedef struct gptq_tuning_t {
@@ -222,6 +240,15 @@ int gptq_validate_g_idx(const int32_t *g_idx_host, int K, int G);
 /* qweight_seq[row-order = perm] from qweight; device pointers. */
 int gptq_resequence_qweight(const uint32_t *qweight, const int32_t *perm, int K, int N, int bits,
                             uint32_t *qweight_seq_out, void *stream);
+/* The decode copy of a 4-bit layer (layouts: gptq_layer_t.qweight_tiled / qconst_tiled): exact integer re-arrangements of the packed nibbles, the
+ * scales (bit copies) and the zero-points (the value the kernels subtract, zero_mode applied), written to caller-owned buffers of
+ * gptq_prepack_decode_bytes() bytes.  Source: layer->qweight_seq when present, else layer->qweight; layer->qweight_tiled / qconst_tiled / tiled_cols
+ * are ignored.  Needs bits = 4, fp16 / bf16, group_size % 32 == 0 with a power-of-two group_size / 32 (or group_size >= K), no raw act-order;
+ * otherwise GPTQ_ERR_UNSUPPORTED (and sizes 0).  The role of the reference's load-time re-layouts -- exllamav2 shuffle_kernel
+ * (exllamav2/cuda/q_matrix.cu:19-42, called :149), exllama make_sequential (exllama/cuda_func/q4_matrix.cu:105-169), Marlin's repack kernel
+ * (marlin/marlin_repack.cu:8-92) -- without touching the checkpoint tensors. */
+int gptq_prepack_decode_bytes(const gptq_layer_t *layer, size_t *tiled_bytes, size_t *const_bytes);
+int gptq_prepack_decode(const gptq_layer_t *layer, uint32_t *qweight_tiled_out, void *qconst_tiled_out, void *stream);
 /* x_out[m, i] = x[m, perm[i]] */
 int gptq_permute_columns(const void *x, const int32_t *perm, int M, int K, int dtype, void *x_out, void *stream);
 

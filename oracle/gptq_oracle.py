@@ -350,3 +350,51 @@ def minmax_quantize(W: torch.Tensor, bits: int, group_size: int, g_idx=None, sym
         scale[:, gi] = s
         zero[:, gi] = torch.clamp(torch.round(-lo / s), 1, maxq) if not sym else torch.full_like(s, (maxq + 1) / 2)
     return scale, zero
+
+
+
+# --------------------------------------------------------------------------- #
+# The decode copy (gptq_prepack_decode, include/gptq_mi355x.h): restated so the tests can pin the device kernels to it.
+# Role in the reference: the load-time re-layouts of its fast backends (exllamav2 shuffle_kernel exllamav2/cuda/q_matrix.cu:19-42, Marlin's repack
+# marlin/marlin_repack.cu:8-92).  The layout is this library's own; what is pinned to the REFERENCE is that it is lossless: the reference's integer
+# unpack of the inverse equals its unpack of the checkpoint tensor, and the constants are the reference's scales / zero-points.
+# --------------------------------------------------------------------------- #
+_PAIR_ORDER = (0, 2, 4, 6, 1, 3, 5, 7)      # stored nibble p holds source nibble _PAIR_ORDER[p]
+
+
+def decode_copy_weights(qweight: torch.Tensor) -> torch.Tensor:
+    """int32 [K/8, N] -> int32 [N/16, chunks, 4 (k-slot), 16 (column), 4 (word)]: word (s, c, kb, col, w) = nibble_pair_order(qweight[16c + 4kb + w, 16s + col]),
+    rows past K/8 zero."""
+    q = qweight.cpu().numpy().astype(np.uint32) if isinstance(qweight, torch.Tensor) else np.asarray(qweight).astype(np.uint32)
+    R, N = q.shape
+    chunks = -(-R // 16)
+    pad = np.zeros((chunks * 16, N), dtype=np.uint32)
+    pad[:R] = q
+    sh = np.zeros_like(pad)
+    for p, src in enumerate(_PAIR_ORDER):
+        sh |= ((pad >> np.uint32(4 * src)) & np.uint32(15)) << np.uint32(4 * p)
+    t = sh.reshape(chunks, 4, 4, N // 16, 16)            # [c, kb, w, s, col]
+    t = t.transpose(3, 0, 1, 4, 2)                       # [s, c, kb, col, w]
+    return torch.from_numpy(np.ascontiguousarray(t).view(np.int32))
+
+
+def decode_copy_weights_inverse(tiled: torch.Tensor, K: int) -> torch.Tensor:
+    """The checkpoint layout int32 [K/8, N] back from a decode copy."""
+    t = tiled.cpu().numpy().view(np.uint32)
+    S, chunks = t.shape[0], t.shape[1]
+    sh = np.ascontiguousarray(t.transpose(1, 2, 4, 0, 3)).reshape(chunks * 16, S * 16)     # [c, kb, w, s, col] -> rows, columns
+    q = np.zeros_like(sh)
+    for p, src in enumerate(_PAIR_ORDER):
+        q |= ((sh >> np.uint32(4 * p)) & np.uint32(15)) << np.uint32(4 * src)
+    return torch.from_numpy(np.ascontiguousarray(q[:K // 8]).view(np.int32))
+
+
+def decode_copy_consts(qzeros: torch.Tensor, scales: torch.Tensor, zero_mode: str) -> torch.Tensor:
+    """uint8 [N/16, G, 48]: 16 scales (bit copies, 2 bytes each, little endian) + 16 one-byte zero-points as used in dequant (4-bit)."""
+    z = unpack_zeros(qzeros, 4, zero_mode).astype(np.uint8)                                 # [G, N]
+    G, N = z.shape
+    sb = scales.cpu().contiguous().view(torch.int16).numpy().view(np.uint8).reshape(G, N, 2)
+    out = np.zeros((N // 16, G, 48), dtype=np.uint8)
+    out[:, :, :32] = sb.reshape(G, N // 16, 32).transpose(1, 0, 2)
+    out[:, :, 32:] = z.reshape(G, N // 16, 16).transpose(1, 0, 2)
+    return torch.from_numpy(out)

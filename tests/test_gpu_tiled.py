@@ -1,0 +1,209 @@
+"""GPU (-m gpu): the load-time decode copy of a 4-bit layer (gptq_prepack_decode: qweight_tiled + qconst_tiled) and the decode kernel that streams it
+(gemv_q4_tiled_kernel, csrc/gemv_tiled.hip).
+
+What is pinned, all against the ORACLE (oracle/gptq_oracle.py), never against another kernel of this library:
+  * gptq_prepack_decode writes exactly what oracle.decode_copy_weights / decode_copy_consts state (bit for bit, ragged K, every group size, both zero-point
+    conventions, fp16 / bf16 scales), and the oracle's integer unpack of the inverse equals its unpack of the checkpoint tensor;
+  * post_init leaves the checkpoint tensors bit-identical and out of the side buffer's way (state_dict keys unchanged);
+  * every output of the tiled kernel against x (fp64) @ W_oracle (fp64) -- default plan and forced (waves, chunks per wave)
+    geometries, 1..4 rows of x, fp16 / bf16, both zero-point conventions, bias, group sizes 32 / 64 / 128 / 256, K with a ragged last chunk,
+    in-launch K slices, 2..4 layers of different widths in one launch; one-hot rows return the oracle's exact dequantised rows; repeated
+    calls are bit-identical.
+The reference's counterpart: tests/test_q4.py:1060-1122 (kernel output against the Python path), test_repacking.py:53-104 (a repacked layout
+must give the same layer)."""
+import ctypes
+
+import pytest
+import torch
+
+from autogptq_amd import _lib
+from autogptq_amd.qlinear_mi355x import QuantLinear, forward_multi
+from oracle import gptq_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = {torch.float16: (1e-3, 1e-3), torch.bfloat16: (8e-3, 8e-3)}
+
+
+def _tune(waves=0, u=0, ks=0):
+    t = _lib.GptqTuning()
+    t.path = 8
+    t.waves, t.ksplit = waves, ks
+    t.reserved[0] = u
+    return t
+
+
+def _layer(K, N, gs, dtype, seed, zero_mode="auto", bias=False):
+    L = O.random_quant_layer(K, N, 4, gs, dtype=dtype, seed=seed, bias=bias)
+    q = QuantLinear(4, gs, K, N, bias, weight_dtype=dtype, zero_mode=zero_mode)
+    q.qweight, q.qzeros, q.scales, q.g_idx = L["qweight"].clone(), L["qzeros"].clone(), L["scales"].clone(), L["g_idx"].clone()
+    if bias:
+        q.bias = L["bias"].clone()
+    q = q.to(DEV)
+    q.post_init()
+    mode = {"auto": O.ZERO_WRAP, "wrap": O.ZERO_WRAP, "nowrap": O.ZERO_NOWRAP}[zero_mode]
+    W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], 4, mode).to(DEV)
+    return L, q, W
+
+
+def _x(M, K, dtype, seed, hot=True):
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(seed)) - 0.5).to(dtype)
+    ks = []
+    if hot and M > 1:
+        for r, k in zip(range(1, M), (K - 1, 0, 129 % K)):
+            x[r].zero_()
+            x[r, k] = 1.0
+            ks.append((r, k))
+    return x.to(DEV), ks
+
+
+def _assert_all(y, xd, W, bias, dtype, what):
+    ref = xd.double() @ W.double()
+    if bias is not None:
+        ref = ref + bias.double()
+    rtol, atol = TOL[dtype]
+    scale = max(1e-6, float(ref.abs().max()))
+    bad = (y.double() - ref).abs() > atol * scale + rtol * ref.abs()
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} outputs out of tolerance, first at {torch.nonzero(bad)[0].tolist()}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("K,N,gs", [(256, 96 + 32, 128), (160, 64, 32), (4096, 4096, 128), (1056, 48 + 16, 1056), (2112, 1040 - 16, 64)])
+def test_prepack_decode_is_the_oracle_restatement(K, N, gs, dtype):
+    import ctypes as C
+    import numpy as np
+
+    lib = _lib.load()
+    for zm in ("auto", "nowrap"):
+        L, q, W = _layer(K, N, gs, dtype, K + N, zero_mode=zm)
+        mode = O.ZERO_WRAP if zm == "auto" else O.ZERO_NOWRAP
+        tb, cb = C.c_size_t(0), C.c_size_t(0)
+        _lib.check(lib.gptq_prepack_decode_bytes(C.byref(q._layer), C.byref(tb), C.byref(cb)))
+        want_t = O.decode_copy_weights(L["qweight"])
+        want_c = O.decode_copy_consts(L["qzeros"], L["scales"], mode)
+        assert tb.value == want_t.numel() * 4 and cb.value == want_c.numel()
+        assert q._qweight_tiled.numel() == tb.value and q._qconst_tiled.numel() == cb.value
+        assert torch.equal(q._qweight_tiled.cpu().view(torch.int32).reshape(want_t.shape), want_t)
+        assert torch.equal(q._qconst_tiled.cpu().reshape(want_c.shape), want_c)
+        # lossless: the reference's integer unpack of the inverse is its unpack of the checkpoint tensor
+        back = O.decode_copy_weights_inverse(q._qweight_tiled.cpu().view(torch.int32).reshape(want_t.shape), K)
+        assert np.array_equal(O.unpack_weights(back, 4), O.unpack_weights(L["qweight"], 4))
+    # argument errors surface as RuntimeError with the C ABI's message (the reference: TORCH_CHECK, exllama_ext.cpp:49-71)
+    with pytest.raises(_lib.GptqError, match="in place"):
+        _lib.check(lib.gptq_prepack_decode(C.byref(q._layer), q.qweight.data_ptr(), q._qconst_tiled.data_ptr(), None))
+    L3 = O.random_quant_layer(256, 64, 3, 32, seed=1)
+    q3 = QuantLinear(3, 32, 256, 64, False)
+    q3.qweight, q3.qzeros, q3.scales, q3.g_idx = L3["qweight"], L3["qzeros"], L3["scales"], L3["g_idx"]
+    q3 = q3.to(DEV)
+    q3.post_init()
+    assert q3._qweight_tiled is None                                        # other packings have no decode copy (yet)
+    with pytest.raises(_lib.GptqError, match="decode copy"):
+        _lib.check(lib.gptq_prepack_decode_bytes(C.byref(q3._layer), C.byref(tb), C.byref(cb)))
+
+
+def test_side_copy_is_derived_and_checkpoint_untouched():
+    L, q, W = _layer(512, 256, 128, torch.float16, 5)
+    assert q._qweight_tiled is not None and q._qconst_tiled is not None and q._layer.tiled_cols == 16
+    assert torch.equal(q.qweight.cpu(), L["qweight"]) and torch.equal(q.qzeros.cpu(), L["qzeros"]) and torch.equal(q.scales.cpu(), L["scales"])
+    assert list(q.state_dict().keys()) == ["qweight", "qzeros", "scales", "g_idx"]
+    assert _lib.describe_plan(q._layer, 1)["kernel"] == "tiled"
+    p = QuantLinear(4, 128, 512, 256, False)
+    p.qweight, p.qzeros, p.scales, p.g_idx = q.qweight, q.qzeros, q.scales, q.g_idx
+    p.post_init(tiled=False)
+    assert p._qweight_tiled is None and _lib.describe_plan(p._layer, 1)["kernel"] != "tiled"
+    x, _ = _x(2, 512, torch.float16, 1)
+    with torch.no_grad():
+        _assert_all(p(x), x, W, None, torch.float16, "checkpoint-layout twin")
+    with pytest.raises(_lib.GptqError, match="path = 8"):
+        p(x, tuning=_tune())
+    # act-order layers keep the in-kernel gather (no side copy of this kind yet)
+    La = O.random_quant_layer(512, 256, 4, 128, act_order=True, seed=2)
+    a = QuantLinear(4, 128, 512, 256, False)
+    a.qweight, a.qzeros, a.scales, a.g_idx = La["qweight"], La["qzeros"], La["scales"], La["g_idx"]
+    a = a.to(DEV)
+    a.post_init()
+    assert a._qweight_tiled is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("K,N,gs", [(1024, 512, 128), (4160, 272 - 16, 32), (2112, 1040 - 16, 64), (512, 2048, 256), (96, 64, 32), (3200, 32, 128), (1056, 64, 1056), (28672, 32, 128)])
+def test_tiled_decode_default_plan(K, N, gs, dtype):
+    """Default plan at shapes with whole and ragged chunks (K / 8 not a multiple of 16), strips that do not fill a wave count evenly,
+    one strip only, and every supported group size."""
+    for zm in ("auto", "nowrap"):
+        L, q, W = _layer(K, N, gs, dtype, K + N + gs, zero_mode=zm, bias=True)
+        assert _lib.describe_plan(q._layer, 1)["kernel"] == "tiled"
+        for M in (1, 2, 3, 4):
+            x, hot = _x(M, K, dtype, M)
+            with torch.no_grad():
+                y, y2 = q(x), q(x)
+            assert torch.equal(y, y2)
+            _assert_all(y, x, W, q.bias, dtype, f"tiled default {K}x{N} g{gs} M={M} {dtype} {zm}")
+            if hot:                              # exactness without the bias (it is added on fp32 before the one rounding; the reference rounds twice)
+                saved, q._layer.bias = q._layer.bias, None
+                with torch.no_grad():
+                    y0 = q(x)
+                q._layer.bias = saved
+                for r, k in hot:
+                    assert torch.equal(y0[r], W[k]), f"one-hot row {r} (k={k}) is not the oracle's W[k], M={M} {K}x{N} g{gs}"
+
+
+@pytest.mark.parametrize("waves,u", [(16, 1), (16, 2), (16, 4), (16, 8), (8, 2), (8, 4), (8, 8), (4, 1), (4, 4), (4, 8), (2, 8), (1, 2), (3, 4)])
+def test_tiled_decode_forced_geometries(waves, u):
+    """Every (waves, chunks per wave) the planner or a sweep can ask for, incl. workgroups that walk their strip in several passes and ones larger
+    than the strip."""
+    for (K, N, gs), dtype in (((2048, 256, 128), torch.float16), ((4160, 64, 64), torch.bfloat16)):
+        L, q, W = _layer(K, N, gs, dtype, waves * 31 + u)
+        for M in (1, 4):
+            x, hot = _x(M, K, dtype, M + u)
+            with torch.no_grad():
+                y = q(x, tuning=_tune(waves, u))
+                y2 = q(x, tuning=_tune(waves, u))
+            assert torch.equal(y, y2)
+            for r, k in hot:
+                assert torch.equal(y[r], W[k])
+            _assert_all(y, x, W, None, dtype, f"tiled waves={waves} u={u} {K}x{N} M={M}")
+
+
+@pytest.mark.parametrize("ks", [2, 3, 4, 8])
+def test_tiled_decode_k_slices(ks):
+    """K slices combined inside the launch through granules (narrow layers: TP shards): forced, and the planner's own on a 64-strip layer."""
+    for (K, N), dtype in (((8192, 256, ), torch.float16), ((4160, 128), torch.bfloat16)):
+        L, q, W = _layer(K, N, 128, dtype, ks)
+        for M in (1, 3):
+            x, hot = _x(M, K, dtype, M)
+            for waves, u in ((8, 2), (16, 1), (4, 4)):
+                with torch.no_grad():
+                    y = q(x, tuning=_tune(waves, u, ks))
+                    y2 = q(x, tuning=_tune(waves, u, ks))
+                assert torch.equal(y, y2), "K-split combine is not bit-reproducible"
+                for r, k in hot:
+                    assert torch.equal(y[r], W[k])
+                _assert_all(y, x, W, None, dtype, f"tiled ksplit={ks} {K}x{N} M={M}")
+    L, q, W = _layer(8192, 1024, 128, torch.float16, 77)                    # Llama-2-70B attention shard at TP = 8
+    plan = _lib.describe_plan(q._layer, 1)
+    assert plan["kernel"] == "tiled" and plan["ksplit"] >= 2
+    x, _ = _x(1, 8192, torch.float16, 3)
+    with torch.no_grad():
+        _assert_all(q(x), x, W, None, torch.float16, "tiled 8192x1024 default (K slices)")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_tiled_multi_layer_launch(dtype):
+    """2..4 layers of DIFFERENT widths that read one x, in one launch (gptq_forward_multi): every output of every layer."""
+    K = 2048
+    widths = (512, 288, 1024, 64)
+    made = [_layer(K, n, 128, dtype, 300 + n) for n in widths]
+    for n_l in (2, 3, 4):
+        layers = [m[1] for m in made[:n_l]]
+        for M in (1, 2, 4):
+            x, hot = _x(M, K, dtype, M)
+            for t in (None, _tune(4, 4), _tune(8, 2), _tune(16, 1, 2)):
+                with torch.no_grad():
+                    ys = forward_multi(layers, x, t)
+                    ys2 = forward_multi(layers, x, t)
+                for i in range(n_l):
+                    assert torch.equal(ys[i], ys2[i])
+                    for r, k in hot:
+                        assert torch.equal(ys[i][r], made[i][2][k])
+                    _assert_all(ys[i], x, made[i][2], None, dtype, f"tiled multi n={n_l} layer {i} M={M}")

@@ -30,7 +30,8 @@ def test_library_loads_and_exports_header_symbols():
 
 def test_struct_layout_matches_header():
     # 5 pointers, 6 int32, 2 pointers, 2 int32  (include/gptq_mi355x.h: gptq_layer_t)
-    assert ctypes.sizeof(_lib.GptqLayer) == 5 * 8 + 6 * 4 + 2 * 8 + 2 * 4
+    assert ctypes.sizeof(_lib.GptqLayer) == 5 * 8 + 6 * 4 + 2 * 8 + 2 * 4 + 2 * 8
+    assert _lib.GptqLayer.tiled_cols.offset == 84 and _lib.GptqLayer.qweight_tiled.offset == 88 and _lib.GptqLayer.qconst_tiled.offset == 96
     assert _lib.GptqLayer.epilogue.offset == 80
     assert _lib.GptqLayer.qweight_seq.offset == 64
     assert ctypes.sizeof(_lib.GptqTuning) == 8 * 4
@@ -707,3 +708,45 @@ def test_planner_fuzz_every_configuration_plans_or_refuses_cleanly():
         assert need < (1 << 34)
         assert lib.gptq_workspace_bytes_max(ctypes.byref(L), M) >= need
     assert {"mfma", "mfma_generic", "generic", "tiled", "skinny64", "stream64", "strip16", "f32_mfma", "mid", "stream"} <= seen, seen
+
+
+
+def test_decode_copy_restatement_matches_the_header_definition():
+    """oracle.decode_copy_weights / decode_copy_consts restate gptq_prepack_decode (include/gptq_mi355x.h, gptq_layer_t.qweight_tiled / qconst_tiled): checked
+    entry by entry against the header's formula on a small layer (ragged last chunk: K = 160), that the magic-number extraction order of a stored word is
+    k0 k1 | k2 k3 | k4 k5 | k6 k7, that the inverse restores the checkpoint tensor (so the reference's integer unpack is unchanged), and that the constants are
+    the reference's scales (bit copies) and zero-points as used (both conventions)."""
+    import numpy as np
+
+    K, N, gs = 160, 64, 32
+    L = O.random_quant_layer(K, N, 4, gs, seed=1)
+    q = L["qweight"].numpy().view(np.uint32)
+    t = O.decode_copy_weights(L["qweight"])
+    assert tuple(t.shape) == (N // 16, 2, 4, 16, 4)
+    tn = t.numpy().view(np.uint32)
+    w = O.unpack_weights(L["qweight"], 4)                                                    # the reference's unpack, [K, N]
+    for s_ in range(N // 16):
+        for c in range(2):
+            for kb in range(4):
+                for col in range(0, 16, 5):
+                    for wi in range(4):
+                        r = 16 * c + 4 * kb + wi
+                        word = int(tn[s_, c, kb, col, wi])
+                        if r >= K // 8:
+                            assert word == 0
+                            continue
+                        got = [(word >> sh) & 15 for sh in (0, 16, 4, 20, 8, 24, 12, 28)]      # (q & 0x000f000f) lo / hi, (q & 0x00f000f0), then the same on q >> 8
+                        assert got == [int(w[8 * r + j, 16 * s_ + col]) for j in range(8)]
+                        assert sorted((word >> (4 * p)) & 15 for p in range(8)) == sorted((int(q[r, 16 * s_ + col]) >> (4 * p)) & 15 for p in range(8))
+    back = O.decode_copy_weights_inverse(t, K)
+    assert torch.equal(back, L["qweight"])
+    assert np.array_equal(O.unpack_weights(back, 4), w)
+    for mode in (O.ZERO_WRAP, O.ZERO_NOWRAP):
+        cst = O.decode_copy_consts(L["qzeros"], L["scales"], mode).numpy()
+        z = O.unpack_zeros(L["qzeros"], 4, mode)
+        sb = L["scales"].view(torch.int16).numpy()
+        for s_ in range(N // 16):
+            for g in range(K // gs):
+                rec = cst[s_, g]
+                assert np.array_equal(rec[:32].view(np.int16), sb[g, 16 * s_:16 * s_ + 16])
+                assert np.array_equal(rec[32:], z[g, 16 * s_:16 * s_ + 16].astype(np.uint8))
