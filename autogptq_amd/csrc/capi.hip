@@ -447,6 +447,10 @@ size_t gptq_workspace_bytes_multi_ex(const gptq_layer_t* const* layers, int n_la
     for (int i = 0; i < n_layers; ++i)
         if (check_layer(layers[i]) != GPTQ_OK) return 0;
     size_t need = 0;
+    if (want_tiled(layers, n_layers, M, tune) && (multi_preferred(layers, n_layers, M) || (tune && tune->path == 8))) {
+        const TiledPlan tp = plan_tiled(layers, n_layers, M, tune);
+        return tp.partial_bytes ? WS_HEADER_BYTES + tp.partial_bytes : 0;
+    }
     if (want_mid_multi(layers, n_layers, M, tune)) {
         const MidPlan mp = plan_mid(layers, n_layers, M, tune);
         return mp.partial_bytes ? WS_HEADER_BYTES + mp.partial_bytes : 0;
@@ -454,10 +458,6 @@ size_t gptq_workspace_bytes_multi_ex(const gptq_layer_t* const* layers, int n_la
     if (want_stream64_multi(layers, n_layers, M, tune)) {
         const Stream64Plan sp = plan_stream64(layers, n_layers, M, tune);
         return sp.partial_bytes ? WS_HEADER_BYTES + sp.partial_bytes : 0;
-    }
-    if (want_tiled(layers, n_layers, M, tune) && multi_preferred(layers, n_layers, M)) {
-        const TiledPlan tp = plan_tiled(layers, n_layers, M, tune);
-        return tp.partial_bytes ? WS_HEADER_BYTES + tp.partial_bytes : 0;
     }
     if (n_layers <= 4) {
         const StreamPlan sp = plan_stream(layers, n_layers, M, tune);
@@ -484,6 +484,11 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
         if (layers[i]->K != layers[0]->K) return fail(GPTQ_ERR_SHAPE, "layers of one gptq_forward_multi call read the same x: in_features %d != %d", layers[i]->K, layers[0]->K);
         if (layers[i]->dtype != layers[0]->dtype) return fail(GPTQ_ERR_UNSUPPORTED, "layers of one gptq_forward_multi call share the dtype of x");
     }
+    // decode rows on layers that carry the decode copy: one launch over the strips of all layers (tools/tiled_sweep.py, M = 4, us: q|k|v 8.6 against
+    // 11.1 for the batched-decode kernel, gate|up 12.9 against 18.9)
+    if (want_tiled(layers, n_layers, M, tune) && (multi_preferred(layers, n_layers, M) || (tune && tune->path == 8)))
+        return tiled_call(layers, n_layers, x, outs, M, wv, stream, tune);
+    if (tune && tune->path == 8) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: these layers do not fit one decode-copy launch (1..4 plain 4-bit layers with qweight_tiled, M <= 4)");
     if (want_mid_multi(layers, n_layers, M, tune)) {
         const MidPlan mp = plan_mid(layers, n_layers, M, tune);
         if (mp.partial_bytes > 0 && wv.body_bytes < mp.partial_bytes)
@@ -500,9 +505,6 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
         if (e != hipSuccess) return hip_fail(e, "gptq batched-decode launch (needs > 64 KiB of LDS: was gptq_init() called on this device?)");
         return GPTQ_OK;
     }
-    if (want_tiled(layers, n_layers, M, tune) && (multi_preferred(layers, n_layers, M) || (tune && tune->path == 8)))
-        return tiled_call(layers, n_layers, x, outs, M, wv, stream, tune);
-    if (tune && tune->path == 8) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: these layers do not fit one strip-major decode launch (1..4 plain 4-bit layers with qweight_tiled, M <= 4)");
     if (n_layers <= 4 && M <= 4) {
         const StreamPlan sp = plan_stream(layers, n_layers, M, tune);
         if (sp.ok && multi_preferred(layers, n_layers, M)) return stream_call(layers, n_layers, sp, x, outs, M, wv, stream);
@@ -766,7 +768,7 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
     const gptq_layer_t* one_t[1] = {&Lc};
     if (!unfused_epilogue && Lc.epilogue == GPTQ_EPI_NONE && want_tiled(one_t, 1, M, tune)) {
         const TiledPlan tp = plan_tiled(one_t, 1, M, tune);
-        snprintf(out, out_bytes, "path=gemv kernel=tiled ln=4 waves=%d u=%d ksplit=%d mt=%d strips=%d pair=0 perm=0 epilogue=none", tp.waves, tp.u, tp.ksplit, tp.mt,
+        snprintf(out, out_bytes, "path=gemv kernel=strips ln=4 waves=%d u=%d ksplit=%d mt=%d strips=%d pair=0 perm=0 epilogue=none", tp.waves, tp.u, tp.ksplit, tp.mt,
                  tp.strips_total);
     } else if (!unfused_epilogue && want_stream_seq(L, M, tune, &Pseq)) {
         const gptq_layer_t* one[1] = {&Pseq};

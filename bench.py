@@ -341,11 +341,11 @@ def _kernel_of(ent, M):
     """Name of the kernel a stack entry launches (host-side plan query)."""
     from autogptq_amd import _lib
     q = ent[3]
-    if isinstance(q, list):
-        return "gptq::gemv_q4_stream_kernel"          # gptq_forward_multi: plain 4-bit layers, M <= 4
+    if isinstance(q, list):                           # gptq_forward_multi: plain 4-bit layers, M <= 4 -- the decode-copy kernel when the layers carry the copy
+        return "gptq::gemv_q4_tiled_kernel" if all(getattr(l, "_qweight_tiled", None) is not None for l in q) else "gptq::gemv_q4_stream_kernel"
     d = _lib.describe_plan(q._layer, M)
     return {"stream": "gptq::gemv_q4_stream_kernel", "mfma": "gptq::gemv_q4_f16_mfma_kernel", "mfma_generic": "gptq::gemv_mfma_generic_kernel",
-            "tiled": "gptq::gemm_kernel"}.get(d.get("kernel"), "gptq::" + str(d.get("kernel")))
+            "strips": "gptq::gemv_q4_tiled_kernel", "tiled": "gptq::gemm_kernel"}.get(d.get("kernel"), "gptq::" + str(d.get("kernel")))
 
 
 def _plan_of(layers, K, N, M):
@@ -485,7 +485,10 @@ def cpu_baseline(M, act_order, budget_s=20.0):
     return {"value": round(total_b / total_t / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
             "sample": "oracle.forward_fast = the reference's own broadcast shift+mask unpack (qlinear_cuda_old.py:295-349) + torch.matmul, "
                       "torch CPU fp16, M=%d, shapes x reps: %s" % (M, ", ".join(reps_done)),
-            "ms_per_layer_mean": round(1e3 * total_t / sum(int(r.split('x')[2]) for r in reps_done), 2)}
+            "ms_per_layer_mean": round(1e3 * total_t / sum(int(r.split('x')[2]) for r in reps_done), 2),
+            # the reference CLASS itself (qlinear_cuda_old.QuantLinear.forward, imported from /root/reference) timed in the 8-core build container,
+            # ms per forward on 4096x4096 / 4096x11008 / 11008x4096: it cannot run on the GPU box, so this port is what is timed here
+            "reference_class_ms_build_container": [30.4, 768, 305]}
 
 
 def bench_tp(device, rank, world, steps, peer_store=False):
@@ -813,6 +816,27 @@ def main():
             out["tp"] = tp
             if isinstance(roof, dict):
                 roof["tp"] = tp                       # the driver keeps `roofline` whole and drops unknown top-level keys
+                # BASELINE config 4 (Llama-2-70B shapes, out_features split over the ranks + one all-gather) as flat scalars beside the DP headline
+                try:
+                    pre = f"tp{world}_"
+                    for lname, ent in tp.items():
+                        if not isinstance(ent, dict):
+                            continue
+                        short = {"attn_qkvo": "attn", "mlp_gate_up": "gate_up", "mlp_column_row_pair": "mlp_pair"}.get(lname, lname)
+                        for k, v in ent.items():
+                            if isinstance(v, (int, float)) and k.startswith("us_"):
+                                roof[pre + short + "_" + k[3:]] = v
+                    for short in ("attn", "gate_up"):
+                        ent = tp.get(short) or {}
+                        w_ = ent.get("us_per_layer_with_allgather_graph", ent.get("us_per_layer_with_allgather"))
+                        l_ = ent.get("us_local_only_graph", ent.get("us_local_only"))
+                        if w_ is not None:
+                            roof[pre + short + "_us"] = w_
+                        if short == "attn" and w_ is not None and l_ is not None:
+                            roof[pre + "local_us"], roof[pre + "allgather_us"] = l_, round(w_ - l_, 2)
+                    out["config"]["parallelism"] = f"dp{world} (headline: one token per rank through its own stack) + tp{world} entries for BASELINE config 4 in roofline.tp{world}_*"
+                except Exception as e:
+                    roof["tp_flat_keys_error"] = repr(e)[:200]
 
     if rank == 0:
         if not prefill and world == 1 and not args.no_extras:
@@ -882,6 +906,43 @@ def main():
                         byc["mlp_call:" + k] = {"frac": v["frac"], "us": v["us_per_mlp"], "bound": "hbm"}
             if byc:
                 roof["by_config"] = byc
+            # ... and once more as FLAT scalars: a parser that keeps only scalar members of `roofline` still records the second headline
+            try:
+                roof["stack_frac"] = round(out["value"] / HBM_PEAK_GBS, 4)
+                roof["stack_GB_per_s"] = out["value"]
+                for nm, v in (roof.get("us_per_launch_by_shape") or {}).items():
+                    roof["us_" + nm.replace(":", "_")] = v
+                if isinstance(pf, dict) and "roofline" in pf:
+                    roof["prefill_frac"] = pf["roofline"]["frac"]
+                    roof["prefill_us"] = pf["roofline"]["us_per_launch_events"]
+                    roof["prefill_TFLOP_s"] = pf["roofline"]["achieved"]
+                    roof["prefill_shape"] = pf["roofline"]["shape"]
+                    roof["prefill_m4096_frac"] = pf["m4096_4096x4096"]["frac"]
+                    roof["prefill_m4096_us"] = pf["m4096_4096x4096"]["us_per_launch_events"]
+                    roof["prefill_m4096_TFLOP_s"] = pf["m4096_4096x4096"]["TFLOP_s"]
+                    tr = pf["roofline"].get("traffic")
+                    if tr:
+                        K_, N_ = [int(t[2:]) for t in pf["roofline"]["shape"].split()[:2]]
+                        roof["prefill_traffic_ratio"] = round(tr / algorithmic_bytes(K_, N_, 2048, act_order=True), 3)
+                    for nm, v in (pf.get("by_shape") or {}).items():
+                        roof["prefill_us_" + nm] = v["us"]
+                if isinstance(c5, dict):
+                    for bits in (3, 8):
+                        fr = [v["frac"] for k, v in c5.items() if isinstance(v, dict) and k.startswith(f"int{bits}_g32_") and k.count("_") == 2 and "frac" in v]
+                        if fr:
+                            roof[f"cfg5_int{bits}_frac_min"], roof[f"cfg5_int{bits}_frac_max"] = min(fr), max(fr)
+                        for k, v in c5.items():
+                            if isinstance(v, dict) and k.startswith(f"int{bits}_g32_") and k.endswith("_prefill_M2048"):
+                                roof[f"cfg5_int{bits}_prefill_frac"] = v["frac"]
+                if isinstance(bd, dict):
+                    for k, v in bd.items():
+                        if isinstance(v, dict) and "us" in v:
+                            roof["mid_" + k.lower() + "_us"] = v["us"]
+                if isinstance(mc, dict) and isinstance(mc.get("default_three_steps"), dict) and "us_per_mlp" in mc["default_three_steps"]:
+                    roof["mlp_call_us"] = mc["default_three_steps"]["us_per_mlp"]
+                    roof["mlp_call_frac"] = mc["default_three_steps"]["frac"]
+            except Exception as e:
+                roof["flat_keys_error"] = repr(e)[:200]
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (bounded sample, ~25 s of host time)
             out["cpu_baseline"] = cpu_baseline(1 if not prefill else 16, act_order)
         print(json.dumps(out))

@@ -106,11 +106,11 @@ def test_side_copy_is_derived_and_checkpoint_untouched():
     assert q._qweight_tiled is not None and q._qconst_tiled is not None and q._layer.tiled_cols == 16
     assert torch.equal(q.qweight.cpu(), L["qweight"]) and torch.equal(q.qzeros.cpu(), L["qzeros"]) and torch.equal(q.scales.cpu(), L["scales"])
     assert list(q.state_dict().keys()) == ["qweight", "qzeros", "scales", "g_idx"]
-    assert _lib.describe_plan(q._layer, 1)["kernel"] == "tiled"
+    assert _lib.describe_plan(q._layer, 1)["kernel"] == "strips"
     p = QuantLinear(4, 128, 512, 256, False)
     p.qweight, p.qzeros, p.scales, p.g_idx = q.qweight, q.qzeros, q.scales, q.g_idx
     p.post_init(tiled=False)
-    assert p._qweight_tiled is None and _lib.describe_plan(p._layer, 1)["kernel"] != "tiled"
+    assert p._qweight_tiled is None and _lib.describe_plan(p._layer, 1)["kernel"] != "strips"
     x, _ = _x(2, 512, torch.float16, 1)
     with torch.no_grad():
         _assert_all(p(x), x, W, None, torch.float16, "checkpoint-layout twin")
@@ -132,7 +132,7 @@ def test_tiled_decode_default_plan(K, N, gs, dtype):
     one strip only, and every supported group size."""
     for zm in ("auto", "nowrap"):
         L, q, W = _layer(K, N, gs, dtype, K + N + gs, zero_mode=zm, bias=True)
-        assert _lib.describe_plan(q._layer, 1)["kernel"] == "tiled"
+        assert _lib.describe_plan(q._layer, 1)["kernel"] == "strips"
         for M in (1, 2, 3, 4):
             x, hot = _x(M, K, dtype, M)
             with torch.no_grad():
@@ -182,7 +182,7 @@ def test_tiled_decode_k_slices(ks):
                 _assert_all(y, x, W, None, dtype, f"tiled ksplit={ks} {K}x{N} M={M}")
     L, q, W = _layer(8192, 1024, 128, torch.float16, 77)                    # Llama-2-70B attention shard at TP = 8
     plan = _lib.describe_plan(q._layer, 1)
-    assert plan["kernel"] == "tiled" and plan["ksplit"] >= 2
+    assert plan["kernel"] == "strips" and plan["ksplit"] >= 2
     x, _ = _x(1, 8192, torch.float16, 3)
     with torch.no_grad():
         _assert_all(q(x), x, W, None, torch.float16, "tiled 8192x1024 default (K slices)")
