@@ -1,0 +1,323 @@
+// gemm_wide.hip -- prefill, round 4: 128 x 512 workgroup tiles, every wave a 128 x 128 tile with its 256 accumulators in the AGPR half of the
+// unified register file (one wave per SIMD, __launch_bounds__(256, 1) = 512 registers per lane).
+//
+// Replaces for LARGE launches (reference): Marlin<...> in autogptq_extension/marlin/marlin_cuda_kernel.cu:216-727 -- its goal, int4 x fp16 on the matrix
+// cores at the dense rate -- and the dequant + cublasHgemm fallbacks (exllama/cuda_func/q4_matmul.cu:225-260, exllamav2/cuda/q_gemm.cu:104-181).
+//
+// Why a second tiled kernel: the counters of gemm_kernel<4, f16, 4, 64> (128 x 64 per wave, two waves per SIMD; profiles/r02_gemm_pmc.txt) show the
+// matrix pipe 45 - 50 % busy with 5.7 VALU + 0.63 LDS per MFMA, and the round-3 ablation (profiles/r03_gemm_ldsb_lab.log) that the A path -- 16
+// ds_read_b128, the x DMA and the barrier per 32 MFMAs -- caps that tile at ~0.55 of peak before a weight is decoded.  A 128 x 128 wave tile reads
+// every A fragment once per 128 columns: 16 ds_read_b128, ONE barrier and half the x staging per 64 MFMAs; the dequantised B fragment is still reused by
+// 4 row tiles (3.25 dequant VALU per MFMA: each wave decodes only its own 128 columns, nothing twice).
+// Per wave and 64-deep K-step: 64 MFMAs (v_mfma_f32_32x32x16), 16 ds_read_b128, 4 x 16-byte weight loads + 2 group-constant loads, 4 x-tile chunks.
+// A lane owns 4 ADJACENT columns (one 16-byte load per packed row; 512 contiguous bytes per half wave) -- column tile nt of the wave is the columns
+// {4 l + nt}: the epilogue then stores 4 adjacent outputs (8 bytes) per lane and row, 256 contiguous bytes per half wave.
+// Used where the launch has enough 128 x 512 tiles to fill 256 CUs (plan_gemm: north_star's M = 4096 on 4096 -> 4096 is exactly 256 of them); 128 x 256
+// tiles (gemm.hip) stay for everything smaller -- M = 2048 on a 4096-wide layer is 128 wide tiles: half the chip.
+// Weights never touch LDS; dequant = gemm.hip's exact magic-number form (bit-identical W, one rounding); x: LDS, double buffered, slot order
+// (k0,k4,k1,k5,k2,k6,k3,k7) written by the staging pass (4 v_perm per 16 bytes) or, for act-order layers, delivered that way by the permute pre-pass and
+// staged by LDS DMA with the XOR swizzle of gemm.hip.
+#include <type_traits>
+
+#include "common.cuh"
+#include "launch.h"
+
+namespace gptq {
+namespace wide {
+
+struct WideParams {
+    const unsigned* qweight;
+    const unsigned* qzeros;
+    const void* scales;
+    const void* bias;
+    const void* x;
+    void* out;
+    int M, K, N, zero_mode, nbm, nbn, ksteps, qrows, groups;
+    unsigned long long kpg_inv;   // ceil(2^32 / (group_size / 64)): group of K-step kt = (kt * kpg_inv) >> 32
+};
+
+__device__ __forceinline__ unsigned and_or(unsigned a, unsigned mask, unsigned orv) {
+    unsigned r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(orv));      // safe here: all 256 accumulator registers are live
+    return r;
+}
+__device__ __forceinline__ unsigned f16x2_bits(f16x2 v) { return __builtin_bit_cast(unsigned, v); }
+
+template <typename T> struct Mma;
+template <> struct Mma<f16> {
+    static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16> {
+    static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+// group constants of a lane's 4 columns: 4 scales (8 bytes) + the qzeros word holding its 4 nibbles
+struct CRaw { u32x2 s; unsigned z; };
+
+template <typename T> struct Deq4;
+template <> struct Deq4<f16> {
+    f16x2 s2[4], c1[4], c2[4];
+    __device__ __forceinline__ void setup(const CRaw& c, unsigned zsh, unsigned zmask) {
+        const f16x2 k960 = {(f16)960.f, (f16)960.f};
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+            const unsigned sw = c.s[col >> 1];
+            const unsigned sb = (col & 1) ? (sw >> 16) : (sw & 0xffffu);
+            s2[col] = as_f16x2(sb * 0x00010001u);
+            const unsigned z = (((c.z >> (zsh + 4 * col)) & 15u) + 1u) & zmask;
+            c1[col] = as_f16x2(z * 0x00010001u + 0xE400E400u);               // -(1024 + z)
+            c2[col] = c1[col] + k960;                                        // -(64 + z), exact
+        }
+    }
+    __device__ __forceinline__ u32x4 frag(unsigned q, int col) const {
+        const unsigned q8 = q >> 8;
+        const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+        const f16x2 h0 = as_f16x2(and_or(q, 0x000f000fu, 0x64006400u)) + c1[col];          // k0,k4 : w - z
+        const f16x2 h1 = as_f16x2(and_or(q, 0x00f000f0u, 0x64006400u)) * r16 + c2[col];    // k1,k5
+        const f16x2 h2 = as_f16x2(and_or(q8, 0x000f000fu, 0x64006400u)) + c1[col];         // k2,k6
+        const f16x2 h3 = as_f16x2(and_or(q8, 0x00f000f0u, 0x64006400u)) * r16 + c2[col];   // k3,k7
+        return u32x4{f16x2_bits(h0 * s2[col]), f16x2_bits(h1 * s2[col]), f16x2_bits(h2 * s2[col]), f16x2_bits(h3 * s2[col])};
+    }
+};
+template <> struct Deq4<bf16> {            // w - z exactly in packed fp16, times the scale in fp32 (exact product), ONE rounding to bf16: the reference's W
+    f16x2 c1[4], c2[4];
+    float s[4];
+    __device__ __forceinline__ void setup(const CRaw& c, unsigned zsh, unsigned zmask) {
+        const f16x2 k960 = {(f16)960.f, (f16)960.f};
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+            const unsigned sw = c.s[col >> 1];
+            const unsigned short sb = (unsigned short)((col & 1) ? (sw >> 16) : (sw & 0xffffu));
+            s[col] = (float)__builtin_bit_cast(bf16, sb);
+            const unsigned z = (((c.z >> (zsh + 4 * col)) & 15u) + 1u) & zmask;
+            c1[col] = as_f16x2(z * 0x00010001u + 0xE400E400u);
+            c2[col] = c1[col] + k960;
+        }
+    }
+    static __device__ __forceinline__ unsigned scaled_pair(f16x2 h, float sc) {
+        const unsigned hb = __builtin_bit_cast(unsigned, h);
+        float lo, hi;
+        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hb), "v"(sc));
+        asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(hb), "v"(sc));
+        const bf16x2 v = {(bf16)lo, (bf16)hi};
+        return __builtin_bit_cast(unsigned, v);
+    }
+    __device__ __forceinline__ u32x4 frag(unsigned q, int col) const {
+        const unsigned q8 = q >> 8;
+        const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+        const f16x2 h0 = as_f16x2(and_or(q, 0x000f000fu, 0x64006400u)) + c1[col];
+        const f16x2 h1 = as_f16x2(and_or(q, 0x00f000f0u, 0x64006400u)) * r16 + c2[col];
+        const f16x2 h2 = as_f16x2(and_or(q8, 0x000f000fu, 0x64006400u)) + c1[col];
+        const f16x2 h3 = as_f16x2(and_or(q8, 0x00f000f0u, 0x64006400u)) * r16 + c2[col];
+        return u32x4{scaled_pair(h0, s[col]), scaled_pair(h1, s[col]), scaled_pair(h2, s[col]), scaled_pair(h3, s[col])};
+    }
+};
+
+__device__ __forceinline__ unsigned short t_bits(f16 v) { return __builtin_bit_cast(unsigned short, v); }
+__device__ __forceinline__ unsigned short t_bits(bf16 v) { return __builtin_bit_cast(unsigned short, v); }
+
+// GLDS: x arrives in k-slot order (act-order layers: the permute pre-pass writes it so) and is staged by LDS DMA into unpadded, XOR-swizzled rows.
+template <typename T, bool GLDS>
+__global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
+    constexpr int BM = 128, BK = 64, KS = 4, MT = 4, NT = 4;
+    constexpr int STRIDE = GLDS ? BK * 2 : BK * 2 + 16;      // bytes per LDS row of x (padded unless DMA-staged)
+    constexpr int NCH = 4;                                   // 16-byte chunks per thread and K-step: 128 rows x 8 chunks / 256 threads
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x BM x STRIDE
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    // logical tile order: an XCD's contiguous run of ids is a compact patch (all column tiles of a few row tiles): its L2 holds few x panels
+    const int L = xcd_remap(blockIdx.x, p.nbm * p.nbn);
+    const int bm = L / p.nbn, bn = L - bm * p.nbn;
+    const int m0 = bm * BM;
+    const int n = bn * 512 + wave * 128 + 4 * l31;            // this lane's first column (it owns n .. n + 3)
+    const bool col_ok = n < p.N;                              // N % 32 == 0: a lane's 4 columns are in or out together
+    const int nl = col_ok ? n : 0;
+    const unsigned short* __restrict__ x = (const unsigned short*)p.x;
+
+    // A staging assignment: chunk c -> (row, 16-byte column); rows past M are clamped (never predicated), their accumulators are not stored
+    int a_row[NCH], a_kc[NCH];
+    unsigned a_off[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = tid + i * 256;
+        a_row[i] = c >> 3;
+        a_kc[i] = c & 7;
+        const int src_kc = GLDS ? (a_kc[i] ^ ((a_row[i] >> 1) & 7)) : a_kc[i];
+        a_off[i] = (unsigned)(min(m0 + a_row[i], p.M - 1) - m0) * (unsigned)p.K * 2u + (unsigned)src_kc * 16u;
+    }
+    const char* a_base = (const char*)(x + (size_t)m0 * p.K);
+    const auto rsrc_q = __builtin_amdgcn_make_buffer_rsrc((void*)p.qweight, 0, (int)((size_t)p.qrows * p.N * 4), 0x00020000);
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (int)((size_t)BM * p.K * 2), 0x00020000);
+    const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.scales, 0, (int)((size_t)p.groups * p.N * 2), 0x00020000);
+    const int zrow_bytes = p.N / 8 * 4;
+    const auto rsrc_z = __builtin_amdgcn_make_buffer_rsrc((void*)p.qzeros, 0, p.groups * zrow_bytes, 0x00020000);
+    const unsigned b_lane_off = ((unsigned)nl + (unsigned)half * (unsigned)p.N) * 4u;
+    const unsigned s_lane_off = (unsigned)nl * 2u;
+    const unsigned z_lane_off = ((unsigned)nl >> 3) * 4u, zsh = ((unsigned)nl & 7u) * 4u;
+    const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
+
+    auto dma_a = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            char* dst = smem + (size_t)buf * (BM * STRIDE) + (size_t)(i * 256 + wave * 64) * 16;
+            lds_dma16(a_base + (size_t)kt * (BK * 2) + a_off[i], lds_addr_of(dst));
+        }
+    };
+    auto load_a = [&](int kt, u32x4 (&r)[NCH]) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, a_off[i], (unsigned)kt * (BK * 2), 0);
+    };
+    auto store_a = [&](int buf, const u32x4 (&r)[NCH]) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            // (x0,x1)(x2,x3)(x4,x5)(x6,x7) -> (x0,x4)(x1,x5)(x2,x6)(x3,x7): the slot order of the B fragments
+            u32x4 o;
+            o[0] = __builtin_amdgcn_perm(r[i][2], r[i][0], 0x05040100u);
+            o[1] = __builtin_amdgcn_perm(r[i][2], r[i][0], 0x07060302u);
+            o[2] = __builtin_amdgcn_perm(r[i][3], r[i][1], 0x05040100u);
+            o[3] = __builtin_amdgcn_perm(r[i][3], r[i][1], 0x07060302u);
+            *(u32x4*)(smem + (size_t)buf * (BM * STRIDE) + a_row[i] * STRIDE + a_kc[i] * 16) = o;
+        }
+    };
+    // weights of one K-step: packed rows kt * 8 + ks * 2 + half, 16 bytes (4 columns) each
+    auto load_b = [&](int kt, u32x4 (&b)[KS]) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            b[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, b_lane_off, (unsigned)((size_t)(kt * 8 + ks * 2) * (size_t)p.N * 4), 0);
+    };
+    auto load_c = [&](int kt, CRaw& c) {
+        const int g = (int)(((unsigned long long)(unsigned)kt * p.kpg_inv) >> 32);
+        c.s = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_s, s_lane_off, (unsigned)g * (unsigned)p.N * 2u, 0));
+        c.z = __builtin_amdgcn_raw_buffer_load_b32(rsrc_z, z_lane_off, (unsigned)(g * zrow_bytes), 0);
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    u32x4 a_next[NCH];
+    u32x4 b0[KS], b1[KS];
+    CRaw c0, c1;
+    const int kt1 = p.ksteps;
+    if constexpr (GLDS) dma_a(0, 0); else load_a(0, a_next);
+    load_b(0, b0);
+    load_c(0, c0);
+    if constexpr (!GLDS) store_a(0, a_next);
+    if constexpr (GLDS) wait_vmcnt<0>();
+    __syncthreads();
+
+    const int a_lane_off = GLDS ? l31 * STRIDE : l31 * STRIDE + half * 16;
+    const int a_swz = (l31 >> 1) & 7;
+    auto step = [&](int kt, auto bufc, const u32x4 (&b_use)[KS], const CRaw& c_use, u32x4 (&b_fill)[KS], CRaw& c_fill) {
+        constexpr int BUF = decltype(bufc)::value;
+        const int ktn = min(kt + 1, kt1 - 1);                  // the last step re-loads itself (no branch in the pipeline)
+        if constexpr (GLDS) {
+            // claim this step's weight words and constants before anything new is issued: the compiler's exact wait lands here (gemm.hip)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(b_use[ks][0]), "v"(b_use[ks][1]), "v"(b_use[ks][2]), "v"(b_use[ks][3]));
+            asm volatile("" ::"v"(c_use.s[0]), "v"(c_use.s[1]), "v"(c_use.z));
+            __builtin_amdgcn_sched_barrier(0);
+            dma_a(ktn, BUF ^ 1);
+        } else {
+            load_a(ktn, a_next);
+        }
+        load_b(ktn, b_fill);
+        load_c(ktn, c_fill);
+        __builtin_amdgcn_sched_barrier(0);                     // keep the prefetch ahead of this step's MFMAs
+        Deq4<T> dq;
+        dq.setup(c_use, zsh, zmask);
+        const char* abase = smem + BUF * (BM * STRIDE) + a_lane_off;
+        // software pipeline over the KS MFMA k-steps: the fragments of ks + 1 (A from LDS, B dequantised in registers) are produced while the 16 MFMAs of ks run
+        u32x4 a[2][MT], bq[2][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[0][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (GLDS ? ((half ^ a_swz) * 16) : 0));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bq[0][nt] = dq.frag(b_use[0][nt], nt);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    a[(ks + 1) & 1][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (GLDS ? ((((ks + 1) * 2 + half) ^ a_swz) * 16) : (ks + 1) * 32));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bq[(ks + 1) & 1][nt] = dq.frag(b_use[ks + 1][nt], nt);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Mma<T>::run(a[ks & 1][mt], bq[ks & 1][nt], acc[mt][nt]);
+        }
+        if constexpr (!GLDS) store_a(BUF ^ 1, a_next);
+        // DMA-staged x: the next tile must have landed before anybody passes the barrier; the KS weight loads + 2 constant loads issued behind it may fly on
+        if constexpr (GLDS) wait_vmcnt<KS + 2>();
+        __syncthreads();
+    };
+    for (int kt = 0; kt < kt1; kt += 2) {                       // the planner only sends even step counts here (K % 128 == 0): no conditional second step --
+        step(kt, std::integral_constant<int, 0>{}, b0, c0, b1, c1);     // with all 256 accumulator registers live, a phi copy of them has nowhere to go but scratch
+        step(kt + 1, std::integral_constant<int, 1>{}, b1, c1, b0, c0);
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: column = lane & 31 (of tile nt: output column n + nt), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (!col_ok) return;
+    float bias[NT] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bias[nt] = DType<T>::to_f32(((const T*)p.bias)[n + nt]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m >= p.M) continue;
+            const unsigned lo = (unsigned)t_bits(DType<T>::from_f32(acc[mt][0][r] + bias[0])) | ((unsigned)t_bits(DType<T>::from_f32(acc[mt][1][r] + bias[1])) << 16);
+            const unsigned hi = (unsigned)t_bits(DType<T>::from_f32(acc[mt][2][r] + bias[2])) | ((unsigned)t_bits(DType<T>::from_f32(acc[mt][3][r] + bias[3])) << 16);
+            *(u32x2*)((unsigned short*)p.out + (size_t)m * p.N + n) = u32x2{lo, hi};
+        }
+    }
+}
+
+}  // namespace wide
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------------------
+bool wide_gemm_ok(const gptq_layer_t& L, int M, bool use_seq, bool xslot_glds) {
+    if (L.bits != 4 || (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16)) return false;
+    if (L.K % 128 || L.group_size % 64 || L.N % 32 || L.epilogue != GPTQ_EPI_NONE) return false;      // an even number of 64-deep K-steps
+    if (use_seq && !xslot_glds) return false;                 // act-order: only with the slot-ordered, DMA-staged x (fp16)
+    (void)M;
+    return true;
+}
+
+hipError_t launch_gemm_wide(const gptq_layer_t& L, const uint32_t* qweight, const void* x, void* out, int M, bool glds, hipStream_t st) {
+    wide::WideParams p{};
+    p.qweight = qweight; p.qzeros = L.qzeros; p.scales = L.scales; p.bias = L.bias; p.x = x; p.out = out;
+    p.M = M; p.K = L.K; p.N = L.N; p.zero_mode = L.zero_mode;
+    p.nbm = (M + 127) / 128; p.nbn = (L.N + 511) / 512;
+    p.ksteps = L.K / 64;
+    p.qrows = L.K / 8;
+    p.groups = (L.K + L.group_size - 1) / L.group_size;
+    const unsigned long long kpg = (unsigned long long)(L.group_size / 64);
+    p.kpg_inv = ((1ull << 32) + kpg - 1) / kpg;
+    const dim3 grid(p.nbm * p.nbn), block(256);
+    if (L.dtype == GPTQ_F16) {
+        if (glds) hipLaunchKernelGGL((wide::gemm_wide_kernel<f16, true>), grid, block, 2 * 128 * 128, st, p);
+        else hipLaunchKernelGGL((wide::gemm_wide_kernel<f16, false>), grid, block, 2 * 128 * 144, st, p);
+    } else {
+        hipLaunchKernelGGL((wide::gemm_wide_kernel<bf16, false>), grid, block, 2 * 128 * 144, st, p);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gptq

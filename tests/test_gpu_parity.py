@@ -25,6 +25,17 @@ DEV = "cuda:0"
 TOL = {torch.float32: (1e-4, 1e-5), torch.float16: (2e-3, 2e-3), torch.bfloat16: (1.6e-2, 1.6e-2)}
 
 
+@pytest.fixture(autouse=True)
+def _checkpoint_layout_kernels():
+    """This file pins the kernels that stream the CHECKPOINT layout (every packing, act-order, fp32, the forced-geometry grids and the planner's
+    documented choices among them): layers are built without the round-4 decode copy, which has its own files (test_gpu_tiled.py and, through the
+    default plan, test_gpu_baseline_configs.py)."""
+    old = QuantLinear.TILED_DECODE
+    QuantLinear.TILED_DECODE = False
+    yield
+    QuantLinear.TILED_DECODE = old
+
+
 def _module_from(qweight, qzeros, scales, g_idx, bias, bits, group_size, zero_mode="auto"):
     K = qweight.shape[0] * 32 // bits
     N = qweight.shape[1]
