@@ -1936,6 +1936,8 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.bk = (L.bits == 4 && pl.mt == 4 && L.K % 64 == 0 && L.group_size % 64 == 0) ? 64 : 32;
     if (tune && tune->reserved[1] == 32) pl.bk = 32;
     pl.variant = tune ? tune->reserved[3] : 0;            // experiment knob: inner-loop schedule variant
+    const int wide_knob = (pl.variant == 44 || pl.variant == 45) ? pl.variant : 0;      // 44 / 45: the 128 x 512 kernel off / forced (A/B runs)
+    if (wide_knob) pl.variant = 0;
     const int tail_knob = (pl.variant >= 40 && pl.variant <= 43) ? pl.variant : 0;      // 40 = balanced tail by the rule below, 41 = off, 42 = the rule without its tile limit (A/B runs),
                                                                                          // 43 = unrun experiment: a K-split launch combined in the launch (every tile a tail tile) instead of slabs + reduce launch
     if (tail_knob) pl.variant = 0;
@@ -2003,6 +2005,23 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
             else pl.tail_lg = 0;
         }
         if (pl.tail) pl.workspace_bytes = pl.xperm_bytes + ((size_t)pl.tail << pl.tail_lg) * (32 * 256 * 16);
+    }
+    // 128 x 512 tiles with a 128 x 128 tile per wave (gemm_wide.hip) where they fill the chip: whole rounds of 256, or enough rounds that the last one
+    // hardly matters (tools/widelab, us per layer, 128 x 256 -> 128 x 512: M = 4096 on 4096^2 131.5 -> 122.8 (256 tiles), 11008x4096 337 -> 314 (256),
+    // 4096x11008 360 -> 342 (704); M = 2048 on 4096x11008 (352 tiles = 1.4 rounds) 187 -> 214 and on 4096^2 (128 tiles) 67 -> 102: those stay here)
+    {
+        const long wt = (long)((M + 127) / 128) * ((L.N + 511) / 512);
+        const long rounds = (wt + 255) / 256;
+        const bool fills = wt >= 256 && (double)wt / (double)(rounds * 256) >= 0.9;
+        pl.wide = wide_knob != 44 && (fills || wide_knob == 45) && pl.mt == 4 && pl.bk == 64 && pl.ksplit == 1 && pl.variant == 0 && tail_knob == 0 &&
+                  wide_gemm_ok(L, M, pl.use_seq, pl.xslot && pl.glds);
+        if (pl.wide) {
+            pl.tail = 0; pl.tail_lg = 0;
+            pl.bn = 512; pl.nbn = (L.N + 511) / 512;
+            pl.workspace_bytes = pl.xperm_bytes;
+            pl.kg = 1;
+            return pl;
+        }
     }
     pl.kg = (kg_ok && pl.tail == 0 && pl.variant != 6 && pl.variant != 16 && ((long)pl.nbm * pl.nbn * pl.ksplit <= 256 || pl.variant == 7 || pl.variant == 17 || pl.variant == 32)) ? 2 : 1;   // 16 / 17: gemmlab timeline variants (one / two K groups); 32: ping-pong
     return pl;
@@ -2186,6 +2205,7 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
         sp.lds_bytes = (land > slabs ? land : slabs) + 16;
         return launch_stream64(one, sp, p.x, outs, M, ws_header, p.partial, pl.use_seq ? L.qweight_seq : nullptr, st);
     }
+    if (pl.wide) return launch_gemm_wide(L, p.qweight, p.x, out, M, pl.use_seq, st);
     e = (L.dtype == GPTQ_F16) ? launch_t<f16>(L, pl, p, st) : launch_t<bf16>(L, pl, p, st);
     if (e != hipSuccess) return e;
     if (pl.ksplit > 1) {

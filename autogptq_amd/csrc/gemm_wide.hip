@@ -217,14 +217,33 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
 
     const int a_lane_off = GLDS ? l31 * STRIDE : l31 * STRIDE + half * 16;
     const int a_swz = (l31 >> 1) & 7;
-    auto step = [&](int kt, auto bufc, const u32x4 (&b_use)[KS], const CRaw& c_use, u32x4 (&b_fill)[KS], CRaw& c_fill) {
+    // One wave per SIMD: nothing else covers this wave's VALU / LDS work, so every MFMA has to be followed by its share of it -- the matrix pipe takes an
+    // MFMA every 32 cycles and the wave can issue ~5 other instructions meanwhile (MI355X_MICROARCH.md, per-instruction table).  Left to itself hipcc emits
+    // the 52-instruction dequant of a k-step as one run and the 16 MFMAs as another (the pipe idles through the first and the wave stalls through the
+    // second: 51 % busy, 1128 TFLOP/s at 4096^3 in tools/widelab); sched_group_barrier spells the interleave out.  The pipeline is continuous ACROSS
+    // K-steps: the constants and the first B fragments of step t + 1 are produced under the last 16 MFMAs of step t (their words were requested a whole
+    // step earlier), and the x tile of t + 1 goes to LDS there too; only the first A fragments of a step wait for the barrier.
+    Deq4<T> dq_cur;
+    u32x4 bq_first[NT];
+    dq_cur.setup(c0, zsh, zmask);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bq_first[nt] = dq_cur.frag(b0[0][nt], nt);
+    auto interleave = [&](auto nvalu) {                       // 16 x { 1 MFMA, n VALU, 1 LDS op every fourth }
+        constexpr int NV = decltype(nvalu)::value;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);       // VALU
+            if ((i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);   // DS read / write
+        }
+    };
+    auto step = [&](int kt, auto bufc, const u32x4 (&b_use)[KS], u32x4 (&b_fill)[KS], CRaw& c_fill) {
         constexpr int BUF = decltype(bufc)::value;
         const int ktn = min(kt + 1, kt1 - 1);                  // the last step re-loads itself (no branch in the pipeline)
         if constexpr (GLDS) {
-            // claim this step's weight words and constants before anything new is issued: the compiler's exact wait lands here (gemm.hip)
+            // claim this step's weight words before anything new is issued: the compiler's exact wait lands here (gemm.hip)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(b_use[ks][0]), "v"(b_use[ks][1]), "v"(b_use[ks][2]), "v"(b_use[ks][3]));
-            asm volatile("" ::"v"(c_use.s[0]), "v"(c_use.s[1]), "v"(c_use.z));
+            for (int ks = 1; ks < KS; ++ks) asm volatile("" ::"v"(b_use[ks][0]), "v"(b_use[ks][1]), "v"(b_use[ks][2]), "v"(b_use[ks][3]));
             __builtin_amdgcn_sched_barrier(0);
             dma_a(ktn, BUF ^ 1);
         } else {
@@ -232,41 +251,45 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
         }
         load_b(ktn, b_fill);
         load_c(ktn, c_fill);
-        __builtin_amdgcn_sched_barrier(0);                     // keep the prefetch ahead of this step's MFMAs
-        Deq4<T> dq;
-        dq.setup(c_use, zsh, zmask);
         const char* abase = smem + BUF * (BM * STRIDE) + a_lane_off;
-        // software pipeline over the KS MFMA k-steps: the fragments of ks + 1 (A from LDS, B dequantised in registers) are produced while the 16 MFMAs of ks run
         u32x4 a[2][MT], bq[2][NT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a[0][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (GLDS ? ((half ^ a_swz) * 16) : 0));
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bq[0][nt] = dq.frag(b_use[0][nt], nt);
+        for (int nt = 0; nt < NT; ++nt) bq[0][nt] = bq_first[nt];
+        __builtin_amdgcn_sched_barrier(0);                     // the prefetch and the first A fragments stay ahead of this step's MFMAs
+        Deq4<T> dq_nx;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + 1 < KS) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     a[(ks + 1) & 1][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (GLDS ? ((((ks + 1) * 2 + half) ^ a_swz) * 16) : (ks + 1) * 32));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < KS) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bq[(ks + 1) & 1][nt] = dq.frag(b_use[ks + 1][nt], nt);
+                for (int nt = 0; nt < NT; ++nt) bq[(ks + 1) & 1][nt] = dq_cur.frag(b_use[ks + 1][nt], nt);
+            } else {
+                // under the last MFMA group: next step's constants and first B fragments (registers only), and its x tile to LDS
+                dq_nx.setup(c_fill, zsh, zmask);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bq_first[nt] = dq_nx.frag(b_fill[0][nt], nt);
+                if constexpr (!GLDS) store_a(BUF ^ 1, a_next);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Mma<T>::run(a[ks & 1][mt], bq[ks & 1][nt], acc[mt][nt]);
+            if (ks + 1 < KS) interleave(std::integral_constant<int, 4>{});
+            else interleave(std::integral_constant<int, 6>{});
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (!GLDS) store_a(BUF ^ 1, a_next);
+        dq_cur = dq_nx;
         // DMA-staged x: the next tile must have landed before anybody passes the barrier; the KS weight loads + 2 constant loads issued behind it may fly on
         if constexpr (GLDS) wait_vmcnt<KS + 2>();
         __syncthreads();
     };
     for (int kt = 0; kt < kt1; kt += 2) {                       // the planner only sends even step counts here (K % 128 == 0): no conditional second step --
-        step(kt, std::integral_constant<int, 0>{}, b0, c0, b1, c1);     // with all 256 accumulator registers live, a phi copy of them has nowhere to go but scratch
-        step(kt + 1, std::integral_constant<int, 1>{}, b1, c1, b0, c0);
+        step(kt, std::integral_constant<int, 0>{}, b0, b1, c1);         // with all 256 accumulator registers live, a phi copy of them has nowhere to go but scratch
+        step(kt + 1, std::integral_constant<int, 1>{}, b1, b0, c0);
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: column = lane & 31 (of tile nt: output column n + nt), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)

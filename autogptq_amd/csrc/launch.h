@@ -45,6 +45,7 @@ hipError_t init_gemm_mid_device();
 
 struct GemmPlan {
     bool supported, use_seq;
+    bool wide;                // 128 x 512 tiles, 128 x 128 per wave, accumulators in AGPRs (gemm_wide.hip): large launches
     bool mid;                 // 17 .. 128 rows, 4-bit: gemm_mid_kernel (midp holds its geometry)
     MidPlan midp;
     bool glds;                // ... and stages it with global_load_lds (DMA) into swizzled, unpadded LDS rows
@@ -128,6 +129,9 @@ bool ldsb_supported(const gptq_layer_t& L, int M);
 hipError_t init_gemm_ldsb_device();
 hipError_t launch_gemm_ldsb(const gptq_layer_t& L, const uint32_t* qweight, const void* x, void* out, int M, hipStream_t st, int bk = 0, int kgroups = 0,
                             int abl = 0);
+// gemm_wide.hip: 128 x 512 prefill tiles, 128 x 128 per wave with the accumulators in AGPRs (4-bit fp16 / bf16; glds: x in k-slot order, staged by LDS DMA)
+bool wide_gemm_ok(const gptq_layer_t& L, int M, bool use_seq, bool xslot_glds);
+hipError_t launch_gemm_wide(const gptq_layer_t& L, const uint32_t* qweight, const void* x, void* out, int M, bool glds, hipStream_t st);
 hipError_t init_gemv_device();
 hipError_t init_gemm_device();
 

@@ -294,3 +294,45 @@ def test_headline_mlp_forward_full_size_with_intermediate(dtype):
         CHECKED["outputs"] += h.numel()
         _assert_all_outputs(y, h, Wd, dtype, f"mlp_forward down M={M} {dtype}")
     del gate, up, down
+
+
+# ------------------------------------------------------------------------------------------ north_star M = 4096: the 128 x 512 kernel
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("K,N,act", [(4096, 4096, True), (4096, 11008, False), (11008, 4096, False), (4096, 11008, True)])
+def test_north_star_m4096_wide_tiles(K, N, act, dtype):
+    """batch x seq = 4096 rows on the Llama-7B shapes: the launches where the planner takes gemm_wide_kernel (128 x 512 tiles, 128 x 128 per wave, accumulators
+    in AGPRs) -- every output against the fp64 oracle product, a one-hot row in every 32-row tile returning the oracle's exact weight row, act-order through
+    the slot-ordered permute pre-pass + DMA staging (fp16; bf16 act-order keeps the 128 x 256 kernel), a half-empty last column tile (11008 = 21.5 x 512)."""
+    from autogptq_amd import _lib
+    L, q, W, W64 = _layer(4, 128, K, N, act, dtype)
+    plan = _lib.describe_plan(q._layer, 4096)
+    assert plan["kernel"] == ("tiled" if (act and dtype == torch.bfloat16) else "wide"), plan
+    _check(4, 128, K, N, 4096, act, dtype)
+
+
+def test_wide_tiles_forced_on_ragged_shapes():
+    """The same kernel forced (tuning.reserved[3] = 45) on shapes with a partial last row tile, a partial last column tile, bias, both zero-point conventions
+    and group sizes 64 / 128 / 256 -- and identical, bit for bit, to the 128 x 256 kernel with one K group (same MFMA k order)."""
+    from autogptq_amd import _lib
+    for (K, N, gs, M, act) in ((256, 544, 128, 200, False), (512, 1056, 64, 333, True), (1024, 512, 256, 129, False), (384, 96, 128, 65, False)):
+        for zm in ("auto", "nowrap"):
+            Lq = O.random_quant_layer(K, N, 4, gs, act_order=act, seed=K + N + M, bias=True)
+            q = QuantLinear(4, gs, K, N, True, zero_mode=zm)
+            q.qweight, q.qzeros, q.scales, q.g_idx, q.bias = Lq["qweight"], Lq["qzeros"], Lq["scales"], Lq["g_idx"], Lq["bias"]
+            q = q.to(DEV)
+            q.post_init()
+            mode = O.ZERO_NOWRAP if (zm == "nowrap" or act) else O.ZERO_WRAP
+            W = O.dequantize(Lq["qweight"], Lq["qzeros"], Lq["scales"], Lq["g_idx"], 4, mode).to(DEV)
+            x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).half().to(DEV)
+            tw, tn = _lib.GptqTuning(), _lib.GptqTuning()
+            tw.path, tw.reserved[3], tw.ksplit = 3, 45, 1
+            tn.path, tn.reserved[3], tn.ksplit = 3, 6, 1
+            assert _lib.describe_plan(q._layer, M, tw)["kernel"] == "wide"
+            with torch.no_grad():
+                yw, yw2, yn = q(x, tuning=tw), q(x, tuning=tw), q(x, tuning=tn)
+            assert torch.equal(yw, yw2)
+            assert torch.equal(yw, yn), f"128 x 512 and 128 x 256 tiles differ ({K}x{N} g{gs} M={M} act={act} {zm})"
+            ref = x.double() @ W.double() + Lq["bias"].to(DEV).double()
+            scale = float(ref.abs().max())
+            bad = (yw.double() - ref).abs() > 1e-3 * scale + 1e-3 * ref.abs()
+            assert not bool(bad.any()), f"{K}x{N} g{gs} M={M} act={act} {zm}: {int(bad.sum())} outputs out of tolerance"
