@@ -543,19 +543,13 @@ static int check_mlp(const gptq_layer_t* gate, const gptq_layer_t* up, const gpt
 }
 static size_t mlp_stage_bytes(const gptq_layer_t* gate, int M) { return ((size_t)M * gate->N * dtype_size(gate->dtype) + 255) / 256 * 256; }
 
-// The one-launch kernel is OPT-IN (tuning.path = 7): measured on MI355X it is slower than the steps below (tools/mlplab, Llama-7B MLP, M = 1:
-// 27.9 - 31.3 us per call against 22.9 us for gptq_forward_multi(gate, up) + gptq_forward(down) and 26.7 us for the three unfused steps;
-// profiles/r03_mlp_ring_timeline.log) -- kept as the measured experiment it is, not as the default.
-static bool mlp_ring_wanted(const gptq_tuning_t* t) { return t && t->path == 7; }
-
 size_t gptq_workspace_bytes_mlp(const gptq_layer_t* gate, const gptq_layer_t* up, const gptq_layer_t* down, int M) {
     return gptq_workspace_bytes_mlp_ex(gate, up, down, M, nullptr);
 }
 
 size_t gptq_workspace_bytes_mlp_ex(const gptq_layer_t* gate, const gptq_layer_t* up, const gptq_layer_t* down, int M, const gptq_tuning_t* tune) {
+    (void)tune;
     if (check_mlp(gate, up, down) != GPTQ_OK || M <= 0) return 0;
-    const MlpPlan mp = mlp_ring_wanted(tune) ? plan_mlp(*gate, *up, *down, M, 0) : MlpPlan{};
-    if (mp.ok) return WS_HEADER_BYTES + mp.exchange_bytes;
     const gptq_layer_t* gu[2] = {gate, up};
     size_t inner = gptq_workspace_bytes_multi_ex(gu, 2, M, nullptr);
     inner = std::max(inner, gptq_workspace_bytes_ex(down, M, nullptr));
@@ -575,19 +569,10 @@ int gptq_mlp_forward_ex(const gptq_layer_t* gate, const gptq_layer_t* up, const 
     if ((rc = check_io(x, out, M))) return rc;
     const WsView wv = split_ws(ws, ws_bytes);
     const size_t have = wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0;
-    const MlpPlan mp = mlp_ring_wanted(tune) ? plan_mlp(*gate, *up, *down, M, 0) : MlpPlan{};
-    if (mlp_ring_wanted(tune) && !mp.ok)
-        return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 7: the one-launch MLP kernel needs M = 1, three plain 4-bit fp16/bf16 layers of one group size "
-                                          "(I <= 16384, K <= 8192, at least one 16-byte column chunk per CU) and gptq_init() on this device");
-    if (mp.ok) {
-        if (wv.body_bytes < mp.exchange_bytes)
-            return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + mp.exchange_bytes, have);
-        hipError_t e = launch_mlp(*gate, *up, *down, mp, x, out, wv.header, wv.body, (hipStream_t)stream);
-        if (e != hipSuccess) return hip_fail(e, "gptq_mlp_forward launch (needs > 64 KiB of LDS: was gptq_init() called on this device?)");
-        return GPTQ_OK;
-    }
-    // Every other case (more than one row of x, act-order or non-4-bit layers, shapes the one-launch kernel does not cover): the same
-    // function as three steps -- gate and up through the multi-layer entry point into two staging buffers at the front of the body,
+    if (tune && tune->path != 0)
+        return fail(GPTQ_ERR_UNSUPPORTED, "gptq_mlp_forward_ex takes no path override (tuning.path = %d): the one-launch persistent kernel of round 3 is a lab now "
+                                          "(tools/lab/mlp_ring.hip), not part of this library", tune->path);
+    // Three steps -- gate and up through the multi-layer entry point (ONE launch for decode rows) into two staging buffers at the front of the body,
     // SiLU * mul in place, down -- each inner call on the ONE ticket header and the body behind the staging buffers.
     const size_t sb = mlp_stage_bytes(gate, M);
     if (wv.body_bytes < 2 * sb)
@@ -610,12 +595,8 @@ int gptq_describe_mlp_plan(const gptq_layer_t* gate, const gptq_layer_t* up, con
     int rc = check_mlp(gate, up, down);
     if (rc) return rc;
     if (M <= 0) return fail(GPTQ_ERR_SHAPE, "M must be > 0, got %d", M);
-    const MlpPlan mp = mlp_ring_wanted(tune) ? plan_mlp(*gate, *up, *down, M, 0) : MlpPlan{};
-    if (mp.ok)
-        snprintf(out, out_bytes, "kernel=mlp_ring launches=1 workgroups=%d waves=16 ring_slots=%d rows_per_dma=%d/%d lds=%zu exchange=%zu", mp.nwg, mp.ns,
-                 1 << mp.lrpiA, 1 << mp.lrpiB, mp.lds_bytes, mp.exchange_bytes);
-    else
-        snprintf(out, out_bytes, "kernel=unfused launches=3+ steps=forward_multi(gate,up)|silu_mul|forward(down)");
+    (void)tune;
+    snprintf(out, out_bytes, "kernel=unfused launches=3+ steps=forward_multi(gate,up)|silu_mul|forward(down)");
     return GPTQ_OK;
 }
 

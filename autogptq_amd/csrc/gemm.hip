@@ -1626,16 +1626,28 @@ __global__ void __launch_bounds__(256) gemm_reduce_kernel(const float* __restric
 // (coalesced 16-byte loads and stores; the gather itself runs on the LDS).
 // SLOT: each 8-chunk is written in the k-slot order of the 4-bit fp16 B fragments (k0,k4,k1,k5,k2,k6,k3,k7), so the tiled
 // GEMM can copy it to LDS verbatim (no v_perm in its K loop).
-template <bool SLOT>
+// x[m, perm[i]] -> out[m, i] for act-order prefill (the role of exllama's column_remap_kernel, exllama/cuda_func/column_remap.cu:9-39).  A 2-byte gather
+// from global memory costs the texture path one address per cycle, so the rows are staged in LDS (coalesced 16-byte loads) and gathered there.
+// Round 4: R rows per workgroup share ONE read of perm[] (16 KiB for K = 4096 -- twice a row of x: with one row per workgroup the index loads were
+// two thirds of the request traffic; 11.7 us = 2.9 TB/s for the 33.5 MB of a 2048 x 4096 x) and the indices stay in registers across the R rows.
+template <bool SLOT, int R>
 __global__ void __launch_bounds__(256) permute_rows_kernel(const unsigned short* __restrict__ x, const int* __restrict__ perm,
                                                            int M, int K, unsigned short* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned short* row = (unsigned short*)smem;
-    for (int m = blockIdx.x; m < M; m += gridDim.x) {
-        for (int i = threadIdx.x * 8; i < K; i += 256 * 8) *(u32x4*)(row + i) = *(const u32x4*)(x + (size_t)m * K + i);
-        __syncthreads();
-        for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
-            const u32x4 p0 = *(const u32x4*)(perm + i), p1 = *(const u32x4*)(perm + i + 4);
+    unsigned short* rows = (unsigned short*)smem;              // [R][K]
+    const int m0 = blockIdx.x * R;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int m = min(m0 + r, M - 1);
+        for (int i = threadIdx.x * 8; i < K; i += 256 * 8) *(u32x4*)(rows + (size_t)r * K + i) = *(const u32x4*)(x + (size_t)m * K + i);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+        const u32x4 p0 = *(const u32x4*)(perm + i), p1 = *(const u32x4*)(perm + i + 4);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (m0 + r >= M) break;
+            const unsigned short* row = rows + (size_t)r * K;
             u32x4 o;
             if constexpr (SLOT) {
                 o[0] = (unsigned)row[p0[0]] | ((unsigned)row[p1[0]] << 16);
@@ -1648,20 +1660,26 @@ __global__ void __launch_bounds__(256) permute_rows_kernel(const unsigned short*
                 o[2] = (unsigned)row[p1[0]] | ((unsigned)row[p1[1]] << 16);
                 o[3] = (unsigned)row[p1[2]] | ((unsigned)row[p1[3]] << 16);
             }
-            *(u32x4*)(out + (size_t)m * K + i) = o;
+            __builtin_nontemporal_store(o, (u32x4*)(out + (size_t)(m0 + r) * K + i));
         }
-        __syncthreads();
     }
 }
 
+template <bool SLOT>
+static void launch_permute_rows_r(const unsigned short* x, const int* perm, int M, int K, unsigned short* out, hipStream_t st) {
+    // rows per workgroup: as many as keep >= 512 workgroups in the launch and <= 64 KiB of LDS (the default dynamic-LDS limit: no per-function grant needed)
+    int r = 1;
+    while (r < 4 && (size_t)(2 * r) * K * 2 <= 64 * 1024 && M / (2 * r) >= 512) r *= 2;
+    const int blocks = (M + r - 1) / r;
+    const size_t lds = (size_t)r * K * 2;
+    if (r == 4) hipLaunchKernelGGL((permute_rows_kernel<SLOT, 4>), dim3(blocks), dim3(256), lds, st, x, perm, M, K, out);
+    else if (r == 2) hipLaunchKernelGGL((permute_rows_kernel<SLOT, 2>), dim3(blocks), dim3(256), lds, st, x, perm, M, K, out);
+    else hipLaunchKernelGGL((permute_rows_kernel<SLOT, 1>), dim3(blocks), dim3(256), lds, st, x, perm, M, K, out);
+}
+
 hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int K, void* x_out, hipStream_t st, bool slot_order) {
-    const int blocks = M < 2048 ? M : 2048;
-    if (slot_order)
-        hipLaunchKernelGGL(permute_rows_kernel<true>, dim3(blocks), dim3(256), (size_t)K * 2, st, (const unsigned short*)x, perm, M, K,
-                           (unsigned short*)x_out);
-    else
-        hipLaunchKernelGGL(permute_rows_kernel<false>, dim3(blocks), dim3(256), (size_t)K * 2, st, (const unsigned short*)x, perm, M, K,
-                           (unsigned short*)x_out);
+    if (slot_order) launch_permute_rows_r<true>((const unsigned short*)x, perm, M, K, (unsigned short*)x_out, st);
+    else launch_permute_rows_r<false>((const unsigned short*)x, perm, M, K, (unsigned short*)x_out, st);
     return hipGetLastError();
 }
 
@@ -1938,8 +1956,7 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.variant = tune ? tune->reserved[3] : 0;            // experiment knob: inner-loop schedule variant
     const int wide_knob = (pl.variant == 44 || pl.variant == 45) ? pl.variant : 0;      // 44 / 45: the 128 x 512 kernel off / forced (A/B runs)
     if (wide_knob) pl.variant = 0;
-    const int tail_knob = (pl.variant >= 40 && pl.variant <= 43) ? pl.variant : 0;      // 40 = balanced tail by the rule below, 41 = off, 42 = the rule without its tile limit (A/B runs),
-                                                                                         // 43 = unrun experiment: a K-split launch combined in the launch (every tile a tail tile) instead of slabs + reduce launch
+    const int tail_knob = (pl.variant >= 40 && pl.variant <= 42) ? pl.variant : 0;      // 40 = balanced tail by the rule below, 41 = off, 42 = the rule without its tile limit (A/B runs)
     if (tail_knob) pl.variant = 0;
     pl.bm = 32 * pl.mt;
     pl.bn = 256;
@@ -1973,15 +1990,6 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     // 124 -> 99, 122 -> 106, 182 -> 153; 4096x11008 M = 768 / 1024 / 1536 / 2304: 106 -> 85, 120 -> 102, 187 -> 161, 242 -> 221;
     // 11008x4096 M = 2176: 281 -> 221.  A tail the model refuses (4096x11008 at M = 2048: 176 tiles) measured 0.97 - 1.0x with two slices.
     pl.tail = 0; pl.tail_lg = 0;
-    if (tail_knob == 43 && pl.ksplit > 1 && pl.mt == 4 && L.N % 256 == 0 && (pl.ksplit & (pl.ksplit - 1)) == 0 && pl.ksplit <= 8 &&
-        pl.ksteps_total % pl.ksplit == 0 && (long)pl.nbm * pl.nbn * 16 * 4 <= (long)WS_HEADER_EPOCH_OFFSET &&
-        (pl.bk == 32 || !pl.use_seq || (pl.xslot && pl.glds) || L.dtype == GPTQ_BF16)) {
-        pl.tail = pl.nbm * pl.nbn;
-        while ((1 << pl.tail_lg) < pl.ksplit) ++pl.tail_lg;
-        pl.ksplit = 1;
-        pl.ksteps_per_split = pl.ksteps_total;
-        pl.workspace_bytes = pl.xperm_bytes + ((size_t)pl.tail << pl.tail_lg) * (32 * 256 * 16);
-    } else
     {
         const long tiles = (long)pl.nbm * pl.nbn, rem = tiles % 256;
         // every 128-row form of the kernel: 4-bit BK = 64 (act-order fp16 only in its DMA-staged form) and the BK = 32 forms of 2- / 3- / 8-bit and g32 layers

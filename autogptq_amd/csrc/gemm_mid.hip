@@ -526,10 +526,14 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
     const size_t pslab = (size_t)p.M * p.nsum;
     bool partials_ready = (p.ksplit == 1 || ks != 0 || p.gran);
     unsigned tag = 0, ep = 0;
-    if (p.ksplit > 1 && p.gran) {                                 // tag = the strip's epoch + 1 in a NaN pattern: no stale granule (older epoch) and no fp32 partial carries it
+    if (p.ksplit > 1) {                                           // the tile's launch epoch: granule tags (tag = epoch + 1 in a NaN pattern) and flag stamps are derived from it
         asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ep) : "s"(p.epochs + tile) : "memory");
         tag = 0x7FE00000u | ((ep + 1u) & 0x1FFFFFu);
     }
+    // Flag combine: a slice's flag word carries THIS launch's stamp (epoch + 1, never 0), not a bare 1.  A producer that arrives after its owner gave up
+    // (bounded wait: another kernel or process held its CU) then leaves a stamp no later launch waits for, instead of a 1 that the next launch on this
+    // tile would take for "published" before the partials are written (round-3 review: persistent silent corruption after one timeout).
+    const unsigned stamp = (ep + 1u) | 0x80000000u;
     bool gave_up = false;
     __syncthreads();                                              // every wave is done with its landing area
     estamp();                                                     // E0: first barrier passed
@@ -553,7 +557,7 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
                 unsigned v = 0;
                 for (unsigned spins = 0;; ++spins) {
                     v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v != 0u) break;
+                    if (v == stamp) break;
                     if (spins > p.max_spins) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
@@ -633,10 +637,11 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
         if (ks != 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every publishing wave drains its write-through stores
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(p.flags + (size_t)tile * 8 + ks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(p.flags + (size_t)tile * 8 + ks, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            __syncthreads();                                      // every partial has been read
+            __syncthreads();                                      // every partial has been read (and every producer has read the epoch: its flag is up)
             if (tid < p.ksplit - 1) __hip_atomic_store(p.flags + (size_t)tile * 8 + 1 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(p.epochs + tile, ep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     estamp();                                                     // E: end
@@ -768,6 +773,7 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
     while (ks > 1 && (long)tiles * ks > 256) --ks;                                     // the owner slice WAITS for the others: every workgroup of the launch must be resident (one per CU, 256 CUs)
     if (ks > S) ks = S;
     if (ks > 1 && (size_t)tiles * 8 * 4 > WS_HEADER_EPOCH_OFFSET) ks = 1;             // 8 flag words per (row block, strip) in the ticket half of the header
+    if (ks > 1 && (size_t)tiles * 4 > WS_HEADER_BYTES - WS_HEADER_TAIL_BYTES - WS_HEADER_EPOCH_OFFSET) ks = 1;   // ... and one epoch word per tile in its second half (flag stamps)
     if (ks < 1) ks = 1;
     pl.ksteps_per_split = (S + ks - 1) / ks;
     pl.ksplit = (S + pl.ksteps_per_split - 1) / pl.ksteps_per_split;                    // no empty slices
@@ -883,10 +889,10 @@ hipError_t launch_mid(const gptq_layer_t* const* Ls, const MidPlan& pl, const vo
     if (pl.ksplit > 1) {
         // the owner slice of a strip WAITS (bounded) for the other slices: every workgroup of the launch must be resident at once -- one per CU (its
         // LDS allows no second).  The planner assumes MI355X's 256 CUs; a device with fewer (partitioned, masked) is refused here, loudly.
+        // (an unknown CU count -- gptq_init() not run on this device -- is refused too: the check must not be skipped silently)
         int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && mlpk::g_cu_count[dev] > 0 &&
-            pl.strips_total * pl.row_blocks * pl.ksplit > mlpk::g_cu_count[dev])
-            return hipErrorLaunchOutOfResources;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || mlpk::g_cu_count[dev] <= 0) return hipErrorNotInitialized;
+        if (pl.strips_total * pl.row_blocks * pl.ksplit > mlpk::g_cu_count[dev]) return hipErrorLaunchOutOfResources;
     }
     midk::MidParams p{};
     int blk = 0, col = 0;

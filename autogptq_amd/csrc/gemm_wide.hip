@@ -74,6 +74,9 @@ template <> struct Deq4<f16> {
         }
     }
     __device__ __forceinline__ u32x4 frag(unsigned q, int col) const {
+#if defined(GPTQ_WIDE_ABL) && (GPTQ_WIDE_ABL & 1)
+        return u32x4{q, q ^ 0x11111111u, q ^ 0x22222222u, q ^ f16x2_bits(s2[col])};      // lab: no dequant math (wrong results by construction)
+#endif
         const unsigned q8 = q >> 8;
         const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
         const f16x2 h0 = as_f16x2(and_or(q, 0x000f000fu, 0x64006400u)) + c1[col];          // k0,k4 : w - z
@@ -262,9 +265,14 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + 1 < KS) {
+#if defined(GPTQ_WIDE_ABL) && (GPTQ_WIDE_ABL & 2)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[(ks + 1) & 1][mt] = a[ks & 1][mt] ^ u32x4{1u, 2u, 3u, (unsigned)ks};   // lab: no A-fragment LDS reads after the first
+#else
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     a[(ks + 1) & 1][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (GLDS ? ((((ks + 1) * 2 + half) ^ a_swz) * 16) : (ks + 1) * 32));
+#endif
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bq[(ks + 1) & 1][nt] = dq_cur.frag(b_use[ks + 1][nt], nt);
             } else {
@@ -272,7 +280,9 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
                 dq_nx.setup(c_fill, zsh, zmask);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bq_first[nt] = dq_nx.frag(b_fill[0][nt], nt);
+#if !(defined(GPTQ_WIDE_ABL) && (GPTQ_WIDE_ABL & 8))
                 if constexpr (!GLDS) store_a(BUF ^ 1, a_next);
+#endif
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -285,7 +295,9 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
         dq_cur = dq_nx;
         // DMA-staged x: the next tile must have landed before anybody passes the barrier; the KS weight loads + 2 constant loads issued behind it may fly on
         if constexpr (GLDS) wait_vmcnt<KS + 2>();
+#if !(defined(GPTQ_WIDE_ABL) && (GPTQ_WIDE_ABL & 4))
         __syncthreads();
+#endif
     };
     for (int kt = 0; kt < kt1; kt += 2) {                       // the planner only sends even step counts here (K % 128 == 0): no conditional second step --
         step(kt, std::integral_constant<int, 0>{}, b0, b1, c1);         // with all 256 accumulator registers live, a phi copy of them has nowhere to go but scratch

@@ -543,8 +543,8 @@ def mlp_forward(gate: QuantLinear, up: QuantLinear, down: QuantLinear, x: torch.
     """``down(silu(gate(x)) * up(x))`` for three mi355x QuantLinears through ONE C-ABI call (gptq_mlp_forward): the role of the
     reference's FusedLlamaMLPForQuantizedModel.forward (auto_gptq/nn_modules/fused_llama_mlp.py:157-242).  gate and up run as one
     multi-layer launch for decode rows, the SiLU * mul on fp32, then down -- any bits / act-order / row count the single layers take,
-    checkpoint tensors untouched, one Python -> C transition instead of three.  ``tuning.path = 7`` selects the experimental
-    one-launch persistent kernel (M = 1, plain 4-bit layers; measured slower than the default)."""
+    checkpoint tensors untouched, one Python -> C transition instead of three.  (Round 3's one-launch persistent kernel was measured slower and is a lab
+    now -- tools/lab/mlp_ring.hip; ``tuning`` with a path override is refused.)"""
     for l in (gate, up, down):
         if l._layer is None:
             l.post_init()
@@ -601,9 +601,10 @@ def mlp_forward(gate: QuantLinear, up: QuantLinear, down: QuantLinear, x: torch.
     return out
 
 
-def mlp_exchange_error(device=None) -> bool:
-    """True if a bounded wait of the one-launch MLP kernel (tuning.path = 7) ever gave up on this device's current-stream workspace:
-    the sticky error word in the workspace header's tail (gptq_mi355x.h).  Synchronises the stream."""
+def exchange_error(device=None) -> bool:
+    """True if a BOUNDED wait of an in-launch exchange (the K-slice combines of the decode and 17..256-row kernels, the balanced tail of the tiled GEMM)
+    ever gave up on this device's current-stream workspace: the sticky error word in the workspace header's tail (gptq_mi355x.h).  A launch whose wait
+    gave up has produced a wrong result; the kernels never hang instead.  Synchronises the stream."""
     device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
     idx = device.index if device.index is not None else torch.cuda.current_device()
     ent = _WORKSPACE.get((idx, int(torch.cuda.current_stream(device).cuda_stream)))
@@ -614,4 +615,7 @@ def mlp_exchange_error(device=None) -> bool:
     return bool(tail[2].item() != 0)
 
 
-__all__ = ["QuantLinear", "reserve_workspace", "forward_multi", "mlp_forward", "mlp_exchange_error"]
+mlp_exchange_error = exchange_error      # round-3 name
+
+
+__all__ = ["QuantLinear", "reserve_workspace", "forward_multi", "mlp_forward", "exchange_error", "mlp_exchange_error"]

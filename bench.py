@@ -149,11 +149,9 @@ def bench_fused(device, n_blocks, steps):
 
 
 def bench_mlp_call(flat_layers, xs, device, steps):
-    """The gated MLP of every block through gptq_mlp_forward (ONE C-ABI call per block: gate|up launch, SiLU*mul, down) and through its
-    opt-in one-launch persistent kernel (tuning.path = 7), each as a hipGraph over all blocks (rotating, HBM-cold weights).  The activation
-    really flows from gate/up into down here (the headline stack feeds down an independent x)."""
-    from autogptq_amd import _lib
-    from autogptq_amd.qlinear_mi355x import mlp_forward, mlp_exchange_error
+    """The gated MLP of every block through gptq_mlp_forward (ONE C-ABI call per block: gate|up launch, SiLU*mul, down) as a hipGraph over all blocks
+    (rotating, HBM-cold weights).  The activation really flows from gate/up into down here (the headline stack feeds down an independent x)."""
+    from autogptq_amd.qlinear_mi355x import mlp_forward, exchange_error
     blocks, i = [], 0
     while i + 2 < len(flat_layers):
         if flat_layers[i][0] == "gate_proj" and flat_layers[i + 1][0] == "up_proj" and flat_layers[i + 2][0] == "down_proj":
@@ -164,26 +162,21 @@ def bench_mlp_call(flat_layers, xs, device, steps):
     x = xs[4096]
     res = {"blocks": len(blocks)}
     wbytes = sum(algorithmic_bytes(4096, 11008, 1) * 2 + algorithmic_bytes(11008, 4096, 1) for _ in blocks[:1])
-    for name, tun in (("default_three_steps", None), ("one_launch_ring_kernel_path7", "ring")):
+    for name in ("default_three_steps",):
         try:
-            t = None
-            if tun:
-                t = _lib.GptqTuning()
-                t.path = 7
             with torch.no_grad():
                 for g_, u_, d_ in blocks:
-                    mlp_forward(g_, u_, d_, x, tuning=t)
+                    mlp_forward(g_, u_, d_, x)
             torch.cuda.synchronize(device)
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr), torch.no_grad():
-                keep = [mlp_forward(g_, u_, d_, x, tuning=t) for g_, u_, d_ in blocks]
+                keep = [mlp_forward(g_, u_, d_, x) for g_, u_, d_ in blocks]
             for _ in range(3):
                 gr.replay()
             _, ev = time_graph(gr, max(3, steps // 2), device)
             per = ev / (max(3, steps // 2) * len(blocks))
-            res[name] = {"us_per_mlp": round(per * 1e6, 2), "GB_per_s": round(wbytes / per / 1e9, 1), "frac": round(wbytes / per / 1e9 / HBM_PEAK_GBS, 4)}
-            if tun:
-                res[name]["bounded_wait_gave_up"] = bool(mlp_exchange_error(device))
+            res[name] = {"us_per_mlp": round(per * 1e6, 2), "GB_per_s": round(wbytes / per / 1e9, 1), "frac": round(wbytes / per / 1e9 / HBM_PEAK_GBS, 4),
+                         "bounded_wait_gave_up": bool(exchange_error(device))}
             del gr, keep
         except Exception as e:
             res[name] = {"error": repr(e)[:200]}

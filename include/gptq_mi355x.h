@@ -51,13 +51,13 @@
  *     {value, tag} granules through the body and are validated by their tag), and in the last 64 bytes the
  *     launch epoch / arrival count / sticky error word ([2]: a bounded wait gave up) of the exchanges.
  *     One workspace serves one stream at a time (launches that may overlap need their own).  Kernels are enqueued on the caller's stream, never synchronise,
- *     and are legal inside hipGraph capture: the forward entry points make no runtime-API call
- *     besides the kernel launches.  No global mutable state in the library; the one per-device
- *     setting it needs (kernels with > 64 KiB of dynamic LDS) is applied by gptq_init(), which the
- *     caller runs once per device, outside any capture, before the first forward.
- *   - results are run-to-run deterministic (no floating-point atomics, fixed summation orders).  The one exception is the opt-in
- *     experimental kernel of gptq_mlp_forward_ex (tuning.path = 7): its waves draw their work from a counter, so the fp32 summation
- *     order may differ between launches (last-bit differences).
+ *     and are legal inside hipGraph capture: besides the kernel launches the forward entry points make one kind of runtime-API call, hipGetDevice(), and only
+ *     for launches whose workgroups wait for each other inside the launch (K slices of the 17..256-row kernel): their grid is checked against the CU count.
+ *     Process-global state of the library: the per-device CU count and the > 64 KiB dynamic-LDS grants, both written once per device by gptq_init(), which
+ *     the caller runs once per device, outside any capture, before the first forward (a launch that needs the CU count and does not find it is refused).
+ *     A bounded wait inside a launch that gives up (another process held the CUs) sets word [2] of the header's last 64 bytes and never hangs the queue:
+ *     that launch's result is wrong and the word stays set -- poll it (autogptq_amd.qlinear_mi355x.exchange_error) where CUs are shared.
+ *   - results are run-to-run deterministic (no floating-point atomics, fixed summation orders): every entry point is bit-reproducible.
  */
 #ifndef GPTQ_MI355X_H
 #define GPTQ_MI355X_H
@@ -128,13 +128,28 @@ typedef struct gptq_layer_t {
 
 #define GPTQ_STRIP_COLS 16
 
-/* Optional launch-shape override for experiments; NULL / zero fields = built-in heuristic. */
+/* Kernel families a caller may force with gptq_tuning_t.path ("does not fit" is then an error instead of a silent fallback). */
+typedef enum gptq_path_t {
+    GPTQ_PATH_AUTO = 0,           /* the planner's choice */
+    GPTQ_PATH_GEMV_GENERIC = 1,   /* fp32-math GEMV: any bits / dtype / raw act-order g_idx */
+    GPTQ_PATH_GEMV_LDS = 2,       /* round-1 LDS-staged 4-bit fp16 GEMV (comparison variant) */
+    GPTQ_PATH_GEMM = 3,           /* the MFMA GEMMs (tiled, wide, strips, 17..256-row kernel: the planner picks among them) */
+    GPTQ_PATH_GEMV_DIRECT = 4,    /* register GEMV with the v_dot2 reduction (comparison variant) */
+    GPTQ_PATH_GEMV_MFMA = 5,      /* matrix-core GEMV on the checkpoint layout (4-bit fp16 / bf16 kernel, or the 2/3/8-bit one) */
+    GPTQ_PATH_GEMV_STREAM = 6,    /* streamed (LDS-DMA) GEMV on the checkpoint layout */
+    GPTQ_PATH_GEMV_DECODE_COPY = 8 /* decode kernel on the load-time decode copy (qweight_tiled / qconst_tiled) */
+} gptq_path_t;
+
+/* Optional launch-shape override; NULL = the planner's choice, which is what a drop-in caller passes.  lanes_n / waves / ksplit / path force a documented
+ * geometry or kernel family.  reserved[] must be zero for a drop-in caller: the measurement tools under tools/ and the forced-geometry grids of the test
+ * suite use these four words as LAB switches (A/B runs, ablations); their slots and values are named in include/gptq_mi355x_lab.h and are not part of
+ * the drop-in contract. */
 typedef struct gptq_tuning_t {
-    int32_t lanes_n;     /* lanes of a wave laid along N (4,8,16,64); 4 columns per lane */
+    int32_t lanes_n;     /* checkpoint-layout GEMVs: lanes of a wave laid along N (4, 8, 16, 64); 4 columns per lane */
     int32_t waves;       /* waves per workgroup (1..16) */
     int32_t ksplit;      /* workgroups along K (1 = no cross-workgroup reduction) */
-    int32_t path;        /* 0 auto, 1 generic GEMV, 2 LDS-staged q4/fp16 GEMV, 3 MFMA GEMM, 4 direct q4/fp16 GEMV, 5 matrix-core GEMV (4-bit fp16 / bf16 kernel, or the 2/3/8-bit one), 6 streamed (LDS-DMA) q4 GEMV, 7 (gptq_mlp_forward_ex only) the one-launch persistent MLP kernel */
-    int32_t reserved[4]; /* [0]: max packed rows per lane and iteration for the register-direct GEMVs, = rows per lane for the streamed one, = K-steps per burst for the batched-decode kernel (0 = heuristic); [1]: 32 = force the 32-deep K-step in the MFMA GEMM, 1 = field-by-field decode in the 3- / 8-bit fp16 matrix-core GEMV instead of the packed magic-number one (A/B runs); [2]: 1 = force the 64-column skinny GEMM, 2 = force the tiled GEMM, 3 = force the 16-column-strip GEMM (4-bit, M <= 64), 4 = force the streamed 64-column-strip batched-decode GEMM (4-bit, M <= 64; waves / ksplit apply), 5 = force the 17..128-row kernel (gemm_mid_kernel: 4-bit, N % 64 == 0, M <= 128; ksplit applies, [0] = stages in flight 2..3, [1] = 1: x through registers instead of LDS DMA, 3: granule instead of flag combine, [3] = 2: 128-column strips for M <= 64); [3]: tiled-GEMM inner-loop schedule variant; 40 / 41 = balanced tail of the tiled GEMM by the planner's rule / off (the rule is the default), 42 = the rule without its 1024-tile limit, 43 = experiment: a K-split launch combined inside the launch */
+    int32_t path;        /* gptq_path_t */
+    int32_t reserved[4]; /* 0; lab switches: gptq_mi355x_lab.h */
 } gptq_tuning_t;
 
 int         gptq_abi_version(void);
@@ -182,18 +197,15 @@ int gptq_forward_multi_ex(const gptq_layer_t *const *layers, int n_layers, const
  * inside + c_proj).  gate and up are [K -> I], down is [I -> N]; plain layers (epilogue NONE), checkpoint tensors untouched; any bits / dtype /
  * act-order the single-layer entry points take.  Default: gate and up through gptq_forward_multi (one launch for decode rows) into two staging
  * buffers in the workspace, SiLU * mul (silu and the product on fp32, rounded once to the layer dtype, as fused_llama_mlp.py:237-239), down.
- * tuning.path = 7 (gptq_mlp_forward_ex; EXPERIMENTAL, measured slower than the default on MI355X -- kept opt-in): M = 1 with three plain 4-bit
- * fp16/bf16 layers of one group size (I <= 16384, K <= 8192) as ONE persistent launch -- one workgroup per CU streams its share of gate and up
- * through an LDS ring that runs on into its rows of `down` while the activation is exchanged through the workspace as self-validating 8-byte
- * granules (no grid barrier, every wait bounded: if a wait ever gives up, word [2] of the header's last 64 bytes is set and stays set).  It needs
- * every workgroup resident at once: gptq_init() records the device's CU count and nothing else may pin whole CUs for the duration of the call. */
+ * gptq_mlp_forward_ex takes no path override (round 3's one-launch persistent kernel was measured slower than these three steps and is a lab now:
+ * tools/lab/mlp_ring.hip); it exists for signature symmetry with the other _ex entry points. */
 size_t gptq_workspace_bytes_mlp(const gptq_layer_t *gate, const gptq_layer_t *up, const gptq_layer_t *down, int M);
 size_t gptq_workspace_bytes_mlp_ex(const gptq_layer_t *gate, const gptq_layer_t *up, const gptq_layer_t *down, int M, const gptq_tuning_t *tuning);
 int gptq_mlp_forward(const gptq_layer_t *gate, const gptq_layer_t *up, const gptq_layer_t *down, const void *x, void *out, int M,
                      void *workspace, size_t workspace_bytes, void *stream);
 int gptq_mlp_forward_ex(const gptq_layer_t *gate, const gptq_layer_t *up, const gptq_layer_t *down, const void *x, void *out, int M,
                         void *workspace, size_t workspace_bytes, void *stream, const gptq_tuning_t *tuning);
-/* Host-only: "kernel=mlp_ring launches=1 workgroups=256 ..." or "kernel=unfused ..." for (gate, up, down, M, tuning); as gptq_describe_plan. */
+/* Host-only: "kernel=unfused launches=3+ steps=..." for (gate, up, down, M, tuning); as gptq_describe_plan. */
 int gptq_describe_mlp_plan(const gptq_layer_t *gate, const gptq_layer_t *up, const gptq_layer_t *down, int M, const gptq_tuning_t *tuning, char *out,
                            size_t out_bytes);
 

@@ -14,6 +14,7 @@
 
 #include "common.cuh"
 #include "launch.h"
+#include "lab_launch.h"
 
 namespace gptq {
 

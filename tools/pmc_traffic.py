@@ -21,10 +21,10 @@ from rocprof_summary import demangle
 def per_kernel(db, counter):
     c = sqlite3.connect(db)
     rows = c.execute(
-        "select k.name, k.grid_x, k.grid_y, k.workgroup_x, avg(p.counter_value), count(*) from pmc_events p join kernels k "
-        "on p.dispatch_id = k.dispatch_id where p.counter_name = ? and k.name like '%gptq%' group by k.name, k.grid_x, k.grid_y, k.workgroup_x",
+        "select k.name, k.grid_x, k.grid_y, k.workgroup_x, avg(p.counter_value), count(*), k.lds_size from pmc_events p join kernels k "
+        "on p.dispatch_id = k.dispatch_id where p.counter_name = ? and k.name like '%gptq%' group by k.name, k.grid_x, k.grid_y, k.workgroup_x, k.lds_size",
         (counter,)).fetchall()
-    return {(r[0], r[1], r[2], r[3]): (r[4], r[5]) for r in rows}
+    return {(r[0], r[1], r[2], r[3], r[6]): (r[4], r[5]) for r in rows}
 
 
 def main():
@@ -41,7 +41,7 @@ def main():
     shapes = [tuple(map(int, s.split("x"))) for s in args.shapes.split(",")]
     out = []
     for key, (kib, n) in sorted(fetch.items()):
-        name, gx, gy, wg = key
+        name, gx, gy, wg, lds = key
         name = demangle(name)
         blocks = gx // wg
         ent = {"kernel": name.split("(")[0].replace("void ", ""), "grid_blocks": [blocks, gy], "workgroup": wg, "dispatches": n,
@@ -51,6 +51,12 @@ def main():
         ent["hbm_bytes_per_launch"] = ent["fetch_bytes_x2"] + (int(w[0] * 1024) if w else 0)
         # label with (K, N, M): the launch geometries bench.py produces (decode: M = 1; prefill: --prefill-m rows)
         ent["K"] = ent["N"] = ent["M"] = None
+        ent["lds_bytes"] = lds
+        if "gemv_q4_tiled_kernel" in name:
+            # decode-copy kernel (round 4): one 16-column strip per workgroup -> N = strips * 16 (a multi-layer launch: the summed width); the staged x
+            # (K * 2 bytes of LDS) tells the 4096-deep layers from the 11008-deep one
+            ent["N"], ent["M"] = blocks * 16, args.m
+            ent["K"] = 11008 if lds and lds > 20000 else 4096
         if "gemv_q4_stream_kernel" in name:
             # streamed GEMV: (workgroups, threads) -> launch; multi-layer launches are labelled with the summed width
             geo = {(192, 1024): (4096, 12288), (688, 512): (4096, 22016), (688, 256): (4096, 22016), (172, 1024): (4096, 11008)}
@@ -68,6 +74,9 @@ def main():
                     ent["K"] = max(cands)
                 elif "mfma_kernel<4, 1, 2," in name:
                     ent["K"] = min(cands)
+            if "gemm_wide_kernel" in name and args.prefill_m:   # 128 x 512 workgroup tiles (bench: M = 4096 on 4096 x 4096)
+                if blocks == -(-4096 // 128) * -(-N // 512) and N == 4096:
+                    ent["N"], ent["M"], ent["K"] = N, 4096, 4096
             if "gemm_kernel" in name and args.prefill_m:        # 128 x 256 workgroup tiles
                 if blocks == -(-args.prefill_m // 128) * -(-N // 256):
                     ent["N"], ent["M"] = N, args.prefill_m

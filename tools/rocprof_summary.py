@@ -63,8 +63,8 @@ def main():
     rows = cur.execute(
         "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
         "grid_x, grid_y, grid_z, workgroup_x, max(lds_size), max(vgpr_count), "
-        "max(accum_vgpr_count), max(sgpr_count) from kernels group by name, grid_x, grid_y, grid_z, workgroup_x "
-        "order by sum(duration) desc").fetchall()      # one row per (kernel, launch geometry): layer shapes stay apart
+        "max(accum_vgpr_count), max(sgpr_count) from kernels group by name, grid_x, grid_y, grid_z, workgroup_x, lds_size "
+        "order by sum(duration) desc").fetchall()      # one row per (kernel, launch geometry, LDS bytes): layer shapes stay apart
     total = sum(r[2] for r in rows) or 1
     print(f"# source: {args.db}")
     print(f"# {'calls':>6} {'total_ms':>9} {'%':>5} {'avg_us':>8} {'min_us':>8} {'max_us':>8}  grid(x,y,z)/wg  lds  vgpr agpr sgpr  kernel")
