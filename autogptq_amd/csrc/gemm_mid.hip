@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
     // Flag combine: a slice's flag word carries THIS launch's stamp (epoch + 1, never 0), not a bare 1.  A producer that arrives after its owner gave up
     // (bounded wait: another kernel or process held its CU) then leaves a stamp no later launch waits for, instead of a 1 that the next launch on this
     // tile would take for "published" before the partials are written (round-3 review: persistent silent corruption after one timeout).
-    const unsigned stamp = (ep + 1u) | 0x80000000u;
+    const unsigned fstamp = (ep + 1u) | 0x80000000u;
     bool gave_up = false;
     __syncthreads();                                              // every wave is done with its landing area
     estamp();                                                     // E0: first barrier passed
@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
                 unsigned v = 0;
                 for (unsigned spins = 0;; ++spins) {
                     v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v == stamp) break;
+                    if (v == fstamp) break;
                     if (spins > p.max_spins) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
@@ -637,7 +637,7 @@ __global__ void __launch_bounds__(512) gemm_mid_kernel(MidParams p) {
         if (ks != 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every publishing wave drains its write-through stores
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(p.flags + (size_t)tile * 8 + ks, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(p.flags + (size_t)tile * 8 + ks, fstamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             __syncthreads();                                      // every partial has been read (and every producer has read the epoch: its flag is up)
             if (tid < p.ksplit - 1) __hip_atomic_store(p.flags + (size_t)tile * 8 + 1 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
