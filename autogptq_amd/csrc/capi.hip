@@ -357,7 +357,7 @@ static int forward_impl(const gptq_layer_t* L, const void* x, void* out, int M, 
             return tiled_call(one, 1, x, outs, M, wv, stream, tune);
         }
         if (tune && tune->path == 8)
-            return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: the decode-copy kernel needs M <= 4 and a plain 4-bit fp16/bf16 layer that carries qweight_tiled / qconst_tiled "
+            return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: the decode-copy kernel needs M <= 4 and a plain 3/4/8-bit fp16/bf16 layer that carries qweight_tiled / qconst_tiled "
                                               "(gptq_prepack_decode; tiled_cols = %d)", GPTQ_STRIP_COLS);
     }
     if (L->epilogue != GPTQ_EPI_NONE && !fused_epilogue_ok(L, M, tune)) {
@@ -686,7 +686,7 @@ int gptq_resequence_qweight(const uint32_t* qweight, const int32_t* perm, int K,
     return GPTQ_OK;
 }
 
-// the layer as the decode copy sees it: plain 4-bit, source rows = qweight_seq when the layer has one
+// the layer as the decode copy sees it: plain 3/4/8-bit, source rows = qweight_seq when the layer has one
 static int decode_copy_source(const gptq_layer_t* L, gptq_layer_t* S) {
     int rc = check_layer(L);
     if (rc) return rc;
@@ -696,7 +696,7 @@ static int decode_copy_source(const gptq_layer_t* L, gptq_layer_t* S) {
     S->tiled_cols = GPTQ_STRIP_COLS;
     S->epilogue = GPTQ_EPI_NONE;                             // a [gate | up] layer with the fused epilogue has no decode copy of its own (its halves do)
     if (L->epilogue != GPTQ_EPI_NONE || !tiled_layer_ok(*S))
-        return fail(GPTQ_ERR_UNSUPPORTED, "the decode copy needs a plain 4-bit fp16/bf16 layer, group_size %% 32 == 0 with group_size / 32 a power of two (or group_size >= K), "
+        return fail(GPTQ_ERR_UNSUPPORTED, "the decode copy needs a plain 3-, 4- or 8-bit fp16/bf16 layer, group_size a power-of-two multiple of 32 (16 at 8 bits) or >= K, "
                                           "and no raw act-order g_idx (bits=%d dtype=%d group_size=%d)", L->bits, L->dtype, L->group_size);
     return GPTQ_OK;
 }
@@ -707,8 +707,8 @@ int gptq_prepack_decode_bytes(const gptq_layer_t* L, size_t* tiled_bytes, size_t
     if (!tiled_bytes || !const_bytes) return fail(GPTQ_ERR_NULL, "tiled_bytes/const_bytes must be non-NULL");
     gptq_layer_t S;
     if (int rc = decode_copy_source(L, &S)) return rc;
-    *tiled_bytes = (size_t)((L->K + 127) / 128) * 1024 * (size_t)(L->N / GPTQ_STRIP_COLS);
-    *const_bytes = (size_t)((L->K + L->group_size - 1) / L->group_size) * 48 * (size_t)(L->N / GPTQ_STRIP_COLS);
+    *tiled_bytes = tiled_weight_bytes(*L);
+    *const_bytes = tiled_const_bytes(*L);
     return GPTQ_OK;
 }
 
@@ -718,7 +718,7 @@ int gptq_prepack_decode(const gptq_layer_t* L, uint32_t* tiled_out, void* const_
     if (int rc = decode_copy_source(L, &S)) return rc;
     const uint32_t* src = L->qweight_seq ? L->qweight_seq : L->qweight;
     if (tiled_out == src || tiled_out == L->qweight) return fail(GPTQ_ERR_UNSUPPORTED, "gptq_prepack_decode does not work in place (the checkpoint tensors are never rewritten)");
-    hipError_t e = launch_prepack_decode(src, L->qzeros, L->scales, L->K, L->N, L->group_size, L->zero_mode, tiled_out, const_out, (hipStream_t)stream);
+    hipError_t e = launch_prepack_decode(src, L->qzeros, L->scales, L->K, L->N, L->bits, L->group_size, L->zero_mode, tiled_out, const_out, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "gptq_prepack_decode launch");
     return GPTQ_OK;
 }

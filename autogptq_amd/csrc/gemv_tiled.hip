@@ -52,13 +52,36 @@ struct TiledParams {
     TiledSeg seg[4];
 };
 
-template <int MT, int U, typename T, int MAXW>
-__global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_q4_tiled_kernel(TiledParams p) {
+// Per packing: what a lane of one chunk load holds.  The chunk is always 4 k-slots x 16 columns; a lane (k-slot, column) holds WPL consecutive words =
+// KPL consecutive k of ONE column, re-encoded at load time (gptq_prepack_decode) so that the packed fp16 magic-number extraction yields the k pairs in
+// the order x lies in memory:
+//   4-bit  4 words = 32 k; stored nibbles k0 k2 k4 k6 k1 k3 k5 k7 per word
+//   8-bit  4 words = 16 k; stored bytes   k0 k2 k1 k3 per word
+//   3-bit  3 words = 32 k (one packing unit, re-encoded without straddlers): word j holds the pairs p = 5 j + i (i = 0..4) = (k 2p, k 2p + 1) at bit 3 i of
+//          its low / high half; bits 15 and 31 of the three words are the bits of k30 / k31.
+template <int BITS> struct TiledFmt;
+template <> struct TiledFmt<4> { static constexpr int WPL = 4, KPL = 32, REC = 48, ZB = 1; };
+template <> struct TiledFmt<8> { static constexpr int WPL = 4, KPL = 16, REC = 64, ZB = 2; };
+template <> struct TiledFmt<3> { static constexpr int WPL = 3, KPL = 32, REC = 48, ZB = 1; };
+
+template <int N_> struct WordsOf { typedef unsigned type __attribute__((ext_vector_type(N_))); };
+
+template <int BITS, int MT, int U, typename T, int MAXW>
+__global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kernel(TiledParams p) {
     constexpr bool BF = std::is_same_v<T, bf16>;
-    unsigned m_lo, m_hi, magic;                                                   // opaque constants: (q & mask) | magic is ONE v_and_or_b32 (gemv.hip)
+    using F = TiledFmt<BITS>;
+    constexpr int WPL = F::WPL, KPL = F::KPL, CKE = 4 * KPL, CHB = 64 * WPL * 4, REC = F::REC, NX = KPL / 8;      // k per chunk, bytes per chunk, x pieces per lane and chunk
+    constexpr int LKPL = KPL == 32 ? 5 : 4;
+    typedef typename WordsOf<WPL>::type qvec;
+    unsigned m_lo, m_hi, m_b, magic;                                              // opaque constants: (q & mask) | magic is ONE v_and_or_b32 (gemv.hip)
     asm("s_mov_b32 %0, 0x000f000f" : "=s"(m_lo));
     asm("s_mov_b32 %0, 0x00f000f0" : "=s"(m_hi));
+    asm("s_mov_b32 %0, 0x00ff00ff" : "=s"(m_b));
     asm("v_mov_b32 %0, 0x64006400" : "=v"(magic));
+    unsigned m3a, m3b, m3c;
+    asm("s_mov_b32 %0, 0x00070007" : "=s"(m3a));
+    asm("s_mov_b32 %0, 0x00380038" : "=s"(m3b));
+    asm("s_mov_b32 %0, 0x01c001c0" : "=s"(m3c));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                    // scalar: the staging loops below are scalar loops
@@ -76,14 +99,14 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_q4_tiled_k
     const int strip = sidx - (s == 0 ? 0 : (s == 1 ? be0 : (s == 2 ? be1 : be2)));
     const int N = sg.N;
     const int cb = ks * cps, ce = min(cb + cps, nchunks);                         // this slice's chunks
-    const int kbeg = cb * 128, kend = min(ce * 128, K);                          // ... and its k range: what is staged of x
-    // LDS: [x: MT rows of (kend - kbeg) values, row stride + 16 B][constants: G x 48 B][cross-wave sums]
-    char* const xs = smem;                                                        // row stride xstride = chunks_per_split * 256 + 16 bytes: the 4 rows of a 4-lane group hit different banks
+    const int kbeg = cb * CKE, kend = min(ce * CKE, K);                           // ... and its k range: what is staged of x
+    // LDS: [x: MT rows of (kend - kbeg) values, row stride + 16 B][constants: G x REC bytes][cross-wave sums]
+    char* const xs = smem;                                                        // row stride xstride = chunks_per_split * CKE * 2 + 16 bytes: the 4 rows of a 4-lane group hit different banks
     char* const cs = smem + (size_t)MT * xstride;
-    float* const red = (float*)(cs + (size_t)G * 48);
-    const char* const cg = (const char*)sg.cst + (size_t)strip * G * 48;          // this strip's constants: one contiguous run
-    const char* const tb = (const char*)(sg.tq + (size_t)strip * nchunks * 256);  // this strip's weights: one contiguous run
-    const unsigned t_lane = (unsigned)lane * 16u;
+    float* const red = (float*)(cs + (((size_t)G * REC + 15) & ~(size_t)15));
+    const char* const cg = (const char*)sg.cst + (size_t)strip * G * REC;         // this strip's constants: one contiguous run
+    const char* const tb = (const char*)sg.tq + (size_t)strip * nchunks * CHB;    // this strip's weights: one contiguous run
+    const unsigned t_lane = (unsigned)lane * (WPL * 4u);
     // ---- stage x and the constants by LDS DMA: no VGPRs, issued FIRST (loads return in issue order), waited for behind the first weight burst
     {
         const unsigned xs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)xs, cs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cs;
@@ -94,22 +117,30 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_q4_tiled_k
             for (int pc0 = wave * 64; pc0 < pieces; pc0 += W * 64)                // wave-uniform trip count
                 if (pc0 + lane < pieces) lds_dma16(xr + (size_t)(pc0 + lane) * 16, xs_lds + m * xstride + pc0 * 16);      // default cache policy: every workgroup reads x
         }
-        const int cpieces = G * 3;
+        const int cpieces = (G * REC) >> 4;                                       // REC is a multiple of 16
         for (int pc0 = wave * 64; pc0 < cpieces; pc0 += W * 64)
             if (pc0 + lane < cpieces) dma16_nt(cg + (size_t)(pc0 + lane) * 16, __builtin_amdgcn_readfirstlane(cs_lds + pc0 * 16));
     }
-    const char* const xl = xs + (size_t)min(lane & 3, MT - 1) * xstride + kb * 64;    // A operand: lane i of a 4-lane group carries x row i
+    const char* const xl = xs + (size_t)min(lane & 3, MT - 1) * xstride + kb * (KPL * 2);    // A operand: lane i of a 4-lane group carries x row i
     float acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = 0.f;
-    const f16x2 k960 = {(f16)960.f, (f16)960.f};
-    const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+    const f16x2 k960 = {(f16)960.f, (f16)960.f}, k896 = {(f16)896.f, (f16)896.f}, k1008 = {(f16)1008.f, (f16)1008.f};
+    const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f}, r8 = {(f16)0.125f, (f16)0.125f}, r64 = {(f16)0.015625f, (f16)0.015625f};
+    auto bits_of = [&](f16x2 hv) -> unsigned {                                    // the pair as the matrix core takes it: fp16, or fp16 -> fp32 -> bf16 (exact: small integers)
+        if constexpr (BF) {
+            const bf16x2 o = {(bf16)(float)hv[0], (bf16)(float)hv[1]};
+            return __builtin_bit_cast(unsigned, o);
+        } else {
+            return __builtin_bit_cast(unsigned, hv);
+        }
+    };
     bool staged = false;
     for (int cbase = cb; cbase < ce; cbase += W * U) {
         const int c0 = cbase + wave * U;
-        u32x4 q[U];
+        qvec q[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) q[j] = __builtin_nontemporal_load((const u32x4*)(tb + ((unsigned)min(c0 + j, ce - 1) * 1024u + t_lane)));
+        for (int j = 0; j < U; ++j) q[j] = __builtin_nontemporal_load((const qvec*)(tb + ((unsigned)min(c0 + j, ce - 1) * (unsigned)CHB + t_lane)));
         if (!staged) {                                                            // first pass only (uniform): the staging DMAs are OLDER than the U loads just issued
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(U) : "memory");
             __syncthreads();
@@ -118,41 +149,58 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_q4_tiled_k
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int cc = min(c0 + j, ce - 1);
-            const int k0 = cc * 128 + kb * 32;                                    // first k of this lane's 4 words
-            const bool live = (c0 + j < ce) && (k0 < K);                          // a ragged last chunk (K % 128 != 0): whole k-slots are missing
-            const int g = min(k0 >> 5 >> gshift, G - 1);
-            const char* cp = cs + g * 48;
+            const int k0 = cc * CKE + kb * KPL;                                   // first k of this lane's words
+            const bool live = (c0 + j < ce) && (k0 < K);                          // a ragged last chunk: whole k-slots are missing
+            const int g = min(k0 >> LKPL >> gshift, G - 1);
+            const char* cp = cs + g * REC;
             const unsigned short sraw = *(const unsigned short*)(cp + col * 2);
-            const unsigned z = *(const unsigned char*)(cp + 32 + col);
-            u32x4 xa[4];
+            unsigned z;
+            if constexpr (F::ZB == 1) z = *(const unsigned char*)(cp + 32 + col);
+            else z = *(const unsigned short*)(cp + 32 + col * 2);
+            u32x4 xa[NX];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) xa[w] = *(const u32x4*)(xl + ((unsigned)(cc - cb) * 256u + w * 16u));
+            for (int w = 0; w < NX; ++w) xa[w] = *(const u32x4*)(xl + ((unsigned)(cc - cb) * (unsigned)(CKE * 2) + w * 16u));
             const f16x2 c1 = as_f16x2(z * 0x00010001u + 0xE400E400u);            // -(1024 + z)
-            const f16x2 c2 = c1 + k960;                                           // -(64 + z)
-            const u32x4 qv = q[j];
+            const qvec qv = q[j];
             f32x4 accg = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (BITS == 4) {
+                const f16x2 c2 = c1 + k960;                                       // -(64 + z)
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const unsigned qw = qv[w], q8 = qw >> 8;
-                const f16x2 h0 = as_f16x2((qw & m_lo) | magic) + c1;              // k0,k1  (stored nibbles 0 and 4)
-                const f16x2 h1 = as_f16x2((qw & m_hi) | magic) * r16 + c2;        // k2,k3  (1 and 5)
-                const f16x2 h2 = as_f16x2((q8 & m_lo) | magic) + c1;              // k4,k5  (2 and 6)
-                const f16x2 h3 = as_f16x2((q8 & m_hi) | magic) * r16 + c2;        // k6,k7  (3 and 7)
-                u32x2 b01, b23;
-                if constexpr (BF) {
-                    // fp16 -> fp32 -> bf16 per pair (exact: integers in [-16, 15]); gfx950 has no packed bf16 arithmetic
-                    auto to_bf = [&](f16x2 hv) -> unsigned {
-                        const bf16x2 o = {(bf16)(float)hv[0], (bf16)(float)hv[1]};
-                        return __builtin_bit_cast(unsigned, o);
-                    };
-                    b01 = u32x2{to_bf(h0), to_bf(h1)};
-                    b23 = u32x2{to_bf(h2), to_bf(h3)};
-                } else {
-                    b01 = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
-                    b23 = u32x2{__builtin_bit_cast(unsigned, h2), __builtin_bit_cast(unsigned, h3)};
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned qw = qv[w], q8 = qw >> 8;
+                    const f16x2 h0 = as_f16x2((qw & m_lo) | magic) + c1;          // k0,k1  (stored nibbles 0 and 4)
+                    const f16x2 h1 = as_f16x2((qw & m_hi) | magic) * r16 + c2;    // k2,k3  (1 and 5)
+                    const f16x2 h2 = as_f16x2((q8 & m_lo) | magic) + c1;          // k4,k5  (2 and 6)
+                    const f16x2 h3 = as_f16x2((q8 & m_hi) | magic) * r16 + c2;    // k6,k7  (3 and 7)
+                    accg = Mma4<T>::run(u32x2{xa[w][0], xa[w][1]}, u32x2{bits_of(h0), bits_of(h1)}, accg);
+                    accg = Mma4<T>::run(u32x2{xa[w][2], xa[w][3]}, u32x2{bits_of(h2), bits_of(h3)}, accg);
                 }
-                accg = Mma4<T>::run(u32x2{xa[w][0], xa[w][1]}, b01, accg);
-                accg = Mma4<T>::run(u32x2{xa[w][2], xa[w][3]}, b23, accg);
+            } else if constexpr (BITS == 8) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {                                     // one word = 4 k = one matrix-core step
+                    const unsigned qw = qv[w], q8 = qw >> 8;
+                    const f16x2 h0 = as_f16x2((qw & m_b) | magic) + c1;           // k0,k1  (stored bytes 0 and 2)
+                    const f16x2 h1 = as_f16x2((q8 & m_b) | magic) + c1;           // k2,k3  (1 and 3)
+                    accg = Mma4<T>::run(u32x2{xa[w >> 1][(w & 1) * 2], xa[w >> 1][(w & 1) * 2 + 1]}, u32x2{bits_of(h0), bits_of(h1)}, accg);
+                }
+            } else {
+                const f16x2 c3 = c1 + k896;                                       // -(128 + z): fields at bit 3, times 1/8
+                const f16x2 c6 = c1 + k1008;                                      // -(16 + z): fields at bit 6, times 1/64
+                unsigned pr[16];                                                  // the 16 k pairs of the unit, in k order
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const unsigned t = qv[w], t6 = t >> 6;
+                    pr[5 * w + 0] = bits_of(as_f16x2((t & m3a) | magic) + c1);
+                    pr[5 * w + 1] = bits_of(as_f16x2((t & m3b) | magic) * r8 + c3);
+                    pr[5 * w + 2] = bits_of(as_f16x2((t & m3c) | magic) * r64 + c6);
+                    pr[5 * w + 3] = bits_of(as_f16x2((t6 & m3b) | magic) * r8 + c3);
+                    pr[5 * w + 4] = bits_of(as_f16x2((t6 & m3c) | magic) * r64 + c6);
+                }
+                const unsigned e = ((qv[0] >> 15) & 0x00010001u) | ((qv[1] >> 14) & 0x00020002u) | ((qv[2] >> 13) & 0x00040004u);   // (k30 | k31 << 16): bits 15 / 31 of the three words
+                pr[15] = bits_of(as_f16x2(e | magic) + c1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    accg = Mma4<T>::run(u32x2{xa[i >> 1][(i & 1) * 2], xa[i >> 1][(i & 1) * 2 + 1]}, u32x2{pr[2 * i], pr[2 * i + 1]}, accg);
             }
             const float sc = DType<T>::to_f32(__builtin_bit_cast(T, sraw));
 #pragma unroll
@@ -178,13 +226,27 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_q4_tiled_k
 }
 
 // ---- plan + launch ---------------------------------------------------------------------------------------------------------------------
+static int tiled_kpl(int bits) { return bits == 8 ? 16 : 32; }          // k per lane and chunk
+static int tiled_chunk_bytes(int bits) { return bits == 3 ? 768 : 1024; }
+static int tiled_rec_bytes(int bits) { return bits == 8 ? 64 : 48; }
+
 bool tiled_layer_ok(const gptq_layer_t& L) {
-    if (!L.qweight_tiled || !L.qconst_tiled || L.tiled_cols != GPTQ_STRIP_COLS || L.epilogue != GPTQ_EPI_NONE || L.bits != 4) return false;
-    if (L.g_idx != nullptr && !(L.qweight_seq && L.perm)) return false;           // raw act-order: per-k groups
+    if (!L.qweight_tiled || !L.qconst_tiled || L.tiled_cols != GPTQ_STRIP_COLS || L.epilogue != GPTQ_EPI_NONE) return false;
+    if (L.bits != 4 && L.bits != 8 && L.bits != 3) return false;
+    if (L.g_idx != nullptr) return false;                                         // act-order: groups per k, not per run of k
     if (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16) return false;
     if (L.K % 32 || L.N % GPTQ_STRIP_COLS) return false;
-    const int gu = L.group_size / 32;                                             // a lane's 32 k lie in one group
-    return L.group_size % 32 == 0 && (L.group_size >= L.K || (gu & (gu - 1)) == 0);
+    const int kpl = tiled_kpl(L.bits);
+    const int gu = L.group_size / kpl;                                            // a lane's k lie in one group
+    return L.group_size % kpl == 0 && (L.group_size >= L.K || (gu & (gu - 1)) == 0);
+}
+
+size_t tiled_weight_bytes(const gptq_layer_t& L) {
+    const int cke = 4 * tiled_kpl(L.bits);
+    return (size_t)((L.K + cke - 1) / cke) * tiled_chunk_bytes(L.bits) * (size_t)(L.N / GPTQ_STRIP_COLS);
+}
+size_t tiled_const_bytes(const gptq_layer_t& L) {
+    return (size_t)((L.K + L.group_size - 1) / L.group_size) * tiled_rec_bytes(L.bits) * (size_t)(L.N / GPTQ_STRIP_COLS);
 }
 
 TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* tune) {
@@ -195,13 +257,15 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
     for (int i = 0; i < n; ++i) {
         const gptq_layer_t& L = *Ls[i];
         if (!tiled_layer_ok(L)) return pl;
-        if (L.K != A.K || L.group_size != A.group_size || L.dtype != A.dtype) return pl;
+        if (L.K != A.K || L.group_size != A.group_size || L.dtype != A.dtype || L.bits != A.bits) return pl;
         strips += L.N / GPTQ_STRIP_COLS;
         nsum += L.N;
     }
     pl.nseg = n;
     pl.mt = M >= 3 ? 4 : M;
-    const int chunks = (A.K + 127) / 128;
+    const int cke = 4 * tiled_kpl(A.bits), rec = tiled_rec_bytes(A.bits);         // k per chunk; bytes of one group's constants
+    const int chunks = (A.K + cke - 1) / cke;
+    pl.bits = A.bits;
     pl.chunks_total = chunks;
     pl.strips_total = strips;
     pl.nsum = nsum;
@@ -216,7 +280,7 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
     const size_t lds_cap = 96 * 1024;
     auto lds_need = [&](int k_slices, int waves) {
         const int cps = (chunks + k_slices - 1) / k_slices;
-        return (size_t)pl.mt * ((size_t)cps * 256 + 16) + (size_t)pl.groups * 48 + (size_t)waves * (pl.mt * 16 + 4) * sizeof(float) + 16;
+        return (size_t)pl.mt * ((size_t)cps * cke * 2 + 16) + (size_t)pl.groups * rec + (size_t)waves * (pl.mt * 16 + 4) * sizeof(float) + 16;
     };
     while (ks < 8 && ks < chunks && lds_need(ks, 16) > lds_cap) ks *= 2;
     if (ks > chunks) ks = chunks;
@@ -238,9 +302,10 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         while (waves > 1 && (waves / 2) * u >= cps) waves /= 2;
     }
     if (waves < 1 || waves > 16 || (u != 1 && u != 2 && u != 4 && u != 8)) return pl;
+    if (A.bits != 4 && u != 2 && u != 4) return pl;                               // the 3- and 8-bit forms are compiled for 2 and 4 chunks in flight
     pl.waves = waves;
     pl.u = u;
-    pl.xstride = cps * 256 + 16;
+    pl.xstride = cps * cke * 2 + 16;
     pl.lds_bytes = lds_need(pl.ksplit, waves);
     if (pl.lds_bytes > 160 * 1024) return pl;
     pl.partial_bytes = pl.ksplit > 1 ? (size_t)(pl.ksplit - 1) * M * nsum * 8 : 0;
@@ -248,31 +313,40 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
     return pl;
 }
 
-// Two compilations per (MT, U, T): workgroups of up to 16 waves (<= 128 VGPRs) and of up to 8 waves.
-template <int MT, int U, typename T>
+// Two compilations per (BITS, MT, U, T): workgroups of up to 16 waves (<= 128 VGPRs) and of up to 8 waves.
+template <int BITS, int MT, int U, typename T>
 static hipError_t launch_tiled_one(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
     if (pl.waves > 8)
-        hipLaunchKernelGGL((gemv_q4_tiled_kernel<MT, U, T, 16>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+        hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 16>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
     else
-        hipLaunchKernelGGL((gemv_q4_tiled_kernel<MT, U, T, 8>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+        hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 8>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
     return hipGetLastError();
 }
-template <int MT, typename T>
+template <int BITS, int MT, typename T>
 static hipError_t launch_tiled_u(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
     switch (pl.u) {
-        case 1: return launch_tiled_one<MT, 1, T>(pl, p, st);
-        case 2: return launch_tiled_one<MT, 2, T>(pl, p, st);
-        case 4: return launch_tiled_one<MT, 4, T>(pl, p, st);
-        case 8: return launch_tiled_one<MT, 8, T>(pl, p, st);
+        case 1: if constexpr (BITS == 4) return launch_tiled_one<BITS, MT, 1, T>(pl, p, st); else return hipErrorInvalidValue;
+        case 2: return launch_tiled_one<BITS, MT, 2, T>(pl, p, st);
+        case 4: return launch_tiled_one<BITS, MT, 4, T>(pl, p, st);
+        case 8: if constexpr (BITS == 4) return launch_tiled_one<BITS, MT, 8, T>(pl, p, st); else return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+}
+template <int BITS, typename T>
+static hipError_t launch_tiled_mt(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
+    switch (pl.mt) {
+        case 1: return launch_tiled_u<BITS, 1, T>(pl, p, st);
+        case 2: return launch_tiled_u<BITS, 2, T>(pl, p, st);
+        case 4: return launch_tiled_u<BITS, 4, T>(pl, p, st);
         default: return hipErrorInvalidValue;
     }
 }
 template <typename T>
-static hipError_t launch_tiled_mt(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
-    switch (pl.mt) {
-        case 1: return launch_tiled_u<1, T>(pl, p, st);
-        case 2: return launch_tiled_u<2, T>(pl, p, st);
-        case 4: return launch_tiled_u<4, T>(pl, p, st);
+static hipError_t launch_tiled_bits(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
+    switch (pl.bits) {
+        case 4: return launch_tiled_mt<4, T>(pl, p, st);
+        case 8: return launch_tiled_mt<8, T>(pl, p, st);
+        case 3: return launch_tiled_mt<3, T>(pl, p, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -299,12 +373,12 @@ hipError_t launch_tiled(const gptq_layer_t* const* Ls, const TiledPlan& pl, cons
     p.max_spins = 1u << 20;
     p.nseg = pl.nseg; p.M = M; p.K = A.K;
     p.chunks = pl.chunks_total; p.chunks_per_split = pl.chunks_per_split; p.ksplit = pl.ksplit;
-    p.gu_shift = A.group_size >= A.K ? 26 : __builtin_ctz((unsigned)(A.group_size / 32));   // group_size == K: every k maps to group 0
+    p.gu_shift = A.group_size >= A.K ? 26 : __builtin_ctz((unsigned)(A.group_size / tiled_kpl(A.bits)));   // group_size == K: every k maps to group 0
     p.nsum = pl.nsum;
     p.groups = pl.groups;
     p.xstride = pl.xstride;
     p.waves = pl.waves;
-    return A.dtype == GPTQ_BF16 ? launch_tiled_mt<bf16>(pl, p, st) : launch_tiled_mt<f16>(pl, p, st);
+    return A.dtype == GPTQ_BF16 ? launch_tiled_bits<bf16>(pl, p, st) : launch_tiled_bits<f16>(pl, p, st);
 }
 
 hipError_t init_gemv_tiled_device() {
@@ -313,10 +387,15 @@ hipError_t init_gemv_tiled_device() {
     // long K at 4 rows of x: the staged activations can pass the 64 KiB default
     auto grant_mt = [&](auto mt) {
         constexpr int MT = decltype(mt)::value;
-        grant(gemv_q4_tiled_kernel<MT, 1, f16, 16>); grant(gemv_q4_tiled_kernel<MT, 2, f16, 16>); grant(gemv_q4_tiled_kernel<MT, 4, f16, 16>); grant(gemv_q4_tiled_kernel<MT, 8, f16, 16>);
-        grant(gemv_q4_tiled_kernel<MT, 1, f16, 8>); grant(gemv_q4_tiled_kernel<MT, 2, f16, 8>); grant(gemv_q4_tiled_kernel<MT, 4, f16, 8>); grant(gemv_q4_tiled_kernel<MT, 8, f16, 8>);
-        grant(gemv_q4_tiled_kernel<MT, 1, bf16, 16>); grant(gemv_q4_tiled_kernel<MT, 2, bf16, 16>); grant(gemv_q4_tiled_kernel<MT, 4, bf16, 16>); grant(gemv_q4_tiled_kernel<MT, 8, bf16, 16>);
-        grant(gemv_q4_tiled_kernel<MT, 1, bf16, 8>); grant(gemv_q4_tiled_kernel<MT, 2, bf16, 8>); grant(gemv_q4_tiled_kernel<MT, 4, bf16, 8>); grant(gemv_q4_tiled_kernel<MT, 8, bf16, 8>);
+        auto grant_u = [&](auto bu, auto uu) {
+            constexpr int B = decltype(bu)::value, U = decltype(uu)::value;
+            grant(gemv_tiled_kernel<B, MT, U, f16, 16>); grant(gemv_tiled_kernel<B, MT, U, f16, 8>);
+            grant(gemv_tiled_kernel<B, MT, U, bf16, 16>); grant(gemv_tiled_kernel<B, MT, U, bf16, 8>);
+        };
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
+        grant_u(I4{}, I1{}); grant_u(I4{}, I2{}); grant_u(I4{}, I4{}); grant_u(I4{}, I8{});
+        grant_u(I8{}, I2{}); grant_u(I8{}, I4{}); grant_u(I3{}, I2{}); grant_u(I3{}, I4{});
     };
     grant_mt(std::integral_constant<int, 1>{}); grant_mt(std::integral_constant<int, 2>{}); grant_mt(std::integral_constant<int, 4>{});
     return e;

@@ -91,10 +91,10 @@ Stream64Plan plan_stream64(const gptq_layer_t* const* layers, int n, int M, cons
 // qweight_override: the re-sequenced rows of a single act-order layer (x is then the permuted copy), else NULL
 hipError_t launch_stream64(const gptq_layer_t* const* layers, const Stream64Plan& pl, const void* x, void* const* outs, int M,
                            void* ws_header, void* partial, const uint32_t* qweight_override, hipStream_t st);
-// Decode from the load-time decode copy (gemv_tiled.hip: gemv_q4_tiled_kernel): 1..4 plain 4-bit layers with qweight_tiled / qconst_tiled that read the same x, M <= 4, one launch.
+// Decode from the load-time decode copy (gemv_tiled.hip: gemv_tiled_kernel): 1..4 plain 3/4/8-bit layers with qweight_tiled / qconst_tiled that read the same x, M <= 4, one launch.
 struct TiledPlan {
     bool ok;                 // every layer qualifies and the geometry fits
-    int nseg, waves, u, mt, ksplit, chunks_total, chunks_per_split, strips_total, nsum, groups, xstride;
+    int nseg, bits, waves, u, mt, ksplit, chunks_total, chunks_per_split, strips_total, nsum, groups, xstride;
     size_t lds_bytes;
     size_t partial_bytes;    // behind the header: [ksplit - 1][M][nsum] granules when ksplit > 1
 };
@@ -103,8 +103,10 @@ TiledPlan plan_tiled(const gptq_layer_t* const* layers, int n, int M, const gptq
 hipError_t launch_tiled(const gptq_layer_t* const* layers, const TiledPlan& pl, const void* x, void* const* outs, int M, void* ws_header, void* ws_body,
                         hipStream_t st);
 hipError_t init_gemv_tiled_device();
-// the decode copy of a 4-bit layer (utils.hip): qweight_tiled (chunks of 16 packed rows x 16 columns, column per lane, nibbles in pair order) and qconst_tiled
-hipError_t launch_prepack_decode(const uint32_t* qweight, const uint32_t* qzeros, const void* scales, int K, int N, int group_size, int zero_mode,
+// the decode copy of a 3/4/8-bit layer (utils.hip): qweight_tiled (chunks of 4 k-slots x 16 columns, column per lane, fields in pair order) and qconst_tiled
+size_t tiled_weight_bytes(const gptq_layer_t& L);
+size_t tiled_const_bytes(const gptq_layer_t& L);
+hipError_t launch_prepack_decode(const uint32_t* qweight, const uint32_t* qzeros, const void* scales, int K, int N, int bits, int group_size, int zero_mode,
                                  uint32_t* tiled_out, void* const_out, hipStream_t st);
 bool stream_preferred(const gptq_layer_t& L, int M);                              // single layer: streamed kernel instead of the register one?
 bool multi_preferred(const gptq_layer_t* const* layers, int n, int M);             // several layers sharing x: one streamed launch?

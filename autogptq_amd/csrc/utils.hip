@@ -241,35 +241,59 @@ __global__ void __launch_bounds__(256) resequence_kernel(const unsigned* __restr
     }
 }
 
-// ---- the decode copy of a 4-bit layer (layouts: include/gptq_mi355x.h, gptq_layer_t.qweight_tiled / qconst_tiled; consumer: gemv_tiled.hip) ----------
-// Load time only.  One workgroup = one 1 KiB chunk (16 packed rows x 16 columns): thread t reads word (row 4 kb + w, column col) with col = t & 15 fastest
-// (64-byte row pieces), shuffles its nibbles into pair order and writes it to slot (kb, col, w) of the chunk.
-// Stored nibble p holds source nibble {0, 2, 4, 6, 1, 3, 5, 7}[p]: (q & 0x000f000f) then picks (k0, k1), (q & 0x00f000f0) (k2, k3), and the same on q >> 8
-// (k4, k5), (k6, k7) -- the order x lies in memory.
-__device__ __forceinline__ unsigned nibble_pair_order(unsigned v) {
-    // even source nibbles k0 k2 k4 k6 -> stored nibbles 0..3, odd ones k1 k3 k5 k7 -> stored nibbles 4..7
-    const unsigned e = v & 0x0f0f0f0fu, o = (v >> 4) & 0x0f0f0f0fu;                  // bytes: k0,k2,k4,k6 / k1,k3,k5,k7 (one nibble per byte)
-    auto squeeze = [](unsigned b) { b = (b | (b >> 4)) & 0x00ff00ffu; return (b | (b >> 8)) & 0x0000ffffu; };   // 4 nibble-bytes -> 16 bits
-    return squeeze(e) | (squeeze(o) << 16);
+// ---- the decode copy of a 3/4/8-bit layer (layouts: include/gptq_mi355x.h, gptq_layer_t.qweight_tiled / qconst_tiled; consumer: gemv_tiled.hip) --------
+// Load time only.  One workgroup = one chunk (4 k-slots x 16 columns, a lane's WPL words adjacent); one thread = one stored word, built field by field
+// from the checkpoint's bit stream of its column (stream_field: the 3-bit straddlers are resolved HERE, the decode kernel never sees one).
+//   4-bit  stored nibble p of word w = k 8w + {0, 2, 4, 6, 1, 3, 5, 7}[p]: (q & 0x000f000f) then picks (k0, k1), (q & 0x00f000f0) (k2, k3), and the
+//          same on q >> 8 (k4, k5), (k6, k7) -- the order x lies in memory
+//   8-bit  stored byte p of word w = k 4w + {0, 2, 1, 3}[p]: (q & 0x00ff00ff) = (k0, k1), the same on q >> 8 = (k2, k3)
+//   3-bit  word j of the lane's three: pair 5j + i (i = 0..4) = (k 2p, k 2p + 1) at bit 3i of the low / high 16 bits; bit 15 / 31 = bit j of k30 / k31
+template <int BITS>
+__global__ void __launch_bounds__(256) prepack_decode_weights_kernel(const unsigned* __restrict__ q, int K, int N, int chunks, unsigned* __restrict__ out) {
+    constexpr int WPL = BITS == 3 ? 3 : 4, KPL = BITS == 8 ? 16 : 32, CKE = 4 * KPL;
+    const int c = blockIdx.x, s = blockIdx.y, t = threadIdx.x;
+    const int col = t & 15, w = (t >> 4) % WPL, kb = (t >> 4) / WPL;              // reads of one k run over 16 adjacent columns
+    if (kb >= 4) return;
+    const int n = s * 16 + col, k0 = c * CKE + kb * KPL;
+    auto val = [&](int k) -> unsigned {                                          // the checkpoint's value (k, n); rows past K read as 0
+        if (k >= K) return 0u;
+        const int unit = k / Pack<BITS>::vals;
+        return stream_field(q + (size_t)unit * Pack<BITS>::words * N + n, (size_t)N, (unsigned)(k - unit * Pack<BITS>::vals), BITS);
+    };
+    unsigned v = 0;
+    if constexpr (BITS == 4) {
+        constexpr int order[8] = {0, 2, 4, 6, 1, 3, 5, 7};
+#pragma unroll
+        for (int p = 0; p < 8; ++p) v |= val(k0 + 8 * w + order[p]) << (4 * p);
+    } else if constexpr (BITS == 8) {
+        constexpr int order[4] = {0, 2, 1, 3};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) v |= val(k0 + 4 * w + order[p]) << (8 * p);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int pr = 5 * w + i;
+            v |= val(k0 + 2 * pr) << (3 * i);
+            v |= val(k0 + 2 * pr + 1) << (16 + 3 * i);
+        }
+        v |= ((val(k0 + 30) >> w) & 1u) << 15;
+        v |= ((val(k0 + 31) >> w) & 1u) << 31;
+    }
+    out[((size_t)s * chunks + c) * (64 * WPL) + (kb * 16 + col) * WPL + w] = v;
 }
-__global__ void __launch_bounds__(256) prepack_decode_weights_kernel(const unsigned* __restrict__ q, int R, int N, int chunks, unsigned* __restrict__ out) {
-    const int c = blockIdx.x, s = blockIdx.y;
-    const int t = threadIdx.x, col = t & 15, w = (t >> 4) & 3, kb = t >> 6;
-    const int r = c * 16 + kb * 4 + w;
-    const unsigned v = r < R ? q[(size_t)r * N + s * 16 + col] : 0u;
-    out[((size_t)s * chunks + c) * 256 + kb * 64 + col * 4 + w] = nibble_pair_order(v);
-}
-// one thread = one (strip, group, column): 2 bytes of scale (bit copy) + 1 byte of zero-point as used
+// one thread = one (strip, group, column): 2 bytes of scale (bit copy) + the zero-point as used (1 byte; 2 bytes at 8 bits, where it reaches 256)
 __global__ void __launch_bounds__(256) prepack_decode_consts_kernel(const unsigned* __restrict__ qzeros, const unsigned short* __restrict__ scales, int G, int N,
-                                                                    int zero_mode, unsigned char* __restrict__ out) {
+                                                                    int bits, int zero_mode, unsigned char* __restrict__ out) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
     if (n >= N) return;
-    const int s = n >> 4, col = n & 15;
-    const unsigned f = (qzeros[(size_t)g * (N >> 3) + (n >> 3)] >> ((n & 7) * 4)) & 15u;
-    const unsigned z = zero_mode == GPTQ_ZERO_WRAP ? ((f + 1u) & 15u) : f + 1u;
-    unsigned char* rec = out + ((size_t)s * G + g) * 48;
+    const int s = n >> 4, col = n & 15, rec_bytes = bits == 8 ? 64 : 48;
+    const unsigned maxq = (1u << bits) - 1u;
+    const unsigned f = stream_field(qzeros + (size_t)g * (N / 32 * bits), 1, (unsigned)n, bits);
+    const unsigned z = zero_mode == GPTQ_ZERO_WRAP ? ((f + 1u) & maxq) : f + 1u;
+    unsigned char* rec = out + ((size_t)s * G + g) * rec_bytes;
     *(unsigned short*)(rec + col * 2) = scales[(size_t)g * N + n];
-    rec[32 + col] = (unsigned char)z;
+    if (bits == 8) *(unsigned short*)(rec + 32 + col * 2) = (unsigned short)z;
+    else rec[32 + col] = (unsigned char)z;
 }
 
 template <typename T>
@@ -363,13 +387,19 @@ hipError_t launch_pack_zeros(const void* zero_in, int G, int N, int bits, int qp
     return hipGetLastError();
 }
 
-hipError_t launch_prepack_decode(const uint32_t* qweight, const uint32_t* qzeros, const void* scales, int K, int N, int group_size, int zero_mode,
+hipError_t launch_prepack_decode(const uint32_t* qweight, const uint32_t* qzeros, const void* scales, int K, int N, int bits, int group_size, int zero_mode,
                                  uint32_t* tiled_out, void* const_out, hipStream_t st) {
-    const int R = K / 8, chunks = (K + 127) / 128, G = (K + group_size - 1) / group_size;
-    hipLaunchKernelGGL(prepack_decode_weights_kernel, dim3(chunks, N / 16), dim3(256), 0, st, qweight, R, N, chunks, tiled_out);
+    const int cke = bits == 8 ? 64 : 128, chunks = (K + cke - 1) / cke, G = (K + group_size - 1) / group_size;
+    const dim3 grid(chunks, N / 16);
+    switch (bits) {
+        case 4: hipLaunchKernelGGL(prepack_decode_weights_kernel<4>, grid, dim3(256), 0, st, qweight, K, N, chunks, tiled_out); break;
+        case 8: hipLaunchKernelGGL(prepack_decode_weights_kernel<8>, grid, dim3(256), 0, st, qweight, K, N, chunks, tiled_out); break;
+        case 3: hipLaunchKernelGGL(prepack_decode_weights_kernel<3>, grid, dim3(192), 0, st, qweight, K, N, chunks, tiled_out); break;
+        default: return hipErrorInvalidValue;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(prepack_decode_consts_kernel, dim3((N + 255) / 256, G), dim3(256), 0, st, qzeros, (const unsigned short*)scales, G, N, zero_mode,
+    hipLaunchKernelGGL(prepack_decode_consts_kernel, dim3((N + 255) / 256, G), dim3(256), 0, st, qzeros, (const unsigned short*)scales, G, N, bits, zero_mode,
                        (unsigned char*)const_out);
     return hipGetLastError();
 }

@@ -335,10 +335,10 @@ def _kernel_of(ent, M):
     from autogptq_amd import _lib
     q = ent[3]
     if isinstance(q, list):                           # gptq_forward_multi: plain 4-bit layers, M <= 4 -- the decode-copy kernel when the layers carry the copy
-        return "gptq::gemv_q4_tiled_kernel" if all(getattr(l, "_qweight_tiled", None) is not None for l in q) else "gptq::gemv_q4_stream_kernel"
+        return "gptq::gemv_tiled_kernel" if all(getattr(l, "_qweight_tiled", None) is not None for l in q) else "gptq::gemv_q4_stream_kernel"
     d = _lib.describe_plan(q._layer, M)
     return {"stream": "gptq::gemv_q4_stream_kernel", "mfma": "gptq::gemv_q4_f16_mfma_kernel", "mfma_generic": "gptq::gemv_mfma_generic_kernel",
-            "strips": "gptq::gemv_q4_tiled_kernel", "tiled": "gptq::gemm_kernel"}.get(d.get("kernel"), "gptq::" + str(d.get("kernel")))
+            "strips": "gptq::gemv_tiled_kernel", "tiled": "gptq::gemm_kernel"}.get(d.get("kernel"), "gptq::" + str(d.get("kernel")))
 
 
 def _plan_of(layers, K, N, M):

@@ -362,20 +362,49 @@ def minmax_quantize(W: torch.Tensor, bits: int, group_size: int, g_idx=None, sym
 _PAIR_ORDER = (0, 2, 4, 6, 1, 3, 5, 7)      # stored nibble p holds source nibble _PAIR_ORDER[p]
 
 
-def decode_copy_weights(qweight: torch.Tensor) -> torch.Tensor:
-    """int32 [K/8, N] -> int32 [N/16, chunks, 4 (k-slot), 16 (column), 4 (word)]: word (s, c, kb, col, w) = nibble_pair_order(qweight[16c + 4kb + w, 16s + col]),
-    rows past K/8 zero."""
-    q = qweight.cpu().numpy().astype(np.uint32) if isinstance(qweight, torch.Tensor) else np.asarray(qweight).astype(np.uint32)
-    R, N = q.shape
-    chunks = -(-R // 16)
-    pad = np.zeros((chunks * 16, N), dtype=np.uint32)
-    pad[:R] = q
-    sh = np.zeros_like(pad)
-    for p, src in enumerate(_PAIR_ORDER):
-        sh |= ((pad >> np.uint32(4 * src)) & np.uint32(15)) << np.uint32(4 * p)
-    t = sh.reshape(chunks, 4, 4, N // 16, 16)            # [c, kb, w, s, col]
-    t = t.transpose(3, 0, 1, 4, 2)                       # [s, c, kb, col, w]
-    return torch.from_numpy(np.ascontiguousarray(t).view(np.int32))
+_BYTE_ORDER = (0, 2, 1, 3)                  # 8-bit: stored byte p holds source value _BYTE_ORDER[p]
+
+
+def _decode_copy_lane_words(v: np.ndarray, bits: int) -> np.ndarray:
+    """v: uint32 [..., KPL] = the KPL consecutive k a lane owns (32; 16 at 8 bits) -> uint32 [..., WPL] stored words (include/gptq_mi355x.h, qweight_tiled)."""
+    if bits == 4:
+        out = np.zeros(v.shape[:-1] + (4,), dtype=np.uint32)
+        for w in range(4):
+            for p, src in enumerate(_PAIR_ORDER):
+                out[..., w] |= v[..., 8 * w + src] << np.uint32(4 * p)
+        return out
+    if bits == 8:
+        out = np.zeros(v.shape[:-1] + (4,), dtype=np.uint32)
+        for w in range(4):
+            for p, src in enumerate(_BYTE_ORDER):
+                out[..., w] |= v[..., 4 * w + src] << np.uint32(8 * p)
+        return out
+    assert bits == 3
+    out = np.zeros(v.shape[:-1] + (3,), dtype=np.uint32)
+    for j in range(3):
+        for i in range(5):
+            pr = 5 * j + i                                   # pair pr = (k 2 pr, k 2 pr + 1)
+            out[..., j] |= v[..., 2 * pr] << np.uint32(3 * i)
+            out[..., j] |= v[..., 2 * pr + 1] << np.uint32(16 + 3 * i)
+        out[..., j] |= ((v[..., 30] >> np.uint32(j)) & np.uint32(1)) << np.uint32(15)
+        out[..., j] |= ((v[..., 31] >> np.uint32(j)) & np.uint32(1)) << np.uint32(31)
+    return out
+
+
+def decode_copy_weights(qweight: torch.Tensor, bits: int = 4) -> torch.Tensor:
+    """int32 [K/32*bits, N] -> int32 [N/16, chunks, 4 (k-slot), 16 (column), WPL (word)]: the lane (kb, col) of chunk c of strip s holds the KPL
+    consecutive k from c * 4 KPL + kb * KPL of column 16 s + col (KPL = 32, 16 at 8 bits; WPL = 4, 3 at 3 bits), re-encoded per
+    _decode_copy_lane_words; k past K read as 0.  At 4 bits this is nibble_pair_order(qweight[16c + 4kb + w, 16s + col])."""
+    assert bits in (3, 4, 8)
+    w = unpack_weights(qweight, bits).astype(np.uint32)                  # [K, N]
+    K, N = w.shape
+    kpl = 16 if bits == 8 else 32
+    cke = 4 * kpl
+    chunks = -(-K // cke)
+    pad = np.zeros((chunks * cke, N), dtype=np.uint32)
+    pad[:K] = w
+    v = pad.reshape(chunks, 4, kpl, N // 16, 16).transpose(3, 0, 1, 4, 2)    # [s, c, kb, col, k in lane]
+    return torch.from_numpy(np.ascontiguousarray(_decode_copy_lane_words(np.ascontiguousarray(v), bits)).view(np.int32))
 
 
 def decode_copy_weights_inverse(tiled: torch.Tensor, K: int) -> torch.Tensor:
@@ -389,12 +418,18 @@ def decode_copy_weights_inverse(tiled: torch.Tensor, K: int) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(q[:K // 8]).view(np.int32))
 
 
-def decode_copy_consts(qzeros: torch.Tensor, scales: torch.Tensor, zero_mode: str) -> torch.Tensor:
-    """uint8 [N/16, G, 48]: 16 scales (bit copies, 2 bytes each, little endian) + 16 one-byte zero-points as used in dequant (4-bit)."""
-    z = unpack_zeros(qzeros, 4, zero_mode).astype(np.uint8)                                 # [G, N]
+def decode_copy_consts(qzeros: torch.Tensor, scales: torch.Tensor, zero_mode: str, bits: int = 4) -> torch.Tensor:
+    """uint8 [N/16, G, REC]: 16 scales (bit copies, 2 bytes each, little endian) at byte 0, then the 16 zero-points as used in dequant from byte 32:
+    one byte each (REC = 48) at 3 / 4 bits, two bytes each (REC = 64) at 8 bits, where nowrap reaches 256."""
+    z = unpack_zeros(qzeros, bits, zero_mode)                                               # [G, N]
     G, N = z.shape
     sb = scales.cpu().contiguous().view(torch.int16).numpy().view(np.uint8).reshape(G, N, 2)
-    out = np.zeros((N // 16, G, 48), dtype=np.uint8)
+    rec = 64 if bits == 8 else 48
+    out = np.zeros((N // 16, G, rec), dtype=np.uint8)
     out[:, :, :32] = sb.reshape(G, N // 16, 32).transpose(1, 0, 2)
-    out[:, :, 32:] = z.reshape(G, N // 16, 16).transpose(1, 0, 2)
+    if bits == 8:
+        zb = z.astype(np.uint16).reshape(G, N, 1).view(np.uint8).reshape(G, N // 16, 32)
+        out[:, :, 32:] = zb.transpose(1, 0, 2)
+    else:
+        out[:, :, 32:] = z.astype(np.uint8).reshape(G, N // 16, 16).transpose(1, 0, 2)
     return torch.from_numpy(out)

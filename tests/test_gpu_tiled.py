@@ -1,5 +1,5 @@
-"""GPU (-m gpu): the load-time decode copy of a 4-bit layer (gptq_prepack_decode: qweight_tiled + qconst_tiled) and the decode kernel that streams it
-(gemv_q4_tiled_kernel, csrc/gemv_tiled.hip).
+"""GPU (-m gpu): the load-time decode copy of a 3-, 4- or 8-bit layer (gptq_prepack_decode: qweight_tiled + qconst_tiled) and the decode kernel that streams it
+(gemv_tiled_kernel, csrc/gemv_tiled.hip).
 
 What is pinned, all against the ORACLE (oracle/gptq_oracle.py), never against another kernel of this library:
   * gptq_prepack_decode writes exactly what oracle.decode_copy_weights / decode_copy_consts state (bit for bit, ragged K, every group size, both zero-point
@@ -33,16 +33,16 @@ def _tune(waves=0, u=0, ks=0):
     return t
 
 
-def _layer(K, N, gs, dtype, seed, zero_mode="auto", bias=False):
-    L = O.random_quant_layer(K, N, 4, gs, dtype=dtype, seed=seed, bias=bias)
-    q = QuantLinear(4, gs, K, N, bias, weight_dtype=dtype, zero_mode=zero_mode)
+def _layer(K, N, gs, dtype, seed, zero_mode="auto", bias=False, bits=4):
+    L = O.random_quant_layer(K, N, bits, gs, dtype=dtype, seed=seed, bias=bias)
+    q = QuantLinear(bits, gs, K, N, bias, weight_dtype=dtype, zero_mode=zero_mode)
     q.qweight, q.qzeros, q.scales, q.g_idx = L["qweight"].clone(), L["qzeros"].clone(), L["scales"].clone(), L["g_idx"].clone()
     if bias:
         q.bias = L["bias"].clone()
     q = q.to(DEV)
     q.post_init()
-    mode = {"auto": O.ZERO_WRAP, "wrap": O.ZERO_WRAP, "nowrap": O.ZERO_NOWRAP}[zero_mode]
-    W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], 4, mode).to(DEV)
+    mode = {"auto": O.ZERO_NOWRAP if bits == 3 else O.ZERO_WRAP, "wrap": O.ZERO_WRAP, "nowrap": O.ZERO_NOWRAP}[zero_mode]     # auto: qlinear_cuda_old's 3-bit branch does not wrap
+    W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], bits, mode).to(DEV)
     return L, q, W
 
 
@@ -91,14 +91,77 @@ def test_prepack_decode_is_the_oracle_restatement(K, N, gs, dtype):
     # argument errors surface as RuntimeError with the C ABI's message (the reference: TORCH_CHECK, exllama_ext.cpp:49-71)
     with pytest.raises(_lib.GptqError, match="in place"):
         _lib.check(lib.gptq_prepack_decode(C.byref(q._layer), q.qweight.data_ptr(), q._qconst_tiled.data_ptr(), None))
-    L3 = O.random_quant_layer(256, 64, 3, 32, seed=1)
-    q3 = QuantLinear(3, 32, 256, 64, False)
-    q3.qweight, q3.qzeros, q3.scales, q3.g_idx = L3["qweight"], L3["qzeros"], L3["scales"], L3["g_idx"]
-    q3 = q3.to(DEV)
-    q3.post_init()
-    assert q3._qweight_tiled is None                                        # other packings have no decode copy (yet)
+    L2 = O.random_quant_layer(256, 64, 2, 32, seed=1)
+    q2 = QuantLinear(2, 32, 256, 64, False)
+    q2.qweight, q2.qzeros, q2.scales, q2.g_idx = L2["qweight"], L2["qzeros"], L2["scales"], L2["g_idx"]
+    q2 = q2.to(DEV)
+    q2.post_init()
+    assert q2._qweight_tiled is None                                        # 2-bit layers have no decode copy
     with pytest.raises(_lib.GptqError, match="decode copy"):
-        _lib.check(lib.gptq_prepack_decode_bytes(C.byref(q3._layer), C.byref(tb), C.byref(cb)))
+        _lib.check(lib.gptq_prepack_decode_bytes(C.byref(q2._layer), C.byref(tb), C.byref(cb)))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("bits,K,N,gs", [(3, 256, 128, 128), (3, 160, 64, 32), (3, 4096, 1024, 128), (3, 1056, 64, 1056), (3, 2112, 1024, 64),
+                                         (8, 256, 128, 128), (8, 160, 64, 16), (8, 4096, 1024, 128), (8, 1056, 64, 1056), (8, 2080, 1024, 32)])
+def test_prepack_decode_3_and_8_bit_is_the_oracle_restatement(bits, K, N, gs, dtype):
+    """The same for the 3-bit (three words per 32 k, no straddlers left) and 8-bit (16 k per lane, 2-byte zero-points) copies."""
+    import ctypes as C
+
+    lib = _lib.load()
+    for zm in ("wrap", "nowrap"):
+        L, q, W = _layer(K, N, gs, dtype, K + N, zero_mode=zm, bits=bits)
+        mode = O.ZERO_WRAP if zm == "wrap" else O.ZERO_NOWRAP
+        tb, cb = C.c_size_t(0), C.c_size_t(0)
+        _lib.check(lib.gptq_prepack_decode_bytes(C.byref(q._layer), C.byref(tb), C.byref(cb)))
+        want_t = O.decode_copy_weights(L["qweight"], bits)
+        want_c = O.decode_copy_consts(L["qzeros"], L["scales"], mode, bits)
+        assert tb.value == want_t.numel() * 4 and cb.value == want_c.numel()
+        assert torch.equal(q._qweight_tiled.cpu().view(torch.int32).reshape(want_t.shape), want_t)
+        assert torch.equal(q._qconst_tiled.cpu().reshape(want_c.shape), want_c)
+        assert torch.equal(q.qweight.cpu(), L["qweight"]) and torch.equal(q.qzeros.cpu(), L["qzeros"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("bits,K,N,gs", [(3, 1024, 512, 128), (3, 4160, 256, 32), (3, 2112, 1024, 64), (3, 96, 64, 32), (3, 1056, 64, 1056), (3, 4096, 4096, 128),
+                                         (8, 1024, 512, 128), (8, 4128, 256, 16), (8, 2080, 1024, 32), (8, 96, 64, 32), (8, 1056, 64, 1056), (8, 4096, 4096, 128),
+                                         (8, 512, 2048, 256), (3, 28672, 32, 128)])
+def test_tiled_decode_3_and_8_bit(bits, K, N, gs, dtype):
+    """Every output of the 3- and 8-bit decode-copy kernels (BASELINE config 5's packings): default plan, forced geometries, K slices, 1..4 rows, both
+    zero-point conventions (8-bit nowrap reaches z = 256: the 2-byte field), one-hot rows exact."""
+    for zm in ("wrap", "nowrap"):
+        L, q, W = _layer(K, N, gs, dtype, K + N + gs + bits, zero_mode=zm, bias=True, bits=bits)
+        assert _lib.describe_plan(q._layer, 1)["kernel"] == "strips"
+        for M in (1, 2, 3, 4):
+            x, hot = _x(M, K, dtype, M)
+            with torch.no_grad():
+                y, y2 = q(x), q(x)
+            assert torch.equal(y, y2)
+            _assert_all(y, x, W, q.bias, dtype, f"tiled int{bits} default {K}x{N} g{gs} M={M} {dtype} {zm}")
+            saved, q._layer.bias = q._layer.bias, None
+            for t in (None, _tune(4, 4), _tune(16, 2), _tune(8, 2, 2), _tune(2, 4, 3)):
+                with torch.no_grad():
+                    y0 = q(x, tuning=t) if t is not None else q(x)
+                for r, k in hot:
+                    assert torch.equal(y0[r], W[k]), f"one-hot row {r} (k={k}) is not the oracle's W[k], int{bits} M={M} {K}x{N} g{gs}"
+                _assert_all(y0, x, W, None, dtype, f"tiled int{bits} forced {K}x{N} g{gs} M={M}")
+            q._layer.bias = saved
+
+
+@pytest.mark.parametrize("bits", [3, 8])
+def test_tiled_multi_layer_launch_3_and_8_bit(bits):
+    K = 2048
+    widths = (512, 288, 64)
+    made = [_layer(K, n, 128, torch.float16, 300 + n, bits=bits) for n in widths]
+    layers = [m[1] for m in made]
+    for M in (1, 4):
+        x, hot = _x(M, K, torch.float16, M)
+        with torch.no_grad():
+            ys = forward_multi(layers, x, None)
+        for i in range(3):
+            for r, k in hot:
+                assert torch.equal(ys[i][r], made[i][2][k])
+            _assert_all(ys[i], x, made[i][2], None, torch.float16, f"tiled multi int{bits} layer {i} M={M}")
 
 
 def test_side_copy_is_derived_and_checkpoint_untouched():

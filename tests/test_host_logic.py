@@ -750,3 +750,52 @@ def test_decode_copy_restatement_matches_the_header_definition():
                 rec = cst[s_, g]
                 assert np.array_equal(rec[:32].view(np.int16), sb[g, 16 * s_:16 * s_ + 16])
                 assert np.array_equal(rec[32:], z[g, 16 * s_:16 * s_ + 16].astype(np.uint8))
+
+
+@pytest.mark.parametrize("bits", [3, 8])
+def test_decode_copy_restatement_3_and_8_bit(bits):
+    """The 3- and 8-bit decode copies (include/gptq_mi355x.h): the masks the decode kernel applies to a stored word yield the reference's unpacked values
+    (oracle.unpack_weights = qlinear_cuda.py:250-290) in k order -- 8-bit (q & 0x00ff00ff) = (k0, k1), (q >> 8 & ...) = (k2, k3); 3-bit five fields per 16-bit
+    half at bits 0, 3, .. 12 with pair p = 5 j + i = (k 2p, k 2p + 1), and (k30, k31) from bits 15 / 31 of the three words -- with a ragged last chunk."""
+    import numpy as np
+
+    K, N, gs = (160, 32, 32) if bits == 3 else (80 * 2, 32, 16)
+    L = O.random_quant_layer(K, N, bits, gs, seed=3)
+    w = O.unpack_weights(L["qweight"], bits)
+    t = O.decode_copy_weights(L["qweight"], bits).numpy().view(np.uint32)
+    kpl, wpl = (16, 4) if bits == 8 else (32, 3)
+    chunks = -(-K // (4 * kpl))
+    assert t.shape == (N // 16, chunks, 4, 16, wpl)
+    for s_ in range(N // 16):
+        for c in range(chunks):
+            for kb in range(4):
+                for col in (0, 7, 15):
+                    k0 = c * 4 * kpl + kb * kpl
+                    words = [int(x) for x in t[s_, c, kb, col]]
+                    if bits == 8:
+                        got = []
+                        for q in words:
+                            got += [q & 0xFF, (q >> 16) & 0xFF, (q >> 8) & 0xFF, (q >> 24) & 0xFF]
+                    else:
+                        pairs = []
+                        for q in words:
+                            for i in range(5):
+                                pairs.append(((q >> (3 * i)) & 7, (q >> (16 + 3 * i)) & 7))
+                        e_lo = sum(((words[j] >> 15) & 1) << j for j in range(3))
+                        e_hi = sum(((words[j] >> 31) & 1) << j for j in range(3))
+                        pairs.append((e_lo, e_hi))
+                        got = [v for pr in pairs for v in pr]
+                    want = [int(w[k0 + j, 16 * s_ + col]) if k0 + j < K else 0 for j in range(kpl)]
+                    assert got == want, (s_, c, kb, col)
+    for mode in (O.ZERO_WRAP, O.ZERO_NOWRAP):
+        cst = O.decode_copy_consts(L["qzeros"], L["scales"], mode, bits).numpy()
+        z = O.unpack_zeros(L["qzeros"], bits, mode)
+        sb = L["scales"].view(torch.int16).numpy()
+        G = K // gs
+        assert cst.shape == (N // 16, G, 64 if bits == 8 else 48)
+        for s_ in range(N // 16):
+            for g in range(G):
+                rec = cst[s_, g]
+                assert np.array_equal(rec[:32].view(np.int16), sb[g, 16 * s_:16 * s_ + 16])
+                zz = rec[32:].view(np.uint16) if bits == 8 else rec[32:]
+                assert np.array_equal(zz.astype(np.int64), z[g, 16 * s_:16 * s_ + 16].astype(np.int64))

@@ -52,7 +52,7 @@ def main():
         # label with (K, N, M): the launch geometries bench.py produces (decode: M = 1; prefill: --prefill-m rows)
         ent["K"] = ent["N"] = ent["M"] = None
         ent["lds_bytes"] = lds
-        if "gemv_q4_tiled_kernel" in name:
+        if "gemv_tiled_kernel" in name:
             # decode-copy kernel (round 4): one 16-column strip per workgroup -> N = strips * 16 (a multi-layer launch: the summed width); the staged x
             # (K * 2 bytes of LDS) tells the 4096-deep layers from the 11008-deep one
             ent["N"], ent["M"] = blocks * 16, args.m

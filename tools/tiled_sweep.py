@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round 4: decode from the strip-major side copy (tuning.path = 8: gemv_q4_tiled_kernel) against the checkpoint-layout kernels (default plan of a
+"""Round 4: decode from the strip-major side copy (tuning.path = 8: gemv_tiled_kernel) against the checkpoint-layout kernels (default plan of a
 layer built WITHOUT the side copy), rotating HBM-cold weights inside a hipGraph; single layers and the multi-layer launches of gptq_forward_multi.
 Usage: python tools/tiled_sweep.py [--m 1] [--dtype f16] [--quick]"""
 import argparse, os, sys
@@ -59,18 +59,23 @@ def main():
     ap.add_argument("--shapes", default="4096x4096,11008x4096,4096x11008")
     ap.add_argument("--no-multi", action="store_true")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--bits", type=int, default=4)
+    ap.add_argument("--gs", type=int, default=128)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
     M = args.m
     cfgs = CONFIGS if not args.quick else [(16, 2, False), (8, 4, False), (4, 4, False)]
+    bits, gs = args.bits, args.gs
+    if bits != 4:
+        cfgs = [c for c in cfgs if c[1] in (2, 4)]
     for K, N in [tuple(map(int, sh.split('x'))) for sh in args.shapes.split(',')]:
-        per = K * N // 2
+        per = K * N * bits // 8
         nl = max(4, min(64, (400 << 20) // per))
-        layers = [make_layer(K, N, dev, dtype=dt, seed=i) for i in range(nl)]
+        layers = [make_layer(K, N, dev, dtype=dt, seed=i, bits=bits, gs=gs) for i in range(nl)]
         twins = [plain_twin(q) for q in layers]
         x = (torch.rand(M, K, device=dev) - 0.5).to(dt)
-        ab = algorithmic_bytes(K, N, M)
+        ab = algorithmic_bytes(K, N, M, bits=bits, gs=gs)
         res = []
         base, ref = timed(lambda: [q(x) for q in twins])
         res.append((base / nl, "checkpoint layout (round-3 default plan)"))
@@ -92,11 +97,11 @@ def main():
         del layers, twins
         torch.cuda.empty_cache()
     for name, K, Ns in () if args.no_multi else (("qkv", 4096, (4096, 4096, 4096)), ("gate_up", 4096, (11008, 11008))):
-        ng = max(3, (400 << 20) // (K * sum(Ns) // 2))
-        groups = [[make_layer(K, n, dev, dtype=dt, seed=100 * gi + i) for i, n in enumerate(Ns)] for gi in range(ng)]
+        ng = max(3, (400 << 20) // (K * sum(Ns) * bits // 8))
+        groups = [[make_layer(K, n, dev, dtype=dt, seed=100 * gi + i, bits=bits, gs=gs) for i, n in enumerate(Ns)] for gi in range(ng)]
         tgroups = [[plain_twin(q) for q in grp] for grp in groups]
         x = (torch.rand(M, K, device=dev) - 0.5).to(dt)
-        ab = sum(algorithmic_bytes(K, n, M) for n in Ns)
+        ab = sum(algorithmic_bytes(K, n, M, bits=bits, gs=gs) for n in Ns)
         res = []
         base, ref = timed(lambda: [forward_multi(grp, x) for grp in tgroups])
         res.append((base / ng, "checkpoint layout forward_multi (round-3 default plan)"))
