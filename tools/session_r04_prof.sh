@@ -7,14 +7,17 @@ R=$GRAFT_REPO_ROOT
 bash $R/tools/prof_bench.sh $TAG > /dev/null 2>&1
 OUT=$R/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
-cat > /tmp/$TAG.gemm.sh <<EOS
-python $R/tools/prefill_shapes.py --ms 4096 --shapes 4096x4096
-python $R/tools/prefill_shapes.py --ms 2048 --shapes 4096x11008
-EOS
-CMD="bash /tmp/$TAG.gemm.sh"
-timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES -d /tmp/$TAG/g1 -o p -- $CMD > $OUT/gemm_pmc1.log 2>&1
-timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU GRBM_GUI_ACTIVE -d /tmp/$TAG/g2 -o p -- $CMD > $OUT/gemm_pmc2.log 2>&1
-python $R/tools/rocprof_summary.py /tmp/$TAG/g1/p_results.db --match gemm > $OUT/gemm_pmc.txt 2>&1
-python $R/tools/rocprof_summary.py /tmp/$TAG/g2/p_results.db --match gemm >> $OUT/gemm_pmc.txt 2>&1
+# one rocprofv3 run per shape and counter set (a second process under the same -o overwrites the first's database)
+: > $OUT/gemm_pmc.txt
+i=0
+for ARGS in "--ms 4096 --shapes 4096x4096" "--ms 2048 --shapes 4096x11008"; do
+  i=$((i+1))
+  CMD="python $R/tools/prefill_shapes.py $ARGS"
+  timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES -d /tmp/$TAG/g1_$i -o p -- $CMD > $OUT/gemm_pmc1_$i.log 2>&1
+  timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU GRBM_GUI_ACTIVE -d /tmp/$TAG/g2_$i -o p -- $CMD > $OUT/gemm_pmc2_$i.log 2>&1
+  echo "## $ARGS" >> $OUT/gemm_pmc.txt
+  python $R/tools/rocprof_summary.py /tmp/$TAG/g1_$i/p_results.db --match gemm >> $OUT/gemm_pmc.txt 2>&1
+  python $R/tools/rocprof_summary.py /tmp/$TAG/g2_$i/p_results.db --match gemm >> $OUT/gemm_pmc.txt 2>&1
+done
 cut -c1-220 $OUT/kernel_stats.txt | head -30
 cat $OUT/pmc_traffic.txt | cut -c1-300 | head -20
