@@ -121,14 +121,61 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
         for (int pc0 = wave * 64; pc0 < cpieces; pc0 += W * 64)
             if (pc0 + lane < cpieces) dma16_nt(cg + (size_t)(pc0 + lane) * 16, __builtin_amdgcn_readfirstlane(cs_lds + pc0 * 16));
     }
+    // bf16 layers: x is converted IN PLACE in the LDS to fp16 with one power-of-two factor per (row, run of KPL k) -- block floating point -- so that the
+    // loop below is the fp16 loop: w - z is a small integer, exact in either type, and turning every fp16 pair into bf16 costs 12 VALU per packed word (the
+    // round-3 kernels' 7 - 25 % bf16 gap).  A run is what one lane sums on the matrix core before its fp32 sums meet the scale, so the factor's inverse rides
+    // on the scale (xe[run][row]); it puts the run's largest |x| into [2^14, 2^15): nothing overflows (bf16 reaches 3e38, fp16 65504), elements more than
+    // 2^-28 below the run's largest lose bits -- below the resolution of the fp32 sum they enter.  Products stay exact (8-bit by 11-bit significands into
+    // fp32), as on the bf16 matrix core.  One thread = one 16-byte piece, the NX pieces of a run in adjacent lanes; one more barrier.
+    // (Tried instead, same speed at one row and slower at four: one factor per row through an LDS atomic max, and each wave converting its own chunks'
+    // x inside the K loop -- profiles/r04_tiled_sweep_bf16_v*.log.)
+    // The conversion is done by every workgroup for its whole K slice: at 3 - 4 rows it costs what converting the weights costs, so those keep the bf16
+    // matrix core (XC false).
+    constexpr bool XC = BF && MT <= 2;
+    using MM = std::conditional_t<XC, f16, T>;                                    // the matrix core's operand type
+    constexpr int ES = MT * 16 + 4;
+    float* const xe = red + W * ES;                                               // [runs of the slice][4 rows] inverse factors (bf16 layers only; planned for)
+    auto x_to_f16 = [&]() {                                                       // every thread of the workgroup, behind the staging barrier
+        const int prow = (kend - kbeg) >> 3, total = prow * MT;                   // pieces per row: a multiple of NX, like the thread stride
+        for (int i0 = 0; i0 < total; i0 += W * 64) {                             // uniform trip count: the shuffles below need every lane
+            const int idx = i0 + tid;
+            const bool ok = idx < total;
+            int m = 0, pc = ok ? idx : 0;
+            if constexpr (MT > 1) { m = pc / prow; pc -= m * prow; }
+            u32x4* const at = (u32x4*)(xs + (size_t)m * xstride + (size_t)pc * 16);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = *at;
+            unsigned mx = 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned a = v[i] & 0x7fff7fffu;
+                mx = max(mx, max(a & 0xffffu, a >> 16));
+            }
+            mx = max(mx, (unsigned)__shfl_xor((int)mx, 1, 64));
+            if constexpr (NX == 4) mx = max(mx, (unsigned)__shfl_xor((int)mx, 2, 64));
+            const int E = (int)((mx >> 7) & 0xffu);                               // biased exponent of the run's largest |x|
+            const int ms = min(max(268 - E, 1), 253);                             // 2^(ms - 127): the largest lands in [2^14, 2^15)
+            const float mult = __builtin_bit_cast(float, (unsigned)ms << 23);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float lo = __builtin_bit_cast(float, v[i] << 16) * mult, hi = __builtin_bit_cast(float, v[i] & 0xffff0000u) * mult;
+                v[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));              // exact unless the result is an fp16 subnormal
+            }
+            if (ok) {
+                *at = v;
+                if ((pc & (NX - 1)) == 0) xe[(pc / NX) * 4 + m] = __builtin_bit_cast(float, (unsigned)(254 - ms) << 23);
+            }
+        }
+        __syncthreads();
+    };
     const char* const xl = xs + (size_t)min(lane & 3, MT - 1) * xstride + kb * (KPL * 2);    // A operand: lane i of a 4-lane group carries x row i
     float acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = 0.f;
     const f16x2 k960 = {(f16)960.f, (f16)960.f}, k896 = {(f16)896.f, (f16)896.f}, k1008 = {(f16)1008.f, (f16)1008.f};
     const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f}, r8 = {(f16)0.125f, (f16)0.125f}, r64 = {(f16)0.015625f, (f16)0.015625f};
-    auto bits_of = [&](f16x2 hv) -> unsigned {                                    // the pair as the matrix core takes it: fp16, or fp16 -> fp32 -> bf16 (exact: small integers)
-        if constexpr (BF) {
+    auto bits_of = [&](f16x2 hv) -> unsigned {                                    // the pair as the matrix core takes it: fp16 (also bf16 layers behind x_to_f16), or
+        if constexpr (BF && !XC) {                                                // fp16 -> fp32 -> bf16 (exact: small integers)
             const bf16x2 o = {(bf16)(float)hv[0], (bf16)(float)hv[1]};
             return __builtin_bit_cast(unsigned, o);
         } else {
@@ -144,6 +191,7 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
         if (!staged) {                                                            // first pass only (uniform): the staging DMAs are OLDER than the U loads just issued
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(U) : "memory");
             __syncthreads();
+            if constexpr (XC) x_to_f16();
             staged = true;
         }
 #pragma unroll
@@ -172,8 +220,8 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
                     const f16x2 h1 = as_f16x2((qw & m_hi) | magic) * r16 + c2;    // k2,k3  (1 and 5)
                     const f16x2 h2 = as_f16x2((q8 & m_lo) | magic) + c1;          // k4,k5  (2 and 6)
                     const f16x2 h3 = as_f16x2((q8 & m_hi) | magic) * r16 + c2;    // k6,k7  (3 and 7)
-                    accg = Mma4<T>::run(u32x2{xa[w][0], xa[w][1]}, u32x2{bits_of(h0), bits_of(h1)}, accg);
-                    accg = Mma4<T>::run(u32x2{xa[w][2], xa[w][3]}, u32x2{bits_of(h2), bits_of(h3)}, accg);
+                    accg = Mma4<MM>::run(u32x2{xa[w][0], xa[w][1]}, u32x2{bits_of(h0), bits_of(h1)}, accg);
+                    accg = Mma4<MM>::run(u32x2{xa[w][2], xa[w][3]}, u32x2{bits_of(h2), bits_of(h3)}, accg);
                 }
             } else if constexpr (BITS == 8) {
 #pragma unroll
@@ -181,7 +229,7 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
                     const unsigned qw = qv[w], q8 = qw >> 8;
                     const f16x2 h0 = as_f16x2((qw & m_b) | magic) + c1;           // k0,k1  (stored bytes 0 and 2)
                     const f16x2 h1 = as_f16x2((q8 & m_b) | magic) + c1;           // k2,k3  (1 and 3)
-                    accg = Mma4<T>::run(u32x2{xa[w >> 1][(w & 1) * 2], xa[w >> 1][(w & 1) * 2 + 1]}, u32x2{bits_of(h0), bits_of(h1)}, accg);
+                    accg = Mma4<MM>::run(u32x2{xa[w >> 1][(w & 1) * 2], xa[w >> 1][(w & 1) * 2 + 1]}, u32x2{bits_of(h0), bits_of(h1)}, accg);
                 }
             } else {
                 const f16x2 c3 = c1 + k896;                                       // -(128 + z): fields at bit 3, times 1/8
@@ -200,11 +248,17 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
                 pr[15] = bits_of(as_f16x2(e | magic) + c1);
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    accg = Mma4<T>::run(u32x2{xa[i >> 1][(i & 1) * 2], xa[i >> 1][(i & 1) * 2 + 1]}, u32x2{pr[2 * i], pr[2 * i + 1]}, accg);
+                    accg = Mma4<MM>::run(u32x2{xa[i >> 1][(i & 1) * 2], xa[i >> 1][(i & 1) * 2 + 1]}, u32x2{pr[2 * i], pr[2 * i + 1]}, accg);
             }
             const float sc = DType<T>::to_f32(__builtin_bit_cast(T, sraw));
+            if constexpr (XC) {
+                const float* const xi = xe + ((cc - cb) * 4 + kb) * 4;           // the run's inverse block factors, one per row
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = live ? fmaf(sc, accg[m], acc[m]) : acc[m];   // a select, not a product by 0: a dead slot's x is whatever the LDS holds
+                for (int m = 0; m < MT; ++m) acc[m] = live ? fmaf(sc * xi[m], accg[m], acc[m]) : acc[m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = live ? fmaf(sc, accg[m], acc[m]) : acc[m];   // a select, not a product by 0: a dead slot's x is whatever the LDS holds
+            }
         }
     }
     // ---- k-slots (two shuffles: a lane owns one column), waves (LDS), then write / publish ---------------------------------------------------
@@ -216,7 +270,6 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
         acc[m] = v;
     }
     if (!staged) __syncthreads();                                                 // (an empty slice never took the staging barrier; the planner makes none)
-    constexpr int ES = MT * 16 + 4;
     if (lane < 16) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) red[wave * ES + m * 16 + lane] = acc[m];
@@ -280,7 +333,8 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
     const size_t lds_cap = 96 * 1024;
     auto lds_need = [&](int k_slices, int waves) {
         const int cps = (chunks + k_slices - 1) / k_slices;
-        return (size_t)pl.mt * ((size_t)cps * cke * 2 + 16) + (size_t)pl.groups * rec + (size_t)waves * (pl.mt * 16 + 4) * sizeof(float) + 16;
+        return (size_t)pl.mt * ((size_t)cps * cke * 2 + 16) + (size_t)pl.groups * rec + (size_t)waves * (pl.mt * 16 + 4) * sizeof(float) + 16 +
+               (A.dtype == GPTQ_BF16 && pl.mt <= 2 ? (size_t)cps * 64 : 0);                      // bf16: one inverse block factor per (run of a chunk's 4, row of 4)
     };
     while (ks < 8 && ks < chunks && lds_need(ks, 16) > lds_cap) ks *= 2;
     if (ks > chunks) ks = chunks;

@@ -335,10 +335,10 @@ def _kernel_of(ent, M):
     from autogptq_amd import _lib
     q = ent[3]
     if isinstance(q, list):                           # gptq_forward_multi: plain 4-bit layers, M <= 4 -- the decode-copy kernel when the layers carry the copy
-        return "gptq::gemv_tiled_kernel" if all(getattr(l, "_qweight_tiled", None) is not None for l in q) else "gptq::gemv_q4_stream_kernel"
+        return f"gptq::gemv_tiled_kernel<{q[0].bits}," if all(getattr(l, "_qweight_tiled", None) is not None for l in q) else "gptq::gemv_q4_stream_kernel"
     d = _lib.describe_plan(q._layer, M)
     return {"stream": "gptq::gemv_q4_stream_kernel", "mfma": "gptq::gemv_q4_f16_mfma_kernel", "mfma_generic": "gptq::gemv_mfma_generic_kernel",
-            "strips": "gptq::gemv_tiled_kernel", "tiled": "gptq::gemm_kernel"}.get(d.get("kernel"), "gptq::" + str(d.get("kernel")))
+            "strips": f"gptq::gemv_tiled_kernel<{q.bits},", "tiled": "gptq::gemm_kernel"}.get(d.get("kernel"), "gptq::" + str(d.get("kernel")))
 
 
 def _plan_of(layers, K, N, M):
@@ -753,6 +753,8 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
         roof["kernel"] = "gptq::gemm_kernel<4, f16, 4, 64>" if prefill else best["kernel"]
         roof["traffic"] = pmc_traffic(roof["kernel"], K, N, M)
+        if roof["kernel"].endswith(","):
+            roof["kernel"] += " MT, U, T, MAXW>"
         roof["shape"] = (f"{best['gname']}: " if best["gname"] else "") + f"K={K} N={N} M={M}" + (" (layers of one gptq_forward_multi launch)" if best["gname"] else "")
         roof["us_per_launch_events"] = round(best["per_launch_s"] * 1e6, 3)
         roof["us_per_launch_by_shape"] = per_type
