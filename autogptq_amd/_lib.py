@@ -31,7 +31,7 @@ EXPORTS = (
     "gptq_awq_unpack", "gptq_awq_repack", "gptq_describe_plan",
     "gptq_init", "gptq_workspace_bytes_max", "gptq_validate_g_idx",
     "gptq_forward_multi", "gptq_workspace_bytes_multi", "gptq_forward_multi_ex", "gptq_workspace_bytes_multi_ex",
-    "gptq_peer_scatter", "gptq_peer_collect", "gptq_peer_gather",
+    "gptq_peer_scatter", "gptq_peer_collect", "gptq_peer_gather", "gptq_forward_scatter", "gptq_forward_gather", "gptq_peer_publish",
     "gptq_mlp_forward", "gptq_mlp_forward_ex", "gptq_workspace_bytes_mlp", "gptq_workspace_bytes_mlp_ex", "gptq_describe_mlp_plan",
 )
 WS_HEADER_BYTES = 65536
@@ -134,6 +134,9 @@ def load() -> ctypes.CDLL:
     lib.gptq_peer_scatter.argtypes = [POINTER(GptqPeerGroup), c_void_p, c_int, c_int, c_int, c_void_p]
     lib.gptq_peer_collect.argtypes = [POINTER(GptqPeerGroup), c_void_p, c_int, c_int, ctypes.c_uint32, c_void_p]
     lib.gptq_peer_gather.argtypes = [POINTER(GptqPeerGroup), c_void_p, c_void_p, c_int, c_int, c_int, ctypes.c_uint32, c_void_p]
+    lib.gptq_peer_publish.argtypes = [POINTER(GptqPeerGroup), c_void_p]
+    lib.gptq_forward_scatter.argtypes = [LP, c_void_p, c_int, POINTER(GptqPeerGroup), c_void_p, c_size_t, c_void_p]
+    lib.gptq_forward_gather.argtypes = [LP, c_void_p, c_void_p, c_int, POINTER(GptqPeerGroup), ctypes.c_uint32, c_void_p, c_size_t, c_void_p]
     for name in EXPORTS:
         if name not in ("gptq_last_error", "gptq_status_string", "gptq_workspace_bytes", "gptq_workspace_bytes_ex",
                         "gptq_workspace_bytes_max", "gptq_workspace_bytes_multi", "gptq_workspace_bytes_multi_ex",

@@ -829,6 +829,13 @@ int gptq_peer_scatter(const gptq_peer_group_t* pg, const void* y_local, int M, i
     return GPTQ_OK;
 }
 
+int gptq_peer_publish(const gptq_peer_group_t* pg, void* stream) {
+    if (int rc = check_peer_group(pg, 1, GPTQ_F16)) return rc;
+    hipError_t e = launch_peer_publish(*pg, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_peer_publish launch");
+    return GPTQ_OK;
+}
+
 int gptq_peer_collect(const gptq_peer_group_t* pg, void* out, int M, int dtype, uint32_t max_spins, void* stream) {
     if (int rc = check_peer_group(pg, M, dtype)) return rc;
     if (!out) return fail(GPTQ_ERR_NULL, "out must be non-NULL");
@@ -836,6 +843,35 @@ int gptq_peer_collect(const gptq_peer_group_t* pg, void* out, int M, int dtype, 
     hipError_t e = launch_peer_collect(*pg, out, M, dtype, max_spins, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "gptq_peer_collect launch");
     return GPTQ_OK;
+}
+
+// The column shard's decode kernel with the scatter as its epilogue: local kernel + one collect launch per tensor-parallel layer.
+int gptq_forward_scatter(const gptq_layer_t* L, const void* x, int M, const gptq_peer_group_t* pg, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_layer(L);
+    if (rc) return rc;
+    if (!x) return fail(GPTQ_ERR_NULL, "x must be non-NULL");
+    if ((rc = check_peer_group(pg, M, L->dtype))) return rc;
+    if (L->N != pg->N / pg->world) return fail(GPTQ_ERR_SHAPE, "the layer's out_features (%d) must be the rank's shard N / world = %d", L->N, pg->N / pg->world);
+    const gptq_layer_t* one[1] = {L};
+    if (L->epilogue != GPTQ_EPI_NONE || !want_tiled(one, 1, M, nullptr))
+        return fail(GPTQ_ERR_UNSUPPORTED, "gptq_forward_scatter: the fused scatter is the epilogue of the decode-copy kernel (M <= 4, a plain 3/4/8-bit fp16/bf16 "
+                                          "layer that carries qweight_tiled / qconst_tiled); use gptq_forward + gptq_peer_scatter for this call");
+    const WsView wv = split_ws(ws, ws_bytes);
+    const TiledPlan tp = plan_tiled(one, 1, M, nullptr);
+    if (tp.partial_bytes > 0 && wv.body_bytes < tp.partial_bytes)
+        return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + tp.partial_bytes, wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0);
+    void* outs[1] = {nullptr};                                  // the rank's own slice travels through its own exchange buffer like every peer's
+    hipError_t e = launch_tiled(one, tp, x, outs, M, wv.header, wv.body, (hipStream_t)stream, pg);
+    if (e != hipSuccess) return hip_fail(e, "gptq_forward_scatter launch (was gptq_init() called on this device?)");
+    return GPTQ_OK;
+}
+
+int gptq_forward_gather(const gptq_layer_t* L, const void* x, void* out, int M, const gptq_peer_group_t* pg, uint32_t max_spins, void* ws, size_t ws_bytes,
+                        void* stream) {
+    if (!out) return fail(GPTQ_ERR_NULL, "out must be non-NULL");
+    if (max_spins == 0) return fail(GPTQ_ERR_SHAPE, "max_spins must be > 0 (the wait is bounded by design)");
+    if (int rc = gptq_forward_scatter(L, x, M, pg, ws, ws_bytes, stream)) return rc;
+    return gptq_peer_collect(pg, out, M, L->dtype, max_spins, stream);
 }
 
 int gptq_peer_gather(const gptq_peer_group_t* pg, const void* y_local, void* out, int M, int n_local, int dtype,

@@ -72,10 +72,11 @@ struct GemvStreamParams {
 
 // Shared tail of the streamed GEMV kernels: row slots (DPP / bpermute), waves (LDS, the kernel's only barrier), then write -- or, with a K split,
 // publish / combine through {fp32, tag} granules.
+// (stage: optional LDS copy of the finished [MT][CT] outputs of the strip; sg.out may then be null.)
 // Second half of the streamed kernels' tail: the per-wave partial sums of the workgroup's CT columns x MT rows are in LDS (red[wave * (MT * CT + 4) + m * CT + c],
 // behind a barrier); cross-wave sum, then write -- or, with a K split, publish / combine through {fp32, tag} granules.
 template <int CT, int MT, typename T, typename PP = GemvStreamParams, typename SG = GemvSeg>
-__device__ __forceinline__ void stream_finish(const PP& p, const SG& sg, int strip, int sidx, int ks, int N, const float* red) {
+__device__ __forceinline__ void stream_finish(const PP& p, const SG& sg, int strip, int sidx, int ks, int N, const float* red, T* stage = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
     constexpr int E = MT * CT, ES = E + 4;                                    // slab stride padded by 16 B: the W partials of an entry spread over banks
     // K split: slice ks >= 1 PUBLISHES its partial sums as 8-byte {fp32, tag} granules (one write-through store each) and is done; slice 0,
@@ -127,7 +128,9 @@ __device__ __forceinline__ void stream_finish(const PP& p, const SG& sg, int str
                 if (k < p.ksplit - 1) __hip_atomic_store(p.gran + (size_t)k * slab + at, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (sg.bias) t += DType<T>::to_f32(((const T*)sg.bias)[n]);
-        ((T*)sg.out)[(size_t)m * N + n] = DType<T>::from_f32(t);
+        const T o = DType<T>::from_f32(t);
+        if (sg.out) ((T*)sg.out)[(size_t)m * N + n] = o;
+        if (stage) stage[m * CT + c] = o;                                      // tensor-parallel epilogue (gemv_tiled.hip): the strip's rows, for the peer stores
     };
     if ((W & (W - 1)) == 0) {
         // every wave takes 64 / W entries per round; its lanes are (entry, partial w) pairs: one LDS read each, then a fixed

@@ -41,6 +41,15 @@ struct TiledSeg {
     int N, col0;             // columns of this layer; its first column in the concatenated partial slab
     int pad_[2];
 };
+// Tensor-parallel epilogue (gptq_forward_scatter; protocol: peer.hip): the owner workgroup of a strip stores its [M][16] outputs at the rank's column
+// offset of EVERY rank's exchange buffer of this call's parity; the rank's arrival flag is raised by the collect launch behind this kernel.
+struct PeerEpi {
+    char* xbuf[2][GPTQ_PEER_MAX];
+    unsigned* flags[GPTQ_PEER_MAX];
+    unsigned* state;         // [0] gathers completed (the epoch)
+    int world, rank;
+    unsigned row_bytes, col_off_bytes, owners, pad_;
+};
 struct TiledParams {
     int blk_end[4];          // cumulative strip count up to and including layer i (unused entries: INT_MAX)
     const void* x;
@@ -50,6 +59,7 @@ struct TiledParams {
     int nseg, M, K, chunks, chunks_per_split, ksplit, gu_shift, nsum, groups, xstride, waves;
     unsigned max_spins;
     TiledSeg seg[4];
+    PeerEpi peer;            // world = 0: none.  Read by the owner workgroups only, behind their K loop.
 };
 
 // Per packing: what a lane of one chunk load holds.  The chunk is always 4 k-slots x 16 columns; a lane (k-slot, column) holds WPL consecutive words =
@@ -275,7 +285,26 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
         for (int m = 0; m < MT; ++m) red[wave * ES + m * 16 + lane] = acc[m];
     }
     __syncthreads();
-    stream_finish<16, MT, T, TiledParams, TiledSeg>(p, sg, strip, sidx, ks, N, red);
+    const int pworld = p.peer.world;
+    T* const stage = pworld > 0 ? (T*)xs : nullptr;                                // the staged x is dead behind the barrier above
+    stream_finish<16, MT, T, TiledParams, TiledSeg>(p, sg, strip, sidx, ks, N, red, stage);
+    if (pworld > 0 && ks == 0) {                                                  // uniform: the strip's owner
+        __syncthreads();
+        const unsigned e = __hip_atomic_load(p.peer.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;      // this gather's epoch (peer.hip)
+        if (tid < pworld * MT * 2) {                                              // (peer, row, half of the strip's 32 bytes)
+            const int r = tid / (MT * 2), m = (tid >> 1) % MT, q = tid & 1;
+            if (m < Mrows) {
+                const u32x4 v = *(const u32x4*)((const char*)stage + m * 32 + q * 16);
+                char* const dst = p.peer.xbuf[e & 1u][r] + (size_t)m * p.peer.row_bytes + p.peer.col_off_bytes + (size_t)strip * 32 + q * 16;
+                // a system-scope WRITE-THROUGH store (sc0 sc1): the payload goes to its home, not into this XCD's L2.  NOT a release fence per
+                // workgroup: at system (and agent) scope that is an L2 write-back, and hundreds of strips doing one each cost 20 - 240 us per launch
+                // (profiles/r04_tp2_same_device_fused_scatter_v1 / v2*.json).
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+            }
+        }
+        // No ticket, no flag here: the rank's arrival flag is raised by its COLLECT launch, which starts behind this kernel in stream order (every store
+        // above has been acknowledged by then).  A ticket drawn by every strip -- 256 .. 896 fetch-adds on one word -- measured 8 - 70 us per launch.
+    }
 }
 
 // ---- plan + launch ---------------------------------------------------------------------------------------------------------------------
@@ -406,9 +435,23 @@ static hipError_t launch_tiled_bits(const TiledPlan& pl, const TiledParams& p, h
 }
 
 hipError_t launch_tiled(const gptq_layer_t* const* Ls, const TiledPlan& pl, const void* x, void* const* outs, int M, void* ws_header, void* ws_body,
-                        hipStream_t st) {
+                        hipStream_t st, const gptq_peer_group_t* pg) {
     if (!pl.ok) return hipErrorInvalidValue;
     TiledParams p{};
+    if (pg) {                                                                     // one layer = this rank's column shard
+        if (pl.nseg != 1 || pg->world < 1 || pg->world > GPTQ_PEER_MAX) return hipErrorInvalidValue;
+        for (int r = 0; r < pg->world; ++r) {
+            p.peer.xbuf[0][r] = (char*)pg->xbuf[0][r];
+            p.peer.xbuf[1][r] = (char*)pg->xbuf[1][r];
+            p.peer.flags[r] = pg->flags[r];
+        }
+        p.peer.state = pg->state;
+        p.peer.world = pg->world;
+        p.peer.rank = pg->rank;
+        p.peer.row_bytes = (unsigned)pg->N * 2u;
+        p.peer.col_off_bytes = (unsigned)pg->rank * (unsigned)Ls[0]->N * 2u;
+        p.peer.owners = (unsigned)pl.strips_total;
+    }
     int blk = 0, col = 0;
     for (int i = 0; i < 4; ++i) p.blk_end[i] = 0x7fffffff;
     for (int i = 0; i < pl.nseg; ++i) {

@@ -101,7 +101,7 @@ struct TiledPlan {
 bool tiled_layer_ok(const gptq_layer_t& L);
 TiledPlan plan_tiled(const gptq_layer_t* const* layers, int n, int M, const gptq_tuning_t* tune);
 hipError_t launch_tiled(const gptq_layer_t* const* layers, const TiledPlan& pl, const void* x, void* const* outs, int M, void* ws_header, void* ws_body,
-                        hipStream_t st);
+                        hipStream_t st, const gptq_peer_group_t* pg = nullptr);      // pg: tensor-parallel epilogue (outs[0] may be null then)
 hipError_t init_gemv_tiled_device();
 // the decode copy of a 3/4/8-bit layer (utils.hip): qweight_tiled (chunks of 4 k-slots x 16 columns, column per lane, fields in pair order) and qconst_tiled
 size_t tiled_weight_bytes(const gptq_layer_t& L);
@@ -134,6 +134,7 @@ hipError_t launch_permute_rows16(const void* x, const int32_t* perm, int M, int 
 hipError_t launch_permute_columns(const void* x, const int32_t* perm, int M, int K, int dtype, void* x_out, hipStream_t st);
 // peer.hip: direct peer-store all-gather (y_local / out may be NULL: scatter-only / collect-only)
 hipError_t launch_peer_scatter(const gptq_peer_group_t& pg, const void* y_local, int M, int n_local, int dtype, hipStream_t st);
+hipError_t launch_peer_publish(const gptq_peer_group_t& pg, hipStream_t st);
 hipError_t launch_peer_collect(const gptq_peer_group_t& pg, void* out, int M, int dtype, unsigned max_spins, hipStream_t st);
 
 }  // namespace gptq

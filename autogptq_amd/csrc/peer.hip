@@ -12,6 +12,9 @@
 //   peer_scatter_kernel    16-byte payload stores, lanes contiguous along a row of the slice; every block then fences at system
 //                          scope and takes a ticket, the last block publishes epoch e + 1 into flags[r][rank] of every rank r
 //                          (system-scope release) and resets the ticket.
+//   (round 4) gptq_forward_scatter makes the payload stores the EPILOGUE of the rank's decode kernel (gemv_tiled.hip: write-through stores, no fence, no
+//                          ticket -- both measured at 8 .. 240 us per launch when every strip does one); the rank's flag is then raised by the first
+//                          block of its collect launch, which starts behind that kernel in stream order (peer_publish_kernel does only that).
 //   peer_collect_kernel    every block: lanes 0..T-1 poll flags[rank][r] (relaxed, system scope) until they carry the epoch --
 //                          a BOUNDED spin (max_spins polls, then state[3] is raised and the kernel carries on instead of
 //                          hanging the queue) -- then a system-scope acquire, then the block copies its share of the gathered
@@ -67,6 +70,11 @@ __global__ void __launch_bounds__(256) peer_scatter_kernel(PeerArgs a, const u32
 
 __global__ void __launch_bounds__(256) peer_collect_kernel(PeerArgs a, u32x4* __restrict__ out, size_t chunks, unsigned max_spins) {
     const unsigned e = __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    // The rank's arrival flag, (re-)published by the first block: everything this rank enqueued in front of this launch has completed (stream order), its
+    // payload stores included -- this is what raises the flag when the scatter was the epilogue of the rank's decode kernel (gptq_forward_scatter, which
+    // has no ticket of its own); behind peer_scatter_kernel it stores the value that kernel already stored.
+    if (blockIdx.x == 0 && (int)threadIdx.x < a.world)
+        __hip_atomic_store(a.flags[threadIdx.x] + a.rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((int)threadIdx.x < a.world) {
         const unsigned* f = a.flags[a.rank] + threadIdx.x;
         unsigned spins = 0;
@@ -92,6 +100,13 @@ __global__ void __launch_bounds__(256) peer_collect_kernel(PeerArgs a, u32x4* __
     }
 }
 
+// The rank's arrival flag on its own: for callers that run several ranks on ONE stream (the simulated-rank tests) or enqueue unrelated work between a
+// gptq_forward_scatter and its collect.  Everything the rank enqueued in front has completed (stream order).
+__global__ void __launch_bounds__(64) peer_publish_kernel(PeerArgs a) {
+    const unsigned e = __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if ((int)threadIdx.x < a.world) __hip_atomic_store(a.flags[threadIdx.x] + a.rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 static PeerArgs peer_args(const gptq_peer_group_t& pg) {
     PeerArgs a{};
     for (int r = 0; r < pg.world; ++r) {
@@ -113,6 +128,11 @@ hipError_t launch_peer_scatter(const gptq_peer_group_t& pg, const void* y_local,
     const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>((total + 255) / 256, 1024));
     hipLaunchKernelGGL(peer_scatter_kernel, dim3(gx, pg.world), dim3(256), 0, st, a, (const u32x4*)y_local, M, cpr,
                        (size_t)pg.N * es, (size_t)pg.rank * n_local * es);
+    return hipGetLastError();
+}
+
+hipError_t launch_peer_publish(const gptq_peer_group_t& pg, hipStream_t st) {
+    hipLaunchKernelGGL(peer_publish_kernel, dim3(1), dim3(64), 0, st, peer_args(pg));
     return hipGetLastError();
 }
 

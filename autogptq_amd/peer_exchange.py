@@ -242,6 +242,32 @@ class PeerExchange:
                                                 _lib.DTYPE_ENUM[self.dtype], self.max_spins, st))
         return out
 
+    def fused_ok(self, qlinear, M: int) -> bool:
+        """Can ``forward_gather`` run this shard?  (The scatter is the epilogue of the decode-copy kernel: M <= 4, a plain 3/4/8-bit layer with its copy.)"""
+        return (M <= 4 and getattr(qlinear, "_qweight_tiled", None) is not None and getattr(qlinear, "epilogue", "none") == "none"
+                and qlinear.outfeatures * self.world == self.N and qlinear.scales.dtype == self.dtype)
+
+    def forward_gather(self, qlinear, x2: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x2 [M, K] -> [M, N]: the rank's column shard ``qlinear`` (an mi355x QuantLinear) computes its slice and stores it into every rank's
+        exchange buffer from its own epilogue (gptq_forward_scatter), then ONE collect launch.  Two launches per tensor-parallel layer."""
+        from .qlinear_mi355x import reserve_workspace
+
+        if qlinear._layer is None:
+            qlinear.post_init()
+        M = x2.shape[0]
+        if out is None:
+            out = torch.empty((M, self.N), dtype=self.dtype, device=self.device)
+        lib = _lib.load()
+        need = int(lib.gptq_workspace_bytes(ctypes.byref(qlinear._layer), M))
+        ws_ptr, ws_bytes = None, 0
+        if need:
+            buf = reserve_workspace(self.device, need)
+            ws_ptr, ws_bytes = buf.data_ptr(), buf.numel()
+        st = _lib.current_stream_handle(self.device)
+        _lib.check(lib.gptq_forward_gather(ctypes.byref(qlinear._layer), x2.data_ptr(), out.data_ptr(), M, ctypes.byref(self.pg), self.max_spins,
+                                           ws_ptr, ws_bytes, st))
+        return out
+
     def check_timeout(self) -> None:
         """Synchronises; raises if any collect so far gave up on a peer."""
         if int(self.state[3].item()) != 0:

@@ -14,6 +14,8 @@ Rank r of T owns columns [r*N/T, (r+1)*N/T): ``qweight[:, n0:n1]``, ``qzeros[:, 
 ``exchange="peer_store"`` (experimental, off by default) replaces the collective by the direct peer-store
 exchange of ``csrc/peer.hip``: every rank stores its slice into every rank's exchange buffer (one xGMI link per peer), raises a
 flag, and copies its own gathered rows out -- two launches, graph-capturable, no rank-major -> column-major copy for M > 1.
+For decode rows (M <= 4) on a shard that carries its decode copy the scatter is the EPILOGUE of the shard's kernel (gptq_forward_scatter): a
+tensor-parallel layer is then the local kernel + one collect launch.
 """
 from __future__ import annotations
 
@@ -64,6 +66,7 @@ class ColumnParallelQuantLinear(nn.Module):
         self.max_rows = max_rows
         self.check_timeout_every = check_timeout_every
         self._calls = 0
+        self.fused_calls = 0                # forwards that ran as local kernel (scatter in its epilogue) + collect
         self._px = None                     # PeerExchange, built on the first forward (needs the output dtype / device)
 
     @classmethod
@@ -86,7 +89,38 @@ class ColumnParallelQuantLinear(nn.Module):
         return cls(local, full.outfeatures, group=group, gather_output=gather_output, exchange=exchange, max_rows=max_rows,
                    check_timeout_every=check_timeout_every)
 
+    def _fused_peer_forward(self, x: torch.Tensor):
+        """Decode rows on a shard that carries its decode copy: the scatter is the kernel's epilogue (gptq_forward_scatter) -- local kernel + one collect.
+        None when this call does not qualify (then: local forward + scatter + collect)."""
+        q = self.local
+        if self.exchange != "peer_store" or not self.gather_output or self.world == 1 or not x.is_cuda or not hasattr(q, "_qweight_tiled"):
+            return None
+        K = q.infeatures
+        M = x.numel() // K if K else 0
+        if M < 1 or M > 4 or x.dtype != q.scales.dtype:
+            return None
+        if q._layer is None:
+            q.post_init()
+        nl = q.outfeatures
+        if self._px is None or self._px.rows_max < M:
+            from .peer_exchange import PeerExchange
+            self._px = PeerExchange(max(M, self.max_rows), self.world * nl, q.scales.dtype, x.device, group=self.group)
+        if not self._px.fused_ok(q, M):
+            return None
+        x2 = x.reshape(-1, K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        out = self._px.forward_gather(q, x2).reshape(x.shape[:-1] + (self.world * nl,))
+        self.fused_calls += 1
+        self._calls += 1
+        if self.check_timeout_every and self._calls % self.check_timeout_every == 0:
+            self._px.check_timeout()
+        return out
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        fused = self._fused_peer_forward(x)
+        if fused is not None:
+            return fused
         y = self.local(x)                                   # [..., N/T]
         if not self.gather_output or self.world == 1:
             return y

@@ -586,7 +586,14 @@ def bench_tp(device, rank, world, steps, peer_store=False):
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 ent["us_per_layer_with_peer_store"] = round(t[0].item() * 1e6, 2)
                 ent["peer_store_equals_allgather"] = bool(torch.equal(yp, mod(x)))
-                put_graphed(ent, "us_per_layer_with_peer_store_graph", lambda: modp(x))      # kernels only: two launches per call
+                put_graphed(ent, "us_per_layer_with_peer_store_graph", lambda: modp(x))      # kernels only: local kernel (scatter in its epilogue) + collect
+                ent["peer_store_scatter_fused_into_kernel"] = bool(modp.fused_calls > 0)
+                if modp.fused_calls > 0:            # the round-3 form beside it: local kernel + scatter launch + collect launch
+                    fused_fn, modp._fused_peer_forward = modp._fused_peer_forward, (lambda x_: None)
+                    try:
+                        put_graphed(ent, "us_per_layer_with_peer_store_unfused_graph", lambda: modp(x))
+                    finally:
+                        modp._fused_peer_forward = fused_fn
                 modp._px.check_timeout()
                 dist.barrier()
                 del modp

@@ -322,6 +322,19 @@ int gptq_peer_scatter(const gptq_peer_group_t *pg, const void *y_local, int M, i
 int gptq_peer_collect(const gptq_peer_group_t *pg, void *out, int M, int dtype, uint32_t max_spins, void *stream);
 int gptq_peer_gather(const gptq_peer_group_t *pg, const void *y_local, void *out, int M, int n_local, int dtype,
                      uint32_t max_spins, void *stream);
+/* The scatter as the EPILOGUE of the rank's decode kernel (round 4): layer = this rank's column shard (layer->N = pg->N / world) carrying its decode copy,
+ * M <= 4.  The strip owners of the decode-copy kernel store their [M][16] outputs straight into every rank's exchange buffer (16-byte system-scope
+ * write-through stores) -- no y_local, no scatter launch: a tensor-parallel layer is the local kernel + ONE collect.  The rank's arrival flag is raised by
+ * the first block of its gptq_peer_collect launch (every collect (re-)publishes the flag of its epoch before it waits: behind this kernel in stream order
+ * the payload is complete); gptq_peer_publish raises it on its own -- needed only when several ranks share ONE stream (simulations: each rank's collect
+ * would wait for flags that later launches of the same stream raise) or when unrelated work sits between the scatter and the collect.
+ * workspace as for gptq_forward (gptq_workspace_bytes(layer, M)).  GPTQ_ERR_UNSUPPORTED when the layer / M does not qualify (then: gptq_forward +
+ * gptq_peer_scatter).  gptq_forward_gather = gptq_forward_scatter + gptq_peer_collect.  Same collective contract as gptq_peer_gather. */
+int gptq_forward_scatter(const gptq_layer_t *layer, const void *x, int M, const gptq_peer_group_t *pg, void *workspace, size_t workspace_bytes,
+                         void *stream);
+int gptq_forward_gather(const gptq_layer_t *layer, const void *x, void *out, int M, const gptq_peer_group_t *pg, uint32_t max_spins, void *workspace,
+                        size_t workspace_bytes, void *stream);
+int gptq_peer_publish(const gptq_peer_group_t *pg, void *stream);
 
 #ifdef __cplusplus
 }

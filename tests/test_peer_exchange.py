@@ -173,6 +173,109 @@ def test_peer_collect_gives_up_instead_of_hanging():
     assert torch.equal(out[:, :nl], y)                          # own slice is there, the peer's is whatever the buffer held
 
 
+def _shards(K, N, T, bits, gs, dtype, dev, seed):
+    """The T column shards of one random layer (each an mi355x QuantLinear with its decode copy) + the oracle's full dequantised weight."""
+    from autogptq_amd import QuantLinear
+    from autogptq_amd.tensor_parallel import ColumnParallelQuantLinear
+    from oracle import gptq_oracle as O
+    L = O.random_quant_layer(K, N, bits, gs, dtype=dtype, seed=seed, bias=True)
+    full = QuantLinear(bits, gs, K, N, True, weight_dtype=dtype)
+    full.qweight, full.qzeros, full.scales, full.g_idx, full.bias = L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"]
+    shards = [ColumnParallelQuantLinear.from_full(full, r, T, device=dev, gather_output=False).local for r in range(T)]
+    for q in shards:
+        q.post_init()
+    mode = O.ZERO_NOWRAP if bits == 3 else O.ZERO_WRAP
+    W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], bits, mode).to(dev)
+    return shards, W, L["bias"].to(dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,K,N,bits,dtype", [(2, 1024, 2048, 4, torch.float16), (4, 2048, 1024, 4, torch.bfloat16), (8, 8192, 8192, 4, torch.float16),
+                                             (8, 4096, 2048, 8, torch.float16), (4, 2048, 2048, 3, torch.float16)])
+def test_forward_scatter_is_the_kernel_epilogue(T, K, N, bits, dtype):
+    """gptq_forward_scatter on T simulated ranks (round 4): every rank's decode-copy kernel stores its slice into every rank's exchange buffer from its own
+    epilogue, then ONE collect per rank.  The gathered rows equal the concatenation of the shards' plain forwards BIT FOR BIT (same kernel, same plan) and
+    every output agrees with x (fp64) @ W_oracle (fp64); three epochs (both parities + a reuse); tickets back at zero; (8, 8192, 8192): the 70B attention
+    shard, whose 64 strips run as K slices combined inside the launch before the owner slice scatters."""
+    from autogptq_amd.qlinear_mi355x import reserve_workspace
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    shards, W, bias = _shards(K, N, T, bits, 128, dtype, dev, 5 + T)
+    nl = N // T
+    assert all(q._qweight_tiled is not None for q in shards)
+    for M in (1, 3, 4):
+        groups, keep = _sim_groups(T, 4, N, dtype, dev)
+        st = _lib.current_stream_handle(dev)
+        need = max(int(lib.gptq_workspace_bytes(ctypes.byref(q._layer), M)) for q in shards)
+        ws = reserve_workspace(dev, need) if need else None
+        for epoch in range(1, 4):
+            x = ((torch.rand(M, K, generator=torch.Generator().manual_seed(100 * epoch + M)) - 0.5)).to(dtype).to(dev)
+            outs = [torch.zeros(M, N, dtype=dtype, device=dev) for _ in range(T)]
+            for r in range(T):
+                _lib.check(lib.gptq_forward_scatter(ctypes.byref(shards[r]._layer), x.data_ptr(), M, ctypes.byref(groups[r]),
+                                                    ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, st))
+            for r in range(T):                                  # the simulated ranks share ONE stream: their flags are raised before anyone's collect waits
+                _lib.check(lib.gptq_peer_publish(ctypes.byref(groups[r]), st))
+            for r in range(T):
+                _lib.check(lib.gptq_peer_collect(ctypes.byref(groups[r]), outs[r].data_ptr(), M, _lib.DTYPE_ENUM[dtype], 1 << 16, st))
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                want = torch.cat([q(x) for q in shards], dim=1)
+            ref = x.double() @ W.double() + bias.double()
+            rtol, atol = (1e-3, 1e-3) if dtype == torch.float16 else (8e-3, 8e-3)
+            assert not bool(((want.double() - ref).abs() > atol * float(ref.abs().max()) + rtol * ref.abs()).any())
+            for r in range(T):
+                assert torch.equal(outs[r], want), (M, epoch, r)
+                assert keep[3][r].tolist() == [epoch, 0, 0, 0]
+                assert keep[2][r][:T].tolist() == [epoch] * T
+    if (T, K) == (8, 8192):
+        assert _lib.describe_plan(shards[0]._layer, 1)["ksplit"] >= 2
+
+
+@pytest.mark.gpu
+def test_forward_gather_replays_inside_a_graph_and_refuses_what_it_cannot_fuse():
+    from autogptq_amd.qlinear_mi355x import reserve_workspace
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    T, K, N, M = 4, 4096, 4096, 2
+    shards, W, bias = _shards(K, N, T, 4, 128, torch.float16, dev, 77)
+    groups, keep = _sim_groups(T, 4, N, torch.float16, dev)
+    x = torch.zeros(M, K, dtype=torch.float16, device=dev)
+    outs = [torch.zeros(M, N, dtype=torch.float16, device=dev) for _ in range(T)]
+    need = max(int(lib.gptq_workspace_bytes(ctypes.byref(q._layer), M)) for q in shards)
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        ws = reserve_workspace(dev, max(need, 1 << 17))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            st = _lib.current_stream_handle(dev)
+            for r in range(T):
+                _lib.check(lib.gptq_forward_scatter(ctypes.byref(shards[r]._layer), x.data_ptr(), M, ctypes.byref(groups[r]), ws.data_ptr(), ws.numel(), st))
+            for r in range(T):
+                _lib.check(lib.gptq_peer_publish(ctypes.byref(groups[r]), st))
+            for r in range(T):
+                _lib.check(lib.gptq_peer_collect(ctypes.byref(groups[r]), outs[r].data_ptr(), M, _lib.GPTQ_F16, 1 << 16, st))
+        for it in range(5):
+            x.copy_(((torch.rand(M, K, generator=torch.Generator().manual_seed(it)) - 0.5)).half())
+            g.replay()
+            s.synchronize()
+            with torch.no_grad():
+                want = torch.cat([q(x) for q in shards], dim=1)
+            for r in range(T):
+                assert torch.equal(outs[r], want), (it, r)
+    assert keep[3][0].tolist() == [5, 0, 0, 0]
+    # what the fused form does not cover is an error the caller falls back from (ColumnParallelQuantLinear: local forward + scatter + collect)
+    st = _lib.current_stream_handle(dev)
+    x8 = torch.zeros(8, K, dtype=torch.float16, device=dev)
+    g8, _ = _sim_groups(T, 8, N, torch.float16, dev)
+    assert lib.gptq_forward_scatter(ctypes.byref(shards[0]._layer), x8.data_ptr(), 8, ctypes.byref(g8[0]), ws.data_ptr(), ws.numel(), st) == 3
+    assert b"gptq_peer_scatter" in lib.gptq_last_error()
+    gbad, _ = _sim_groups(2, 4, N, torch.float16, dev)                # N / world != the shard's width
+    assert lib.gptq_forward_scatter(ctypes.byref(shards[0]._layer), x.data_ptr(), 1, ctypes.byref(gbad[0]), ws.data_ptr(), ws.numel(), st) == 2
+    assert lib.gptq_forward_gather(ctypes.byref(shards[0]._layer), x.data_ptr(), outs[0].data_ptr(), 1, ctypes.byref(groups[0]), 0, ws.data_ptr(), ws.numel(), st) == 2
+    assert lib.gptq_forward_scatter(None, x.data_ptr(), 1, ctypes.byref(groups[0]), None, 0, st) == 1
+
+
 @pytest.mark.gpu
 def test_fine_grained_buffer_is_plain_device_memory_for_torch():
     """hipExtMallocWithFlags(finegrained) memory wrapped as a tensor: zeroed, writable by torch kernels, visible through a second alias of
@@ -227,7 +330,9 @@ def _ipc_worker(rank, world, port, M, q):
                 y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], None, None, 4, O.ZERO_WRAP)
                 errs.append(float((y.double().cpu() - y64).abs().max() / y64.abs().max()))
         dist.barrier()                                              # nobody unmaps while a peer may still store
-        q.put((rank, tuple(y.shape) == (M, N) and max(errs) < 3e-3 and cp._px.fine_grained, errs + [("fine_grained", cp._px.fine_grained)]))
+        fused_as_expected = cp.fused_calls == (3 if M <= 4 else 0)      # decode rows: the scatter is the shard kernel's epilogue (gptq_forward_scatter)
+        q.put((rank, tuple(y.shape) == (M, N) and max(errs) < 3e-3 and cp._px.fine_grained and fused_as_expected,
+               errs + [("fine_grained", cp._px.fine_grained), ("fused_calls", cp.fused_calls)]))
     finally:
         dist.destroy_process_group()
 
