@@ -514,6 +514,30 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
         return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 3 / reserved[2] = 4: these layers do not fit one batched-decode launch (2..4 plain 4-bit layers, M <= 64)");
     if (tune && tune->path == 3 && tune->reserved[2] == 5)
         return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 3 / reserved[2] = 5: these layers do not fit one gemm_mid_kernel launch (2..4 plain 4-bit layers, N %% 64 == 0, M <= 256)");
+    // Act-order layers that share ONE perm -- q / k / v and gate / up of a GPTQ checkpoint do: the activation order comes from the Hessian of the
+    // layers' common input (the reference's fused q/k/v caller relies on it: fused_llama_attn.py:188 hands the kernels q_proj's order for all three) --
+    // read ONE permuted x: the first layer's GEMM call permutes into the head of the workspace, the others find it there.  The caller says so by
+    // passing the same `perm` pointer (QuantLinear.share_act_order / forward_multi do that once the g_idx tensors compared equal).
+    if (n_layers >= 2 && !tune && layers[0]->perm && layers[0]->qweight_seq && layers[0]->g_idx) {
+        GemmPlan pls[4];
+        bool shared = n_layers <= 4;
+        for (int i = 0; shared && i < n_layers; ++i) {
+            const gptq_layer_t* L = layers[i];
+            shared = L->perm == layers[0]->perm && L->qweight_seq && L->g_idx && L->epilogue == GPTQ_EPI_NONE && L->K == layers[0]->K &&
+                     L->dtype == layers[0]->dtype && L->dtype != GPTQ_F32 && want_gemm(L, M, nullptr);
+            if (!shared) break;
+            pls[i] = plan_gemm(*L, M, nullptr);
+            shared = pls[i].supported && pls[i].use_seq && !pls[i].f32 && pls[i].xslot == pls[0].xslot && pls[i].xperm_bytes == pls[0].xperm_bytes &&
+                     pls[i].workspace_bytes <= wv.body_bytes;
+        }
+        if (shared) {
+            for (int i = 0; i < n_layers; ++i) {
+                hipError_t e = launch_gemm(*layers[i], pls[i], x, outs[i], M, wv.header, wv.body, (hipStream_t)stream, i > 0);
+                if (e != hipSuccess) return hip_fail(e, "gptq_gemm launch (shared permuted x)");
+            }
+            return GPTQ_OK;
+        }
+    }
     for (int i = 0; i < n_layers; ++i) {           // anything the one-launch kernel does not cover: the same result, layer by layer
         int rc = forward_impl(layers[i], x, outs[i], M, wv, stream, nullptr);
         if (rc) return rc;

@@ -2147,8 +2147,10 @@ static hipError_t launch_t(const gptq_layer_t& L, const GemmPlan& pl, const Gemm
     }
 }
 
+// x_permuted: the permuted x of this plan already sits at the head of `workspace` (an earlier layer of the same gptq_forward_multi call that shares
+// this layer's perm put it there): the permute launch is skipped.
 hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x, void* out, int M,
-                       void* ws_header, void* workspace, hipStream_t st) {
+                       void* ws_header, void* workspace, hipStream_t st, bool x_permuted) {
     if (!pl.supported) return hipErrorNotSupported;
     GemmParams p{};
     p.qweight = pl.use_seq ? L.qweight_seq : L.qweight;
@@ -2185,9 +2187,11 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
     if (pl.use_seq) {
         // k-slot order for the DMA-staged tiled kernel: the LDS-staged row kernel; plain order: whichever permute kernel fits M and K
         // (a few long rows -- batched decode -- take the flat gather: 11008x4096 M = 8 act-order 16.8 -> ~14.5 us)
-        e = pl.xslot ? launch_permute_rows16(x, L.perm, M, L.K, workspace, st, true)
-                     : launch_permute_columns(x, L.perm, M, L.K, L.dtype, workspace, st);
-        if (e != hipSuccess) return e;
+        if (!x_permuted) {
+            e = pl.xslot ? launch_permute_rows16(x, L.perm, M, L.K, workspace, st, true)
+                         : launch_permute_columns(x, L.perm, M, L.K, L.dtype, workspace, st);
+            if (e != hipSuccess) return e;
+        }
         p.x = workspace;
     }
     p.partial = (float*)((char*)workspace + pl.xperm_bytes);

@@ -64,7 +64,7 @@ struct GemmPlan {
 };
 GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune);
 hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x, void* out, int M,
-                       void* ws_header, void* workspace, hipStream_t st);
+                       void* ws_header, void* workspace, hipStream_t st, bool x_permuted = false);
 
 // Streamed GEMV (gemv_q4_stream_kernel): 1..4 plain 4-bit layers that read the same x, one launch.
 constexpr size_t WS_HEADER_BYTES = 65536;      // front of every workspace: arrival tickets of the in-launch K-split combine (kept zero)

@@ -467,6 +467,23 @@ def _pack_fields(vals_u32: torch.Tensor, bits: int) -> torch.Tensor:
     return out.to(torch.int32).contiguous()
 
 
+def share_act_order(layers) -> bool:
+    """Act-order layers that read the same input and carry the SAME g_idx -- q / k / v and gate / up of a GPTQ checkpoint do: the order comes from the
+    Hessian of their common input (the reference's fused q/k/v caller relies on it, fused_llama_attn.py:188) -- are pointed at ONE ``perm`` buffer; the
+    C ABI takes the shared pointer as "these layers read one permuted x" and permutes x once per gptq_forward_multi call instead of once per layer.
+    Compared once (when forward_multi first sees the group); True if the group now shares."""
+    a = layers[0]
+    if len(layers) < 2 or a._layer is None or not a._layer.perm or not a._layer.qweight_seq:
+        return False
+    for l in layers[1:]:
+        if l._layer is None or not l._layer.perm or l.g_idx.shape != a.g_idx.shape or l.g_idx.device != a.g_idx.device or not torch.equal(l.g_idx, a.g_idx):
+            return False
+    for l in layers[1:]:
+        l._layer.perm = a._layer.perm
+        l._keepalive = tuple(l._keepalive) + (a._keepalive,)          # layer 0's perm tensor lives as long as the sharers do
+    return True
+
+
 def forward_multi(layers, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = None):
     """``[l(x) for l in layers]`` for mi355x QuantLinears that read the same input, through gptq_forward_multi: ONE launch for
     q/k/v or gate/up of a decode step (M <= 4, plain 4-bit layers), the layers one by one otherwise.  The checkpoint tensors
@@ -497,6 +514,7 @@ def forward_multi(layers, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = No
         key = tuple(id(l._layer) for l in layers)
         ent = _MULTI.get(key)
         if ent is None:
+            share_act_order(layers)
             arr = (ctypes.POINTER(_lib.GptqLayer) * n)(*[ctypes.pointer(l._layer) for l in layers])
             optr_arr = (ctypes.c_void_p * n)()
             ent = _MULTI[key] = (arr, {}, [l._layer for l in layers], optr_arr, ctypes.addressof(arr), ctypes.addressof(optr_arr))
@@ -571,6 +589,7 @@ def mlp_forward(gate: QuantLinear, up: QuantLinear, down: QuantLinear, x: torch.
         need_by_m = _MULTI.get(key)
         if need_by_m is None:
             need_by_m = _MULTI[key] = {}
+            share_act_order([gate, up])                 # act-order gate / up with one g_idx: one permuted x for both
         tref = ctypes.byref(tuning) if tuning is not None else None
         need = need_by_m.get(M) if tuning is None else None
         if need is None:

@@ -50,9 +50,11 @@ def algorithmic_bytes(K, N, M, bits=4, gs=128, act_order=False, dtype_bytes=2, b
     return b
 
 
-def make_layer(K, N, device, bits=4, gs=128, act_order=False, dtype=torch.float16, seed=0):
+def make_layer(K, N, device, bits=4, gs=128, act_order=False, dtype=torch.float16, seed=0, order_seed=None):
     """Synthetic layer, generated on the device: random packed words (every bit pattern is legal),
-    scales 0.002*(1+0.1*rand) -- the recipe of SURVEY section 8(d) / tests/test_q4.py:1086-1112."""
+    scales 0.002*(1+0.1*rand) -- the recipe of SURVEY section 8(d) / tests/test_q4.py:1086-1112.
+    order_seed: the activation order (g_idx permutation) from its own seed -- layers that read the same input get the same one, as GPTQ
+    produces them (the order is the argsort of the Hessian diagonal of the layers' common input; the reference's fused q/k/v caller relies on it)."""
     import autogptq_amd
 
     g = torch.Generator(device=device).manual_seed(seed)
@@ -63,7 +65,8 @@ def make_layer(K, N, device, bits=4, gs=128, act_order=False, dtype=torch.float1
     q.scales = (0.002 * (1 + 0.1 * torch.rand(G, N, device=device, generator=g))).to(dtype)
     gi = torch.arange(K, device=device, dtype=torch.int32) // gs
     if act_order:
-        gi = gi[torch.randperm(K, device=device, generator=g)]
+        go = g if order_seed is None else torch.Generator(device=device).manual_seed(order_seed)
+        gi = gi[torch.randperm(K, device=device, generator=go)]
     q.g_idx = gi.contiguous()
     q = q.to(device)
     q.post_init()
@@ -74,7 +77,9 @@ def build_stack(device, n_blocks, M, act_order, dtype=torch.float16):
     layers = []
     for b in range(n_blocks):
         for i, (name, K, N) in enumerate(LLAMA7B_BLOCK):
-            layers.append((name, K, N, make_layer(K, N, device, act_order=act_order, dtype=dtype, seed=b * 16 + i)))
+            # q / k / v read one input and so do gate / up: one activation order per group of a block (o and down have their own)
+            grp = {"q_proj": 0, "k_proj": 0, "v_proj": 0, "gate_proj": 1, "up_proj": 1}.get(name, 2 + i)
+            layers.append((name, K, N, make_layer(K, N, device, act_order=act_order, dtype=dtype, seed=b * 16 + i, order_seed=10_000 + b * 16 + grp)))
     xs = {K: (torch.rand(M, K, device=device) - 0.5).to(dtype) for K in (4096, 11008)}
     return layers, xs
 
@@ -278,7 +283,7 @@ def bench_prefill(device, steps):
             "traffic": pmc_traffic("gemm", K, N, M), "kernel": "gptq::gemm_kernel<4, f16, ...> (%s)" % plan, "shape": f"K={K} N={N} M={M} desc_act",
             "us_per_launch_events": round(per * 1e6, 2), "flops_per_launch": 2 * M * K * N,
             "note": "per-launch time is the whole layer call: x permutation (if the plan has a separate pass) + GEMM"}
-    del g, outs, layers
+    del g, outs
     torch.cuda.empty_cache()
     # north_star: (batch x seq = 4096, 4096 -> 4096), int4 g128, sequential groups; 40 distinct layers (> 256 MiB with x / out)
     M2 = 4096
@@ -327,6 +332,23 @@ def bench_prefill(device, steps):
         out["remainder_rounds"] = rem
     except Exception as e:
         out["remainder_rounds"] = {"error": repr(e)[:200]}
+    # the same stack as a decoder block calls it: q|k|v and gate|up through gptq_forward_multi, which permutes x ONCE for layers that share their
+    # activation order (4 permute launches per block instead of 7)
+    grouped = None
+    try:
+        gl = group_stack(layers)
+        gg, go = capture(gl, xs, device)
+        for _ in range(2):
+            gg.replay()
+        _, evg = time_graph(gg, steps, device)
+        grouped = {"TFLOP_s": round(flops_step * steps / evg / 1e12, 1), "ms_per_step": round(1e3 * evg / steps, 3),
+                   "note": "q|k|v and gate|up of a block through gptq_forward_multi: one shared permuted x per group (they carry one g_idx, as GPTQ produces them)"}
+        del gg, go
+    except Exception as e:
+        grouped = {"error": repr(e)[:200]}
+    out["grouped"] = grouped
+    del layers
+    torch.cuda.empty_cache()
     return out
 
 
@@ -888,6 +910,8 @@ def main():
                 roof["prefill_m4096_4096x4096"] = dict(bound="mfma", unit="TFLOP/s", peak=MFMA_PEAK_TFLOPS, achieved=pf["m4096_4096x4096"]["TFLOP_s"],
                                                        frac=pf["m4096_4096x4096"]["frac"], us_per_launch_events=pf["m4096_4096x4096"]["us_per_launch_events"])
                 roof["prefill_stack_TFLOP_s"] = pf.get("TFLOP_s")
+                if isinstance(pf.get("grouped"), dict) and "TFLOP_s" in pf["grouped"]:
+                    roof["prefill_stack_grouped_TFLOP_s"] = pf["grouped"]["TFLOP_s"]        # q|k|v, gate|up via gptq_forward_multi: one permuted x per group
                 if isinstance(pf.get("remainder_rounds"), dict):
                     roof["prefill_remainder_rounds"] = pf["remainder_rounds"]
             byc = {}

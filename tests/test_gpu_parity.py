@@ -1623,6 +1623,43 @@ def test_forward_multi_equals_layer_by_layer(M, act):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("M", [64, 200, 2048])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_forward_multi_shares_one_permuted_x_between_layers_of_one_act_order(M, dtype):
+    """q / k / v (and gate / up) of a GPTQ checkpoint carry ONE g_idx (the order is the argsort of the Hessian diagonal of their common input; the
+    reference's fused q/k/v caller hands the kernels q_proj's order for all three, fused_llama_attn.py:188).  forward_multi points such layers at one
+    `perm` buffer (share_act_order) and the C ABI then permutes x ONCE per call: the outputs are BIT-IDENTICAL to separate calls and agree with the fp64
+    oracle; layers whose g_idx differ keep their own perms (and their own permute launches)."""
+    from autogptq_amd.qlinear_mi355x import forward_multi, share_act_order
+    K = 2048
+    base = O.random_quant_layer(K, 512, 4, 128, act_order=True, dtype=dtype, seed=5)
+    Ls = [base] + [O.random_quant_layer(K, n, 4, 128, act_order=True, dtype=dtype, seed=6 + i) for i, n in enumerate((256, 1024))]
+    for L in Ls[1:]:
+        L["g_idx"] = base["g_idx"].clone()                       # the same activation order (the packed rows are random words: any order is a valid layer)
+    qs = [_module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], None, 4, 128) for L in Ls]
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype).to(DEV)
+    with torch.no_grad():
+        sep = [q(x) for q in qs]                                 # before sharing: each layer its own perm and permute launch
+        ys = forward_multi(qs, x)
+        ys2 = forward_multi(qs, x)
+    assert qs[1]._layer.perm == qs[0]._layer.perm and qs[2]._layer.perm == qs[0]._layer.perm
+    mode = O.reference_zero_mode(True, 4)
+    for y, y2, s_, L in zip(ys, ys2, sep, Ls):
+        assert torch.equal(y, y2) and torch.equal(y, s_)
+        ref = O.forward_f64(x.cpu(), L["qweight"], L["qzeros"], L["scales"], L["g_idx"], None, 4, mode)
+        _assert_close(y, ref, ref, dtype, K, "shared permuted x vs oracle")
+    with torch.no_grad():
+        for q, s_ in zip(qs, sep):                               # a sharer on its own still works (its perm pointer is layer 0's buffer)
+            assert torch.equal(q(x), s_)
+    other = O.random_quant_layer(K, 256, 4, 128, act_order=True, dtype=dtype, seed=99)
+    qo = _module_from(other["qweight"], other["qzeros"], other["scales"], other["g_idx"], None, 4, 128)
+    qo.post_init()
+    assert not share_act_order([qs[0], qo])
+    with torch.no_grad():
+        ym = forward_multi([qs[0], qo], x)
+        assert torch.equal(ym[0], sep[0]) and torch.equal(ym[1], qo(x))
+
+
 # ------------------------------------------------------------------------- fp32 I/O above M = 8: exact-f32 matrix core
 @pytest.mark.parametrize("act", [False, True])
 @pytest.mark.parametrize("bits,gs,K,N,M", [(4, 128, 1024, 512, 9), (4, 32, 512, 160, 40), (3, 32, 1024, 256, 130), (8, 32, 512, 384, 300),
