@@ -1954,7 +1954,7 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.bk = (L.bits == 4 && pl.mt == 4 && L.K % 64 == 0 && L.group_size % 64 == 0) ? 64 : 32;
     if (tune && tune->reserved[1] == 32) pl.bk = 32;
     pl.variant = tune ? tune->reserved[3] : 0;            // experiment knob: inner-loop schedule variant
-    const int wide_knob = (pl.variant == 44 || pl.variant == 45) ? pl.variant : 0;      // 44 / 45: the 128 x 512 kernel off / forced (A/B runs)
+    const int wide_knob = (pl.variant >= 44 && pl.variant <= 47) ? pl.variant : 0;      // 44 / 45: the 128 x 512 kernel off / forced; 46 / 47: by the rule / forced, on the checkpoint rows even when the layer has a decode copy (A/B runs)
     if (wide_knob) pl.variant = 0;
     const int tail_knob = (pl.variant >= 40 && pl.variant <= 42) ? pl.variant : 0;      // 40 = balanced tail by the rule below, 41 = off, 42 = the rule without its tile limit (A/B runs)
     if (tail_knob) pl.variant = 0;
@@ -2021,9 +2021,11 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
         const long wt = (long)((M + 127) / 128) * ((L.N + 511) / 512);
         const long rounds = (wt + 255) / 256;
         const bool fills = wt >= 256 && (double)wt / (double)(rounds * 256) >= 0.9;
-        pl.wide = wide_knob != 44 && (fills || wide_knob == 45) && pl.mt == 4 && pl.bk == 64 && pl.ksplit == 1 && pl.variant == 0 && tail_knob == 0 &&
+        pl.wide = wide_knob != 44 && (fills || wide_knob == 45 || wide_knob == 47) && pl.mt == 4 && pl.bk == 64 && pl.ksplit == 1 && pl.variant == 0 && tail_knob == 0 &&
                   wide_gemm_ok(L, M, pl.use_seq, pl.xslot && pl.glds);
         if (pl.wide) {
+            // plain layers that carry their decode copy: weights from it, raw x by LDS DMA (gemm_wide_kernel<T, true, true>); knob 46 keeps the checkpoint rows (A/B)
+            pl.wide_tiled = !pl.use_seq && L.qweight_tiled != nullptr && L.tiled_cols == GPTQ_STRIP_COLS && L.N % GPTQ_STRIP_COLS == 0 && wide_knob != 46 && wide_knob != 47;
             pl.tail = 0; pl.tail_lg = 0;
             pl.bn = 512; pl.nbn = (L.N + 511) / 512;
             pl.workspace_bytes = pl.xperm_bytes;
@@ -2217,7 +2219,7 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
         sp.lds_bytes = (land > slabs ? land : slabs) + 16;
         return launch_stream64(one, sp, p.x, outs, M, ws_header, p.partial, pl.use_seq ? L.qweight_seq : nullptr, st);
     }
-    if (pl.wide) return launch_gemm_wide(L, p.qweight, p.x, out, M, pl.use_seq, st);
+    if (pl.wide) return launch_gemm_wide(L, p.qweight, p.x, out, M, pl.use_seq, st, pl.wide_tiled);
     e = (L.dtype == GPTQ_F16) ? launch_t<f16>(L, pl, p, st) : launch_t<bf16>(L, pl, p, st);
     if (e != hipSuccess) return e;
     if (pl.ksplit > 1) {

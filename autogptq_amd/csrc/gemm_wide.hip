@@ -26,13 +26,13 @@ namespace gptq {
 namespace wide {
 
 struct WideParams {
-    const unsigned* qweight;
+    const unsigned* qweight;      // TILED: the layer's decode copy (qweight_tiled), else the checkpoint / re-sequenced rows
     const unsigned* qzeros;
     const void* scales;
     const void* bias;
     const void* x;
     void* out;
-    int M, K, N, zero_mode, nbm, nbn, ksteps, qrows, groups;
+    int M, K, N, zero_mode, nbm, nbn, ksteps, qrows, groups, chunks;
     unsigned long long kpg_inv;   // ceil(2^32 / (group_size / 64)): group of K-step kt = (kt * kpg_inv) >> 32
 };
 
@@ -124,8 +124,14 @@ __device__ __forceinline__ unsigned short t_bits(f16 v) { return __builtin_bit_c
 __device__ __forceinline__ unsigned short t_bits(bf16 v) { return __builtin_bit_cast(unsigned short, v); }
 
 // GLDS: x arrives in k-slot order (act-order layers: the permute pre-pass writes it so) and is staged by LDS DMA into unpadded, XOR-swizzled rows.
-template <typename T, bool GLDS>
+// TILED (implies GLDS): the weights come from the layer's DECODE COPY (gptq_prepack_decode: strips of 16 columns, a column's 32 consecutive k in 4
+// adjacent words, nibbles in pair order).  The same extraction then yields (k, k + 1) pairs in the order x lies in memory, so the RAW x is DMA-staged: no
+// register round trip, no v_perm, no ds_write (the ablation of the register-staged form put them at 9 % of the loop).  A lane still owns 4 adjacent
+// columns: 4 x 16 bytes = 64 contiguous bytes per (lane, K-step); its half takes one 32-k slot of the step (k = 32 half + 8 ks for MFMA ks), and the A
+// fragment of (ks, half) is piece 4 half + ks of the row's 128-byte step segment.
+template <typename T, bool GLDS, bool TILED = false>
 __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
+    static_assert(!TILED || GLDS, "the decode copy is read with DMA-staged raw x");
     constexpr int BM = 128, BK = 64, KS = 4, MT = 4, NT = 4;
     constexpr int STRIDE = GLDS ? BK * 2 : BK * 2 + 16;      // bytes per LDS row of x (padded unless DMA-staged)
     constexpr int NCH = 4;                                   // 16-byte chunks per thread and K-step: 128 rows x 8 chunks / 256 threads
@@ -154,12 +160,13 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
         a_off[i] = (unsigned)(min(m0 + a_row[i], p.M - 1) - m0) * (unsigned)p.K * 2u + (unsigned)src_kc * 16u;
     }
     const char* a_base = (const char*)(x + (size_t)m0 * p.K);
-    const auto rsrc_q = __builtin_amdgcn_make_buffer_rsrc((void*)p.qweight, 0, (int)((size_t)p.qrows * p.N * 4), 0x00020000);
+    const auto rsrc_q = __builtin_amdgcn_make_buffer_rsrc((void*)p.qweight, 0, TILED ? (int)((size_t)(p.N / 16) * p.chunks * 1024) : (int)((size_t)p.qrows * p.N * 4), 0x00020000);
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (int)((size_t)BM * p.K * 2), 0x00020000);
     const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)p.scales, 0, (int)((size_t)p.groups * p.N * 2), 0x00020000);
     const int zrow_bytes = p.N / 8 * 4;
     const auto rsrc_z = __builtin_amdgcn_make_buffer_rsrc((void*)p.qzeros, 0, p.groups * zrow_bytes, 0x00020000);
-    const unsigned b_lane_off = ((unsigned)nl + (unsigned)half * (unsigned)p.N) * 4u;
+    const unsigned b_lane_off = TILED ? ((unsigned)nl >> 4) * (unsigned)p.chunks * 1024u + (unsigned)half * 256u + ((unsigned)nl & 15u) * 16u    // strip, k-slot, column
+                                      : ((unsigned)nl + (unsigned)half * (unsigned)p.N) * 4u;
     const unsigned s_lane_off = (unsigned)nl * 2u;
     const unsigned z_lane_off = ((unsigned)nl >> 3) * 4u, zsh = ((unsigned)nl & 7u) * 4u;
     const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
@@ -188,11 +195,20 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
         }
     };
     // weights of one K-step: packed rows kt * 8 + ks * 2 + half, 16 bytes (4 columns) each
+    // TILED: b[col] = the 4 words (MFMA steps ks = 0..3) of column n + col in k-slot 2 (kt & 1) + half of chunk kt / 2
     auto load_b = [&](int kt, u32x4 (&b)[KS]) {
+        if constexpr (TILED) {
+            const unsigned so = (unsigned)(kt >> 1) * 1024u + (unsigned)(kt & 1) * 512u;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            b[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, b_lane_off, (unsigned)((size_t)(kt * 8 + ks * 2) * (size_t)p.N * 4), 0);
+            for (int col = 0; col < NT; ++col) b[col] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, b_lane_off + col * 16u, so, 0);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                b[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, b_lane_off, (unsigned)((size_t)(kt * 8 + ks * 2) * (size_t)p.N * 4), 0);
+        }
     };
+    auto bw = [](const u32x4 (&b)[KS], int ks, int nt) -> unsigned { return TILED ? b[nt][ks] : b[ks][nt]; };      // the word of MFMA step ks, column tile nt
+    auto a_piece = [&](int ks) -> int { return TILED ? (half * 4 + ks) : (ks * 2 + half); };                          // 16-byte piece of the row's step segment
     auto load_c = [&](int kt, CRaw& c) {
         const int g = (int)(((unsigned long long)(unsigned)kt * p.kpg_inv) >> 32);
         c.s = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_s, s_lane_off, (unsigned)g * (unsigned)p.N * 2u, 0));
@@ -230,7 +246,7 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
     u32x4 bq_first[NT];
     dq_cur.setup(c0, zsh, zmask);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bq_first[nt] = dq_cur.frag(b0[0][nt], nt);
+    for (int nt = 0; nt < NT; ++nt) bq_first[nt] = dq_cur.frag(bw(b0, 0, nt), nt);
     auto interleave = [&](auto nvalu) {                       // 16 x { 1 MFMA, n VALU, 1 LDS op every fourth }
         constexpr int NV = decltype(nvalu)::value;
 #pragma unroll
@@ -257,7 +273,7 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
         const char* abase = smem + BUF * (BM * STRIDE) + a_lane_off;
         u32x4 a[2][MT], bq[2][NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[0][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (GLDS ? ((half ^ a_swz) * 16) : 0));
+        for (int mt = 0; mt < MT; ++mt) a[0][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (GLDS ? ((a_piece(0) ^ a_swz) * 16) : 0));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bq[0][nt] = bq_first[nt];
         __builtin_amdgcn_sched_barrier(0);                     // the prefetch and the first A fragments stay ahead of this step's MFMAs
@@ -271,15 +287,15 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
 #else
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    a[(ks + 1) & 1][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (GLDS ? ((((ks + 1) * 2 + half) ^ a_swz) * 16) : (ks + 1) * 32));
+                    a[(ks + 1) & 1][mt] = *(const u32x4*)(abase + mt * 32 * STRIDE + (GLDS ? ((a_piece(ks + 1) ^ a_swz) * 16) : (ks + 1) * 32));
 #endif
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bq[(ks + 1) & 1][nt] = dq_cur.frag(b_use[ks + 1][nt], nt);
+                for (int nt = 0; nt < NT; ++nt) bq[(ks + 1) & 1][nt] = dq_cur.frag(bw(b_use, ks + 1, nt), nt);
             } else {
                 // under the last MFMA group: next step's constants and first B fragments (registers only), and its x tile to LDS
                 dq_nx.setup(c_fill, zsh, zmask);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bq_first[nt] = dq_nx.frag(b_fill[0][nt], nt);
+                for (int nt = 0; nt < NT; ++nt) bq_first[nt] = dq_nx.frag(bw(b_fill, 0, nt), nt);
 #if !(defined(GPTQ_WIDE_ABL) && (GPTQ_WIDE_ABL & 8))
                 if constexpr (!GLDS) store_a(BUF ^ 1, a_next);
 #endif
@@ -335,9 +351,10 @@ bool wide_gemm_ok(const gptq_layer_t& L, int M, bool use_seq, bool xslot_glds) {
     return true;
 }
 
-hipError_t launch_gemm_wide(const gptq_layer_t& L, const uint32_t* qweight, const void* x, void* out, int M, bool glds, hipStream_t st) {
+hipError_t launch_gemm_wide(const gptq_layer_t& L, const uint32_t* qweight, const void* x, void* out, int M, bool glds, hipStream_t st, bool tiled) {
     wide::WideParams p{};
-    p.qweight = qweight; p.qzeros = L.qzeros; p.scales = L.scales; p.bias = L.bias; p.x = x; p.out = out;
+    p.qweight = tiled ? L.qweight_tiled : qweight;
+    p.chunks = L.K / 128; p.qzeros = L.qzeros; p.scales = L.scales; p.bias = L.bias; p.x = x; p.out = out;
     p.M = M; p.K = L.K; p.N = L.N; p.zero_mode = L.zero_mode;
     p.nbm = (M + 127) / 128; p.nbn = (L.N + 511) / 512;
     p.ksteps = L.K / 64;
@@ -346,6 +363,11 @@ hipError_t launch_gemm_wide(const gptq_layer_t& L, const uint32_t* qweight, cons
     const unsigned long long kpg = (unsigned long long)(L.group_size / 64);
     p.kpg_inv = ((1ull << 32) + kpg - 1) / kpg;
     const dim3 grid(p.nbm * p.nbn), block(256);
+    if (tiled) {                                              // plain layer with its decode copy: raw x by DMA
+        if (L.dtype == GPTQ_F16) hipLaunchKernelGGL((wide::gemm_wide_kernel<f16, true, true>), grid, block, 2 * 128 * 128, st, p);
+        else hipLaunchKernelGGL((wide::gemm_wide_kernel<bf16, true, true>), grid, block, 2 * 128 * 128, st, p);
+        return hipGetLastError();
+    }
     if (L.dtype == GPTQ_F16) {
         if (glds) hipLaunchKernelGGL((wide::gemm_wide_kernel<f16, true>), grid, block, 2 * 128 * 128, st, p);
         else hipLaunchKernelGGL((wide::gemm_wide_kernel<f16, false>), grid, block, 2 * 128 * 144, st, p);

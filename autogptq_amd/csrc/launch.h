@@ -45,6 +45,7 @@ hipError_t init_gemm_mid_device();
 
 struct GemmPlan {
     bool supported, use_seq;
+    bool wide_tiled;          // ... reading the layer's decode copy, raw x staged by LDS DMA
     bool wide;                // 128 x 512 tiles, 128 x 128 per wave, accumulators in AGPRs (gemm_wide.hip): large launches
     bool mid;                 // 17 .. 128 rows, 4-bit: gemm_mid_kernel (midp holds its geometry)
     MidPlan midp;
@@ -114,7 +115,7 @@ hipError_t launch_silu_mul2(const void* g, const void* u, void* out, size_t tota
 hipError_t init_mlp_device();
 // gemm_wide.hip: 128 x 512 prefill tiles, 128 x 128 per wave with the accumulators in AGPRs (4-bit fp16 / bf16; glds: x in k-slot order, staged by LDS DMA)
 bool wide_gemm_ok(const gptq_layer_t& L, int M, bool use_seq, bool xslot_glds);
-hipError_t launch_gemm_wide(const gptq_layer_t& L, const uint32_t* qweight, const void* x, void* out, int M, bool glds, hipStream_t st);
+hipError_t launch_gemm_wide(const gptq_layer_t& L, const uint32_t* qweight, const void* x, void* out, int M, bool glds, hipStream_t st, bool tiled = false);
 hipError_t init_gemv_device();
 hipError_t init_gemm_device();
 

@@ -38,6 +38,8 @@
 #define GPTQ_LAB_VARIANT_TAIL_NO_LIMIT 42 /* the rule without its 1024-tile limit */
 #define GPTQ_LAB_VARIANT_WIDE_OFF 44      /* never the 128 x 512 kernel */
 #define GPTQ_LAB_VARIANT_WIDE_ON 45       /* the 128 x 512 kernel wherever it is legal */
+#define GPTQ_LAB_VARIANT_WIDE_ROWS 46     /* the planner's rule, but the checkpoint rows even when the layer carries a decode copy (register-staged x) */
+#define GPTQ_LAB_VARIANT_WIDE_ROWS_ON 47  /* 45 + 46 */
 /* (9..24, 32: ablation / timeline / ping-pong variants compiled only into tools/gemmlab with -DGPTQ_GEMM_ABLATIONS) */
 
 #endif /* GPTQ_MI355X_LAB_H */

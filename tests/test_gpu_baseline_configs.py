@@ -306,7 +306,8 @@ def test_north_star_m4096_wide_tiles(K, N, act, dtype):
     from autogptq_amd import _lib
     L, q, W, W64 = _layer(4, 128, K, N, act, dtype)
     plan = _lib.describe_plan(q._layer, 4096)
-    assert plan["kernel"] == ("tiled" if (act and dtype == torch.bfloat16) else "wide"), plan
+    # plain layers carry their decode copy: the wide kernel reads it and stages the raw x by LDS DMA ("wide_copy"); act-order fp16: checkpoint rows
+    assert plan["kernel"] == ("tiled" if (act and dtype == torch.bfloat16) else ("wide" if act else "wide_copy")), plan
     _check(4, 128, K, N, 4096, act, dtype)
 
 
@@ -324,15 +325,28 @@ def test_wide_tiles_forced_on_ragged_shapes():
             mode = O.ZERO_NOWRAP if (zm == "nowrap" or act) else O.ZERO_WRAP
             W = O.dequantize(Lq["qweight"], Lq["qzeros"], Lq["scales"], Lq["g_idx"], 4, mode).to(DEV)
             x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).half().to(DEV)
-            tw, tn = _lib.GptqTuning(), _lib.GptqTuning()
-            tw.path, tw.reserved[3], tw.ksplit = 3, 45, 1
+            tw, tn, tc = _lib.GptqTuning(), _lib.GptqTuning(), _lib.GptqTuning()
+            tw.path, tw.reserved[3], tw.ksplit = 3, 47, 1          # wide tiles on the checkpoint rows (register-staged x)
             tn.path, tn.reserved[3], tn.ksplit = 3, 6, 1
+            tc.path, tc.reserved[3], tc.ksplit = 3, 45, 1          # wide tiles, from the decode copy where the layer has one (raw x by LDS DMA)
             assert _lib.describe_plan(q._layer, M, tw)["kernel"] == "wide"
+            has_copy = q._qweight_tiled is not None and K % 128 == 0
+            assert _lib.describe_plan(q._layer, M, tc)["kernel"] == ("wide_copy" if has_copy else "wide")
             with torch.no_grad():
                 yw, yw2, yn = q(x, tuning=tw), q(x, tuning=tw), q(x, tuning=tn)
-            assert torch.equal(yw, yw2)
+                yc, yc2 = q(x, tuning=tc), q(x, tuning=tc)
+            assert torch.equal(yw, yw2) and torch.equal(yc, yc2)
             assert torch.equal(yw, yn), f"128 x 512 and 128 x 256 tiles differ ({K}x{N} g{gs} M={M} act={act} {zm})"
             ref = x.double() @ W.double() + Lq["bias"].to(DEV).double()
             scale = float(ref.abs().max())
-            bad = (yw.double() - ref).abs() > 1e-3 * scale + 1e-3 * ref.abs()
-            assert not bool(bad.any()), f"{K}x{N} g{gs} M={M} act={act} {zm}: {int(bad.sum())} outputs out of tolerance"
+            for y, what in ((yw, "rows"), (yc, "copy")):           # the copy form sums k in another order (a half-wave takes 32 consecutive k): same tolerance, not the same bits
+                bad = (y.double() - ref).abs() > 1e-3 * scale + 1e-3 * ref.abs()
+                assert not bool(bad.any()), f"{K}x{N} g{gs} M={M} act={act} {zm} ({what}): {int(bad.sum())} outputs out of tolerance"
+            hot = torch.zeros(M, K, dtype=torch.float16, device=DEV)
+            rows = torch.arange(M, device=DEV)
+            hot[rows, (rows * 37) % K] = 1.0                       # one-hot rows: the exact dequantised rows through the copy form too
+            saved, q._layer.bias = q._layer.bias, None
+            with torch.no_grad():
+                yh = q(hot, tuning=tc)
+            q._layer.bias = saved
+            assert torch.equal(yh, W[(rows * 37) % K])
