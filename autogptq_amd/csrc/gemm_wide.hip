@@ -129,7 +129,8 @@ __device__ __forceinline__ unsigned short t_bits(bf16 v) { return __builtin_bit_
 // register round trip, no v_perm, no ds_write (the ablation of the register-staged form put them at 9 % of the loop).  A lane still owns 4 adjacent
 // columns: 4 x 16 bytes = 64 contiguous bytes per (lane, K-step); its half takes one 32-k slot of the step (k = 32 half + 8 ks for MFMA ks), and the A
 // fragment of (ks, half) is piece 4 half + ks of the row's 128-byte step segment.
-template <typename T, bool GLDS, bool TILED = false>
+// G128: group_size % 128 == 0 -- the two 64-deep steps of a loop body lie in one group: constants are loaded and set up once per body, not per step.
+template <typename T, bool GLDS, bool TILED = false, bool G128 = false>
 __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
     static_assert(!TILED || GLDS, "the decode copy is read with DMA-staged raw x");
     constexpr int BM = 128, BK = 64, KS = 4, MT = 4, NT = 4;
@@ -258,6 +259,7 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
     };
     auto step = [&](int kt, auto bufc, const u32x4 (&b_use)[KS], u32x4 (&b_fill)[KS], CRaw& c_fill) {
         constexpr int BUF = decltype(bufc)::value;
+        constexpr bool NEWG = !(G128 && BUF == 0);             // does step kt + 1 open a new group?  (G128: only behind the odd step of a body)
         const int ktn = min(kt + 1, kt1 - 1);                  // the last step re-loads itself (no branch in the pipeline)
         if constexpr (GLDS) {
             // claim this step's weight words before anything new is issued: the compiler's exact wait lands here (gemm.hip)
@@ -269,7 +271,7 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
             load_a(ktn, a_next);
         }
         load_b(ktn, b_fill);
-        load_c(ktn, c_fill);
+        if constexpr (NEWG) load_c(ktn, c_fill);
         const char* abase = smem + BUF * (BM * STRIDE) + a_lane_off;
         u32x4 a[2][MT], bq[2][NT];
 #pragma unroll
@@ -293,7 +295,8 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
                 for (int nt = 0; nt < NT; ++nt) bq[(ks + 1) & 1][nt] = dq_cur.frag(bw(b_use, ks + 1, nt), nt);
             } else {
                 // under the last MFMA group: next step's constants and first B fragments (registers only), and its x tile to LDS
-                dq_nx.setup(c_fill, zsh, zmask);
+                if constexpr (NEWG) dq_nx.setup(c_fill, zsh, zmask);
+                else dq_nx = dq_cur;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bq_first[nt] = dq_nx.frag(bw(b_fill, 0, nt), nt);
 #if !(defined(GPTQ_WIDE_ABL) && (GPTQ_WIDE_ABL & 8))
@@ -310,7 +313,7 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
         }
         dq_cur = dq_nx;
         // DMA-staged x: the next tile must have landed before anybody passes the barrier; the KS weight loads + 2 constant loads issued behind it may fly on
-        if constexpr (GLDS) wait_vmcnt<KS + 2>();
+        if constexpr (GLDS) wait_vmcnt<KS + (NEWG ? 2 : 0)>();
 #if !(defined(GPTQ_WIDE_ABL) && (GPTQ_WIDE_ABL & 4))
         __syncthreads();
 #endif
@@ -364,8 +367,14 @@ hipError_t launch_gemm_wide(const gptq_layer_t& L, const uint32_t* qweight, cons
     p.kpg_inv = ((1ull << 32) + kpg - 1) / kpg;
     const dim3 grid(p.nbm * p.nbn), block(256);
     if (tiled) {                                              // plain layer with its decode copy: raw x by DMA
-        if (L.dtype == GPTQ_F16) hipLaunchKernelGGL((wide::gemm_wide_kernel<f16, true, true>), grid, block, 2 * 128 * 128, st, p);
-        else hipLaunchKernelGGL((wide::gemm_wide_kernel<bf16, true, true>), grid, block, 2 * 128 * 128, st, p);
+        const bool g128 = L.group_size % 128 == 0;
+        if (L.dtype == GPTQ_F16) {
+            if (g128) hipLaunchKernelGGL((wide::gemm_wide_kernel<f16, true, true, true>), grid, block, 2 * 128 * 128, st, p);
+            else hipLaunchKernelGGL((wide::gemm_wide_kernel<f16, true, true, false>), grid, block, 2 * 128 * 128, st, p);
+        } else {
+            if (g128) hipLaunchKernelGGL((wide::gemm_wide_kernel<bf16, true, true, true>), grid, block, 2 * 128 * 128, st, p);
+            else hipLaunchKernelGGL((wide::gemm_wide_kernel<bf16, true, true, false>), grid, block, 2 * 128 * 128, st, p);
+        }
         return hipGetLastError();
     }
     if (L.dtype == GPTQ_F16) {
