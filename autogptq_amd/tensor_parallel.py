@@ -174,7 +174,11 @@ class RowParallelQuantLinear(nn.Module):
     outputs; bias is added after the reduction.  Sequential groups only (an act-order g_idx mixes groups across the whole K)."""
 
     def __init__(self, local: Callable[[torch.Tensor], torch.Tensor], k_range, bias: Optional[torch.Tensor] = None,
-                 group: Optional[dist.ProcessGroup] = None, input_is_parallel: bool = True):
+                 group: Optional[dist.ProcessGroup] = None, input_is_parallel: bool = True, fp32_reduce_max_elems: Optional[int] = 64 * 16384):
+        """fp32_reduce_max_elems: outputs of up to this many elements are summed over the ranks in fp32 and rounded ONCE (decode rows, batched decode);
+        larger (prefill-sized) ones are all-reduced in the layer dtype in one pass -- Megatron's row-parallel choice: half the bytes on the links, but
+        each of the T partial sums is rounded before the sum (for K / T terms of |x w| <= 1 that is T half-ulp errors: ~2e-3 relative at T = 8 in fp16)
+        and a partial sum beyond 65504 overflows fp16 where the fp32 total would not.  None = always fp32.  bf16 layers cannot overflow this way."""
         super().__init__()
         self.local = local
         self.k0, self.k1 = k_range
@@ -182,10 +186,10 @@ class RowParallelQuantLinear(nn.Module):
         self.group = group
         self.input_is_parallel = input_is_parallel
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.fp32_reduce_max_elems = 64 * 16384             # outputs up to 64 rows x 16 K columns take the fp32 reduction
+        self.fp32_reduce_max_elems = fp32_reduce_max_elems   # default: up to 64 rows x 16 K columns take the fp32 reduction
 
     @classmethod
-    def from_full(cls, full, rank: int, world: int, group=None, device=None, input_is_parallel=True):
+    def from_full(cls, full, rank: int, world: int, group=None, device=None, input_is_parallel=True, fp32_reduce_max_elems: Optional[int] = 64 * 16384):
         from .qlinear_mi355x import QuantLinear, _is_sequential_g_idx
 
         if not _is_sequential_g_idx(full.g_idx, full.group_size):
@@ -200,13 +204,14 @@ class RowParallelQuantLinear(nn.Module):
         if device is not None:
             local = local.to(device)
             bias = None if bias is None else bias.to(device)
-        return cls(local, (k0, k1), bias=bias, group=group, input_is_parallel=input_is_parallel)
+        return cls(local, (k0, k1), bias=bias, group=group, input_is_parallel=input_is_parallel, fp32_reduce_max_elems=fp32_reduce_max_elems)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.input_is_parallel:
             x = x[..., self.k0:self.k1].contiguous()
         y = self.local(x)
-        if self.world > 1 and y.numel() > self.fp32_reduce_max_elems and not (y.is_cuda and _host_staged(self.group)):
+        if (self.world > 1 and self.fp32_reduce_max_elems is not None and y.numel() > self.fp32_reduce_max_elems
+                and not (y.is_cuda and _host_staged(self.group))):
             # prefill-sized outputs: reduce in the layer dtype (what Megatron's row-parallel linear does) -- ONE pass over [M, N] instead
             # of cast-up, fp32 all-reduce (twice the bytes on xGMI) and cast-down; the T partial sums are each rounded once more
             dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)

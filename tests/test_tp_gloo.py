@@ -116,6 +116,52 @@ def test_row_parallel_two_ranks_gloo(bits, gs, K, N, M):
     assert all(ok for _, ok, _ in res), res
 
 
+def _worker_row_threshold(rank, world, port, q):
+    """The two reductions of RowParallelQuantLinear on the SAME fp16 partial sums: threshold below the output size (one pass in fp16, every partial rounded
+    before the sum) against threshold None (fp32 sum, one rounding)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from autogptq_amd.tensor_parallel import RowParallelQuantLinear, shard_packed_rows
+        bits, gs, K, N, M = 4, 128, 1024, 256, 8
+        L = O.random_quant_layer(K, N, bits, gs, seed=9, bias=True)
+        x = (torch.rand(M, K, generator=torch.Generator().manual_seed(3)) - 0.5).half()
+        mode = O.reference_zero_mode(False, bits)
+        qw, qz, sc, (k0, k1) = shard_packed_rows(L["qweight"], L["qzeros"], L["scales"], bits, gs, rank, world)
+
+        def local(xx):                                   # fp16 partial product, as the HIP shard returns it
+            return O.forward(xx.float(), qw, qz, sc.float(), None, None, bits, mode).half()
+
+        lo = RowParallelQuantLinear(local, (k0, k1), bias=L["bias"], input_is_parallel=False, fp32_reduce_max_elems=M * N - 1)
+        hi = RowParallelQuantLinear(local, (k0, k1), bias=L["bias"], input_is_parallel=False, fp32_reduce_max_elems=None)
+        assert lo.fp32_reduce_max_elems == M * N - 1 and hi.fp32_reduce_max_elems is None
+        y_lo, y_hi = lo(x), hi(x)
+        ref = O.forward(x.float(), L["qweight"], L["qzeros"], L["scales"].float(), L["g_idx"], L["bias"].float(), bits, mode)
+        scale = float(ref.abs().max())
+        e_lo, e_hi = float((y_lo.float() - ref).abs().max()) / scale, float((y_hi.float() - ref).abs().max()) / scale
+        # fp32 reduce: the partials' own fp16 rounding + one final rounding; fp16 reduce: one more rounding per rank.  Stated tolerance: 2e-3 of the
+        # largest output for both at T = 2 (the matmul tolerance of the GPU tests), and the one-pass form is allowed up to 2x the fp32 form's error + 1 ulp
+        q.put((rank, e_lo <= 2e-3 and e_hi <= 2e-3 and e_lo <= 2 * e_hi + 1e-3 and y_lo.dtype == torch.float16 and y_hi.dtype == torch.float16, (e_lo, e_hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_parallel_reduce_precision_threshold_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_row_threshold, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+
+
 def _worker_mlp(rank, world, port, K, F, gs, M, q):
     """Megatron pairing on a gated MLP: gate/up column-parallel WITHOUT gather, down row-parallel with input_is_parallel=True:
     one all-reduce per block, no all-gather.  Rank-local matmuls are played by the oracle (fp32)."""
