@@ -130,9 +130,7 @@ bool want_stream(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
 bool want_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* t) {
     if (M > 4 || n < 1 || n > 4) return false;
     if (t && t->path != 0 && t->path != 8) return false;
-    for (int i = 0; i < n; ++i)
-        if (Ls[i]->g_idx != nullptr) return false;                 // act-order layers: the tiled copy holds qweight_seq; x has to be permuted first (not wired yet)
-    return plan_tiled(Ls, n, M, t).ok;
+    return plan_tiled(Ls, n, M, t).ok;                             // act-order layers: the copy holds the re-sequenced rows, the kernel gathers x through perm
 }
 
 // act-order layers on the streamed GEMV: x permuted once by the column-permute pre-pass, the kernel streams the re-sequenced rows of a
@@ -720,8 +718,8 @@ static int decode_copy_source(const gptq_layer_t* L, gptq_layer_t* S) {
     S->tiled_cols = GPTQ_STRIP_COLS;
     S->epilogue = GPTQ_EPI_NONE;                             // a [gate | up] layer with the fused epilogue has no decode copy of its own (its halves do)
     if (L->epilogue != GPTQ_EPI_NONE || !tiled_layer_ok(*S))
-        return fail(GPTQ_ERR_UNSUPPORTED, "the decode copy needs a plain 3-, 4- or 8-bit fp16/bf16 layer, group_size a power-of-two multiple of 32 (16 at 8 bits) or >= K, "
-                                          "and no raw act-order g_idx (bits=%d dtype=%d group_size=%d)", L->bits, L->dtype, L->group_size);
+        return fail(GPTQ_ERR_UNSUPPORTED, "the decode copy needs a 3-, 4- or 8-bit fp16/bf16 layer, group_size a power-of-two multiple of 32 (16 at 8 bits) or >= K, "
+                                          "and for act-order layers qweight_seq + perm (bits=%d dtype=%d group_size=%d)", L->bits, L->dtype, L->group_size);
     return GPTQ_OK;
 }
 

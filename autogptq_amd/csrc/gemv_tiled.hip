@@ -26,286 +26,12 @@
 //     group sum, times the scale: the arithmetic of every other decode kernel here (one-hot rows return the reference's exact scales * (w - z));
 //   * a lane owns ONE column: k-slots by two shuffles, waves through LDS, K slices through {fp32, tag} granules (stream_finish, gemv_shared.cuh);
 //   * up to four layers that share x in one launch (gptq_forward_multi).
-#include "gemv_shared.cuh"
+#include "gemv_tiled_kernel.cuh"
 
 namespace gptq {
 
-// Kernel arguments, laid out for a short prologue: everything a workgroup needs to find its layer sits in the first bytes (loaded with the other scalars
-// at kernel entry), the layer's pointers are ONE dependent scalar load.  (The first version walked GemvStreamParams::seg[] with a dependent kernarg load per
-// step and divided by ksplit: ~230 instructions and five scalar-load round trips before the first weight load, ~1 us per launch against the lab kernel.)
-struct TiledSeg {
-    const unsigned* tq;      // qweight_tiled
-    const void* cst;         // qconst_tiled
-    const void* bias;
-    void* out;
-    int N, col0;             // columns of this layer; its first column in the concatenated partial slab
-    int pad_[2];
-};
-// Tensor-parallel epilogue (gptq_forward_scatter; protocol: peer.hip): the owner workgroup of a strip stores its [M][16] outputs at the rank's column
-// offset of EVERY rank's exchange buffer of this call's parity; the rank's arrival flag is raised by the collect launch behind this kernel.
-struct PeerEpi {
-    char* xbuf[2][GPTQ_PEER_MAX];
-    unsigned* flags[GPTQ_PEER_MAX];
-    unsigned* state;         // [0] gathers completed (the epoch)
-    int world, rank;
-    unsigned row_bytes, col_off_bytes, owners, pad_;
-};
-struct TiledParams {
-    int blk_end[4];          // cumulative strip count up to and including layer i (unused entries: INT_MAX)
-    const void* x;
-    unsigned long long* gran;   // K-split exchange granules (stream_finish)
-    unsigned* epochs;
-    unsigned* err;
-    int nseg, M, K, chunks, chunks_per_split, ksplit, gu_shift, nsum, groups, xstride, waves;
-    unsigned max_spins;
-    TiledSeg seg[4];
-    PeerEpi peer;            // world = 0: none.  Read by the owner workgroups only, behind their K loop.
-};
-
-// Per packing: what a lane of one chunk load holds.  The chunk is always 4 k-slots x 16 columns; a lane (k-slot, column) holds WPL consecutive words =
-// KPL consecutive k of ONE column, re-encoded at load time (gptq_prepack_decode) so that the packed fp16 magic-number extraction yields the k pairs in
-// the order x lies in memory:
-//   4-bit  4 words = 32 k; stored nibbles k0 k2 k4 k6 k1 k3 k5 k7 per word
-//   8-bit  4 words = 16 k; stored bytes   k0 k2 k1 k3 per word
-//   3-bit  3 words = 32 k (one packing unit, re-encoded without straddlers): word j holds the pairs p = 5 j + i (i = 0..4) = (k 2p, k 2p + 1) at bit 3 i of
-//          its low / high half; bits 15 and 31 of the three words are the bits of k30 / k31.
-template <int BITS> struct TiledFmt;
-template <> struct TiledFmt<4> { static constexpr int WPL = 4, KPL = 32, REC = 48, ZB = 1; };
-template <> struct TiledFmt<8> { static constexpr int WPL = 4, KPL = 16, REC = 64, ZB = 2; };
-template <> struct TiledFmt<3> { static constexpr int WPL = 3, KPL = 32, REC = 48, ZB = 1; };
-
-template <int N_> struct WordsOf { typedef unsigned type __attribute__((ext_vector_type(N_))); };
-
-template <int BITS, int MT, int U, typename T, int MAXW>
-__global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kernel(TiledParams p) {
-    constexpr bool BF = std::is_same_v<T, bf16>;
-    using F = TiledFmt<BITS>;
-    constexpr int WPL = F::WPL, KPL = F::KPL, CKE = 4 * KPL, CHB = 64 * WPL * 4, REC = F::REC, NX = KPL / 8;      // k per chunk, bytes per chunk, x pieces per lane and chunk
-    constexpr int LKPL = KPL == 32 ? 5 : 4;
-    typedef typename WordsOf<WPL>::type qvec;
-    unsigned m_lo, m_hi, m_b, magic;                                              // opaque constants: (q & mask) | magic is ONE v_and_or_b32 (gemv.hip)
-    asm("s_mov_b32 %0, 0x000f000f" : "=s"(m_lo));
-    asm("s_mov_b32 %0, 0x00f000f0" : "=s"(m_hi));
-    asm("s_mov_b32 %0, 0x00ff00ff" : "=s"(m_b));
-    asm("v_mov_b32 %0, 0x64006400" : "=v"(magic));
-    unsigned m3a, m3b, m3c;
-    asm("s_mov_b32 %0, 0x00070007" : "=s"(m3a));
-    asm("s_mov_b32 %0, 0x00380038" : "=s"(m3b));
-    asm("s_mov_b32 %0, 0x01c001c0" : "=s"(m3c));
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                    // scalar: the staging loops below are scalar loops
-    const int col = lane & 15, kb = lane >> 4;                                    // lane = kb * 16 + col: lane-linear inside the chunk
-    // every scalar argument in ONE batch of kernarg loads (the empty asm pins them here: left to itself the compiler loads them one dependent step at a time)
-    int ksplit = p.ksplit, be0 = p.blk_end[0], be1 = p.blk_end[1], be2 = p.blk_end[2], nchunks = p.chunks, cps = p.chunks_per_split, K = p.K, Mrows = p.M,
-        G = p.groups, xstride = p.xstride, gshift = p.gu_shift, W = p.waves;
-    const char* xg = (const char*)p.x;
-    asm volatile("" : "+s"(ksplit), "+s"(be0), "+s"(be1), "+s"(be2), "+s"(nchunks), "+s"(cps), "+s"(K), "+s"(Mrows), "+s"(G), "+s"(xstride), "+s"(gshift), "+s"(W), "+s"(xg));
-    // workgroup -> (strip over all layers, K slice); no XCD remap: strips share nothing but x, which every L2 holds
-    int sidx = blockIdx.x, ks = 0;
-    if (ksplit != 1) { sidx = (int)blockIdx.x / ksplit; ks = (int)blockIdx.x - sidx * ksplit; }      // uniform branch: the division only where slices exist
-    const int s = (sidx >= be0) + (sidx >= be1) + (sidx >= be2);                  // scalar compares on entry-loaded words
-    const TiledSeg sg = p.seg[s];                                                 // one dependent kernarg load
-    const int strip = sidx - (s == 0 ? 0 : (s == 1 ? be0 : (s == 2 ? be1 : be2)));
-    const int N = sg.N;
-    const int cb = ks * cps, ce = min(cb + cps, nchunks);                         // this slice's chunks
-    const int kbeg = cb * CKE, kend = min(ce * CKE, K);                           // ... and its k range: what is staged of x
-    // LDS: [x: MT rows of (kend - kbeg) values, row stride + 16 B][constants: G x REC bytes][cross-wave sums]
-    char* const xs = smem;                                                        // row stride xstride = chunks_per_split * CKE * 2 + 16 bytes: the 4 rows of a 4-lane group hit different banks
-    char* const cs = smem + (size_t)MT * xstride;
-    float* const red = (float*)(cs + (((size_t)G * REC + 15) & ~(size_t)15));
-    const char* const cg = (const char*)sg.cst + (size_t)strip * G * REC;         // this strip's constants: one contiguous run
-    const char* const tb = (const char*)sg.tq + (size_t)strip * nchunks * CHB;    // this strip's weights: one contiguous run
-    const unsigned t_lane = (unsigned)lane * (WPL * 4u);
-    // ---- stage x and the constants by LDS DMA: no VGPRs, issued FIRST (loads return in issue order), waited for behind the first weight burst
-    {
-        const unsigned xs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)xs, cs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cs;
-        const int pieces = (kend - kbeg) >> 3;                                    // 16-byte pieces per x row
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const char* xr = xg + ((size_t)min(m, Mrows - 1) * K + kbeg) * 2;
-            for (int pc0 = wave * 64; pc0 < pieces; pc0 += W * 64)                // wave-uniform trip count
-                if (pc0 + lane < pieces) lds_dma16(xr + (size_t)(pc0 + lane) * 16, xs_lds + m * xstride + pc0 * 16);      // default cache policy: every workgroup reads x
-        }
-        const int cpieces = (G * REC) >> 4;                                       // REC is a multiple of 16
-        for (int pc0 = wave * 64; pc0 < cpieces; pc0 += W * 64)
-            if (pc0 + lane < cpieces) dma16_nt(cg + (size_t)(pc0 + lane) * 16, __builtin_amdgcn_readfirstlane(cs_lds + pc0 * 16));
-    }
-    // bf16 layers: x is converted IN PLACE in the LDS to fp16 with one power-of-two factor per (row, run of KPL k) -- block floating point -- so that the
-    // loop below is the fp16 loop: w - z is a small integer, exact in either type, and turning every fp16 pair into bf16 costs 12 VALU per packed word (the
-    // round-3 kernels' 7 - 25 % bf16 gap).  A run is what one lane sums on the matrix core before its fp32 sums meet the scale, so the factor's inverse rides
-    // on the scale (xe[run][row]); it puts the run's largest |x| into [2^14, 2^15): nothing overflows (bf16 reaches 3e38, fp16 65504), elements more than
-    // 2^-28 below the run's largest lose bits -- below the resolution of the fp32 sum they enter.  Products stay exact (8-bit by 11-bit significands into
-    // fp32), as on the bf16 matrix core.  One thread = one 16-byte piece, the NX pieces of a run in adjacent lanes; one more barrier.
-    // (Tried instead, same speed at one row and slower at four: one factor per row through an LDS atomic max, and each wave converting its own chunks'
-    // x inside the K loop -- profiles/r04_tiled_sweep_bf16_v*.log.)
-    // The conversion is done by every workgroup for its whole K slice: at 3 - 4 rows it costs what converting the weights costs, so those keep the bf16
-    // matrix core (XC false).
-    constexpr bool XC = BF && MT <= 2;
-    using MM = std::conditional_t<XC, f16, T>;                                    // the matrix core's operand type
-    constexpr int ES = MT * 16 + 4;
-    float* const xe = red + W * ES;                                               // [runs of the slice][4 rows] inverse factors (bf16 layers only; planned for)
-    auto x_to_f16 = [&]() {                                                       // every thread of the workgroup, behind the staging barrier
-        const int prow = (kend - kbeg) >> 3, total = prow * MT;                   // pieces per row: a multiple of NX, like the thread stride
-        for (int i0 = 0; i0 < total; i0 += W * 64) {                             // uniform trip count: the shuffles below need every lane
-            const int idx = i0 + tid;
-            const bool ok = idx < total;
-            int m = 0, pc = ok ? idx : 0;
-            if constexpr (MT > 1) { m = pc / prow; pc -= m * prow; }
-            u32x4* const at = (u32x4*)(xs + (size_t)m * xstride + (size_t)pc * 16);
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) v = *at;
-            unsigned mx = 0u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned a = v[i] & 0x7fff7fffu;
-                mx = max(mx, max(a & 0xffffu, a >> 16));
-            }
-            mx = max(mx, (unsigned)__shfl_xor((int)mx, 1, 64));
-            if constexpr (NX == 4) mx = max(mx, (unsigned)__shfl_xor((int)mx, 2, 64));
-            const int E = (int)((mx >> 7) & 0xffu);                               // biased exponent of the run's largest |x|
-            const int ms = min(max(268 - E, 1), 253);                             // 2^(ms - 127): the largest lands in [2^14, 2^15)
-            const float mult = __builtin_bit_cast(float, (unsigned)ms << 23);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float lo = __builtin_bit_cast(float, v[i] << 16) * mult, hi = __builtin_bit_cast(float, v[i] & 0xffff0000u) * mult;
-                v[i] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));              // exact unless the result is an fp16 subnormal
-            }
-            if (ok) {
-                *at = v;
-                if ((pc & (NX - 1)) == 0) xe[(pc / NX) * 4 + m] = __builtin_bit_cast(float, (unsigned)(254 - ms) << 23);
-            }
-        }
-        __syncthreads();
-    };
-    const char* const xl = xs + (size_t)min(lane & 3, MT - 1) * xstride + kb * (KPL * 2);    // A operand: lane i of a 4-lane group carries x row i
-    float acc[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = 0.f;
-    const f16x2 k960 = {(f16)960.f, (f16)960.f}, k896 = {(f16)896.f, (f16)896.f}, k1008 = {(f16)1008.f, (f16)1008.f};
-    const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f}, r8 = {(f16)0.125f, (f16)0.125f}, r64 = {(f16)0.015625f, (f16)0.015625f};
-    auto bits_of = [&](f16x2 hv) -> unsigned {                                    // the pair as the matrix core takes it: fp16 (also bf16 layers behind x_to_f16), or
-        if constexpr (BF && !XC) {                                                // fp16 -> fp32 -> bf16 (exact: small integers)
-            const bf16x2 o = {(bf16)(float)hv[0], (bf16)(float)hv[1]};
-            return __builtin_bit_cast(unsigned, o);
-        } else {
-            return __builtin_bit_cast(unsigned, hv);
-        }
-    };
-    bool staged = false;
-    for (int cbase = cb; cbase < ce; cbase += W * U) {
-        const int c0 = cbase + wave * U;
-        qvec q[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) q[j] = __builtin_nontemporal_load((const qvec*)(tb + ((unsigned)min(c0 + j, ce - 1) * (unsigned)CHB + t_lane)));
-        if (!staged) {                                                            // first pass only (uniform): the staging DMAs are OLDER than the U loads just issued
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(U) : "memory");
-            __syncthreads();
-            if constexpr (XC) x_to_f16();
-            staged = true;
-        }
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int cc = min(c0 + j, ce - 1);
-            const int k0 = cc * CKE + kb * KPL;                                   // first k of this lane's words
-            const bool live = (c0 + j < ce) && (k0 < K);                          // a ragged last chunk: whole k-slots are missing
-            const int g = min(k0 >> LKPL >> gshift, G - 1);
-            const char* cp = cs + g * REC;
-            const unsigned short sraw = *(const unsigned short*)(cp + col * 2);
-            unsigned z;
-            if constexpr (F::ZB == 1) z = *(const unsigned char*)(cp + 32 + col);
-            else z = *(const unsigned short*)(cp + 32 + col * 2);
-            u32x4 xa[NX];
-#pragma unroll
-            for (int w = 0; w < NX; ++w) xa[w] = *(const u32x4*)(xl + ((unsigned)(cc - cb) * (unsigned)(CKE * 2) + w * 16u));
-            const f16x2 c1 = as_f16x2(z * 0x00010001u + 0xE400E400u);            // -(1024 + z)
-            const qvec qv = q[j];
-            f32x4 accg = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (BITS == 4) {
-                const f16x2 c2 = c1 + k960;                                       // -(64 + z)
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const unsigned qw = qv[w], q8 = qw >> 8;
-                    const f16x2 h0 = as_f16x2((qw & m_lo) | magic) + c1;          // k0,k1  (stored nibbles 0 and 4)
-                    const f16x2 h1 = as_f16x2((qw & m_hi) | magic) * r16 + c2;    // k2,k3  (1 and 5)
-                    const f16x2 h2 = as_f16x2((q8 & m_lo) | magic) + c1;          // k4,k5  (2 and 6)
-                    const f16x2 h3 = as_f16x2((q8 & m_hi) | magic) * r16 + c2;    // k6,k7  (3 and 7)
-                    accg = Mma4<MM>::run(u32x2{xa[w][0], xa[w][1]}, u32x2{bits_of(h0), bits_of(h1)}, accg);
-                    accg = Mma4<MM>::run(u32x2{xa[w][2], xa[w][3]}, u32x2{bits_of(h2), bits_of(h3)}, accg);
-                }
-            } else if constexpr (BITS == 8) {
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {                                     // one word = 4 k = one matrix-core step
-                    const unsigned qw = qv[w], q8 = qw >> 8;
-                    const f16x2 h0 = as_f16x2((qw & m_b) | magic) + c1;           // k0,k1  (stored bytes 0 and 2)
-                    const f16x2 h1 = as_f16x2((q8 & m_b) | magic) + c1;           // k2,k3  (1 and 3)
-                    accg = Mma4<MM>::run(u32x2{xa[w >> 1][(w & 1) * 2], xa[w >> 1][(w & 1) * 2 + 1]}, u32x2{bits_of(h0), bits_of(h1)}, accg);
-                }
-            } else {
-                const f16x2 c3 = c1 + k896;                                       // -(128 + z): fields at bit 3, times 1/8
-                const f16x2 c6 = c1 + k1008;                                      // -(16 + z): fields at bit 6, times 1/64
-                unsigned pr[16];                                                  // the 16 k pairs of the unit, in k order
-#pragma unroll
-                for (int w = 0; w < 3; ++w) {
-                    const unsigned t = qv[w], t6 = t >> 6;
-                    pr[5 * w + 0] = bits_of(as_f16x2((t & m3a) | magic) + c1);
-                    pr[5 * w + 1] = bits_of(as_f16x2((t & m3b) | magic) * r8 + c3);
-                    pr[5 * w + 2] = bits_of(as_f16x2((t & m3c) | magic) * r64 + c6);
-                    pr[5 * w + 3] = bits_of(as_f16x2((t6 & m3b) | magic) * r8 + c3);
-                    pr[5 * w + 4] = bits_of(as_f16x2((t6 & m3c) | magic) * r64 + c6);
-                }
-                const unsigned e = ((qv[0] >> 15) & 0x00010001u) | ((qv[1] >> 14) & 0x00020002u) | ((qv[2] >> 13) & 0x00040004u);   // (k30 | k31 << 16): bits 15 / 31 of the three words
-                pr[15] = bits_of(as_f16x2(e | magic) + c1);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    accg = Mma4<MM>::run(u32x2{xa[i >> 1][(i & 1) * 2], xa[i >> 1][(i & 1) * 2 + 1]}, u32x2{pr[2 * i], pr[2 * i + 1]}, accg);
-            }
-            const float sc = DType<T>::to_f32(__builtin_bit_cast(T, sraw));
-            if constexpr (XC) {
-                const float* const xi = xe + ((cc - cb) * 4 + kb) * 4;           // the run's inverse block factors, one per row
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = live ? fmaf(sc * xi[m], accg[m], acc[m]) : acc[m];
-            } else {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = live ? fmaf(sc, accg[m], acc[m]) : acc[m];   // a select, not a product by 0: a dead slot's x is whatever the LDS holds
-            }
-        }
-    }
-    // ---- k-slots (two shuffles: a lane owns one column), waves (LDS), then write / publish ---------------------------------------------------
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        float v = acc[m];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        acc[m] = v;
-    }
-    if (!staged) __syncthreads();                                                 // (an empty slice never took the staging barrier; the planner makes none)
-    if (lane < 16) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) red[wave * ES + m * 16 + lane] = acc[m];
-    }
-    __syncthreads();
-    const int pworld = p.peer.world;
-    T* const stage = pworld > 0 ? (T*)xs : nullptr;                                // the staged x is dead behind the barrier above
-    stream_finish<16, MT, T, TiledParams, TiledSeg>(p, sg, strip, sidx, ks, N, red, stage);
-    if (pworld > 0 && ks == 0) {                                                  // uniform: the strip's owner
-        __syncthreads();
-        const unsigned e = __hip_atomic_load(p.peer.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;      // this gather's epoch (peer.hip)
-        if (tid < pworld * MT * 2) {                                              // (peer, row, half of the strip's 32 bytes)
-            const int r = tid / (MT * 2), m = (tid >> 1) % MT, q = tid & 1;
-            if (m < Mrows) {
-                const u32x4 v = *(const u32x4*)((const char*)stage + m * 32 + q * 16);
-                char* const dst = p.peer.xbuf[e & 1u][r] + (size_t)m * p.peer.row_bytes + p.peer.col_off_bytes + (size_t)strip * 32 + q * 16;
-                // a system-scope WRITE-THROUGH store (sc0 sc1): the payload goes to its home, not into this XCD's L2.  NOT a release fence per
-                // workgroup: at system (and agent) scope that is an L2 write-back, and hundreds of strips doing one each cost 20 - 240 us per launch
-                // (profiles/r04_tp2_same_device_fused_scatter_v1 / v2*.json).
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
-            }
-        }
-        // No ticket, no flag here: the rank's arrival flag is raised by its COLLECT launch, which starts behind this kernel in stream order (every store
-        // above has been acknowledged by then).  A ticket drawn by every strip -- 256 .. 896 fetch-adds on one word -- measured 8 - 70 us per launch.
-    }
-}
+hipError_t launch_tiled_act(const TiledPlan& pl, const TiledParams& p, int dtype, hipStream_t st);      // gemv_tiled_act.hip
+hipError_t init_gemv_tiled_act_device();
 
 // ---- plan + launch ---------------------------------------------------------------------------------------------------------------------
 static int tiled_kpl(int bits) { return bits == 8 ? 16 : 32; }          // k per lane and chunk
@@ -315,7 +41,7 @@ static int tiled_rec_bytes(int bits) { return bits == 8 ? 64 : 48; }
 bool tiled_layer_ok(const gptq_layer_t& L) {
     if (!L.qweight_tiled || !L.qconst_tiled || L.tiled_cols != GPTQ_STRIP_COLS || L.epilogue != GPTQ_EPI_NONE) return false;
     if (L.bits != 4 && L.bits != 8 && L.bits != 3) return false;
-    if (L.g_idx != nullptr) return false;                                         // act-order: groups per k, not per run of k
+    if (L.g_idx != nullptr && !(L.perm && L.qweight_seq)) return false;           // act-order: only with the re-sequenced rows (the copy is made of them) and perm
     if (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16) return false;
     if (L.K % 32 || L.N % GPTQ_STRIP_COLS) return false;
     const int kpl = tiled_kpl(L.bits);
@@ -339,7 +65,7 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
     for (int i = 0; i < n; ++i) {
         const gptq_layer_t& L = *Ls[i];
         if (!tiled_layer_ok(L)) return pl;
-        if (L.K != A.K || L.group_size != A.group_size || L.dtype != A.dtype || L.bits != A.bits) return pl;
+        if (L.K != A.K || L.group_size != A.group_size || L.dtype != A.dtype || L.bits != A.bits || (L.g_idx != nullptr) != (A.g_idx != nullptr)) return pl;
         strips += L.N / GPTQ_STRIP_COLS;
         nsum += L.N;
     }
@@ -359,11 +85,13 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         ks = 1;
         while (strips * ks < 128 && chunks / (ks * 2) >= 8) ks *= 2;
     }
-    const size_t lds_cap = 96 * 1024;
+    const size_t raw_bytes = A.g_idx ? (size_t)pl.mt * ((size_t)A.K * 2 + 16) + 16 : 0;      // act-order: does not shrink with K slices
+    const size_t lds_cap = 96 * 1024 + raw_bytes;
     auto lds_need = [&](int k_slices, int waves) {
         const int cps = (chunks + k_slices - 1) / k_slices;
         return (size_t)pl.mt * ((size_t)cps * cke * 2 + 16) + (size_t)pl.groups * rec + (size_t)waves * (pl.mt * 16 + 4) * sizeof(float) + 16 +
-               (A.dtype == GPTQ_BF16 && pl.mt <= 2 ? (size_t)cps * 64 : 0);                      // bf16: one inverse block factor per (run of a chunk's 4, row of 4)
+               (A.dtype == GPTQ_BF16 && pl.mt <= 2 ? (size_t)cps * 64 : 0) +
+               (A.g_idx ? (size_t)pl.mt * ((size_t)A.K * 2 + 16) + 16 : 0);         // act-order: the raw x rows, whole K                      // bf16: one inverse block factor per (run of a chunk's 4, row of 4)
     };
     while (ks < 8 && ks < chunks && lds_need(ks, 16) > lds_cap) ks *= 2;
     if (ks > chunks) ks = chunks;
@@ -385,53 +113,16 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         while (waves > 1 && (waves / 2) * u >= cps) waves /= 2;
     }
     if (waves < 1 || waves > 16 || (u != 1 && u != 2 && u != 4 && u != 8)) return pl;
-    if (A.bits != 4 && u != 2 && u != 4) return pl;                               // the 3- and 8-bit forms are compiled for 2 and 4 chunks in flight
+    if ((A.bits != 4 || A.g_idx) && u != 2 && u != 4) return pl;                  // the 3- / 8-bit and the act-order forms are compiled for 2 and 4 chunks in flight
     pl.waves = waves;
     pl.u = u;
     pl.xstride = cps * cke * 2 + 16;
     pl.lds_bytes = lds_need(pl.ksplit, waves);
+    pl.xraw_off = A.g_idx ? (int)((pl.lds_bytes - ((size_t)pl.mt * ((size_t)A.K * 2 + 16) + 16) + 15) & ~(size_t)15) : 0;
     if (pl.lds_bytes > 160 * 1024) return pl;
     pl.partial_bytes = pl.ksplit > 1 ? (size_t)(pl.ksplit - 1) * M * nsum * 8 : 0;
     pl.ok = true;
     return pl;
-}
-
-// Two compilations per (BITS, MT, U, T): workgroups of up to 16 waves (<= 128 VGPRs) and of up to 8 waves.
-template <int BITS, int MT, int U, typename T>
-static hipError_t launch_tiled_one(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
-    if (pl.waves > 8)
-        hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 16>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
-    else
-        hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 8>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
-    return hipGetLastError();
-}
-template <int BITS, int MT, typename T>
-static hipError_t launch_tiled_u(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
-    switch (pl.u) {
-        case 1: if constexpr (BITS == 4) return launch_tiled_one<BITS, MT, 1, T>(pl, p, st); else return hipErrorInvalidValue;
-        case 2: return launch_tiled_one<BITS, MT, 2, T>(pl, p, st);
-        case 4: return launch_tiled_one<BITS, MT, 4, T>(pl, p, st);
-        case 8: if constexpr (BITS == 4) return launch_tiled_one<BITS, MT, 8, T>(pl, p, st); else return hipErrorInvalidValue;
-        default: return hipErrorInvalidValue;
-    }
-}
-template <int BITS, typename T>
-static hipError_t launch_tiled_mt(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
-    switch (pl.mt) {
-        case 1: return launch_tiled_u<BITS, 1, T>(pl, p, st);
-        case 2: return launch_tiled_u<BITS, 2, T>(pl, p, st);
-        case 4: return launch_tiled_u<BITS, 4, T>(pl, p, st);
-        default: return hipErrorInvalidValue;
-    }
-}
-template <typename T>
-static hipError_t launch_tiled_bits(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
-    switch (pl.bits) {
-        case 4: return launch_tiled_mt<4, T>(pl, p, st);
-        case 8: return launch_tiled_mt<8, T>(pl, p, st);
-        case 3: return launch_tiled_mt<3, T>(pl, p, st);
-        default: return hipErrorInvalidValue;
-    }
 }
 
 hipError_t launch_tiled(const gptq_layer_t* const* Ls, const TiledPlan& pl, const void* x, void* const* outs, int M, void* ws_header, void* ws_body,
@@ -458,7 +149,7 @@ hipError_t launch_tiled(const gptq_layer_t* const* Ls, const TiledPlan& pl, cons
         const gptq_layer_t& L = *Ls[i];
         blk += L.N / GPTQ_STRIP_COLS;
         p.blk_end[i] = blk;
-        p.seg[i] = TiledSeg{L.qweight_tiled, L.qconst_tiled, L.bias, outs[i], L.N, col, {0, 0}};
+        p.seg[i] = TiledSeg{L.qweight_tiled, L.qconst_tiled, L.bias, outs[i], L.N, col, L.g_idx ? L.perm : nullptr};
         col += L.N;
     }
     p.blk_end[3] = 0x7fffffff;                                                    // the selector adds three compares: a fourth layer is reached by the first three
@@ -475,27 +166,15 @@ hipError_t launch_tiled(const gptq_layer_t* const* Ls, const TiledPlan& pl, cons
     p.groups = pl.groups;
     p.xstride = pl.xstride;
     p.waves = pl.waves;
-    return A.dtype == GPTQ_BF16 ? launch_tiled_bits<bf16>(pl, p, st) : launch_tiled_bits<f16>(pl, p, st);
+    p.xraw_off = pl.xraw_off;
+    if (A.g_idx) return launch_tiled_act(pl, p, A.dtype, st);                     // gemv_tiled_act.hip
+    return A.dtype == GPTQ_BF16 ? launch_tiled_bits<bf16, false>(pl, p, st) : launch_tiled_bits<f16, false>(pl, p, st);
 }
 
 hipError_t init_gemv_tiled_device() {
-    hipError_t e = hipSuccess;
-    auto grant = [&](auto kern) { hipError_t r = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e == hipSuccess) e = r; };
-    // long K at 4 rows of x: the staged activations can pass the 64 KiB default
-    auto grant_mt = [&](auto mt) {
-        constexpr int MT = decltype(mt)::value;
-        auto grant_u = [&](auto bu, auto uu) {
-            constexpr int B = decltype(bu)::value, U = decltype(uu)::value;
-            grant(gemv_tiled_kernel<B, MT, U, f16, 16>); grant(gemv_tiled_kernel<B, MT, U, f16, 8>);
-            grant(gemv_tiled_kernel<B, MT, U, bf16, 16>); grant(gemv_tiled_kernel<B, MT, U, bf16, 8>);
-        };
-        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-        using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
-        grant_u(I4{}, I1{}); grant_u(I4{}, I2{}); grant_u(I4{}, I4{}); grant_u(I4{}, I8{});
-        grant_u(I8{}, I2{}); grant_u(I8{}, I4{}); grant_u(I3{}, I2{}); grant_u(I3{}, I4{});
-    };
-    grant_mt(std::integral_constant<int, 1>{}); grant_mt(std::integral_constant<int, 2>{}); grant_mt(std::integral_constant<int, 4>{});
-    return e;
+    hipError_t e = grant_tiled_lds<false>();
+    hipError_t e2 = init_gemv_tiled_act_device();
+    return e != hipSuccess ? e : e2;
 }
 
 }  // namespace gptq

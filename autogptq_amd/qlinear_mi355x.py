@@ -242,13 +242,13 @@ class QuantLinear(nn.Module):
         L.epilogue = _lib.EPI_SILU_MUL if self.epilogue == "silu_mul" else _lib.EPI_NONE
         L.qweight_tiled = L.qconst_tiled = None
         L.tiled_cols = 0
-        # Decode copy (plain 3-, 4- and 8-bit fp16 / bf16 layers): what exllamav2's shuffle / Marlin's repack do at load time (q_matrix.cu:19-42,149;
+        # Decode copy (3-, 4- and 8-bit fp16 / bf16 layers; act-order ones from their re-sequenced rows -- the kernel gathers x through perm): what exllamav2's shuffle / Marlin's repack do at load time (q_matrix.cu:19-42,149;
         # marlin_repack.cu:8-92) -- into NON-PERSISTENT storage, the checkpoint tensors stay as they are.  Costs a second copy of the packed weights in
         # HBM; QuantLinear.TILED_DECODE = False (or post_init(tiled=False)) turns it off.
         qweight_tiled = qconst_tiled = None
         if tiled is None:
             tiled = self.TILED_DECODE
-        if tiled and self.bits in (3, 4, 8) and not self.act_order and self.epilogue == "none":
+        if tiled and self.bits in (3, 4, 8) and self.epilogue == "none":             # act-order layers: a copy of the re-sequenced rows (qweight_seq above)
             tb, cb = ctypes.c_size_t(0), ctypes.c_size_t(0)
             if lib.gptq_prepack_decode_bytes(ctypes.byref(L), ctypes.byref(tb), ctypes.byref(cb)) == 0:      # a layer that does not qualify simply has none
                 qweight_tiled = torch.empty(tb.value, dtype=torch.uint8, device=dev)

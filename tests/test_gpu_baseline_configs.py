@@ -330,7 +330,7 @@ def test_wide_tiles_forced_on_ragged_shapes():
             tn.path, tn.reserved[3], tn.ksplit = 3, 6, 1
             tc.path, tc.reserved[3], tc.ksplit = 3, 45, 1          # wide tiles, from the decode copy where the layer has one (raw x by LDS DMA)
             assert _lib.describe_plan(q._layer, M, tw)["kernel"] == "wide"
-            has_copy = q._qweight_tiled is not None and K % 128 == 0
+            has_copy = q._qweight_tiled is not None and K % 128 == 0 and not act      # act-order prefill reads the re-sequenced rows (slot-ordered permuted x)
             assert _lib.describe_plan(q._layer, M, tc)["kernel"] == ("wide_copy" if has_copy else "wide")
             with torch.no_grad():
                 yw, yw2, yn = q(x, tuning=tw), q(x, tuning=tw), q(x, tuning=tn)

@@ -33,15 +33,15 @@ def _tune(waves=0, u=0, ks=0):
     return t
 
 
-def _layer(K, N, gs, dtype, seed, zero_mode="auto", bias=False, bits=4):
-    L = O.random_quant_layer(K, N, bits, gs, dtype=dtype, seed=seed, bias=bias)
+def _layer(K, N, gs, dtype, seed, zero_mode="auto", bias=False, bits=4, act=False):
+    L = O.random_quant_layer(K, N, bits, gs, dtype=dtype, seed=seed, bias=bias, act_order=act)
     q = QuantLinear(bits, gs, K, N, bias, weight_dtype=dtype, zero_mode=zero_mode)
     q.qweight, q.qzeros, q.scales, q.g_idx = L["qweight"].clone(), L["qzeros"].clone(), L["scales"].clone(), L["g_idx"].clone()
     if bias:
         q.bias = L["bias"].clone()
     q = q.to(DEV)
     q.post_init()
-    mode = {"auto": O.ZERO_NOWRAP if bits == 3 else O.ZERO_WRAP, "wrap": O.ZERO_WRAP, "nowrap": O.ZERO_NOWRAP}[zero_mode]     # auto: qlinear_cuda_old's 3-bit branch does not wrap
+    mode = {"auto": O.ZERO_NOWRAP if (bits == 3 or act) else O.ZERO_WRAP, "wrap": O.ZERO_WRAP, "nowrap": O.ZERO_NOWRAP}[zero_mode]     # auto: qlinear_cuda_old's 3-bit branch and the act-order class do not wrap
     W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], bits, mode).to(DEV)
     return L, q, W
 
@@ -179,13 +179,20 @@ def test_side_copy_is_derived_and_checkpoint_untouched():
         _assert_all(p(x), x, W, None, torch.float16, "checkpoint-layout twin")
     with pytest.raises(_lib.GptqError, match="path = 8"):
         p(x, tuning=_tune())
-    # act-order layers keep the in-kernel gather (no side copy of this kind yet)
+    # act-order layers: the copy is made of the re-sequenced rows (the kernel gathers x through perm); the checkpoint tensors stay as they are
     La = O.random_quant_layer(512, 256, 4, 128, act_order=True, seed=2)
     a = QuantLinear(4, 128, 512, 256, False)
     a.qweight, a.qzeros, a.scales, a.g_idx = La["qweight"], La["qzeros"], La["scales"], La["g_idx"]
     a = a.to(DEV)
     a.post_init()
-    assert a._qweight_tiled is None
+    assert a._qweight_tiled is not None and _lib.describe_plan(a._layer, 1)["kernel"] == "strips"
+    assert torch.equal(a.qweight.cpu(), La["qweight"]) and torch.equal(a.g_idx.cpu(), La["g_idx"])
+    # the copy == the oracle's restatement applied to the oracle's re-sequenced rows (rows of w in the stable group order, re-packed)
+    import numpy as np
+    perm = O.sequential_permutation(La["g_idx"])
+    seq = torch.from_numpy(O.pack_rows(O.unpack_weights(La["qweight"], 4)[perm], 4))
+    want = O.decode_copy_weights(seq)
+    assert torch.equal(a._qweight_tiled.cpu().view(torch.int32).reshape(want.shape), want)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
@@ -270,3 +277,58 @@ def test_tiled_multi_layer_launch(dtype):
                     for r, k in hot:
                         assert torch.equal(ys[i][r], made[i][2][k])
                     _assert_all(ys[i], x, made[i][2], None, dtype, f"tiled multi n={n_l} layer {i} M={M}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("bits,K,N,gs", [(4, 1024, 512, 128), (4, 4096, 4096, 128), (4, 4160, 256, 32), (4, 2112, 1024, 64), (4, 96, 64, 32), (4, 11008, 256, 128),
+                                         (4, 28672, 32, 128), (3, 2048, 512, 128), (3, 4096, 1024, 32), (8, 2048, 512, 128), (8, 4128, 256, 16)])
+def test_tiled_decode_act_order(bits, K, N, gs, dtype):
+    """Act-order (desc_act=True) layers through the decode-copy kernel: the copy holds the re-sequenced rows, the workgroup gathers x[perm[i]] while it stages
+    x.  Every output against x (fp64) @ W_oracle (fp64) with the act-order class's zero convention, one-hot rows exact (a one at ORIGINAL position k must
+    return W[k]), default plan + forced geometries + K slices, 1..4 rows, long K (several gather passes per thread)."""
+    L, q, W = _layer(K, N, gs, dtype, K + N + gs + bits, bias=True, bits=bits, act=True)
+    assert q._qweight_tiled is not None and _lib.describe_plan(q._layer, 1)["kernel"] == "strips"
+    for M in (1, 2, 3, 4):
+        x, hot = _x(M, K, dtype, M)
+        with torch.no_grad():
+            y, y2 = q(x), q(x)
+        assert torch.equal(y, y2)
+        _assert_all(y, x, W, q.bias, dtype, f"tiled act-order int{bits} default {K}x{N} g{gs} M={M} {dtype}")
+        saved, q._layer.bias = q._layer.bias, None
+        for t in (None, _tune(4, 4), _tune(16, 2), _tune(8, 2, 2), _tune(2, 4, 3)):
+            if t is not None:                     # the raw rows of x (whole K) may not fit the LDS at this M: such calls keep the in-kernel-gather kernels
+                try:
+                    if _lib.describe_plan(q._layer, M, t).get("kernel") != "strips":
+                        continue
+                except _lib.GptqError:
+                    continue
+            with torch.no_grad():
+                y0 = q(x, tuning=t) if t is not None else q(x)
+            for r, k in hot:
+                assert torch.equal(y0[r], W[k]), f"one-hot row {r} (k={k}) is not the oracle's W[k], act-order int{bits} M={M} {K}x{N} g{gs}"
+            _assert_all(y0, x, W, None, dtype, f"tiled act-order int{bits} forced {K}x{N} g{gs} M={M}")
+        q._layer.bias = saved
+
+
+def test_tiled_multi_layer_launch_act_order():
+    """q | k | v-like act-order layers in ONE launch, each with its OWN perm (and once sharing one g_idx): every output, every layer."""
+    K = 2048
+    made = [_layer(K, n, 128, torch.float16, 700 + n, act=True) for n in (512, 288, 64)]
+    layers = [m[1] for m in made]
+    for M in (1, 4):
+        x, hot = _x(M, K, torch.float16, M)
+        with torch.no_grad():
+            ys = forward_multi(layers, x, None)
+            ys2 = forward_multi(layers, x, None)
+        for i in range(3):
+            assert torch.equal(ys[i], ys2[i])
+            for r, k in hot:
+                assert torch.equal(ys[i][r], made[i][2][k])
+            _assert_all(ys[i], x, made[i][2], None, torch.float16, f"tiled multi act-order layer {i} M={M}")
+    # a plain and an act-order layer do not share a launch (different staging): layer by layer, same results
+    Lp, qp, Wp = _layer(K, 128, 128, torch.float16, 5)
+    x, _ = _x(2, K, torch.float16, 9)
+    with torch.no_grad():
+        ym = forward_multi([qp, layers[0]], x, None)
+    _assert_all(ym[0], x, Wp, None, torch.float16, "mixed group, plain layer")
+    _assert_all(ym[1], x, made[0][2], None, torch.float16, "mixed group, act-order layer")

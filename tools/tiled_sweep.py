@@ -45,6 +45,7 @@ def plain_twin(q):
     """The same layer without the strip-major side copy (what rounds 1-3 ran)."""
     p = QuantLinear(q.bits, q.group_size, q.infeatures, q.outfeatures, False, weight_dtype=q.scales.dtype)
     p.qweight, p.qzeros, p.scales, p.g_idx = q.qweight, q.qzeros, q.scales, q.g_idx
+    p = p.to(q.qweight.device)
     p.post_init(tiled=False)
     return p
 
@@ -59,6 +60,7 @@ def main():
     ap.add_argument("--shapes", default="4096x4096,11008x4096,4096x11008")
     ap.add_argument("--no-multi", action="store_true")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--act", action="store_true", help="act-order (desc_act=True) layers")
     ap.add_argument("--bits", type=int, default=4)
     ap.add_argument("--gs", type=int, default=128)
     args = ap.parse_args()
@@ -67,12 +69,12 @@ def main():
     M = args.m
     cfgs = CONFIGS if not args.quick else [(16, 2, False), (8, 4, False), (4, 4, False)]
     bits, gs = args.bits, args.gs
-    if bits != 4:
+    if bits != 4 or args.act:
         cfgs = [c for c in cfgs if c[1] in (2, 4)]
     for K, N in [tuple(map(int, sh.split('x'))) for sh in args.shapes.split(',')]:
         per = K * N * bits // 8
         nl = max(4, min(64, (400 << 20) // per))
-        layers = [make_layer(K, N, dev, dtype=dt, seed=i, bits=bits, gs=gs) for i in range(nl)]
+        layers = [make_layer(K, N, dev, dtype=dt, seed=i, bits=bits, gs=gs, act_order=args.act) for i in range(nl)]
         twins = [plain_twin(q) for q in layers]
         x = (torch.rand(M, K, device=dev) - 0.5).to(dt)
         ab = algorithmic_bytes(K, N, M, bits=bits, gs=gs)
@@ -98,7 +100,7 @@ def main():
         torch.cuda.empty_cache()
     for name, K, Ns in () if args.no_multi else (("qkv", 4096, (4096, 4096, 4096)), ("gate_up", 4096, (11008, 11008))):
         ng = max(3, (400 << 20) // (K * sum(Ns) * bits // 8))
-        groups = [[make_layer(K, n, dev, dtype=dt, seed=100 * gi + i, bits=bits, gs=gs) for i, n in enumerate(Ns)] for gi in range(ng)]
+        groups = [[make_layer(K, n, dev, dtype=dt, seed=100 * gi + i, bits=bits, gs=gs, act_order=args.act, order_seed=(7000 + gi) if args.act else None) for i, n in enumerate(Ns)] for gi in range(ng)]
         tgroups = [[plain_twin(q) for q in grp] for grp in groups]
         x = (torch.rand(M, K, device=dev) - 0.5).to(dt)
         ab = sum(algorithmic_bytes(K, n, M, bits=bits, gs=gs) for n in Ns)
