@@ -875,7 +875,7 @@ int gptq_forward_scatter(const gptq_layer_t* L, const void* x, int M, const gptq
     if ((rc = check_peer_group(pg, M, L->dtype))) return rc;
     if (L->N != pg->N / pg->world) return fail(GPTQ_ERR_SHAPE, "the layer's out_features (%d) must be the rank's shard N / world = %d", L->N, pg->N / pg->world);
     const gptq_layer_t* one[1] = {L};
-    if (L->epilogue != GPTQ_EPI_NONE || !want_tiled(one, 1, M, nullptr))
+    if (L->epilogue != GPTQ_EPI_NONE || L->g_idx || !want_tiled(one, 1, M, nullptr) || (plan_tiled(one, 1, M, nullptr).u != 2 && plan_tiled(one, 1, M, nullptr).u != 4))
         return fail(GPTQ_ERR_UNSUPPORTED, "gptq_forward_scatter: the fused scatter is the epilogue of the decode-copy kernel (M <= 4, a plain 3/4/8-bit fp16/bf16 "
                                           "layer that carries qweight_tiled / qconst_tiled); use gptq_forward + gptq_peer_scatter for this call");
     const WsView wv = split_ws(ws, ws_bytes);

@@ -32,6 +32,8 @@ namespace gptq {
 
 hipError_t launch_tiled_act(const TiledPlan& pl, const TiledParams& p, int dtype, hipStream_t st);      // gemv_tiled_act.hip
 hipError_t init_gemv_tiled_act_device();
+hipError_t launch_tiled_peer(const TiledPlan& pl, const TiledParams& p, int dtype, hipStream_t st);     // gemv_tiled_peer.hip
+hipError_t init_gemv_tiled_peer_device();
 
 // ---- plan + launch ---------------------------------------------------------------------------------------------------------------------
 static int tiled_kpl(int bits) { return bits == 8 ? 16 : 32; }          // k per lane and chunk
@@ -167,14 +169,19 @@ hipError_t launch_tiled(const gptq_layer_t* const* Ls, const TiledPlan& pl, cons
     p.xstride = pl.xstride;
     p.waves = pl.waves;
     p.xraw_off = pl.xraw_off;
+    if (pg) {                                                                     // plain layers, 2 or 4 chunks per wave in flight (the compiled forms)
+        if (A.g_idx || (pl.u != 2 && pl.u != 4)) return hipErrorInvalidValue;
+        return launch_tiled_peer(pl, p, A.dtype, st);                             // gemv_tiled_peer.hip
+    }
     if (A.g_idx) return launch_tiled_act(pl, p, A.dtype, st);                     // gemv_tiled_act.hip
-    return A.dtype == GPTQ_BF16 ? launch_tiled_bits<bf16, false>(pl, p, st) : launch_tiled_bits<f16, false>(pl, p, st);
+    return A.dtype == GPTQ_BF16 ? launch_tiled_bits<bf16, 0>(pl, p, st) : launch_tiled_bits<f16, 0>(pl, p, st);
 }
 
 hipError_t init_gemv_tiled_device() {
-    hipError_t e = grant_tiled_lds<false>();
+    hipError_t e = grant_tiled_lds<0>();
     hipError_t e2 = init_gemv_tiled_act_device();
-    return e != hipSuccess ? e : e2;
+    hipError_t e3 = init_gemv_tiled_peer_device();
+    return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : e3);
 }
 
 }  // namespace gptq

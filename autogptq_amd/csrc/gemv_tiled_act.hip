@@ -5,8 +5,8 @@
 namespace gptq {
 
 hipError_t launch_tiled_act(const TiledPlan& pl, const TiledParams& p, int dtype, hipStream_t st) {
-    return dtype == GPTQ_BF16 ? launch_tiled_bits<bf16, true>(pl, p, st) : launch_tiled_bits<f16, true>(pl, p, st);
+    return dtype == GPTQ_BF16 ? launch_tiled_bits<bf16, 1>(pl, p, st) : launch_tiled_bits<f16, 1>(pl, p, st);
 }
-hipError_t init_gemv_tiled_act_device() { return grant_tiled_lds<true>(); }
+hipError_t init_gemv_tiled_act_device() { return grant_tiled_lds<1>(); }
 
 }  // namespace gptq

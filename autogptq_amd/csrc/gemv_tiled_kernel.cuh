@@ -52,11 +52,14 @@ template <> struct TiledFmt<3> { static constexpr int WPL = 3, KPL = 32, REC = 4
 
 template <int N_> struct WordsOf { typedef unsigned type __attribute__((ext_vector_type(N_))); };
 
-// ACT: an act-order layer -- the decode copy holds the re-sequenced rows (position i = original k perm[i], groups in sequence); the workgroup DMAs the raw
+// XM = 1 (ACT): an act-order layer -- the decode copy holds the re-sequenced rows (position i = original k perm[i], groups in sequence); the workgroup DMAs the raw
 // x rows (whole K) into the LDS and gathers its slice through perm LDS -> LDS (one more barrier; + M (2 K + 16) bytes of LDS); the rest is the plain kernel.
-template <int BITS, int MT, int U, typename T, int MAXW, bool ACT = false>
+// (XM = 2 was a GATED form -- the down projection of an MLP forming silu(g) * u while staging its input: correct, and no faster than the elementwise launch it
+// removed (20.6 against 20.0 us per Llama-7B MLP: every workgroup repeats the activation); not kept.)
+template <int BITS, int MT, int U, typename T, int MAXW, int XM = 0>
 __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kernel(TiledParams p) {
     constexpr bool BF = std::is_same_v<T, bf16>;
+    constexpr bool ACT = XM == 1, PEER = XM == 3;          // 3: plain staging + the tensor-parallel epilogue (gemv_tiled_peer.hip)
     using F = TiledFmt<BITS>;
     constexpr int WPL = F::WPL, KPL = F::KPL, CKE = 4 * KPL, CHB = 64 * WPL * 4, REC = F::REC, NX = KPL / 8;      // k per chunk, bytes per chunk, x pieces per lane and chunk
     constexpr int LKPL = KPL == 32 ? 5 : 4;
@@ -99,14 +102,14 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
     {
         const unsigned xs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)xs, cs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cs;
         const int pieces = (kend - kbeg) >> 3;                                    // 16-byte pieces per x row
-        if constexpr (!ACT) {
+        if constexpr (XM == 0 || XM == 3) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const char* xr = xg + ((size_t)min(m, Mrows - 1) * K + kbeg) * 2;
                 for (int pc0 = wave * 64; pc0 < pieces; pc0 += W * 64)            // wave-uniform trip count
                     if (pc0 + lane < pieces) lds_dma16(xr + (size_t)(pc0 + lane) * 16, xs_lds + m * xstride + pc0 * 16);      // default cache policy: every workgroup reads x
             }
-        } else {
+        } else if constexpr (ACT) {
             // act-order: the RAW rows, whole K (a slice's positions map to any original k), by the same DMA; the gather through perm is LDS -> LDS
             const int rpieces = K >> 3;
             const unsigned xr_lds = xs_lds + (unsigned)p.xraw_off;
@@ -317,10 +320,10 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
         for (int m = 0; m < MT; ++m) red[wave * ES + m * 16 + lane] = acc[m];
     }
     __syncthreads();
-    const int pworld = p.peer.world;
-    T* const stage = pworld > 0 ? (T*)xs : nullptr;                                // the staged x is dead behind the barrier above
+    T* const stage = PEER ? (T*)xs : nullptr;                                      // the staged x is dead behind the barrier above
     stream_finish<16, MT, T, TiledParams, TiledSeg>(p, sg, strip, sidx, ks, N, red, stage);
-    if (pworld > 0 && ks == 0) {                                                  // uniform: the strip's owner
+    if constexpr (PEER) if (ks == 0) {                                            // uniform: the strip's owner
+        const int pworld = p.peer.world;
         __syncthreads();
         const unsigned e = __hip_atomic_load(p.peer.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;      // this gather's epoch (peer.hip)
         if (tid < pworld * MT * 2) {                                              // (peer, row, half of the strip's 32 bytes)
@@ -339,46 +342,46 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
     }
 }
 
-// Two compilations per (BITS, MT, U, T, ACT): workgroups of up to 16 waves (<= 128 VGPRs) and of up to 8 waves.
-template <int BITS, int MT, int U, typename T, bool ACT>
+// Two compilations per (BITS, MT, U, T, XM): workgroups of up to 16 waves (<= 128 VGPRs) and of up to 8 waves.
+template <int BITS, int MT, int U, typename T, int XM>
 static hipError_t launch_tiled_one(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
     if (pl.waves > 8)
-        hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 16, ACT>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+        hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 16, XM>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
     else
-        hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 8, ACT>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+        hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 8, XM>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
     return hipGetLastError();
 }
-template <int BITS, int MT, typename T, bool ACT>
+template <int BITS, int MT, typename T, int XM>
 static hipError_t launch_tiled_u(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
     switch (pl.u) {
-        case 1: if constexpr (BITS == 4 && !ACT) return launch_tiled_one<BITS, MT, 1, T, ACT>(pl, p, st); else return hipErrorInvalidValue;
-        case 2: return launch_tiled_one<BITS, MT, 2, T, ACT>(pl, p, st);
-        case 4: return launch_tiled_one<BITS, MT, 4, T, ACT>(pl, p, st);
-        case 8: if constexpr (BITS == 4 && !ACT) return launch_tiled_one<BITS, MT, 8, T, ACT>(pl, p, st); else return hipErrorInvalidValue;
+        case 1: if constexpr (BITS == 4 && XM == 0) return launch_tiled_one<BITS, MT, 1, T, XM>(pl, p, st); else return hipErrorInvalidValue;
+        case 2: return launch_tiled_one<BITS, MT, 2, T, XM>(pl, p, st);
+        case 4: return launch_tiled_one<BITS, MT, 4, T, XM>(pl, p, st);
+        case 8: if constexpr (BITS == 4 && XM == 0) return launch_tiled_one<BITS, MT, 8, T, XM>(pl, p, st); else return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }
-template <int BITS, typename T, bool ACT>
+template <int BITS, typename T, int XM>
 static hipError_t launch_tiled_mt(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
     switch (pl.mt) {
-        case 1: return launch_tiled_u<BITS, 1, T, ACT>(pl, p, st);
-        case 2: return launch_tiled_u<BITS, 2, T, ACT>(pl, p, st);
-        case 4: return launch_tiled_u<BITS, 4, T, ACT>(pl, p, st);
+        case 1: return launch_tiled_u<BITS, 1, T, XM>(pl, p, st);
+        case 2: return launch_tiled_u<BITS, 2, T, XM>(pl, p, st);
+        case 4: return launch_tiled_u<BITS, 4, T, XM>(pl, p, st);
         default: return hipErrorInvalidValue;
     }
 }
-template <typename T, bool ACT>
+template <typename T, int XM>
 static hipError_t launch_tiled_bits(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
     switch (pl.bits) {
-        case 4: return launch_tiled_mt<4, T, ACT>(pl, p, st);
-        case 8: return launch_tiled_mt<8, T, ACT>(pl, p, st);
-        case 3: return launch_tiled_mt<3, T, ACT>(pl, p, st);
+        case 4: return launch_tiled_mt<4, T, XM>(pl, p, st);
+        case 8: return launch_tiled_mt<8, T, XM>(pl, p, st);
+        case 3: return launch_tiled_mt<3, T, XM>(pl, p, st);
         default: return hipErrorInvalidValue;
     }
 }
 
-// grants > 64 KiB of dynamic LDS to every instantiation of one ACT value (long K at 4 rows of x: the staged activations can pass the default)
-template <bool ACT>
+// grants > 64 KiB of dynamic LDS to every instantiation of one x mode (long K at 4 rows of x: the staged activations can pass the default)
+template <int XM>
 static hipError_t grant_tiled_lds() {
     hipError_t e = hipSuccess;
     auto grant = [&](auto kern) { hipError_t r = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e == hipSuccess) e = r; };
@@ -386,12 +389,12 @@ static hipError_t grant_tiled_lds() {
         constexpr int MT = decltype(mt)::value;
         auto grant_u = [&](auto bu, auto uu) {
             constexpr int B = decltype(bu)::value, U = decltype(uu)::value;
-            grant(gemv_tiled_kernel<B, MT, U, f16, 16, ACT>); grant(gemv_tiled_kernel<B, MT, U, f16, 8, ACT>);
-            grant(gemv_tiled_kernel<B, MT, U, bf16, 16, ACT>); grant(gemv_tiled_kernel<B, MT, U, bf16, 8, ACT>);
+            grant(gemv_tiled_kernel<B, MT, U, f16, 16, XM>); grant(gemv_tiled_kernel<B, MT, U, f16, 8, XM>);
+            grant(gemv_tiled_kernel<B, MT, U, bf16, 16, XM>); grant(gemv_tiled_kernel<B, MT, U, bf16, 8, XM>);
         };
         using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
         using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
-        if constexpr (!ACT) { grant_u(I4{}, I1{}); grant_u(I4{}, I8{}); }          // 1 and 8 chunks in flight: sweep geometries of the plain 4-bit form only
+        if constexpr (XM == 0) { grant_u(I4{}, I1{}); grant_u(I4{}, I8{}); }          // 1 and 8 chunks in flight: sweep geometries of the plain 4-bit form only
         grant_u(I4{}, I2{}); grant_u(I4{}, I4{});
         grant_u(I8{}, I2{}); grant_u(I8{}, I4{}); grant_u(I3{}, I2{}); grant_u(I3{}, I4{});
     };
