@@ -86,6 +86,8 @@ def _is_sequential_g_idx(g_idx: torch.Tensor, group_size: int) -> bool:
 
 class QuantLinear(nn.Module):
     QUANT_TYPE = "mi355x"
+    EXCHANGE_CHECK_EVERY = 4096   # workspace-taking calls between two reads of the exchanges' sticky error word (0 = never; exchange_error() reads it on demand)
+    _exchange_calls = 0
     TILED_DECODE = True       # post_init derives the strip-major side copy of qweight for the decode kernels (a second copy of the packed weights)
 
     def __init__(
@@ -281,6 +283,15 @@ class QuantLinear(nn.Module):
         if need == 0:
             return None, 0
         buf = reserve_workspace(device, need)
+        # Calls that take a workspace are the ones with an in-launch exchange (K slices, balanced tail): every EXCHANGE_CHECK_EVERY of them the sticky
+        # error word of the workspace is read (a device -> host read: a sync point, hence periodic; never inside a stream capture).  A bounded wait that
+        # gave up has produced a wrong result somewhere since the last check -- it must not pass silently.
+        n = QuantLinear._exchange_calls = QuantLinear._exchange_calls + 1
+        every = QuantLinear.EXCHANGE_CHECK_EVERY
+        if every and n % every == 0 and not torch.cuda.is_current_stream_capturing():
+            if exchange_error(device):
+                raise RuntimeError("gptq_mi355x: a bounded wait of an in-launch exchange gave up (another client kept part of the GPU busy?): at least one result "
+                                   "since the last check is wrong; see exchange_error()")
         return buf.data_ptr(), buf.numel()
 
     def forward(self, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = None):

@@ -332,3 +332,29 @@ def test_tiled_multi_layer_launch_act_order():
         ym = forward_multi([qp, layers[0]], x, None)
     _assert_all(ym[0], x, Wp, None, torch.float16, "mixed group, plain layer")
     _assert_all(ym[1], x, made[0][2], None, torch.float16, "mixed group, act-order layer")
+
+
+def test_sticky_exchange_error_is_read_periodically():
+    """A bounded in-launch wait that gives up raises the workspace's sticky error word (the kernels never hang); QuantLinear reads it every
+    EXCHANGE_CHECK_EVERY workspace-taking calls instead of leaving it to the caller (round-3 advice)."""
+    from autogptq_amd import qlinear_mi355x as qm
+    L, q, W = _layer(8192, 256, 128, torch.float16, 3)                    # 16 strips: K slices, i.e. a workspace and an exchange
+    assert _lib.describe_plan(q._layer, 1)["ksplit"] >= 2
+    x, _ = _x(1, 8192, torch.float16, 1)
+    saved = QuantLinear.EXCHANGE_CHECK_EVERY
+    QuantLinear.EXCHANGE_CHECK_EVERY = 1
+    try:
+        with torch.no_grad():
+            y = q(x)                                                      # checked: clean
+        assert not qm.exchange_error(DEV)
+        ws = qm._WORKSPACE[(torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))][0]
+        tail = ws[_lib.WS_HEADER_BYTES - 64:_lib.WS_HEADER_BYTES].view(torch.int32)
+        tail[2] = 1                                                       # what a wait that gave up leaves behind
+        with pytest.raises(RuntimeError, match="bounded wait"):
+            with torch.no_grad():
+                q(x)
+        tail[2] = 0
+        with torch.no_grad():
+            assert torch.equal(q(x), y)
+    finally:
+        QuantLinear.EXCHANGE_CHECK_EVERY = saved
