@@ -499,19 +499,33 @@ def forward_multi(layers, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = No
     """``[l(x) for l in layers]`` for mi355x QuantLinears that read the same input, through gptq_forward_multi: ONE launch for
     q/k/v or gate/up of a decode step (M <= 4, plain 4-bit layers), the layers one by one otherwise.  The checkpoint tensors
     are used where they are (the reference's fused modules concatenate copies of them, fused_llama_attn.py:171-203)."""
+    # Everything that depends only on the GROUP is checked and resolved once per group (keyed by the layers' C structs) and kept in _MULTI: a decode
+    # launch here takes 4.5 - 12 us, and the reference's callers are eager (generate() under inference_mode) -- per call only what depends on x remains.
     a = layers[0]
-    for l in layers:
-        if l._layer is None:
-            l.post_init()
-    dev = a._dev
+    n = len(layers)
+    key = tuple([id(l._layer) for l in layers]) if a._layer is not None else None
+    ent = _MULTI.get(key) if key is not None else None
+    if ent is None:
+        for l in layers:
+            if l._layer is None:
+                l.post_init()
+        if any(l.infeatures != a.infeatures for l in layers):
+            raise RuntimeError("forward_multi: every layer must take the input's feature count")
+        if any(l._w_dtype != a._w_dtype for l in layers):
+            raise RuntimeError("forward_multi: the layers must share the weight dtype")
+        if any(l._dev != a._dev for l in layers):
+            raise RuntimeError("forward_multi: the layers must be on one device")
+        share_act_order(layers)
+        key = tuple([id(l._layer) for l in layers])
+        arr = (ctypes.POINTER(_lib.GptqLayer) * n)(*[ctypes.pointer(l._layer) for l in layers])
+        optr_arr = (ctypes.c_void_p * n)()
+        ent = _MULTI[key] = (arr, {}, [l._layer for l in layers], optr_arr, ctypes.addressof(arr), ctypes.addressof(optr_arr),
+                             a._dev, a.infeatures, a._w_dtype, tuple(l._n_out for l in layers), a._dev_index, sum(l._n_out for l in layers))
+    arr, need_by_m, _, optrs, arr_addr, optr_addr, dev, K, w_dtype, n_outs, idx = ent[:11]
     if x.device != dev:
         raise RuntimeError(f"mi355x forward_multi: input is on {x.device}, the layers on {dev}")
-    K = a.infeatures
-    if x.shape[-1] != K or any(l.infeatures != K for l in layers):
+    if x.shape[-1] != K:
         raise RuntimeError("forward_multi: every layer must take the input's feature count")
-    w_dtype = a._w_dtype
-    if any(l._w_dtype != w_dtype for l in layers):
-        raise RuntimeError("forward_multi: the layers must share the weight dtype")
     x_dtype = x.dtype
     x2 = x.to(w_dtype) if x_dtype != w_dtype else x
     if x2.dim() != 2:
@@ -519,39 +533,31 @@ def forward_multi(layers, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = No
     if not x2.is_contiguous():
         x2 = x2.contiguous()
     M = x2.shape[0]
-    outs = [torch.empty((M, l._n_out), dtype=w_dtype, device=dev) for l in layers]
+    if M == 1:      # one decode row: ONE allocation, the outputs are its column slices (contiguous for a single row) -- torch.empty is 1.9 us of a ~10 us call
+        outs = list(torch.empty((1, ent[11]), dtype=w_dtype, device=dev).split(n_outs, dim=1))
+    else:
+        outs = [torch.empty((M, no), dtype=w_dtype, device=dev) for no in n_outs]
     if M:
-        n = len(layers)
-        key = tuple(id(l._layer) for l in layers)
-        ent = _MULTI.get(key)
-        if ent is None:
-            share_act_order(layers)
-            arr = (ctypes.POINTER(_lib.GptqLayer) * n)(*[ctypes.pointer(l._layer) for l in layers])
-            optr_arr = (ctypes.c_void_p * n)()
-            ent = _MULTI[key] = (arr, {}, [l._layer for l in layers], optr_arr, ctypes.addressof(arr), ctypes.addressof(optr_arr))
-        arr, need_by_m = ent[0], ent[1]
-        tref = ctypes.byref(tuning) if tuning is not None else None
         need = need_by_m.get(M) if tuning is None else None
         if need is None:
+            tref = ctypes.byref(tuning) if tuning is not None else None
             need = int(_lib.load().gptq_workspace_bytes_multi_ex(arr, n, M, tref))
             if tuning is None:
                 need_by_m[M] = need
-        ws_ptr, ws_bytes = None, 0
+        ws_ptr, ws_bytes = 0, 0
         if need:
             buf = reserve_workspace(dev, need)
             ws_ptr, ws_bytes = buf.data_ptr(), buf.numel()
-        optrs = ent[3]
         for i in range(n):
             optrs[i] = outs[i].data_ptr()
-        idx = a._dev_index
         fast = _lib.fast
-
         def launch():
             if fast is not None:
-                return fast.forward_multi(ent[4], n, x2.data_ptr(), ent[5], M, ws_ptr or 0, ws_bytes, _raw_stream(idx),
+                return fast.forward_multi(arr_addr, n, x2.data_ptr(), optr_addr, M, ws_ptr, ws_bytes, _raw_stream(idx),
                                           ctypes.addressof(tuning) if tuning is not None else 0)
-            return _lib.load().gptq_forward_multi_ex(arr, n, x2.data_ptr(), optrs, M, ws_ptr, ws_bytes, _raw_stream(idx), tref)
-        if idx != torch.cuda.current_device():
+            return _lib.load().gptq_forward_multi_ex(arr, n, x2.data_ptr(), optrs, M, ws_ptr or None, ws_bytes, _raw_stream(idx),
+                                                     ctypes.byref(tuning) if tuning is not None else None)
+        if idx != torch.cuda.current_device():              # rare: the layers' device is not the current one
             with torch.cuda.device(idx):
                 rc = launch()
         else:
