@@ -125,7 +125,7 @@ bool want_stream(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
     return stream_preferred(*L, M);
 }
 
-// Decode from the strip-major side copy (gemv_tiled.hip): plain 4-bit fp16 / bf16 layers that carry qweight_tiled, M <= 4.  tuning.path = 8 forces it
+// Decode from the strip-major side copy (gemv_tiled.hip): 3- / 4- / 8-bit fp16 / bf16 layers (plain or act-order) that carry qweight_tiled, M <= 4.  tuning.path = 8 forces it
 // ("does not fit" is then an error), any other explicit path keeps the checkpoint-layout kernels (A/B runs).
 bool want_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* t) {
     if (M > 4 || n < 1 || n > 4) return false;
@@ -486,7 +486,7 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
     // 11.1 for the batched-decode kernel, gate|up 12.9 against 18.9)
     if (want_tiled(layers, n_layers, M, tune) && (multi_preferred(layers, n_layers, M) || (tune && tune->path == 8)))
         return tiled_call(layers, n_layers, x, outs, M, wv, stream, tune);
-    if (tune && tune->path == 8) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: these layers do not fit one decode-copy launch (1..4 plain 4-bit layers with qweight_tiled, M <= 4)");
+    if (tune && tune->path == 8) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: these layers do not fit one decode-copy launch (1..4 layers of one packing with qweight_tiled, all plain or all act-order, M <= 4)");
     if (want_mid_multi(layers, n_layers, M, tune)) {
         const MidPlan mp = plan_mid(layers, n_layers, M, tune);
         if (mp.partial_bytes > 0 && wv.body_bytes < mp.partial_bytes)

@@ -1,4 +1,6 @@
-// gemv_tiled.hip -- decode (M <= 4) from the load-time DECODE COPY of a 4-bit layer (round 4).
+// gemv_tiled.hip -- decode (M <= 4) from the load-time DECODE COPY of a 3-, 4- or 8-bit layer, plain or act-order (round 4).  The kernel itself:
+// gemv_tiled_kernel.cuh (instantiated here for plain layers, in gemv_tiled_act.hip for act-order ones, in gemv_tiled_peer.hip with the tensor-parallel
+// epilogue); this file: the planner and the launch.  The 4-bit layout as the example (the other packings: TiledFmt, gptq_mi355x.h):
 //
 // What the reference does at load time in every fast backend -- exllamav2 shuffle_kernel (autogptq_extension/exllamav2/cuda/q_matrix.cu:19-42,
 // called from :149), exllama make_sequential (exllama/cuda_func/q4_matrix.cu:105-169), Marlin gptq_repack + its scale permutation

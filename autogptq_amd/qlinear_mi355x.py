@@ -497,7 +497,8 @@ def share_act_order(layers) -> bool:
 
 def forward_multi(layers, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = None):
     """``[l(x) for l in layers]`` for mi355x QuantLinears that read the same input, through gptq_forward_multi: ONE launch for
-    q/k/v or gate/up of a decode step (M <= 4, plain 4-bit layers), the layers one by one otherwise.  The checkpoint tensors
+    q/k/v or gate/up of a decode step (M <= 4; 3- / 4- / 8-bit layers that carry their decode copy, plain or act-order), batched-decode and prefill
+    rows through the multi-layer kernels or layer by layer (act-order layers of one g_idx then share ONE permuted x).  The checkpoint tensors
     are used where they are (the reference's fused modules concatenate copies of them, fused_llama_attn.py:171-203)."""
     # Everything that depends only on the GROUP is checked and resolved once per group (keyed by the layers' C structs) and kept in _MULTI: a decode
     # launch here takes 4.5 - 12 us, and the reference's callers are eager (generate() under inference_mode) -- per call only what depends on x remains.

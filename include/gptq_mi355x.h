@@ -183,10 +183,11 @@ int gptq_forward(const gptq_layer_t *layer, const void *x, void *out, int M,
 /* n_layers independent layers that read the SAME x[M, K] -- q/k/v of an attention block, gate/up of a gated MLP -- in one
  * call: outs[i] is [M, layers[i]->N].  The reference fuses such layers by concatenating their packed tensors along
  * out_features into one QuantLinear (fused_llama_attn.py:171-203, fused_llama_mlp.py:157-242); this entry point gives the
- * same single launch (M <= 64, plain 4-bit fp16/bf16 layers, <= 4 of them: one streamed kernel over the column strips of
- * all layers -- the matrix-core GEMV up to 4 rows, the batched-decode kernel from 5 to 64 rows where the planner prefers it)
- * without touching or copying the checkpoint tensors, and runs the layers one after the other in every other case --
- * results are those of n gptq_forward calls either way (same values within fp rounding: the K split may differ).
+ * same single launch (<= 4 layers: up to 4 rows the decode-copy kernel over the column strips of all layers -- 3- / 4- / 8-bit fp16 / bf16 layers that
+ * carry qweight_tiled, all plain or all act-order; 5 to 128 rows the batched-decode / 17..128-row kernels on plain 4-bit layers where the planner
+ * prefers them) without touching or copying the checkpoint tensors, and runs the layers one after the other in every other case -- except that
+ * act-order layers which share ONE `perm` pointer (q / k / v, gate / up of a GPTQ checkpoint: the order comes from their common input) read ONE
+ * permuted x per call.  Results are those of n gptq_forward calls either way (same values within fp rounding: the K split may differ).
  * Workspace: gptq_workspace_bytes_multi. */
 size_t gptq_workspace_bytes_multi(const gptq_layer_t *const *layers, int n_layers, int M);
 int gptq_forward_multi(const gptq_layer_t *const *layers, int n_layers, const void *x, void *const *outs, int M,
