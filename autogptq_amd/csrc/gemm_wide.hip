@@ -173,11 +173,20 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
     const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
 
     auto dma_a = [&](int kt, int buf) {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            char* dst = smem + (size_t)buf * (BM * STRIDE) + (size_t)(i * 256 + wave * 64) * 16;
-            lds_dma16(a_base + (size_t)kt * (BK * 2) + a_off[i], lds_addr_of(dst));
-        }
+        // the four DMAs of a thread as ONE asm block: m0 saved / restored once, the step's base in an SGPR pair, the lane's four offsets fixed in VGPRs (no
+        // per-step address VALU; -1 us of 119 at M = 4096 on 4096^2 against four lds_dma16 calls, tools/widelab2)
+        const char* sb = a_base + (size_t)kt * (BK * 2);
+        const unsigned l0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem + (size_t)buf * (BM * STRIDE) + (size_t)(wave * 64) * 16));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %9\n\t"
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %9\n\t"
+                     "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %9\n\t"
+                     "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %9\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(a_off[0]), "v"(a_off[1]), "v"(a_off[2]), "v"(a_off[3]), "s"(l0), "s"(l0 + 4096u), "s"(l0 + 8192u), "s"(l0 + 12288u), "s"(sb)
+                     : "memory");
     };
     auto load_a = [&](int kt, u32x4 (&r)[NCH]) {
 #pragma unroll
@@ -266,12 +275,12 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
 #pragma unroll
             for (int ks = 1; ks < KS; ++ks) asm volatile("" ::"v"(b_use[ks][0]), "v"(b_use[ks][1]), "v"(b_use[ks][2]), "v"(b_use[ks][3]));
             __builtin_amdgcn_sched_barrier(0);
-            dma_a(ktn, BUF ^ 1);
         } else {
             load_a(ktn, a_next);
         }
-        load_b(ktn, b_fill);
-        if constexpr (NEWG) load_c(ktn, c_fill);
+        // the next step's weight / constant loads and its x DMA are issued BETWEEN this step's MFMA groups (below), not here: in front of the groups they
+        // were ~50 instructions the matrix pipe waited through (-2 us of 119, tools/widelab2: the loads' cost is their issue, not their latency --
+        // replacing every step's addresses by step 0's, cache-resident, changed 1 us; removing the loads 6)
         const char* abase = smem + BUF * (BM * STRIDE) + a_lane_off;
         u32x4 a[2][MT], bq[2][NT];
 #pragma unroll
@@ -303,17 +312,43 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_kernel(WideParams p) {
                 if constexpr (!GLDS) store_a(BUF ^ 1, a_next);
 #endif
             }
+            if (ks == 0) {                                     // next step's weights + constants: under MFMA group 0
+#if defined(GPTQ_WIDE_ABL) && (GPTQ_WIDE_ABL & 32)
+#pragma unroll
+                for (int i = 0; i < KS; ++i) b_fill[i] = b_use[i] ^ u32x4{1u, 2u, 3u, 4u};      // lab: no weight loads after the first step
+#elif defined(GPTQ_WIDE_ABL) && (GPTQ_WIDE_ABL & 64)
+                load_b(0, b_fill);                             // lab: always step 0's (cache-resident) words: issue cost without the latency
+#else
+                load_b(ktn, b_fill);
+#endif
+                if constexpr (NEWG) load_c(ktn, c_fill);
+            }
+            if constexpr (GLDS) if (ks == 1) {                 // next step's x tile: under group 1
+#if defined(GPTQ_WIDE_ABL) && (GPTQ_WIDE_ABL & 128)
+                dma_a(0, BUF ^ 1);
+#elif !(defined(GPTQ_WIDE_ABL) && (GPTQ_WIDE_ABL & 16))
+                dma_a(ktn, BUF ^ 1);
+#endif
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Mma<T>::run(a[ks & 1][mt], bq[ks & 1][nt], acc[mt][nt]);
-            if (ks + 1 < KS) interleave(std::integral_constant<int, 4>{});
+            if (ks == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    if ((i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);
+                    if ((i & 1) == 1 && i < 12) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 6 VMEM reads: the 4 weight + 2 constant loads
+                }
+            } else if (ks + 1 < KS) interleave(std::integral_constant<int, 4>{});
             else interleave(std::integral_constant<int, 6>{});
             __builtin_amdgcn_sched_barrier(0);
         }
         dq_cur = dq_nx;
-        // DMA-staged x: the next tile must have landed before anybody passes the barrier; the KS weight loads + 2 constant loads issued behind it may fly on
-        if constexpr (GLDS) wait_vmcnt<KS + (NEWG ? 2 : 0)>();
+        // DMA-staged x: the next tile must have landed before anybody passes the barrier
+        if constexpr (GLDS) wait_vmcnt<0>();                   // the DMAs are the step's newest VMEM operations
 #if !(defined(GPTQ_WIDE_ABL) && (GPTQ_WIDE_ABL & 4))
         __syncthreads();
 #endif
