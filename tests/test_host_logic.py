@@ -711,6 +711,61 @@ def test_planner_fuzz_every_configuration_plans_or_refuses_cleanly():
 
 
 
+def test_planner_fuzz_layers_with_a_decode_copy():
+    """The same over layers that carry the decode copy (round 4; pointers never dereferenced by the planner): gptq_prepack_decode_bytes agrees with the
+    layouts' sizes or refuses; up to 4 rows the plan is the decode-copy kernel ("strips") whenever a copy can exist and its geometry fits -- with legal
+    geometry (1..16 waves, 1 / 2 / 4 / 8 chunks per wave, <= 8 K slices, workspace = header + (ksplit - 1) M N 8 bytes of granules) -- act-order layers
+    only with their re-sequenced rows; M = 4096 on wide layers takes the wide tiles from the copy ("wide_copy") only for plain layers."""
+    import random
+    lib = _lib.load()
+    rnd = random.Random(4)
+    Ks = [32, 64, 96, 128, 160, 512, 1024, 2048, 4096, 4160, 8192, 11008, 28672]
+    Ns = [16, 32, 64, 96, 256, 1024, 3584, 4096, 11008, 12288, 22016, 28672]
+    seen = set()
+    for _ in range(4000):
+        K, N, bits = rnd.choice(Ks), rnd.choice(Ns), rnd.choice((2, 3, 4, 8))
+        gs = rnd.choice((16, 32, 64, 96, 128, 256, K))
+        L = _layer(K=K, N=N, bits=bits, group_size=gs, dtype=rnd.choice((0, 1, 2)), zero_mode=rnd.choice((0, 1)), epilogue=rnd.choice((0, 0, 0, 1)))
+        act = rnd.choice((0, 0, 1, 2))
+        if act:
+            L.g_idx = 0x1000
+            if act == 2:
+                L.qweight_seq = L.perm = 0x1000
+        tb, cb = ctypes.c_size_t(7), ctypes.c_size_t(7)
+        rc = lib.gptq_prepack_decode_bytes(ctypes.byref(L), ctypes.byref(tb), ctypes.byref(cb))
+        kpl = 16 if bits == 8 else 32
+        can = (bits in (3, 4, 8) and L.dtype in (0, 1) and L.epilogue == 0 and K % 32 == 0 and N % 32 == 0 and gs % kpl == 0 and act != 1
+               and (gs >= K or ((gs // kpl) & (gs // kpl - 1)) == 0))
+        if not can:
+            assert rc != 0 and tb.value == 0 and cb.value == 0, (rc, K, N, bits, gs, act)
+            continue
+        assert rc == 0, (lib.gptq_last_error(), K, N, bits, gs, act)
+        cke = 4 * kpl
+        assert tb.value == -(-K // cke) * (768 if bits == 3 else 1024) * (N // 16)
+        assert cb.value == -(-K // gs) * (64 if bits == 8 else 48) * (N // 16)
+        L.qweight_tiled = L.qconst_tiled = 0x2000
+        L.tiled_cols = 16
+        for M in (1, 2, 3, 4, 5, 4096):
+            buf = ctypes.create_string_buffer(512)
+            rc = lib.gptq_describe_plan(ctypes.byref(L), M, None, buf, len(buf))
+            assert rc in (0, 2, 3), (rc, K, N, bits, gs, M)
+            if rc:
+                continue
+            plan = dict(kv.split("=", 1) for kv in buf.value.decode().split())
+            seen.add(plan["kernel"])
+            need = lib.gptq_workspace_bytes(ctypes.byref(L), M)
+            if plan["kernel"] == "strips":
+                ks, waves, u = int(plan["ksplit"]), int(plan["waves"]), int(plan["u"])
+                assert M <= 4 and 1 <= ks <= 8 and 1 <= waves <= 16 and u in (1, 2, 4, 8), plan
+                assert need == (0 if ks == 1 else 65536 + (ks - 1) * M * N * 8), (plan, need)
+            if M > 4:
+                assert plan["kernel"] != "strips", plan
+            if plan["kernel"] == "wide_copy":
+                assert M >= 2048 and bits == 4 and not act and K % 128 == 0, plan
+            assert lib.gptq_workspace_bytes_max(ctypes.byref(L), M) >= need
+    assert {"strips", "wide_copy"} <= seen, seen
+
+
 def test_decode_copy_restatement_matches_the_header_definition():
     """oracle.decode_copy_weights / decode_copy_consts restate gptq_prepack_decode (include/gptq_mi355x.h, gptq_layer_t.qweight_tiled / qconst_tiled): checked
     entry by entry against the header's formula on a small layer (ragged last chunk: K = 160), that the magic-number extraction order of a stored word is
