@@ -525,7 +525,7 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
                      L->dtype == layers[0]->dtype && L->dtype != GPTQ_F32 && want_gemm(L, M, nullptr);
             if (!shared) break;
             pls[i] = plan_gemm(*L, M, nullptr);
-            shared = pls[i].supported && pls[i].use_seq && !pls[i].f32 && pls[i].xslot == pls[0].xslot && pls[i].xperm_bytes == pls[0].xperm_bytes &&
+            shared = pls[i].supported && pls[i].use_seq && !pls[i].f32 && pls[i].xslot == pls[0].xslot && pls[i].xnat == pls[0].xnat && pls[i].xperm_bytes == pls[0].xperm_bytes &&
                      pls[i].workspace_bytes <= wv.body_bytes;
         }
         if (shared) {

@@ -2021,11 +2021,15 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
         const long wt = (long)((M + 127) / 128) * ((L.N + 511) / 512);
         const long rounds = (wt + 255) / 256;
         const bool fills = wt >= 256 && (double)wt / (double)(rounds * 256) >= 0.9;
+        // layers that carry their decode copy: weights from it, raw x by LDS DMA (gemm_wide_kernel<T, true, true>); knob 46 / 47 keep the checkpoint rows (A/B).
+        // Act-order layers: the copy is made of the re-sequenced rows, so x is permuted in NATURAL order (xnat) instead of the row form's slot order -- and
+        // bf16 act-order layers, which have no slot-ordered permute, get the wide tiles this way.
+        const bool copy_ok = L.qweight_tiled != nullptr && L.tiled_cols == GPTQ_STRIP_COLS && L.N % GPTQ_STRIP_COLS == 0 && wide_knob != 46 && wide_knob != 47;
         pl.wide = wide_knob != 44 && (fills || wide_knob == 45 || wide_knob == 47) && pl.mt == 4 && pl.bk == 64 && pl.ksplit == 1 && pl.variant == 0 && tail_knob == 0 &&
-                  wide_gemm_ok(L, M, pl.use_seq, pl.xslot && pl.glds);
+                  (wide_gemm_ok(L, M, pl.use_seq, pl.xslot && pl.glds) || (copy_ok && wide_gemm_ok(L, M, false, false)));
         if (pl.wide) {
-            // plain layers that carry their decode copy: weights from it, raw x by LDS DMA (gemm_wide_kernel<T, true, true>); knob 46 keeps the checkpoint rows (A/B)
-            pl.wide_tiled = !pl.use_seq && L.qweight_tiled != nullptr && L.tiled_cols == GPTQ_STRIP_COLS && L.N % GPTQ_STRIP_COLS == 0 && wide_knob != 46 && wide_knob != 47;
+            pl.wide_tiled = copy_ok;
+            pl.xnat = pl.wide_tiled && pl.use_seq;
             pl.tail = 0; pl.tail_lg = 0;
             pl.bn = 512; pl.nbn = (L.N + 511) / 512;
             pl.workspace_bytes = pl.xperm_bytes;
@@ -2190,8 +2194,9 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
         // k-slot order for the DMA-staged tiled kernel: the LDS-staged row kernel; plain order: whichever permute kernel fits M and K
         // (a few long rows -- batched decode -- take the flat gather: 11008x4096 M = 8 act-order 16.8 -> ~14.5 us)
         if (!x_permuted) {
-            e = pl.xslot ? launch_permute_rows16(x, L.perm, M, L.K, workspace, st, true)
-                         : launch_permute_columns(x, L.perm, M, L.K, L.dtype, workspace, st);
+            e = pl.xnat ? launch_permute_rows16(x, L.perm, M, L.K, workspace, st, false)
+                : pl.xslot ? launch_permute_rows16(x, L.perm, M, L.K, workspace, st, true)
+                           : launch_permute_columns(x, L.perm, M, L.K, L.dtype, workspace, st);
             if (e != hipSuccess) return e;
         }
         p.x = workspace;

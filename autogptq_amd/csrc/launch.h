@@ -46,6 +46,7 @@ hipError_t init_gemm_mid_device();
 struct GemmPlan {
     bool supported, use_seq;
     bool wide_tiled;          // ... reading the layer's decode copy, raw x staged by LDS DMA
+    bool xnat;                // act-order + wide_tiled: x permuted in natural order (the copy is of the re-sequenced rows)
     bool wide;                // 128 x 512 tiles, 128 x 128 per wave, accumulators in AGPRs (gemm_wide.hip): large launches
     bool mid;                 // 17 .. 128 rows, 4-bit: gemm_mid_kernel (midp holds its geometry)
     MidPlan midp;

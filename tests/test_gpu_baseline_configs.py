@@ -306,8 +306,9 @@ def test_north_star_m4096_wide_tiles(K, N, act, dtype):
     from autogptq_amd import _lib
     L, q, W, W64 = _layer(4, 128, K, N, act, dtype)
     plan = _lib.describe_plan(q._layer, 4096)
-    # plain layers carry their decode copy: the wide kernel reads it and stages the raw x by LDS DMA ("wide_copy"); act-order fp16: checkpoint rows
-    assert plan["kernel"] == ("tiled" if (act and dtype == torch.bfloat16) else ("wide" if act else "wide_copy")), plan
+    # the layers carry their decode copy (act-order ones: of the re-sequenced rows): the wide kernel reads it and stages the raw -- for act-order layers the
+    # naturally permuted -- x by LDS DMA
+    assert plan["kernel"] == "wide_copy", plan
     _check(4, 128, K, N, 4096, act, dtype)
 
 
@@ -330,7 +331,7 @@ def test_wide_tiles_forced_on_ragged_shapes():
             tn.path, tn.reserved[3], tn.ksplit = 3, 6, 1
             tc.path, tc.reserved[3], tc.ksplit = 3, 45, 1          # wide tiles, from the decode copy where the layer has one (raw x by LDS DMA)
             assert _lib.describe_plan(q._layer, M, tw)["kernel"] == "wide"
-            has_copy = q._qweight_tiled is not None and K % 128 == 0 and not act      # act-order prefill reads the re-sequenced rows (slot-ordered permuted x)
+            has_copy = q._qweight_tiled is not None and K % 128 == 0
             assert _lib.describe_plan(q._layer, M, tc)["kernel"] == ("wide_copy" if has_copy else "wide")
             with torch.no_grad():
                 yw, yw2, yn = q(x, tuning=tw), q(x, tuning=tw), q(x, tuning=tn)
