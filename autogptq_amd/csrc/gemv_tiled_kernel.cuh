@@ -1,5 +1,6 @@
-// gemv_tiled_kernel.cuh -- the decode-copy kernel and its launch templates (included by gemv_tiled.hip: plain layers, and gemv_tiled_act.hip: act-order
-// layers -- two translation units only to halve the build's longest compile).  Description: gemv_tiled.hip.
+// gemv_tiled_kernel.cuh -- the decode-copy kernel and its launch templates, included by three translation units: gemv_tiled.hip (plain layers, XM = 0),
+// gemv_tiled_act.hip (act-order layers, XM = 1) and gemv_tiled_peer.hip (plain layers with the tensor-parallel epilogue, XM = 3) -- separate only for
+// build time, and so that the plain kernels carry nothing of the other forms.  Description: gemv_tiled.hip.
 #pragma once
 #include "gemv_shared.cuh"
 
@@ -35,7 +36,7 @@ struct TiledParams {
     int xraw_off;            // ACT kernels: byte offset of the raw x rows (whole K, row stride 2 K + 16) in the dynamic LDS
     unsigned max_spins;
     TiledSeg seg[4];
-    PeerEpi peer;            // world = 0: none.  Read by the owner workgroups only, behind their K loop.
+    PeerEpi peer;            // XM = 3 kernels only: read by the owner workgroups behind their K loop
 };
 
 // Per packing: what a lane of one chunk load holds.  The chunk is always 4 k-slots x 16 columns; a lane (k-slot, column) holds WPL consecutive words =
