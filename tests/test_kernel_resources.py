@@ -1,0 +1,63 @@
+"""CPU: the register budget of the hot kernels, read from the BUILT library (no GPU): the code objects inside libgptq_mi355x.so are unbundled with the
+ROCm LLVM tools and their kernel metadata (llvm-readelf --notes) checked -- the decode-copy kernels must not touch scratch (a spill in a 5-microsecond kernel is
+what the first strip-major version lost a round of sweeps to), the wide prefill kernel lives in all 512 registers of a lane and may spill a handful, never more.
+Skipped where the LLVM tools or the library are missing (the product needs neither)."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "autogptq_amd", "libgptq_mi355x.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _kernels():
+    tools = [os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not os.path.exists(SO) or not all(os.path.exists(t) for t in tools):
+        pytest.skip("built library or ROCm LLVM tools not present")
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.check_call([tools[0], f"--dump-section=.hip_fatbin={fat}", SO, os.path.join(d, "copy.so")])
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+        assert starts, "no offload bundle in .hip_fatbin"
+        for i, a in enumerate(starts):                      # one bundle per translation unit
+            part = os.path.join(d, f"b{i}.bin")
+            open(part, "wb").write(blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+            co = os.path.join(d, f"co{i}.o")
+            r = subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={part}", f"--output={co}"],
+                               capture_output=True)
+            if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
+                continue
+            notes = subprocess.run([tools[2], "--notes", co], capture_output=True, text=True).stdout
+            for ent in re.split(r"\n  - ", notes):
+                nm = re.search(r"\.name:\s+(\S+)", ent)
+                if not nm:
+                    continue
+                get = lambda key: int(m.group(1)) if (m := re.search(rf"\.{key}:\s+(\d+)", ent)) else None
+                out[nm.group(1)] = {"vgpr": get("vgpr_count"), "agpr": get("agpr_count"), "spill": get("vgpr_spill_count"), "scratch": get("private_segment_fixed_size"),
+                                    "lds": get("group_segment_fixed_size")}
+    return out
+
+
+def test_hot_kernels_stay_inside_their_register_budget():
+    ks = _kernels()
+    tiled = {n: v for n, v in ks.items() if "gemv_tiled_kernel" in n}
+    # plain (XM = 0), act-order (1) and tensor-parallel (3) forms x 3 packings x 3 row counts x chunk depths x 2 dtypes x 2 workgroup sizes
+    assert len(tiled) >= 240, len(tiled)
+    bad = {n: v for n, v in tiled.items() if v["spill"] or v["scratch"]}
+    assert not bad, f"decode-copy kernels touching scratch: {list(bad.items())[:4]}"
+    assert all(v["vgpr"] <= 128 for v in tiled.values())             # 16-wave workgroups: 4 waves per SIMD
+    wide = {n: v for n, v in ks.items() if "gemm_wide_kernel" in n}
+    assert len(wide) >= 7
+    for n, v in wide.items():
+        assert v["vgpr"] == 512 or (v["vgpr"] or 0) + (v["agpr"] or 0) == 512, (n, v)      # accumulators in the AGPR half
+        assert (v["spill"] or 0) <= 4 and (v["scratch"] or 0) <= 32, (n, v)
+    mid = {n: v for n, v in ks.items() if "gemm_mid_kernel" in n}
+    assert mid and all((v["spill"] or 0) == 0 for v in mid.values())
