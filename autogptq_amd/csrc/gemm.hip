@@ -33,6 +33,7 @@
 
 #include "common.cuh"
 #include "launch.h"
+#include "../../include/gptq_mi355x_lab.h"
 
 namespace gptq {
 
@@ -1954,9 +1955,10 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.bk = (L.bits == 4 && pl.mt == 4 && L.K % 64 == 0 && L.group_size % 64 == 0) ? 64 : 32;
     if (tune && tune->reserved[1] == 32) pl.bk = 32;
     pl.variant = tune ? tune->reserved[3] : 0;            // experiment knob: inner-loop schedule variant
-    const int wide_knob = (pl.variant >= 44 && pl.variant <= 47) ? pl.variant : 0;      // 44 / 45: the 128 x 512 kernel off / forced; 46 / 47: by the rule / forced, on the checkpoint rows even when the layer has a decode copy (A/B runs)
+    // lab switches (include/gptq_mi355x_lab.h): the 128 x 512 kernel off / forced; by the rule / forced on the checkpoint rows even when the layer has a decode copy
+    const int wide_knob = (pl.variant >= GPTQ_LAB_VARIANT_WIDE_OFF && pl.variant <= GPTQ_LAB_VARIANT_WIDE_ROWS_ON) ? pl.variant : 0;
     if (wide_knob) pl.variant = 0;
-    const int tail_knob = (pl.variant >= 40 && pl.variant <= 42) ? pl.variant : 0;      // 40 = balanced tail by the rule below, 41 = off, 42 = the rule without its tile limit (A/B runs)
+    const int tail_knob = (pl.variant >= GPTQ_LAB_VARIANT_TAIL_ON && pl.variant <= GPTQ_LAB_VARIANT_TAIL_NO_LIMIT) ? pl.variant : 0;      // balanced tail: by the rule below / off / the rule without its tile limit
     if (tail_knob) pl.variant = 0;
     pl.bm = 32 * pl.mt;
     pl.bn = 256;
@@ -1995,8 +1997,8 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
         // every 128-row form of the kernel: 4-bit BK = 64 (act-order fp16 only in its DMA-staged form) and the BK = 32 forms of 2- / 3- / 8-bit and g32 layers
         const bool legal = pl.mt == 4 && pl.ksplit == 1 && pl.variant == 0 && L.N % 256 == 0 &&
                            (pl.bk == 32 || !pl.use_seq || (pl.xslot && pl.glds) || L.dtype == GPTQ_BF16);
-        const bool wanted = tail_knob == 40 || tail_knob == 42 || (tail_knob == 0 && GEMM_TAIL_DEFAULT);
-        if (legal && wanted && tiles > 256 && (tiles <= 1024 || tail_knob == 42) && rem > 0) {      // above ~4 rounds: +5 - 7 % in one harness, -4 % in another
+        const bool wanted = tail_knob == GPTQ_LAB_VARIANT_TAIL_ON || tail_knob == GPTQ_LAB_VARIANT_TAIL_NO_LIMIT || (tail_knob == 0 && GEMM_TAIL_DEFAULT);
+        if (legal && wanted && tiles > 256 && (tiles <= 1024 || tail_knob == GPTQ_LAB_VARIANT_TAIL_NO_LIMIT) && rem > 0) {      // above ~4 rounds: +5 - 7 % in one harness, -4 % in another
             const double t_round = 1.05 * (L.K / 64.0) * (L.bits != 4 ? 1.35 : (pl.bk == 32 ? 1.1 : 1.0));      // 2- / 3- / 8-bit prefill: 660 - 770 TFLOP/s
             double best = 0.0;
             for (int lg = 1; lg <= 3; ++lg) {
@@ -2024,8 +2026,8 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
         // layers that carry their decode copy: weights from it, raw x by LDS DMA (gemm_wide_kernel<T, true, true>); knob 46 / 47 keep the checkpoint rows (A/B).
         // Act-order layers: the copy is made of the re-sequenced rows, so x is permuted in NATURAL order (xnat) instead of the row form's slot order -- and
         // bf16 act-order layers, which have no slot-ordered permute, get the wide tiles this way.
-        const bool copy_ok = L.qweight_tiled != nullptr && L.tiled_cols == GPTQ_STRIP_COLS && L.N % GPTQ_STRIP_COLS == 0 && wide_knob != 46 && wide_knob != 47;
-        pl.wide = wide_knob != 44 && (fills || wide_knob == 45 || wide_knob == 47) && pl.mt == 4 && pl.bk == 64 && pl.ksplit == 1 && pl.variant == 0 && tail_knob == 0 &&
+        const bool copy_ok = L.qweight_tiled != nullptr && L.tiled_cols == GPTQ_STRIP_COLS && L.N % GPTQ_STRIP_COLS == 0 && wide_knob != GPTQ_LAB_VARIANT_WIDE_ROWS && wide_knob != GPTQ_LAB_VARIANT_WIDE_ROWS_ON;
+        pl.wide = wide_knob != GPTQ_LAB_VARIANT_WIDE_OFF && (fills || wide_knob == GPTQ_LAB_VARIANT_WIDE_ON || wide_knob == GPTQ_LAB_VARIANT_WIDE_ROWS_ON) && pl.mt == 4 && pl.bk == 64 && pl.ksplit == 1 && pl.variant == 0 && tail_knob == 0 &&
                   (wide_gemm_ok(L, M, pl.use_seq, pl.xslot && pl.glds) || (copy_ok && wide_gemm_ok(L, M, false, false)));
         if (pl.wide) {
             pl.wide_tiled = copy_ok;
