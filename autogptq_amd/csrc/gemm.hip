@@ -1666,8 +1666,63 @@ __global__ void __launch_bounds__(256) permute_rows_kernel(const unsigned short*
     }
 }
 
+// Round 4, second form: FOUR rows per workgroup held INTERLEAVED in the LDS ([k][4 rows]: 8 bytes per k), so that one ds_read_b64 per index fetches the
+// value of all four rows -- 8 LDS reads + 16 v_perm per four 16-byte outputs where the row-major form above takes 32 ds_read_u16 + 32 address adds + 16
+// packs (tools/isa: ~88 -> ~32 instructions per four outputs; the kernel is bound by its instruction stream, not by the 33.5 MB it moves).  The load phase
+// transposes 4 rows x 8 k in registers (16 v_perm) and writes 64 contiguous bytes.  LDS: 8 K bytes (88 KiB at K = 11008: granted by init_gemm_device).
+template <bool SLOT>
+__global__ void __launch_bounds__(256) permute_rows4_kernel(const unsigned short* __restrict__ x, const int* __restrict__ perm, int M, int K,
+                                                            unsigned short* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];                // [K][4] values
+    const int m0 = blockIdx.x * 4;
+    const unsigned short* xr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xr[r] = x + (size_t)min(m0 + r, M - 1) * K;
+    for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+        u32x4 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = *(const u32x4*)(xr[r] + i);
+        u32x4 o[4];                                                             // 8 k x {rows 0 | 1, rows 2 | 3}
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            o[w][0] = __builtin_amdgcn_perm(v[1][w], v[0][w], 0x05040100u);     // k = 2 w:     row 0 | row 1 << 16
+            o[w][1] = __builtin_amdgcn_perm(v[3][w], v[2][w], 0x05040100u);     //              row 2 | row 3 << 16
+            o[w][2] = __builtin_amdgcn_perm(v[1][w], v[0][w], 0x07060302u);     // k = 2 w + 1
+            o[w][3] = __builtin_amdgcn_perm(v[3][w], v[2][w], 0x07060302u);
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) *(u32x4*)(smem + (size_t)i * 8 + w * 16) = o[w];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+        const u32x4 p0 = *(const u32x4*)(perm + i), p1 = *(const u32x4*)(perm + i + 4);
+        u32x2 g[8];                                                             // g[j] = the four rows' values at source index j of this piece
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { g[j] = *(const u32x2*)(smem + (size_t)p0[j] * 8); g[4 + j] = *(const u32x2*)(smem + (size_t)p1[j] * 8); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (m0 + r >= M) break;
+            const unsigned sel = (r & 1) ? 0x07060302u : 0x05040100u;
+            const int h = r >> 1;
+            u32x4 o;
+            if constexpr (SLOT) {                                                // (k0, k4) (k1, k5) (k2, k6) (k3, k7): the slot order of the B fragments
+#pragma unroll
+                for (int w = 0; w < 4; ++w) o[w] = __builtin_amdgcn_perm(g[4 + w][h], g[w][h], sel);
+            } else {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) o[w] = __builtin_amdgcn_perm(g[2 * w + 1][h], g[2 * w][h], sel);
+            }
+            __builtin_nontemporal_store(o, (u32x4*)(out + (size_t)(m0 + r) * K + i));
+        }
+    }
+}
+
 template <bool SLOT>
 static void launch_permute_rows_r(const unsigned short* x, const int* perm, int M, int K, unsigned short* out, hipStream_t st) {
+    if (M >= 1024 && (size_t)K * 8 <= 160 * 1024 && K % 8 == 0) {                // prefill rows: the interleaved four-row form
+        hipLaunchKernelGGL((permute_rows4_kernel<SLOT>), dim3((M + 3) / 4), dim3(256), (size_t)K * 8, st, x, perm, M, K, out);
+        return;
+    }
     // rows per workgroup: as many as keep >= 512 workgroups in the launch and <= 64 KiB of LDS (the default dynamic-LDS limit: no per-function grant needed)
     int r = 1;
     while (r < 4 && (size_t)(2 * r) * K * 2 <= 64 * 1024 && M / (2 * r) >= 512) r *= 2;
@@ -1712,6 +1767,8 @@ template <typename T> static hipError_t grant_stream64_t() {
 
 hipError_t init_gemm_device() {
     hipError_t e = grant_lds<4, f16, 4, 64, 1, true, true, 2>();
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)permute_rows4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)permute_rows4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = grant_lds<4, f16, 4, 64, 1, false, false, 2>();
     if (e == hipSuccess) e = grant_lds<4, bf16, 4, 64, 1, false, false, 2>();
 #ifdef GPTQ_GEMM_ABLATIONS
