@@ -63,3 +63,25 @@ def forward_f64(x, qweight, qzeros, scales, g_idx, bias, bits, group_size, nowra
                                        M, K, N, bits, group_size, int(nowrap), _p(y, ctypes.c_double))
     assert rc == 0
     return y
+
+
+def decode_copy_weights(qweight: np.ndarray, bits: int) -> np.ndarray:
+    """uint32 [N/16, chunks, 4, 16, WPL] (include/gptq_mi355x.h: qweight_tiled)."""
+    q = np.ascontiguousarray(qweight, dtype=np.int32)
+    K, N = q.shape[0] * 32 // bits, q.shape[1]
+    kpl, wpl = (16 if bits == 8 else 32), (3 if bits == 3 else 4)
+    out = np.empty((N // 16, -(-K // (4 * kpl)), 4, 16, wpl), np.uint32)
+    rc = lib().gptq_oracle_decode_copy_weights(_p(q, ctypes.c_int32), K, N, bits, _p(out, ctypes.c_uint32))
+    assert rc == 0
+    return out
+
+
+def decode_copy_consts(qzeros: np.ndarray, scale_bits: np.ndarray, bits: int, nowrap: bool) -> np.ndarray:
+    """uint8 [N/16, G, REC] (include/gptq_mi355x.h: qconst_tiled); scale_bits = the 16-bit scales viewed as uint16 [G, N]."""
+    q = np.ascontiguousarray(qzeros, dtype=np.int32)
+    sb = np.ascontiguousarray(scale_bits, dtype=np.uint16)
+    G, N = sb.shape
+    out = np.empty((N // 16, G, 64 if bits == 8 else 48), np.uint8)
+    rc = lib().gptq_oracle_decode_copy_consts(_p(q, ctypes.c_int32), _p(sb, ctypes.c_uint16), G, N, bits, int(nowrap), _p(out, ctypes.c_uint8))
+    assert rc == 0
+    return out

@@ -78,3 +78,86 @@ int gptq_oracle_forward_f64(const float *x, const int32_t *qweight, const int32_
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * The decode copy (include/gptq_mi355x.h, gptq_prepack_decode): the library's own load-time
+ * re-layout, the role exllamav2's shuffle (exllamav2/cuda/q_matrix.cu:19-42) and Marlin's
+ * repack (marlin/marlin_repack.cu:8-92) play in the reference.  Stated here DESTINATION-first
+ * (for every stored bit: which source value and which of its bits), where gptq_oracle.py
+ * states it source-first with reshapes -- the two check each other, and both check the
+ * device kernels.
+ *
+ * A lane owns KPL consecutive k (32; 16 at 8 bits) of one column and stores them in WPL words
+ * (4; 3 at 3 bits).  lane_value_of_bit answers: stored bit b of word j of a lane is bit *vb of
+ * the lane's value number *vk.
+ * ------------------------------------------------------------------------------------------ */
+static void lane_value_of_bit(int bits, int j, int b, int *vk, int *vb)
+{
+    if (bits == 4) {                     /* nibble p of word j holds k = 8 j + (0 2 4 6 1 3 5 7)[p] */
+        int p = b >> 2;
+        *vk = 8 * j + (p < 4 ? 2 * p : 2 * (p - 4) + 1);
+        *vb = b & 3;
+    } else if (bits == 8) {              /* byte p of word j holds k = 4 j + (0 2 1 3)[p] */
+        int p = b >> 3;
+        *vk = 4 * j + (p == 1 ? 2 : p == 2 ? 1 : p);
+        *vb = b & 7;
+    } else {                             /* 3 bits: halves hold the even / odd k of pairs 5 j .. 5 j + 4; bit 15 / 31 = bit j of k 30 / 31 */
+        int half = b >> 4, r = b & 15;
+        if (r == 15) { *vk = 30 + half; *vb = j; }
+        else         { *vk = 2 * (5 * j + r / 3) + half; *vb = r % 3; }
+    }
+}
+
+/* out: uint32 [N/16][chunks][4][16][WPL], chunks = ceil(K / (4 KPL)); k >= K read as 0 */
+int gptq_oracle_decode_copy_weights(const int32_t *qweight, int K, int N, int bits, uint32_t *out)
+{
+    if (!(bits == 3 || bits == 4 || bits == 8) || K % 32 || N % 16) return 1;
+    const int kpl = bits == 8 ? 16 : 32, wpl = bits == 3 ? 3 : 4;
+    const int chunks = (K + 4 * kpl - 1) / (4 * kpl);
+    size_t o = 0;
+    for (int s = 0; s < N / 16; ++s)
+        for (int c = 0; c < chunks; ++c)
+            for (int slot = 0; slot < 4; ++slot)
+                for (int col = 0; col < 16; ++col)
+                    for (int j = 0; j < wpl; ++j, ++o) {
+                        uint32_t word = 0;
+                        for (int b = 0; b < 32; ++b) {
+                            int vk, vb;
+                            lane_value_of_bit(bits, j, b, &vk, &vb);
+                            long k = ((long)c * 4 + slot) * kpl + vk;
+                            if (k >= K) continue;
+                            uint32_t v = stream_field((const uint32_t *)qweight + 16 * s + col, (size_t)N, (size_t)k, bits);
+                            word |= ((v >> vb) & 1u) << b;
+                        }
+                        out[o] = word;
+                    }
+    return 0;
+}
+
+/* out: bytes [N/16][G][REC]; REC = 48 (16 x u16 scale bits, 16 x u8 zero) or, at 8 bits, 64 (16 x u16 zero).
+ * scale_bits = the checkpoint's 16-bit scales verbatim, [G, N]. */
+int gptq_oracle_decode_copy_consts(const int32_t *qzeros, const uint16_t *scale_bits, int G, int N, int bits,
+                                   int zero_mode, uint8_t *out)
+{
+    if (!(bits == 3 || bits == 4 || bits == 8) || N % 32) return 1;
+    const int rec = bits == 8 ? 64 : 48;
+    const size_t row_words = (size_t)N / 32 * bits;
+    for (int s = 0; s < N / 16; ++s)
+        for (int g = 0; g < G; ++g) {
+            uint8_t *r = out + ((size_t)s * G + g) * rec;
+            for (int col = 0; col < 16; ++col) {
+                int n = 16 * s + col;
+                uint16_t sb = scale_bits[(size_t)g * N + n];
+                int32_t z = (int32_t)stream_field((const uint32_t *)qzeros + g * row_words, 1, (size_t)n, bits) + 1;
+                if (zero_mode == 0) z &= (1 << bits) - 1;
+                r[2 * col] = (uint8_t)(sb & 255);
+                r[2 * col + 1] = (uint8_t)(sb >> 8);
+                if (bits == 8) {
+                    r[32 + 2 * col] = (uint8_t)(z & 255);
+                    r[32 + 2 * col + 1] = (uint8_t)(z >> 8);
+                } else
+                    r[32 + col] = (uint8_t)z;
+            }
+        }
+    return 0;
+}

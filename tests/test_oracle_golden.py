@@ -146,6 +146,22 @@ def test_c_oracle_random_words(bits):
                               O.unpack_zeros(L["qzeros"], bits, mode))
 
 
+@pytest.mark.parametrize("bits,K,N,gs", [(4, 256, 128, 64), (4, 160, 64, 32), (3, 256, 64, 128), (3, 96, 32, 32), (8, 128, 64, 64), (8, 96, 32, 32)])
+def test_c_oracle_decode_copy_matches_the_numpy_restatement(bits, K, N, gs):
+    """The decode copy (include/gptq_mi355x.h, gptq_prepack_decode) stated twice: source-first with reshapes in gptq_oracle.py, destination-first bit by
+    bit in gptq_oracle.c; ragged K (a last chunk that is part padding) included.  The device kernels are pinned to the numpy one in tests/test_gpu_tiled.py."""
+    from oracle import c_oracle as C
+    L = O.random_quant_layer(K, N, bits, gs, seed=17 * bits + K)
+    want = O.decode_copy_weights(L["qweight"], bits).numpy().view(np.uint32)
+    got = C.decode_copy_weights(L["qweight"].numpy(), bits)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    sb = L["scales"].contiguous().view(torch.int16).numpy().view(np.uint16)
+    for mode in (O.ZERO_WRAP, O.ZERO_NOWRAP):
+        wantc = O.decode_copy_consts(L["qzeros"], L["scales"], mode, bits).numpy()
+        gotc = C.decode_copy_consts(L["qzeros"].numpy(), sb, bits, mode == O.ZERO_NOWRAP)
+        assert gotc.shape == wantc.shape and np.array_equal(gotc, wantc)
+
+
 # ---------------------------------------------------------------- AWQ ingest (auto_gptq/modeling/_utils.py:525-701)
 AWQ_GOLDEN = ["awq_k128_n64_g32.npz", "awq_k256_n128_g128.npz", "awq_k64_n64_g32_zero_edges.npz"]
 
