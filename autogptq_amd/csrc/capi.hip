@@ -127,8 +127,19 @@ bool want_stream(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
 
 // Decode from the strip-major side copy (gemv_tiled.hip): 3- / 4- / 8-bit fp16 / bf16 layers (plain or act-order) that carry qweight_tiled, M <= 4.  tuning.path = 8 forces it
 // ("does not fit" is then an error), any other explicit path keeps the checkpoint-layout kernels (A/B runs).
+// 5..8 rows (MT = 8: two matrix-core steps per decoded pair, 8 staged rows of x per workgroup): every 16-column strip stages its own copy of x, which is what
+// this form loses to the 64-column-strip kernels on wide layers (tools/tiled_sweep.py --m 8, profiles/r04_tiled_sweep_m8.log, us, this / checkpoint-layout
+// default: 11008x4096 18.7 / 12.3, 4096x11008 12.9 / 10.8, q|k|v 13.1 / 11.7, gate|up 22.1 / 18.3) and wins only on a single square-ish 4096-wide layer
+// (4096^2: 6.62 / 7.20) -- the planner takes it there by itself (profiles/r04_tiled_sweep_rows8_default_rule.log, M = 8: 4096^2 6.60 / 7.29, 2048^2 4.78 / 6.89,
+// 4096x2048 5.95 / 7.66, 2048x4096 5.05 / 5.25, 3072^2 6.16 / 6.10; M = 5: 6.47 / 7.11, 4.77 / 6.79), tuning.path = 8 asks for it anywhere.
+constexpr int TILED_ROWS_MAX = 8;
+static bool tiled_rows8_pays(const gptq_layer_t* const* Ls, int n) {
+    const gptq_layer_t& L = *Ls[0];
+    return n == 1 && L.bits == 4 && !L.g_idx && L.K >= 2048 && L.K <= 4096 && L.N >= 2048 && L.N <= 4096;
+}
 bool want_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* t) {
-    if (M > 4 || n < 1 || n > 4) return false;
+    if (M > TILED_ROWS_MAX || n < 1 || n > 4) return false;
+    if (M > 4 && !(t && t->path == 8) && !tiled_rows8_pays(Ls, n)) return false;
     if (t && t->path != 0 && t->path != 8) return false;
     return plan_tiled(Ls, n, M, t).ok;                             // act-order layers: the copy holds the re-sequenced rows, the kernel gathers x through perm
 }
@@ -355,7 +366,7 @@ static int forward_impl(const gptq_layer_t* L, const void* x, void* out, int M, 
             return tiled_call(one, 1, x, outs, M, wv, stream, tune);
         }
         if (tune && tune->path == 8)
-            return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: the decode-copy kernel needs M <= 4 and a plain 3/4/8-bit fp16/bf16 layer that carries qweight_tiled / qconst_tiled "
+            return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: the decode-copy kernel needs M <= 8 and a plain or re-sequenced act-order 3/4/8-bit fp16/bf16 layer that carries qweight_tiled / qconst_tiled "
                                               "(gptq_prepack_decode; tiled_cols = %d)", GPTQ_STRIP_COLS);
     }
     if (L->epilogue != GPTQ_EPI_NONE && !fused_epilogue_ok(L, M, tune)) {
@@ -486,7 +497,7 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
     // 11.1 for the batched-decode kernel, gate|up 12.9 against 18.9)
     if (want_tiled(layers, n_layers, M, tune) && (multi_preferred(layers, n_layers, M) || (tune && tune->path == 8)))
         return tiled_call(layers, n_layers, x, outs, M, wv, stream, tune);
-    if (tune && tune->path == 8) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: these layers do not fit one decode-copy launch (1..4 layers of one packing with qweight_tiled, all plain or all act-order, M <= 4)");
+    if (tune && tune->path == 8) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: these layers do not fit one decode-copy launch (1..4 layers of one packing with qweight_tiled, all plain or all act-order, M <= 8)");
     if (want_mid_multi(layers, n_layers, M, tune)) {
         const MidPlan mp = plan_mid(layers, n_layers, M, tune);
         if (mp.partial_bytes > 0 && wv.body_bytes < mp.partial_bytes)
@@ -875,7 +886,7 @@ int gptq_forward_scatter(const gptq_layer_t* L, const void* x, int M, const gptq
     if ((rc = check_peer_group(pg, M, L->dtype))) return rc;
     if (L->N != pg->N / pg->world) return fail(GPTQ_ERR_SHAPE, "the layer's out_features (%d) must be the rank's shard N / world = %d", L->N, pg->N / pg->world);
     const gptq_layer_t* one[1] = {L};
-    if (L->epilogue != GPTQ_EPI_NONE || L->g_idx || !want_tiled(one, 1, M, nullptr) || (plan_tiled(one, 1, M, nullptr).u != 2 && plan_tiled(one, 1, M, nullptr).u != 4))
+    if (M > 4 || L->epilogue != GPTQ_EPI_NONE || L->g_idx || !want_tiled(one, 1, M, nullptr) || (plan_tiled(one, 1, M, nullptr).u != 2 && plan_tiled(one, 1, M, nullptr).u != 4))
         return fail(GPTQ_ERR_UNSUPPORTED, "gptq_forward_scatter: the fused scatter is the epilogue of the decode-copy kernel (M <= 4, a plain 3/4/8-bit fp16/bf16 "
                                           "layer that carries qweight_tiled / qconst_tiled); use gptq_forward + gptq_peer_scatter for this call");
     const WsView wv = split_ws(ws, ws_bytes);

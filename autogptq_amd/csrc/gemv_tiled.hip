@@ -1,4 +1,4 @@
-// gemv_tiled.hip -- decode (M <= 4) from the load-time DECODE COPY of a 3-, 4- or 8-bit layer, plain or act-order (round 4).  The kernel itself:
+// gemv_tiled.hip -- decode (M <= 4; 5..8 rows where it pays: capi.hip, want_tiled) from the load-time DECODE COPY of a 3-, 4- or 8-bit layer, plain or act-order (round 4).  The kernel itself:
 // gemv_tiled_kernel.cuh (instantiated here for plain layers, in gemv_tiled_act.hip for act-order ones, in gemv_tiled_peer.hip with the tensor-parallel
 // epilogue); this file: the planner and the launch.  The 4-bit layout as the example (the other packings: TiledFmt, gptq_mi355x.h):
 //
@@ -63,7 +63,7 @@ size_t tiled_const_bytes(const gptq_layer_t& L) {
 
 TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* tune) {
     TiledPlan pl{};
-    if (n < 1 || n > 4 || M < 1 || M > 4) return pl;
+    if (n < 1 || n > 4 || M < 1 || M > 8) return pl;
     const gptq_layer_t& A = *Ls[0];
     int strips = 0, nsum = 0;
     for (int i = 0; i < n; ++i) {
@@ -74,7 +74,7 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         nsum += L.N;
     }
     pl.nseg = n;
-    pl.mt = M >= 3 ? 4 : M;
+    pl.mt = M >= 5 ? 8 : (M >= 3 ? 4 : M);                                        // 5..8 rows: a second A operand (rows 4..7), two matrix-core steps per decoded pair
     const int cke = 4 * tiled_kpl(A.bits), rec = tiled_rec_bytes(A.bits);         // k per chunk; bytes of one group's constants
     const int chunks = (A.K + cke - 1) / cke;
     pl.bits = A.bits;
@@ -114,10 +114,11 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         const int wgs = strips * pl.ksplit;
         if (wgs <= 320) { waves = 16; u = 2; }
         else { waves = 4; u = 4; }
+        if (pl.mt > 4) { waves = 8; u = 4; }                                      // 5..8 rows, 4096^2: 6.62 us (4 x 4: 6.82, 16 x 2: 6.92)
         while (waves > 1 && (waves / 2) * u >= cps) waves /= 2;
     }
     if (waves < 1 || waves > 16 || (u != 1 && u != 2 && u != 4 && u != 8)) return pl;
-    if ((A.bits != 4 || A.g_idx) && u != 2 && u != 4) return pl;                  // the 3- / 8-bit and the act-order forms are compiled for 2 and 4 chunks in flight
+    if ((A.bits != 4 || A.g_idx || pl.mt > 4) && u != 2 && u != 4) return pl;     // the 3- / 8-bit, the act-order and the 5..8-row forms are compiled for 2 and 4 chunks in flight
     pl.waves = waves;
     pl.u = u;
     pl.xstride = cps * cke * 2 + 16;
@@ -134,7 +135,7 @@ hipError_t launch_tiled(const gptq_layer_t* const* Ls, const TiledPlan& pl, cons
     if (!pl.ok) return hipErrorInvalidValue;
     TiledParams p{};
     if (pg) {                                                                     // one layer = this rank's column shard
-        if (pl.nseg != 1 || pg->world < 1 || pg->world > GPTQ_PEER_MAX) return hipErrorInvalidValue;
+        if (pl.nseg != 1 || pl.mt > 4 || pg->world < 1 || pg->world > GPTQ_PEER_MAX) return hipErrorInvalidValue;
         for (int r = 0; r < pg->world; ++r) {
             p.peer.xbuf[0][r] = (char*)pg->xbuf[0][r];
             p.peer.xbuf[1][r] = (char*)pg->xbuf[1][r];

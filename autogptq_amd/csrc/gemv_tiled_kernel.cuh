@@ -211,6 +211,7 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
         __syncthreads();
     };
     const char* const xl = xs + (size_t)min(lane & 3, MT - 1) * xstride + kb * (KPL * 2);    // A operand: lane i of a 4-lane group carries x row i
+    const char* const xl2 = xs + (size_t)min(4 + (lane & 3), MT - 1) * xstride + kb * (KPL * 2);   // MT = 8: rows 4..7, a second matrix-core step per decoded pair
     float acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = 0.f;
@@ -254,9 +255,18 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
             u32x4 xa[NX];
 #pragma unroll
             for (int w = 0; w < NX; ++w) xa[w] = *(const u32x4*)(xl + ((unsigned)(cc - cb) * (unsigned)(CKE * 2) + w * 16u));
+            u32x4 xb[MT > 4 ? NX : 1];
+            if constexpr (MT > 4) {
+#pragma unroll
+                for (int w = 0; w < NX; ++w) xb[w] = *(const u32x4*)(xl2 + ((unsigned)(cc - cb) * (unsigned)(CKE * 2) + w * 16u));
+            }
             const f16x2 c1 = as_f16x2(z * 0x00010001u + 0xE400E400u);            // -(1024 + z)
             const qvec qv = q[j];
-            f32x4 accg = {0.f, 0.f, 0.f, 0.f};
+            f32x4 accg = {0.f, 0.f, 0.f, 0.f}, accg2 = {0.f, 0.f, 0.f, 0.f};
+            auto mm = [&](int pc, int hf, unsigned b0, unsigned b1) __attribute__((always_inline)) {      // 4 k of the lane's column against x piece pc, half hf: rows 0..3 (and 4..7)
+                accg = Mma4<MM>::run(u32x2{xa[pc][hf * 2], xa[pc][hf * 2 + 1]}, u32x2{b0, b1}, accg);
+                if constexpr (MT > 4) accg2 = Mma4<MM>::run(u32x2{xb[pc][hf * 2], xb[pc][hf * 2 + 1]}, u32x2{b0, b1}, accg2);
+            };
             if constexpr (BITS == 4) {
                 const f16x2 c2 = c1 + k960;                                       // -(64 + z)
 #pragma unroll
@@ -266,8 +276,8 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
                     const f16x2 h1 = as_f16x2((qw & m_hi) | magic) * r16 + c2;    // k2,k3  (1 and 5)
                     const f16x2 h2 = as_f16x2((q8 & m_lo) | magic) + c1;          // k4,k5  (2 and 6)
                     const f16x2 h3 = as_f16x2((q8 & m_hi) | magic) * r16 + c2;    // k6,k7  (3 and 7)
-                    accg = Mma4<MM>::run(u32x2{xa[w][0], xa[w][1]}, u32x2{bits_of(h0), bits_of(h1)}, accg);
-                    accg = Mma4<MM>::run(u32x2{xa[w][2], xa[w][3]}, u32x2{bits_of(h2), bits_of(h3)}, accg);
+                    mm(w, 0, bits_of(h0), bits_of(h1));
+                    mm(w, 1, bits_of(h2), bits_of(h3));
                 }
             } else if constexpr (BITS == 8) {
 #pragma unroll
@@ -275,7 +285,7 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
                     const unsigned qw = qv[w], q8 = qw >> 8;
                     const f16x2 h0 = as_f16x2((qw & m_b) | magic) + c1;           // k0,k1  (stored bytes 0 and 2)
                     const f16x2 h1 = as_f16x2((q8 & m_b) | magic) + c1;           // k2,k3  (1 and 3)
-                    accg = Mma4<MM>::run(u32x2{xa[w >> 1][(w & 1) * 2], xa[w >> 1][(w & 1) * 2 + 1]}, u32x2{bits_of(h0), bits_of(h1)}, accg);
+                    mm(w >> 1, w & 1, bits_of(h0), bits_of(h1));
                 }
             } else {
                 const f16x2 c3 = c1 + k896;                                       // -(128 + z): fields at bit 3, times 1/8
@@ -293,8 +303,7 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
                 const unsigned e = ((qv[0] >> 15) & 0x00010001u) | ((qv[1] >> 14) & 0x00020002u) | ((qv[2] >> 13) & 0x00040004u);   // (k30 | k31 << 16): bits 15 / 31 of the three words
                 pr[15] = bits_of(as_f16x2(e | magic) + c1);
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    accg = Mma4<MM>::run(u32x2{xa[i >> 1][(i & 1) * 2], xa[i >> 1][(i & 1) * 2 + 1]}, u32x2{pr[2 * i], pr[2 * i + 1]}, accg);
+                for (int i = 0; i < 8; ++i) mm(i >> 1, i & 1, pr[2 * i], pr[2 * i + 1]);
             }
             const float sc = DType<T>::to_f32(__builtin_bit_cast(T, sraw));
             if constexpr (XC) {
@@ -303,7 +312,7 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
                 for (int m = 0; m < MT; ++m) acc[m] = live ? fmaf(sc * xi[m], accg[m], acc[m]) : acc[m];
             } else {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = live ? fmaf(sc, accg[m], acc[m]) : acc[m];   // a select, not a product by 0: a dead slot's x is whatever the LDS holds
+                for (int m = 0; m < MT; ++m) acc[m] = live ? fmaf(sc, m < 4 ? accg[m] : accg2[m - 4], acc[m]) : acc[m];   // a select, not a product by 0: a dead slot's x is whatever the LDS holds
             }
         }
     }
@@ -355,10 +364,10 @@ static hipError_t launch_tiled_one(const TiledPlan& pl, const TiledParams& p, hi
 template <int BITS, int MT, typename T, int XM>
 static hipError_t launch_tiled_u(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
     switch (pl.u) {
-        case 1: if constexpr (BITS == 4 && XM == 0) return launch_tiled_one<BITS, MT, 1, T, XM>(pl, p, st); else return hipErrorInvalidValue;
+        case 1: if constexpr (BITS == 4 && XM == 0 && MT <= 4) return launch_tiled_one<BITS, MT, 1, T, XM>(pl, p, st); else return hipErrorInvalidValue;
         case 2: return launch_tiled_one<BITS, MT, 2, T, XM>(pl, p, st);
         case 4: return launch_tiled_one<BITS, MT, 4, T, XM>(pl, p, st);
-        case 8: if constexpr (BITS == 4 && XM == 0) return launch_tiled_one<BITS, MT, 8, T, XM>(pl, p, st); else return hipErrorInvalidValue;
+        case 8: if constexpr (BITS == 4 && XM == 0 && MT <= 4) return launch_tiled_one<BITS, MT, 8, T, XM>(pl, p, st); else return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }
@@ -368,6 +377,7 @@ static hipError_t launch_tiled_mt(const TiledPlan& pl, const TiledParams& p, hip
         case 1: return launch_tiled_u<BITS, 1, T, XM>(pl, p, st);
         case 2: return launch_tiled_u<BITS, 2, T, XM>(pl, p, st);
         case 4: return launch_tiled_u<BITS, 4, T, XM>(pl, p, st);
+        case 8: if constexpr (XM != 3) return launch_tiled_u<BITS, 8, T, XM>(pl, p, st); else return hipErrorInvalidValue;      // 5..8 rows: plain and act-order forms
         default: return hipErrorInvalidValue;
     }
 }
@@ -395,11 +405,12 @@ static hipError_t grant_tiled_lds() {
         };
         using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
         using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
-        if constexpr (XM == 0) { grant_u(I4{}, I1{}); grant_u(I4{}, I8{}); }          // 1 and 8 chunks in flight: sweep geometries of the plain 4-bit form only
+        if constexpr (XM == 0 && MT <= 4) { grant_u(I4{}, I1{}); grant_u(I4{}, I8{}); }          // 1 and 8 chunks in flight: sweep geometries of the plain 4-bit form only
         grant_u(I4{}, I2{}); grant_u(I4{}, I4{});
         grant_u(I8{}, I2{}); grant_u(I8{}, I4{}); grant_u(I3{}, I2{}); grant_u(I3{}, I4{});
     };
     grant_mt(std::integral_constant<int, 1>{}); grant_mt(std::integral_constant<int, 2>{}); grant_mt(std::integral_constant<int, 4>{});
+    if constexpr (XM != 3) grant_mt(std::integral_constant<int, 8>{});
     return e;
 }
 

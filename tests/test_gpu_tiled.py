@@ -50,7 +50,7 @@ def _x(M, K, dtype, seed, hot=True):
     x = (torch.rand(M, K, generator=torch.Generator().manual_seed(seed)) - 0.5).to(dtype)
     ks = []
     if hot and M > 1:
-        for r, k in zip(range(1, M), (K - 1, 0, 129 % K)):
+        for r, k in zip(range(1, M), (K - 1, 0, 129 % K, 31 % K, (K // 2 + 1) % K, 64 % K, (K - 33) % K)):     # rows 4..7: the second A operand of the 5..8-row form
             x[r].zero_()
             x[r, k] = 1.0
             ks.append((r, k))
@@ -308,6 +308,39 @@ def test_tiled_decode_act_order(bits, K, N, gs, dtype):
                 assert torch.equal(y0[r], W[k]), f"one-hot row {r} (k={k}) is not the oracle's W[k], act-order int{bits} M={M} {K}x{N} g{gs}"
             _assert_all(y0, x, W, None, dtype, f"tiled act-order int{bits} forced {K}x{N} g{gs} M={M}")
         q._layer.bias = saved
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("bits,K,N,gs,act", [(4, 1024, 512, 128, False), (4, 4160, 256, 32, False), (4, 11008, 64, 128, False), (4, 96, 64, 32, False), (3, 2112, 256, 64, False),
+                                             (8, 2048, 512, 128, False), (8, 4128, 64, 16, False), (4, 2048, 512, 128, True), (3, 4096, 256, 32, True), (8, 2048, 256, 128, True)])
+def test_tiled_decode_5_to_8_rows(bits, K, N, gs, act, dtype):
+    """5..8 rows of x on the decode copy (MT = 8: rows 4..7 are a second A operand, two matrix-core steps per decoded pair; asked for with tuning.path = 8):
+    every output against x (fp64) @ W_oracle (fp64), one-hot rows in BOTH halves exact, default and forced geometries, K slices (long K: the planner's own --
+    eight staged rows of x do not fit one workgroup's LDS), bit-reproducible."""
+    L, q, W = _layer(K, N, gs, dtype, K + N + gs + bits + 5, bits=bits, act=act)
+    for M in (5, 6, 8):
+        x, hot = _x(M, K, dtype, M)
+        for t in (_tune(), _tune(16, 2), _tune(4, 4), _tune(8, 2, 2)):
+            try:
+                if _lib.describe_plan(q._layer, M, t).get("kernel") != "strips":
+                    continue
+            except _lib.GptqError:                # (act-order: the raw rows of x, whole K, may not fit the LDS)
+                continue
+            with torch.no_grad():
+                y, y2 = q(x, tuning=t), q(x, tuning=t)
+            assert torch.equal(y, y2)
+            for r, k in hot:
+                assert torch.equal(y[r], W[k]), f"one-hot row {r} (k={k}) is not the oracle's W[k], int{bits} M={M} {K}x{N} g{gs} act={act}"
+            _assert_all(y, x, W, None, dtype, f"tiled int{bits} {K}x{N} g{gs} M={M} act={act} waves={t.waves} u={t.reserved[0]} ks={t.ksplit}")
+    if not act and bits == 4 and K == 1024:       # several layers in one launch, 8 rows
+        L2, q2, W2 = _layer(K, 288, gs, dtype, 99, bits=bits)
+        x, hot = _x(8, K, dtype, 8)
+        with torch.no_grad():
+            ys = forward_multi([q, q2], x, _tune())
+        for y, Wi in zip(ys, (W, W2)):
+            for r, k in hot:
+                assert torch.equal(y[r], Wi[k])
+            _assert_all(y, x, Wi, None, dtype, "tiled multi, 8 rows")
 
 
 def test_tiled_multi_layer_launch_act_order():
