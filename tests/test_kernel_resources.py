@@ -49,8 +49,9 @@ def _kernels():
 def test_hot_kernels_stay_inside_their_register_budget():
     ks = _kernels()
     tiled = {n: v for n, v in ks.items() if "gemv_tiled_kernel" in n}
-    # plain (XM = 0), act-order (1) and tensor-parallel (3) forms x 3 packings x 3 row counts x chunk depths x 2 dtypes x 2 workgroup sizes
-    assert len(tiled) >= 240, len(tiled)
+    # plain (XM = 0), act-order (1) and tensor-parallel (3) forms x 3 packings x 3 row counts (+ the 5..8-row form of the plain and act-order kernels) x chunk
+    # depths x 2 dtypes x 2 workgroup sizes
+    assert len(tiled) >= 288, len(tiled)
     bad = {n: v for n, v in tiled.items() if v["spill"] or v["scratch"]}
     assert not bad, f"decode-copy kernels touching scratch: {list(bad.items())[:4]}"
     assert all(v["vgpr"] <= 128 for v in tiled.values())             # 16-wave workgroups: 4 waves per SIMD
