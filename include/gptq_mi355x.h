@@ -142,7 +142,8 @@ typedef enum gptq_path_t {
     GPTQ_PATH_GEMV_DIRECT = 4,    /* register GEMV with the v_dot2 reduction (comparison variant) */
     GPTQ_PATH_GEMV_MFMA = 5,      /* matrix-core GEMV on the checkpoint layout (4-bit fp16 / bf16 kernel, or the 2/3/8-bit one) */
     GPTQ_PATH_GEMV_STREAM = 6,    /* streamed (LDS-DMA) GEMV on the checkpoint layout */
-    GPTQ_PATH_GEMV_DECODE_COPY = 8 /* decode kernel on the load-time decode copy (qweight_tiled / qconst_tiled) */
+    GPTQ_PATH_GEMV_DECODE_COPY = 8 /* decode kernel on the load-time decode copy (qweight_tiled / qconst_tiled): M <= 8; the planner's own choice up to 4 rows, and at
+                                    * 5..8 rows on single plain 4-bit layers with K and N in 2048..4096 */
 } gptq_path_t;
 
 /* Optional launch-shape override; NULL = the planner's choice, which is what a drop-in caller passes.  lanes_n / waves / ksplit / path force a documented
