@@ -854,3 +854,59 @@ def test_decode_copy_restatement_3_and_8_bit(bits):
                 assert np.array_equal(rec[:32].view(np.int16), sb[g, 16 * s_:16 * s_ + 16])
                 zz = rec[32:].view(np.uint16) if bits == 8 else rec[32:]
                 assert np.array_equal(zz.astype(np.int64), z[g, 16 * s_:16 * s_ + 16].astype(np.int64))
+
+
+def test_tools_and_bench_parse():
+    """Every measurement script under tools/ (and bench.py, __graft_entry__.py) at least parses and only imports what exists: they run on the GPU box where a
+    SyntaxError or a renamed helper costs a paid call.  Names imported from this repo's own modules are resolved against those modules' top-level
+    definitions (AST only: nothing is executed, no GPU needed)."""
+    import ast
+    import glob
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    assert len(files) > 20
+
+    def top_level_names(path):
+        tree = ast.parse(open(path).read(), path)
+        names = set()
+        for node in tree.body:
+            if isinstance(node, (ast.FunctionDef, ast.ClassDef, ast.AsyncFunctionDef)):
+                names.add(node.name)
+            elif isinstance(node, (ast.Assign, ast.AnnAssign, ast.AugAssign)):
+                for t in (node.targets if isinstance(node, ast.Assign) else [node.target]):
+                    for n in ast.walk(t):
+                        if isinstance(n, ast.Name):
+                            names.add(n.id)
+            elif isinstance(node, (ast.Import, ast.ImportFrom)):
+                for a in node.names:
+                    names.add((a.asname or a.name).split(".")[0])
+            elif isinstance(node, (ast.If, ast.Try, ast.With, ast.For)):
+                for n in ast.walk(node):
+                    if isinstance(n, (ast.FunctionDef, ast.ClassDef)):
+                        names.add(n.name)
+                    elif isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store):
+                        names.add(n.id)
+                    elif isinstance(n, (ast.Import, ast.ImportFrom)):
+                        for a in n.names:
+                            names.add((a.asname or a.name).split(".")[0])
+        return names
+
+    own = {"bench": os.path.join(root, "bench.py")}
+    for mod in glob.glob(os.path.join(root, "autogptq_amd", "*.py")):
+        own["autogptq_amd." + os.path.basename(mod)[:-3]] = mod
+    own["autogptq_amd"] = os.path.join(root, "autogptq_amd", "__init__.py")
+    for mod in glob.glob(os.path.join(root, "oracle", "*.py")):
+        own["oracle." + os.path.basename(mod)[:-3]] = mod
+    defined = {k: top_level_names(v) for k, v in own.items()}
+    submodules = {"autogptq_amd": {k.split(".", 1)[1] for k in own if k.startswith("autogptq_amd.")},
+                  "oracle": {k.split(".", 1)[1] for k in own if k.startswith("oracle.")}}
+    missing = []
+    for f in files:
+        tree = ast.parse(open(f).read(), f)                      # SyntaxError fails the test here
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ImportFrom) and node.level == 0 and node.module in defined:
+                for a in node.names:
+                    if a.name != "*" and a.name not in defined[node.module] and a.name not in submodules.get(node.module, ()):
+                        missing.append((os.path.relpath(f, root), node.module, a.name))
+    assert not missing, missing
