@@ -265,6 +265,7 @@ int gptq_init(void) {
     if (e == hipSuccess) e = init_mlp_device();
     if (e == hipSuccess) e = init_gemm_mid_device();
     if (e == hipSuccess) e = init_gemv_tiled_device();
+    if (e == hipSuccess) e = init_gemm_wide_sk_device();
     if (e != hipSuccess) return hip_fail(e, "gptq_init (hipFuncSetAttribute)");
     return GPTQ_OK;
 }
@@ -796,7 +797,7 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
                  sp.u, sp.ksplit, sp.mt, sp.strips_total);
     } else if (want_gemm(&Lc, M, tune)) {
         const GemmPlan g = plan_gemm(Lc, M, tune);
-        const char* kern = g.f32 ? "f32_mfma" : g.wide ? (g.wide_tiled ? "wide_copy" : "wide") : g.mid ? "mid" : (g.stream64 ? "stream64" : (g.strip16 ? "strip16" : (g.skinny ? "skinny64" : "tiled")));
+        const char* kern = g.f32 ? "f32_mfma" : g.wsk ? "wide_sk" : g.wide ? (g.wide_tiled ? "wide_copy" : "wide") : g.mid ? "mid" : (g.stream64 ? "stream64" : (g.strip16 ? "strip16" : (g.skinny ? "skinny64" : "tiled")));
         snprintf(out, out_bytes, "path=gemm kernel=%s mt=%d bk=%d kg=%d ksplit=%d tiles=%dx%d tail=%d tail_slices=%d perm=%d dma=%d waves=%d u=%d epilogue=%s", kern, g.mt, g.bk,
                  g.kg == 2 ? 2 : 1, g.ksplit, g.nbm, g.nbn, g.tail, g.tail ? (1 << g.tail_lg) : 1, g.use_seq ? 1 : 0, (g.glds || g.stream64 || g.mid) ? 1 : 0, g.waves, g.u,
                  unfused_epilogue ? "separate" : "none");

@@ -2017,6 +2017,8 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     if (wide_knob) pl.variant = 0;
     const int tail_knob = (pl.variant >= GPTQ_LAB_VARIANT_TAIL_ON && pl.variant <= GPTQ_LAB_VARIANT_TAIL_NO_LIMIT) ? pl.variant : 0;      // balanced tail: by the rule below / off / the rule without its tile limit
     if (tail_knob) pl.variant = 0;
+    const int sk_knob = (pl.variant == GPTQ_LAB_VARIANT_WIDE_SK_ON || pl.variant == GPTQ_LAB_VARIANT_WIDE_SK_OFF) ? pl.variant : 0;
+    if (sk_knob) pl.variant = 0;
     pl.bm = 32 * pl.mt;
     pl.bn = 256;
     pl.nbm = (M + pl.bm - 1) / pl.bm;
@@ -2072,6 +2074,20 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
             else pl.tail_lg = 0;
         }
         if (pl.tail) pl.workspace_bytes = pl.xperm_bytes + ((size_t)pl.tail << pl.tail_lg) * (32 * 256 * 16);
+    }
+    // The 128 x 128 wave tile as a stream-K partition of 128 x 256 tiles (gemm_wide_sk.hip): every CU runs the same number of 128-deep K-chunks whatever the tile
+    // count -- BASELINE config 3 (M = 2048: 256 / 688 / 256 tiles on the three Llama-7B shapes).  Decode-copy layers only (act-order: x permuted in natural order).
+    if (pl.mt == 4 && pl.bk == 64 && pl.variant == 0 && wide_knob == 0 && tail_knob == 0 && sk_knob != GPTQ_LAB_VARIANT_WIDE_SK_OFF && L.N % GPTQ_STRIP_COLS == 0 &&
+        !(tune && tune->ksplit > 0 && tune->path == 3 && tune->ksplit != 1) && wide_sk_ok(L, M)) {
+        if (sk_knob == GPTQ_LAB_VARIANT_WIDE_SK_ON || wide_sk_pays(L, M)) {
+            pl.wsk = true;
+            pl.wskg = wide_sk_geom(L, M);
+            pl.wide = false; pl.wide_tiled = true; pl.xnat = pl.use_seq; pl.xslot = false; pl.glds = true;
+            pl.tail = 0; pl.tail_lg = 0; pl.ksplit = 1; pl.ksteps_per_split = pl.ksteps_total; pl.kg = 2;
+            pl.bn = 256; pl.nbm = pl.wskg.nbm; pl.nbn = pl.wskg.nbn;
+            pl.workspace_bytes = pl.xperm_bytes + pl.wskg.slot_bytes;
+            return pl;
+        }
     }
     // 128 x 512 tiles with a 128 x 128 tile per wave (gemm_wide.hip) where they fill the chip: whole rounds of 256, or enough rounds that the last one
     // hardly matters (tools/widelab, us per layer, 128 x 256 -> 128 x 512: M = 4096 on 4096^2 131.5 -> 122.8 (256 tiles), 11008x4096 337 -> 314 (256),
@@ -2283,6 +2299,7 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
         sp.lds_bytes = (land > slabs ? land : slabs) + 16;
         return launch_stream64(one, sp, p.x, outs, M, ws_header, p.partial, pl.use_seq ? L.qweight_seq : nullptr, st);
     }
+    if (pl.wsk) return launch_gemm_wide_sk(L, p.x, out, M, ws_header, (char*)workspace + pl.xperm_bytes, st);
     if (pl.wide) return launch_gemm_wide(L, p.qweight, p.x, out, M, pl.use_seq, st, pl.wide_tiled);
     e = (L.dtype == GPTQ_F16) ? launch_t<f16>(L, pl, p, st) : launch_t<bf16>(L, pl, p, st);
     if (e != hipSuccess) return e;

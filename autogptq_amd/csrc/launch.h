@@ -43,8 +43,17 @@ hipError_t launch_mid(const gptq_layer_t* const* layers, const MidPlan& pl, cons
                       const uint32_t* qweight_override, hipStream_t st);
 hipError_t init_gemm_mid_device();
 
+// gemm_wide_sk.hip: the same wave tile as a stream-K partition (one persistent workgroup per CU; 128 x 256 tiles, two K parts per workgroup) for launches
+// that do not divide into whole rounds of 128 x 512 tiles; weights from the decode copy only
+struct WideSkGeom {
+    int nbm, nbn, upt, units_total, lg_nwg;
+    size_t slot_bytes;        // published accumulators of cut tiles: 256 KiB per workgroup (0 when every range boundary is a tile boundary)
+};
+
 struct GemmPlan {
     bool supported, use_seq;
+    bool wsk;                 // stream-K partition of 128 x 256 tiles with the 128 x 128 wave tile (gemm_wide_sk.hip); implies wide_tiled (+ xnat for act-order layers)
+    WideSkGeom wskg;
     bool wide_tiled;          // ... reading the layer's decode copy, raw x staged by LDS DMA
     bool xnat;                // act-order + wide_tiled: x permuted in natural order (the copy is of the re-sequenced rows)
     bool wide;                // 128 x 512 tiles, 128 x 128 per wave, accumulators in AGPRs (gemm_wide.hip): large launches
@@ -117,6 +126,11 @@ hipError_t init_mlp_device();
 // gemm_wide.hip: 128 x 512 prefill tiles, 128 x 128 per wave with the accumulators in AGPRs (4-bit fp16 / bf16; glds: x in k-slot order, staged by LDS DMA)
 bool wide_gemm_ok(const gptq_layer_t& L, int M, bool use_seq, bool xslot_glds);
 hipError_t launch_gemm_wide(const gptq_layer_t& L, const uint32_t* qweight, const void* x, void* out, int M, bool glds, hipStream_t st, bool tiled = false);
+bool wide_sk_ok(const gptq_layer_t& L, int M);
+bool wide_sk_pays(const gptq_layer_t& L, int M);      // the planner's measured preference over the whole-tile kernels
+WideSkGeom wide_sk_geom(const gptq_layer_t& L, int M);
+hipError_t launch_gemm_wide_sk(const gptq_layer_t& L, const void* x, void* out, int M, void* ws_header, void* slots, hipStream_t st);
+hipError_t init_gemm_wide_sk_device();
 hipError_t init_gemv_device();
 hipError_t init_gemm_device();
 

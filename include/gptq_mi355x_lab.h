@@ -40,6 +40,8 @@
 #define GPTQ_LAB_VARIANT_WIDE_ON 45       /* the 128 x 512 kernel wherever it is legal */
 #define GPTQ_LAB_VARIANT_WIDE_ROWS 46     /* the planner's rule, but the checkpoint rows even when the layer carries a decode copy (register-staged x) */
 #define GPTQ_LAB_VARIANT_WIDE_ROWS_ON 47  /* 45 + 46 */
+#define GPTQ_LAB_VARIANT_WIDE_SK_ON 48    /* the stream-K form of the wide tile (gemm_wide_sk.hip) wherever it is legal */
+#define GPTQ_LAB_VARIANT_WIDE_SK_OFF 49   /* never the stream-K form */
 /* (9..24, 32: ablation / timeline / ping-pong variants compiled only into tools/gemmlab with -DGPTQ_GEMM_ABLATIONS) */
 
 #endif /* GPTQ_MI355X_LAB_H */
