@@ -1712,7 +1712,9 @@ __global__ void __launch_bounds__(256) permute_rows4_kernel(const unsigned short
 #pragma unroll
                 for (int w = 0; w < 4; ++w) o[w] = __builtin_amdgcn_perm(g[2 * w + 1][h], g[2 * w][h], sel);
             }
-            __builtin_nontemporal_store(o, (u32x4*)(out + (size_t)(m0 + r) * K + i));
+            // plain stores: the GEMM behind this pass reads the permuted x at once -- written around the caches (nontemporal, round 4) the 45 MB of a K = 11008
+            // call came back from HBM and cost the stream-K prefill kernel 7 us per layer call (profiles/r05_wide_sk_ab_v4.log); the pass itself is no slower
+            *(u32x4*)(out + (size_t)(m0 + r) * K + i) = o;
         }
     }
 }
@@ -2075,20 +2077,6 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
         }
         if (pl.tail) pl.workspace_bytes = pl.xperm_bytes + ((size_t)pl.tail << pl.tail_lg) * (32 * 256 * 16);
     }
-    // The 128 x 128 wave tile as a stream-K partition of 128 x 256 tiles (gemm_wide_sk.hip): every CU runs the same number of 128-deep K-chunks whatever the tile
-    // count -- BASELINE config 3 (M = 2048: 256 / 688 / 256 tiles on the three Llama-7B shapes).  Decode-copy layers only (act-order: x permuted in natural order).
-    if (pl.mt == 4 && pl.bk == 64 && pl.variant == 0 && wide_knob == 0 && tail_knob == 0 && sk_knob != GPTQ_LAB_VARIANT_WIDE_SK_OFF && L.N % GPTQ_STRIP_COLS == 0 &&
-        !(tune && tune->ksplit > 0 && tune->path == 3 && tune->ksplit != 1) && wide_sk_ok(L, M)) {
-        if (sk_knob == GPTQ_LAB_VARIANT_WIDE_SK_ON || wide_sk_pays(L, M)) {
-            pl.wsk = true;
-            pl.wskg = wide_sk_geom(L, M);
-            pl.wide = false; pl.wide_tiled = true; pl.xnat = pl.use_seq; pl.xslot = false; pl.glds = true;
-            pl.tail = 0; pl.tail_lg = 0; pl.ksplit = 1; pl.ksteps_per_split = pl.ksteps_total; pl.kg = 2;
-            pl.bn = 256; pl.nbm = pl.wskg.nbm; pl.nbn = pl.wskg.nbn;
-            pl.workspace_bytes = pl.xperm_bytes + pl.wskg.slot_bytes;
-            return pl;
-        }
-    }
     // 128 x 512 tiles with a 128 x 128 tile per wave (gemm_wide.hip) where they fill the chip: whole rounds of 256, or enough rounds that the last one
     // hardly matters (tools/widelab, us per layer, 128 x 256 -> 128 x 512: M = 4096 on 4096^2 131.5 -> 122.8 (256 tiles), 11008x4096 337 -> 314 (256),
     // 4096x11008 360 -> 342 (704); M = 2048 on 4096x11008 (352 tiles = 1.4 rounds) 187 -> 214 and on 4096^2 (128 tiles) 67 -> 102: those stay here)
@@ -2102,6 +2090,20 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
         const bool copy_ok = L.qweight_tiled != nullptr && L.tiled_cols == GPTQ_STRIP_COLS && L.N % GPTQ_STRIP_COLS == 0 && wide_knob != GPTQ_LAB_VARIANT_WIDE_ROWS && wide_knob != GPTQ_LAB_VARIANT_WIDE_ROWS_ON;
         pl.wide = wide_knob != GPTQ_LAB_VARIANT_WIDE_OFF && (fills || wide_knob == GPTQ_LAB_VARIANT_WIDE_ON || wide_knob == GPTQ_LAB_VARIANT_WIDE_ROWS_ON) && pl.mt == 4 && pl.bk == 64 && pl.ksplit == 1 && pl.variant == 0 && tail_knob == 0 &&
                   (wide_gemm_ok(L, M, pl.use_seq, pl.xslot && pl.glds) || (copy_ok && wide_gemm_ok(L, M, false, false)));
+        // The same wave tile as a stream-K partition of 128 x 256 tiles (gemm_wide_sk.hip) everywhere else from ~768 rows: every CU runs the same number of
+        // 128-deep K-chunks whatever the tile count -- BASELINE config 3 (M = 2048: 256 / 688 / 256 tiles on the three Llama-7B shapes).  Decode-copy layers
+        // only (act-order: x permuted in natural order).
+        if (pl.mt == 4 && pl.bk == 64 && pl.variant == 0 && wide_knob == 0 && tail_knob == 0 && sk_knob != GPTQ_LAB_VARIANT_WIDE_SK_OFF && copy_ok &&
+            !(tune && tune->ksplit > 0 && tune->path == 3 && tune->ksplit != 1) && wide_sk_ok(L, M) &&
+            (sk_knob == GPTQ_LAB_VARIANT_WIDE_SK_ON || (!pl.wide && wide_sk_pays(L, M)))) {
+            pl.wsk = true;
+            pl.wskg = wide_sk_geom(L, M);
+            pl.wide = false; pl.wide_tiled = true; pl.xnat = pl.use_seq; pl.xslot = false; pl.glds = true;
+            pl.tail = 0; pl.tail_lg = 0; pl.ksplit = 1; pl.ksteps_per_split = pl.ksteps_total; pl.kg = 2;
+            pl.bn = 256; pl.nbm = pl.wskg.nbm; pl.nbn = pl.wskg.nbn;
+            pl.workspace_bytes = pl.xperm_bytes + pl.wskg.slot_bytes;
+            return pl;
+        }
         if (pl.wide) {
             pl.wide_tiled = copy_ok;
             pl.xnat = pl.wide_tiled && pl.use_seq;

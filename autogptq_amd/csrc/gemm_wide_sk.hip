@@ -10,9 +10,9 @@
 // A unit = one K-chunk pair: chunk j of part 0 and chunk upt + j of part 1 (upt = K / 256 units per tile).  Workgroup b runs units
 // [b U / G, (b + 1) U / G) in ascending (tile, j) order.  A tile cut between workgroups is finished by the workgroup that holds its HEAD piece (j = 0 ...) --
 // which it reaches LAST in its range -- while every other piece is the FIRST thing its workgroup runs: that workgroup publishes its fp32 accumulators
-// (write-through stores, 64 KiB per wave) and raises a flag without ever waiting for anybody, so a finisher only waits for workgroups that have nothing
+// (the two K parts already summed: write-through stores, 32 KiB per wave) and raises a flag without ever waiting for anybody, so a finisher only waits for workgroups that have nothing
 // in front of their publish (no residency assumption beyond "every workgroup is eventually scheduled"; the grid is one workgroup per CU anyway).  Sums
-// are formed in a fixed order (own part + partner part through LDS, then the published pieces in range order, part 0 before part 1): bit-reproducible.
+// are formed in a fixed order (part 0 + part 1 of every piece through LDS, then the published pieces in range order): bit-reproducible.
 // The last row tile is SHIFTED UP to end at row M (m0 = M - 128) instead of clamping rows: no x address of the DMA ever needs a per-lane clamp (M >= 128);
 // the overlapped rows are computed twice and stored once, by the tile they belong to.
 // Weights: the layer's decode copy (gptq_prepack_decode), raw x by LDS DMA, the exact magic-number dequant -- the loop body is gemm_wide_kernel<T, true,
@@ -40,13 +40,15 @@ struct WskParams {
     unsigned max_spins;
     unsigned long long kpg_inv;   // ceil(2^32 / (group_size / 64)): group of K-step kt = (kt * kpg_inv) >> 32
     unsigned* flags;              // workspace header: [workgroup] "my piece is published"; zero before and after every launch
-    float* slots;                 // [workgroup][wave][64 quads][64 lanes] float4: the accumulators of a published piece
+    float* slots;                 // [workgroup][wave][32 quads][64 lanes] float4: the 64-row sums (both K parts) of a published piece
     unsigned* err;                // sticky error word: a bounded wait gave up
 };
 
 constexpr int WSK_XT_BYTES = 128 * 128;                       // one x tile: 128 rows x 64 k x 2 bytes
-constexpr int WSK_LDS_BYTES = 4 * 32768;                      // the exchange area (4 waves x 32 KiB) over the four x tiles (2 buffers x 2 K parts x 16 KiB)
-constexpr size_t WSK_SLOT_FLOATS = (size_t)4 * 64 * 64 * 4;   // one workgroup's published piece: 256 KiB
+constexpr int WSK_EX_OFFSET = 4 * WSK_XT_BYTES;               // the four x tiles (2 buffers x 2 K parts x 16 KiB) ...
+constexpr int WSK_LDS_BYTES = WSK_EX_OFFSET + 4 * 16384;      // ... and the exchange area behind them (4 waves x 16 KiB per pass)
+constexpr size_t WSK_WAVE_SLOT_FLOATS = (size_t)32 * 64 * 4;  // a wave's half of its 128 x 128 tile, the two K parts summed: 32 KiB
+constexpr size_t WSK_SLOT_FLOATS = 4 * WSK_WAVE_SLOT_FLOATS;   // one workgroup's published piece: 128 KiB
 
 template <typename T, bool G128>
 __global__ void __launch_bounds__(256, 1) gemm_wide_sk_kernel(WskParams p) {
@@ -85,7 +87,9 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_sk_kernel(WskParams p) {
     int kt_last = 0;
 
     auto dma_a4 = [&](int kt, int buf, int q) {                // DMAs 4 q .. 4 q + 3 of the wave's eight
-        const char* sb = a_tile + (size_t)kt * 128 + (size_t)(cw * 8 + q * 4) * a_grp_bytes;
+        // LDS rows 8 j .. 8 j + 7 (j = 8 cw + 4 q + i) take the rows of 32-row block j / 4 -- of block 3 - j / 4 for K part 1 (finish() relies on it)
+        const int j0 = cw * 8 + q * 4;
+        const char* sb = a_tile + (size_t)kt * 128 + (size_t)((kp ? 3 - (j0 >> 2) : (j0 >> 2)) * 4) * a_grp_bytes;
         const unsigned l0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem + (size_t)(buf * 2 + kp) * WSK_XT_BYTES + (size_t)(cw * 8 + q * 4) * 1024));
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\t"
@@ -160,9 +164,9 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_sk_kernel(WskParams p) {
             if (ks == 0) {                                     // next step's weights + constants: under MFMA group 0
                 load_b(ktn, b_fill);
                 if constexpr (NEWG) load_c(ktn, c_fill);
-            }
-            if (ks == 1) dma_a4(ktn, BUF ^ 1, 0);              // next step's x tile: under groups 1 and 2
-            if (ks == 2) dma_a4(ktn, BUF ^ 1, 1);
+                dma_a4(ktn, BUF ^ 1, 0);                       // the next step's x tile: behind the weight loads and inside group 1 (in groups 1 and 2 the
+            }                                                  // second half lands too late: the compiler's wait for the weights, in front of group 3's
+            if (ks == 1) dma_a4(ktn, BUF ^ 1, 1);              // VALU work, is a vmcnt(0) that covers the DMAs as well: +5 % measured)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -184,100 +188,138 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_sk_kernel(WskParams p) {
         __syncthreads();
     };
 
-    // exchange + output of a finished tile: this wave keeps row tiles OWN .. OWN + 1 and hands the other two to its partner (same columns, other K part)
-    auto finish = [&](auto ownc, int m0, int m_lo, int bn, int lane_e, int nb) {
-        constexpr int OWN = decltype(ownc)::value, OTHER = 2 - OWN;
+    // End of a segment.  K part 1 keeps its x tile with the four 32-row blocks in REVERSED order (dma_a4), so its accumulators acc[mt] belong to row block
+    // 3 - mt: in register terms every wave keeps acc[0..1] and hands acc[2..3] to its partner (same columns, other K part) through LDS -- one code path
+    // for both K parts (a branch over which accumulators to read makes hipcc copy all 256 out of the AGPRs behind the K loop and spill them).  Two passes
+    // of 16 KiB per wave (acc[3] -> the partner's acc[0], then acc[2] -> its acc[1]): the exchange area does not alias the x tiles, whose first buffer
+    // is already being filled for the next segment.
+    // pub: the piece is a later part of a tile another workgroup finishes -- the 64-row sums of the two K parts go to this workgroup's slot (write-through
+    // stores, 32 KiB per wave).  Else the published pieces of the tile (workgroups Lb + 1 .. Lb + nb, in range order) are added and the outputs stored.
+    auto finish = [&](bool pub, int m0, int m_lo, int bn, int lane_e, int nb) {
         const int half_e = lane_e >> 5;
         const int n = bn * 256 + cw * 128 + 4 * (lane_e & 31);
         const bool col_ok = n < p.N;
-        char* const ex_mine = smem + (size_t)wave * 32768;
-        const char* const ex_partner = smem + (size_t)(wave ^ 2) * 32768;
+        char* const ex_mine = smem + WSK_EX_OFFSET + (size_t)wave * 16384 + (size_t)lane_e * 16;
+        const char* const ex_partner = smem + WSK_EX_OFFSET + (size_t)(wave ^ 2) * 16384 + (size_t)lane_e * 16;
+        float bias[NT] = {0.f, 0.f, 0.f, 0.f};
+        if (!pub && p.bias && col_ok) {
 #pragma unroll
-        for (int mtl = 0; mtl < 2; ++mtl)
+            for (int nt = 0; nt < NT; ++nt) bias[nt] = DType<T>::to_f32(((const T*)p.bias)[n + nt]);
+        }
+        float* const my_slot = p.slots + ((size_t)Lb * 4 + wave) * WSK_WAVE_SLOT_FLOATS + (size_t)lane_e * 4;
+#pragma unroll
+        for (int mtl = 0; mtl < 2; ++mtl) {
+            const int rb = kp ? 3 - mtl : mtl;                 // the 32-row block acc[mtl] holds
+            if (mtl == 1) __syncthreads();                     // pass 0's values have been read
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
-                    const f32x16& a = acc[OTHER + mtl][nt];
+                    const f32x16& a = acc[3 - mtl][nt];        // the partner's acc[mtl] is the same row block
                     const f32x4 v = {a[rq * 4], a[rq * 4 + 1], a[rq * 4 + 2], a[rq * 4 + 3]};
-                    *(f32x4*)(ex_mine + (size_t)((((mtl * NT + nt) * 4 + rq) * 64 + lane_e) * 16)) = v;
+                    *(f32x4*)(ex_mine + (size_t)((nt * 4 + rq) * 1024)) = v;
                 }
-        __syncthreads();                                       // ... and thread 0's flag waits are behind everybody
-        float bias[NT] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && col_ok) {
+            __syncthreads();                                   // ... and (pass 0) the finisher's flag waits are behind everybody
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bias[nt] = DType<T>::to_f32(((const T*)p.bias)[n + nt]);
-        }
+            for (int rp = 0; rp < 2; ++rp) {                   // two row quads (8 rows x 4 columns per lane) at a time
+                f32x4 v[2][NT];
 #pragma unroll
-        for (int mtl = 0; mtl < 2; ++mtl) {
-            const int mt = OWN + mtl;
+                for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                f32x4 v[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const f32x16& a = acc[OWN + mtl][nt];
-                    const f32x4 mine = {a[rq * 4], a[rq * 4 + 1], a[rq * 4 + 2], a[rq * 4 + 3]};
-                    const f32x4 theirs = *(const f32x4*)(ex_partner + (size_t)((((mtl * NT + nt) * 4 + rq) * 64 + lane_e) * 16));
-                    v[nt] = (OWN == 0) ? (mine + theirs) : (theirs + mine);      // part 0 + part 1 on both sides (fp32 addition commutes: written for the reader)
-                }
-                for (int s = 0; s < nb; ++s) {                 // published pieces, in range order, part 0 before part 1
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        const float* slot = p.slots + ((size_t)(Lb + 1 + s) * 4 + (size_t)(kk * 2 + cw)) * (64 * 64 * 4);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {      // agent-scope loads: they bypass this XCD's non-coherent L2 lines
-                            const unsigned long long* src = (const unsigned long long*)(slot + (size_t)((((mt * NT + nt) * 4 + rq) * 64 + lane_e) * 4));
-                            const unsigned long long w0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const unsigned long long w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            v[nt][0] += __builtin_bit_cast(float, (unsigned)w0);
-                            v[nt][1] += __builtin_bit_cast(float, (unsigned)(w0 >> 32));
-                            v[nt][2] += __builtin_bit_cast(float, (unsigned)w1);
-                            v[nt][3] += __builtin_bit_cast(float, (unsigned)(w1 >> 32));
-                        }
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int rq = rp * 2 + r2;
+                        const f32x16& a = acc[mtl][nt];
+                        const f32x4 mine = {a[rq * 4], a[rq * 4 + 1], a[rq * 4 + 2], a[rq * 4 + 3]};
+                        const f32x4 theirs = *(const f32x4*)(ex_partner + (size_t)((nt * 4 + rq) * 1024));
+                        v[r2][nt] = mine + theirs;             // fp32 a + b == b + a: the same bits whichever K part this wave is
                     }
-                }
-                if (col_ok) {
+                if (pub) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {              // C/D layout of the 32x32 MFMA: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), r = 4 rq + i
-                        const int m = m0 + mt * 32 + i + 8 * rq + 4 * half_e;
-                        if (m < m_lo) continue;                // the shifted last row tile stores only its own rows (the rows above belong to the tile before it)
-                        const unsigned lo = (unsigned)t_bits(DType<T>::from_f32(v[0][i] + bias[0])) | ((unsigned)t_bits(DType<T>::from_f32(v[1][i] + bias[1])) << 16);
-                        const unsigned hi = (unsigned)t_bits(DType<T>::from_f32(v[2][i] + bias[2])) | ((unsigned)t_bits(DType<T>::from_f32(v[3][i] + bias[3])) << 16);
-                        *(u32x2*)((unsigned short*)p.out + (size_t)m * p.N + n) = u32x2{lo, hi};
+                    for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            // s_nop inside the string: nothing is padded behind an asm statement, and the next instruction may overwrite the data registers
+                            // (dead to the compiler) while the store still reads them (gemm.hip, tools/tail_diag.py)
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(my_slot + (size_t)(((mtl * 4 + rp * 2 + r2) * NT + nt) * 256)), "v"(v[r2][nt]) : "memory");
+                        }
+                } else {
+                    for (int s = 0; s < nb; ++s) {             // published pieces, in range order: 8 x 16-byte loads in flight per lane
+                        const float* slot = p.slots + ((size_t)(Lb + 1 + s) * 4 + wave) * WSK_WAVE_SLOT_FLOATS + (size_t)lane_e * 4;
+                        unsigned long long w[2][NT][2];
+#pragma unroll
+                        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {  // agent-scope loads: they bypass this XCD's non-coherent L2 lines
+                                const unsigned long long* src = (const unsigned long long*)(slot + (size_t)(((mtl * 4 + rp * 2 + r2) * NT + nt) * 256));
+                                w[r2][nt][0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                w[r2][nt][1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+#pragma unroll
+                        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                v[r2][nt][0] += __builtin_bit_cast(float, (unsigned)w[r2][nt][0]);
+                                v[r2][nt][1] += __builtin_bit_cast(float, (unsigned)(w[r2][nt][0] >> 32));
+                                v[r2][nt][2] += __builtin_bit_cast(float, (unsigned)w[r2][nt][1]);
+                                v[r2][nt][3] += __builtin_bit_cast(float, (unsigned)(w[r2][nt][1] >> 32));
+                            }
+                    }
+                    if (col_ok) {
+#pragma unroll
+                        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {      // C/D layout of the 32x32 MFMA: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), r = 4 rq + i
+                                const int m = m0 + rb * 32 + i + 8 * (rp * 2 + r2) + 4 * half_e;
+                                if (m < m_lo) continue;        // the shifted last row tile stores only its own rows (the rows above belong to the tile before it)
+                                const unsigned lo = (unsigned)t_bits(DType<T>::from_f32(v[r2][0][i] + bias[0])) | ((unsigned)t_bits(DType<T>::from_f32(v[r2][1][i] + bias[1])) << 16);
+                                const unsigned hi = (unsigned)t_bits(DType<T>::from_f32(v[r2][2][i] + bias[2])) | ((unsigned)t_bits(DType<T>::from_f32(v[r2][3][i] + bias[3])) << 16);
+                                *(u32x2*)((unsigned short*)p.out + (size_t)m * p.N + n) = u32x2{lo, hi};
+                            }
                     }
                 }
             }
         }
+        if (pub) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every publishing wave drains its write-through stores
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(p.flags + Lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     };
 
-    for (;;) {                                                 // segments: the pieces of tiles inside [u0, u1)
-        const int t = u0 / p.upt;
-        const int j0 = u0 - t * p.upt;
-        const int len = min(p.upt - j0, u1 - u0);
-        const int bm = t / p.nbn, bn = t - bm * p.nbn;
-        const int m0 = min(bm * 128, p.M - 128);
+    // Segments: the pieces of tiles inside [u0, u1).  open_segment() sets the per-tile state of the segment starting at u0 and ISSUES its first loads (x tile
+    // of the first step into buffer 0, weights and constants into b0 / c0); it is called for segment s + 1 between the K loop and the epilogue of segment s,
+    // so that the memory latency of a segment's first step lies under the previous segment's exchange and stores.
+    int t = 0, j0 = 0, len = 0, bm = 0, bn = 0, m0 = 0, kt0 = 0, kt1 = 0;
+    auto open_segment = [&]() {
+        t = u0 / p.upt;
+        j0 = u0 - t * p.upt;
+        len = min(p.upt - j0, u1 - u0);
+        bm = t / p.nbn;
+        bn = t - bm * p.nbn;
+        m0 = min(bm * 128, p.M - 128);
         const int n = bn * 256 + cw * 128 + 4 * l31;          // this lane's first column (it owns n .. n + 3)
-        const bool col_ok = n < p.N;                           // N % 32 == 0: a lane's 4 columns are in or out together
-        const int nl = col_ok ? n : 0;
+        const int nl = n < p.N ? n : 0;                        // N % 32 == 0: a lane's 4 columns are in or out together
         a_tile = (const char*)p.x + (size_t)m0 * p.K * 2;
         b_lane_off = ((unsigned)nl >> 4) * (unsigned)p.chunks * 1024u + (unsigned)half * 256u + ((unsigned)nl & 15u) * 16u;    // strip, k-slot, column
         s_lane_off = (unsigned)nl * 2u;
         z_lane_off = ((unsigned)nl >> 3) * 4u;
         zsh = ((unsigned)nl & 7u) * 4u;
-        const int kt0 = 2 * (kp * p.upt + j0), kt1 = kt0 + 2 * len;
+        kt0 = 2 * (kp * p.upt + j0);
+        kt1 = kt0 + 2 * len;
         kt_last = kt1 - 1;
-
+        dma_a4(kt0, 0, 0);
+        dma_a4(kt0, 0, 1);
+        load_b(kt0, b0);
+        load_c(kt0, c0);
+    };
+    open_segment();
+    for (;;) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-        dma_a4(kt0, 0, 0);
-        dma_a4(kt0, 0, 1);
-        load_b(kt0, b0);
-        load_c(kt0, c0);
         wait_vmcnt<0>();
         __syncthreads();
         dq_cur.setup(c0, zsh, zmask);
@@ -289,52 +331,35 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_sk_kernel(WskParams p) {
             step(kt + 1, std::integral_constant<int, 1>{}, b1, b0, c0);
         }
 
-        // everything the epilogues address is derived from this copy of the lane id, which the compiler cannot see through: their ~130 address
+        // the finished piece, then the next segment's first loads, then the piece's epilogue
+        const int e_t = t, e_m0 = m0, e_mlo = bm * 128, e_bn = bn;
+        const bool head = j0 == 0, complete = j0 + len == p.upt;
+        u0 += len;
+        const bool more = u0 < u1;
+        if (more) open_segment();
+        // everything the epilogue addresses is derived from this copy of the lane id, which the compiler cannot see through: its ~100 address
         // computations are loop invariants it would otherwise hoist over the K loop and spill (all 512 registers are taken there)
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        const bool head = j0 == 0, complete = j0 + len == p.upt;
-        if (!head) {
-            // a later piece of a tile somebody else finishes: publish, drain the write-through stores, raise the flag -- no wait on anybody
-            float* const slot = p.slots + ((size_t)Lb * 4 + wave) * (64 * 64 * 4);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        const f32x16& a = acc[mt][nt];
-                        const f32x4 v = {a[rq * 4], a[rq * 4 + 1], a[rq * 4 + 2], a[rq * 4 + 3]};
-                        // s_nop inside the string: nothing is padded behind an asm statement, and the next instruction may overwrite the data registers
-                        // (dead to the compiler) while the store still reads them (gemm.hip, tools/tail_diag.py)
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(slot + (size_t)((((mt * NT + nt) * 4 + rq) * 64 + lane_e) * 4)), "v"(v) : "memory");
-                    }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(p.flags + Lb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            int nb = 0;                                         // published pieces of this tile: workgroups Lb + 1 .. Lb + nb
-            if (!complete) {
-                const int te = (t + 1) * p.upt;
-                int b = Lb + 1;
-                while (range_start(b + 1) < te) ++b;
-                nb = b - Lb;
-                if (tid < nb) {                                 // bounded waits (the publishers have nothing in front of their publish)
-                    unsigned* const f = p.flags + Lb + 1 + tid;
-                    for (unsigned spins = 0;; ++spins) {
-                        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                        if (spins > p.max_spins) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                    __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int nb = 0;                                             // published pieces of this tile: workgroups Lb + 1 .. Lb + nb
+        if (head && !complete) {
+            const int te = (e_t + 1) * p.upt;
+            int b = Lb + 1;
+            while (range_start(b + 1) < te) ++b;
+            nb = b - Lb;
+            if (tid < nb) {                                     // bounded waits (the publishers have nothing in front of their publish)
+                unsigned* const f = p.flags + Lb + 1 + tid;
+                for (unsigned spins = 0;; ++spins) {
+                    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                    if (spins > p.max_spins) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(2);
                 }
+                __hip_atomic_store(f, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (kp == 0) finish(std::integral_constant<int, 0>{}, m0, bm * 128, bn, lane_e, nb);
-            else finish(std::integral_constant<int, 2>{}, m0, bm * 128, bn, lane_e, nb);
         }
-        u0 += len;
-        if (u0 >= u1) break;
-        __syncthreads();                                       // the exchange area is the next segment's x tiles
+        // a later piece of a tile somebody else finishes is published without waiting for anybody; the head piece's holder finishes the tile
+        finish(!head, e_m0, e_mlo, e_bn, lane_e, nb);
+        if (!more) break;
     }
 }
 
@@ -348,8 +373,15 @@ bool wide_sk_ok(const gptq_layer_t& L, int M) {
     return M >= 128;
 }
 
-// Provisional rule (round 5, before the sweep of tools/wide_sk_ab.py): prefill row counts.
-bool wide_sk_pays(const gptq_layer_t& L, int M) { return wide_sk_ok(L, M) && M >= 1024; }
+// Measured preference over the whole-tile kernels (tools/wide_sk_ab.py, profiles/r05_wide_sk_sweep.log: layer call incl. the x permute of act-order layers, us,
+// 128 x 256 tiles -> this, M = 2048: 4096^2 69.2 -> 63.5 (act-order 75.4 -> 71.2), 4096x11008 202.9 -> 178.7 (200.5 -> 191.0), 11008x4096 175.6 -> 163.3
+// (191.4 -> 182.6); 1.03 - 1.28x from 768 rows up on every shape, 0.87 - 0.89x at 512 rows on 4096^2 (each tile cut in four) and 1.06 - 1.12x there on the
+// two large shapes).  Where whole 128 x 512 tiles fill their rounds (M = 4096 / 8192 on these shapes) gemm_wide_kernel stays: 0.90 - 1.00x -- the
+// caller (plan_gemm) asks that first.
+bool wide_sk_pays(const gptq_layer_t& L, int M) {
+    if (!wide_sk_ok(L, M)) return false;
+    return M >= 768 || (M >= 512 && (size_t)L.K * L.N >= ((size_t)32 << 20));
+}
 
 WideSkGeom wide_sk_geom(const gptq_layer_t& L, int M) {
     WideSkGeom g{};
@@ -360,7 +392,7 @@ WideSkGeom wide_sk_geom(const gptq_layer_t& L, int M) {
     g.units_total = (int)units;
     g.lg_nwg = 8;                                             // one workgroup per CU
     while (g.lg_nwg > 0 && (1L << g.lg_nwg) > units) --g.lg_nwg;
-    // does any range boundary fall inside a tile?  (then pieces are published: 256 KiB per workgroup behind the permuted x)
+    // does any range boundary fall inside a tile?  (then pieces are published: 128 KiB per workgroup behind the permuted x)
     bool cut = false;
     for (int b = 1; b < (1 << g.lg_nwg) && !cut; ++b) cut = (((long)b * units) >> g.lg_nwg) % g.upt != 0;
     g.slot_bytes = cut ? ((size_t)1 << g.lg_nwg) * wide::WSK_SLOT_FLOATS * sizeof(float) : 0;
@@ -370,6 +402,10 @@ WideSkGeom wide_sk_geom(const gptq_layer_t& L, int M) {
 template <typename T, bool G128>
 static hipError_t grant_wsk() {
     return hipFuncSetAttribute((const void*)wide::gemm_wide_sk_kernel<T, G128>, hipFuncAttributeMaxDynamicSharedMemorySize, wide::WSK_LDS_BYTES);
+}
+template <typename T, bool G128>
+static void launch_wsk(dim3 grid, dim3 block, hipStream_t st, const wide::WskParams& p) {
+    hipLaunchKernelGGL((wide::gemm_wide_sk_kernel<T, G128>), grid, block, wide::WSK_LDS_BYTES, st, p);
 }
 hipError_t init_gemm_wide_sk_device() {
     hipError_t e = grant_wsk<f16, true>();
@@ -398,11 +434,11 @@ hipError_t launch_gemm_wide_sk(const gptq_layer_t& L, const void* x, void* out, 
     const dim3 grid(1 << g.lg_nwg), block(256);
     const bool g128 = L.group_size % 128 == 0;
     if (L.dtype == GPTQ_F16) {
-        if (g128) hipLaunchKernelGGL((wide::gemm_wide_sk_kernel<f16, true>), grid, block, wide::WSK_LDS_BYTES, st, p);
-        else hipLaunchKernelGGL((wide::gemm_wide_sk_kernel<f16, false>), grid, block, wide::WSK_LDS_BYTES, st, p);
+        if (g128) launch_wsk<f16, true>(grid, block, st, p);
+        else launch_wsk<f16, false>(grid, block, st, p);
     } else {
-        if (g128) hipLaunchKernelGGL((wide::gemm_wide_sk_kernel<bf16, true>), grid, block, wide::WSK_LDS_BYTES, st, p);
-        else hipLaunchKernelGGL((wide::gemm_wide_sk_kernel<bf16, false>), grid, block, wide::WSK_LDS_BYTES, st, p);
+        if (g128) launch_wsk<bf16, true>(grid, block, st, p);
+        else launch_wsk<bf16, false>(grid, block, st, p);
     }
     return hipGetLastError();
 }

@@ -121,6 +121,11 @@ def test_config5_int3_int8_g32_llama7b_shapes(bits, K, N, dtype, act):
 def test_config3_int4_g128_desc_act_prefill_2048(K, N, dtype):
     """BASELINE config 3: int4 g128 desc_act=True, seq_len 2048 prefill on all three Llama-7B shapes (the tiled MFMA
     kernel with the group-sorted weight copy and permuted x), plus the decode / batched-decode row counts."""
+    from autogptq_amd import _lib
+    _, q, _, _ = _layer(4, 128, K, N, True, dtype)
+    plan = _lib.describe_plan(q._layer, 2048)
+    # round 5: the stream-K form of the 128 x 128 wave tile on the decode copy (csrc/gemm_wide_sk.hip), x permuted in natural order by the pre-pass
+    assert plan["kernel"] == "wide_sk" and plan["perm"] == 1 and plan["tiles"] == f"16x{N // 256}", plan
     for M in (2048, 1, 8, 64):
         _check(4, 128, K, N, M, True, dtype)
 

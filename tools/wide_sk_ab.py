@@ -16,14 +16,15 @@ ap.add_argument("--dtype", default="f16")
 ap.add_argument("--act", default="0,1")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--layers", type=int, default=6)
+ap.add_argument("--dv", default="0", help="lab: DMA placement variants of the stream-K kernel to time (tuning.reserved[0])")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 dt = torch.float16 if a.dtype == "f16" else torch.bfloat16
 
 
-def tune(v):
+def tune(v, dv=0):
     t = _lib.GptqTuning()
-    t.path, t.reserved[3] = 3, v
+    t.path, t.reserved[3], t.reserved[0] = 3, v, dv
     return t
 
 
@@ -43,14 +44,14 @@ for shp in a.shapes.split(","):
             best = {}
             names = {}
             for _ in range(a.rounds):
-                for name, v in (("without", 49), ("stream-K", 48)):
-                    t = tune(v)
+                for name, v, dv in [("without", 49, 0)] + [("stream-K" + (f" dv{d}" if d else ""), 48, int(d)) for d in a.dv.split(",")]:
+                    t = tune(v, dv)
                     names[name] = _lib.describe_plan(ls[0]._layer, M, t).get("kernel")
                     s = run(ls, x, t, reps=3)
                     best[name] = min(best.get(name, 1e9), s)
             d = _lib.describe_plan(ls[0]._layer, M)
-            w, s = best["without"], best["stream-K"]
-            print(f"{K}x{N} M={M:5d} {a.dtype} act={act} default={d.get('kernel'):9s} | without [{names['without']:9s}] {w * 1e6:8.1f} us {2 * M * K * N / w / 1e12:6.0f} TF | "
-                  f"stream-K {s * 1e6:8.1f} us {2 * M * K * N / s / 1e12:6.0f} TF | {w / s:5.2f}x", flush=True)
+            w = best.pop("without")
+            print(f"{K}x{N} M={M:5d} {a.dtype} act={act} default={d.get('kernel'):9s} | without [{names['without']:9s}] {w * 1e6:8.1f} us {2 * M * K * N / w / 1e12:6.0f} TF | " +
+                  " | ".join(f"{k} {s * 1e6:8.1f} us {2 * M * K * N / s / 1e12:6.0f} TF {w / s:5.2f}x" for k, s in best.items()), flush=True)
             del x
         del ls
