@@ -243,14 +243,17 @@ class PeerExchange:
         return out
 
     def fused_ok(self, qlinear, M: int) -> bool:
-        """Can ``forward_gather`` run this shard?  (The scatter is the epilogue of the decode-copy kernel: M <= 4, a plain 3/4/8-bit layer with its copy.)"""
+        """Can ``forward_gather`` run this shard?  Mirrors gptq_forward_scatter's own preconditions (csrc/capi.hip): the scatter is the epilogue of the
+        decode-copy kernel -- M <= 4, a PLAIN (no act-order: the gather-through-perm form has no scatter epilogue) 3/4/8-bit layer with its copy."""
+        if qlinear._layer is None:
+            qlinear.post_init()
         return (M <= 4 and getattr(qlinear, "_qweight_tiled", None) is not None and getattr(qlinear, "epilogue", "none") == "none"
-                and qlinear.outfeatures * self.world == self.N and qlinear.scales.dtype == self.dtype)
+                and not qlinear.act_order and qlinear.outfeatures * self.world == self.N and qlinear.scales.dtype == self.dtype)
 
     def forward_gather(self, qlinear, x2: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x2 [M, K] -> [M, N]: the rank's column shard ``qlinear`` (an mi355x QuantLinear) computes its slice and stores it into every rank's
         exchange buffer from its own epilogue (gptq_forward_scatter), then ONE collect launch.  Two launches per tensor-parallel layer."""
-        from .qlinear_mi355x import reserve_workspace
+        from .qlinear_mi355x import exchange_tick, reserve_workspace
 
         if qlinear._layer is None:
             qlinear.post_init()
@@ -263,6 +266,7 @@ class PeerExchange:
         if need:
             buf = reserve_workspace(self.device, need)
             ws_ptr, ws_bytes = buf.data_ptr(), buf.numel()
+            exchange_tick(self.device)
         st = _lib.current_stream_handle(self.device)
         _lib.check(lib.gptq_forward_gather(ctypes.byref(qlinear._layer), x2.data_ptr(), out.data_ptr(), M, ctypes.byref(self.pg), self.max_spins,
                                            ws_ptr, ws_bytes, st))

@@ -283,19 +283,7 @@ class QuantLinear(nn.Module):
         if need == 0:
             return None, 0
         buf = reserve_workspace(device, need)
-        # Calls that take a workspace are the ones with an in-launch exchange (K slices, balanced tail): every EXCHANGE_CHECK_EVERY of them the sticky
-        # error word of the workspace is read (a device -> host read: a sync point, hence periodic; never inside a stream capture).  A bounded wait that
-        # gave up has produced a wrong result somewhere since the last check -- it must not pass silently.
-        n = QuantLinear._exchange_calls = QuantLinear._exchange_calls + 1
-        every = QuantLinear.EXCHANGE_CHECK_EVERY
-        if every and n % every == 0 and not torch.cuda.is_current_stream_capturing():
-            try:
-                bad = exchange_error(device)
-            except RuntimeError:                # e.g. another thread is capturing in global mode: a synchronising read is not allowed now -- next time
-                bad = False
-            if bad:
-                raise RuntimeError("gptq_mi355x: a bounded wait of an in-launch exchange gave up (another client kept part of the GPU busy?): at least one result "
-                                   "since the last check is wrong; see exchange_error()")
+        exchange_tick(device)
         return buf.data_ptr(), buf.numel()
 
     def forward(self, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = None):
@@ -553,6 +541,7 @@ def forward_multi(layers, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = No
         if need:
             buf = reserve_workspace(dev, need)
             ws_ptr, ws_bytes = buf.data_ptr(), buf.numel()
+            exchange_tick(dev)
         for i in range(n):
             optrs[i] = outs[i].data_ptr()
         fast = _lib.fast
@@ -619,6 +608,7 @@ def mlp_forward(gate: QuantLinear, up: QuantLinear, down: QuantLinear, x: torch.
             if tuning is None:
                 need_by_m[M] = need
         buf = reserve_workspace(dev, max(need, 1))
+        exchange_tick(dev)
         idx = gate._dev_index
         fast = _lib.fast
 
@@ -642,7 +632,24 @@ def mlp_forward(gate: QuantLinear, up: QuantLinear, down: QuantLinear, x: torch.
     return out
 
 
-def exchange_error(device=None) -> bool:
+def exchange_tick(device) -> None:
+    """Called by every entry point that hands the kernels a workspace (QuantLinear.forward, forward_multi, mlp_forward, PeerExchange.forward_gather): those
+    are the calls with an in-launch exchange (K slices, balanced tail, stream-K pieces).  Every QuantLinear.EXCHANGE_CHECK_EVERY of them the sticky error
+    word of the workspace is read (a device -> host read: a sync point, hence periodic; never inside a stream capture).  A bounded wait that gave up has
+    produced a wrong result somewhere since the last check -- it must not pass silently.  The word is cleared once reported, so ONE timeout raises once."""
+    n = QuantLinear._exchange_calls = QuantLinear._exchange_calls + 1
+    every = QuantLinear.EXCHANGE_CHECK_EVERY
+    if every and n % every == 0 and not torch.cuda.is_current_stream_capturing():
+        try:
+            bad = exchange_error(device, clear=True)
+        except RuntimeError:                    # e.g. another thread is capturing in global mode: a synchronising read is not allowed now -- next time
+            bad = False
+        if bad:
+            raise RuntimeError("gptq_mi355x: a bounded wait of an in-launch exchange gave up (another client kept part of the GPU busy?): at least one result "
+                               "since the last check is wrong; see exchange_error()")
+
+
+def exchange_error(device=None, clear: bool = False) -> bool:
     """True if a BOUNDED wait of an in-launch exchange (the K-slice combines of the decode and 17..256-row kernels, the balanced tail of the tiled GEMM)
     ever gave up on this device's current-stream workspace: the sticky error word in the workspace header's tail (gptq_mi355x.h).  A launch whose wait
     gave up has produced a wrong result; the kernels never hang instead.  Synchronises the stream."""
@@ -653,10 +660,13 @@ def exchange_error(device=None) -> bool:
         return False
     torch.cuda.synchronize(device)
     tail = ent[0][_lib.WS_HEADER_BYTES - 64:_lib.WS_HEADER_BYTES].view(torch.int32)
-    return bool(tail[2].item() != 0)
+    bad = bool(tail[2].item() != 0)
+    if bad and clear:
+        tail[2] = 0
+    return bad
 
 
 mlp_exchange_error = exchange_error      # round-3 name
 
 
-__all__ = ["QuantLinear", "reserve_workspace", "forward_multi", "mlp_forward", "exchange_error", "mlp_exchange_error"]
+__all__ = ["QuantLinear", "reserve_workspace", "forward_multi", "mlp_forward", "exchange_error", "exchange_tick", "mlp_exchange_error"]

@@ -270,22 +270,43 @@ def time_graph(g, reps, device, dist_barrier=None):
     return t1 - t0, e0.elapsed_time(e1) * 1e-3
 
 
-def pmc_traffic(kernel, K, N, M):
+def pmc_traffic(kernel, K, N, M, exact=False):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE
     passes (profiles/pmc_traffic.json, produced by tools/pmc_traffic.py from separate counter-only runs of this
-    same command; FETCH_SIZE already doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if absent."""
+    same command -- the prefill kernels from one run per shape, tools/session_r05_prof.sh; FETCH_SIZE already doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  exact: the rocprof kernel name has to be THIS template instantiation (the round-4 line
+    reported the int3 kernel's bytes for the 4-bit act-order one: a substring match on "gemm").  None if absent."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
+    norm = lambda t: t.replace(" ", "")
     try:
         with open(path) as f:
             d = json.load(f)
         for ent in d.get("kernels", []):
-            if (ent["kernel"] in kernel or kernel in ent["kernel"]) and ent["K"] == K and ent["N"] == N and ent["M"] == M:
+            same = norm(ent["kernel"]) == norm(kernel) if exact else (ent["kernel"] in kernel or kernel in ent["kernel"])
+            if same and ent["K"] == K and ent["N"] == N and ent["M"] == M:
                 return ent["hbm_bytes_per_launch"]
     except Exception:
         return None
     return None
+
+
+def rocprof_gemm_kernel(plan, dtype="f16", group_size=128):
+    """The name rocprofv3 reports (tools/rocprof_summary.py: demangled, without the argument list) for the prefill kernel of a plan dict
+    (gptq_describe_plan): what profiles/r05_kernel_stats.txt and profiles/pmc_traffic.json key their rows by."""
+    k = plan.get("kernel")
+    g128 = "true" if group_size % 128 == 0 else "false"
+    if k == "wide_sk":
+        return f"gptq::wide::gemm_wide_sk_kernel<{dtype}, {g128}>"
+    if k == "wide_copy":
+        return f"gptq::wide::gemm_wide_kernel<{dtype}, true, true, {g128}>"
+    if k == "wide":
+        return f"gptq::wide::gemm_wide_kernel<{dtype}, {'true' if plan.get('dma') else 'false'}, false, false>"
+    if k == "tiled":
+        dma = "true" if plan.get("dma") else "false"
+        return f"gptq::gemm_kernel<4, {dtype}, {plan.get('mt')}, {plan.get('bk')}, 1, {dma}, {dma}, {plan.get('kg')}, {'true' if plan.get('tail') else 'false'}>"
+    return "gptq::" + str(k)
 
 
 def _time_layers(layers, xs, device, reps):
@@ -319,8 +340,10 @@ def bench_prefill(device, steps):
     _, K, N, per = best
     ach = 2 * M * K * N / per / 1e12
     plan = _plan_of(layers, K, N, M)
+    pd = _plan_dict(layers, K, N, M)
+    kname = rocprof_gemm_kernel(pd)
     roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-            "traffic": pmc_traffic("gemm", K, N, M), "kernel": "gptq::gemm_kernel<4, f16, ...> (%s)" % plan, "shape": f"K={K} N={N} M={M} desc_act",
+            "traffic": pmc_traffic(kname, K, N, M, exact=True), "kernel": kname, "plan": plan, "shape": f"K={K} N={N} M={M} desc_act",
             "us_per_launch_events": round(per * 1e6, 2), "flops_per_launch": 2 * M * K * N,
             "note": "per-launch time is the whole layer call: x permutation (if the plan has a separate pass) + GEMM"}
     del g, outs
@@ -331,11 +354,13 @@ def bench_prefill(device, steps):
     xs2 = {4096: (torch.rand(M2, 4096, device=device) - 0.5).half()}
     per2 = _time_layers(ls, xs2, device, max(2, steps // 2))
     ach2 = 2 * M2 * 4096 * 4096 / per2 / 1e12
+    pd2 = _plan_dict(ls, 4096, 4096, M2)
+    k2 = rocprof_gemm_kernel(pd2)
     out = {"workload": "Llama-7B shapes x 4 blocks, int4 g128 desc_act=True, M=2048 (BASELINE config 3), 28 layers in one hipGraph",
            "TFLOP_s": round(flops_step * steps / ev / 1e12, 1), "ms_per_step": round(1e3 * ev / steps, 3), "tokens_per_s": round(M * steps / ev, 1),
            "by_shape": per_type, "roofline": roof,
            "m4096_4096x4096": {"us_per_launch_events": round(per2 * 1e6, 2), "TFLOP_s": round(ach2, 1), "frac": round(ach2 / MFMA_PEAK_TFLOPS, 4),
-                               "plan": _plan_of(ls, 4096, 4096, M2)}}
+                               "plan": _plan_of(ls, 4096, 4096, M2), "kernel": k2, "traffic": pmc_traffic(k2, 4096, 4096, M2, exact=True)}}
     del ls, xs2
     torch.cuda.empty_cache()
     # row counts that leave a remainder round of 128 x 256 tiles (balanced tail): the planner's default against whole tiles only
@@ -402,14 +427,16 @@ def _kernel_of(ent, M):
             "strips": f"gptq::gemv_tiled_kernel<{q.bits},", "tiled": "gptq::gemm_kernel"}.get(d.get("kernel"), "gptq::" + str(d.get("kernel")))
 
 
-def _plan_of(layers, K, N, M):
-    import ctypes
+def _plan_dict(layers, K, N, M):
     from autogptq_amd import _lib
     for _, k, n, q in layers:
         if (k, n) == (K, N):
-            d = _lib.describe_plan(q._layer, M)
-            return " ".join(f"{a}={b}" for a, b in d.items())
-    return ""
+            return _lib.describe_plan(q._layer, M)
+    return {}
+
+
+def _plan_of(layers, K, N, M):
+    return " ".join(f"{a}={b}" for a, b in _plan_dict(layers, K, N, M).items())
 
 
 def bench_config5(device, steps):
@@ -991,12 +1018,21 @@ def main():
                     roof["prefill_m4096_frac"] = pf["m4096_4096x4096"]["frac"]
                     roof["prefill_m4096_us"] = pf["m4096_4096x4096"]["us_per_launch_events"]
                     roof["prefill_m4096_TFLOP_s"] = pf["m4096_4096x4096"]["TFLOP_s"]
+                    roof["prefill_kernel"] = pf["roofline"]["kernel"]
+                    roof["m4096_frac"], roof["m4096_us"] = pf["m4096_4096x4096"]["frac"], pf["m4096_4096x4096"]["us_per_launch_events"]
+                    roof["m4096_kernel"] = pf["m4096_4096x4096"].get("kernel")
                     tr = pf["roofline"].get("traffic")
+                    roof["prefill_traffic"] = tr
                     if tr:
                         K_, N_ = [int(t[2:]) for t in pf["roofline"]["shape"].split()[:2]]
                         roof["prefill_traffic_ratio"] = round(tr / algorithmic_bytes(K_, N_, 2048, act_order=True), 3)
+                    tr2 = pf["m4096_4096x4096"].get("traffic")
+                    roof["m4096_traffic"] = tr2
+                    if tr2:
+                        roof["m4096_traffic_ratio"] = round(tr2 / algorithmic_bytes(4096, 4096, 4096), 3)
                     for nm, v in (pf.get("by_shape") or {}).items():
                         roof["prefill_us_" + nm] = v["us"]
+                        roof["prefill_TFLOP_s_" + nm] = v["TFLOP_s"]
                 if isinstance(c5, dict):
                     for bits in (3, 8):
                         fr = [v["frac"] for k, v in c5.items() if isinstance(v, dict) and k.startswith(f"int{bits}_g32_") and k.count("_") == 2 and "frac" in v]
@@ -1009,6 +1045,19 @@ def main():
                     for k, v in bd.items():
                         if isinstance(v, dict) and "us" in v:
                             roof["mid_" + k.lower() + "_us"] = v["us"]
+                    if isinstance(bd.get("M64_4096x4096"), dict):
+                        roof["m64_us_4096"] = bd["M64_4096x4096"].get("us")
+                eg = out.get("eager")
+                if isinstance(eg, dict):
+                    for k in ("host_us_per_call", "us_per_call", "GB_per_s"):
+                        if k in eg:
+                            roof["eager_" + k] = eg[k]
+                    if "host_us_per_call" in eg:
+                        roof["eager_us_per_call"] = eg["host_us_per_call"]
+                fc = out.get("fused_callers")
+                if isinstance(fc, dict) and "ms_per_step" in fc:
+                    roof["fused_ms_per_step"] = fc["ms_per_step"]
+                    roof["fused_GB_per_s"] = fc.get("GB_per_s")
                 if isinstance(mc, dict) and isinstance(mc.get("default_three_steps"), dict) and "us_per_mlp" in mc["default_three_steps"]:
                     roof["mlp_call_us"] = mc["default_three_steps"]["us_per_mlp"]
                     roof["mlp_call_frac"] = mc["default_three_steps"]["frac"]

@@ -188,7 +188,10 @@ int gptq_forward(const gptq_layer_t *layer, const void *x, void *out, int M,
  * carry qweight_tiled, all plain or all act-order; 5 to 128 rows the batched-decode / 17..128-row kernels on plain 4-bit layers where the planner
  * prefers them) without touching or copying the checkpoint tensors, and runs the layers one after the other in every other case -- except that
  * act-order layers which share ONE `perm` pointer (q / k / v, gate / up of a GPTQ checkpoint: the order comes from their common input) read ONE
- * permuted x per call.  Results are those of n gptq_forward calls either way (same values within fp rounding: the K split may differ).
+ * permuted x per call.  CONTRACT of a shared `perm` pointer: the layers that carry it have IDENTICAL g_idx, and every one's qweight_seq was built with
+ * that permutation (gptq_make_sequential + gptq_resequence_qweight) -- pointer equality is all this entry point checks; a caller that reuses one perm
+ * buffer for layers with different activation orders gets wrong results (the Python side compares the g_idx tensors once: share_act_order).
+ * Results are those of n gptq_forward calls either way (same values within fp rounding: the K split may differ).
  * Workspace: gptq_workspace_bytes_multi. */
 size_t gptq_workspace_bytes_multi(const gptq_layer_t *const *layers, int n_layers, int M);
 int gptq_forward_multi(const gptq_layer_t *const *layers, int n_layers, const void *x, void *const *outs, int M,
@@ -319,7 +322,10 @@ typedef struct gptq_peer_group_t {
 
 /* scatter: y_local [M, n_local] (n_local = N / world) -> columns [rank*n_local, (rank+1)*n_local) of every rank's exchange
  * buffer, then the arrival flags.  collect: wait for all ranks' slices of this call, copy [M, N] to `out`, advance the epoch.
- * gather = scatter + collect.  Independent work of the caller may be enqueued between scatter and collect. */
+ * gather = scatter + collect.  Independent work of the caller may be enqueued between scatter and collect -- ON THE SAME STREAM: every collect
+ * (re-)publishes this rank's arrival flag of its epoch when it starts (that is what lets gptq_forward_scatter go without a flag of its own), which is only
+ * correct behind the rank's payload stores in stream order.  A scatter on one stream and its collect on another -- or a collect enqueued first -- raises
+ * the flag over an incomplete payload and the peers copy stale rows without any error. */
 int gptq_peer_scatter(const gptq_peer_group_t *pg, const void *y_local, int M, int n_local, int dtype, void *stream);
 int gptq_peer_collect(const gptq_peer_group_t *pg, void *out, int M, int dtype, uint32_t max_spins, void *stream);
 int gptq_peer_gather(const gptq_peer_group_t *pg, const void *y_local, void *out, int M, int n_local, int dtype,

@@ -386,8 +386,13 @@ def test_sticky_exchange_error_is_read_periodically():
         with pytest.raises(RuntimeError, match="bounded wait"):
             with torch.no_grad():
                 q(x)
-        tail[2] = 0
+        assert int(tail[2].item()) == 0                                   # reported once, then cleared (round-4 advice): one timeout, one exception
         with torch.no_grad():
             assert torch.equal(q(x), y)
+        tail[2] = 1                                                       # the multi-layer entry point reads the same word (it takes the same workspace)
+        with pytest.raises(RuntimeError, match="bounded wait"):
+            with torch.no_grad():
+                qm.forward_multi([q], x)
+        assert int(tail[2].item()) == 0
     finally:
         QuantLinear.EXCHANGE_CHECK_EVERY = saved

@@ -306,7 +306,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _ipc_worker(rank, world, port, M, q):
+def _ipc_worker(rank, world, port, M, q, act=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -317,7 +317,7 @@ def _ipc_worker(rank, world, port, M, q):
         from oracle import gptq_oracle as O
         dev = "cuda:0"
         K, N = 1024, 2048
-        L = O.random_quant_layer(K, N, 4, 128, act_order=False, seed=11)                 # identical on every rank
+        L = O.random_quant_layer(K, N, 4, 128, act_order=act, seed=11)                   # identical on every rank
         m = QuantLinear(4, 128, K, N, False)
         m.qweight, m.qzeros, m.scales, m.g_idx = L["qweight"], L["qzeros"], L["scales"], L["g_idx"]
         cp = ColumnParallelQuantLinear.from_full(m, rank, world, device=dev, gather_output=True, exchange="peer_store", max_rows=M)
@@ -327,10 +327,12 @@ def _ipc_worker(rank, world, port, M, q):
                 x = (torch.rand(M, K, generator=torch.Generator().manual_seed(20 + it)) - 0.5).half()
                 y = cp(x.to(dev))
                 cp._px.check_timeout()
-                y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], None, None, 4, O.ZERO_WRAP)
+                y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"] if act else None, None, 4, O.ZERO_NOWRAP if act else O.ZERO_WRAP)
                 errs.append(float((y.double().cpu() - y64).abs().max() / y64.abs().max()))
         dist.barrier()                                              # nobody unmaps while a peer may still store
-        fused_as_expected = cp.fused_calls == (3 if M <= 4 else 0)      # decode rows: the scatter is the shard kernel's epilogue (gptq_forward_scatter)
+        # decode rows of a plain shard: the scatter is the shard kernel's epilogue (gptq_forward_scatter); act-order shards (their decode kernel gathers x through
+        # perm and has no scatter epilogue) take local forward + scatter + collect
+        fused_as_expected = cp.fused_calls == (3 if (M <= 4 and not act) else 0)
         q.put((rank, tuple(y.shape) == (M, N) and max(errs) < 3e-3 and cp._px.fine_grained and fused_as_expected,
                errs + [("fine_grained", cp._px.fine_grained), ("fused_calls", cp.fused_calls)]))
     finally:
@@ -338,14 +340,14 @@ def _ipc_worker(rank, world, port, M, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M", [1, 48])
-def test_two_processes_one_gpu_peer_store_column_parallel(M):
+@pytest.mark.parametrize("M,act", [(1, False), (48, False), (1, True), (4, True)], ids=["M1", "M48", "M1-act", "M4-act"])
+def test_two_processes_one_gpu_peer_store_column_parallel(M, act):
     import torch.multiprocessing as mp
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_ipc_worker, args=(r, world, port, M, q)) for r in range(world)]
+    procs = [ctx.Process(target=_ipc_worker, args=(r, world, port, M, q, act)) for r in range(world)]
     for p in procs:
         p.start()
     res, deadline = [], time.time() + 150

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--shapes", default="4096x4096,4096x11008,11008x4096", help="KxN list used to label decode dispatches")
     ap.add_argument("--m", type=int, default=1)
     ap.add_argument("--prefill-m", type=int, default=0, help="rows per step of the prefill bench (labels gemm_kernel dispatches)")
+    ap.add_argument("--label-gemm", default="", help="K,N,M: EVERY gptq gemm* dispatch of these databases gets this label (a single-shape run: tools/prefill_one.py)")
+    ap.add_argument("--append", default="", help="an existing pmc_traffic.json: its rows are kept, rows of this run with the same (kernel, K, N, M) replace them")
     args = ap.parse_args()
     fetch = per_kernel(args.fetch, "FETCH_SIZE")
     write = per_kernel(args.write, "WRITE_SIZE") if args.write else {}
@@ -84,7 +86,17 @@ def main():
                     ent["K_candidates"] = cands
                     if len(cands) == 1:
                         ent["K"] = cands[0]
+        if args.label_gemm and "gemm" in name:
+            ent["K"], ent["N"], ent["M"] = map(int, args.label_gemm.split(","))
+            ent.pop("K_candidates", None)
         out.append(ent)
+    if args.label_gemm:                                        # a single-shape run: only its GEMM rows are of interest
+        out = [e for e in out if "gemm" in e["kernel"]]
+    if args.append and os.path.exists(args.append):
+        old = json.load(open(args.append)).get("kernels", [])
+        key = lambda e: (e["kernel"].replace(" ", ""), e.get("K"), e.get("N"), e.get("M"), tuple(e.get("grid_blocks") or ()))
+        new = {key(e) for e in out}
+        out = [e for e in old if key(e) not in new] + out
     with open(args.out, "w") as f:
         json.dump({"source": {"fetch": args.fetch, "write": args.write}, "note": "FETCH_SIZE doubled (gfx950 correction)",
                    "kernels": out}, f, indent=1)
