@@ -139,6 +139,7 @@ static bool tiled_rows8_pays(const gptq_layer_t* const* Ls, int n) {
 }
 bool want_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* t) {
     if (M > TILED_ROWS_MAX || n < 1 || n > 4) return false;
+    if (Ls[0]->epilogue != GPTQ_EPI_NONE && (n != 1 || M > 4)) return false;     // a [gate | up] layer: the pair form of the kernel (gemv_tiled_pair.hip)
     if (M > 4 && !(t && t->path == 8) && !tiled_rows8_pays(Ls, n)) return false;
     if (t && t->path != 0 && t->path != 8) return false;
     return plan_tiled(Ls, n, M, t).ok;                             // act-order layers: the copy holds the re-sequenced rows, the kernel gathers x through perm
@@ -217,7 +218,12 @@ static bool fused_epilogue_ok(const gptq_layer_t* L, int M, const gptq_tuning_t*
 }
 
 // Body = what the kernels use behind the ticket header; the public figure adds the header whenever there is a body.
+static bool tiled_pair_call(const gptq_layer_t* L, int M, const gptq_tuning_t* tune) {
+    const gptq_layer_t* one[1] = {L};
+    return L->epilogue == GPTQ_EPI_SILU_MUL && want_tiled(one, 1, M, tune);
+}
 static size_t body_bytes(const gptq_layer_t* L, int M, const gptq_tuning_t* tune) {
+    if (tiled_pair_call(L, M, tune)) return 0;                                    // decode rows of a [gate | up] layer that carries its copy: one launch, no scratch
     if (L->epilogue != GPTQ_EPI_NONE && !fused_epilogue_ok(L, M, tune)) {
         gptq_layer_t Lc = *L;
         Lc.epilogue = GPTQ_EPI_NONE;
@@ -369,6 +375,13 @@ static int forward_impl(const gptq_layer_t* L, const void* x, void* out, int M, 
         if (tune && tune->path == 8)
             return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: the decode-copy kernel needs M <= 8 and a plain or re-sequenced act-order 3/4/8-bit fp16/bf16 layer that carries qweight_tiled / qconst_tiled "
                                               "(gptq_prepack_decode; tiled_cols = %d)", GPTQ_STRIP_COLS);
+    }
+    if (tiled_pair_call(L, M, tune)) {                                            // SiLU * mul as the epilogue of the decode-copy kernel (round 5)
+        rc = check_io(x, out, M);
+        if (rc) return rc;
+        const gptq_layer_t* one[1] = {L};
+        void* outs[1] = {out};
+        return tiled_call(one, 1, x, outs, M, wv, stream, tune);
     }
     if (L->epilogue != GPTQ_EPI_NONE && !fused_epilogue_ok(L, M, tune)) {
         rc = check_io(x, out, M);
@@ -728,8 +741,9 @@ static int decode_copy_source(const gptq_layer_t* L, gptq_layer_t* S) {
     S->qweight_tiled = (const uint32_t*)(uintptr_t)16;       // placeholders: tiled_layer_ok() only asks whether the copy COULD exist
     S->qconst_tiled = (const void*)(uintptr_t)16;
     S->tiled_cols = GPTQ_STRIP_COLS;
-    S->epilogue = GPTQ_EPI_NONE;                             // a [gate | up] layer with the fused epilogue has no decode copy of its own (its halves do)
-    if (L->epilogue != GPTQ_EPI_NONE || !tiled_layer_ok(*S))
+    // a plain [gate | up] layer with the fused epilogue gets a copy too (round 5: its decode kernel pairs strip s of the two halves); act-order ones do not
+    if (L->epilogue != GPTQ_EPI_NONE && (L->g_idx != nullptr || L->N % (2 * GPTQ_STRIP_COLS) != 0)) S->epilogue = -1;
+    if (S->epilogue == -1 || !tiled_layer_ok(*S))
         return fail(GPTQ_ERR_UNSUPPORTED, "the decode copy needs a 3-, 4- or 8-bit fp16/bf16 layer, group_size a power-of-two multiple of 32 (16 at 8 bits) or >= K, "
                                           "and for act-order layers qweight_seq + perm (bits=%d dtype=%d group_size=%d)", L->bits, L->dtype, L->group_size);
     return GPTQ_OK;
@@ -772,6 +786,13 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
     int rc = check_layer(L);
     if (rc) return rc;
     if (M <= 0) return fail(GPTQ_ERR_SHAPE, "M must be > 0, got %d", M);
+    if (tiled_pair_call(L, M, tune)) {
+        const gptq_layer_t* one[1] = {L};
+        const TiledPlan tp = plan_tiled(one, 1, M, tune);
+        snprintf(out, out_bytes, "path=gemv kernel=strips ln=4 waves=%d u=%d ksplit=%d mt=%d strips=%d pair=1 perm=0 epilogue=fused", tp.waves, tp.u, tp.ksplit, tp.mt,
+                 tp.strips_total);
+        return GPTQ_OK;
+    }
     const bool unfused_epilogue = L->epilogue != GPTQ_EPI_NONE && !fused_epilogue_ok(L, M, tune);
     gptq_layer_t Lc = *L;
     gptq_tuning_t local;

@@ -36,14 +36,19 @@ hipError_t launch_tiled_act(const TiledPlan& pl, const TiledParams& p, int dtype
 hipError_t init_gemv_tiled_act_device();
 hipError_t launch_tiled_peer(const TiledPlan& pl, const TiledParams& p, int dtype, hipStream_t st);     // gemv_tiled_peer.hip
 hipError_t init_gemv_tiled_peer_device();
+hipError_t launch_tiled_pair(const TiledPlan& pl, const TiledParams& p, int dtype, hipStream_t st);     // gemv_tiled_pair.hip
+hipError_t init_gemv_tiled_pair_device();
 
 // ---- plan + launch ---------------------------------------------------------------------------------------------------------------------
 static int tiled_kpl(int bits) { return bits == 8 ? 16 : 32; }          // k per lane and chunk
 static int tiled_chunk_bytes(int bits) { return bits == 3 ? 768 : 1024; }
 static int tiled_rec_bytes(int bits) { return bits == 8 ? 64 : 48; }
 
+// A [gate | up] layer with the SILU_MUL epilogue: a plain (no act-order) layer whose halves are whole strips
+static bool tiled_pair_layer(const gptq_layer_t& L) { return L.epilogue == GPTQ_EPI_SILU_MUL && L.g_idx == nullptr && L.N % (2 * GPTQ_STRIP_COLS) == 0; }
+
 bool tiled_layer_ok(const gptq_layer_t& L) {
-    if (!L.qweight_tiled || !L.qconst_tiled || L.tiled_cols != GPTQ_STRIP_COLS || L.epilogue != GPTQ_EPI_NONE) return false;
+    if (!L.qweight_tiled || !L.qconst_tiled || L.tiled_cols != GPTQ_STRIP_COLS || (L.epilogue != GPTQ_EPI_NONE && !tiled_pair_layer(L))) return false;
     if (L.bits != 4 && L.bits != 8 && L.bits != 3) return false;
     if (L.g_idx != nullptr && !(L.perm && L.qweight_seq)) return false;           // act-order: only with the re-sequenced rows (the copy is made of them) and perm
     if (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16) return false;
@@ -66,13 +71,17 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
     if (n < 1 || n > 4 || M < 1 || M > 8) return pl;
     const gptq_layer_t& A = *Ls[0];
     int strips = 0, nsum = 0;
+    const bool pair = A.epilogue == GPTQ_EPI_SILU_MUL;                             // one [gate | up] layer: a workgroup per PAIR of strips, M <= 4, no K slices
+    if (pair && (n != 1 || M > 4)) return pl;
     for (int i = 0; i < n; ++i) {
         const gptq_layer_t& L = *Ls[i];
-        if (!tiled_layer_ok(L)) return pl;
+        if (!tiled_layer_ok(L) || (L.epilogue != GPTQ_EPI_NONE) != pair) return pl;
         if (L.K != A.K || L.group_size != A.group_size || L.dtype != A.dtype || L.bits != A.bits || (L.g_idx != nullptr) != (A.g_idx != nullptr)) return pl;
         strips += L.N / GPTQ_STRIP_COLS;
         nsum += L.N;
     }
+    if (pair) strips /= 2;
+    pl.pair = pair;
     pl.nseg = n;
     pl.mt = M >= 5 ? 8 : (M >= 3 ? 4 : M);                                        // 5..8 rows: a second A operand (rows 4..7), two matrix-core steps per decoded pair
     const int cke = 4 * tiled_kpl(A.bits), rec = tiled_rec_bytes(A.bits);         // k per chunk; bytes of one group's constants
@@ -87,17 +96,19 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
     int ks = (tune && tune->ksplit) ? tune->ksplit : 0;
     if (!ks) {
         ks = 1;
-        while (strips * ks < 128 && chunks / (ks * 2) >= 8) ks *= 2;
+        while (!pair && strips * ks < 128 && chunks / (ks * 2) >= 8) ks *= 2;
     }
+    if (pair && ks != 1) return pl;
     const size_t raw_bytes = A.g_idx ? (size_t)pl.mt * ((size_t)A.K * 2 + 16) + 16 : 0;      // act-order: does not shrink with K slices
     const size_t lds_cap = 96 * 1024 + raw_bytes;
     auto lds_need = [&](int k_slices, int waves) {
         const int cps = (chunks + k_slices - 1) / k_slices;
-        return (size_t)pl.mt * ((size_t)cps * cke * 2 + 16) + (size_t)pl.groups * rec + (size_t)waves * (pl.mt * 16 + 4) * sizeof(float) + 16 +
+        return (size_t)pl.mt * ((size_t)cps * cke * 2 + 16) + (pair ? 2 : 1) * (((size_t)pl.groups * rec + 15) & ~(size_t)15) + (size_t)waves * (pl.mt * 16 + 4) * sizeof(float) + 16 +
                (A.dtype == GPTQ_BF16 && pl.mt <= 2 ? (size_t)cps * 64 : 0) +
                (A.g_idx ? (size_t)pl.mt * ((size_t)A.K * 2 + 16) + 16 : 0);         // act-order: the raw x rows, whole K                      // bf16: one inverse block factor per (run of a chunk's 4, row of 4)
     };
-    while (ks < 8 && ks < chunks && lds_need(ks, 16) > lds_cap) ks *= 2;
+    while (!pair && ks < 8 && ks < chunks && lds_need(ks, 16) > lds_cap) ks *= 2;
+    if (pair && lds_need(1, 16) > lds_cap) return pl;
     if (ks > chunks) ks = chunks;
     if (ks > 8) ks = 8;                                                           // the owner's poll is unrolled over at most 7 other slices
     const int cps = (chunks + ks - 1) / ks;
@@ -115,10 +126,12 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         if (wgs <= 320) { waves = 16; u = 2; }
         else { waves = 4; u = 4; }
         if (pl.mt > 4) { waves = 8; u = 4; }                                      // 5..8 rows, 4096^2: 6.62 us (4 x 4: 6.82, 16 x 2: 6.92)
-        while (waves > 1 && (waves / 2) * u >= cps) waves /= 2;
+        if (pair && waves == 4) waves = 8;                                        // two strips per workgroup: the 4-wave form's work per wave
+        while (waves > (pair ? 2 : 1) && (waves / (pair ? 4 : 2)) * u >= cps) waves /= 2;
     }
+    if (pair && (waves & 1)) return pl;
     if (waves < 1 || waves > 16 || (u != 1 && u != 2 && u != 4 && u != 8)) return pl;
-    if ((A.bits != 4 || A.g_idx || pl.mt > 4) && u != 2 && u != 4) return pl;     // the 3- / 8-bit, the act-order and the 5..8-row forms are compiled for 2 and 4 chunks in flight
+    if ((A.bits != 4 || A.g_idx || pl.mt > 4 || pair) && u != 2 && u != 4) return pl;     // the 3- / 8-bit, the act-order and the 5..8-row forms are compiled for 2 and 4 chunks in flight
     pl.waves = waves;
     pl.u = u;
     pl.xstride = cps * cke * 2 + 16;
@@ -152,7 +165,7 @@ hipError_t launch_tiled(const gptq_layer_t* const* Ls, const TiledPlan& pl, cons
     for (int i = 0; i < 4; ++i) p.blk_end[i] = 0x7fffffff;
     for (int i = 0; i < pl.nseg; ++i) {
         const gptq_layer_t& L = *Ls[i];
-        blk += L.N / GPTQ_STRIP_COLS;
+        blk += L.N / GPTQ_STRIP_COLS / (pl.pair ? 2 : 1);
         p.blk_end[i] = blk;
         p.seg[i] = TiledSeg{L.qweight_tiled, L.qconst_tiled, L.bias, outs[i], L.N, col, L.g_idx ? L.perm : nullptr};
         col += L.N;
@@ -176,6 +189,7 @@ hipError_t launch_tiled(const gptq_layer_t* const* Ls, const TiledPlan& pl, cons
         if (A.g_idx || (pl.u != 2 && pl.u != 4)) return hipErrorInvalidValue;
         return launch_tiled_peer(pl, p, A.dtype, st);                             // gemv_tiled_peer.hip
     }
+    if (pl.pair) return (pl.u == 2 || pl.u == 4) ? launch_tiled_pair(pl, p, A.dtype, st) : hipErrorInvalidValue;   // gemv_tiled_pair.hip
     if (A.g_idx) return launch_tiled_act(pl, p, A.dtype, st);                     // gemv_tiled_act.hip
     return A.dtype == GPTQ_BF16 ? launch_tiled_bits<bf16, 0>(pl, p, st) : launch_tiled_bits<f16, 0>(pl, p, st);
 }
@@ -184,7 +198,8 @@ hipError_t init_gemv_tiled_device() {
     hipError_t e = grant_tiled_lds<0>();
     hipError_t e2 = init_gemv_tiled_act_device();
     hipError_t e3 = init_gemv_tiled_peer_device();
-    return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : e3);
+    hipError_t e4 = init_gemv_tiled_pair_device();
+    return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : (e3 != hipSuccess ? e3 : e4));
 }
 
 }  // namespace gptq

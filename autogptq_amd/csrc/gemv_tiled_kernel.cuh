@@ -1,6 +1,7 @@
-// gemv_tiled_kernel.cuh -- the decode-copy kernel and its launch templates, included by three translation units: gemv_tiled.hip (plain layers, XM = 0),
-// gemv_tiled_act.hip (act-order layers, XM = 1) and gemv_tiled_peer.hip (plain layers with the tensor-parallel epilogue, XM = 3) -- separate only for
-// build time, and so that the plain kernels carry nothing of the other forms.  Description: gemv_tiled.hip.
+// gemv_tiled_kernel.cuh -- the decode-copy kernel and its launch templates, included by four translation units: gemv_tiled.hip (plain layers, XM = 0),
+// gemv_tiled_act.hip (act-order layers, XM = 1), gemv_tiled_peer.hip (plain layers with the tensor-parallel epilogue, XM = 3) and gemv_tiled_pair.hip
+// ([gate | up] layers with the fused SiLU * mul epilogue, XM = 4) -- separate only for build time, and so that the plain kernels carry nothing of the
+// other forms.  Description: gemv_tiled.hip.
 #pragma once
 #include "gemv_shared.cuh"
 
@@ -61,6 +62,10 @@ template <int BITS, int MT, int U, typename T, int MAXW, int XM = 0>
 __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kernel(TiledParams p) {
     constexpr bool BF = std::is_same_v<T, bf16>;
     constexpr bool ACT = XM == 1, PEER = XM == 3;          // 3: plain staging + the tensor-parallel epilogue (gemv_tiled_peer.hip)
+    // XM = 4 (PAIR, round 5): a [gate | up] layer with the SILU_MUL epilogue (the reference's fused MLP: auto_gptq/nn_modules/fused_llama_mlp.py:131-306).  A
+    // workgroup takes strip s of the gate half AND strip s of the up half (N / 32 strips further) behind ONE staged x: the first half of its waves
+    // streams the one, the second half the other; SiLU(gate) * up is formed on the fp32 sums behind the cross-wave reduction (no K slices: the planner).
+    constexpr bool PAIR = XM == 4;
     using F = TiledFmt<BITS>;
     constexpr int WPL = F::WPL, KPL = F::KPL, CKE = 4 * KPL, CHB = 64 * WPL * 4, REC = F::REC, NX = KPL / 8;      // k per chunk, bytes per chunk, x pieces per lane and chunk
     constexpr int LKPL = KPL == 32 ? 5 : 4;
@@ -90,20 +95,25 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
     const TiledSeg sg = p.seg[s];                                                 // one dependent kernarg load
     const int strip = sidx - (s == 0 ? 0 : (s == 1 ? be0 : (s == 2 ? be1 : be2)));
     const int N = sg.N;
+    const int Wh = PAIR ? (W >> 1) : W;                                           // waves per strip
+    const int sel = PAIR ? (wave >= Wh ? 1 : 0) : 0;                              // PAIR: 0 = the gate strip, 1 = the up strip (wave-uniform)
+    const int wv = PAIR ? wave - sel * Wh : wave;
+    const int strip_w = PAIR ? strip + sel * (N >> 5) : strip;                    // the strip this WAVE streams
     const int cb = ks * cps, ce = min(cb + cps, nchunks);                         // this slice's chunks
     const int kbeg = cb * CKE, kend = min(ce * CKE, K);                           // ... and its k range: what is staged of x
     // LDS: [x: MT rows of (kend - kbeg) values, row stride + 16 B][constants: G x REC bytes][cross-wave sums]
     char* const xs = smem;                                                        // row stride xstride = chunks_per_split * CKE * 2 + 16 bytes: the 4 rows of a 4-lane group hit different banks
     char* const cs = smem + (size_t)MT * xstride;
-    float* const red = (float*)(cs + (((size_t)G * REC + 15) & ~(size_t)15));
+    const size_t cpad = ((size_t)G * REC + 15) & ~(size_t)15;
+    float* const red = (float*)(cs + (PAIR ? 2 : 1) * cpad);
     const char* const cg = (const char*)sg.cst + (size_t)strip * G * REC;         // this strip's constants: one contiguous run
-    const char* const tb = (const char*)sg.tq + (size_t)strip * nchunks * CHB;    // this strip's weights: one contiguous run
+    const char* const tb = (const char*)sg.tq + (size_t)strip_w * nchunks * CHB;  // this wave's strip of weights: one contiguous run
     const unsigned t_lane = (unsigned)lane * (WPL * 4u);
     // ---- stage x and the constants by LDS DMA: no VGPRs, issued FIRST (loads return in issue order), waited for behind the first weight burst
     {
         const unsigned xs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)xs, cs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cs;
         const int pieces = (kend - kbeg) >> 3;                                    // 16-byte pieces per x row
-        if constexpr (XM == 0 || XM == 3) {
+        if constexpr (XM == 0 || XM == 3 || XM == 4) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const char* xr = xg + ((size_t)min(m, Mrows - 1) * K + kbeg) * 2;
@@ -124,6 +134,11 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
         const int cpieces = (G * REC) >> 4;                                       // REC is a multiple of 16
         for (int pc0 = wave * 64; pc0 < cpieces; pc0 += W * 64)
             if (pc0 + lane < cpieces) dma16_nt(cg + (size_t)(pc0 + lane) * 16, __builtin_amdgcn_readfirstlane(cs_lds + pc0 * 16));
+        if constexpr (PAIR) {                                                     // the up strip's constants behind the gate strip's
+            const char* const cg2 = cg + (size_t)(N >> 5) * G * REC;
+            for (int pc0 = wave * 64; pc0 < cpieces; pc0 += W * 64)
+                if (pc0 + lane < cpieces) dma16_nt(cg2 + (size_t)(pc0 + lane) * 16, __builtin_amdgcn_readfirstlane(cs_lds + (unsigned)cpad + pc0 * 16));
+        }
     }
     // ACT: one thread = one 16-byte piece of the staged rows: 8 consecutive positions -> 32 contiguous bytes of perm (global, requested HERE, in front of the
     // weight loads), then 8 two-byte LDS reads per row from the raw x the DMA above delivers.  (Gathering x from global instead -- 8 scattered 2-byte
@@ -226,8 +241,8 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
         }
     };
     bool staged = false;
-    for (int cbase = cb; cbase < ce; cbase += W * U) {
-        const int c0 = cbase + wave * U;
+    for (int cbase = cb; cbase < ce; cbase += Wh * U) {
+        const int c0 = cbase + wv * U;
         qvec q[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) q[j] = __builtin_nontemporal_load((const qvec*)(tb + ((unsigned)min(c0 + j, ce - 1) * (unsigned)CHB + t_lane)));
@@ -247,7 +262,7 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
             const int k0 = cc * CKE + kb * KPL;                                   // first k of this lane's words
             const bool live = (c0 + j < ce) && (k0 < K);                          // a ragged last chunk: whole k-slots are missing
             const int g = min(k0 >> LKPL >> gshift, G - 1);
-            const char* cp = cs + g * REC;
+            const char* cp = cs + (PAIR ? (size_t)sel * cpad : (size_t)0) + g * REC;
             const unsigned short sraw = *(const unsigned short*)(cp + col * 2);
             unsigned z;
             if constexpr (F::ZB == 1) z = *(const unsigned char*)(cp + 32 + col);
@@ -330,6 +345,22 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
         for (int m = 0; m < MT; ++m) red[wave * ES + m * 16 + lane] = acc[m];
     }
     __syncthreads();
+    if constexpr (PAIR) {
+        // entry e = (row m, column c): gate = the sum over the first half of the waves, up = over the second half (fixed order), SiLU on the fp32 sum --
+        // the arithmetic of the fused GEMV epilogue of rounds 1-3 (gemv.hip) and, up to the one rounding it saves, of silu_mul_kernel (utils.hip)
+        const int NH = N >> 1;
+        if (tid < MT * 16) {
+            const int m = tid >> 4, c = tid & 15, n = strip * 16 + c;
+            float s0 = 0.f, s1 = 0.f;
+            for (int w = 0; w < Wh; ++w) { s0 += red[w * ES + tid]; s1 += red[(Wh + w) * ES + tid]; }
+            if (m < Mrows && n < NH) {
+                if (sg.bias) { s0 += DType<T>::to_f32(((const T*)sg.bias)[n]); s1 += DType<T>::to_f32(((const T*)sg.bias)[n + NH]); }
+                const float g = s0 / (1.f + __expf(-s0));
+                ((T*)sg.out)[(size_t)m * NH + n] = DType<T>::from_f32(g * s1);
+            }
+        }
+        return;
+    }
     T* const stage = PEER ? (T*)xs : nullptr;                                      // the staged x is dead behind the barrier above
     stream_finish<16, MT, T, TiledParams, TiledSeg>(p, sg, strip, sidx, ks, N, red, stage);
     if constexpr (PEER) if (ks == 0) {                                            // uniform: the strip's owner
@@ -377,7 +408,7 @@ static hipError_t launch_tiled_mt(const TiledPlan& pl, const TiledParams& p, hip
         case 1: return launch_tiled_u<BITS, 1, T, XM>(pl, p, st);
         case 2: return launch_tiled_u<BITS, 2, T, XM>(pl, p, st);
         case 4: return launch_tiled_u<BITS, 4, T, XM>(pl, p, st);
-        case 8: if constexpr (XM != 3) return launch_tiled_u<BITS, 8, T, XM>(pl, p, st); else return hipErrorInvalidValue;      // 5..8 rows: plain and act-order forms
+        case 8: if constexpr (XM != 3 && XM != 4) return launch_tiled_u<BITS, 8, T, XM>(pl, p, st); else return hipErrorInvalidValue;      // 5..8 rows: plain and act-order forms
         default: return hipErrorInvalidValue;
     }
 }
@@ -410,7 +441,7 @@ static hipError_t grant_tiled_lds() {
         grant_u(I8{}, I2{}); grant_u(I8{}, I4{}); grant_u(I3{}, I2{}); grant_u(I3{}, I4{});
     };
     grant_mt(std::integral_constant<int, 1>{}); grant_mt(std::integral_constant<int, 2>{}); grant_mt(std::integral_constant<int, 4>{});
-    if constexpr (XM != 3) grant_mt(std::integral_constant<int, 8>{});
+    if constexpr (XM != 3 && XM != 4) grant_mt(std::integral_constant<int, 8>{});
     return e;
 }
 

@@ -250,7 +250,7 @@ class QuantLinear(nn.Module):
         qweight_tiled = qconst_tiled = None
         if tiled is None:
             tiled = self.TILED_DECODE
-        if tiled and self.bits in (3, 4, 8) and self.epilogue == "none":             # act-order layers: a copy of the re-sequenced rows (qweight_seq above)
+        if tiled and self.bits in (3, 4, 8):             # act-order layers: a copy of the re-sequenced rows (qweight_seq above); [gate | up] layers with the fused epilogue: the C side decides
             tb, cb = ctypes.c_size_t(0), ctypes.c_size_t(0)
             if lib.gptq_prepack_decode_bytes(ctypes.byref(L), ctypes.byref(tb), ctypes.byref(cb)) == 0:      # a layer that does not qualify simply has none
                 qweight_tiled = torch.empty(tb.value, dtype=torch.uint8, device=dev)

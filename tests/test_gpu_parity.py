@@ -1006,7 +1006,7 @@ def test_fused_gate_up_wide_layer_small_batch(M, act):
         y2 = fused(x.to(DEV))
     q = next(m for m in fused.modules() if isinstance(m, QuantLinear))
     d = _lib.describe_plan(q._layer, M)
-    if M <= 2:
+    if M <= 2:      # (this file runs with QuantLinear.TILED_DECODE = False: the kernels of rounds 1-3; the pair form of the decode-copy kernel: test_gpu_tiled.py)
         assert d["epilogue"] == "fused", d
     else:
         assert (d["kernel"], d["epilogue"]) == ("stream64", "separate"), d

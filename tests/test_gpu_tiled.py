@@ -396,3 +396,53 @@ def test_sticky_exchange_error_is_read_periodically():
         assert int(tail[2].item()) == 0
     finally:
         QuantLinear.EXCHANGE_CHECK_EVERY = saved
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("K,I,gs,bits", [(1024, 704, 128, 4), (4096, 11008, 128, 4), (2112, 96, 64, 4), (1024, 1408, 32, 3), (1024, 1408, 32, 8), (160, 32, 32, 4)],
+                         ids=["1024x704", "llama7b-mlp", "ragged-k", "int3", "int8", "tiny"])
+def test_gate_up_silu_mul_is_the_epilogue_of_the_decode_copy_kernel(K, I, gs, bits, dtype):
+    """Round 5: a [gate | up] layer (epilogue='silu_mul', the reference's fused MLP: auto_gptq/nn_modules/fused_llama_mlp.py:131-306) carries its decode copy and
+    its decode rows run the PAIR form of gemv_tiled_kernel (csrc/gemv_tiled_pair.hip): plan pinned, EVERY output against silu(x @ W_gate + b) * (x @ W_up + b)
+    formed in fp64 from the oracle's weights, repeated calls bit-identical, checkpoint tensors untouched; forced geometries too."""
+    from autogptq_amd.fused import fuse_gate_up
+    Lg = O.random_quant_layer(K, I, bits, gs, dtype=dtype, seed=K + I, bias=True)
+    Lu = O.random_quant_layer(K, I, bits, gs, dtype=dtype, seed=K + I + 1, bias=True)
+    for L in (Lg, Lu):
+        L["scales"] = (L["scales"].float() * (8 if K < 2048 else 4)).to(dtype)      # gate pre-activations of order 1: SiLU off its linear part
+    mods = []
+    for L in (Lg, Lu):
+        m = QuantLinear(bits, gs, K, I, True, weight_dtype=dtype)
+        m.qweight, m.qzeros, m.scales, m.g_idx, m.bias = L["qweight"].clone(), L["qzeros"].clone(), L["scales"].clone(), L["g_idx"].clone(), L["bias"].clone()
+        mods.append(m)
+    fused = fuse_gate_up(*mods).to(DEV)
+    q = next(m for m in fused.modules() if isinstance(m, QuantLinear))
+    q.post_init()
+    assert q._qweight_tiled is not None, "a plain [gate | up] layer gets a decode copy"
+    before = {k: v.clone() for k, v in q.state_dict().items()}
+    mode = O.reference_zero_mode(False, bits)
+    Wg = O.dequantize(Lg["qweight"], Lg["qzeros"], Lg["scales"], Lg["g_idx"], bits, mode).to(DEV).double()
+    Wu = O.dequantize(Lu["qweight"], Lu["qzeros"], Lu["scales"], Lu["g_idx"], bits, mode).to(DEV).double()
+    bg, bu = Lg["bias"].to(DEV).double(), Lu["bias"].to(DEV).double()
+    rtol, atol = {torch.float16: (2e-3, 2e-3), torch.bfloat16: (1.6e-2, 1.6e-2)}[dtype]       # one rounding of the product of two sums
+    for M in (1, 2, 3, 4):
+        x, _ = _x(M, K, dtype, M, hot=False)
+        plans = [None] + ([_tune(16, 2), _tune(8, 4), _tune(4, 4), _tune(2, 2)] if M in (1, 4) else [])
+        for t in plans:
+            d = _lib.describe_plan(q._layer, M, t)
+            assert (d["kernel"], int(d["pair"]), d["epilogue"]) == ("strips", 1, "fused") and int(d["strips"]) == I // 16, d
+            with torch.no_grad():
+                y, y2 = q(x, tuning=t), q(x, tuning=t)
+            assert tuple(y.shape) == (M, I) and torch.equal(y, y2)
+            ref = torch.nn.functional.silu(x.double() @ Wg + bg) * (x.double() @ Wu + bu)
+            scale = float(ref.abs().max())
+            bad = (y.double() - ref).abs() > atol * scale + rtol * ref.abs()
+            assert not bool(bad.any()), f"M={M} {d}: {int(bad.sum())}/{bad.numel()} outputs out of tolerance, first {torch.nonzero(bad)[0].tolist()}"
+    assert float((x.double() @ Wg + bg).abs().max()) > 0.5
+    for k, v in q.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    with torch.no_grad():                                                           # 5+ rows: the staged path as before, on the same layer
+        x8, _ = _x(8, K, dtype, 8, hot=False)
+        y8 = q(x8)
+    ref8 = torch.nn.functional.silu(x8.double() @ Wg + bg) * (x8.double() @ Wu + bu)
+    assert not bool(((y8.double() - ref8).abs() > 3 * atol * float(ref8.abs().max()) + 3 * rtol * ref8.abs()).any())

@@ -734,8 +734,9 @@ def test_planner_fuzz_layers_with_a_decode_copy():
         tb, cb = ctypes.c_size_t(7), ctypes.c_size_t(7)
         rc = lib.gptq_prepack_decode_bytes(ctypes.byref(L), ctypes.byref(tb), ctypes.byref(cb))
         kpl = 16 if bits == 8 else 32
-        can = (bits in (3, 4, 8) and L.dtype in (0, 1) and L.epilogue == 0 and K % 32 == 0 and N % 32 == 0 and gs % kpl == 0 and act != 1
-               and (gs >= K or ((gs // kpl) & (gs // kpl - 1)) == 0))
+        # [gate | up] layers with the fused epilogue: plain ones get a copy too (round 5: the pair form of the decode kernel), act-order ones do not
+        can = (bits in (3, 4, 8) and L.dtype in (0, 1) and (L.epilogue == 0 or (act == 0 and N % 64 == 0)) and K % 32 == 0 and N % 32 == 0 and gs % kpl == 0
+               and act != 1 and (gs >= K or ((gs // kpl) & (gs // kpl - 1)) == 0))
         if not can:
             assert rc != 0 and tb.value == 0 and cb.value == 0, (rc, K, N, bits, gs, act)
             continue
@@ -758,6 +759,8 @@ def test_planner_fuzz_layers_with_a_decode_copy():
                 ks, waves, u = int(plan["ksplit"]), int(plan["waves"]), int(plan["u"])
                 assert M <= 8 and 1 <= ks <= 8 and 1 <= waves <= 16 and u in (1, 2, 4, 8), plan
                 assert need == (0 if ks == 1 else 65536 + (ks - 1) * M * N * 8), (plan, need)
+                if L.epilogue:      # the pair form: strip s of gate and of up per workgroup, an even number of waves, no K slices, nothing staged in a workspace
+                    assert plan["pair"] == "1" and plan["epilogue"] == "fused" and M <= 4 and ks == 1 and waves % 2 == 0 and int(plan["strips"]) == N // 32, plan
             if M > 4 and plan["kernel"] == "strips":      # 5..8 rows: only where the measured rule says it pays (a single plain 4-bit layer around 4096 x 4096)
                 assert M <= 8 and bits == 4 and act == 0 and 2048 <= K <= 4096 and 2048 <= N <= 4096, plan
             if plan["kernel"] == "wide_copy":
