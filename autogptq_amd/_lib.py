@@ -161,6 +161,7 @@ def _bind_fastcall(lib) -> None:
         from . import _fastcall
     except ImportError:
         fast = None
+        _bind_fastfwd(lib)
         return
     try:
         _fastcall.bind(ctypes.cast(lib.gptq_forward_ex, c_void_p).value, ctypes.cast(lib.gptq_forward_multi_ex, c_void_p).value,
@@ -169,6 +170,27 @@ def _bind_fastcall(lib) -> None:
         fast = None
         return
     fast = _fastcall
+    _bind_fastfwd(lib)
+
+
+fwd = None       # autogptq_amd/_fastfwd.so (the eager per-call path in C++ on ATen), or None: the Python path does it all
+
+
+def _bind_fastfwd(lib) -> None:
+    """The C++ fast path of QuantLinear.forward / forward_multi (cext/fastfwd.cpp), if it was built for this torch: the same two C-ABI functions of the
+    same loaded library behind one METH_FASTCALL call that also allocates the output and reads the current stream.  Absent or unloadable (another torch
+    version): the Python path is complete without it."""
+    global fwd
+    fwd = None
+    if os.environ.get("GPTQ_MI355X_NO_FASTFWD"):
+        return
+    try:
+        import torch  # noqa: F401  (libtorch_python must be loaded first)
+        from . import _fastfwd
+        _fastfwd.bind(ctypes.cast(lib.gptq_forward_ex, c_void_p).value, ctypes.cast(lib.gptq_forward_multi_ex, c_void_p).value)
+    except Exception:
+        return
+    fwd = _fastfwd
 
 
 def check(status: int) -> None:

@@ -137,12 +137,17 @@ static bool tiled_rows8_pays(const gptq_layer_t* const* Ls, int n) {
     const gptq_layer_t& L = *Ls[0];
     return n == 1 && L.bits == 4 && !L.g_idx && L.K >= 2048 && L.K <= 4096 && L.N >= 2048 && L.N <= 4096;
 }
-bool want_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* t) {
+// plan_out: the plan the answer was derived from (the eager decode call computes it ONCE: a launch of this kernel runs for 4.5 us, the host side of an eager
+// call is measured in the same unit -- tools/host_cost.py)
+bool want_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* t, TiledPlan* plan_out = nullptr) {
     if (M > TILED_ROWS_MAX || n < 1 || n > 4) return false;
+    if (Ls[0]->qweight_tiled == nullptr) return false;
     if (Ls[0]->epilogue != GPTQ_EPI_NONE && (n != 1 || M > 4)) return false;     // a [gate | up] layer: the pair form of the kernel (gemv_tiled_pair.hip)
     if (M > 4 && !(t && t->path == 8) && !tiled_rows8_pays(Ls, n)) return false;
     if (t && t->path != 0 && t->path != 8) return false;
-    return plan_tiled(Ls, n, M, t).ok;                             // act-order layers: the copy holds the re-sequenced rows, the kernel gathers x through perm
+    const TiledPlan tp = plan_tiled(Ls, n, M, t);                  // act-order layers: the copy holds the re-sequenced rows, the kernel gathers x through perm
+    if (plan_out) *plan_out = tp;
+    return tp.ok;
 }
 
 // act-order layers on the streamed GEMV: x permuted once by the column-permute pre-pass, the kernel streams the re-sequenced rows of a
@@ -350,8 +355,9 @@ static int stream_call(const gptq_layer_t* const* Ls, int n, const StreamPlan& s
     return GPTQ_OK;
 }
 
-static int tiled_call(const gptq_layer_t* const* Ls, int n, const void* x, void* const* outs, int M, const WsView& wv, void* stream, const gptq_tuning_t* tune) {
-    const TiledPlan tp = plan_tiled(Ls, n, M, tune);
+static int tiled_call(const gptq_layer_t* const* Ls, int n, const void* x, void* const* outs, int M, const WsView& wv, void* stream, const gptq_tuning_t* tune,
+                      const TiledPlan* planned = nullptr) {
+    const TiledPlan tp = planned ? *planned : plan_tiled(Ls, n, M, tune);
     if (tp.partial_bytes > 0 && wv.body_bytes < tp.partial_bytes)
         return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + tp.partial_bytes, wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0);
     hipError_t e = launch_tiled(Ls, tp, x, outs, M, wv.header, wv.body, (hipStream_t)stream);
@@ -366,11 +372,12 @@ static int forward_impl(const gptq_layer_t* L, const void* x, void* out, int M, 
     const size_t have = wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0;
     if (L->epilogue == GPTQ_EPI_NONE) {
         const gptq_layer_t* one[1] = {L};
-        if (want_tiled(one, 1, M, tune)) {
+        TiledPlan tp;
+        if (want_tiled(one, 1, M, tune, &tp)) {
             rc = check_io(x, out, M);
             if (rc) return rc;
             void* outs[1] = {out};
-            return tiled_call(one, 1, x, outs, M, wv, stream, tune);
+            return tiled_call(one, 1, x, outs, M, wv, stream, tune, &tp);
         }
         if (tune && tune->path == 8)
             return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: the decode-copy kernel needs M <= 8 and a plain or re-sequenced act-order 3/4/8-bit fp16/bf16 layer that carries qweight_tiled / qconst_tiled "
@@ -509,8 +516,11 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
     }
     // decode rows on layers that carry the decode copy: one launch over the strips of all layers (tools/tiled_sweep.py, M = 4, us: q|k|v 8.6 against
     // 11.1 for the batched-decode kernel, gate|up 12.9 against 18.9)
-    if (want_tiled(layers, n_layers, M, tune) && (multi_preferred(layers, n_layers, M) || (tune && tune->path == 8)))
-        return tiled_call(layers, n_layers, x, outs, M, wv, stream, tune);
+    {
+        TiledPlan tp;
+        if (want_tiled(layers, n_layers, M, tune, &tp) && (multi_preferred(layers, n_layers, M) || (tune && tune->path == 8)))
+            return tiled_call(layers, n_layers, x, outs, M, wv, stream, tune, &tp);
+    }
     if (tune && tune->path == 8) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: these layers do not fit one decode-copy launch (1..4 layers of one packing with qweight_tiled, all plain or all act-order, M <= 8)");
     if (want_mid_multi(layers, n_layers, M, tune)) {
         const MidPlan mp = plan_mid(layers, n_layers, M, tune);

@@ -168,4 +168,92 @@ def load_packed_layers(model: nn.Module, state_dict: Dict[str, torch.Tensor], bi
     return model
 
 
-__all__ = ["make_quant", "pack_model", "autogptq_post_init", "find_layers", "load_packed_layers"]
+class DecodeStepGraph:
+    """One decode step of a causal LM with a STATIC key/value cache as ONE hipGraph (capture_decode_step).  ``graph(input_ids[, cache_position])`` copies the
+    small inputs into the captured buffers, replays and returns the captured logits tensor (overwritten by the next replay: clone it to keep it)."""
+
+    def __init__(self, graph, ids, pos, logits, cache):
+        self.graph, self.input_ids, self.cache_position, self.logits, self.past_key_values = graph, ids, pos, logits, cache
+
+    def __call__(self, input_ids: torch.Tensor, cache_position: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self.input_ids.copy_(input_ids.reshape(self.input_ids.shape))
+        if self.cache_position is not None:
+            if cache_position is None:
+                raise ValueError("this model takes cache_position: pass the position of the token")
+            self.cache_position.copy_(cache_position.reshape(self.cache_position.shape))
+        self.graph.replay()
+        return self.logits
+
+
+def capture_decode_step(model: nn.Module, past_key_values, batch_size: int = 1, warmup: int = 2) -> DecodeStepGraph:
+    """Capture ``model(input_ids[B, 1], past_key_values=<static cache>)`` -- every QuantLinear launch of a decode step (128 per token on Llama-7B with the
+    grouped q|k|v / gate|up calls) plus the attention, norms and the lm_head around them -- into one hipGraph.
+
+    Why: the reference's ``generate()`` is eager (auto_gptq/modeling/_base.py:415-418) and a decode launch of this backend runs for 4.5 - 11 us, which is
+    what one eager Python call costs on the host; replayed from a graph the same launches run back to back (bench.py's headline is measured that way).
+    Needs a cache of fixed shape (``transformers.StaticCache(config, max_cache_len)``): the graph bakes addresses in.  Call ``autogptq_post_init`` first (the
+    workspace is sized before capture; nothing is allocated by forward inside it).
+
+    Where the token lands: transformers 5 keeps the write position in the cache itself (``StaticLayer.cumulative_length``, a device tensor every update
+    advances in place -- the captured step does that too, so successive replays walk through the cache); the ``warmup`` eager steps run here advance it as
+    well and are undone (they need ``warmup`` free slots behind the current length; what they wrote there is beyond the restored length and overwritten
+    by the real steps).  Models whose forward still takes ``cache_position`` (transformers 4, the reference's pin) get it as a second captured input;
+    warm-up and capture then run at the cache's LAST slot.
+    Everything else the model does in a step has to be capturable too: with transformers 5 use ``model.set_attn_implementation("sdpa")`` (its eager-attention
+    mask path creates a device scalar from a Python float per call -- a host copy, refused under capture).
+
+    Use::
+
+        cache = StaticCache(model.config, max_cache_len=L)
+        logits = model(prompt_ids, past_key_values=cache, use_cache=True).logits              # eager prefill
+        step = capture_decode_step(model, cache)
+        for _ in range(new_tokens):
+            tok = step(tok.view(1, 1))[:, -1].argmax(-1)
+    """
+    import inspect
+    dev = next(model.parameters()).device
+    if dev.type != "cuda":
+        raise RuntimeError("capture_decode_step needs the model on a ROCm GPU")
+    takes_pos = "cache_position" in inspect.signature(model.forward).parameters
+    ids = torch.zeros((batch_size, 1), dtype=torch.long, device=dev)
+    pos = None
+    if takes_pos:
+        last = None
+        for getter in ("get_max_length", "get_max_cache_shape"):
+            if last is None and hasattr(past_key_values, getter):
+                try:
+                    v = getattr(past_key_values, getter)()
+                    last = int(v) - 1 if v is not None and int(v) > 0 else None
+                except Exception:
+                    last = None
+        if last is None and hasattr(past_key_values, "max_cache_len"):
+            last = int(past_key_values.max_cache_len) - 1
+        if last is None or last < 0:
+            raise ValueError("capture_decode_step needs a static key/value cache (fixed max_cache_len)")
+        pos = torch.full((1,), last, dtype=torch.long, device=dev)
+    counters = [l.cumulative_length for l in getattr(past_key_values, "layers", []) if torch.is_tensor(getattr(l, "cumulative_length", None))]
+    saved = [c.clone() for c in counters]
+
+    def step():
+        kw = dict(input_ids=ids, past_key_values=past_key_values, use_cache=True, return_dict=True)
+        if pos is not None:
+            kw["cache_position"] = pos
+        return model(**kw).logits
+
+    cur = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side), torch.no_grad():
+        for _ in range(max(1, warmup)):           # plans, workspace needs and the per-stream scratch are resolved here, outside the capture
+            step()
+        for c, v in zip(counters, saved):         # the warm-up steps advanced the cache's write position: put it back
+            c.copy_(v)
+    cur.wait_stream(side)
+    torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g):
+        logits = step()
+    return DecodeStepGraph(g, ids, pos, logits, past_key_values)
+
+
+__all__ = ["make_quant", "pack_model", "autogptq_post_init", "find_layers", "load_packed_layers", "capture_decode_step", "DecodeStepGraph"]

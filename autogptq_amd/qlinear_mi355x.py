@@ -149,6 +149,7 @@ class QuantLinear(nn.Module):
         self._keepalive = ()          # tensors the raw pointers in _layer refer to
         self._qweight_tiled = self._qconst_tiled = None    # the decode copy (post_init), never part of state_dict
         self._ws_need = {}            # M -> workspace bytes
+        self._ws0_mask = 0            # bit M set: M rows (1..63) are known to need no workspace -- what the C++ fast path (cext/fastfwd.cpp) serves; 0 = never
         self.act_order = None         # resolved by post_init
 
     # ------------------------------------------------------------------ state handling
@@ -168,6 +169,7 @@ class QuantLinear(nn.Module):
         self._keepalive = ()
         self._qweight_tiled = self._qconst_tiled = None
         self._ws_need = {}
+        self._ws0_mask = 0
 
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)
@@ -270,6 +272,8 @@ class QuantLinear(nn.Module):
         self._keepalive = (self.qweight, self.qzeros, self.scales, self.g_idx, self.bias, qweight_seq, perm, qweight_tiled, qconst_tiled)
         self._qweight_tiled, self._qconst_tiled = qweight_tiled, qconst_tiled
         self._ws_need = {}
+        self._ws0_mask = 0
+        self._dt_code = _lib.fwd.dtype_code(self.scales) if _lib.fwd is not None else -1
         return self
 
     # ------------------------------------------------------------------ forward
@@ -280,6 +284,8 @@ class QuantLinear(nn.Module):
                                                             ctypes.byref(tuning) if tuning is not None else None))
             if tuning is None:
                 self._ws_need[M] = need
+                if need == 0 and 0 < M < 64 and _lib.fwd is not None:
+                    self._ws0_mask |= 1 << M
         if need == 0:
             return None, 0
         buf = reserve_workspace(device, need)
@@ -289,7 +295,16 @@ class QuantLinear(nn.Module):
     def forward(self, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = None):
         # The reference's callers are eager (generate() under inference_mode, auto_gptq/modeling/_base.py:415-418), and a decode
         # kernel here runs for ~5 us: everything per call that is not the launch is kept to attribute reads -- device, dtype,
-        # ctypes handles and the layer pointer are resolved once in post_init.
+        # ctypes handles and the layer pointer are resolved once in post_init.  Row counts already known to need no workspace (decode rows: the mask is 0 until
+        # the path below has seen the row count once) go through the C++ fast path: checks on x, at::empty, current stream and the C-ABI call in one
+        # METH_FASTCALL entry (cext/fastfwd.cpp); it answers None for anything but the plain case.
+        mask = self._ws0_mask
+        if mask and tuning is None:
+            r = _lib.fwd.forward(self._layer_addr, x, self.infeatures, self._n_out, self._dt_code, self._dev_index, mask)
+            if r is not None:
+                if r.__class__ is int:
+                    _lib.check(r)
+                return r
         if self._layer is None:
             if x.device.type != "cuda":
                 raise RuntimeError("mi355x QuantLinear.forward needs a ROCm GPU tensor "
@@ -515,6 +530,14 @@ def forward_multi(layers, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = No
         ent = _MULTI[key] = (arr, {}, [l._layer for l in layers], optr_arr, ctypes.addressof(arr), ctypes.addressof(optr_arr),
                              a._dev, a.infeatures, a._w_dtype, tuple(l._n_out for l in layers), a._dev_index, sum(l._n_out for l in layers))
     arr, need_by_m, _, optrs, arr_addr, optr_addr, dev, K, w_dtype, n_outs, idx = ent[:11]
+    if tuning is None:
+        mask = need_by_m.get(-1)           # row counts of this group known to need no workspace: the C++ fast path (cext/fastfwd.cpp) serves them
+        if mask:
+            r = _lib.fwd.forward_multi(arr_addr, n, x, K, n_outs, a._dt_code, idx, optr_addr, mask)
+            if r is not None:
+                if r.__class__ is int:
+                    _lib.check(r)
+                return list(r)
     if x.device != dev:
         raise RuntimeError(f"mi355x forward_multi: input is on {x.device}, the layers on {dev}")
     if x.shape[-1] != K:
@@ -537,6 +560,8 @@ def forward_multi(layers, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = No
             need = int(_lib.load().gptq_workspace_bytes_multi_ex(arr, n, M, tref))
             if tuning is None:
                 need_by_m[M] = need
+                if need == 0 and 0 < M < 64 and _lib.fwd is not None:
+                    need_by_m[-1] = need_by_m.get(-1, 0) | (1 << M)
         ws_ptr, ws_bytes = 0, 0
         if need:
             buf = reserve_workspace(dev, need)

@@ -98,3 +98,43 @@ def test_tiny_llama_generate_matches_dequantised_twin(tmp_path, desc_act, fused)
         gq = qm.generate(ids, max_new_tokens=16, do_sample=False, pad_token_id=0)
     assert gt.shape == (1, 28)
     assert torch.equal(gt, gq), (gt.tolist(), gq.tolist())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("desc_act", [False, True], ids=["seq", "act"])
+def test_tiny_llama_decode_step_as_one_hipgraph(tmp_path, desc_act):
+    """model_utils.capture_decode_step: one decode step of the quantised tiny Llama with a StaticCache as ONE hipGraph -- replayed
+    token by token it must produce exactly the tokens the same model generates eagerly (greedy), and its logits must match the eager step's."""
+    from transformers import StaticCache
+    from autogptq_amd.fused import inject_fused_llama
+    from autogptq_amd.model_utils import autogptq_post_init, capture_decode_step
+
+    dev = "cuda:0"
+    m = TL.fresh_model(2)
+    TL.quantize_and_pack(m, desc_act)
+    TL.save_checkpoint(m, str(tmp_path), desc_act)
+    del m
+    qm, _, _ = TL.load_checkpoint(str(tmp_path))
+    qm = qm.to(dev)
+    inject_fused_llama(qm)                                  # q|k|v and gate|up through gptq_forward_multi: the grouped launches of bench.py's headline
+    qm = autogptq_post_init(qm, use_act_order=desc_act, max_input_length=64)
+    qm.set_attn_implementation("sdpa")                      # transformers' eager mask path builds torch.tensor(0.0, device=...) per call: a host copy, not capturable
+    P, NEW, L = 9, 12, 32
+    ids = torch.randint(0, 512, (1, P), generator=torch.Generator().manual_seed(7)).to(dev)
+    with torch.no_grad():
+        want = qm.generate(ids, max_new_tokens=NEW, do_sample=False, pad_token_id=0)[0, P:].tolist()
+        cache = StaticCache(qm.config, max_cache_len=L)
+        logits = qm(ids, past_key_values=cache, use_cache=True).logits
+        step = capture_decode_step(qm, cache)
+        tok = logits[:, -1].argmax(-1)
+        got = [int(tok)]
+        for i in range(NEW - 1):
+            lg = step(tok.view(1, 1))
+            if i == 0:                                      # the captured step against the same step run eagerly on a second cache
+                c2 = StaticCache(qm.config, max_cache_len=L)
+                qm(ids, past_key_values=c2, use_cache=True)
+                le = qm(tok.view(1, 1), past_key_values=c2, use_cache=True).logits
+                assert float((lg.float() - le.float()).abs().max()) <= 2e-3 * float(le.float().abs().max())
+            tok = lg[:, -1].argmax(-1)
+            got.append(int(tok))
+    assert got == want, (got, want)
