@@ -72,6 +72,22 @@ class GptqError(RuntimeError):
         self.status = status
 
 
+class _Lab:
+    """Names of the LAB switches carried in GptqTuning.reserved[] (include/gptq_mi355x_lab.h is the one definition: parsed here, prefix GPTQ_LAB_ dropped) --
+    ``t.reserved[LAB.GEMM_VARIANT] = LAB.VARIANT_WIDE_SK_ON`` instead of ``t.reserved[3] = 48``.  Not part of the drop-in boundary."""
+
+    def __init__(self):
+        path = os.path.join(os.path.dirname(_HERE), "include", "gptq_mi355x_lab.h")
+        try:
+            text = open(path).read()
+        except OSError:
+            text = ""
+        for m in __import__("re").finditer(r"^#define\s+GPTQ_LAB_(\w+)\s+(\d+)", text, flags=8):
+            setattr(self, m.group(1), int(m.group(2)))
+
+
+LAB = _Lab()
+
 _lib = None
 
 

@@ -170,6 +170,7 @@ class QuantLinear(nn.Module):
         self._qweight_tiled = self._qconst_tiled = None
         self._ws_need = {}
         self._ws0_mask = 0
+        object.__setattr__(self, "_parts", None)
 
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)
@@ -197,7 +198,7 @@ class QuantLinear(nn.Module):
                                f"(got {dev}); there is no CPU path.")
         lib = _lib.load()
         if self.g_idx.numel() != self.infeatures:
-            raise NotImplementedError("len(g_idx) != infeatures (fused-QKV g_idx) is not supported.")
+            return self._post_init_fused_g_idx(temp_dq, tiled)
         # raw device pointers go to the kernels: every buffer has to live on the module's GPU (a host pointer would fault there)
         for name in ("qzeros", "scales", "g_idx", "bias"):
             t = getattr(self, name)
@@ -276,6 +277,34 @@ class QuantLinear(nn.Module):
         self._dt_code = _lib.fwd.dtype_code(self.scales) if _lib.fwd is not None else -1
         return self
 
+    def _post_init_fused_g_idx(self, temp_dq, tiled):
+        """``len(g_idx) == n * infeatures``: the reference's fused q/k/v module of act-order projections (fused_llama_attn.py:186 concatenates the three g_idx;
+        qlinear_cuda.py:300-312 then dequantises column block i -- ``infeatures`` columns wide, its ``num_dim`` -- with g_idx[i K : (i + 1) K]).  Here the n
+        column blocks become n internal layers, each with its own activation order (side copies of the column slices: the checkpoint tensors stay as they
+        are and stay the module's state_dict), and forward runs them through ``forward_multi``: the same values as the reference's per-block loop."""
+        K, N = self.infeatures, self.outfeatures
+        n = self.g_idx.numel() // K if K else 0
+        if n < 2 or self.g_idx.numel() != n * K or N != n * K:
+            raise NotImplementedError(f"len(g_idx) = {self.g_idx.numel()} is neither infeatures ({K}) nor n * infeatures with outfeatures = n * infeatures "
+                                      "(the reference's fused-QKV layout, qlinear_cuda.py:300-312).")
+        if self.epilogue != "none":
+            raise NotImplementedError("a fused-QKV g_idx cannot be combined with an output epilogue")
+        zpw = self.bits * K // 32                       # qzeros words per column block
+        parts = []
+        for i in range(n):
+            p = QuantLinear(self.bits, self.group_size, K, K, self.bias is not None, weight_dtype=self.scales.dtype, zero_mode=self.zero_mode)
+            p.qweight = self.qweight[:, i * K:(i + 1) * K].contiguous()
+            p.qzeros = self.qzeros[:, i * zpw:(i + 1) * zpw].contiguous()
+            p.scales = self.scales[:, i * K:(i + 1) * K].contiguous()
+            p.g_idx = self.g_idx[i * K:(i + 1) * K].to(torch.int32).contiguous()
+            if self.bias is not None:
+                p.bias = self.bias[i * K:(i + 1) * K].contiguous()
+            p.post_init(temp_dq, tiled)
+            parts.append(p)
+        object.__setattr__(self, "_parts", parts)       # not registered submodules: derived state, never part of state_dict
+        self.act_order = any(p.act_order for p in parts)
+        return self
+
     # ------------------------------------------------------------------ forward
     def _workspace(self, M: int, device, tuning=None):
         need = self._ws_need.get(M) if tuning is None else None
@@ -306,10 +335,13 @@ class QuantLinear(nn.Module):
                     _lib.check(r)
                 return r
         if self._layer is None:
-            if x.device.type != "cuda":
-                raise RuntimeError("mi355x QuantLinear.forward needs a ROCm GPU tensor "
-                                   f"(got {x.device}); there is no CPU path in this backend.")
-            self.post_init()
+            if getattr(self, "_parts", None) is None:
+                if x.device.type != "cuda":
+                    raise RuntimeError("mi355x QuantLinear.forward needs a ROCm GPU tensor "
+                                       f"(got {x.device}); there is no CPU path in this backend.")
+                self.post_init()
+            if getattr(self, "_parts", None) is not None:      # fused-QKV g_idx: n column blocks with their own activation orders
+                return torch.cat(forward_multi(self._parts, x, tuning), dim=-1)
         dev = self._dev
         if x.device != dev:
             if x.device.type != "cuda":
@@ -366,8 +398,10 @@ class QuantLinear(nn.Module):
     # ------------------------------------------------------------------ dequant / unpack helpers
     def dequantize(self) -> torch.Tensor:
         """[K, N] dequantised weight in the scales dtype (bit-exact w.r.t. the reference's `weights`)."""
-        if self._layer is None:
+        if self._layer is None and getattr(self, "_parts", None) is None:
             self.post_init()
+        if getattr(self, "_parts", None) is not None:
+            return torch.cat([p.dequantize() for p in self._parts], dim=1)
         W = torch.empty((self.infeatures, self.outfeatures), dtype=self.scales.dtype, device=self.qweight.device)
         with torch.cuda.device(self.qweight.device):
             _lib.check(_lib.load().gptq_dequant(ctypes.byref(self._layer), W.data_ptr(),

@@ -318,7 +318,7 @@ def test_north_star_m4096_wide_tiles(K, N, act, dtype):
 
 
 def test_wide_tiles_forced_on_ragged_shapes():
-    """The same kernel forced (tuning.reserved[3] = 45) on shapes with a partial last row tile, a partial last column tile, bias, both zero-point conventions
+    """The same kernel forced (tuning.reserved[GPTQ_LAB_GEMM_VARIANT] = GPTQ_LAB_VARIANT_WIDE_ON) on shapes with a partial last row tile, a partial last column tile, bias, both zero-point conventions
     and group sizes 64 / 128 / 256 -- and identical, bit for bit, to the 128 x 256 kernel with one K group (same MFMA k order)."""
     from autogptq_amd import _lib
     for (K, N, gs, M, act) in ((256, 544, 128, 200, False), (512, 1056, 64, 333, True), (1024, 512, 256, 129, False), (384, 96, 128, 65, False)):
@@ -332,9 +332,10 @@ def test_wide_tiles_forced_on_ragged_shapes():
             W = O.dequantize(Lq["qweight"], Lq["qzeros"], Lq["scales"], Lq["g_idx"], 4, mode).to(DEV)
             x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).half().to(DEV)
             tw, tn, tc = _lib.GptqTuning(), _lib.GptqTuning(), _lib.GptqTuning()
-            tw.path, tw.reserved[3], tw.ksplit = 3, 47, 1          # wide tiles on the checkpoint rows (register-staged x)
-            tn.path, tn.reserved[3], tn.ksplit = 3, 6, 1
-            tc.path, tc.reserved[3], tc.ksplit = 3, 45, 1          # wide tiles, from the decode copy where the layer has one (raw x by LDS DMA)
+            LAB = _lib.LAB
+            tw.path, tw.reserved[LAB.GEMM_VARIANT], tw.ksplit = 3, LAB.VARIANT_WIDE_ROWS_ON, 1          # wide tiles on the checkpoint rows (register-staged x)
+            tn.path, tn.reserved[LAB.GEMM_VARIANT], tn.ksplit = 3, LAB.VARIANT_ONE_K_GROUP, 1
+            tc.path, tc.reserved[LAB.GEMM_VARIANT], tc.ksplit = 3, LAB.VARIANT_WIDE_ON, 1          # wide tiles, from the decode copy where the layer has one (raw x by LDS DMA)
             assert _lib.describe_plan(q._layer, M, tw)["kernel"] == "wide"
             has_copy = q._qweight_tiled is not None and K % 128 == 0
             assert _lib.describe_plan(q._layer, M, tc)["kernel"] == ("wide_copy" if has_copy else "wide")

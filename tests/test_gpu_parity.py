@@ -214,7 +214,7 @@ def test_magic_number_decode_3_and_8_bit(bits, gs, K, N, M):
         q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], bits, gs, zero_mode=zm)
         y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], bits, mode)
         t_old = _tuning(path=5)
-        t_old.reserved[1] = 1
+        t_old.reserved[_lib.LAB.OPT] = _lib.LAB.OPT_FIELD_DECODE
         with torch.no_grad():
             y_new = q(x.to(DEV), tuning=_tuning(path=5))
             y_old = q(x.to(DEV), tuning=t_old)
@@ -405,7 +405,7 @@ def test_mid_kernel(M, K, N, gs, act, dtype, stages, ksplit, xreg):
     # xreg: 1 = x through registers, 3 = granule combine instead of flags, 10 = 128-column strips (two 64-column halves per wave; <= 64 rows, N % 128 == 0)
     if xreg == 10 and (M > 64 or N % 128):
         pytest.skip("128-column strips: up to 64 rows, N a multiple of 128")
-    t.reserved[0], t.reserved[1], t.reserved[2], t.reserved[3] = stages, (xreg if xreg < 10 else 0), 5, (2 if xreg == 10 else 0)
+    t.reserved[_lib.LAB.DEPTH], t.reserved[_lib.LAB.OPT], t.reserved[_lib.LAB.GEMM_KERNEL], t.reserved[_lib.LAB.GEMM_VARIANT] = stages, (xreg if xreg < 10 else 0), _lib.LAB.GEMM_MID, (2 if xreg == 10 else 0)
     q.post_init()
     d = _lib.describe_plan(q._layer, M, t)
     assert d["kernel"] == "mid", d
@@ -451,7 +451,7 @@ def test_mid_kernel_int8(M, K, N, gs, act, dtype, rbs, ksplit):
         mode = O.ZERO_WRAP if zm == "wrap" else O.ZERO_NOWRAP
         y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 8, mode)
         t = _tuning(path=3, ksplit=ksplit, lanes_n=rbs)
-        t.reserved[2] = 5
+        t.reserved[_lib.LAB.GEMM_KERNEL] = _lib.LAB.GEMM_MID
         q.post_init()
         d = _lib.describe_plan(q._layer, M, t)
         if d["kernel"] != "mid":                     # one group per K-step and a long unsplit K: the per-wave group table does not fit the LDS
@@ -487,7 +487,7 @@ def test_mid_kernel_int3(M, K, N, gs, act, dtype, rbs, ksplit):
         mode = O.ZERO_WRAP if zm == "wrap" else O.ZERO_NOWRAP
         y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 3, mode)
         t = _tuning(path=3, ksplit=ksplit, lanes_n=rbs)
-        t.reserved[2] = 5
+        t.reserved[_lib.LAB.GEMM_KERNEL] = _lib.LAB.GEMM_MID
         q.post_init()
         d = _lib.describe_plan(q._layer, M, t)
         if d["kernel"] != "mid":
@@ -521,7 +521,7 @@ def test_mid_kernel_int2(M, K, N, gs, act, dtype, rbs, ksplit):
         mode = O.ZERO_WRAP if zm == "wrap" else O.ZERO_NOWRAP
         y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 2, mode)
         t = _tuning(path=3, ksplit=ksplit, lanes_n=rbs)
-        t.reserved[2] = 5
+        t.reserved[_lib.LAB.GEMM_KERNEL] = _lib.LAB.GEMM_MID
         q.post_init()
         d = _lib.describe_plan(q._layer, M, t)
         assert d["kernel"] == "mid", d
@@ -549,7 +549,7 @@ def test_mid_multi_layer_launch_3_and_8_bit(bits, gs, M):
     qs = [_module_from(L["qweight"], L["qzeros"], L["scales"], None, L["bias"], bits, gs) for L in Ls]
     x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).half().to(DEV)
     t = _tuning(path=3)
-    t.reserved[2] = 5
+    t.reserved[_lib.LAB.GEMM_KERNEL] = _lib.LAB.GEMM_MID
     with torch.no_grad():
         yf = forward_multi(qs, x, tuning=t)
         yd = forward_multi(qs, x)
@@ -574,7 +574,7 @@ def test_mid_kernel_row_blocks(M, K, N, gs, act, dtype, rbs, ksplit):
     x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype)
     y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP)
     t = _tuning(path=3, ksplit=ksplit, lanes_n=rbs)
-    t.reserved[2] = 5
+    t.reserved[_lib.LAB.GEMM_KERNEL] = _lib.LAB.GEMM_MID
     q.post_init()
     d = _lib.describe_plan(q._layer, M, t)
     assert d["kernel"] == "mid" and int(d["tiles"].split("x")[0]) > 1, d
@@ -609,7 +609,7 @@ def test_mid_multi_layer_launch(M, K, widths, gs, dtype, stages, ksplit):
     qs = [_module_from(L["qweight"], L["qzeros"], L["scales"], None, L["bias"], 4, gs) for L in Ls]
     x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype).to(DEV)
     t = _tuning(path=3, ksplit=ksplit)
-    t.reserved[0], t.reserved[2] = stages, 5
+    t.reserved[_lib.LAB.DEPTH], t.reserved[_lib.LAB.GEMM_KERNEL] = stages, _lib.LAB.GEMM_MID
     with torch.no_grad():
         ys = forward_multi(qs, x, tuning=t)
         ys2 = forward_multi(qs, x, tuning=t)
@@ -713,9 +713,9 @@ def test_gemm_schedule_variants(variant, act):
     x = (torch.rand(M, K, generator=torch.Generator().manual_seed(3)) - 0.5).half().to(DEV)
     q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, 128, zero_mode="wrap")
     t = _tuning(path=3)
-    t.reserved[3] = variant
+    t.reserved[_lib.LAB.GEMM_VARIANT] = variant
     t6 = _tuning(path=3)
-    t6.reserved[3] = 6
+    t6.reserved[_lib.LAB.GEMM_VARIANT] = _lib.LAB.VARIANT_ONE_K_GROUP
     with torch.no_grad():
         y0 = q(x, tuning=t6)
         y1 = q(x, tuning=t)
@@ -737,7 +737,7 @@ def test_gemm_k_groups_inside_workgroup(dtype, act, K, N, M, ksplit):
     x = (torch.rand(M, K, generator=torch.Generator().manual_seed(4)) - 0.5).to(dtype).to(DEV)
     q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, 128, zero_mode="wrap")
     t6, t7 = _tuning(path=3, ksplit=ksplit), _tuning(path=3, ksplit=ksplit)
-    t6.reserved[3], t7.reserved[3] = 6, 7
+    t6.reserved[_lib.LAB.GEMM_VARIANT], t7.reserved[_lib.LAB.GEMM_VARIANT] = _lib.LAB.VARIANT_ONE_K_GROUP, _lib.LAB.VARIANT_TWO_K_GROUPS
     with torch.no_grad():
         y6 = q(x, tuning=t6)
         y7 = q(x, tuning=t7)
@@ -760,7 +760,7 @@ def _check_balanced_tail(bits, gs, dtype, act, K, N, M, slices=None):
     x = (torch.rand(M, K, generator=torch.Generator().manual_seed(40)) - 0.5).to(dtype).to(DEV)
     q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], bits, gs, zero_mode="wrap")
     t_on, t_off = _tuning(path=3), _tuning(path=3)
-    t_on.reserved[3], t_off.reserved[3] = 40, 41
+    t_on.reserved[_lib.LAB.GEMM_VARIANT], t_off.reserved[_lib.LAB.GEMM_VARIANT] = _lib.LAB.VARIANT_TAIL_ON, _lib.LAB.VARIANT_TAIL_OFF
     with torch.no_grad():
         y_off = q(x, tuning=t_off)
         ys = [q(x, tuning=t_on) for _ in range(4)]
@@ -819,7 +819,7 @@ def test_strip16_batched_decode_kernel(M, K, N, gs, act, dtype):
     x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype)
     y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP)
     t3, t1, t3k = _tuning(path=3), _tuning(path=3), _tuning(path=3, ksplit=3)
-    t3.reserved[2], t1.reserved[2], t3k.reserved[2] = 3, 1, 3
+    t3.reserved[_lib.LAB.GEMM_KERNEL], t1.reserved[_lib.LAB.GEMM_KERNEL], t3k.reserved[_lib.LAB.GEMM_KERNEL] = _lib.LAB.GEMM_STRIP16, _lib.LAB.GEMM_SKINNY, _lib.LAB.GEMM_STRIP16
     with torch.no_grad():
         y3, y3b = q(x.to(DEV), tuning=t3), q(x.to(DEV), tuning=t3)
         y1 = q(x.to(DEV), tuning=t1)
@@ -887,7 +887,7 @@ def test_full_size_prefill_properties(K, N, M, act):
     # (c) a 128-aligned row block on its own
     r0 = (M // 2) // 128 * 128
     t = _tuning(path=3, ksplit=1)
-    t.reserved[3] = 6                  # same K decomposition for both launches (no K groups inside the workgroup)
+    t.reserved[_lib.LAB.GEMM_VARIANT] = _lib.LAB.VARIANT_ONE_K_GROUP                  # same K decomposition for both launches (no K groups inside the workgroup)
     with torch.no_grad():
         y_ns = q(x, tuning=t)
         yblk = q(x[r0:r0 + 128].contiguous(), tuning=t)
@@ -1490,7 +1490,7 @@ def test_pack_on_gpu_module_from_cpu_quantizer_outputs_and_device_mismatch_error
 # ------------------------------------------------------------------------- streamed GEMV (LDS DMA) + gptq_forward_multi
 def _stream_tuning(ln, waves, u, ksplit):
     t = _tuning(path=6, lanes_n=ln, waves=waves, ksplit=ksplit)
-    t.reserved[0] = u
+    t.reserved[_lib.LAB.DEPTH] = u
     return t
 
 
@@ -1715,7 +1715,7 @@ def test_stream64_batched_decode_kernel(M, K, N, gs, act, dtype, waves, u, kspli
     x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype)
     y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP)
     t = _tuning(path=3, waves=waves, ksplit=ksplit)
-    t.reserved[0], t.reserved[2] = u, 4
+    t.reserved[_lib.LAB.DEPTH], t.reserved[_lib.LAB.GEMM_KERNEL] = u, _lib.LAB.GEMM_STREAM64
     q.post_init()
     d = _lib.describe_plan(q._layer, M, t)
     assert d["kernel"] == "stream64", d
@@ -1746,7 +1746,7 @@ def test_stream64_multi_layer_launch(M, K, widths, gs, dtype, waves, u, ksplit):
     qs = [_module_from(L["qweight"], L["qzeros"], L["scales"], None, L["bias"], 4, gs) for L in Ls]
     x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype).to(DEV)
     t = _tuning(path=3, waves=waves, ksplit=ksplit)
-    t.reserved[0], t.reserved[2] = u, 4
+    t.reserved[_lib.LAB.DEPTH], t.reserved[_lib.LAB.GEMM_KERNEL] = u, _lib.LAB.GEMM_STREAM64
     with torch.no_grad():
         ys = forward_multi(qs, x, tuning=t)
         ys2 = forward_multi(qs, x, tuning=t)

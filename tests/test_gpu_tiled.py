@@ -29,7 +29,7 @@ def _tune(waves=0, u=0, ks=0):
     t = _lib.GptqTuning()
     t.path = 8
     t.waves, t.ksplit = waves, ks
-    t.reserved[0] = u
+    t.reserved[_lib.LAB.DEPTH] = u
     return t
 
 
@@ -446,3 +446,37 @@ def test_gate_up_silu_mul_is_the_epilogue_of_the_decode_copy_kernel(K, I, gs, bi
         y8 = q(x8)
     ref8 = torch.nn.functional.silu(x8.double() @ Wg + bg) * (x8.double() @ Wu + bu)
     assert not bool(((y8.double() - ref8).abs() > 3 * atol * float(ref8.abs().max()) + 3 * rtol * ref8.abs()).any())
+
+
+@pytest.mark.parametrize("bits,gs", [(4, 128), (8, 32), (3, 64)])
+def test_fused_qkv_g_idx_of_three_activation_orders(bits, gs):
+    """``len(g_idx) == 3 K``: the reference's fused q/k/v module of act-order projections (fused_llama_attn.py:186 concatenates the three g_idx;
+    qlinear_cuda.py:300-312 dequantises column block i with g_idx[i K : (i + 1) K]).  One module holding the concatenated checkpoint tensors must give, for
+    every row count, the outputs of the three projections run on their own -- every output against the oracle's per-block weights -- and dequantize() their
+    concatenation, with the state_dict left as loaded; a g_idx length that is no multiple of K is still refused."""
+    K = 512
+    Ls = [O.random_quant_layer(K, K, bits, gs, act_order=True, seed=70 + i, bias=True) for i in range(3)]
+    f = QuantLinear(bits, gs, K, 3 * K, True)
+    f.qweight = torch.cat([L["qweight"] for L in Ls], dim=1)
+    f.qzeros = torch.cat([L["qzeros"] for L in Ls], dim=1)
+    f.scales = torch.cat([L["scales"] for L in Ls], dim=1)
+    f.g_idx = torch.cat([L["g_idx"] for L in Ls], dim=0)
+    f.bias = torch.cat([L["bias"] for L in Ls], dim=0)
+    f = f.to(DEV)
+    before = {k: v.clone() for k, v in f.state_dict().items()}
+    mode = O.reference_zero_mode(True, bits)
+    W = torch.cat([O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], bits, mode) for L in Ls], dim=1).to(DEV)
+    bias = torch.cat([L["bias"] for L in Ls]).to(DEV)
+    for M in (1, 3, 8, 40, 300):
+        x, _ = _x(M, K, torch.float16, M, hot=False)
+        with torch.no_grad():
+            y, y2 = f(x), f(x)
+        assert tuple(y.shape) == (M, 3 * K) and torch.equal(y, y2)
+        _assert_all(y, x, W, bias, torch.float16, f"fused q|k|v, three activation orders, M={M}")
+    with torch.no_grad():
+        assert torch.equal(f.dequantize(), W)
+    assert set(f.state_dict()) == set(before) and all(torch.equal(f.state_dict()[k], before[k]) for k in before)
+    bad = QuantLinear(bits, gs, K, 3 * K, False)
+    bad.g_idx = torch.zeros(K + 32, dtype=torch.int32)
+    with pytest.raises(NotImplementedError, match="n \\* infeatures"):
+        bad.to(DEV).post_init()

@@ -14,12 +14,12 @@ from oracle import gptq_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-WIDE_SK_ON, WIDE_SK_OFF = 48, 49          # include/gptq_mi355x_lab.h
+WIDE_SK_ON, WIDE_SK_OFF = _lib.LAB.VARIANT_WIDE_SK_ON, _lib.LAB.VARIANT_WIDE_SK_OFF          # include/gptq_mi355x_lab.h
 
 
 def _tune(v):
     t = _lib.GptqTuning()
-    t.path, t.reserved[3] = 3, v
+    t.path, t.reserved[_lib.LAB.GEMM_VARIANT] = 3, v
     return t
 
 

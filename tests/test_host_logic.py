@@ -440,7 +440,7 @@ def test_balanced_tail_rule():
     launch relies on: K steps divide over the slices, the flag words fit the ticket half of the header, the workspace covers the slabs."""
     lib = _lib.load()
     off = _lib.GptqTuning()
-    off.path, off.reserved[3] = 3, 41
+    off.path, off.reserved[_lib.LAB.GEMM_VARIANT] = 3, _lib.LAB.VARIANT_TAIL_OFF
     pinned = [  # K, N, M, act, dtype -> (tail, slices)
         (4096, 11008, 2048, True, 0, (0, 1)),        # 688 tiles: 176 left over, two slices would only move 45 MB around (measured 0.97 - 1.0x)
         (4096, 11008, 4096, True, 0, (0, 1)),        # 1376 tiles, 96 left over: 6.7 % predicted = noise level measured (+5 % / -5 % in two sessions)

@@ -365,3 +365,75 @@ def test_two_processes_one_gpu_peer_store_column_parallel(M, act):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
+
+
+def _two_gpu_worker(rank, world, port, exchange, calls, q):
+    """One rank per REAL device: the column shard's decode kernel with the fused scatter storing into the peer's exchange buffer across xGMI (peer_store), or
+    RCCL's all_gather_into_tensor (all_gather) -- every output of every call against the oracle, the sticky timeout word read at the end."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = f"cuda:{rank}"
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    try:
+        from autogptq_amd import QuantLinear
+        from autogptq_amd.tensor_parallel import ColumnParallelQuantLinear
+        from oracle import gptq_oracle as O
+        K, N = 4096, 4096
+        L = O.random_quant_layer(K, N, 4, 128, act_order=False, seed=21)                 # identical on every rank
+        m = QuantLinear(4, 128, K, N, False)
+        m.qweight, m.qzeros, m.scales, m.g_idx = L["qweight"], L["qzeros"], L["scales"], L["g_idx"]
+        W = O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], 4, O.ZERO_WRAP).to(dev).double()
+        cp = ColumnParallelQuantLinear.from_full(m, rank, world, device=dev, gather_output=True, exchange=exchange, max_rows=4)
+        worst, bad_calls = 0.0, 0
+        with torch.no_grad():
+            for it in range(calls):
+                M = 1 + it % 4
+                x = (torch.rand(M, K, generator=torch.Generator().manual_seed(100 + it)) - 0.5).half().to(dev)
+                y = cp(x)
+                if it % 50 == 0 or it >= calls - 8:                                  # every output, on a sample of the calls and the last ones back to back
+                    ref = x.double() @ W
+                    err = float((y.double() - ref).abs().max() / ref.abs().max())
+                    worst = max(worst, err)
+                    bad_calls += int(err > 3e-3)
+        if exchange == "peer_store":
+            cp._px.check_timeout()                                                   # raises if any collect gave up on the peer
+        dist.barrier()
+        fused_ok = exchange != "peer_store" or cp.fused_calls == calls
+        q.put((rank, tuple(y.shape) == (M, N) and bad_calls == 0 and fused_ok, dict(worst=worst, bad_calls=bad_calls, fused_calls=getattr(cp, "fused_calls", None))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the first multi-GPU lease runs it by itself)")
+@pytest.mark.parametrize("exchange", ["all_gather", "peer_store"])
+def test_two_gpus_column_parallel_across_xgmi(exchange):
+    """The first test that runs on two REAL devices: RCCL all-gather and the direct peer-store exchange with the scatter fused into the decode kernel's epilogue
+    (csrc/gemv_tiled_kernel.cuh: sc0 sc1 write-through stores into the PEER's buffer, the flag raised by the collect launch) -- 1,000 back-to-back calls,
+    outputs against the oracle, the sticky error word checked.  Every earlier TP test ran with both ranks on one device, where "peer" memory is local."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_gpu_worker, args=(r, world, port, exchange, 1000, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res, deadline = [], time.time() + 300
+    while len(res) < world:
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() > deadline:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                pytest.fail(f"two-GPU workers: exit codes {[p.exitcode for p in procs]}, results so far {res}")
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
