@@ -135,7 +135,15 @@ bool want_stream(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
 constexpr int TILED_ROWS_MAX = 8;
 static bool tiled_rows8_pays(const gptq_layer_t* const* Ls, int n) {
     const gptq_layer_t& L = *Ls[0];
-    return n == 1 && L.bits == 4 && !L.g_idx && L.K >= 2048 && L.K <= 4096 && L.N >= 2048 && L.N <= 4096;
+    if (n == 1 && L.bits == 4 && !L.g_idx && L.K >= 2048 && L.K <= 4096 && L.N >= 2048 && L.N <= 4096) return true;
+    // launches of 1024+ strips (gate|up of a 7B block): two strips per workgroup behind one staged x (gemv_tiled_multi.hip) -- M = 8 16.5 us against 17.3 for
+    // the batched-decode kernel on the checkpoint rows (profiles/r05_multi_strip_ab.log); 8 rows of x over the whole K have to fit the LDS
+    long strips = 0;
+    for (int i = 0; i < n; ++i) {
+        if (Ls[i]->bits != 4 || Ls[i]->g_idx || Ls[i]->N % 32) return false;
+        strips += Ls[i]->N / 16;
+    }
+    return n >= 2 && strips >= 1024 && L.K <= 4096;
 }
 // plan_out: the plan the answer was derived from (the eager decode call computes it ONCE: a launch of this kernel runs for 4.5 us, the host side of an eager
 // call is measured in the same unit -- tools/host_cost.py)

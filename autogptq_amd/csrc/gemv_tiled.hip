@@ -38,6 +38,8 @@ hipError_t launch_tiled_peer(const TiledPlan& pl, const TiledParams& p, int dtyp
 hipError_t init_gemv_tiled_peer_device();
 hipError_t launch_tiled_pair(const TiledPlan& pl, const TiledParams& p, int dtype, hipStream_t st);     // gemv_tiled_pair.hip
 hipError_t init_gemv_tiled_pair_device();
+hipError_t launch_tiled_multi(const TiledPlan& pl, const TiledParams& p, int dtype, hipStream_t st);    // gemv_tiled_multi.hip
+hipError_t init_gemv_tiled_multi_device();
 
 // ---- plan + launch ---------------------------------------------------------------------------------------------------------------------
 static int tiled_kpl(int bits) { return bits == 8 ? 16 : 32; }          // k per lane and chunk
@@ -82,6 +84,20 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
     }
     if (pair) strips /= 2;
     pl.pair = pair;
+    // Strips per workgroup (gemv_tiled_multi.hip): 3..8 rows of plain layers whose widths are whole groups of strips and that need no K slices -- every strip
+    // staging its own rows of x is what those forms lose on layers of many strips.  tuning.reserved[GPTQ_LAB_OPT] = 1 / 2 / 4 (with path = 8) forces the count.
+    int nstr = 1;
+    if (!pair && M >= 3 && !A.g_idx) {
+        // measured (tools/multi_strip_ab.py, profiles/r05_multi_strip_ab.log, us, 1 / 2 / 4 strips per workgroup): gate|up M = 4 13.2 / 12.6 / 16.5, M = 8 21.2 / 16.5 / 21.4
+        // (the batched-decode kernel on the checkpoint rows: 17.3); q|k|v M = 8 12.8 / 11.2 / 11.3 (10.8); 4096x11008 M = 8 12.2 / 11.0 / 11.0 (10.5); 3..4 rows
+        // on launches below ~1000 strips lose 0.7 - 1 us -- two strips per workgroup from 1024 strips up, else one
+        const int want = (tune && tune->path == 8 && tune->reserved[1]) ? tune->reserved[1] : (strips >= 1024 ? 2 : 1);
+        if (want == 2 || want == 4) {
+            nstr = want;
+            for (int i = 0; i < n; ++i)
+                if (Ls[i]->N % (GPTQ_STRIP_COLS * want) != 0) nstr = 1;
+        }
+    }
     pl.nseg = n;
     pl.mt = M >= 5 ? 8 : (M >= 3 ? 4 : M);                                        // 5..8 rows: a second A operand (rows 4..7), two matrix-core steps per decoded pair
     const int cke = 4 * tiled_kpl(A.bits), rec = tiled_rec_bytes(A.bits);         // k per chunk; bytes of one group's constants
@@ -99,11 +115,17 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         while (!pair && strips * ks < 128 && chunks / (ks * 2) >= 8) ks *= 2;
     }
     if (pair && ks != 1) return pl;
+    if (nstr > 1 && (ks != 1 || strips / nstr < 96)) nstr = 1;                    // K slices (narrow layers): one strip per workgroup, as before
+    if (nstr > 1 && (size_t)pl.mt * ((size_t)chunks * cke * 2 + 16) + (size_t)nstr * (((size_t)pl.groups * rec + 15) & ~(size_t)15) + 16 * (pl.mt * 16 + 4) * sizeof(float) + 16 > 96 * 1024)
+        nstr = 1;                                                                 // the rows of x over the whole K do not fit next to the constants (8 rows at K = 11008): K slices, one strip per workgroup
+    pl.nstr = nstr;
+    if (nstr > 1) strips /= nstr;
+    pl.strips_total = strips;
     const size_t raw_bytes = A.g_idx ? (size_t)pl.mt * ((size_t)A.K * 2 + 16) + 16 : 0;      // act-order: does not shrink with K slices
     const size_t lds_cap = 96 * 1024 + raw_bytes;
     auto lds_need = [&](int k_slices, int waves) {
         const int cps = (chunks + k_slices - 1) / k_slices;
-        return (size_t)pl.mt * ((size_t)cps * cke * 2 + 16) + (pair ? 2 : 1) * (((size_t)pl.groups * rec + 15) & ~(size_t)15) + (size_t)waves * (pl.mt * 16 + 4) * sizeof(float) + 16 +
+        return (size_t)pl.mt * ((size_t)cps * cke * 2 + 16) + (pair ? 2 : nstr) * (((size_t)pl.groups * rec + 15) & ~(size_t)15) + (size_t)waves * (pl.mt * 16 + 4) * sizeof(float) + 16 +
                (A.dtype == GPTQ_BF16 && pl.mt <= 2 ? (size_t)cps * 64 : 0) +
                (A.g_idx ? (size_t)pl.mt * ((size_t)A.K * 2 + 16) + 16 : 0);         // act-order: the raw x rows, whole K                      // bf16: one inverse block factor per (run of a chunk's 4, row of 4)
     };
@@ -127,11 +149,14 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         else { waves = 4; u = 4; }
         if (pl.mt > 4) { waves = 8; u = 4; }                                      // 5..8 rows, 4096^2: 6.62 us (4 x 4: 6.82, 16 x 2: 6.92)
         if (pair && waves == 4) waves = 8;                                        // two strips per workgroup: the 4-wave form's work per wave
-        while (waves > (pair ? 2 : 1) && (waves / (pair ? 4 : 2)) * u >= cps) waves /= 2;
+        if (nstr > 1) { waves = nstr == 4 ? 16 : 8; u = 4; }                      // four (two) strips x four waves x four chunks in flight
+        const int per = pair ? 2 : nstr;
+        while (waves > per && (waves / (2 * per)) * u >= cps) waves /= 2;
     }
     if (pair && (waves & 1)) return pl;
+    if (nstr > 1 && waves % nstr != 0) return pl;
     if (waves < 1 || waves > 16 || (u != 1 && u != 2 && u != 4 && u != 8)) return pl;
-    if ((A.bits != 4 || A.g_idx || pl.mt > 4 || pair) && u != 2 && u != 4) return pl;     // the 3- / 8-bit, the act-order and the 5..8-row forms are compiled for 2 and 4 chunks in flight
+    if ((A.bits != 4 || A.g_idx || pl.mt > 4 || pair || nstr > 1) && u != 2 && u != 4) return pl;     // the 3- / 8-bit, the act-order and the 5..8-row forms are compiled for 2 and 4 chunks in flight
     pl.waves = waves;
     pl.u = u;
     pl.xstride = cps * cke * 2 + 16;
@@ -165,7 +190,7 @@ hipError_t launch_tiled(const gptq_layer_t* const* Ls, const TiledPlan& pl, cons
     for (int i = 0; i < 4; ++i) p.blk_end[i] = 0x7fffffff;
     for (int i = 0; i < pl.nseg; ++i) {
         const gptq_layer_t& L = *Ls[i];
-        blk += L.N / GPTQ_STRIP_COLS / (pl.pair ? 2 : 1);
+        blk += L.N / GPTQ_STRIP_COLS / (pl.pair ? 2 : pl.nstr);
         p.blk_end[i] = blk;
         p.seg[i] = TiledSeg{L.qweight_tiled, L.qconst_tiled, L.bias, outs[i], L.N, col, L.g_idx ? L.perm : nullptr};
         col += L.N;
@@ -190,6 +215,7 @@ hipError_t launch_tiled(const gptq_layer_t* const* Ls, const TiledPlan& pl, cons
         return launch_tiled_peer(pl, p, A.dtype, st);                             // gemv_tiled_peer.hip
     }
     if (pl.pair) return (pl.u == 2 || pl.u == 4) ? launch_tiled_pair(pl, p, A.dtype, st) : hipErrorInvalidValue;   // gemv_tiled_pair.hip
+    if (pl.nstr > 1) return (pl.u == 2 || pl.u == 4) ? launch_tiled_multi(pl, p, A.dtype, st) : hipErrorInvalidValue;  // gemv_tiled_multi.hip
     if (A.g_idx) return launch_tiled_act(pl, p, A.dtype, st);                     // gemv_tiled_act.hip
     return A.dtype == GPTQ_BF16 ? launch_tiled_bits<bf16, 0>(pl, p, st) : launch_tiled_bits<f16, 0>(pl, p, st);
 }
@@ -199,7 +225,8 @@ hipError_t init_gemv_tiled_device() {
     hipError_t e2 = init_gemv_tiled_act_device();
     hipError_t e3 = init_gemv_tiled_peer_device();
     hipError_t e4 = init_gemv_tiled_pair_device();
-    return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : (e3 != hipSuccess ? e3 : e4));
+    hipError_t e5 = init_gemv_tiled_multi_device();
+    return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : (e3 != hipSuccess ? e3 : (e4 != hipSuccess ? e4 : e5)));
 }
 
 }  // namespace gptq

@@ -66,6 +66,11 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
     // workgroup takes strip s of the gate half AND strip s of the up half (N / 32 strips further) behind ONE staged x: the first half of its waves
     // streams the one, the second half the other; SiLU(gate) * up is formed on the fp32 sums behind the cross-wave reduction (no K slices: the planner).
     constexpr bool PAIR = XM == 4;
+    // XM = 5 / 6 (MULTI, round 5): FOUR / TWO adjacent strips of a layer per workgroup behind ONE staged x -- the 5..8-row form staged 64 KiB of x per
+    // 16-column strip (K = 4096), which the per-CU L2 pull rate (~50 GB/s, profiles/r03_xfetch_lab.log) turned into microseconds on layers of hundreds of
+    // strips; the waves split into NSTR groups, one per strip, and the cross-wave sum is per strip (no K slices: the planner).
+    constexpr bool MULTI = XM == 5 || XM == 6;
+    constexpr int NSTR = PAIR ? 2 : (XM == 5 ? 4 : (XM == 6 ? 2 : 1));            // strips per workgroup
     using F = TiledFmt<BITS>;
     constexpr int WPL = F::WPL, KPL = F::KPL, CKE = 4 * KPL, CHB = 64 * WPL * 4, REC = F::REC, NX = KPL / 8;      // k per chunk, bytes per chunk, x pieces per lane and chunk
     constexpr int LKPL = KPL == 32 ? 5 : 4;
@@ -95,25 +100,25 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
     const TiledSeg sg = p.seg[s];                                                 // one dependent kernarg load
     const int strip = sidx - (s == 0 ? 0 : (s == 1 ? be0 : (s == 2 ? be1 : be2)));
     const int N = sg.N;
-    const int Wh = PAIR ? (W >> 1) : W;                                           // waves per strip
-    const int sel = PAIR ? (wave >= Wh ? 1 : 0) : 0;                              // PAIR: 0 = the gate strip, 1 = the up strip (wave-uniform)
-    const int wv = PAIR ? wave - sel * Wh : wave;
-    const int strip_w = PAIR ? strip + sel * (N >> 5) : strip;                    // the strip this WAVE streams
+    const int Wh = NSTR == 4 ? (W >> 2) : (NSTR == 2 ? (W >> 1) : W);             // waves per strip
+    const int sel = NSTR == 1 ? 0 : ((wave >= Wh ? 1 : 0) + (NSTR == 4 ? (wave >= 2 * Wh ? 1 : 0) + (wave >= 3 * Wh ? 1 : 0) : 0));      // which of the workgroup's strips (wave-uniform); PAIR: 0 = gate, 1 = up
+    const int wv = NSTR == 1 ? wave : wave - sel * Wh;
+    const int strip_w = PAIR ? strip + sel * (N >> 5) : (MULTI ? strip * NSTR + sel : strip);      // the strip this WAVE streams
     const int cb = ks * cps, ce = min(cb + cps, nchunks);                         // this slice's chunks
     const int kbeg = cb * CKE, kend = min(ce * CKE, K);                           // ... and its k range: what is staged of x
     // LDS: [x: MT rows of (kend - kbeg) values, row stride + 16 B][constants: G x REC bytes][cross-wave sums]
     char* const xs = smem;                                                        // row stride xstride = chunks_per_split * CKE * 2 + 16 bytes: the 4 rows of a 4-lane group hit different banks
     char* const cs = smem + (size_t)MT * xstride;
     const size_t cpad = ((size_t)G * REC + 15) & ~(size_t)15;
-    float* const red = (float*)(cs + (PAIR ? 2 : 1) * cpad);
-    const char* const cg = (const char*)sg.cst + (size_t)strip * G * REC;         // this strip's constants: one contiguous run
+    float* const red = (float*)(cs + NSTR * cpad);
+    const char* const cg = (const char*)sg.cst + (size_t)(MULTI ? strip * NSTR : strip) * G * REC;      // this strip's (MULTI: these strips') constants: one contiguous run
     const char* const tb = (const char*)sg.tq + (size_t)strip_w * nchunks * CHB;  // this wave's strip of weights: one contiguous run
     const unsigned t_lane = (unsigned)lane * (WPL * 4u);
     // ---- stage x and the constants by LDS DMA: no VGPRs, issued FIRST (loads return in issue order), waited for behind the first weight burst
     {
         const unsigned xs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)xs, cs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)cs;
         const int pieces = (kend - kbeg) >> 3;                                    // 16-byte pieces per x row
-        if constexpr (XM == 0 || XM == 3 || XM == 4) {
+        if constexpr (XM == 0 || XM == 3 || XM == 4 || MULTI) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const char* xr = xg + ((size_t)min(m, Mrows - 1) * K + kbeg) * 2;
@@ -131,7 +136,7 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
                     if (pc0 + lane < rpieces) lds_dma16(xr + (size_t)(pc0 + lane) * 16, xr_lds + m * (K * 2 + 16) + pc0 * 16);
             }
         }
-        const int cpieces = (G * REC) >> 4;                                       // REC is a multiple of 16
+        const int cpieces = ((G * REC) >> 4) * (MULTI ? NSTR : 1);                // REC is a multiple of 16 (MULTI: adjacent strips' records are adjacent, cpad = G * REC)
         for (int pc0 = wave * 64; pc0 < cpieces; pc0 += W * 64)
             if (pc0 + lane < cpieces) dma16_nt(cg + (size_t)(pc0 + lane) * 16, __builtin_amdgcn_readfirstlane(cs_lds + pc0 * 16));
         if constexpr (PAIR) {                                                     // the up strip's constants behind the gate strip's
@@ -262,7 +267,7 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
             const int k0 = cc * CKE + kb * KPL;                                   // first k of this lane's words
             const bool live = (c0 + j < ce) && (k0 < K);                          // a ragged last chunk: whole k-slots are missing
             const int g = min(k0 >> LKPL >> gshift, G - 1);
-            const char* cp = cs + (PAIR ? (size_t)sel * cpad : (size_t)0) + g * REC;
+            const char* cp = cs + (NSTR > 1 ? (size_t)sel * cpad : (size_t)0) + g * REC;
             const unsigned short sraw = *(const unsigned short*)(cp + col * 2);
             unsigned z;
             if constexpr (F::ZB == 1) z = *(const unsigned char*)(cp + 32 + col);
@@ -361,6 +366,19 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
         }
         return;
     }
+    if constexpr (MULTI) {
+        // per strip: the sum over its group of waves (fixed order), bias, one rounding
+        for (int e = tid; e < NSTR * MT * 16; e += W * 64) {
+            const int s4 = e / (MT * 16), r = e - s4 * (MT * 16), m = r >> 4, c = r & 15, n = (strip * NSTR + s4) * 16 + c;
+            float t = 0.f;
+            for (int w = 0; w < Wh; ++w) t += red[(s4 * Wh + w) * ES + r];
+            if (m < Mrows && n < N) {
+                if (sg.bias) t += DType<T>::to_f32(((const T*)sg.bias)[n]);
+                ((T*)sg.out)[(size_t)m * N + n] = DType<T>::from_f32(t);
+            }
+        }
+        return;
+    }
     T* const stage = PEER ? (T*)xs : nullptr;                                      // the staged x is dead behind the barrier above
     stream_finish<16, MT, T, TiledParams, TiledSeg>(p, sg, strip, sidx, ks, N, red, stage);
     if constexpr (PEER) if (ks == 0) {                                            // uniform: the strip's owner
@@ -404,11 +422,14 @@ static hipError_t launch_tiled_u(const TiledPlan& pl, const TiledParams& p, hipS
 }
 template <int BITS, typename T, int XM>
 static hipError_t launch_tiled_mt(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
+    if constexpr (XM == 5 || XM == 6) {                                           // multi-strip workgroups: the 3..4-row and 5..8-row forms only
+        if (pl.mt != 4 && pl.mt != 8) return hipErrorInvalidValue;
+    }
     switch (pl.mt) {
-        case 1: return launch_tiled_u<BITS, 1, T, XM>(pl, p, st);
-        case 2: return launch_tiled_u<BITS, 2, T, XM>(pl, p, st);
+        case 1: if constexpr (XM != 5 && XM != 6) return launch_tiled_u<BITS, 1, T, XM>(pl, p, st); else return hipErrorInvalidValue;
+        case 2: if constexpr (XM != 5 && XM != 6) return launch_tiled_u<BITS, 2, T, XM>(pl, p, st); else return hipErrorInvalidValue;
         case 4: return launch_tiled_u<BITS, 4, T, XM>(pl, p, st);
-        case 8: if constexpr (XM != 3 && XM != 4) return launch_tiled_u<BITS, 8, T, XM>(pl, p, st); else return hipErrorInvalidValue;      // 5..8 rows: plain and act-order forms
+        case 8: if constexpr (XM != 3 && XM != 4) return launch_tiled_u<BITS, 8, T, XM>(pl, p, st); else return hipErrorInvalidValue;      // 5..8 rows: plain, act-order and multi-strip forms
         default: return hipErrorInvalidValue;
     }
 }
@@ -440,7 +461,8 @@ static hipError_t grant_tiled_lds() {
         grant_u(I4{}, I2{}); grant_u(I4{}, I4{});
         grant_u(I8{}, I2{}); grant_u(I8{}, I4{}); grant_u(I3{}, I2{}); grant_u(I3{}, I4{});
     };
-    grant_mt(std::integral_constant<int, 1>{}); grant_mt(std::integral_constant<int, 2>{}); grant_mt(std::integral_constant<int, 4>{});
+    if constexpr (XM != 5 && XM != 6) { grant_mt(std::integral_constant<int, 1>{}); grant_mt(std::integral_constant<int, 2>{}); }
+    grant_mt(std::integral_constant<int, 4>{});
     if constexpr (XM != 3 && XM != 4) grant_mt(std::integral_constant<int, 8>{});
     return e;
 }

@@ -105,6 +105,7 @@ hipError_t launch_stream64(const gptq_layer_t* const* layers, const Stream64Plan
 // Decode from the load-time decode copy (gemv_tiled.hip: gemv_tiled_kernel): 1..4 plain 3/4/8-bit layers with qweight_tiled / qconst_tiled that read the same x, M <= 4, one launch.
 struct TiledPlan {
     bool ok;                 // every layer qualifies and the geometry fits
+    int nstr;                // strips per workgroup (1; 2 / 4: gemv_tiled_multi.hip -- adjacent strips of a layer behind one staged x)
     bool pair;               // one [gate | up] layer with the SILU_MUL epilogue: a workgroup per pair of strips, SiLU * mul behind the cross-wave sum
     int nseg, bits, waves, u, mt, ksplit, chunks_total, chunks_per_split, strips_total, nsum, groups, xstride, xraw_off;
     size_t lds_bytes;

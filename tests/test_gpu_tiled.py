@@ -480,3 +480,41 @@ def test_fused_qkv_g_idx_of_three_activation_orders(bits, gs):
     bad.g_idx = torch.zeros(K + 32, dtype=torch.int32)
     with pytest.raises(NotImplementedError, match="n \\* infeatures"):
         bad.to(DEV).post_init()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("nstr", [2, 4])
+def test_several_strips_per_workgroup_behind_one_staged_x(nstr, dtype):
+    """Round 5 (gemv_tiled_multi.hip, XM = 5 / 6): FOUR / TWO adjacent strips of a layer per workgroup share ONE staged x; the waves split into one group per
+    strip and the cross-wave sum is per strip.  Forced (tuning.path = 8, reserved[GPTQ_LAB_OPT] = strips per workgroup) at 3..8 rows on a single layer and on
+    a three-layer launch; EVERY output against the oracle, one-hot rows exact, bit-reproducible, and the planner's own choice at 5..8 rows is that form."""
+    LAB = _lib.LAB
+    K = 1024
+    made = [_layer(K, N, 128, dtype, 300 + i, bias=True) for i, N in enumerate((6400, 1024, 1024))]
+    layers = [m[1] for m in made]
+    for M in (3, 4, 5, 8):
+        x, ks = _x(M, K, dtype, M)
+        t = _tune()
+        t.reserved[LAB.OPT] = nstr
+        d = _lib.describe_plan(layers[0]._layer, M, t)
+        assert d["kernel"] == "strips" and int(d["strips"]) == 6400 // 16 // nstr, d
+        with torch.no_grad():
+            y, y2 = layers[0](x, tuning=t), layers[0](x, tuning=t)
+            ym = forward_multi(layers, x, t)
+        assert torch.equal(y, y2)
+        _assert_all(y, x, made[0][2], made[0][0]["bias"].to(DEV), dtype, f"{nstr} strips per workgroup, M={M}")
+        for (L, q, W), yy in zip(made, ym):
+            _assert_all(yy, x, W, L["bias"].to(DEV), dtype, f"{nstr} strips per workgroup, three layers in one launch, M={M}, N={q.outfeatures}")
+        assert torch.equal(ym[0], y)
+        saved = [q._layer.bias for q in layers]
+        for q in layers:
+            q._layer.bias = None
+        with torch.no_grad():
+            yh = layers[0](x, tuning=t)
+        for q, b in zip(layers, saved):
+            q._layer.bias = b
+        for r, k in ks:
+            assert torch.equal(yh[r], made[0][2][k]), f"one-hot row {r} -> k={k} (M={M})"
+    t8 = _tune()
+    d = _lib.describe_plan(layers[0]._layer, 8, t8)                 # path = 8 without a count: the planner's own (two strips per workgroup only from 1024 strips)
+    assert int(d["strips"]) == 6400 // 16, d
