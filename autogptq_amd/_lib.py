@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPTQ_MI355X_LIB", os.path.join(_HERE, "libgptq_mi355x.so"))
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 GPTQ_F16, GPTQ_BF16, GPTQ_F32 = 0, 1, 2
 ZERO_WRAP, ZERO_NOWRAP = 0, 1
@@ -27,7 +27,7 @@ EXPORTS = (
     "gptq_abi_version", "gptq_last_error", "gptq_status_string", "gptq_workspace_bytes", "gptq_workspace_bytes_ex",
     "gptq_forward", "gptq_forward_ex", "gptq_gemv", "gptq_gemm", "gptq_dequant",
     "gptq_unpack_weights", "gptq_unpack_zeros", "gptq_pack_weights", "gptq_pack_zeros",
-    "gptq_make_sequential", "gptq_resequence_qweight", "gptq_permute_columns", "gptq_prepack_decode", "gptq_prepack_decode_bytes",
+    "gptq_make_sequential", "gptq_resequence_qweight", "gptq_permute_columns", "gptq_prepack_decode", "gptq_prepack_decode_bytes", "gptq_unprepack_decode",
     "gptq_awq_unpack", "gptq_awq_repack", "gptq_describe_plan",
     "gptq_init", "gptq_workspace_bytes_max", "gptq_validate_g_idx",
     "gptq_forward_multi", "gptq_workspace_bytes_multi", "gptq_forward_multi_ex", "gptq_workspace_bytes_multi_ex",
@@ -136,6 +136,7 @@ def load() -> ctypes.CDLL:
     lib.gptq_permute_columns.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.gptq_prepack_decode_bytes.argtypes = [POINTER(GptqLayer), POINTER(c_size_t), POINTER(c_size_t)]
     lib.gptq_prepack_decode.argtypes = [POINTER(GptqLayer), c_void_p, c_void_p, c_void_p]
+    lib.gptq_unprepack_decode.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.gptq_describe_plan.argtypes = [POINTER(GptqLayer), c_int, POINTER(GptqTuning), c_char_p, c_size_t]
     lib.gptq_awq_unpack.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.gptq_awq_repack.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]

@@ -789,6 +789,16 @@ int gptq_prepack_decode(const gptq_layer_t* L, uint32_t* tiled_out, void* const_
     return GPTQ_OK;
 }
 
+int gptq_unprepack_decode(const uint32_t* qweight_tiled, int K, int N, int bits, uint32_t* qweight_out, void* stream) {
+    if (!qweight_tiled || !qweight_out) return fail(GPTQ_ERR_NULL, "qweight_tiled/qweight_out must be non-NULL");
+    if (bits != 3 && bits != 4 && bits != 8) return fail(GPTQ_ERR_UNSUPPORTED, "the decode copy exists for 3-, 4- and 8-bit layers (got %d)", bits);
+    if (K <= 0 || N <= 0 || K % 32 || N % GPTQ_STRIP_COLS) return fail(GPTQ_ERR_SHAPE, "K (%d) must be a positive multiple of 32 and N (%d) of %d", K, N, GPTQ_STRIP_COLS);
+    if ((const void*)qweight_tiled == (const void*)qweight_out) return fail(GPTQ_ERR_UNSUPPORTED, "gptq_unprepack_decode does not work in place");
+    hipError_t e = launch_unprepack_decode(qweight_tiled, K, N, bits, qweight_out, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "gptq_unprepack_decode launch");
+    return GPTQ_OK;
+}
+
 int gptq_permute_columns(const void* x, const int32_t* perm, int M, int K, int dtype, void* x_out, void* stream) {
     if (!x || !perm || !x_out) return fail(GPTQ_ERR_NULL, "x/perm/x_out must be non-NULL");
     if (!dtype_ok(dtype)) return fail(GPTQ_ERR_UNSUPPORTED, "unsupported dtype enum %d", dtype);

@@ -121,6 +121,7 @@ size_t tiled_weight_bytes(const gptq_layer_t& L);
 size_t tiled_const_bytes(const gptq_layer_t& L);
 hipError_t launch_prepack_decode(const uint32_t* qweight, const uint32_t* qzeros, const void* scales, int K, int N, int bits, int group_size, int zero_mode,
                                  uint32_t* tiled_out, void* const_out, hipStream_t st);
+hipError_t launch_unprepack_decode(const uint32_t* tiled, int K, int N, int bits, uint32_t* qweight_out, hipStream_t st);      // the exact inverse (weights)
 bool stream_preferred(const gptq_layer_t& L, int M);                              // single layer: streamed kernel instead of the register one?
 bool multi_preferred(const gptq_layer_t* const* layers, int n, int M);             // several layers sharing x: one streamed launch?
 hipError_t launch_silu_mul2(const void* g, const void* u, void* out, size_t total, int dtype, hipStream_t st);

@@ -281,6 +281,48 @@ __global__ void __launch_bounds__(256) prepack_decode_weights_kernel(const unsig
     }
     out[((size_t)s * chunks + c) * (64 * WPL) + (kb * 16 + col) * WPL + w] = v;
 }
+// The inverse of the weights half (round 5: gptq_unprepack_decode): one thread = one word of the checkpoint layout [K/32*bits, N], rebuilt value by value from
+// the copy -- what lets a layer whose checkpoint rows have left the HBM (QuantLinear.post_init(release_checkpoint_layout=True)) still serve the kernels that
+// read rows, and what state_dict() / a re-save would be rebuilt from.  Reference behaviour it answers: the in-place re-layouts of exllama / exllamav2
+// (q4_matrix.cu:160, q_matrix.cu:149) keep ONE copy of the weights on the device.
+template <int BITS>
+__global__ void __launch_bounds__(256) unprepack_decode_weights_kernel(const unsigned* __restrict__ t, int K, int N, int chunks, unsigned* __restrict__ out) {
+    constexpr int WPL = BITS == 3 ? 3 : 4, KPL = BITS == 8 ? 16 : 32, CKE = 4 * KPL;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;          // output word (row r, column n)
+    if (n >= N) return;
+    const int s = n >> 4, col = n & 15;
+    auto val = [&](int k) -> unsigned {                                          // the copy's value (k, n)
+        const int c = k / CKE, kb = (k - c * CKE) / KPL, j = k - c * CKE - kb * KPL;
+        const unsigned* lw = t + ((size_t)s * chunks + c) * (64 * WPL) + (kb * 16 + col) * WPL;
+        if constexpr (BITS == 4) {
+            const int i = j & 7, p = (i & 1) ? 4 + (i >> 1) : (i >> 1);          // stored nibble order k0 k2 k4 k6 k1 k3 k5 k7
+            return (lw[j >> 3] >> (4 * p)) & 15u;
+        } else if constexpr (BITS == 8) {
+            const int i = j & 3, p = i == 1 ? 2 : (i == 2 ? 1 : i);              // stored byte order k0 k2 k1 k3
+            return (lw[j >> 2] >> (8 * p)) & 255u;
+        } else {
+            const int pr = j >> 1, hi = (j & 1) * 16;
+            if (pr < 15) return (lw[pr / 5] >> (3 * (pr % 5) + hi)) & 7u;
+            return ((lw[0] >> (15 + hi)) & 1u) | (((lw[1] >> (15 + hi)) & 1u) << 1) | (((lw[2] >> (15 + hi)) & 1u) << 2);
+        }
+    };
+    unsigned v = 0;
+    if constexpr (BITS == 3) {
+        const int unit = r / 3, wi = r - unit * 3;                               // 32 values in 96 bits, little-endian bit stream (qlinear_cuda.py:144-162)
+        for (int f = 0; f < 32; ++f) {
+            const int bit = 3 * f - 32 * wi;                                     // position of field f in this word
+            if (bit <= -3 || bit >= 32) continue;
+            const unsigned x = val(unit * 32 + f);
+            v |= bit >= 0 ? (x << bit) : (x >> (-bit));
+        }
+    } else {
+        constexpr int P = 32 / BITS;
+#pragma unroll
+        for (int f = 0; f < P; ++f) v |= val(r * P + f) << (BITS * f);
+    }
+    out[(size_t)r * N + n] = v;
+}
+
 // one thread = one (strip, group, column): 2 bytes of scale (bit copy) + the zero-point as used (1 byte; 2 bytes at 8 bits, where it reaches 256)
 __global__ void __launch_bounds__(256) prepack_decode_consts_kernel(const unsigned* __restrict__ qzeros, const unsigned short* __restrict__ scales, int G, int N,
                                                                     int bits, int zero_mode, unsigned char* __restrict__ out) {
@@ -384,6 +426,18 @@ hipError_t launch_pack_weights(const void* W, const void* scale_in, const void* 
 hipError_t launch_pack_zeros(const void* zero_in, int G, int N, int bits, int qparam_dtype, uint32_t* qzeros_out, hipStream_t st) {
     dim3 grid((N / unit_vals(bits) + 255) / 256, G), block(256);
     GPTQ_BITS_SWITCH(bits, hipLaunchKernelGGL(pack_zeros_kernel<B>, grid, block, 0, st, zero_in, G, N, qparam_dtype, qzeros_out));
+    return hipGetLastError();
+}
+
+hipError_t launch_unprepack_decode(const uint32_t* tiled, int K, int N, int bits, uint32_t* qweight_out, hipStream_t st) {
+    const int cke = bits == 8 ? 64 : 128, chunks = (K + cke - 1) / cke, rows = K / 32 * bits;
+    const dim3 grid((N + 255) / 256, rows);
+    switch (bits) {
+        case 4: hipLaunchKernelGGL(unprepack_decode_weights_kernel<4>, grid, dim3(256), 0, st, tiled, K, N, chunks, qweight_out); break;
+        case 8: hipLaunchKernelGGL(unprepack_decode_weights_kernel<8>, grid, dim3(256), 0, st, tiled, K, N, chunks, qweight_out); break;
+        case 3: hipLaunchKernelGGL(unprepack_decode_weights_kernel<3>, grid, dim3(256), 0, st, tiled, K, N, chunks, qweight_out); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -85,9 +85,14 @@ def pack_model(model: nn.Module, quantizers: dict, bits: int, group_size: int, d
         qlayers[name].pack(layers[name], scale, zero, g_idx)
 
 
-def autogptq_post_init(model: nn.Module, use_act_order: bool = False, max_input_length: Optional[int] = None) -> nn.Module:
+def autogptq_post_init(model: nn.Module, use_act_order: bool = False, max_input_length: Optional[int] = None,
+                       release_checkpoint_layout: Optional[bool] = None, decode_copy: Optional[bool] = None) -> nn.Module:
     """post_init every mi355x layer and size the per-device scratch once (so forward never allocates; needed before hipGraph
-    capture).  ``max_input_length`` bounds the rows M the scratch is sized for (default 2048, the reference's exllama default)."""
+    capture).  ``max_input_length`` bounds the rows M the scratch is sized for (default 2048, the reference's exllama default).
+    Memory (the model-level switches for what post_init keeps next to the checkpoint tensors): ``decode_copy=False`` builds no decode copy (1x the packed
+    bytes, the round-1..3 kernels); ``release_checkpoint_layout=True`` keeps the copy and moves ``qweight`` of plain layers to pinned host memory (1x on
+    the device again; ``state_dict()`` unchanged; row counts whose kernel reads packed rows rebuild them per call into one shared scratch).  Default: both
+    layouts on the device (2x; act-order layers 3x with their re-sequenced rows) -- 288 GB of HBM is what makes that the default."""
     rows = max_input_length or 2048
     need: Dict[torch.device, int] = {}
     for _, sub in model.named_modules():
@@ -95,7 +100,7 @@ def autogptq_post_init(model: nn.Module, use_act_order: bool = False, max_input_
             continue
         if sub.qweight.device.type != "cuda":
             continue
-        sub.post_init()
+        sub.post_init(tiled=decode_copy, release_checkpoint_layout=release_checkpoint_layout)
         lib = _lib.load()
         # the need is not monotone in M (K splits come and go with the kernel the planner picks): maximum over 1..rows
         b = int(lib.gptq_workspace_bytes_max(ctypes.byref(sub._layer), rows))

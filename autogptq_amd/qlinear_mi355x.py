@@ -78,6 +78,23 @@ except AttributeError:                 # pragma: no cover
         return torch.cuda.current_stream(idx).cuda_stream
 
 
+_ROWS_SCRATCH: dict = {}    # device index -> uint8 tensor: packed rows rebuilt from a decode copy (layers whose checkpoint layout was released)
+
+
+def reserve_rows_scratch(device, nbytes: int) -> torch.Tensor:
+    """One buffer per device, grown (never shrunk) to the largest released layer: gptq_unprepack_decode writes a layer's packed rows here right before a kernel
+    that reads rows runs.  Calls on one stream are ordered; layers that run concurrently on several streams must not be released."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _ROWS_SCRATCH.get(idx)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=torch.device("cuda", idx))
+        if idx in _ROWS_SCRATCH:
+            _RETIRED.append(_ROWS_SCRATCH[idx])       # a captured graph may still hold the old address
+        _ROWS_SCRATCH[idx] = buf
+    return buf
+
+
 def _is_sequential_g_idx(g_idx: torch.Tensor, group_size: int) -> bool:
     k = g_idx.numel()
     ref = torch.arange(k, dtype=torch.int64, device=g_idx.device) // group_size
@@ -89,6 +106,13 @@ class QuantLinear(nn.Module):
     EXCHANGE_CHECK_EVERY = 4096   # workspace-taking calls between two reads of the exchanges' sticky error word (0 = never; exchange_error() reads it on demand)
     _exchange_calls = 0
     TILED_DECODE = True       # post_init derives the strip-major side copy of qweight for the decode kernels (a second copy of the packed weights)
+    # Round 5: ONE copy of the weights on the device.  With the switch on (or post_init(release_checkpoint_layout=True) / autogptq_post_init(...,
+    # release_checkpoint_layout=True)) a PLAIN layer that carries its decode copy moves ``qweight`` to pinned host memory behind post_init -- state_dict()
+    # still returns it, bit for bit -- and the decode and prefill kernels (M <= 4, 5..8 where planned, M >= ~512) run from the copy alone.  Row counts whose
+    # kernel reads packed ROWS (the batched-decode band) rebuild them per call into a scratch shared by all layers of the device (gptq_unprepack_decode: the
+    # exact inverse, ~10 us for a 4096 x 11008 layer).  Act-order layers keep their buffers (the copy is made of their re-sequenced rows).
+    RELEASE_CHECKPOINT_LAYOUT = False
+    _extra_bytes_logged = False
 
     def __init__(
         self,
@@ -148,6 +172,7 @@ class QuantLinear(nn.Module):
         self._layer = None            # ctypes GptqLayer
         self._keepalive = ()          # tensors the raw pointers in _layer refer to
         self._qweight_tiled = self._qconst_tiled = None    # the decode copy (post_init), never part of state_dict
+        self._released = False        # post_init(release_checkpoint_layout=True): qweight lives in pinned host memory, rows are rebuilt on demand
         self._ws_need = {}            # M -> workspace bytes
         self._ws0_mask = 0            # bit M set: M rows (1..63) are known to need no workspace -- what the C++ fast path (cext/fastfwd.cpp) serves; 0 = never
         self.act_order = None         # resolved by post_init
@@ -170,6 +195,7 @@ class QuantLinear(nn.Module):
         self._qweight_tiled = self._qconst_tiled = None
         self._ws_need = {}
         self._ws0_mask = 0
+        self._rows_need = {}
         object.__setattr__(self, "_parts", None)
 
     def _load_from_state_dict(self, *args, **kwargs):
@@ -188,10 +214,12 @@ class QuantLinear(nn.Module):
         return _lib.ZERO_WRAP
 
     # ------------------------------------------------------------------ post_init
-    def post_init(self, temp_dq=None, tiled=None):
+    def post_init(self, temp_dq=None, tiled=None, release_checkpoint_layout=None):
         """Snapshot device pointers and, for act-order layers, derive the group-sorted copy of
         qweight plus the x permutation (side buffers; qweight itself is never modified -- the
         reference's exllama backends overwrite it in place, q4_matrix.cu:160)."""
+        if self.qweight.device.type != "cuda" and self.scales.device.type == "cuda" and getattr(self, "_released", False):
+            self.qweight = self.qweight.to(self.scales.device)      # a released layer initialised again: the rows come back first
         dev = self.qweight.device
         if dev.type != "cuda":
             raise RuntimeError("mi355x QuantLinear.post_init needs the module on a ROCm GPU device "
@@ -275,7 +303,47 @@ class QuantLinear(nn.Module):
         self._ws_need = {}
         self._ws0_mask = 0
         self._dt_code = _lib.fwd.dtype_code(self.scales) if _lib.fwd is not None else -1
+        self._released = False
+        self._rows_need = {}
+        if release_checkpoint_layout is None:
+            release_checkpoint_layout = self.RELEASE_CHECKPOINT_LAYOUT
+        if qweight_tiled is not None:
+            extra = qweight_tiled.numel() + qconst_tiled.numel() + (qweight_seq.numel() * 4 if qweight_seq is not None else 0)
+            if release_checkpoint_layout and not self.act_order:
+                # the checkpoint rows leave the HBM: the registered buffer becomes a pinned host tensor (state_dict() unchanged), the kernels that read rows
+                # get them rebuilt into the shared scratch (_rows_scratch) right before they run
+                self._qweight_rows_bytes = self.qweight.numel() * 4
+                host = torch.empty(self.qweight.shape, dtype=self.qweight.dtype, pin_memory=True)
+                host.copy_(self.qweight)
+                self.qweight = host
+                L.qweight = reserve_rows_scratch(dev, self._qweight_rows_bytes).data_ptr()
+                self._keepalive = (None,) + tuple(self._keepalive[1:])
+                self._released = True
+            elif not QuantLinear._extra_bytes_logged:
+                QuantLinear._extra_bytes_logged = True
+                logger.info("mi355x QuantLinear: post_init keeps a decode copy of the packed weights next to the checkpoint tensors (+%d bytes for this layer; "
+                            "%s).  QuantLinear.TILED_DECODE = False turns the copy off, RELEASE_CHECKPOINT_LAYOUT = True (or "
+                            "autogptq_post_init(release_checkpoint_layout=True)) keeps ONE copy on the device.", extra,
+                            "act-order: + the re-sequenced rows" if qweight_seq is not None else "plain layer: 2x the packed bytes")
         return self
+
+    def _rebuild_rows(self, M: int, tuning=None) -> None:
+        """Released layers: if the kernel planned for M rows reads packed ROWS, rebuild them from the decode copy into the device's shared scratch (whose address
+        the layer struct already carries) -- in stream order right in front of the call.  The answer per row count is cached."""
+        need = self._rows_need.get(M) if tuning is None else None
+        if need is None:
+            d = _lib.describe_plan(self._layer, M, tuning)
+            need = not (d.get("kernel") in ("strips", "wide_sk", "wide_copy"))
+            if tuning is None:
+                self._rows_need[M] = need
+        if need:
+            dev = self._dev
+            buf = reserve_rows_scratch(dev, self._qweight_rows_bytes)
+            if buf.data_ptr() != self._layer.qweight:
+                self._layer.qweight = buf.data_ptr()
+            with torch.cuda.device(dev):
+                _lib.check(_lib.load().gptq_unprepack_decode(self._qweight_tiled.data_ptr(), self.infeatures, self.outfeatures, self.bits, buf.data_ptr(),
+                                                             _lib.current_stream_handle(dev)))
 
     def _post_init_fused_g_idx(self, temp_dq, tiled):
         """``len(g_idx) == n * infeatures``: the reference's fused q/k/v module of act-order projections (fused_llama_attn.py:186 concatenates the three g_idx;
@@ -328,7 +396,7 @@ class QuantLinear(nn.Module):
         # the path below has seen the row count once) go through the C++ fast path: checks on x, at::empty, current stream and the C-ABI call in one
         # METH_FASTCALL entry (cext/fastfwd.cpp); it answers None for anything but the plain case.
         mask = self._ws0_mask
-        if mask and tuning is None:
+        if mask and tuning is None and not self._released:
             r = _lib.fwd.forward(self._layer_addr, x, self.infeatures, self._n_out, self._dt_code, self._dev_index, mask)
             if r is not None:
                 if r.__class__ is int:
@@ -365,6 +433,8 @@ class QuantLinear(nn.Module):
         M = x2.shape[0]
         n_out = self._n_out
         out = torch.empty((M, n_out), dtype=w_dtype, device=dev)
+        if M != 0 and self._released:
+            self._rebuild_rows(M, tuning)
         if M != 0:
             need = self._ws_need.get(M) if tuning is None else None
             if need == 0:
@@ -402,10 +472,19 @@ class QuantLinear(nn.Module):
             self.post_init()
         if getattr(self, "_parts", None) is not None:
             return torch.cat([p.dequantize() for p in self._parts], dim=1)
-        W = torch.empty((self.infeatures, self.outfeatures), dtype=self.scales.dtype, device=self.qweight.device)
-        with torch.cuda.device(self.qweight.device):
+        dev = self.scales.device
+        if self._released:
+            self._rows_need.pop(-1, None)
+            self._rows_need[-1] = True
+            buf = reserve_rows_scratch(dev, self._qweight_rows_bytes)
+            self._layer.qweight = buf.data_ptr()
+            with torch.cuda.device(dev):
+                _lib.check(_lib.load().gptq_unprepack_decode(self._qweight_tiled.data_ptr(), self.infeatures, self.outfeatures, self.bits, buf.data_ptr(),
+                                                             _lib.current_stream_handle(dev)))
+        W = torch.empty((self.infeatures, self.outfeatures), dtype=self.scales.dtype, device=dev)
+        with torch.cuda.device(dev):
             _lib.check(_lib.load().gptq_dequant(ctypes.byref(self._layer), W.data_ptr(),
-                                                _lib.current_stream_handle(self.qweight.device)))
+                                                _lib.current_stream_handle(dev)))
         return W
 
     # ------------------------------------------------------------------ pack
@@ -545,6 +624,9 @@ def forward_multi(layers, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = No
     # launch here takes 4.5 - 12 us, and the reference's callers are eager (generate() under inference_mode) -- per call only what depends on x remains.
     a = layers[0]
     n = len(layers)
+    if any(getattr(l, "_released", False) for l in layers) and x.numel() // max(1, a.infeatures) > 4:
+        # layers whose checkpoint rows left the HBM share ONE rows scratch: beyond the decode rows (which run from the copies) they are called one by one
+        return [l(x, tuning) for l in layers]
     key = tuple([id(l._layer) for l in layers]) if a._layer is not None else None
     ent = _MULTI.get(key) if key is not None else None
     if ent is None:
@@ -636,6 +718,9 @@ def mlp_forward(gate: QuantLinear, up: QuantLinear, down: QuantLinear, x: torch.
     for l in (gate, up, down):
         if l._layer is None:
             l.post_init()
+    if any(getattr(l, "_released", False) for l in (gate, up, down)) and x.numel() // max(1, gate.infeatures) > 4:
+        g, u = forward_multi([gate, up], x)              # released layers (one shared rows scratch): composed from single calls
+        return down(torch.nn.functional.silu(g) * u)
     dev = gate._dev
     if x.device != dev:
         raise RuntimeError(f"mi355x mlp_forward: input is on {x.device}, the layers on {dev}")

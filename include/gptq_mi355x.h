@@ -69,7 +69,7 @@
 extern "C" {
 #endif
 
-#define GPTQ_MI355X_ABI_VERSION 6
+#define GPTQ_MI355X_ABI_VERSION 7
 #define GPTQ_WORKSPACE_HEADER_BYTES 65536
 
 typedef enum gptq_status_t {
@@ -271,6 +271,11 @@ int gptq_resequence_qweight(const uint32_t *qweight, const int32_t *perm, int K,
  * (marlin/marlin_repack.cu:8-92) -- without touching the checkpoint tensors. */
 int gptq_prepack_decode_bytes(const gptq_layer_t *layer, size_t *tiled_bytes, size_t *const_bytes);
 int gptq_prepack_decode(const gptq_layer_t *layer, uint32_t *qweight_tiled_out, void *qconst_tiled_out, void *stream);
+/* The exact inverse of the weights half (round 5): qweight_out [K/32*bits, N] = the packed rows the copy was made from (qweight, or qweight_seq of an act-order
+ * layer), bit for bit.  What lets ONE copy of the weights stay on the device -- the reference's fast backends re-lay their weights IN PLACE
+ * (exllama/cuda_func/q4_matrix.cu:160, exllamav2/cuda/q_matrix.cu:149) -- while state_dict() / a re-save / the kernels that read rows are still served:
+ * QuantLinear.post_init(release_checkpoint_layout=True) moves qweight to host memory and rebuilds rows into a shared scratch only for calls that need them. */
+int gptq_unprepack_decode(const uint32_t *qweight_tiled, int K, int N, int bits, uint32_t *qweight_out, void *stream);
 /* x_out[m, i] = x[m, perm[i]] */
 int gptq_permute_columns(const void *x, const int32_t *perm, int M, int K, int dtype, void *x_out, void *stream);
 

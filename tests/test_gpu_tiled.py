@@ -518,3 +518,60 @@ def test_several_strips_per_workgroup_behind_one_staged_x(nstr, dtype):
     t8 = _tune()
     d = _lib.describe_plan(layers[0]._layer, 8, t8)                 # path = 8 without a count: the planner's own (two strips per workgroup only from 1024 strips)
     assert int(d["strips"]) == 6400 // 16, d
+
+
+@pytest.mark.parametrize("bits,K,N,gs", [(4, 4096, 4096, 128), (4, 160, 64, 32), (8, 2112, 1024, 64), (3, 1056, 64, 1056), (3, 4096, 256, 32), (8, 96, 32, 32)])
+def test_unprepack_decode_is_the_exact_inverse(bits, K, N, gs):
+    """gptq_unprepack_decode(gptq_prepack_decode(qweight)) == qweight, bit for bit, for every packing with a decode copy (ragged last chunks, the 3-bit
+    straddlers); at 4 bits also the oracle's own inverse (decode_copy_weights_inverse)."""
+    lib = _lib.load()
+    L, q, W = _layer(K, N, gs, torch.float16, K + N + bits, bits=bits)
+    assert q._qweight_tiled is not None
+    back = torch.empty_like(q.qweight)
+    _lib.check(lib.gptq_unprepack_decode(q._qweight_tiled.data_ptr(), K, N, bits, back.data_ptr(), _lib.current_stream_handle(torch.device(DEV))))
+    torch.cuda.synchronize()
+    assert torch.equal(back.cpu(), L["qweight"]), "the inverse does not restore the checkpoint rows"
+    if bits == 4:
+        chunks = -(-K // 128)
+        t = q._qweight_tiled.view(torch.int32).reshape(N // 16, chunks, 4, 16, 4).cpu()
+        assert torch.equal(O.decode_copy_weights_inverse(t, K), L["qweight"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_release_checkpoint_layout_keeps_one_copy_on_the_device(dtype):
+    """post_init(release_checkpoint_layout=True): qweight of a plain layer moves to pinned host memory (state_dict unchanged, bit for bit), decode and prefill
+    rows run from the decode copy alone and the row counts in between rebuild the packed rows into the shared scratch -- every row count gives the SAME bits
+    as the layer that keeps both layouts; two released layers of different shapes interleave on one scratch; .to() brings the rows back."""
+    from autogptq_amd import qlinear_mi355x as qm
+    shapes = [(1024, 2048, 128), (2048, 512, 64)]
+    pairs = []
+    for i, (K, N, gs) in enumerate(shapes):
+        L = O.random_quant_layer(K, N, 4, gs, dtype=dtype, seed=500 + i, bias=True)
+        mods = []
+        for rel in (False, True):
+            m = QuantLinear(4, gs, K, N, True, weight_dtype=dtype)
+            m.qweight, m.qzeros, m.scales, m.g_idx, m.bias = L["qweight"].clone(), L["qzeros"].clone(), L["scales"].clone(), L["g_idx"].clone(), L["bias"].clone()
+            m = m.to(DEV)
+            m.post_init(release_checkpoint_layout=rel)
+            mods.append(m)
+        keep, rel = mods
+        assert rel._released and rel.qweight.device.type == "cpu" and rel.qweight.is_pinned() and keep.qweight.device.type == "cuda"
+        assert torch.equal(rel.state_dict()["qweight"].cpu(), L["qweight"]) and set(rel.state_dict()) == set(keep.state_dict())
+        pairs.append((L, keep, rel))
+    for M in (1, 4, 8, 16, 64, 200, 1024):
+        for (L, keep, rel) in pairs:                            # interleaved: the second layer's rebuild overwrites the scratch the first one used
+            x, _ = _x(M, L["K"], dtype, M, hot=False)
+            with torch.no_grad():
+                assert torch.equal(rel(x), keep(x)), f"released layer differs at M={M}"
+    with torch.no_grad():
+        for (L, keep, rel) in pairs:
+            assert torch.equal(rel.dequantize(), keep.dequantize())
+            x, _ = _x(16, L["K"], dtype, 3, hot=False)
+            ym = qm.forward_multi([rel], x)[0]
+            assert torch.equal(ym, keep(x))
+    L, keep, rel = pairs[0]
+    rel2 = rel.to(DEV)                                          # the rows come back with the module
+    assert rel2.qweight.device.type == "cuda" and torch.equal(rel2.qweight.cpu(), L["qweight"])
+    x, _ = _x(16, L["K"], dtype, 5, hot=False)
+    with torch.no_grad():
+        assert torch.equal(rel2(x), keep(x))
