@@ -2093,12 +2093,13 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
         // The same wave tile as a stream-K partition of 128 x 256 tiles (gemm_wide_sk.hip) everywhere else from ~768 rows: every CU runs the same number of
         // 128-deep K-chunks whatever the tile count -- BASELINE config 3 (M = 2048: 256 / 688 / 256 tiles on the three Llama-7B shapes).  Decode-copy layers
         // only (act-order: x permuted in natural order).
-        if (pl.mt == 4 && pl.bk == 64 && pl.variant == 0 && wide_knob == 0 && tail_knob == 0 && sk_knob != GPTQ_LAB_VARIANT_WIDE_SK_OFF && copy_ok &&
+        if (pl.mt == 4 && pl.variant == 0 && wide_knob == 0 && tail_knob == 0 && sk_knob != GPTQ_LAB_VARIANT_WIDE_SK_OFF && copy_ok &&      // (wide_sk_ok has the kernel's own conditions: 3 / 4 bits, 32-wide groups too)
             !(tune && tune->ksplit > 0 && tune->path == 3 && tune->ksplit != 1) && wide_sk_ok(L, M) &&
             (sk_knob == GPTQ_LAB_VARIANT_WIDE_SK_ON || (!pl.wide && wide_sk_pays(L, M)))) {
             pl.wsk = true;
             pl.wskg = wide_sk_geom(L, M);
             pl.wide = false; pl.wide_tiled = true; pl.xnat = pl.use_seq; pl.xslot = false; pl.glds = true;
+            pl.bk = 64; pl.ksteps_total = L.K / 64;
             pl.tail = 0; pl.tail_lg = 0; pl.ksplit = 1; pl.ksteps_per_split = pl.ksteps_total; pl.kg = 2;
             pl.bn = 256; pl.nbm = pl.wskg.nbm; pl.nbn = pl.wskg.nbn;
             pl.workspace_bytes = pl.xperm_bytes + pl.wskg.slot_bytes;
@@ -2247,7 +2248,7 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
     p.ksteps_total = pl.ksteps_total; p.ksteps_per_split = pl.ksteps_per_split;
     p.qrows = L.K / 32 * L.bits;
     if (!pl.f32) {
-        const unsigned long long kpg = (unsigned long long)(L.group_size / pl.bk);       // K-steps per group (>= 1: group_size % bk == 0)
+        const unsigned long long kpg = (unsigned long long)(L.group_size >= pl.bk ? L.group_size / pl.bk : 1);       // K-steps per group (the stream-K kernel alone runs 64-deep steps on 32-wide groups and has its own parameters)
         p.kpg_inv = ((1ull << 32) + kpg - 1) / kpg;
     }
     hipError_t e;

@@ -92,6 +92,113 @@ template <> struct Deq4<bf16> {            // w - z exactly in packed fp16, time
     }
 };
 
+// ---- 3-bit and 8-bit forms (round 5: the stream-K kernel on BASELINE config 5) -----------------------------------------------------------------------
+// Constants come from the decode copy's records (qconst_tiled: 16 scales + 16 zero-points AS USED per strip and group): 4 scales (8 bytes) and the
+// zero-points of the lane's 4 columns -- one byte each at 3 bits (z <= 8), 16 bits each at 8 bits (z <= 256).
+struct CRaw8 { u32x2 s; u32x2 z; };
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+
+__device__ __forceinline__ unsigned bf16_scaled_pair(f16x2 h, float sc) {      // (w - z) exact in fp16, times the scale in fp32, ONE rounding to bf16
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    float lo, hi;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hb), "v"(sc));
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(hb), "v"(sc));
+    const bf16x2 v = {(bf16)lo, (bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+template <typename T> struct Scale4;           // the 4 columns' scales and the last step of every pair: (w - z) * scale, rounded once to T
+template <> struct Scale4<f16> {
+    f16x2 s2[4];
+    __device__ __forceinline__ void setup(u32x2 s) {
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+            const unsigned sw = s[col >> 1];
+            s2[col] = as_f16x2(((col & 1) ? (sw >> 16) : (sw & 0xffffu)) * 0x00010001u);
+        }
+    }
+    __device__ __forceinline__ unsigned mul(f16x2 h, int col) const { return f16x2_bits(h * s2[col]); }
+};
+template <> struct Scale4<bf16> {
+    float s[4];
+    __device__ __forceinline__ void setup(u32x2 sv) {
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+            const unsigned sw = sv[col >> 1];
+            s[col] = (float)__builtin_bit_cast(bf16, (unsigned short)((col & 1) ? (sw >> 16) : (sw & 0xffffu)));
+        }
+    }
+    __device__ __forceinline__ unsigned mul(f16x2 h, int col) const { return bf16_scaled_pair(h, s[col]); }
+};
+
+// 3 bits (decode copy, utils.hip prepack_decode_weights_kernel<3>): word j of a lane's three holds pair 5 j + i = (k 2p, k 2p + 1) at bit 3 i of its low / high
+// half, i = 0..4; bit 15 / 31 of word j = bit j of k30 / k31.  A field inside the fp16 mantissa (bits 0..9) is read in place: OR-ing the exponent of 1024
+// gives 1024 + 2^(3i) w, and one fma with 2^(-3i) and -(2^(10-3i) + z) leaves w - z exactly; fields i = 3, 4 are read from q >> 6 as i = 1, 2.
+template <typename T> struct Deq3 {
+    Scale4<T> sc;
+    f16x2 c0[4], c1[4], c2[4];
+    __device__ __forceinline__ void setup(const CRaw& c) {
+        sc.setup(c.s);
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+            const unsigned z = (c.z >> (8 * col)) & 0xffu;
+            c0[col] = as_f16x2(z * 0x00010001u + 0xE400E400u);                 // -(1024 + z)
+            c1[col] = as_f16x2(z * 0x00080008u + 0xD800D800u);                 // -(128 + z): the ulp at 128 is 1/8
+            c2[col] = as_f16x2(z * 0x00400040u + 0xCC00CC00u);                 // -(16 + z): the ulp at 16 is 1/64
+        }
+    }
+    __device__ __forceinline__ f16x2 p0(unsigned q, int col) const { return as_f16x2(and_or(q, 0x00070007u, 0x64006400u)) + c0[col]; }
+    __device__ __forceinline__ f16x2 p1(unsigned q, int col) const {
+        const f16x2 r = {(f16)0.125f, (f16)0.125f};
+        return as_f16x2(and_or(q, 0x00380038u, 0x64006400u)) * r + c1[col];
+    }
+    __device__ __forceinline__ f16x2 p2(unsigned q, int col) const {
+        const f16x2 r = {(f16)0.015625f, (f16)0.015625f};
+        return as_f16x2(and_or(q, 0x01c001c0u, 0x64006400u)) * r + c2[col];
+    }
+    // the 8 values k = 8 ks .. 8 ks + 7 of the lane's 32 (pairs 4 ks .. 4 ks + 3); ks is a constant after unrolling
+    __device__ __forceinline__ u32x4 frag(const u32x3& w, int ks, int col) const {
+        f16x2 h[4];
+        if (ks == 0) {
+            h[0] = p0(w[0], col); h[1] = p1(w[0], col); h[2] = p2(w[0], col); h[3] = p1(w[0] >> 6, col);
+        } else if (ks == 1) {
+            h[0] = p2(w[0] >> 6, col); h[1] = p0(w[1], col); h[2] = p1(w[1], col); h[3] = p2(w[1], col);
+        } else if (ks == 2) {
+            const unsigned q6 = w[1] >> 6;
+            h[0] = p1(q6, col); h[1] = p2(q6, col); h[2] = p0(w[2], col); h[3] = p1(w[2], col);
+        } else {
+            const unsigned q6 = w[2] >> 6;
+            unsigned t = (w[0] >> 15) & 0x00010001u;
+            t = and_or(w[1] >> 14, 0x00020002u, t);
+            t = and_or(w[2] >> 13, 0x00040004u, t);
+            h[0] = p2(w[2], col); h[1] = p1(q6, col); h[2] = p2(q6, col); h[3] = p0(t, col);
+        }
+        return u32x4{sc.mul(h[0], col), sc.mul(h[1], col), sc.mul(h[2], col), sc.mul(h[3], col)};
+    }
+};
+
+// 8 bits: stored byte p of word w = k 4 w + {0, 2, 1, 3}[p]: (q & 0x00ff00ff) = (k0, k1), the same on q >> 8 = (k2, k3); 1024 + w - (1024 + z) is exact
+template <typename T> struct Deq8 {
+    Scale4<T> sc;
+    f16x2 c1[4];
+    __device__ __forceinline__ void setup(const CRaw8& c) {
+        sc.setup(c.s);
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+            const unsigned zw = c.z[col >> 1];
+            const unsigned z = (col & 1) ? (zw >> 16) : (zw & 0xffffu);
+            c1[col] = as_f16x2(z * 0x00010001u + 0xE400E400u);
+        }
+    }
+    // the 8 values of one MFMA step: two adjacent words of the lane's eight
+    __device__ __forceinline__ u32x4 frag(unsigned q0, unsigned q1, int col) const {
+        const f16x2 h0 = as_f16x2(and_or(q0, 0x00ff00ffu, 0x64006400u)) + c1[col];
+        const f16x2 h1 = as_f16x2(and_or(q0 >> 8, 0x00ff00ffu, 0x64006400u)) + c1[col];
+        const f16x2 h2 = as_f16x2(and_or(q1, 0x00ff00ffu, 0x64006400u)) + c1[col];
+        const f16x2 h3 = as_f16x2(and_or(q1 >> 8, 0x00ff00ffu, 0x64006400u)) + c1[col];
+        return u32x4{sc.mul(h0, col), sc.mul(h1, col), sc.mul(h2, col), sc.mul(h3, col)};
+    }
+};
+
 __device__ __forceinline__ unsigned short t_bits(f16 v) { return __builtin_bit_cast(unsigned short, v); }
 __device__ __forceinline__ unsigned short t_bits(bf16 v) { return __builtin_bit_cast(unsigned short, v); }
 

@@ -35,19 +35,40 @@ CASES = [
 ]
 
 
+# the 3-bit decode copy and 32-wide groups (gemm_wide_sk_b38.hip; BASELINE config 5 is int3 / int8 at group_size 32): (bits, K, N, group_size, M, act_order)
+CASES_B38 = [
+    (3, 1024, 512, 128, 256, False, "3 bits, groups of 128: every tile cut in 4"),
+    (3, 512, 1056, 32, 128 * 86 - 77, True, "3 bits, 32-wide groups (each half of the wave on its own group), act-order, shifted last row tile, partial last column tile"),
+    (3, 768, 544, 64, 333, False, "3 bits, groups of 64, three units per tile, ragged M and N"),
+    (3, 4096, 512, 32, 640, False, "3 bits g32, deep K"),
+    (4, 1024, 544, 32, 333, False, "4 bits on 32-wide groups: constants from the checkpoint rows, one group per half"),
+    (4, 2048, 256, 32, 128, True, "4 bits g32 act-order: one tile, one finisher adds 7 published pieces"),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("case", CASES_B38, ids=[f"int{c[0]}_{c[1]}x{c[2]}g{c[3]}M{c[4]}{'act' if c[5] else ''}" for c in CASES_B38])
+def test_wide_sk_3bit_and_g32_every_output(case, dtype):
+    _every_output(case[0], case[1:], dtype)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
 @pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}x{c[1]}g{c[2]}M{c[3]}{'act' if c[4] else ''}" for c in CASES])
 def test_wide_sk_forced_every_output(case, dtype):
+    _every_output(4, case, dtype)
+
+
+def _every_output(bits, case, dtype):
     K, N, gs, M, act, _ = case
     for zm in ("auto", "nowrap"):
-        Lq = O.random_quant_layer(K, N, 4, gs, act_order=act, seed=K + N + M, bias=True, dtype=dtype)
-        q = QuantLinear(4, gs, K, N, True, weight_dtype=dtype, zero_mode=zm)
+        Lq = O.random_quant_layer(K, N, bits, gs, act_order=act, seed=K + N + M, bias=True, dtype=dtype)
+        q = QuantLinear(bits, gs, K, N, True, weight_dtype=dtype, zero_mode=zm)
         q.qweight, q.qzeros, q.scales, q.g_idx, q.bias = Lq["qweight"], Lq["qzeros"], Lq["scales"], Lq["g_idx"], Lq["bias"]
         q = q.to(DEV)
         q.post_init()
         assert q._qweight_tiled is not None
-        mode = O.ZERO_NOWRAP if (zm == "nowrap" or act) else O.ZERO_WRAP
-        W = O.dequantize(Lq["qweight"], Lq["qzeros"], Lq["scales"], Lq["g_idx"], 4, mode).to(DEV)
+        mode = O.ZERO_NOWRAP if (zm == "nowrap" or act or bits == 3) else O.ZERO_WRAP          # auto: qlinear_cuda_old's 3-bit branch and the act-order class do not wrap
+        W = O.dequantize(Lq["qweight"], Lq["qzeros"], Lq["scales"], Lq["g_idx"], bits, mode).to(DEV)
         x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype).to(DEV)
         t = _tune(WIDE_SK_ON)
         plan = _lib.describe_plan(q._layer, M, t)
@@ -59,7 +80,7 @@ def test_wide_sk_forced_every_output(case, dtype):
         rtol = 1e-3 if dtype == torch.float16 else 8e-3
         scale = float(ref.abs().max())
         bad = (y.double() - ref).abs() > rtol * scale + rtol * ref.abs()
-        assert not bool(bad.any()), f"{K}x{N} g{gs} M={M} act={act} {zm} {dtype}: {int(bad.sum())}/{bad.numel()} outputs out of tolerance, first {torch.nonzero(bad)[0].tolist()}"
+        assert not bool(bad.any()), f"int{bits} {K}x{N} g{gs} M={M} act={act} {zm} {dtype}: {int(bad.sum())}/{bad.numel()} outputs out of tolerance, first {torch.nonzero(bad)[0].tolist()}"
         hot = torch.zeros(M, K, dtype=dtype, device=DEV)
         rows = torch.arange(M, device=DEV)
         hot[rows, (rows * 37 + 5) % K] = 1.0                   # one-hot rows through every tile, piece and K part

@@ -16,6 +16,8 @@ ap.add_argument("--dtype", default="f16")
 ap.add_argument("--act", default="0,1")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--layers", type=int, default=6)
+ap.add_argument("--bits", type=int, default=4)
+ap.add_argument("--gs", type=int, default=128)
 ap.add_argument("--dv", default="0", help="lab: DMA placement variants of the stream-K kernel to time (tuning.reserved[0])")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -38,7 +40,7 @@ del warm, xw
 for shp in a.shapes.split(","):
     K, N = map(int, shp.split("x"))
     for act in map(int, a.act.split(",")):
-        ls = [make_layer(K, N, dev, dtype=dt, seed=i, act_order=bool(act)) for i in range(a.layers)]
+        ls = [make_layer(K, N, dev, bits=a.bits, gs=a.gs, dtype=dt, seed=i, act_order=bool(act)) for i in range(a.layers)]
         for M in map(int, a.ms.split(",")):
             x = (torch.rand(M, K, device=dev) - 0.5).to(dt)
             best = {}
@@ -51,7 +53,7 @@ for shp in a.shapes.split(","):
                     best[name] = min(best.get(name, 1e9), s)
             d = _lib.describe_plan(ls[0]._layer, M)
             w = best.pop("without")
-            print(f"{K}x{N} M={M:5d} {a.dtype} act={act} default={d.get('kernel'):9s} | without [{names['without']:9s}] {w * 1e6:8.1f} us {2 * M * K * N / w / 1e12:6.0f} TF | " +
+            print(f"int{a.bits} g{a.gs} {K}x{N} M={M:5d} {a.dtype} act={act} default={d.get('kernel'):9s} | without [{names['without']:9s}] {w * 1e6:8.1f} us {2 * M * K * N / w / 1e12:6.0f} TF | " +
                   " | ".join(f"{k} {s * 1e6:8.1f} us {2 * M * K * N / s / 1e12:6.0f} TF {w / s:5.2f}x" for k, s in best.items()), flush=True)
             del x
         del ls
