@@ -39,9 +39,9 @@ __global__ void __launch_bounds__(256, 1) gemm_wide_sk_kernel(WskParams p) {
 int wide_sk_group_mode(int group_size) { return group_size % 128 == 0 ? 0 : (group_size % 64 == 0 ? 1 : (group_size == 32 ? 2 : -1)); }
 
 bool wide_sk_ok(const gptq_layer_t& L, int M) {
-    if ((L.bits != 4 && L.bits != 3) || (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16)) return false;
+    if ((L.bits != 4 && L.bits != 3 && L.bits != 8) || (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16)) return false;
     if (L.qweight_tiled == nullptr || L.tiled_cols != GPTQ_STRIP_COLS) return false;
-    if (L.bits != 4 && L.qconst_tiled == nullptr) return false;                                      // 3 bits reads the copy's constant records
+    if (L.bits != 4 && L.qconst_tiled == nullptr) return false;                                      // 3 / 8 bits read the copy's constant records
     if (L.K % 256 || wide_sk_group_mode(L.group_size) < 0 || L.N % 32 || L.epilogue != GPTQ_EPI_NONE) return false;      // two K parts of whole 128-deep chunks
     return M >= 128;
 }
@@ -53,7 +53,7 @@ bool wide_sk_ok(const gptq_layer_t& L, int M) {
 // caller (plan_gemm) asks that first.
 bool wide_sk_pays(const gptq_layer_t& L, int M) {
     if (!wide_sk_ok(L, M)) return false;
-    // 3 bits and 32-wide groups have no other 64-deep kernel (the row kernel runs them in BK = 32 steps): 1.13 - 1.92x from 512 rows on every shape
+    // 3 / 8 bits and 32-wide groups have no other 64-deep kernel (the row kernel runs them in BK = 32 steps): 1.13 - 1.92x (8 bits: 1.02 - 1.50x) from 512 rows on every shape
     // (profiles/r05_wide_sk_b38_ab.log: int3 g32 M = 2048: 109 -> 64, 257 -> 188, 276 -> 163 us; int4 g32: 92 -> 63, 211 -> 189, 229 -> 164 us)
     if (L.bits != 4 || wide_sk_group_mode(L.group_size) == 2) return M >= 512;
     return M >= 768 || (M >= 512 && (size_t)L.K * L.N >= ((size_t)32 << 20));
@@ -103,7 +103,7 @@ hipError_t launch_gemm_wide_sk(const gptq_layer_t& L, const void* x, void* out, 
     p.qweight = L.qweight_tiled; p.qconst = L.qconst_tiled; p.qzeros = L.qzeros; p.scales = L.scales; p.bias = L.bias; p.x = x; p.out = out;
     p.M = M; p.K = L.K; p.N = L.N; p.zero_mode = L.zero_mode;
     p.nbm = g.nbm; p.nbn = g.nbn; p.upt = g.upt; p.units_total = g.units_total; p.lg_nwg = g.lg_nwg;
-    p.chunks = L.K / 128;
+    p.chunks = L.bits == 8 ? L.K / 64 : L.K / 128;          // the decode copy's chunks: 4 k-slots of 32 (8 bits: 16) values
     p.groups = (L.K + L.group_size - 1) / L.group_size;
     const unsigned long long kpg = (unsigned long long)(L.group_size >= 64 ? L.group_size / 64 : 1);
     p.kpg_inv = ((1ull << 32) + kpg - 1) / kpg;

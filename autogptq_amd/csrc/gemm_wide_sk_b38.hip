@@ -1,4 +1,4 @@
-// gemm_wide_sk_b38.hip -- the stream-K prefill kernel (gemm_wide_sk.hip) on the 3-bit decode copy and on 32-wide groups: BASELINE config 5's prefill rows,
+// gemm_wide_sk_b38.hip -- the stream-K prefill kernel (gemm_wide_sk.hip) on the 3-bit and 8-bit decode copies and on 32-wide groups: BASELINE config 5's prefill rows,
 // which ran on the 128 x 256 BK = 32 row kernel (gemm.hip) at 0.31 - 0.33 of the dense bf16 peak where the 4-bit g128 layer reaches 0.42.  Same schedule, same
 // x path, same exchange; the weights come from the copy's 3-word lanes (utils.hip: prepack_decode_weights_kernel<3>) and the constants from its records
 // (qconst_tiled: the zero-point as used, so no wrap mask in the loop).  Reference behaviour: qlinear_cuda_old.py:203-262 dequantises every width to fp16 and
@@ -30,6 +30,9 @@ static hipError_t grant_all() {
     if (e == hipSuccess) e = grant_one<T, 3, 0>();
     if (e == hipSuccess) e = grant_one<T, 3, 1>();
     if (e == hipSuccess) e = grant_one<T, 3, 2>();
+    if (e == hipSuccess) e = grant_one<T, 8, 0>();
+    if (e == hipSuccess) e = grant_one<T, 8, 1>();
+    if (e == hipSuccess) e = grant_one<T, 8, 2>();
     return e;
 }
 hipError_t init_gemm_wide_skb_device() {
@@ -45,7 +48,11 @@ static void launch_one(dim3 grid, dim3 block, hipStream_t st, const wide::WskPar
 template <typename T>
 static void launch_t(int bits, int gm, dim3 grid, dim3 block, hipStream_t st, const wide::WskParams& p) {
     if (bits == 4) launch_one<T, 4, 2>(grid, block, st, p);
-    else if (gm == 0) launch_one<T, 3, 0>(grid, block, st, p);
+    else if (bits == 8) {
+        if (gm == 0) launch_one<T, 8, 0>(grid, block, st, p);
+        else if (gm == 1) launch_one<T, 8, 1>(grid, block, st, p);
+        else launch_one<T, 8, 2>(grid, block, st, p);
+    } else if (gm == 0) launch_one<T, 3, 0>(grid, block, st, p);
     else if (gm == 1) launch_one<T, 3, 1>(grid, block, st, p);
     else launch_one<T, 3, 2>(grid, block, st, p);
 }

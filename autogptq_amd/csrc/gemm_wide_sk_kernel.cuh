@@ -43,13 +43,20 @@ template <int BITS> struct WRaw { u32x4 w[4]; };
 template <> struct WRaw<3> { u32x3 w[4]; };
 template <typename T, int BITS> struct DeqOf { typedef Deq4<T> type; };
 template <typename T> struct DeqOf<T, 3> { typedef Deq3<T> type; };
+template <typename T> struct DeqOf<T, 8> { typedef Deq8<T> type; };
+// 8 bits: a step's weights are 8 words per column -- twice the registers of the 4-bit form, which the kernel does not have (all 256 accumulator registers
+// and ~250 of the 256 others are live).  Three 4-word sets rotate instead of two 8-word buffers: a step reads LO (MFMA steps 0, 1) and HI (2, 3); the next
+// step's LO words are loaded into the FREE set under MFMA group 0 and its HI words into LO under group 1, when LO's last words have been dequantised.
+// Then (lo, hi, fr) <- (fr, lo, hi).
+struct Use8 { WRaw<8>& lo; WRaw<8>& hi; WRaw<8>& fr; };
 
 template <typename T, int BITS, int GM>
 __device__ __forceinline__ void wsk_body(const WskParams& p) {
     constexpr int KS = 4, MT = 4, NT = 4, STRIDE = 128;
     constexpr bool G128 = GM == 0, G32 = GM == 2;
-    constexpr unsigned CHUNK_BYTES = BITS == 3 ? 768u : 1024u;          // one (strip, 128-deep chunk) of the decode copy
-    constexpr unsigned REC = 48u;                                       // one (strip, group) constant record
+    constexpr unsigned CHUNK_BYTES = BITS == 3 ? 768u : 1024u;          // one (strip, 128-deep chunk) of the decode copy; 8 bits: 64-deep chunks
+    constexpr unsigned REC = BITS == 8 ? 64u : 48u;                     // one (strip, group) constant record
+    using CR = std::conditional_t<BITS == 8, CRaw8, CRaw>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,24 +120,30 @@ __device__ __forceinline__ void wsk_body(const WskParams& p) {
             else b.w[col] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, b_lane_off + col * 16u, so, 0);
         }
     };
-    auto load_c = [&](int kt, CRaw& c) {
+    auto load_b8 = [&](int kt, WRaw<8>& b, unsigned hi) {      // 8 bits: k-slots 2 half + hi of chunk kt (16 k each): words 4 hi .. 4 hi + 3 of the lane's eight
+#pragma unroll
+        for (int col = 0; col < NT; ++col) b.w[col] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_q, b_lane_off + hi * 256u + col * 16u, (unsigned)kt * 1024u, 0);
+    };
+    auto load_c = [&](int kt, CR& c) {
         // 32-wide groups: the lane's group is 2 kt + half, and half is part of s_lane_off / z_lane_off
         const int g = G32 ? 2 * kt : (int)(((unsigned long long)(unsigned)kt * p.kpg_inv) >> 32);
         c.s = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_s, s_lane_off, (unsigned)g * srow_bytes, 0));
-        c.z = __builtin_amdgcn_raw_buffer_load_b32(rsrc_z, z_lane_off, (unsigned)g * zrow_step, 0);
+        if constexpr (BITS == 8) c.z = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_z, z_lane_off, (unsigned)g * zrow_step, 0));
+        else c.z = __builtin_amdgcn_raw_buffer_load_b32(rsrc_z, z_lane_off, (unsigned)g * zrow_step, 0);
     };
-    auto setup_dq = [&](typename DeqOf<T, BITS>::type& d, const CRaw& c) {
+    auto setup_dq = [&](typename DeqOf<T, BITS>::type& d, const CR& c) {
         if constexpr (BITS == 4) d.setup(c, zsh, zmask);
         else d.setup(c);
     };
-    auto frag_of = [&](const typename DeqOf<T, BITS>::type& d, const WRaw<BITS>& b, int nt, int ks) -> u32x4 {
+    auto frag_of = [&](const typename DeqOf<T, BITS>::type& d, const auto& b, int nt, int ks) -> u32x4 {
         if constexpr (BITS == 4) return d.frag(b.w[nt][ks], nt);
-        else return d.frag(b.w[nt], ks, nt);
+        else if constexpr (BITS == 3) return d.frag(b.w[nt], ks, nt);
+        else return ks < 2 ? d.frag(b.lo.w[nt][2 * ks], b.lo.w[nt][2 * ks + 1], nt) : d.frag(b.hi.w[nt][2 * ks - 4], b.hi.w[nt][2 * ks - 3], nt);
     };
 
     f32x16 acc[MT][NT];
-    WRaw<BITS> b0, b1;
-    CRaw c0, c1;
+    WRaw<BITS> b0, b1, b2;                                    // (b2: 8 bits only)
+    CR c0, c1;
     typename DeqOf<T, BITS>::type dq_cur;
     u32x4 bq_first[NT];
 
@@ -145,7 +158,7 @@ __device__ __forceinline__ void wsk_body(const WskParams& p) {
     };
     // One 64-deep K-step of this wave's K part (gemm_wide.hip's pipeline: the next step's constants and first B fragments under the last MFMA group, its
     // weight / constant loads inside group 0, its x DMAs inside groups 1 and 2).
-    auto step = [&](int kt, auto bufc, const WRaw<BITS>& b_use, WRaw<BITS>& b_fill, CRaw& c_fill) {
+    auto step = [&](int kt, auto bufc, const auto& b_use, auto& b_fill, CR& c_fill) {      // 8 bits: b_use = b_fill = the Use8 of the step
         constexpr int BUF = decltype(bufc)::value;
         constexpr bool NEWG = !(G128 && BUF == 0);             // does step kt + 1 open a new group?  (G128: only behind the odd step of a body)
         const int ktn = min(kt + 1, kt_last);                  // the segment's last step re-loads itself (no branch in the pipeline)
@@ -153,6 +166,8 @@ __device__ __forceinline__ void wsk_body(const WskParams& p) {
 #pragma unroll
         for (int ks = 1; ks < KS; ++ks) {
             if constexpr (BITS == 3) asm volatile("" ::"v"(b_use.w[ks][0]), "v"(b_use.w[ks][1]), "v"(b_use.w[ks][2]));
+            else if constexpr (BITS == 8) asm volatile("" ::"v"(b_use.lo.w[ks][0]), "v"(b_use.lo.w[ks][1]), "v"(b_use.lo.w[ks][2]), "v"(b_use.lo.w[ks][3]),
+                                                       "v"(b_use.hi.w[ks][0]), "v"(b_use.hi.w[ks][1]), "v"(b_use.hi.w[ks][2]), "v"(b_use.hi.w[ks][3]));
             else asm volatile("" ::"v"(b_use.w[ks][0]), "v"(b_use.w[ks][1]), "v"(b_use.w[ks][2]), "v"(b_use.w[ks][3]));
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -175,14 +190,21 @@ __device__ __forceinline__ void wsk_body(const WskParams& p) {
                 if constexpr (NEWG) setup_dq(dq_nx, c_fill);
                 else dq_nx = dq_cur;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bq_first[nt] = frag_of(dq_nx, b_fill, nt, 0);
+                for (int nt = 0; nt < NT; ++nt) {
+                    if constexpr (BITS == 8) bq_first[nt] = dq_nx.frag(b_fill.fr.w[nt][0], b_fill.fr.w[nt][1], nt);
+                    else bq_first[nt] = frag_of(dq_nx, b_fill, nt, 0);
+                }
             }
             if (ks == 0) {                                     // next step's weights + constants: under MFMA group 0
-                load_b(ktn, b_fill);
+                if constexpr (BITS == 8) load_b8(ktn, b_fill.fr, 0u);
+                else load_b(ktn, b_fill);
                 if constexpr (NEWG) load_c(ktn, c_fill);
                 dma_a4(ktn, BUF ^ 1, 0);                       // the next step's x tile: behind the weight loads and inside group 1 (in groups 1 and 2 the
             }                                                  // second half lands too late: the compiler's wait for the weights, in front of group 3's
-            if (ks == 1) dma_a4(ktn, BUF ^ 1, 1);              // VALU work, is a vmcnt(0) that covers the DMAs as well: +5 % measured)
+            if (ks == 1) {                                     // VALU work, is a vmcnt(0) that covers the DMAs as well: +5 % measured)
+                dma_a4(ktn, BUF ^ 1, 1);
+                if constexpr (BITS == 8) load_b8(ktn, b_fill.lo, 1u);      // LO's words 2, 3 went into bq[1] under group 0
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -194,6 +216,14 @@ __device__ __forceinline__ void wsk_body(const WskParams& p) {
                     __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                     if ((i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);
                     if ((i & 1) == 1 && i < 12) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 6 VMEM reads: the 4 weight + 2 constant loads
+                }
+            } else if (BITS == 8 && ks == 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    if ((i & 3) == 0) __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);
+                    if ((i & 1) == 1 && i < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // the 4 HI loads
                 }
             } else if (ks + 1 < KS) interleave(std::integral_constant<int, 4>{});
             else interleave(std::integral_constant<int, 6>{});
@@ -317,6 +347,7 @@ __device__ __forceinline__ void wsk_body(const WskParams& p) {
         const int nl = n < p.N ? n : 0;                        // N % 32 == 0: a lane's 4 columns are in or out together
         a_tile = (const char*)p.x + (size_t)m0 * p.K * 2;
         if constexpr (BITS == 3) b_lane_off = ((unsigned)nl >> 4) * (unsigned)p.chunks * 768u + (unsigned)half * 192u + ((unsigned)nl & 15u) * 12u;
+        else if constexpr (BITS == 8) b_lane_off = ((unsigned)nl >> 4) * (unsigned)p.chunks * 1024u + (unsigned)half * 512u + ((unsigned)nl & 15u) * 16u;
         else b_lane_off = ((unsigned)nl >> 4) * (unsigned)p.chunks * 1024u + (unsigned)half * 256u + ((unsigned)nl & 15u) * 16u;    // strip, k-slot, column
         if constexpr (BITS == 4) {
             s_lane_off = (unsigned)nl * 2u;
@@ -324,7 +355,7 @@ __device__ __forceinline__ void wsk_body(const WskParams& p) {
             zsh = ((unsigned)nl & 7u) * 4u;
         } else {                                               // the strip's records; 16 scales, then 16 zero-point bytes
             s_lane_off = ((unsigned)nl >> 4) * (unsigned)p.groups * REC + ((unsigned)nl & 15u) * 2u;
-            z_lane_off = ((unsigned)nl >> 4) * (unsigned)p.groups * REC + 32u + ((unsigned)nl & 15u);
+            z_lane_off = ((unsigned)nl >> 4) * (unsigned)p.groups * REC + 32u + ((unsigned)nl & 15u) * (BITS == 8 ? 2u : 1u);
         }
         if constexpr (G32) { s_lane_off += (unsigned)half * srow_bytes; z_lane_off += (unsigned)half * zrow_step; }
         kt0 = 2 * (kp * p.upt + j0);
@@ -332,7 +363,8 @@ __device__ __forceinline__ void wsk_body(const WskParams& p) {
         kt_last = kt1 - 1;
         dma_a4(kt0, 0, 0);
         dma_a4(kt0, 0, 1);
-        load_b(kt0, b0);
+        if constexpr (BITS == 8) { load_b8(kt0, b0, 0u); load_b8(kt0, b1, 1u); }
+        else load_b(kt0, b0);
         load_c(kt0, c0);
     };
     open_segment();
@@ -347,11 +379,22 @@ __device__ __forceinline__ void wsk_body(const WskParams& p) {
         __syncthreads();
         setup_dq(dq_cur, c0);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bq_first[nt] = frag_of(dq_cur, b0, nt, 0);
+        for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (BITS == 8) bq_first[nt] = dq_cur.frag(b0.w[nt][0], b0.w[nt][1], nt);
+            else bq_first[nt] = frag_of(dq_cur, b0, nt, 0);
+        }
 
         for (int kt = kt0; kt < kt1; kt += 2) {                 // a unit is a whole 128-deep chunk: no conditional second step
-            step(kt, std::integral_constant<int, 0>{}, b0, b1, c1);
-            step(kt + 1, std::integral_constant<int, 1>{}, b1, b0, c0);
+            if constexpr (BITS == 8) {
+                Use8 ua{b0, b1, b2}, ub{b2, b0, b1};
+                step(kt, std::integral_constant<int, 0>{}, ua, ua, c1);          // -> lo = b2, hi = b0 (b1 free)
+                step(kt + 1, std::integral_constant<int, 1>{}, ub, ub, c0);      // -> lo = b1, hi = b2 (b0 free)
+                const WRaw<8> t = b0;
+                b0 = b1; b1 = b2; b2 = t;
+            } else {
+                step(kt, std::integral_constant<int, 0>{}, b0, b1, c1);
+                step(kt + 1, std::integral_constant<int, 1>{}, b1, b0, c0);
+            }
         }
 
         // the finished piece, then the next segment's first loads, then the piece's epilogue

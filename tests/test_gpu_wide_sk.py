@@ -41,6 +41,10 @@ CASES_B38 = [
     (3, 512, 1056, 32, 128 * 86 - 77, True, "3 bits, 32-wide groups (each half of the wave on its own group), act-order, shifted last row tile, partial last column tile"),
     (3, 768, 544, 64, 333, False, "3 bits, groups of 64, three units per tile, ragged M and N"),
     (3, 4096, 512, 32, 640, False, "3 bits g32, deep K"),
+    (8, 1024, 512, 128, 256, False, "8 bits (three rotating 4-word register sets), groups of 128: every tile cut in 4"),
+    (8, 512, 1056, 32, 128 * 86 - 77, True, "8 bits, 32-wide groups, act-order, shifted last row tile, partial last column tile"),
+    (8, 768, 544, 64, 333, False, "8 bits, groups of 64, three units per tile (an odd number of two-step bodies between rotations), ragged M and N"),
+    (8, 4096, 512, 32, 640, False, "8 bits g32, deep K"),
     (4, 1024, 544, 32, 333, False, "4 bits on 32-wide groups: constants from the checkpoint rows, one group per half"),
     (4, 2048, 256, 32, 128, True, "4 bits g32 act-order: one tile, one finisher adds 7 published pieces"),
 ]
