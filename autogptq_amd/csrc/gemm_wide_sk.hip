@@ -55,7 +55,9 @@ bool wide_sk_pays(const gptq_layer_t& L, int M) {
     if (!wide_sk_ok(L, M)) return false;
     // 3 / 8 bits and 32-wide groups have no other 64-deep kernel (the row kernel runs them in BK = 32 steps): 1.13 - 1.92x (8 bits: 1.02 - 1.50x) from 512 rows on every shape
     // (profiles/r05_wide_sk_b38_ab.log: int3 g32 M = 2048: 109 -> 64, 257 -> 188, 276 -> 163 us; int4 g32: 92 -> 63, 211 -> 189, 229 -> 164 us)
-    if (L.bits != 4 || wide_sk_group_mode(L.group_size) == 2) return M >= 512;
+    // below: 384 rows 1.18 - 2.09x on the two large shapes (0.97 - 1.05x on 4096^2), 256 rows 1.24 - 1.51x on 4096 -> 11008 only (0.71 - 0.94x elsewhere)
+    if (L.bits != 4 || wide_sk_group_mode(L.group_size) == 2)
+        return M >= 512 || (M >= 384 && (size_t)L.K * L.N >= ((size_t)32 << 20)) || (M >= 256 && L.N >= 2 * L.K && (size_t)L.K * L.N >= ((size_t)32 << 20));
     return M >= 768 || (M >= 512 && (size_t)L.K * L.N >= ((size_t)32 << 20));
 }
 

@@ -292,12 +292,14 @@ def pmc_traffic(kernel, K, N, M, exact=False):
     return None
 
 
-def rocprof_gemm_kernel(plan, dtype="f16", group_size=128):
+def rocprof_gemm_kernel(plan, dtype="f16", group_size=128, bits=4):
     """The name rocprofv3 reports (tools/rocprof_summary.py: demangled, without the argument list) for the prefill kernel of a plan dict
     (gptq_describe_plan): what profiles/r05_kernel_stats.txt and profiles/pmc_traffic.json key their rows by."""
     k = plan.get("kernel")
     g128 = "true" if group_size % 128 == 0 else "false"
     if k == "wide_sk":
+        if bits != 4 or group_size == 32:          # csrc/gemm_wide_sk_b38.hip: <T, BITS, group mode 0 / 1 / 2 = groups of 128 / 64 multiples / 32>
+            return f"gptq::wide::gemm_wide_skb_kernel<{dtype}, {bits}, {0 if group_size % 128 == 0 else (1 if group_size % 64 == 0 else 2)}>"
         return f"gptq::wide::gemm_wide_sk_kernel<{dtype}, {g128}>"
     if k == "wide_copy":
         return f"gptq::wide::gemm_wide_kernel<{dtype}, true, true, {g128}>"

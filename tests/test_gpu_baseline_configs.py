@@ -109,8 +109,12 @@ def _check(bits, gs, K, N, M, act, dtype):
 @pytest.mark.parametrize("bits", [3, 8])
 def test_config5_int3_int8_g32_llama7b_shapes(bits, K, N, dtype, act):
     """BASELINE config 5: int3 / int8, group_size 32, on the Llama-7B layer shapes -- GEMV-generic plans at full
-    K (16 waves, U = 4 for int8, masked tail rows), strips / skinny at M = 16 / 64, tiled BK = 32 GEMM with two-word
-    B fragments at M = 2048."""
+    K (16 waves, U = 4 for int8, masked tail rows), strips / skinny at M = 16 / 64, and at M = 2048 the stream-K prefill kernel on the 3- / 8-bit decode
+    copy (csrc/gemm_wide_sk_b38.hip: each half of the wave on its own 32-wide group; act-order: x permuted in natural order by the pre-pass)."""
+    from autogptq_amd import _lib
+    _, q, _, _ = _layer(bits, 32, K, N, act, dtype)
+    plan = _lib.describe_plan(q._layer, 2048)
+    assert plan["kernel"] == "wide_sk" and plan["perm"] == int(act) and plan["tiles"] == f"16x{N // 256}", plan
     for M in (1, 4, 8, 16, 64, 2048):
         _check(bits, 32, K, N, M, act, dtype)
 
