@@ -95,6 +95,9 @@ __device__ __forceinline__ void wsk_body(const WskParams& p) {
     int kt_last = 0;
 
     auto dma_a4 = [&](int kt, int buf, int q) {                // DMAs 4 q .. 4 q + 3 of the wave's eight
+#if defined(GPTQ_WSK_ABL) && (GPTQ_WSK_ABL & 4)
+        if (kt != 0x7fffffff) return;                          // lab: no x DMAs (the tiles keep whatever the LDS held)
+#endif
         // LDS rows 8 j .. 8 j + 7 (j = 8 cw + 4 q + i) take the rows of 32-row block j / 4 -- of block 3 - j / 4 for K part 1 (finish() relies on it)
         const int j0 = cw * 8 + q * 4;
         const char* sb = a_tile + (size_t)kt * 128 + (size_t)((kp ? 3 - (j0 >> 2) : (j0 >> 2)) * 4) * a_grp_bytes;
@@ -136,6 +139,9 @@ __device__ __forceinline__ void wsk_body(const WskParams& p) {
         else d.setup(c);
     };
     auto frag_of = [&](const typename DeqOf<T, BITS>::type& d, const auto& b, int nt, int ks) -> u32x4 {
+#if defined(GPTQ_WSK_ABL) && (GPTQ_WSK_ABL & 8)
+        if constexpr (BITS == 4) { const unsigned q = b.w[nt][ks]; return u32x4{q, q ^ 0x11111111u, q ^ 0x22222222u, q ^ f16x2_bits(d.c1[nt])}; }      // lab: no dequant math
+#endif
         if constexpr (BITS == 4) return d.frag(b.w[nt][ks], nt);
         else if constexpr (BITS == 3) return d.frag(b.w[nt], ks, nt);
         else return ks < 2 ? d.frag(b.lo.w[nt][2 * ks], b.lo.w[nt][2 * ks + 1], nt) : d.frag(b.hi.w[nt][2 * ks - 4], b.hi.w[nt][2 * ks - 3], nt);
@@ -230,8 +236,16 @@ __device__ __forceinline__ void wsk_body(const WskParams& p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         dq_cur = dq_nx;
+#if defined(GPTQ_WSK_ABL) && (GPTQ_WSK_ABL & 1)
+        // lab (tools/lab/wsk_ablate.sh; wrong results by construction): nobody waits for the step's loads
+#else
         wait_vmcnt<0>();                                       // the next tile must have landed before anybody passes the barrier (the DMAs are the step's newest VMEM operations)
+#endif
+#if defined(GPTQ_WSK_ABL) && (GPTQ_WSK_ABL & 2)
+        // lab: no barrier between the steps
+#else
         __syncthreads();
+#endif
     };
 
     // End of a segment.  K part 1 keeps its x tile with the four 32-row blocks in REVERSED order (dma_a4), so its accumulators acc[mt] belong to row block
