@@ -769,6 +769,49 @@ def test_planner_fuzz_layers_with_a_decode_copy():
     assert {"strips", "wide_copy"} <= seen, seen
 
 
+def test_stream_k_prefill_rules_for_every_packing():
+    """Round 5, host only: where the planner sends prefill rows of layers that carry a decode copy to the stream-K kernel (csrc/gemm_wide_sk.hip: wide_sk_ok /
+    wide_sk_pays) -- 4-bit groups of 64 / 128 multiples from 768 rows (512 on large layers) unless whole rounds of 128 x 512 tiles fill the chip, and the 3-bit,
+    8-bit and 32-wide-group forms (gemm_wide_sk_b38.hip) from 512 rows (384 / 256 on large layers: profiles/r05_wide_sk_b38_ab.log) -- and that the workspace
+    query covers the published pieces (128 KiB per workgroup when any range boundary falls inside a tile) behind the permuted x of act-order layers."""
+    lib = _lib.load()
+
+    def plan(bits, gs, K, N, M, act=False, copy=True, dtype=0):
+        L = _layer(K=K, N=N, bits=bits, group_size=gs, dtype=dtype)
+        if act:
+            L.g_idx = L.qweight_seq = L.perm = 0x1000
+        if copy:
+            L.qweight_tiled = L.qconst_tiled = 0x2000
+            L.tiled_cols = 16
+        buf = ctypes.create_string_buffer(512)
+        assert lib.gptq_describe_plan(ctypes.byref(L), M, None, buf, len(buf)) == 0, lib.gptq_last_error()
+        d = dict(kv.split("=", 1) for kv in buf.value.decode().split())
+        return d, lib.gptq_workspace_bytes(ctypes.byref(L), M)
+
+    for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
+        for act in (False, True):
+            d, need = plan(4, 128, K, N, 2048, act)                                   # BASELINE config 3
+            assert d["kernel"] == "wide_sk" and d["perm"] == str(int(act)) and d["tiles"] == f"16x{-(-N // 256)}", d
+            cut = N == 11008                                                            # 688 tiles on 256 workgroups; 256 tiles = one each, nothing published
+            xperm = 2048 * K * 2 if act else 0
+            assert need == (65536 if (cut or act) else 0) + xperm + (256 * 131072 if cut else 0), (d, need)      # header + permuted x + 128 KiB per workgroup
+        assert plan(4, 128, K, N, 4096)[0]["kernel"] == "wide_copy"                    # whole rounds of 128 x 512 tiles stay whole tiles
+        assert plan(4, 128, K, N, 2048, copy=False)[0]["kernel"] != "wide_sk"          # no copy, no stream-K
+        for bits in (3, 8):                                                            # BASELINE config 5
+            for dtype in (0, 1):
+                assert plan(bits, 32, K, N, 2048, dtype=dtype)[0]["kernel"] == "wide_sk"
+            assert plan(bits, 32, K, N, 2048, act=True)[0]["kernel"] == "wide_sk"
+            assert plan(bits, 128, K, N, 4096)[0]["kernel"] == "wide_sk"               # no 128 x 512 form for these widths
+            assert plan(bits, 32, K, N, 512)[0]["kernel"] == "wide_sk"
+            assert plan(bits, 32, K, N, 384)[0]["kernel"] == ("wide_sk" if K * N >= 32 << 20 else "tiled")
+            assert plan(bits, 32, K, N, 256)[0]["kernel"] == ("wide_sk" if (K, N) == (4096, 11008) else "tiled")
+            assert plan(bits, 32, K, N, 128)[0]["kernel"] != "wide_sk"
+        assert plan(4, 32, K, N, 2048)[0]["kernel"] == "wide_sk"                       # 4 bits on 32-wide groups: each half of the wave on its own group
+    assert plan(4, 96, 4032, 4096, 2048)[0]["kernel"] != "wide_sk"                     # groups of 96: not a group mode of the kernel
+    assert plan(3, 32, 4096 + 128, 4096, 2048)[0]["kernel"] != "wide_sk"               # K % 256 != 0: the two K parts need whole 128-deep chunks
+    assert plan(2, 32, 4096, 4096, 2048, copy=False)[0]["kernel"] != "wide_sk"         # 2 bits have no decode copy
+
+
 def test_decode_copy_restatement_matches_the_header_definition():
     """oracle.decode_copy_weights / decode_copy_consts restate gptq_prepack_decode (include/gptq_mi355x.h, gptq_layer_t.qweight_tiled / qconst_tiled): checked
     entry by entry against the header's formula on a small layer (ragged last chunk: K = 160), that the magic-number extraction order of a stored word is
