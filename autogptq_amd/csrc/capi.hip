@@ -76,6 +76,7 @@ bool want_gemm(const gptq_layer_t* L, int M, const gptq_tuning_t* t) {
         const GemmPlan gf = plan_gemm(*L, M, t);
         return gf.supported && (long)gf.nbm * gf.nbn >= 64;      // fewer tiles than a quarter of the chip: the GEMV still wins (4096x4096 M = 128: ~170 us against 455)
     }
+    if (!t && L->epilogue == GPTQ_EPI_NONE && rows_pays(*L, M)) return true;      // 5 .. 128 rows from the decode copy (gemm_rows.hip; plan_gemm picks it)
     if (L->bits != 4) {
         // 2/3/8-bit: the matrix-core GEMV handles 4 rows of x per pass over the weights and the generic (act-order) kernel fewer, so the
         // weight-streaming GEMMs take over early (tools/cliff_scan.py --slice C, 4096x11008, us: int8 M = 8: 47.6 GEMV, 25.6 tiled at
@@ -151,6 +152,7 @@ bool want_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t
     if (M > TILED_ROWS_MAX || n < 1 || n > 4) return false;
     if (Ls[0]->qweight_tiled == nullptr) return false;
     if (Ls[0]->epilogue != GPTQ_EPI_NONE && (n != 1 || M > 4)) return false;     // a [gate | up] layer: the pair form of the kernel (gemv_tiled_pair.hip)
+    if (M > 4 && !(t && t->path == 8) && n == 1 && rows_pays(*Ls[0], M)) return false;      // 5+ rows of one layer: the exchange-free batched-decode kernel (gemm_rows.hip: 4096^2 M = 5 / 8 7.1 / 7.3 -> 5.5 / 5.6 us)
     if (M > 4 && !(t && t->path == 8) && !tiled_rows8_pays(Ls, n)) return false;
     if (t && t->path != 0 && t->path != 8) return false;
     const TiledPlan tp = plan_tiled(Ls, n, M, t);                  // act-order layers: the copy holds the re-sequenced rows, the kernel gathers x through perm
@@ -285,6 +287,7 @@ int gptq_init(void) {
     if (e == hipSuccess) e = init_gemm_mid_device();
     if (e == hipSuccess) e = init_gemv_tiled_device();
     if (e == hipSuccess) e = init_gemm_wide_sk_device();
+    if (e == hipSuccess) e = init_gemm_rows_device();
     if (e != hipSuccess) return hip_fail(e, "gptq_init (hipFuncSetAttribute)");
     return GPTQ_OK;
 }
@@ -846,7 +849,7 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
                  sp.u, sp.ksplit, sp.mt, sp.strips_total);
     } else if (want_gemm(&Lc, M, tune)) {
         const GemmPlan g = plan_gemm(Lc, M, tune);
-        const char* kern = g.f32 ? "f32_mfma" : g.wsk ? "wide_sk" : g.wide ? (g.wide_tiled ? "wide_copy" : "wide") : g.mid ? "mid" : (g.stream64 ? "stream64" : (g.strip16 ? "strip16" : (g.skinny ? "skinny64" : "tiled")));
+        const char* kern = g.f32 ? "f32_mfma" : g.rows ? "rows" : g.wsk ? "wide_sk" : g.wide ? (g.wide_tiled ? "wide_copy" : "wide") : g.mid ? "mid" : (g.stream64 ? "stream64" : (g.strip16 ? "strip16" : (g.skinny ? "skinny64" : "tiled")));
         snprintf(out, out_bytes, "path=gemm kernel=%s mt=%d bk=%d kg=%d ksplit=%d tiles=%dx%d tail=%d tail_slices=%d perm=%d dma=%d waves=%d u=%d epilogue=%s", kern, g.mt, g.bk,
                  g.kg == 2 ? 2 : 1, g.ksplit, g.nbm, g.nbn, g.tail, g.tail ? (1 << g.tail_lg) : 1, g.use_seq ? 1 : 0, (g.glds || g.stream64 || g.mid) ? 1 : 0, g.waves, g.u,
                  unfused_epilogue ? "separate" : "none");

@@ -1921,6 +1921,23 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.use_seq = (L.g_idx != nullptr);
     pl.xperm_bytes = pl.use_seq ? align_up((size_t)M * L.K * 2, 256) : 0;
     const int force_skinny = tune ? tune->reserved[2] : 0;      // experiment knob: 1 = skinny, 2 = tiled
+    // 5 .. ~256 rows of a layer that carries its decode copy: whole-K workgroups, no exchange (gemm_rows.hip); lab knobs 50 / 51 force it on / off
+    {
+        const int knob = tune ? tune->reserved[3] : 0;
+        if (knob == GPTQ_LAB_VARIANT_ROWS_ON || (knob != GPTQ_LAB_VARIANT_ROWS_OFF && (!tune || tune->path != 3 || knob == 0) && force_skinny == 0 && rows_pays(L, M))) {
+            const RowsPlan rp = plan_rows(L, M, knob == GPTQ_LAB_VARIANT_ROWS_ON ? tune : nullptr);
+            if (rp.ok) {
+                pl.rows = true;
+                pl.rowsp = rp;
+                pl.xnat = pl.use_seq;
+                pl.mt = rp.rb; pl.bk = 128; pl.bm = 16 * rp.rb; pl.bn = 16 * rp.s; pl.nbm = rp.npm; pl.nbn = rp.nsg;
+                pl.waves = rp.waves; pl.u = 2; pl.kg = 1;
+                pl.ksplit = 1; pl.ksteps_total = pl.ksteps_per_split = L.K / 128;
+                pl.workspace_bytes = pl.xperm_bytes;
+                return pl;
+            }
+        }
+    }
     // Measured crossovers (tools/midm_bench.py, us per launch at M = 9/16/32/64):
     //   4096x4096   strips16  8.0/ 9.1/12.3/19.6   skinny64 12.1/12.3/12.7/15.5   tiled 15.5/15.7/17.1/22.6
     //   11008x4096  strips16 17.9/20.1/27.9/47.9   skinny64 23.2/23.1/24.0/27.4   tiled 27.6/28.0/28.8/37.2
@@ -2302,6 +2319,7 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
         sp.lds_bytes = (land > slabs ? land : slabs) + 16;
         return launch_stream64(one, sp, p.x, outs, M, ws_header, p.partial, pl.use_seq ? L.qweight_seq : nullptr, st);
     }
+    if (pl.rows) return launch_gemm_rows(L, pl.rowsp, p.x, out, M, st);
     if (pl.wsk) return launch_gemm_wide_sk(L, p.x, out, M, ws_header, (char*)workspace + pl.xperm_bytes, st);
     if (pl.wide) return launch_gemm_wide(L, p.qweight, p.x, out, M, pl.use_seq, st, pl.wide_tiled);
     e = (L.dtype == GPTQ_F16) ? launch_t<f16>(L, pl, p, st) : launch_t<bf16>(L, pl, p, st);

@@ -1,0 +1,126 @@
+// gemm_rows.hip -- batched decode, round 5 (late): 5 ... ~256 rows from the DECODE COPY with NO exchange between workgroups.
+//
+// Why another kernel for this band.  The rounds 2 - 4 kernels (gemm_mid / stream64 / strip16: checkpoint rows, K slices combined across workgroups) sit at
+// 0.10 - 0.27 of the HBM roofline: every K slice pays an exchange hop (2.5 - 3 us: write-through stores, flag, poll, loads), and the lab kernel of this round
+// (tools/lab/gemm_strips.hip) was sized for a per-CU L2 pull of ~50 GB/s.  tools/lab/xpull.hip measures what one workgroup per CU really pulls from a buffer
+// every workgroup reads (the x of a launch): 105 - 125 GB/s per CU with 8 - 16 waves and 4 - 8 KiB in flight per wave, registers or LDS DMA alike
+// (profiles/r05_xpull.log) -- close to the 64 bytes per clock of the L2 -> CU path.  At that rate a workgroup can afford to read ITS ROWS OF x OVER THE WHOLE K:
+//   workgroup (pm, sg) = rows [16 RB pm, + 16 RB) x columns of S adjacent 16-column strips, the whole K; its waves split the 128-deep chunks of K between
+//   them (contiguous ranges) and meet once, through LDS, at the end.  Nothing is published, nobody waits for another workgroup, the sum order is fixed.
+// Per chunk a wave DMAs its rows of x (RB x 4 KiB, wave-private LDS buffers: no barrier in the K loop), loads S strip-chunks of the copy (1 KiB each, one
+// lane = 32 consecutive k of one column, as the decode kernel reads them) and the strips' constants, dequantises (the exact magic-number form, 13 VALU per
+// 8 weights) and feeds v_mfma_f32_16x16x32: lane (column c, k-slot g) of MFMA step w holds k = 32 g + 8 w + 0..7 of the chunk on BOTH operands -- x is read
+// from LDS in that order (16-byte pieces, XOR-swizzled against the 256-byte row pitch on the GLOBAL side of the DMA).
+// Tried and dropped: x straight into registers (MFMA step w = k-slot w, the weights as one dword per lane and step): no LDS at all in the loop, parity-green,
+// and 1.6 - 1.8x SLOWER -- the MFMA operand layout puts the four lanes of a quad on four different rows of x, i.e. four cache lines per quad where the DMA's
+// lane order keeps a quad inside one line (profiles/r05_rows_ab.log, "v2").
+// Cost model (plan_rows): bytes pulled per CU = K (32 RB + 8 S) + constants; dequant VALU grows with the number of row tiles (every row tile dequantises
+// its strips again); the planner picks (RB, S) per shape and row count from the measured table.
+// Reference behaviour this band answers: exllamav2 serves M <= 50 from the same re-laid matrix as M = 1 (exllamav2/cuda/q_gemm.cu:118, config.h:4,
+// q_gemm_kernel_gptq.cuh:39-194), cuda / cuda_old use the fused kernel below 128 rows (qlinear_cuda.py:34,212).
+#include "gemm_rows_kernel.cuh"
+
+namespace gptq {
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------------------
+static int rows_group_mode(const gptq_layer_t& L) {
+    if (L.group_size >= 128) {
+        if (L.group_size >= L.K) return 0;
+        const int q = L.group_size / 128;
+        return (L.group_size % 128 == 0 && (q & (q - 1)) == 0) ? 0 : -1;
+    }
+    return L.group_size == 64 ? 1 : (L.group_size == 32 ? 2 : -1);
+}
+
+bool rows_ok(const gptq_layer_t& L, int M) {
+    if ((L.bits != 4 && L.bits != 3 && L.bits != 8) || (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16)) return false;
+    if (L.qweight_tiled == nullptr || L.qconst_tiled == nullptr || L.tiled_cols != GPTQ_STRIP_COLS) return false;
+    if (L.K % 128 || L.N % 16 || L.epilogue != GPTQ_EPI_NONE || rows_group_mode(L) < 0) return false;
+    if ((size_t)M * L.K * 2 >= ((size_t)1 << 32)) return false;            // 32-bit x offsets per lane
+    return M >= 1 && M <= 1024;
+}
+
+// The planner's measured preference (tools/rows_ab.py against the default plan, profiles/r05_rows_ab.log; us per layer call, default -> this kernel):
+//   4096^2      M = 5 / 8 / 16 / 32 / 64 / 96 / 128:  7.1 / 7.3 / 7.7 / 11.1 / 11.9 / 13.2 / 13.2  ->  5.5 / 5.6 / 5.8 / 6.9 / 8.2 / 10.8 / 11.0
+//   4096x11008                                        11.1 / 11.0 / 11.2 / 15.1 / 21.6 / 25.1 / 26.6  ->  8.8 / 8.8 / 8.9 / 11.3 / 14.2 / 23.4 / 25.0
+//   11008x4096                                        12.6 / 12.8 / 13.2 / 15.7 / 20.3 / 28.4 / 28.9  ->  9.2 / 9.3 / 10.1 / 13.1 / 16.0 / 21.5 / 22.0
+// i.e. 1.07 - 1.6x from 5 to 128 rows; 192 / 256 rows 0.82 - 1.04x (every further row tile dequantises the strips again): the older kernels keep those.
+bool rows_pays(const gptq_layer_t& L, int M) {
+    if (!rows_ok(L, M)) return false;
+    // (bench.py's rotating HBM-cold layers read 4096x11008 at M = 128 as 27.1 against 26.5 us: from 65 rows only layers of at most 8192 columns)
+    return M >= 5 && (M <= 64 || (M <= 128 && L.N <= 8192)) && L.K >= 2048 && L.N >= 2048;
+}
+
+RowsPlan plan_rows(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
+    RowsPlan pl{};
+    if (!rows_ok(L, M)) return pl;
+    const int strips = L.N / 16, chunks = L.K / 128;
+    // forced geometry (lab): tuning.path = 3, reserved[0] = RB (1 / 2), reserved[1] = S
+    int rb = 0, s = 0;
+    if (tune && tune->path == 3 && (tune->reserved[0] == 1 || tune->reserved[0] == 2) && tune->reserved[1] >= 1 && tune->reserved[1] <= 6) {
+        rb = tune->reserved[0];
+        s = tune->reserved[1];
+        if (s == 5 || (s == 6 && (rb == 1 || L.bits != 4))) s = 0;
+    }
+    if (!rb || !s) {
+        // cost model, us: the workgroups of one round pull K (32 RB + 8 S) bytes each at ~110 GB/s per CU; a SIMD dequantises S strips x (K / 128) chunks x 4
+        // words x ~17 issue slots (13 VALU + the MFMAs and LDS reads of its row blocks) for each of the waves it hosts
+        double best = 1e30;
+        for (int crb = 1; crb <= 2; ++crb) {
+            if (crb == 2 && M <= 16) continue;
+            for (int cs : {1, 2, 3, 4, 6}) {
+                if (cs == 6 && (crb == 1 || L.bits != 4)) continue;
+                if (cs == 4 && crb == 1 && L.bits == 8) continue;          // (spills at 128 registers)
+                const long wgs = (long)((M + 16 * crb - 1) / (16 * crb)) * ((strips + cs - 1) / cs);
+                const long rounds = (wgs + 255) / 256;
+                const double pull = (double)L.K * (32.0 * crb + 8.0 * cs) / 110e3;                       // us per workgroup
+                const double valu = (double)chunks * cs * 4.0 * (17.0 + 4.0 * crb) * 4.0 / 4.0 / 2.1e3;    // us per workgroup: its waves share 4 SIMDs
+                const double t = rounds * (pull > valu ? pull : valu) + 0.15 * rounds;
+                if (t < best) { best = t; rb = crb; s = cs; }
+            }
+        }
+    }
+    pl.rb = rb; pl.s = s;
+    pl.xbufs = 2;
+    pl.waves = 16 / rb;                                        // 128 KiB of x buffers: 2 x RB x 4 KiB per wave
+    if (pl.waves > chunks) pl.waves = chunks;
+    pl.cpw = (chunks + pl.waves - 1) / pl.waves;
+    pl.npm = (M + 16 * rb - 1) / (16 * rb);
+    pl.nsg = (strips + s - 1) / s;
+    pl.lds_bytes = (size_t)pl.waves * pl.xbufs * rb * 4096;
+    const size_t red = (size_t)pl.waves * rb * s * 1024;        // the cross-wave sum reuses the x buffers
+    if (red > pl.lds_bytes) pl.lds_bytes = red;
+    pl.ok = true;
+    return pl;
+}
+
+hipError_t launch_gemm_rows_b38(int bits, int dtype, int gm, const RowsPlan& pl, const rowsk::RowsParams& p, hipStream_t st);      // gemm_rows_b38.hip
+hipError_t init_gemm_rows_b38_device();
+
+hipError_t init_gemm_rows_device() {
+    hipError_t e = rows_grant_bits<4>();
+    if (e == hipSuccess) e = init_gemm_rows_b38_device();
+    return e;
+}
+
+hipError_t launch_gemm_rows(const gptq_layer_t& L, const RowsPlan& pl, const void* x, void* out, int M, hipStream_t st) {
+    if (!pl.ok || !rows_ok(L, M)) return hipErrorInvalidValue;
+    rowsk::RowsParams p{};
+    p.qweight = L.qweight_tiled; p.qconst = (const char*)L.qconst_tiled; p.bias = L.bias; p.x = x; p.out = out;
+    p.M = M; p.K = L.K; p.N = L.N;
+    p.chunks = L.K / 128;
+    p.groups = (L.K + L.group_size - 1) / L.group_size;
+    p.gshift = 31;
+    if (L.group_size >= 128 && L.group_size < L.K) {
+        int q = L.group_size / 128, sh = 0;
+        while ((1 << sh) < q) ++sh;
+        p.gshift = sh;
+    }
+    p.strips = L.N / 16;
+    p.npm = pl.npm; p.nsg = pl.nsg; p.cpw = pl.cpw;
+    const int gm = rows_group_mode(L);
+    if (L.bits == 4) return rows_launch_bits<4>(L.dtype, gm, pl, p, st);
+    return launch_gemm_rows_b38(L.bits, L.dtype, gm, pl, p, st);          // gemm_rows_b38.hip
+}
+
+}  // namespace gptq

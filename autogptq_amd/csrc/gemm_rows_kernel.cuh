@@ -1,0 +1,368 @@
+// gemm_rows_kernel.cuh -- the exchange-free batched-decode kernel (see gemm_rows.hip for the design) and the per-width launch ladder; instantiated by
+// gemm_rows.hip (4 bits) and gemm_rows_b38.hip (3 / 8 bits).
+#pragma once
+#include <type_traits>
+
+#include "common.cuh"
+#include "gemm_wide_common.cuh"
+#include "launch.h"
+
+namespace gptq {
+namespace rowsk {
+
+struct RowsParams {
+    const unsigned* qweight;      // the layer's decode copy (qweight_tiled)
+    const char* qconst;           // its constant records (qconst_tiled): [strip][group][48 bytes]
+    const void* bias;
+    const void* x;                // [M][K] (act-order layers: permuted in natural order of the re-sequenced rows by the pre-pass)
+    void* out;
+    int M, K, N;
+    int chunks;                   // K / 128
+    int groups;
+    int gshift;                   // group_size >= 128: group of chunk c = c >> gshift (31: one group)
+    int strips;                   // N / 16
+    int npm;                      // row tiles of 16 RB rows
+    int nsg;                      // groups of S strips
+    int cpw;                      // chunks per wave (the last waves may run short or empty)
+};
+
+template <typename T> struct Mma16;
+template <> struct Mma16<f16> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma16<bf16> {
+    static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+// one column's constants, one word (8 weights in pair order) at a time: w - z exactly in packed fp16, times the scale with ONE rounding to T
+template <typename T> struct Deq1;
+template <> struct Deq1<f16> {
+    f16x2 s2, c1, c2;
+    __device__ __forceinline__ void setup(unsigned sraw, unsigned z) {
+        const f16x2 k960 = {(f16)960.f, (f16)960.f};
+        s2 = as_f16x2(sraw * 0x00010001u);
+        c1 = as_f16x2(z * 0x00010001u + 0xE400E400u);                // -(1024 + z)
+        c2 = c1 + k960;                                               // -(64 + z)
+    }
+    __device__ __forceinline__ u32x4 frag(unsigned q) const {
+        const unsigned q8 = q >> 8;
+        const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+        const f16x2 h0 = as_f16x2(wide::and_or(q, 0x000f000fu, 0x64006400u)) + c1;
+        const f16x2 h1 = as_f16x2(wide::and_or(q, 0x00f000f0u, 0x64006400u)) * r16 + c2;
+        const f16x2 h2 = as_f16x2(wide::and_or(q8, 0x000f000fu, 0x64006400u)) + c1;
+        const f16x2 h3 = as_f16x2(wide::and_or(q8, 0x00f000f0u, 0x64006400u)) * r16 + c2;
+        return u32x4{wide::f16x2_bits(h0 * s2), wide::f16x2_bits(h1 * s2), wide::f16x2_bits(h2 * s2), wide::f16x2_bits(h3 * s2)};
+    }
+};
+template <> struct Deq1<bf16> {
+    float s;
+    f16x2 c1, c2;
+    __device__ __forceinline__ void setup(unsigned sraw, unsigned z) {
+        const f16x2 k960 = {(f16)960.f, (f16)960.f};
+        s = (float)__builtin_bit_cast(bf16, (unsigned short)sraw);
+        c1 = as_f16x2(z * 0x00010001u + 0xE400E400u);
+        c2 = c1 + k960;
+    }
+    __device__ __forceinline__ u32x4 frag(unsigned q) const {
+        const unsigned q8 = q >> 8;
+        const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
+        const f16x2 h0 = as_f16x2(wide::and_or(q, 0x000f000fu, 0x64006400u)) + c1;
+        const f16x2 h1 = as_f16x2(wide::and_or(q, 0x00f000f0u, 0x64006400u)) * r16 + c2;
+        const f16x2 h2 = as_f16x2(wide::and_or(q8, 0x000f000fu, 0x64006400u)) + c1;
+        const f16x2 h3 = as_f16x2(wide::and_or(q8, 0x00f000f0u, 0x64006400u)) * r16 + c2;
+        return u32x4{wide::bf16_scaled_pair(h0, s), wide::bf16_scaled_pair(h1, s), wide::bf16_scaled_pair(h2, s), wide::bf16_scaled_pair(h3, s)};
+    }
+};
+
+// 3 bits (utils.hip prepack_decode_weights_kernel<3>): word j of the lane's three holds pairs 5 j + i at bit 3 i of its halves, bit 15 / 31 = bit j of k30 / k31;
+// fields inside the fp16 mantissa are read in place (gemm_wide_common.cuh: Deq3 is the four-column form of the same arithmetic)
+template <typename T> struct Deq1_3 {
+    wide::Scale4<T> sc;                                            // (column 0 of it)
+    f16x2 c0, c1, c2;
+    __device__ __forceinline__ void setup(unsigned sraw, unsigned z) {
+        sc.setup(u32x2{sraw & 0xffffu, 0u});
+        c0 = as_f16x2(z * 0x00010001u + 0xE400E400u);                 // -(1024 + z)
+        c1 = as_f16x2(z * 0x00080008u + 0xD800D800u);                 // -(128 + z)
+        c2 = as_f16x2(z * 0x00400040u + 0xCC00CC00u);                 // -(16 + z)
+    }
+    __device__ __forceinline__ f16x2 p0(unsigned q) const { return as_f16x2(wide::and_or(q, 0x00070007u, 0x64006400u)) + c0; }
+    __device__ __forceinline__ f16x2 p1(unsigned q) const {
+        const f16x2 rr = {(f16)0.125f, (f16)0.125f};
+        return as_f16x2(wide::and_or(q, 0x00380038u, 0x64006400u)) * rr + c1;
+    }
+    __device__ __forceinline__ f16x2 p2(unsigned q) const {
+        const f16x2 rr = {(f16)0.015625f, (f16)0.015625f};
+        return as_f16x2(wide::and_or(q, 0x01c001c0u, 0x64006400u)) * rr + c2;
+    }
+    __device__ __forceinline__ u32x4 frag(const wide::u32x3& w, int ks) const {      // k = 8 ks .. 8 ks + 7 of the lane's 32
+        f16x2 h[4];
+        if (ks == 0) {
+            h[0] = p0(w[0]); h[1] = p1(w[0]); h[2] = p2(w[0]); h[3] = p1(w[0] >> 6);
+        } else if (ks == 1) {
+            h[0] = p2(w[0] >> 6); h[1] = p0(w[1]); h[2] = p1(w[1]); h[3] = p2(w[1]);
+        } else if (ks == 2) {
+            const unsigned q6 = w[1] >> 6;
+            h[0] = p1(q6); h[1] = p2(q6); h[2] = p0(w[2]); h[3] = p1(w[2]);
+        } else {
+            const unsigned q6 = w[2] >> 6;
+            unsigned t = (w[0] >> 15) & 0x00010001u;
+            t = wide::and_or(w[1] >> 14, 0x00020002u, t);
+            t = wide::and_or(w[2] >> 13, 0x00040004u, t);
+            h[0] = p2(w[2]); h[1] = p1(q6); h[2] = p2(q6); h[3] = p0(t);
+        }
+        return u32x4{sc.mul(h[0], 0), sc.mul(h[1], 0), sc.mul(h[2], 0), sc.mul(h[3], 0)};
+    }
+};
+// 8 bits: stored byte p of word w = k 4 w + {0, 2, 1, 3}[p]
+template <typename T> struct Deq1_8 {
+    wide::Scale4<T> sc;
+    f16x2 c1;
+    __device__ __forceinline__ void setup(unsigned sraw, unsigned z) {
+        sc.setup(u32x2{sraw & 0xffffu, 0u});
+        c1 = as_f16x2(z * 0x00010001u + 0xE400E400u);
+    }
+    __device__ __forceinline__ u32x4 frag(unsigned q0, unsigned q1) const {
+        const f16x2 h0 = as_f16x2(wide::and_or(q0, 0x00ff00ffu, 0x64006400u)) + c1;
+        const f16x2 h1 = as_f16x2(wide::and_or(q0 >> 8, 0x00ff00ffu, 0x64006400u)) + c1;
+        const f16x2 h2 = as_f16x2(wide::and_or(q1, 0x00ff00ffu, 0x64006400u)) + c1;
+        const f16x2 h3 = as_f16x2(wide::and_or(q1 >> 8, 0x00ff00ffu, 0x64006400u)) + c1;
+        return u32x4{sc.mul(h0, 0), sc.mul(h1, 0), sc.mul(h2, 0), sc.mul(h3, 0)};
+    }
+};
+template <typename T, int BITS> struct DeqSel { typedef Deq1<T> type; };
+template <typename T> struct DeqSel<T, 3> { typedef Deq1_3<T> type; };
+template <typename T> struct DeqSel<T, 8> { typedef Deq1_8<T> type; };
+
+// GM: 0 = group_size a multiple of 128 (one group per chunk), 1 = 64 (k-slots 0, 1 | 2, 3), 2 = 32 (one group per k-slot)
+// BITS = 8: the copy's chunks are 64 deep (a lane = 16 k of one column): a 128-deep x chunk takes two of them, MFMA step w reads words 2 (w & 1), + 1 of
+// half w >> 1, and the constants are loaded per half (group modes: 128-multiples, 64 = one group per half, 32 = k-slots 0, 1 | 2, 3 of each half)
+// Two x buffers per wave in LDS: the next chunk's rows are in flight under this chunk's MFMAs.  (One buffer and twice the waves: no faster, tools/rows_ab.py.)
+template <typename T, int BITS, int RB, int S, int GM>
+__global__ void __launch_bounds__(RB == 2 ? 512 : 1024) gemm_rows_kernel(RowsParams p) {
+    constexpr int XBUFS = 2;
+    constexpr int NH = BITS == 8 ? 2 : 1;                      // chunks of the copy per 128-deep x chunk
+    constexpr unsigned REC = BITS == 8 ? 64u : 48u, WCH = BITS == 3 ? 768u : 1024u;      // constant record, strip-chunk of the copy
+    constexpr int R = 16 * RB, XB = R * 256, NDMA = R / 4, NW = 3 * NH * S;      // rows, bytes of one x chunk, its DMA instructions, a chunk's weight + constant loads
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+    const int Lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int pm = Lb % p.npm, sg = Lb / p.npm;              // consecutive workgroups (one XCD): the same strips, the next rows
+    const int m0 = pm * R, s0 = sg * S;
+    const int r = lane & 15, g = lane >> 4;
+    char* const xbuf = smem + (size_t)wave * XBUFS * XB;
+    const unsigned xbuf_lds = lds_addr_of(xbuf);
+
+    // x DMA i (4 rows x 256 bytes): lane (rr = lane >> 4, slot = lane & 15) fetches piece slot ^ (row & 15) of row 4 i + rr -- the four lanes of a quad stay inside
+    // one 64-byte line (16 lines per instruction: the minimum) -- so that LDS slot s of row R holds piece s ^ (R & 15): the reads below (16 rows, one piece
+    // each) then fall on 16 different slots = all 64 banks
+    unsigned xoff[NDMA];
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int row = 4 * i + g;
+        const int m = min(m0 + row, p.M - 1);                 // rows past M repeat the last one (their outputs are not stored)
+        xoff[i] = (unsigned)m * (unsigned)p.K * 2u + (unsigned)((r ^ (row & 15)) * 16);
+    }
+    // A fragment of row block rb, MFMA step w: the 16-byte piece of row 16 rb + r that holds the lane's k -- 3 / 4 bits: k = 32 g + 8 w (piece 4 g + w);
+    // 8 bits: k = 64 (w >> 1) + 16 g + 8 (w & 1) (piece 8 (w >> 1) + 2 g + (w & 1)) -- stored at slot piece ^ r
+    unsigned aoff[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int piece = BITS == 8 ? 8 * (w >> 1) + 2 * g + (w & 1) : 4 * g + w;
+        aoff[w] = (unsigned)(r * 256 + ((piece ^ r) * 16));
+    }
+    // weights: lane * 16 (12 at 3 bits) of the strip-chunk; constants: record (strip, group): scale at 2 col, zero-point (as used) at 32 + col (8 bits: 32 + 2 col)
+    const unsigned wlane = (unsigned)lane * (BITS == 3 ? 12u : 16u);
+    const unsigned glane = BITS == 8 ? (GM == 2 ? (unsigned)(g >> 1) * REC : 0u) : (GM == 2 ? (unsigned)g * REC : (GM == 1 ? (unsigned)(g >> 1) * REC : 0u));
+    const unsigned slane = glane + (unsigned)r * 2u, zlane = glane + 32u + (unsigned)r * (BITS == 8 ? 2u : 1u);
+    const int c0 = wave * p.cpw, c1 = min(c0 + p.cpw, p.chunks);
+
+    // One chunk's packed weights and constants (registers: every use below is inlined and unrolled).  The weights come from HBM, x from L2: a ring of DW
+    // chunks of weights is kept in flight per wave (issued up front, refilled behind each chunk's MFMAs).
+    constexpr int RING4 = 4 * S * (BITS == 8 ? 12 : (BITS == 3 ? 5 : 6));      // registers of a four-chunk ring
+    constexpr int DW = RING4 <= (RB == 1 ? 56 : 120) ? 4 : 2;
+    using WV = std::conditional_t<BITS == 3, wide::u32x3, u32x4>;      // a lane's words of one chunk of the copy (written by ONE load: no copies between the load and the wait)
+    struct Buf { WV wq[S][NH]; unsigned cs[S][NH], cz[S][NH]; };
+    Buf q[DW];
+    auto issue_w = [&](int c, Buf& B) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int strip = min(s0 + s, p.strips - 1);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const char* wsrc = (const char*)p.qweight + ((size_t)strip * (p.chunks * NH) + (c * NH + h)) * WCH;
+                const int grp = GM == 0 ? min(c >> p.gshift, p.groups - 1) : (BITS == 8 ? (GM == 1 ? 2 * c + h : 4 * c + 2 * h) : (GM == 1 ? 2 * c : 4 * c));
+                const char* csrc = p.qconst + ((size_t)strip * p.groups + grp) * REC;
+                if constexpr (BITS == 3) asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(B.wq[s][h]) : "v"(wlane), "s"(wsrc) : "memory");
+                else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B.wq[s][h]) : "v"(wlane), "s"(wsrc) : "memory");
+                asm volatile("global_load_ushort %0, %1, %2" : "=v"(B.cs[s][h]) : "v"(slane), "s"(csrc) : "memory");
+                if constexpr (BITS == 8) asm volatile("global_load_ushort %0, %1, %2" : "=v"(B.cz[s][h]) : "v"(zlane), "s"(csrc) : "memory");
+                else asm volatile("global_load_ubyte %0, %1, %2" : "=v"(B.cz[s][h]) : "v"(zlane), "s"(csrc) : "memory");
+            }
+        }
+    };
+    // DMAs [i0, i1) of chunk c's rows into buffer b
+    auto issue_x = [&](int c, int b, int i0, int i1) __attribute__((always_inline)) {
+        const char* xsrc = (const char*)p.x + (size_t)c * 256;
+        const unsigned l0 = __builtin_amdgcn_readfirstlane(xbuf_lds + (unsigned)(b * XB));
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+            const unsigned xo = xoff[i];                       // (an asm operand alone does not capture the array in a generic lambda)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l0 + (unsigned)(i * 1024)), "v"(xo), "s"(xsrc) : "memory");
+        }
+    };
+    // the registers pass through a statement behind the wait so that no use of them is scheduled in front of it
+    auto claim = [&](Buf& B) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) asm volatile("" : "+v"(B.wq[s][h]), "+v"(B.cs[s][h]), "+v"(B.cz[s][h])::"memory");
+    };
+
+    f32x4 acc[RB][S];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[rb][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // chunk in buffer b; the NEXT chunk's x DMAs (cn, into the other buffer) are issued a quarter at a time behind the MFMAs of each step: eight DMAs in a row
+    // fill the wave's VMEM queue and stall it at the issue port for as long as the TA takes to drain them -- the pull time then ADDS to the dequant time
+    // instead of hiding under it (first version: time = 3.0 + 0.012 per KiB of x + 0.034 per KiB of weights, strictly additive; tools/rows_ab.py)
+    auto compute = [&](const Buf& B, int b, int cn, bool has_x) __attribute__((always_inline)) {
+        typename DeqSel<T, BITS>::type dq[S][NH];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) dq[s][h].setup(B.cs[s][h], B.cz[s][h]);
+        const char* xb = xbuf + b * XB;
+        u32x4 a[4][RB];                                        // all the chunk's x fragments first: the LDS latency lies under the dequant of step 0
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) a[w][rb] = *(const u32x4*)(xb + rb * 4096 + aoff[w]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                u32x4 bq;
+                if constexpr (BITS == 4) bq = dq[s][0].frag(B.wq[s][0][w]);
+                else if constexpr (BITS == 3) bq = dq[s][0].frag(B.wq[s][0], w);
+                else bq = dq[s][w >> 1].frag(B.wq[s][w >> 1][2 * (w & 1)], B.wq[s][w >> 1][2 * (w & 1) + 1]);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb][s] = Mma16<T>::run(a[w][rb], bq, acc[rb][s]);
+            }
+            if (has_x) issue_x(cn, b ^ 1, w * (NDMA / 4), (w + 1) * (NDMA / 4));
+        }
+    };
+
+    if (c0 < c1) {
+#pragma unroll
+        for (int j = 0; j < DW; ++j)
+            if (c0 + j < c1) issue_w(c0 + j, q[j]);
+        issue_x(c0, 0, 0, NDMA);
+        for (int cb = c0; cb < c1; cb += DW) {
+#pragma unroll
+            for (int j = 0; j < DW; ++j) {
+                const int c = cb + j;
+                if (c >= c1) break;
+                // VMEM queue, oldest first: W(c0 .. c0 + DW - 1), x(c0) | x(c0 + 1) under the MFMAs of c0, W(c0 + DW) | x(c0 + 2), W(c0 + DW + 1) | ...
+                // chunk c needs x(c) and everything older (W(c) is); behind x(c) there is only W(c + DW - 1), issued at the end of the previous iteration
+                const bool has_w = c > c0 && c + DW - 1 < c1;
+                if (has_w) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                claim(q[j]);
+                compute(q[j], j & 1, c + 1, c + 1 < c1);
+                if (c + DW < c1) issue_w(c + DW, q[j]);
+            }
+        }
+    }
+
+    // ---- the waves' sums meet in LDS (fixed order), bias, store ------------------------------------------------------------------------------
+    __syncthreads();                                           // every wave is done with its x buffers
+    float* const red = (float*)smem;                           // [wave][rb][s][lane] float4
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int s = 0; s < S; ++s) *(f32x4*)(red + ((size_t)((wave * RB + rb) * S + s) * 64 + lane) * 4) = acc[rb][s];
+    __syncthreads();
+    for (int item = tid; item < RB * S * 64; item += (int)blockDim.x) {
+        const int l = item & 63, t = item >> 6, s = t % S, rb = t / S;
+        f32x4 v = *(const f32x4*)(red + ((size_t)((0 * RB + rb) * S + s) * 64 + l) * 4);
+        for (int w = 1; w < nw; ++w) v += *(const f32x4*)(red + ((size_t)((w * RB + rb) * S + s) * 64 + l) * 4);
+        const int strip = s0 + s;
+        if (strip >= p.strips) continue;
+        const int n = strip * 16 + (l & 15);
+        const float bv = p.bias ? DType<T>::to_f32(((const T*)p.bias)[n]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                          // C/D layout of the 16x16 MFMA: row = 4 (lane >> 4) + i, column = lane & 15
+            const int m = m0 + 16 * rb + 4 * (l >> 4) + i;
+            if (m < p.M) ((T*)p.out)[(size_t)m * p.N + n] = DType<T>::from_f32(v[i] + bv);
+        }
+    }
+}
+
+}  // namespace rowsk
+
+// ---- instantiation ladder of one bit width (grant the dynamic LDS, launch) ----------------------------------------------------------------------
+template <typename T, int BITS, int RB, int S, int GM>
+static hipError_t rows_grant_one() {
+    return hipFuncSetAttribute((const void*)rowsk::gemm_rows_kernel<T, BITS, RB, S, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <typename T, int BITS, int RB, int GM>
+static hipError_t rows_grant_s() {
+    hipError_t e = rows_grant_one<T, BITS, RB, 1, GM>();
+    if (e == hipSuccess) e = rows_grant_one<T, BITS, RB, 2, GM>();
+    if (e == hipSuccess) e = rows_grant_one<T, BITS, RB, 3, GM>();
+    if (e == hipSuccess) e = rows_grant_one<T, BITS, RB, 4, GM>();
+    if constexpr (RB == 2 && BITS == 4) { if (e == hipSuccess) e = rows_grant_one<T, BITS, RB, 6, GM>(); }      // (RB = 1: 6 strips spill at 128 registers; 8 spill in either form)
+    return e;
+}
+template <typename T, int BITS>
+static hipError_t rows_grant_t() {
+    hipError_t e = rows_grant_s<T, BITS, 1, 0>();
+    if (e == hipSuccess) e = rows_grant_s<T, BITS, 2, 0>();
+    if (e == hipSuccess) e = rows_grant_s<T, BITS, 1, 1>();
+    if (e == hipSuccess) e = rows_grant_s<T, BITS, 2, 1>();
+    if (e == hipSuccess) e = rows_grant_s<T, BITS, 1, 2>();
+    if (e == hipSuccess) e = rows_grant_s<T, BITS, 2, 2>();
+    return e;
+}
+template <int BITS>
+static hipError_t rows_grant_bits() {
+    hipError_t e = rows_grant_t<f16, BITS>();
+    if (e == hipSuccess) e = rows_grant_t<bf16, BITS>();
+    return e;
+}
+
+template <typename T, int BITS, int RB, int S, int GM>
+static void rows_launch_one(const RowsPlan& pl, const rowsk::RowsParams& p, hipStream_t st) {
+    hipLaunchKernelGGL((rowsk::gemm_rows_kernel<T, BITS, RB, S, GM>), dim3(pl.npm * pl.nsg), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+}
+template <typename T, int BITS, int RB, int GM>
+static hipError_t rows_launch_s(const RowsPlan& pl, const rowsk::RowsParams& p, hipStream_t st) {
+    switch (pl.s) {
+        case 1: rows_launch_one<T, BITS, RB, 1, GM>(pl, p, st); break;
+        case 2: rows_launch_one<T, BITS, RB, 2, GM>(pl, p, st); break;
+        case 3: rows_launch_one<T, BITS, RB, 3, GM>(pl, p, st); break;
+        case 4: rows_launch_one<T, BITS, RB, 4, GM>(pl, p, st); break;
+        case 6: if constexpr (RB == 2 && BITS == 4) { rows_launch_one<T, BITS, RB, 6, GM>(pl, p, st); break; } else return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+template <typename T, int BITS, int GM>
+static hipError_t rows_launch_rb(const RowsPlan& pl, const rowsk::RowsParams& p, hipStream_t st) {
+    return pl.rb == 1 ? rows_launch_s<T, BITS, 1, GM>(pl, p, st) : rows_launch_s<T, BITS, 2, GM>(pl, p, st);
+}
+template <int BITS>
+static hipError_t rows_launch_bits(int dtype, int gm, const RowsPlan& pl, const rowsk::RowsParams& p, hipStream_t st) {
+    if (dtype == GPTQ_F16) return gm == 0 ? rows_launch_rb<f16, BITS, 0>(pl, p, st) : (gm == 1 ? rows_launch_rb<f16, BITS, 1>(pl, p, st) : rows_launch_rb<f16, BITS, 2>(pl, p, st));
+    return gm == 0 ? rows_launch_rb<bf16, BITS, 0>(pl, p, st) : (gm == 1 ? rows_launch_rb<bf16, BITS, 1>(pl, p, st) : rows_launch_rb<bf16, BITS, 2>(pl, p, st));
+}
+
+}  // namespace gptq

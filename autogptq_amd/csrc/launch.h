@@ -50,8 +50,22 @@ struct WideSkGeom {
     size_t slot_bytes;        // published accumulators of cut tiles: 256 KiB per workgroup (0 when every range boundary is a tile boundary)
 };
 
+// gemm_rows.hip: 5 .. ~256 rows from the decode copy, a workgroup = 16 rb rows x s strips x the whole K, no exchange between workgroups
+struct RowsPlan {
+    bool ok;
+    int rb, s, xbufs, waves, cpw, npm, nsg;
+    size_t lds_bytes;
+};
+bool rows_ok(const gptq_layer_t& L, int M);
+bool rows_pays(const gptq_layer_t& L, int M);
+RowsPlan plan_rows(const gptq_layer_t& L, int M, const gptq_tuning_t* tune);
+hipError_t launch_gemm_rows(const gptq_layer_t& L, const RowsPlan& pl, const void* x, void* out, int M, hipStream_t st);
+hipError_t init_gemm_rows_device();
+
 struct GemmPlan {
     bool supported, use_seq;
+    bool rows;                // gemm_rows.hip (rowsp holds its geometry); act-order layers: x permuted in natural order (xnat)
+    RowsPlan rowsp;
     bool wsk;                 // stream-K partition of 128 x 256 tiles with the 128 x 128 wave tile (gemm_wide_sk.hip); implies wide_tiled (+ xnat for act-order layers)
     WideSkGeom wskg;
     bool wide_tiled;          // ... reading the layer's decode copy, raw x staged by LDS DMA

@@ -333,7 +333,7 @@ class QuantLinear(nn.Module):
         need = self._rows_need.get(M) if tuning is None else None
         if need is None:
             d = _lib.describe_plan(self._layer, M, tuning)
-            need = not (d.get("kernel") in ("strips", "wide_sk", "wide_copy"))
+            need = not (d.get("kernel") in ("strips", "rows", "wide_sk", "wide_copy"))          # the kernels that read the decode copy
             if tuning is None:
                 self._rows_need[M] = need
         if need:

@@ -42,6 +42,8 @@
 #define GPTQ_LAB_VARIANT_WIDE_ROWS_ON 47  /* 45 + 46 */
 #define GPTQ_LAB_VARIANT_WIDE_SK_ON 48    /* the stream-K form of the wide tile (gemm_wide_sk.hip) wherever it is legal */
 #define GPTQ_LAB_VARIANT_WIDE_SK_OFF 49   /* never the stream-K form */
+#define GPTQ_LAB_VARIANT_ROWS_ON 50       /* the exchange-free batched-decode kernel (gemm_rows.hip) wherever it is legal; reserved[0] = row blocks of 16 (1 / 2), reserved[1] = strips per workgroup (0: the planner's) */
+#define GPTQ_LAB_VARIANT_ROWS_OFF 51      /* never that kernel */
 /* (9..24, 32: ablation / timeline / ping-pong variants compiled only into tools/gemmlab with -DGPTQ_GEMM_ABLATIONS) */
 
 #endif /* GPTQ_MI355X_LAB_H */
