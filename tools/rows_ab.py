@@ -16,6 +16,7 @@ ap.add_argument("--xb", default="2", help="x buffers per wave (2: double-buffere
 ap.add_argument("--dtype", default="f16")
 ap.add_argument("--act", default="0")
 ap.add_argument("--gs", type=int, default=128)
+ap.add_argument("--bits", type=int, default=4)
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--default-baseline", type=int, default=1)
 ap.add_argument("--layers", type=int, default=8)
@@ -41,7 +42,7 @@ geoms = [tuple(map(int, g.split("x"))) for g in a.geoms.split(",")]
 for shp in a.shapes.split(","):
     K, N = map(int, shp.split("x"))
     for act in map(int, a.act.split(",")):
-        ls = [make_layer(K, N, dev, gs=a.gs, dtype=dt, seed=i, act_order=bool(act)) for i in range(a.layers)]
+        ls = [make_layer(K, N, dev, bits=a.bits, gs=a.gs, dtype=dt, seed=i, act_order=bool(act)) for i in range(a.layers)]
         for M in map(int, a.ms.split(",")):
             x = (torch.rand(M, K, device=dev) - 0.5).to(dt)
             best = {}
@@ -63,7 +64,7 @@ for shp in a.shapes.split(","):
                         best[key] = min(best.get(key, 1e9), run(ls, x, t, reps=5))
             w = best.pop("without")
             kb = min(best, key=best.get) if best else None
-            print(f"int4 g{a.gs} {K}x{N} M={M:4d} {a.dtype} act={act} | without [{kname:9s}] {w * 1e6:7.2f} us | " +
+            print(f"int{a.bits} g{a.gs} {K}x{N} M={M:4d} {a.dtype} act={act} | without [{kname:9s}] {w * 1e6:7.2f} us | " +
                   " ".join(f"{k} {v * 1e6:6.2f}" for k, v in best.items()) + (f" | best {kb} {best[kb] * 1e6:6.2f} us {w / best[kb]:5.2f}x" if kb else ""), flush=True)
             del x
         del ls
