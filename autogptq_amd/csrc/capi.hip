@@ -249,6 +249,7 @@ static size_t body_bytes(const gptq_layer_t* L, int M, const gptq_tuning_t* tune
     size_t a = plan_gemv(*L, M, tune).workspace_bytes;
     GemmPlan g = plan_gemm(*L, M, tune);
     size_t b = g.supported ? g.workspace_bytes : 0;
+    if (g.supported && g.rows && want_gemm(L, M, tune)) return b;                 // the exchange-free batched-decode kernel: nothing but the permuted x of act-order layers
     size_t c = 0;
     {
         const gptq_layer_t* one[1] = {L};

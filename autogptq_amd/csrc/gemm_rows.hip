@@ -18,6 +18,8 @@
 // its strips again); the planner picks (RB, S) per shape and row count from the measured table.
 // Reference behaviour this band answers: exllamav2 serves M <= 50 from the same re-laid matrix as M = 1 (exllamav2/cuda/q_gemm.cu:118, config.h:4,
 // q_gemm_kernel_gptq.cuh:39-194), cuda / cuda_old use the fused kernel below 128 rows (qlinear_cuda.py:34,212).
+#include <cstdlib>
+
 #include "gemm_rows_kernel.cuh"
 
 namespace gptq {
@@ -45,10 +47,16 @@ bool rows_ok(const gptq_layer_t& L, int M) {
 //   4096x11008                                        11.1 / 11.0 / 11.2 / 15.1 / 21.6 / 25.1 / 26.6  ->  8.8 / 8.8 / 8.9 / 11.3 / 14.2 / 23.4 / 25.0
 //   11008x4096                                        12.6 / 12.8 / 13.2 / 15.7 / 20.3 / 28.4 / 28.9  ->  9.2 / 9.3 / 10.1 / 13.1 / 16.0 / 21.5 / 22.0
 // i.e. 1.07 - 1.6x from 5 to 128 rows; 192 / 256 rows 0.82 - 1.04x (every further row tile dequantises the strips again): the older kernels keep those.
+// Other model shapes (old default -> this kernel, same log, M = 8 / 16 / 32 / 64 / 128): 2048^2 1.24 - 2.26x, 4096x2048 1.25 - 2.21x, 1024x8192 and 8192x1024
+// 1.09 - 2.30x, 5120^2 1.25 - 1.47x, 8192^2 1.10 - 1.18x up to 64 rows (0.87x at 128); it LOSES on the largest layers, where the launch is several rounds
+// of workgroups that each pull their rows of x again: 8192x28672 0.84 - 0.87x (1.21x at 32 rows), 5120x13824 0.94 - 0.97x at 8 / 16 rows, 13824x5120
+// 0.93 - 1.0x up to 32 rows, 28672x8192 0.69 - 1.03x.  Hence: layers of at most 64 Mi weights, 128 rows only up to 46 M weights and 8192 columns.
 bool rows_pays(const gptq_layer_t& L, int M) {
-    if (!rows_ok(L, M)) return false;
-    // (bench.py's rotating HBM-cold layers read 4096x11008 at M = 128 as 27.1 against 26.5 us: from 65 rows only layers of at most 8192 columns)
-    return M >= 5 && (M <= 64 || (M <= 128 && L.N <= 8192)) && L.K >= 2048 && L.N >= 2048;
+    static const bool lab_off = getenv("GPTQ_LAB_NO_ROWS") != nullptr;      // lab (tools/session_r05_rows2.sh): the planner as it was before this kernel
+    if (lab_off || !rows_ok(L, M)) return false;
+    const size_t kn = (size_t)L.K * L.N;
+    if (M < 5 || M > 128 || L.K < 1024 || L.N < 1024 || kn > ((size_t)64 << 20)) return false;
+    return M <= 64 || (kn <= (size_t)46000000 && L.N <= 8192);
 }
 
 RowsPlan plan_rows(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {

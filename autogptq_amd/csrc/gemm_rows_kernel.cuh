@@ -293,7 +293,14 @@ __global__ void __launch_bounds__(RB == 2 ? 512 : 1024) gemm_rows_kernel(RowsPar
     for (int item = tid; item < RB * S * 64; item += (int)blockDim.x) {
         const int l = item & 63, t = item >> 6, s = t % S, rb = t / S;
         f32x4 v = *(const f32x4*)(red + ((size_t)((0 * RB + rb) * S + s) * 64 + l) * 4);
-        for (int w = 1; w < nw; ++w) v += *(const f32x4*)(red + ((size_t)((w * RB + rb) * S + s) * 64 + l) * 4);
+        for (int w0 = 1; w0 < nw; w0 += 4) {                   // four loads in flight, added in wave order (a serial chain of 15 LDS round trips otherwise)
+            f32x4 t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = *(const f32x4*)(red + ((size_t)((min(w0 + j, nw - 1) * RB + rb) * S + s) * 64 + l) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (w0 + j < nw) v += t[j];
+        }
         const int strip = s0 + s;
         if (strip >= p.strips) continue;
         const int n = strip * 16 + (l & 15);

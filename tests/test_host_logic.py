@@ -812,6 +812,47 @@ def test_stream_k_prefill_rules_for_every_packing():
     assert plan(2, 32, 4096, 4096, 2048, copy=False)[0]["kernel"] != "wide_sk"         # 2 bits have no decode copy
 
 
+def test_batched_decode_rows_kernel_rules():
+    """Round 5, host only: 5 .. 128 rows of a layer that carries its decode copy go to the exchange-free kernel (csrc/gemm_rows.hip: rows_ok / rows_pays /
+    plan_rows) -- 3-, 4- and 8-bit, 32- / 64-wide groups and power-of-two multiples of 128, layers of 1024+ rows and columns and at most 64 Mi weights, 65+ rows
+    only up to 46 M weights and 8192 columns -- with a geometry the library is built for (RB in {1, 2}, S in {1, 2, 3, 4, 6}; 6 strips only at 4 bits with two row
+    blocks), no workspace beyond the permuted x of act-order layers; decode rows keep the decode kernel, 129+ rows and layers without a copy the older ones."""
+    lib = _lib.load()
+
+    def plan(bits, gs, K, N, M, act=False, copy=True, dtype=0):
+        L = _layer(K=K, N=N, bits=bits, group_size=gs, dtype=dtype)
+        if act:
+            L.g_idx = L.qweight_seq = L.perm = 0x1000
+        if copy:
+            L.qweight_tiled = L.qconst_tiled = 0x2000
+            L.tiled_cols = 16
+        buf = ctypes.create_string_buffer(512)
+        assert lib.gptq_describe_plan(ctypes.byref(L), M, None, buf, len(buf)) == 0, lib.gptq_last_error()
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split()), lib.gptq_workspace_bytes(ctypes.byref(L), M)
+
+    for bits in (3, 4, 8):
+        for gs in (32, 64, 128, 256):
+            for K, N in ((4096, 4096), (4096, 11008), (11008, 4096), (2048, 2048), (8192, 1024), (1024, 8192), (8192, 8192)):
+                for M in (5, 8, 16, 33, 64):
+                    for act in (False, True):
+                        d, need = plan(bits, gs, K, N, M, act)
+                        assert d["kernel"] == "rows", (bits, gs, K, N, M, act, d)
+                        rb, s = int(d["mt"]), int(d["tiles"].split("x")[1])
+                        assert rb in (1, 2) and int(d["tiles"].split("x")[0]) == -(-M // (16 * rb)), d
+                        per = -(-(N // 16) // s)                      # strips per workgroup
+                        assert per in (1, 2, 3, 4, 6) and (per != 6 or (bits == 4 and rb == 2)) and not (bits == 8 and rb == 1 and per == 4), d
+                        assert need == (65536 + (M * K * 2 + 255) // 256 * 256 if act else 0), (d, need)      # header + permuted x, or nothing
+    for M in (96, 128):
+        assert plan(4, 128, 4096, 4096, M)[0]["kernel"] == "rows" and plan(4, 128, 11008, 4096, M)[0]["kernel"] == "rows"
+        assert plan(4, 128, 4096, 11008, M)[0]["kernel"] != "rows" and plan(4, 128, 8192, 8192, M)[0]["kernel"] != "rows"
+    for M in (1, 2, 4):
+        assert plan(4, 128, 4096, 4096, M)[0]["kernel"] == "strips"
+    assert plan(4, 128, 4096, 4096, 129)[0]["kernel"] != "rows" and plan(4, 128, 4096, 4096, 16, copy=False)[0]["kernel"] != "rows"
+    assert plan(4, 128, 8192, 28672, 16)[0]["kernel"] != "rows" and plan(4, 128, 512, 4096, 16)[0]["kernel"] != "rows"      # several rounds of workgroups / a small layer
+    assert plan(2, 128, 4096, 4096, 16, copy=False)[0]["kernel"] != "rows"
+    assert plan(4, 96, 4032, 4096, 16)[0]["kernel"] != "rows"                                                             # groups of 96
+
+
 def test_decode_copy_restatement_matches_the_header_definition():
     """oracle.decode_copy_weights / decode_copy_consts restate gptq_prepack_decode (include/gptq_mi355x.h, gptq_layer_t.qweight_tiled / qconst_tiled): checked
     entry by entry against the header's formula on a small layer (ragged last chunk: K = 160), that the magic-number extraction order of a stored word is
