@@ -10,6 +10,7 @@
 
 #include "common.cuh"
 #include "launch.h"
+#include "../../include/gptq_mi355x_lab.h"
 
 using namespace gptq;
 
@@ -493,6 +494,9 @@ size_t gptq_workspace_bytes_multi_ex(const gptq_layer_t* const* layers, int n_la
         const TiledPlan tp = plan_tiled(layers, n_layers, M, tune);
         return tp.partial_bytes ? WS_HEADER_BYTES + tp.partial_bytes : 0;
     }
+    if (n_layers >= 2 && ((tune && tune->path == 3 && tune->reserved[3] == GPTQ_LAB_VARIANT_ROWS_ON && rows_multi_ok(layers, n_layers, M)) || (!tune && rows_multi_pays(layers, n_layers, M))) &&
+        plan_rows_multi(layers, n_layers, M, nullptr).ok)
+        return layers[0]->g_idx ? WS_HEADER_BYTES + xperm16_bytes(layers[0], M) : 0;      // gemm_rows.hip over all layers: nothing but the permuted x of act-order layers
     if (want_mid_multi(layers, n_layers, M, tune)) {
         const MidPlan mp = plan_mid(layers, n_layers, M, tune);
         return mp.partial_bytes ? WS_HEADER_BYTES + mp.partial_bytes : 0;
@@ -534,6 +538,25 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
             return tiled_call(layers, n_layers, x, outs, M, wv, stream, tune, &tp);
     }
     if (tune && tune->path == 8) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: these layers do not fit one decode-copy launch (1..4 layers of one packing with qweight_tiled, all plain or all act-order, M <= 8)");
+    // 5 .. 128 rows on layers that carry the decode copy: the exchange-free kernel over the strip groups of all layers (gemm_rows.hip); act-order layers of
+    // ONE order (the same perm pointer: QuantLinear.share_act_order) read one permuted x
+    const bool rows_forced = tune && tune->path == 3 && tune->reserved[3] == GPTQ_LAB_VARIANT_ROWS_ON && rows_multi_ok(layers, n_layers, M);      // lab knob 50
+    if (n_layers >= 2 && (rows_forced || (!tune && rows_multi_pays(layers, n_layers, M)))) {
+        const RowsPlan rp = plan_rows_multi(layers, n_layers, M, nullptr);
+        if (rp.ok) {
+            const void* xin = x;
+            if (layers[0]->g_idx) {
+                const size_t xb = xperm16_bytes(layers[0], M);
+                if (wv.body_bytes < xb) return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + xb, wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0);
+                hipError_t e = launch_permute_rows16(x, layers[0]->perm, M, layers[0]->K, wv.body, (hipStream_t)stream, false);
+                if (e != hipSuccess) return hip_fail(e, "gptq x permute launch");
+                xin = wv.body;
+            }
+            hipError_t e = launch_gemm_rows_multi(layers, n_layers, rp, xin, outs, M, (hipStream_t)stream);
+            if (e != hipSuccess) return hip_fail(e, "gptq batched-decode launch (gemm_rows; was gptq_init() called on this device?)");
+            return GPTQ_OK;
+        }
+    }
     if (want_mid_multi(layers, n_layers, M, tune)) {
         const MidPlan mp = plan_mid(layers, n_layers, M, tune);
         if (mp.partial_bytes > 0 && wv.body_bytes < mp.partial_bytes)

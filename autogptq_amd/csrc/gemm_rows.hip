@@ -59,10 +59,13 @@ bool rows_pays(const gptq_layer_t& L, int M) {
     return M <= 64 || (kn <= (size_t)46000000 && L.N <= 8192);
 }
 
-RowsPlan plan_rows(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
+// strips_of: the strip counts of the n layers of one launch (a strip group never straddles two layers); nullptr: the one layer L
+static RowsPlan plan_rows_n(const gptq_layer_t& L, int M, const gptq_tuning_t* tune, const int* strips_of, int n) {
     RowsPlan pl{};
     if (!rows_ok(L, M)) return pl;
-    const int strips = L.N / 16, chunks = L.K / 128;
+    const int one_layer = L.N / 16, chunks = L.K / 128;
+    if (!strips_of) { strips_of = &one_layer; n = 1; }
+    auto groups_of = [&](int cs) { long g = 0; for (int i = 0; i < n; ++i) g += (strips_of[i] + cs - 1) / cs; return g; };
     // forced geometry (lab): tuning.path = 3, reserved[0] = RB (1 / 2), reserved[1] = S
     int rb = 0, s = 0;
     if (tune && tune->path == 3 && (tune->reserved[0] == 1 || tune->reserved[0] == 2) && tune->reserved[1] >= 1 && tune->reserved[1] <= 6) {
@@ -79,11 +82,13 @@ RowsPlan plan_rows(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
             for (int cs : {1, 2, 3, 4, 6}) {
                 if (cs == 6 && (crb == 1 || L.bits != 4)) continue;
                 if (cs == 4 && crb == 1 && L.bits == 8) continue;          // (spills at 128 registers)
-                const long wgs = (long)((M + 16 * crb - 1) / (16 * crb)) * ((strips + cs - 1) / cs);
+                const long wgs = (long)((M + 16 * crb - 1) / (16 * crb)) * groups_of(cs);
                 const long rounds = (wgs + 255) / 256;
                 const double pull = (double)L.K * (32.0 * crb + 8.0 * cs) / 110e3;                       // us per workgroup
                 const double valu = (double)chunks * cs * 4.0 * (17.0 + 4.0 * crb) * 4.0 / 4.0 / 2.1e3;    // us per workgroup: its waves share 4 SIMDs
-                const double t = rounds * (pull > valu ? pull : valu) + 0.15 * rounds;
+                // + ~2 us per round: a workgroup owns its CU (128 KiB of LDS), so the first HBM round trip of its weights and its cross-wave sum are not hidden by the
+                // next one (4096x11008 M = 16: 688 one-strip workgroups = 3 rounds 12.6 us, 230 three-strip ones 8.9)
+                const double t = rounds * ((pull > valu ? pull : valu) + 2.0);
                 if (t < best) { best = t; rb = crb; s = cs; }
             }
         }
@@ -94,7 +99,7 @@ RowsPlan plan_rows(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     if (pl.waves > chunks) pl.waves = chunks;
     pl.cpw = (chunks + pl.waves - 1) / pl.waves;
     pl.npm = (M + 16 * rb - 1) / (16 * rb);
-    pl.nsg = (strips + s - 1) / s;
+    pl.nsg = (int)groups_of(s);
     pl.lds_bytes = (size_t)pl.waves * pl.xbufs * rb * 4096;
     const size_t red = (size_t)pl.waves * rb * s * 1024;        // the cross-wave sum reuses the x buffers
     if (red > pl.lds_bytes) pl.lds_bytes = red;
@@ -111,11 +116,59 @@ hipError_t init_gemm_rows_device() {
     return e;
 }
 
-hipError_t launch_gemm_rows(const gptq_layer_t& L, const RowsPlan& pl, const void* x, void* out, int M, hipStream_t st) {
-    if (!pl.ok || !rows_ok(L, M)) return hipErrorInvalidValue;
+// 1 .. 4 layers in one launch (gptq_forward_multi): the same packing, group size, K and dtype, no fused epilogue; outs[i] = layer i's [M][N_i]
+bool rows_multi_ok(const gptq_layer_t* const* Ls, int n, int M) {
+    if (n < 1 || n > 4) return false;
+    for (int i = 0; i < n; ++i) {
+        const gptq_layer_t& L = *Ls[i];
+        if (!rows_ok(L, M) || L.bits != Ls[0]->bits || L.group_size != Ls[0]->group_size || L.K != Ls[0]->K || L.dtype != Ls[0]->dtype) return false;
+        if ((L.g_idx != nullptr) != (Ls[0]->g_idx != nullptr) || (L.g_idx && L.perm != Ls[0]->perm)) return false;      // plain layers, or act-order layers of ONE order
+    }
+    return true;
+}
+
+// Several layers in one launch.  The multi-layer forms of the older kernels (gemm_stream64 up to 16 rows, gemm_mid above) have enough strips to work with and hold
+// their own: same-session, gptq_forward_multi, old -> this kernel (tools/rows_multi_ab.py, profiles/r05_rows_ab.log, us): q|k|v 7B M = 8 / 16 / 32 / 64 / 128
+// 11.3 / 11.4 / 15.2 / 21.7 / 35.5 -> 12.0 / 12.3 / 15.1 / 23.1 / 35.7, q|k|v 13B 13.7 / 14.0 / 19.7 / 28.2 / 45.4 -> 15.7 / 16.2 / 18.3 / 29.5 / 52.5; only the
+// 1376 strips of gate|up 7B between the two older kernels' sweet spots gain: M = 32 / 64 29.0 / 41.5 -> 20.1 / 32.0 (8 / 16 / 128: 16.5 / 18.5 / 58.7 -> 16.8 / 20.1 / 57.7).
+bool rows_multi_pays(const gptq_layer_t* const* Ls, int n, int M) {
+    if (!rows_multi_ok(Ls, n, M)) return false;
+    long strips = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!rows_pays(*Ls[i], M)) return false;
+        strips += Ls[i]->N / 16;
+    }
+    return M >= 24 && M <= 64 && strips >= 1024;
+}
+
+RowsPlan plan_rows(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) { return plan_rows_n(L, M, tune, nullptr, 1); }
+
+RowsPlan plan_rows_multi(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* tune) {
+    if (!rows_multi_ok(Ls, n, M)) return RowsPlan{};
+    int strips_of[4];
+    for (int i = 0; i < n; ++i) strips_of[i] = Ls[i]->N / 16;
+    return plan_rows_n(*Ls[0], M, tune, strips_of, n);
+}
+
+hipError_t launch_gemm_rows_multi(const gptq_layer_t* const* Ls, int n, const RowsPlan& pl, const void* x, void* const* outs, int M, hipStream_t st) {
+    if (!pl.ok || !rows_multi_ok(Ls, n, M)) return hipErrorInvalidValue;
+    const gptq_layer_t& L = *Ls[0];
     rowsk::RowsParams p{};
-    p.qweight = L.qweight_tiled; p.qconst = (const char*)L.qconst_tiled; p.bias = L.bias; p.x = x; p.out = out;
-    p.M = M; p.K = L.K; p.N = L.N;
+    int end = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (i < n) {
+            p.seg[i].qweight = Ls[i]->qweight_tiled; p.seg[i].qconst = (const char*)Ls[i]->qconst_tiled; p.seg[i].bias = Ls[i]->bias; p.seg[i].out = outs[i];
+            p.seg[i].N = Ls[i]->N; p.seg[i].strips = Ls[i]->N / 16;
+            end += (Ls[i]->N / 16 + pl.s - 1) / pl.s;
+            p.sg_end[i] = end;
+        } else {
+            p.seg[i] = p.seg[0];
+            p.sg_end[i] = 0x7fffffff;
+        }
+    }
+    if (end != pl.nsg) return hipErrorInvalidValue;
+    p.x = x;
+    p.M = M; p.K = L.K;
     p.chunks = L.K / 128;
     p.groups = (L.K + L.group_size - 1) / L.group_size;
     p.gshift = 31;
@@ -124,11 +177,16 @@ hipError_t launch_gemm_rows(const gptq_layer_t& L, const RowsPlan& pl, const voi
         while ((1 << sh) < q) ++sh;
         p.gshift = sh;
     }
-    p.strips = L.N / 16;
     p.npm = pl.npm; p.nsg = pl.nsg; p.cpw = pl.cpw;
     const int gm = rows_group_mode(L);
     if (L.bits == 4) return rows_launch_bits<4>(L.dtype, gm, pl, p, st);
     return launch_gemm_rows_b38(L.bits, L.dtype, gm, pl, p, st);          // gemm_rows_b38.hip
+}
+
+hipError_t launch_gemm_rows(const gptq_layer_t& L, const RowsPlan& pl, const void* x, void* out, int M, hipStream_t st) {
+    const gptq_layer_t* one[1] = {&L};
+    void* outs[1] = {out};
+    return launch_gemm_rows_multi(one, 1, pl, x, outs, M, st);
 }
 
 }  // namespace gptq

@@ -10,19 +10,24 @@
 namespace gptq {
 namespace rowsk {
 
-struct RowsParams {
+// 1 .. 4 layers that read the same x (q|k|v, gate|up: gptq_forward_multi) in ONE launch: the strip groups of layer 0, then of layer 1, ...
+struct RowsSeg {
     const unsigned* qweight;      // the layer's decode copy (qweight_tiled)
-    const char* qconst;           // its constant records (qconst_tiled): [strip][group][48 bytes]
+    const char* qconst;           // its constant records (qconst_tiled): [strip][group][48 / 64 bytes]
     const void* bias;
-    const void* x;                // [M][K] (act-order layers: permuted in natural order of the re-sequenced rows by the pre-pass)
     void* out;
-    int M, K, N;
+    int N, strips;                // out_features, N / 16
+};
+struct RowsParams {
+    RowsSeg seg[4];
+    int sg_end[4];                // strip groups up to and including layer i (unused entries: INT_MAX)
+    const void* x;                // [M][K] (act-order layers: permuted in natural order of the re-sequenced rows by the pre-pass)
+    int M, K;
     int chunks;                   // K / 128
     int groups;
     int gshift;                   // group_size >= 128: group of chunk c = c >> gshift (31: one group)
-    int strips;                   // N / 16
     int npm;                      // row tiles of 16 RB rows
-    int nsg;                      // groups of S strips
+    int nsg;                      // strip groups of all layers
     int cpw;                      // chunks per wave (the last waves may run short or empty)
 };
 
@@ -151,8 +156,13 @@ __global__ void __launch_bounds__(RB == 2 ? 512 : 1024) gemm_rows_kernel(RowsPar
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
     const int Lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int pm = Lb % p.npm, sg = Lb / p.npm;              // consecutive workgroups (one XCD): the same strips, the next rows
-    const int m0 = pm * R, s0 = sg * S;
+    const int pm = Lb % p.npm, sgi = Lb / p.npm;             // consecutive workgroups (one XCD): the same strips, the next rows
+    const int li = (sgi >= p.sg_end[0]) + (sgi >= p.sg_end[1]) + (sgi >= p.sg_end[2]);      // the layer this strip group belongs to
+    const RowsSeg& Ls = p.seg[li];
+    const int m0 = pm * R, s0 = (sgi - (li ? p.sg_end[li - 1] : 0)) * S;
+    const int n_strips = Ls.strips, n_out = Ls.N;
+    const char* const qw_base = (const char*)Ls.qweight;
+    const char* const qc_base = Ls.qconst;
     const int r = lane & 15, g = lane >> 4;
     char* const xbuf = smem + (size_t)wave * XBUFS * XB;
     const unsigned xbuf_lds = lds_addr_of(xbuf);
@@ -191,12 +201,12 @@ __global__ void __launch_bounds__(RB == 2 ? 512 : 1024) gemm_rows_kernel(RowsPar
     auto issue_w = [&](int c, Buf& B) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const int strip = min(s0 + s, p.strips - 1);
+            const int strip = min(s0 + s, n_strips - 1);
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
-                const char* wsrc = (const char*)p.qweight + ((size_t)strip * (p.chunks * NH) + (c * NH + h)) * WCH;
+                const char* wsrc = qw_base + ((size_t)strip * (p.chunks * NH) + (c * NH + h)) * WCH;
                 const int grp = GM == 0 ? min(c >> p.gshift, p.groups - 1) : (BITS == 8 ? (GM == 1 ? 2 * c + h : 4 * c + 2 * h) : (GM == 1 ? 2 * c : 4 * c));
-                const char* csrc = p.qconst + ((size_t)strip * p.groups + grp) * REC;
+                const char* csrc = qc_base + ((size_t)strip * p.groups + grp) * REC;
                 if constexpr (BITS == 3) asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(B.wq[s][h]) : "v"(wlane), "s"(wsrc) : "memory");
                 else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B.wq[s][h]) : "v"(wlane), "s"(wsrc) : "memory");
                 asm volatile("global_load_ushort %0, %1, %2" : "=v"(B.cs[s][h]) : "v"(slane), "s"(csrc) : "memory");
@@ -302,13 +312,13 @@ __global__ void __launch_bounds__(RB == 2 ? 512 : 1024) gemm_rows_kernel(RowsPar
                 if (w0 + j < nw) v += t[j];
         }
         const int strip = s0 + s;
-        if (strip >= p.strips) continue;
+        if (strip >= n_strips) continue;
         const int n = strip * 16 + (l & 15);
-        const float bv = p.bias ? DType<T>::to_f32(((const T*)p.bias)[n]) : 0.f;
+        const float bv = Ls.bias ? DType<T>::to_f32(((const T*)Ls.bias)[n]) : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                          // C/D layout of the 16x16 MFMA: row = 4 (lane >> 4) + i, column = lane & 15
             const int m = m0 + 16 * rb + 4 * (l >> 4) + i;
-            if (m < p.M) ((T*)p.out)[(size_t)m * p.N + n] = DType<T>::from_f32(v[i] + bv);
+            if (m < p.M) ((T*)Ls.out)[(size_t)m * n_out + n] = DType<T>::from_f32(v[i] + bv);
         }
     }
 }

@@ -60,6 +60,10 @@ bool rows_ok(const gptq_layer_t& L, int M);
 bool rows_pays(const gptq_layer_t& L, int M);
 RowsPlan plan_rows(const gptq_layer_t& L, int M, const gptq_tuning_t* tune);
 hipError_t launch_gemm_rows(const gptq_layer_t& L, const RowsPlan& pl, const void* x, void* out, int M, hipStream_t st);
+bool rows_multi_ok(const gptq_layer_t* const* Ls, int n, int M);      // 1 .. 4 layers that read the same x in ONE launch (gptq_forward_multi)
+bool rows_multi_pays(const gptq_layer_t* const* Ls, int n, int M);
+RowsPlan plan_rows_multi(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t* tune);
+hipError_t launch_gemm_rows_multi(const gptq_layer_t* const* Ls, int n, const RowsPlan& pl, const void* x, void* const* outs, int M, hipStream_t st);
 hipError_t init_gemm_rows_device();
 
 struct GemmPlan {

@@ -76,3 +76,47 @@ def test_rows_forced_every_output(case, bits, dtype):
             yh = q(hot, tuning=t)
         q._layer.bias = saved
         assert torch.equal(yh, W[(rows * 37 + 5) % K]), f"one-hot rows are not the exact dequantised weight rows (RB={rb} S={s})"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("bits,gs", [(4, 128), (3, 32), (8, 64)])
+@pytest.mark.parametrize("act", [False, True], ids=["seq", "act"])
+def test_rows_several_layers_in_one_launch(bits, gs, act, dtype):
+    """gptq_forward_multi at 5 .. 64 rows: the strip groups of q|k|v (and of a [gate, up] pair of unequal widths) in ONE launch of the exchange-free kernel;
+    act-order layers of one activation order read one permuted x.  Every output of every layer against the oracle product, repeat calls bit-identical, and the
+    workspace query says what the path needs: nothing, or the header + the permuted x."""
+    import ctypes
+    from autogptq_amd.qlinear_mi355x import forward_multi
+    t = _lib.GptqTuning()                                     # forced (lab knob 50): the planner's own rule takes only launches of 1024+ strips at 24 .. 64 rows
+    t.path, t.reserved[_lib.LAB.GEMM_VARIANT] = 3, _lib.LAB.VARIANT_ROWS_ON
+    K = 1024
+    for widths in ((1024, 1024, 1024), (1536, 1024)):
+        qs, Ws, bs = [], [], []
+        g0 = None
+        for i, N in enumerate(widths):
+            Lq = O.random_quant_layer(K, N, bits, gs, act_order=act, seed=7 * N + i + bits, bias=True, dtype=dtype)
+            if act:
+                g0 = Lq["g_idx"] if g0 is None else g0
+                Lq["g_idx"] = g0.clone()                      # one activation order for the group, as GPTQ produces q / k / v
+            q = QuantLinear(bits, gs, K, N, True, weight_dtype=dtype)
+            q.qweight, q.qzeros, q.scales, q.g_idx, q.bias = Lq["qweight"], Lq["qzeros"], Lq["scales"], Lq["g_idx"], Lq["bias"]
+            q = q.to(DEV)
+            q.post_init()
+            mode = O.ZERO_NOWRAP if q.resolved_zero_mode() == 1 else O.ZERO_WRAP
+            qs.append(q)
+            Ws.append(O.dequantize(Lq["qweight"], Lq["qzeros"], Lq["scales"], Lq["g_idx"], bits, mode).to(DEV))
+            bs.append(Lq["bias"].to(DEV))
+        for M in (5, 16, 33, 64):
+            x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype).to(DEV)
+            with torch.no_grad():
+                ys, ys2 = forward_multi(qs, x, t), forward_multi(qs, x, t)
+            arr = (ctypes.POINTER(_lib.GptqLayer) * len(qs))(*[ctypes.pointer(q._layer) for q in qs])
+            need = int(_lib.load().gptq_workspace_bytes_multi_ex(arr, len(qs), M, ctypes.byref(t)))
+            assert need == (65536 + (M * K * 2 + 255) // 256 * 256 if act else 0), need          # = the exchange-free kernel took the launch
+            rtol = 1e-3 if dtype == torch.float16 else 8e-3
+            for y, y2, W, b in zip(ys, ys2, Ws, bs):
+                assert torch.equal(y, y2), "not bit-reproducible"
+                ref = x.double() @ W.double() + b.double()
+                scale = float(ref.abs().max())
+                bad = (y.double() - ref).abs() > rtol * scale + rtol * ref.abs()
+                assert not bool(bad.any()), f"int{bits} g{gs} widths={widths} M={M} act={act} {dtype}: {int(bad.sum())}/{bad.numel()} outputs out of tolerance"
