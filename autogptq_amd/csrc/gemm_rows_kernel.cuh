@@ -145,7 +145,9 @@ template <typename T> struct DeqSel<T, 8> { typedef Deq1_8<T> type; };
 // GM: 0 = group_size a multiple of 128 (one group per chunk), 1 = 64 (k-slots 0, 1 | 2, 3), 2 = 32 (one group per k-slot)
 // BITS = 8: the copy's chunks are 64 deep (a lane = 16 k of one column): a 128-deep x chunk takes two of them, MFMA step w reads words 2 (w & 1), + 1 of
 // half w >> 1, and the constants are loaded per half (group modes: 128-multiples, 64 = one group per half, 32 = k-slots 0, 1 | 2, 3 of each half)
-// Two x buffers per wave in LDS: the next chunk's rows are in flight under this chunk's MFMAs.  (One buffer and twice the waves: no faster, tools/rows_ab.py.)
+// Two x buffers per wave in LDS: the next chunk's rows are in flight under this chunk's MFMAs.  (One buffer and twice the waves: no faster; TWO chunks of x in
+// flight per wave -- chunk c + 2 DMA'd into the buffer whose fragments have just gone to registers: parity-green and 3 - 8 % SLOWER in a same-session A/B of the
+// two libraries: the pull is not bound by bytes in flight.  tools/rows_ab.py, profiles/r05_rows_ab.log.)
 template <typename T, int BITS, int RB, int S, int GM>
 __global__ void __launch_bounds__(RB == 2 ? 512 : 1024) gemm_rows_kernel(RowsParams p) {
     constexpr int XBUFS = 2;
