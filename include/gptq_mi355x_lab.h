@@ -2,7 +2,10 @@
  *
  * NOT part of the drop-in boundary: a reference-side binding passes tuning = NULL.  These switches exist for the measurement tools under tools/ (sweeps,
  * interleaved A/B runs, ablations) and for the forced-geometry grids of the test suite, which pin every kernel the planner can choose.  A slot means
- * what the kernel family selected by gptq_tuning_t.path says it means; 0 is always "the planner's value". */
+ * what the kernel family selected by gptq_tuning_t.path says it means; 0 is always "the planner's value".
+ *
+ * One switch is an ENVIRONMENT variable (read once per process): GPTQ_LAB_NO_ROWS=1 -- the planner as it was before csrc/gemm_rows.hip (the exchange-free
+ * batched-decode kernel), for old-default-against-new-default runs with tuning = NULL (tools/session_r05_rows2.sh, tools/rows_multi_ab.py). */
 #ifndef GPTQ_MI355X_LAB_H
 #define GPTQ_MI355X_LAB_H
 
