@@ -4,14 +4,17 @@
 
 namespace gptq {
 
+hipError_t init_gemm_rows_b3_device();                        // gemm_rows_b3.hip
+hipError_t launch_gemm_rows_b3(int dtype, int gm, const RowsPlan& pl, const rowsk::RowsParams& p, hipStream_t st);
+
 hipError_t init_gemm_rows_b38_device() {
-    hipError_t e = rows_grant_bits<3>();
+    hipError_t e = init_gemm_rows_b3_device();
     if (e == hipSuccess) e = rows_grant_bits<8>();
     return e;
 }
 
 hipError_t launch_gemm_rows_b38(int bits, int dtype, int gm, const RowsPlan& pl, const rowsk::RowsParams& p, hipStream_t st) {
-    if (bits == 3) return rows_launch_bits<3>(dtype, gm, pl, p, st);
+    if (bits == 3) return launch_gemm_rows_b3(dtype, gm, pl, p, st);
     if (bits == 8) return rows_launch_bits<8>(dtype, gm, pl, p, st);
     return hipErrorInvalidValue;
 }
