@@ -193,7 +193,20 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
     // x inside the K loop -- profiles/r04_tiled_sweep_bf16_v*.log.)
     // The conversion is done by every workgroup for its whole K slice: at 3 - 4 rows it costs what converting the weights costs, so those keep the bf16
     // matrix core (XC false).
-    constexpr bool XC = BF && MT <= 2;
+    // Round 5, 4-bit bf16 layers at 1 - 2 rows (XS, instead of XC): neither operand is converted.  (q >> 4 i) & 0x000f000f OR-ed with the bf16 pattern of 128 IS the bf16 pair
+    // (128 + w_k, 128 + w_k+1) -- 7 VALU per packed word where the fp16 route takes 13 (+ 12 to turn the pairs into bf16 at 3 - 4 rows) -- raw x goes to the bf16
+    // matrix core, and the bias is taken out of the fp32 sum of every run: sum x (128 + w) - (128 + z) sum x = sum x (w - z), with the run sums of x (xe[run][row],
+    // fp32) formed ONCE per workgroup behind the staging barrier (a read-only pass: cheaper than the block-floating rewrite).  Products are exact in fp32; the
+    // cancellation costs log2(143 / 8) ~ 4 of the fp32 sum's 24 bits, far below bf16's 8; a one-hot row still returns (128 + w) - (128 + z) = w - z exactly.
+    // Same-session A/B against the round-4 forms (tools/lab/tiled_noxs.sh, profiles/r05_bf16_vs_f16.log; bf16 behind fp16): 1 row 6 - 13 % -> 2 - 7 %, 2 rows
+    // 11 - 27 % -> 6 - 17 %; at 3 - 4 rows the per-workgroup pass over x costs more than converting the weight pairs does (13 - 48 % -> 19 - 75 %): those keep
+    // the bf16 matrix core with converted weights.
+#ifdef GPTQ_TILED_NO_XS                                                            // lab: the round-4 bf16 forms (A/B build: tools/lab/tiled_noxs.sh)
+    constexpr bool XS = false;
+#else
+    constexpr bool XS = BF && BITS == 4 && MT <= 2;
+#endif
+    constexpr bool XC = BF && MT <= 2 && !XS;
     using MM = std::conditional_t<XC, f16, T>;                                    // the matrix core's operand type
     constexpr int ES = MT * 16 + 4;
     float* const xe = red + W * ES;                                               // [runs of the slice][4 rows] inverse factors (bf16 layers only; planned for)
@@ -230,6 +243,24 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
         }
         __syncthreads();
     };
+    auto x_sums = [&]() {                                                         // XS: xe[run][row] = the fp32 sum of the run's x; one thread = one 16-byte piece, the NX pieces of a run in adjacent lanes
+        const int prow = (kend - kbeg) >> 3, total = prow * MT;
+        for (int i0 = 0; i0 < total; i0 += W * 64) {                             // uniform trip count: the shuffles below need every lane
+            const int idx = i0 + tid;
+            const bool ok = idx < total;
+            int m = 0, pc = ok ? idx : 0;
+            if constexpr (MT > 1) { m = pc / prow; pc -= m * prow; }
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = *(const u32x4*)(xs + (size_t)m * xstride + (size_t)pc * 16);
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sm += __builtin_bit_cast(float, v[i] << 16) + __builtin_bit_cast(float, v[i] & 0xffff0000u);
+            sm += __shfl_xor(sm, 1, 64);
+            if constexpr (NX == 4) sm += __shfl_xor(sm, 2, 64);
+            if (ok && (pc & (NX - 1)) == 0) xe[(pc / NX) * 4 + m] = sm;
+        }
+        __syncthreads();
+    };
     const char* const xl = xs + (size_t)min(lane & 3, MT - 1) * xstride + kb * (KPL * 2);    // A operand: lane i of a 4-lane group carries x row i
     const char* const xl2 = xs + (size_t)min(4 + (lane & 3), MT - 1) * xstride + kb * (KPL * 2);   // MT = 8: rows 4..7, a second matrix-core step per decoded pair
     float acc[MT];
@@ -259,6 +290,7 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
             }
             __syncthreads();
             if constexpr (XC) x_to_f16();
+            if constexpr (XS) x_sums();
             staged = true;
         }
 #pragma unroll
@@ -287,7 +319,16 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
                 accg = Mma4<MM>::run(u32x2{xa[pc][hf * 2], xa[pc][hf * 2 + 1]}, u32x2{b0, b1}, accg);
                 if constexpr (MT > 4) accg2 = Mma4<MM>::run(u32x2{xb[pc][hf * 2], xb[pc][hf * 2 + 1]}, u32x2{b0, b1}, accg2);
             };
-            if constexpr (BITS == 4) {
+            if constexpr (BITS == 4 && XS) {
+                unsigned magicb;
+                asm("v_mov_b32 %0, 0x43004300" : "=v"(magicb));                   // bf16 128.0 twice: its 7 mantissa bits take a 4-bit field with an ulp of 1
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned qw = qv[w];
+                    mm(w, 0, (qw & m_lo) | magicb, ((qw >> 4) & m_lo) | magicb);            // (k0, k1) (k2, k3): stored nibbles 0 | 4, 1 | 5
+                    mm(w, 1, ((qw >> 8) & m_lo) | magicb, ((qw >> 12) & m_lo) | magicb);    // (k4, k5) (k6, k7)
+                }
+            } else if constexpr (BITS == 4) {
                 const f16x2 c2 = c1 + k960;                                       // -(64 + z)
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
@@ -326,7 +367,12 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
                 for (int i = 0; i < 8; ++i) mm(i >> 1, i & 1, pr[2 * i], pr[2 * i + 1]);
             }
             const float sc = DType<T>::to_f32(__builtin_bit_cast(T, sraw));
-            if constexpr (XC) {
+            if constexpr (XS) {
+                const float* const xv = xe + ((cc - cb) * 4 + kb) * 4;           // the run's sums of x, one per row
+                const float zc = (float)(128u + z);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = live ? fmaf(sc, fmaf(-zc, xv[m], accg[m]), acc[m]) : acc[m];
+            } else if constexpr (XC) {
                 const float* const xi = xe + ((cc - cb) * 4 + kb) * 4;           // the run's inverse block factors, one per row
 #pragma unroll
                 for (int m = 0; m < MT; ++m) acc[m] = live ? fmaf(sc * xi[m], accg[m], acc[m]) : acc[m];
