@@ -42,6 +42,8 @@ bool rows_ok(const gptq_layer_t& L, int M) {
     return M >= 1 && M <= 1024;
 }
 
+RowsPlan plan_rows(const gptq_layer_t& L, int M, const gptq_tuning_t* tune);
+
 // The planner's measured preference (tools/rows_ab.py against the default plan, profiles/r05_rows_ab.log; us per layer call, default -> this kernel):
 //   4096^2      M = 5 / 8 / 16 / 32 / 64 / 96 / 128:  7.1 / 7.3 / 7.7 / 11.1 / 11.9 / 13.2 / 13.2  ->  5.5 / 5.6 / 5.8 / 6.9 / 8.2 / 10.8 / 11.0
 //   4096x11008                                        11.1 / 11.0 / 11.2 / 15.1 / 21.6 / 25.1 / 26.6  ->  8.8 / 8.8 / 8.9 / 11.3 / 14.2 / 23.4 / 25.0
@@ -55,8 +57,16 @@ bool rows_pays(const gptq_layer_t& L, int M) {
     static const bool lab_off = getenv("GPTQ_LAB_NO_ROWS") != nullptr;      // lab (tools/session_r05_rows2.sh): the planner as it was before this kernel
     if (lab_off || !rows_ok(L, M)) return false;
     const size_t kn = (size_t)L.K * L.N;
-    if (M < 5 || M > 128 || L.K < 1024 || L.N < 1024 || kn > ((size_t)64 << 20)) return false;
-    return M <= 64 || (kn <= (size_t)46000000 && L.N <= 8192);
+    if (M < 5 || M > 256 || L.K < 1024 || L.N < 1024 || kn > ((size_t)64 << 20)) return false;
+    if (M <= 64) return true;
+    if (kn > (size_t)46000000 || L.N > 8192) return false;
+    // 129 .. 256 rows (short prompts): the 64-row form (4 bits: gemm_rows64_kernel, half the dequant replication) -- 4096^2 M = 160 / 192 / 256 17.0 / 18.5 / 18.8 ->
+    // 14.9 - 16.6 us, 11008x4096 38.5 / 38.7 / 39.5 -> 29.4 - 34.2; 4096x11008 1.0x, 320+ rows 0.6 - 1.06x (the tiled / stream-K prefill kernels keep those)
+    // (only as ONE round of workgroups: 5120^2 at 224 / 256 rows = 320 workgroups 28.5 / 28.9 -> 29.9 / 30.2; 2048^2 17.3 - 20.1 -> 7.0 - 8.4, 5120^2 up to 192 rows 24 -> 19.5)
+    if (M <= 128) return true;
+    if (L.bits != 4) return false;
+    const RowsPlan rp = plan_rows(L, M, nullptr);
+    return rp.ok && (long)rp.npm * rp.nsg <= 256;
 }
 
 // strips_of: the strip counts of the n layers of one launch (a strip group never straddles two layers); nullptr: the one layer L
@@ -66,21 +76,21 @@ static RowsPlan plan_rows_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     const int one_layer = L.N / 16, chunks = L.K / 128;
     if (!strips_of) { strips_of = &one_layer; n = 1; }
     auto groups_of = [&](int cs) { long g = 0; for (int i = 0; i < n; ++i) g += (strips_of[i] + cs - 1) / cs; return g; };
-    // forced geometry (lab): tuning.path = 3, reserved[0] = RB (1 / 2), reserved[1] = S
+    // forced geometry (lab): tuning.path = 3, reserved[0] = RB (1 / 2; 4 = the 64-row form, 4 bits), reserved[1] = S
     int rb = 0, s = 0;
-    if (tune && tune->path == 3 && (tune->reserved[0] == 1 || tune->reserved[0] == 2) && tune->reserved[1] >= 1 && tune->reserved[1] <= 6) {
+    if (tune && tune->path == 3 && (tune->reserved[0] == 1 || tune->reserved[0] == 2 || (tune->reserved[0] == 4 && L.bits == 4)) && tune->reserved[1] >= 1 && tune->reserved[1] <= 6) {
         rb = tune->reserved[0];
         s = tune->reserved[1];
-        if (s == 5 || (s == 6 && (rb == 1 || L.bits != 4))) s = 0;
+        if (s == 5 || (s == 6 && (rb != 2 || L.bits != 4))) s = 0;
     }
     if (!rb || !s) {
         // cost model, us: the workgroups of one round pull K (32 RB + 8 S) bytes each at ~110 GB/s per CU; a SIMD dequantises S strips x (K / 128) chunks x 4
         // words x ~17 issue slots (13 VALU + the MFMAs and LDS reads of its row blocks) for each of the waves it hosts
         double best = 1e30;
-        for (int crb = 1; crb <= 2; ++crb) {
-            if (crb == 2 && M <= 16) continue;
+        for (int crb = 1; crb <= 4; crb *= 2) {
+            if ((crb == 2 && M <= 16) || (crb == 4 && (M <= 128 || L.bits != 4))) continue;      // the 64-row form: no faster up to 128 rows (profiles/r05_rows_ab.log)
             for (int cs : {1, 2, 3, 4, 6}) {
-                if (cs == 6 && (crb == 1 || L.bits != 4)) continue;
+                if (cs == 6 && (crb != 2 || L.bits != 4)) continue;
                 if (cs == 4 && crb == 1 && L.bits == 8) continue;          // (spills at 128 registers)
                 const long wgs = (long)((M + 16 * crb - 1) / (16 * crb)) * groups_of(cs);
                 const long rounds = (wgs + 255) / 256;
@@ -95,12 +105,12 @@ static RowsPlan plan_rows_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     }
     pl.rb = rb; pl.s = s;
     pl.xbufs = 2;
-    pl.waves = 16 / rb;                                        // 128 KiB of x buffers: 2 x RB x 4 KiB per wave
+    pl.waves = rb == 4 ? 8 : 16 / rb;                          // 128 KiB of x buffers: 2 x RB x 4 KiB per wave (64 rows: 2 x 8 KiB half chunks)
     if (pl.waves > chunks) pl.waves = chunks;
     pl.cpw = (chunks + pl.waves - 1) / pl.waves;
     pl.npm = (M + 16 * rb - 1) / (16 * rb);
     pl.nsg = (int)groups_of(s);
-    pl.lds_bytes = (size_t)pl.waves * pl.xbufs * rb * 4096;
+    pl.lds_bytes = rb == 4 ? (size_t)pl.waves * 2 * 8192 : (size_t)pl.waves * pl.xbufs * rb * 4096;
     const size_t red = (size_t)pl.waves * rb * s * 1024;        // the cross-wave sum reuses the x buffers
     if (red > pl.lds_bytes) pl.lds_bytes = red;
     pl.ok = true;

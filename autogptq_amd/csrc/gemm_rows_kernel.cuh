@@ -325,6 +325,177 @@ __global__ void __launch_bounds__(RB == 2 ? 512 : 1024) gemm_rows_kernel(RowsPar
     }
 }
 
+// ---- 64 rows per workgroup (4 bits) -------------------------------------------------------------------------------------------------------------
+// The x an XCD's L2 hands out depends only on the number of strip groups (each pulls all M rows), the dequant work on the number of ROW TILES (each
+// dequantises its strips again).  Up to 128 rows the 32-row form above is bound by the former (a 64-row form measured the same); from ~160 rows the row
+// tiles multiply and this form -- 4 row blocks per workgroup, half the replication -- takes over from the older kernels up to where the stream-K prefill
+// kernel starts.  64 rows x 128 k of x are 16 KiB -- two buffers per wave would leave LDS for 4 waves -- so a wave stages HALF chunks (64 k: 8 KiB, two
+// buffers) and the k order changes with it: half h of a chunk is k-slots 2 h, 2 h + 1; MFMA step w of the half gives lane (r, g) the
+// k = 32 (2 h + (g >> 1)) + 8 (2 (g & 1) + w) + 0..7 -- on the x side piece 2 g + w of the row's 128-byte half segment (contiguous: 8 rows per DMA
+// instruction, a quad inside one line), on the weight side words 2 (g & 1) + {0, 1} of k-slot 2 h + (g >> 1) of the lane's column: ONE 8-byte load per half.
+// The fragments of a half go to registers first; the SAME buffer then takes the next chunk's half under this half's MFMAs.
+template <typename T, int S, int GM>
+__global__ void __launch_bounds__(512) gemm_rows64_kernel(RowsParams p) {
+    constexpr int RB = 4, R = 64, HB = R * 128, NDMA = 8, NW = 6 * S;      // bytes of one x half-chunk, its DMA instructions, a CHUNK's weight + constant loads
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+    const int Lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int pm = Lb % p.npm, sgi = Lb / p.npm;
+    const int li = (sgi >= p.sg_end[0]) + (sgi >= p.sg_end[1]) + (sgi >= p.sg_end[2]);
+    const RowsSeg& Ls = p.seg[li];
+    const int m0 = pm * R, s0 = (sgi - (li ? p.sg_end[li - 1] : 0)) * S;
+    const int n_strips = Ls.strips, n_out = Ls.N;
+    const char* const qw_base = (const char*)Ls.qweight;
+    const char* const qc_base = Ls.qconst;
+    const int r = lane & 15, g = lane >> 4;
+    char* const xbuf = smem + (size_t)wave * 2 * HB;
+    const unsigned xbuf_lds = lds_addr_of(xbuf);
+
+    // x DMA i of a half (8 rows x 128 bytes): lane (row 8 i + (lane >> 3), slot lane & 7) fetches piece slot ^ ((row >> 1) & 7): LDS slot s of row R holds piece
+    // s ^ ((R >> 1) & 7), so the 16 rows of a fragment read (one piece each, 128-byte pitch) fall on all 64 banks
+    unsigned xoff[NDMA];
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int row = 8 * i + (lane >> 3);
+        const int m = min(m0 + row, p.M - 1);
+        xoff[i] = (unsigned)m * (unsigned)p.K * 2u + (unsigned)((((lane & 7) ^ ((row >> 1) & 7))) * 16);
+    }
+    unsigned aoff[2];                                          // fragment of row block rb, step w: piece 2 g + w of row 16 rb + r -> slot (2 g + w) ^ ((r >> 1) & 7)   (16 rb >> 1 is a multiple of 8)
+#pragma unroll
+    for (int w = 0; w < 2; ++w) aoff[w] = (unsigned)(r * 128 + (((2 * g + w) ^ ((r >> 1) & 7)) * 16));
+    const unsigned wlane = (unsigned)(g >> 1) * 256u + (unsigned)r * 16u + (unsigned)(g & 1) * 8u;      // + 512 h: words 2 (g & 1), + 1 of k-slot 2 h + (g >> 1)
+    const unsigned glane = GM == 2 ? (unsigned)(g >> 1) * 48u : 0u;      // 32-wide groups: group 4 c + 2 h + (g >> 1); 64-wide: 2 c + h; 128-multiples: c >> gshift
+    const unsigned slane = glane + (unsigned)r * 2u, zlane = glane + 32u + (unsigned)r;
+    const int c0 = wave * p.cpw, c1 = min(c0 + p.cpw, p.chunks);
+
+    constexpr int DW = S <= 3 ? 4 : 2;
+    struct Buf { u32x2 wq[S][2]; unsigned cs[S][2], cz[S][2]; };
+    Buf q[DW];
+    auto issue_w = [&](int c, Buf& B) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int strip = min(s0 + s, n_strips - 1);
+            const char* wsrc = qw_base + ((size_t)strip * p.chunks + c) * 1024;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int grp = GM == 0 ? min(c >> p.gshift, p.groups - 1) : (GM == 1 ? 2 * c + h : 4 * c + 2 * h);
+                const char* csrc = qc_base + ((size_t)strip * p.groups + grp) * 48;
+                if (h == 0) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(B.wq[s][0]) : "v"(wlane), "s"(wsrc) : "memory");
+                else asm volatile("global_load_dwordx2 %0, %1, %2 offset:512" : "=v"(B.wq[s][1]) : "v"(wlane), "s"(wsrc) : "memory");
+                asm volatile("global_load_ushort %0, %1, %2" : "=v"(B.cs[s][h]) : "v"(slane), "s"(csrc) : "memory");
+                asm volatile("global_load_ubyte %0, %1, %2" : "=v"(B.cz[s][h]) : "v"(zlane), "s"(csrc) : "memory");
+            }
+        }
+    };
+    auto issue_x = [&](int c, int h, int i0, int i1) __attribute__((always_inline)) {      // DMAs [i0, i1) of half h of chunk c into buffer h
+        const char* xsrc = (const char*)p.x + (size_t)c * 256 + (size_t)h * 128;
+        const unsigned l0 = __builtin_amdgcn_readfirstlane(xbuf_lds + (unsigned)(h * HB));
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+            const unsigned xo = xoff[i];
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l0 + (unsigned)(i * 1024)), "v"(xo), "s"(xsrc) : "memory");
+        }
+    };
+    auto claim = [&](Buf& B) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(B.wq[s][h]), "+v"(B.cs[s][h]), "+v"(B.cz[s][h])::"memory");
+    };
+
+    f32x4 acc[RB][S];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[rb][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // half h of the chunk in buffer h; the same half of chunk cn follows it into the buffer under the MFMAs (its fragments are in registers by then)
+    auto compute = [&](const Buf& B, int h, int cn, bool has_x) __attribute__((always_inline)) {
+        Deq1<T> dq[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) dq[s].setup(B.cs[s][h], B.cz[s][h]);
+        const char* xb = xbuf + h * HB;
+        u32x4 a[2][RB];
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) a[w][rb] = *(const u32x4*)(xb + rb * 2048 + aoff[w]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the buffer is free from here on
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const u32x4 bq = dq[s].frag(B.wq[s][h][w]);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) acc[rb][s] = Mma16<T>::run(a[w][rb], bq, acc[rb][s]);
+            }
+            if (has_x) issue_x(cn, h, w * (NDMA / 2), (w + 1) * (NDMA / 2));
+        }
+    };
+    auto wait_vm = [&](bool dma, bool wts) __attribute__((always_inline)) {
+        if (dma && wts) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA + NW) : "memory");
+        else if (dma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else if (wts) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    // VMEM queue of a wave, oldest first: W(c0 .. c0 + DW - 1), x(c0, 0), x(c0, 1) | x(c0 + 1, 0) under half 0 of c0, x(c0 + 1, 1) under half 1, W(c0 + DW) | ...
+    //   half 0 of chunk c needs x(c, 0) (W(c) is older: DW >= 2); behind it: x(c, 1), then W(c - 1 + DW) (end of chunk c - 1, not for c = c0)
+    //   half 1 needs x(c, 1); behind it: W(c - 1 + DW), x(c + 1, 0) (issued under half 0 of this chunk)
+    if (c0 < c1) {
+#pragma unroll
+        for (int j = 0; j < DW; ++j)
+            if (c0 + j < c1) issue_w(c0 + j, q[j]);
+        issue_x(c0, 0, 0, NDMA);
+        issue_x(c0, 1, 0, NDMA);
+        for (int cb = c0; cb < c1; cb += DW) {
+#pragma unroll
+            for (int j = 0; j < DW; ++j) {
+                const int c = cb + j;
+                if (c >= c1) break;
+                const bool has_w = c > c0 && c - 1 + DW < c1, more = c + 1 < c1;
+                wait_vm(true, has_w);                          // x(c, 1) is always behind x(c, 0)
+                claim(q[j]);
+                compute(q[j], 0, c + 1, more);
+                wait_vm(more, has_w);
+                compute(q[j], 1, c + 1, more);
+                if (c + DW < c1) issue_w(c + DW, q[j]);
+            }
+        }
+    }
+
+    __syncthreads();
+    float* const red = (float*)smem;                           // [wave][rb][s][lane] float4
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int s = 0; s < S; ++s) *(f32x4*)(red + ((size_t)((wave * RB + rb) * S + s) * 64 + lane) * 4) = acc[rb][s];
+    __syncthreads();
+    for (int item = tid; item < RB * S * 64; item += (int)blockDim.x) {
+        const int l = item & 63, t = item >> 6, s = t % S, rb = t / S;
+        f32x4 v = *(const f32x4*)(red + ((size_t)((0 * RB + rb) * S + s) * 64 + l) * 4);
+        for (int w0 = 1; w0 < nw; w0 += 4) {
+            f32x4 tt[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tt[j] = *(const f32x4*)(red + ((size_t)((min(w0 + j, nw - 1) * RB + rb) * S + s) * 64 + l) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (w0 + j < nw) v += tt[j];
+        }
+        const int strip = s0 + s;
+        if (strip >= n_strips) continue;
+        const int n = strip * 16 + (l & 15);
+        const float bv = Ls.bias ? DType<T>::to_f32(((const T*)Ls.bias)[n]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 16 * rb + 4 * (l >> 4) + i;
+            if (m < p.M) ((T*)Ls.out)[(size_t)m * n_out + n] = DType<T>::from_f32(v[i] + bv);
+        }
+    }
+}
+
 }  // namespace rowsk
 
 // ---- instantiation ladder of one bit width (grant the dynamic LDS, launch) ----------------------------------------------------------------------
@@ -351,10 +522,19 @@ static hipError_t rows_grant_t() {
     if (e == hipSuccess) e = rows_grant_s<T, BITS, 2, 2>();
     return e;
 }
+template <typename T, int GM> static hipError_t rows64_grant();
 template <int BITS>
 static hipError_t rows_grant_bits() {
     hipError_t e = rows_grant_t<f16, BITS>();
     if (e == hipSuccess) e = rows_grant_t<bf16, BITS>();
+    if constexpr (BITS == 4) {
+        if (e == hipSuccess) e = rows64_grant<f16, 0>();
+        if (e == hipSuccess) e = rows64_grant<f16, 1>();
+        if (e == hipSuccess) e = rows64_grant<f16, 2>();
+        if (e == hipSuccess) e = rows64_grant<bf16, 0>();
+        if (e == hipSuccess) e = rows64_grant<bf16, 1>();
+        if (e == hipSuccess) e = rows64_grant<bf16, 2>();
+    }
     return e;
 }
 
@@ -374,8 +554,31 @@ static hipError_t rows_launch_s(const RowsPlan& pl, const rowsk::RowsParams& p, 
     }
     return hipGetLastError();
 }
+template <typename T, int GM>
+static hipError_t rows64_launch(const RowsPlan& pl, const rowsk::RowsParams& p, hipStream_t st) {
+    const dim3 grid(pl.npm * pl.nsg), block(pl.waves * 64);
+    switch (pl.s) {
+        case 1: hipLaunchKernelGGL((rowsk::gemm_rows64_kernel<T, 1, GM>), grid, block, pl.lds_bytes, st, p); break;
+        case 2: hipLaunchKernelGGL((rowsk::gemm_rows64_kernel<T, 2, GM>), grid, block, pl.lds_bytes, st, p); break;
+        case 3: hipLaunchKernelGGL((rowsk::gemm_rows64_kernel<T, 3, GM>), grid, block, pl.lds_bytes, st, p); break;
+        case 4: hipLaunchKernelGGL((rowsk::gemm_rows64_kernel<T, 4, GM>), grid, block, pl.lds_bytes, st, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+template <typename T, int GM>
+static hipError_t rows64_grant() {
+    hipError_t e = hipFuncSetAttribute((const void*)rowsk::gemm_rows64_kernel<T, 1, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rowsk::gemm_rows64_kernel<T, 2, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rowsk::gemm_rows64_kernel<T, 3, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rowsk::gemm_rows64_kernel<T, 4, GM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e;
+}
 template <typename T, int BITS, int GM>
 static hipError_t rows_launch_rb(const RowsPlan& pl, const rowsk::RowsParams& p, hipStream_t st) {
+    if constexpr (BITS == 4) {
+        if (pl.rb == 4) return rows64_launch<T, GM>(pl, p, st);
+    }
     return pl.rb == 1 ? rows_launch_s<T, BITS, 1, GM>(pl, p, st) : rows_launch_s<T, BITS, 2, GM>(pl, p, st);
 }
 template <int BITS>

@@ -34,12 +34,12 @@ CASES = [
     (1280, 128, 1280, 48, True, "one group for the whole K, act-order"),
     (11008, 64, 128, 31, False, "86 chunks: uneven chunk ranges per wave"),
 ]
-GEOMS = [(1, 1), (1, 2), (1, 3), (1, 4), (2, 1), (2, 2), (2, 3), (2, 4), (2, 6)]
+GEOMS = [(1, 1), (1, 2), (1, 3), (1, 4), (2, 1), (2, 2), (2, 3), (2, 4), (2, 6), (4, 1), (4, 2), (4, 3), (4, 4)]      # (4, S): the 64-row form (half chunks), 4 bits
 
 
 def _geoms(bits):
     """(RB, S) the library builds per width: 6 strips only at 4 bits; 8 bits: 4 strips only with two row blocks (registers)."""
-    return [(rb, s) for rb, s in GEOMS if not (s == 6 and bits != 4) and not (bits == 8 and rb == 1 and s == 4)]
+    return [(rb, s) for rb, s in GEOMS if not (s == 6 and bits != 4) and not (bits == 8 and rb == 1 and s == 4) and not (rb == 4 and bits != 4)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])

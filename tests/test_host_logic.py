@@ -838,7 +838,7 @@ def test_batched_decode_rows_kernel_rules():
                         d, need = plan(bits, gs, K, N, M, act)
                         assert d["kernel"] == "rows", (bits, gs, K, N, M, act, d)
                         rb, s = int(d["mt"]), int(d["tiles"].split("x")[1])
-                        assert rb in (1, 2) and int(d["tiles"].split("x")[0]) == -(-M // (16 * rb)), d
+                        assert rb in (1, 2) and int(d["tiles"].split("x")[0]) == -(-M // (16 * rb)), d      # (the 64-row form only from 129 rows)
                         per = -(-(N // 16) // s)                      # strips per workgroup
                         assert per in (1, 2, 3, 4, 6) and (per != 6 or (bits == 4 and rb == 2)) and not (bits == 8 and rb == 1 and per == 4), d
                         assert need == (65536 + (M * K * 2 + 255) // 256 * 256 if act else 0), (d, need)      # header + permuted x, or nothing
@@ -847,7 +847,11 @@ def test_batched_decode_rows_kernel_rules():
         assert plan(4, 128, 4096, 11008, M)[0]["kernel"] != "rows" and plan(4, 128, 8192, 8192, M)[0]["kernel"] != "rows"
     for M in (1, 2, 4):
         assert plan(4, 128, 4096, 4096, M)[0]["kernel"] == "strips"
-    assert plan(4, 128, 4096, 4096, 129)[0]["kernel"] != "rows" and plan(4, 128, 4096, 4096, 16, copy=False)[0]["kernel"] != "rows"
+    for M in (129, 192, 256):                                    # short prompts: the 64-row form, 4 bits only
+        d = plan(4, 128, 4096, 4096, M)[0]
+        assert d["kernel"] == "rows" and d["mt"] in ("2", "4"), d
+        assert plan(3, 128, 4096, 4096, M)[0]["kernel"] != "rows" and plan(4, 128, 4096, 11008, M)[0]["kernel"] != "rows"
+    assert plan(4, 128, 4096, 4096, 257)[0]["kernel"] != "rows" and plan(4, 128, 4096, 4096, 16, copy=False)[0]["kernel"] != "rows"
     assert plan(4, 128, 8192, 28672, 16)[0]["kernel"] != "rows" and plan(4, 128, 512, 4096, 16)[0]["kernel"] != "rows"      # several rounds of workgroups / a small layer
     assert plan(2, 128, 4096, 4096, 16, copy=False)[0]["kernel"] != "rows"
     assert plan(4, 96, 4032, 4096, 16)[0]["kernel"] != "rows"                                                             # groups of 96

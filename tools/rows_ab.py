@@ -51,7 +51,7 @@ for shp in a.shapes.split(","):
             for _ in range(a.rounds):
                 best["without"] = min(best.get("without", 1e9), run(ls, x, toff, reps=5))
                 for rb, s in geoms:
-                    if rb == 2 and M <= 16:
+                    if (rb == 2 and M <= 16) or (rb == 4 and M <= 48):
                         continue
                     for xb in map(int, a.xb.split(",")):
                         if not rb and xb != 2:
