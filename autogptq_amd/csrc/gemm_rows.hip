@@ -57,7 +57,7 @@ bool rows_pays(const gptq_layer_t& L, int M) {
     static const bool lab_off = getenv("GPTQ_LAB_NO_ROWS") != nullptr;      // lab (tools/session_r05_rows2.sh): the planner as it was before this kernel
     if (lab_off || !rows_ok(L, M)) return false;
     const size_t kn = (size_t)L.K * L.N;
-    if (M < 5 || M > 256 || L.K < 1024 || L.N < 1024 || kn > ((size_t)64 << 20)) return false;
+    if (M < 5 || M > 512 || L.K < 1024 || L.N < 1024 || kn > ((size_t)64 << 20)) return false;
     if (M <= 64) return true;
     if (kn > (size_t)46000000 || L.N > 8192) return false;
     // 129 .. 256 rows (short prompts): the 64-row form (4 bits: gemm_rows64_kernel, half the dequant replication) -- 4096^2 M = 160 / 192 / 256 17.0 / 18.5 / 18.8 ->
@@ -65,8 +65,11 @@ bool rows_pays(const gptq_layer_t& L, int M) {
     // (only as ONE round of workgroups: 5120^2 at 224 / 256 rows = 320 workgroups 28.5 / 28.9 -> 29.9 / 30.2; 2048^2 17.3 - 20.1 -> 7.0 - 8.4, 5120^2 up to 192 rows 24 -> 19.5)
     if (M <= 128) return true;
     if (L.bits != 4) return false;
+    // Small layers (at most 8 Mi weights), where the tiled kernel has too few tiles: 1.1 - 2.2x up to 512 rows whatever the round count (2048^2 M = 320 .. 512
+    // 22.2 - 23.6 -> 10.2 - 11.9 us, 4096x2048 22.3 - 24.4 -> 15.1 - 17.6, 2048x4096 24.4 - 28.2 -> 18.6 - 21.4, 8192x1024 25.3 - 26.7 -> 16.4 - 20.4, 2560^2 23.8 - 25.4 -> 13.7 - 21.5)
+    if (kn <= ((size_t)8 << 20)) return true;
     const RowsPlan rp = plan_rows(L, M, nullptr);
-    return rp.ok && (long)rp.npm * rp.nsg <= 256;
+    return rp.ok && M <= 256 && (long)rp.npm * rp.nsg <= 256;
 }
 
 // strips_of: the strip counts of the n layers of one launch (a strip group never straddles two layers); nullptr: the one layer L
