@@ -512,6 +512,17 @@ def bench_batched(device, steps):
                                      "plan": _plan_of(ls, K, N, M)}
             del ls, xs
             torch.cuda.empty_cache()
+    # short prompts (a few hundred rows; round 5: the 64-row form of the same kernel where it beats the tiled one): one row count, two shapes
+    for K, N in ((4096, 4096), (11008, 4096)):
+        M = 256
+        n = max(4, -(-(320 << 20) // (K * N // 2)))
+        ls = [("b", K, N, make_layer(K, N, device, seed=7100 + i)) for i in range(n)]
+        xs = {K: (torch.rand(M, K, device=device) - 0.5).half()}
+        per = _time_layers(ls, xs, device, max(3, steps // 2))
+        res[f"short_prompt_M{M}_{K}x{N}"] = {"us": round(per * 1e6, 2), "TFLOP_s": round(2 * M * K * N / per / 1e12, 1), "mfma_frac": round(2 * M * K * N / per / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                              "plan": _plan_of(ls, K, N, M)}
+        del ls, xs
+        torch.cuda.empty_cache()
     return res
 
 
@@ -1015,6 +1026,8 @@ def main():
                 for k, v in bd.items():
                     if isinstance(v, dict) and "frac" in v:
                         byc["batched_decode:" + k] = {"frac": v["frac"], "us": v["us"], "bound": "hbm"}
+                    elif isinstance(v, dict) and "mfma_frac" in v:
+                        byc["batched_decode:" + k] = {"frac": v["mfma_frac"], "us": v["us"], "bound": "mfma"}
             mc = out.get("mlp_call")
             if isinstance(mc, dict):
                 for k, v in mc.items():
