@@ -84,7 +84,7 @@ static RowsPlan plan_rows_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     if (tune && tune->path == 3 && (tune->reserved[0] == 1 || tune->reserved[0] == 2 || (tune->reserved[0] == 4 && L.bits == 4)) && tune->reserved[1] >= 1 && tune->reserved[1] <= 6) {
         rb = tune->reserved[0];
         s = tune->reserved[1];
-        if (s == 5 || (s == 6 && (rb != 2 || L.bits != 4))) s = 0;
+        if (s == 5 || (s == 6 && (rb != 2 || L.bits != 4)) || (s == 4 && rb == 1 && L.bits == 8)) s = 0;      // (forms that are not built, or spill: the asm loads must never be spilled)
     }
     if (!rb || !s) {
         // cost model, us: the workgroups of one round pull K (32 RB + 8 S) bytes each at ~110 GB/s per CU; a SIMD dequantises S strips x (K / 128) chunks x 4
