@@ -62,3 +62,15 @@ def test_hot_kernels_stay_inside_their_register_budget():
         assert (v["spill"] or 0) <= 4 and (v["scratch"] or 0) <= 32, (n, v)
     mid = {n: v for n, v in ks.items() if "gemm_mid_kernel" in n}
     assert mid and all((v["spill"] or 0) == 0 for v in mid.values())
+    # round 5: the stream-K prefill kernel (every packing: 512 registers, no scratch) ...
+    sk = {n: v for n, v in ks.items() if "gemm_wide_sk" in n}
+    assert len(sk) >= 4 + 14, len(sk)                               # <T, G128> x 4 and <T, BITS, GM> x 14
+    for n, v in sk.items():
+        assert (v["vgpr"] or 0) <= 512 and (v["agpr"] or 0) == 256 and (v["spill"] or 0) == 0 and (v["scratch"] or 0) == 0, (n, v)      # (vgpr_count = both halves)
+    # ... and the exchange-free batched-decode kernels: their weight / constant loads are inline asm whose results sit in registers across a hand-counted
+    # s_waitcnt -- a spilled one would be stored before it has landed.  Every form the planner (or the lab knob) can launch is spill-free; the one geometry
+    # that is not (8 bits, one row block, four strips) is refused by plan_rows.
+    rows = {n: v for n, v in ks.items() if "gemm_rows_kernel" in n or "gemm_rows64_kernel" in n}
+    assert len(rows) >= 2 * 3 * (9 + 8 + 8) + 24, len(rows)
+    spilled = {n for n, v in rows.items() if (v["spill"] or 0) or (v["scratch"] or 0)}
+    assert all("gemm_rows_kernel" in n and "Li8ELi1ELi4E" in n for n in spilled), sorted(spilled)[:4]      # <T, 8, 1, 4, GM> only
