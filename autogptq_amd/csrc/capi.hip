@@ -250,7 +250,7 @@ static size_t body_bytes(const gptq_layer_t* L, int M, const gptq_tuning_t* tune
     size_t a = plan_gemv(*L, M, tune).workspace_bytes;
     GemmPlan g = plan_gemm(*L, M, tune);
     size_t b = g.supported ? g.workspace_bytes : 0;
-    if (g.supported && g.rows && want_gemm(L, M, tune)) return b;                 // the exchange-free batched-decode kernel: nothing but the permuted x of act-order layers
+    if (g.supported && (g.rows || g.panel) && want_gemm(L, M, tune)) return b;                 // the exchange-free batched-decode kernel: nothing but the permuted x of act-order layers
     size_t c = 0;
     {
         const gptq_layer_t* one[1] = {L};
@@ -290,6 +290,7 @@ int gptq_init(void) {
     if (e == hipSuccess) e = init_gemv_tiled_device();
     if (e == hipSuccess) e = init_gemm_wide_sk_device();
     if (e == hipSuccess) e = init_gemm_rows_device();
+    if (e == hipSuccess) e = init_gemm_panel_device();
     if (e != hipSuccess) return hip_fail(e, "gptq_init (hipFuncSetAttribute)");
     return GPTQ_OK;
 }
@@ -873,7 +874,7 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
                  sp.u, sp.ksplit, sp.mt, sp.strips_total);
     } else if (want_gemm(&Lc, M, tune)) {
         const GemmPlan g = plan_gemm(Lc, M, tune);
-        const char* kern = g.f32 ? "f32_mfma" : g.rows ? "rows" : g.wsk ? "wide_sk" : g.wide ? (g.wide_tiled ? "wide_copy" : "wide") : g.mid ? "mid" : (g.stream64 ? "stream64" : (g.strip16 ? "strip16" : (g.skinny ? "skinny64" : "tiled")));
+        const char* kern = g.f32 ? "f32_mfma" : g.rows ? "rows" : g.panel ? "panel" : g.wsk ? "wide_sk" : g.wide ? (g.wide_tiled ? "wide_copy" : "wide") : g.mid ? "mid" : (g.stream64 ? "stream64" : (g.strip16 ? "strip16" : (g.skinny ? "skinny64" : "tiled")));
         snprintf(out, out_bytes, "path=gemm kernel=%s mt=%d bk=%d kg=%d ksplit=%d tiles=%dx%d tail=%d tail_slices=%d perm=%d dma=%d waves=%d u=%d epilogue=%s", kern, g.mt, g.bk,
                  g.kg == 2 ? 2 : 1, g.ksplit, g.nbm, g.nbn, g.tail, g.tail ? (1 << g.tail_lg) : 1, g.use_seq ? 1 : 0, (g.glds || g.stream64 || g.mid) ? 1 : 0, g.waves, g.u,
                  unfused_epilogue ? "separate" : "none");

@@ -1938,6 +1938,24 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
             }
         }
     }
+    // 129 .. ~767 rows (and 128 rows on wide layers) of a layer that carries its decode copy: whole-K panels of 64 x 32 nt tiles, no exchange (gemm_panel.hip);
+    // lab knobs 52 / 53 force it on / off
+    {
+        const int knob = tune ? tune->reserved[3] : 0;
+        if (knob == GPTQ_LAB_VARIANT_PANEL_ON || (knob != GPTQ_LAB_VARIANT_PANEL_OFF && (!tune || tune->path != 3 || knob == 0) && force_skinny == 0 && panel_pays(L, M))) {
+            const PanelPlan pp = plan_panel(L, M, knob == GPTQ_LAB_VARIANT_PANEL_ON ? tune : nullptr);
+            if (pp.ok) {
+                pl.panel = true;
+                pl.panelp = pp;
+                pl.xnat = pl.use_seq;
+                pl.mt = pp.mt; pl.bk = 64; pl.bm = 32 * pp.mt; pl.bn = 32 * pp.nt; pl.nbm = pp.nbm; pl.nbn = pp.nbn;
+                pl.waves = pp.kp; pl.u = 2; pl.kg = pp.kp;
+                pl.ksplit = 1; pl.ksteps_total = pl.ksteps_per_split = L.K / 64;
+                pl.workspace_bytes = pl.xperm_bytes;
+                return pl;
+            }
+        }
+    }
     // Measured crossovers (tools/midm_bench.py, us per launch at M = 9/16/32/64):
     //   4096x4096   strips16  8.0/ 9.1/12.3/19.6   skinny64 12.1/12.3/12.7/15.5   tiled 15.5/15.7/17.1/22.6
     //   11008x4096  strips16 17.9/20.1/27.9/47.9   skinny64 23.2/23.1/24.0/27.4   tiled 27.6/28.0/28.8/37.2
@@ -2320,6 +2338,7 @@ hipError_t launch_gemm(const gptq_layer_t& L, const GemmPlan& pl, const void* x,
         return launch_stream64(one, sp, p.x, outs, M, ws_header, p.partial, pl.use_seq ? L.qweight_seq : nullptr, st);
     }
     if (pl.rows) return launch_gemm_rows(L, pl.rowsp, p.x, out, M, st);
+    if (pl.panel) return launch_gemm_panel(L, pl.panelp, p.x, out, M, st);
     if (pl.wsk) return launch_gemm_wide_sk(L, p.x, out, M, ws_header, (char*)workspace + pl.xperm_bytes, st);
     if (pl.wide) return launch_gemm_wide(L, p.qweight, p.x, out, M, pl.use_seq, st, pl.wide_tiled);
     e = (L.dtype == GPTQ_F16) ? launch_t<f16>(L, pl, p, st) : launch_t<bf16>(L, pl, p, st);

@@ -66,8 +66,22 @@ RowsPlan plan_rows_multi(const gptq_layer_t* const* Ls, int n, int M, const gptq
 hipError_t launch_gemm_rows_multi(const gptq_layer_t* const* Ls, int n, const RowsPlan& pl, const void* x, void* const* outs, int M, hipStream_t st);
 hipError_t init_gemm_rows_device();
 
+// gemm_panel.hip: 129 .. ~767 rows from the decode copy, a workgroup = 32 mt rows x 32 nt columns x the whole K (kp waves = K parts), no exchange between workgroups
+struct PanelPlan {
+    bool ok;
+    int mt, nt, kp, nbm, nbn, spw;
+    size_t lds_bytes;
+};
+bool panel_ok(const gptq_layer_t& L, int M);
+bool panel_pays(const gptq_layer_t& L, int M);
+PanelPlan plan_panel(const gptq_layer_t& L, int M, const gptq_tuning_t* tune);
+hipError_t launch_gemm_panel(const gptq_layer_t& L, const PanelPlan& pl, const void* x, void* out, int M, hipStream_t st);
+hipError_t init_gemm_panel_device();
+
 struct GemmPlan {
     bool supported, use_seq;
+    bool panel;               // gemm_panel.hip (panelp holds its geometry); act-order layers: x permuted in natural order (xnat)
+    PanelPlan panelp;
     bool rows;                // gemm_rows.hip (rowsp holds its geometry); act-order layers: x permuted in natural order (xnat)
     RowsPlan rowsp;
     bool wsk;                 // stream-K partition of 128 x 256 tiles with the 128 x 128 wave tile (gemm_wide_sk.hip); implies wide_tiled (+ xnat for act-order layers)

@@ -1,0 +1,107 @@
+"""GPU (-m gpu): the whole-K panel kernel (csrc/gemm_panel.hip: 64 x 32 NT (or 128 x 32 NT) workgroup tiles over the whole K, the waves of a workgroup are K
+parts that meet once through LDS, nothing exchanged between workgroups) -- forced with tuning.reserved[3] = GPTQ_LAB_VARIANT_PANEL_ON in every tile geometry
+on shapes chosen for its seams, and by the planner's own rule at the row counts of the band (129 ... 767) on three shapes.
+
+Every case: EVERY output against x (fp64) @ W_oracle (fp64) (+ bias), bit reproducibility of a repeated call, one-hot rows return the oracle's exact
+dequantised weight rows.  Reference behaviour this band answers: exllama / exllamav2 switch to dequant + cuBLAS above their row thresholds
+(autogptq_extension/exllamav2/cuda/q_gemm.cu:104-181, exllama/cuda_func/q4_matmul.cu:225-260), Marlin runs its stripe partition at any M
+(marlin/marlin_cuda_kernel.cu:234-300); checked the way the reference checks its kernels (tests/test_q4.py:1060-1122)."""
+import pytest
+import torch
+
+from autogptq_amd import _lib
+from autogptq_amd.qlinear_mi355x import QuantLinear
+from oracle import gptq_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+PANEL_ON = _lib.LAB.VARIANT_PANEL_ON          # include/gptq_mi355x_lab.h
+
+
+def _tune(geom=0, kp=0):
+    t = _lib.GptqTuning()
+    t.path, t.reserved[_lib.LAB.GEMM_VARIANT], t.reserved[0], t.reserved[1] = 3, PANEL_ON, geom, kp
+    return t
+
+
+# (K, N, group_size, M, act_order, what the shape exercises)
+CASES = [
+    (1024, 256, 128, 64, False, "one row tile, 16 steps on 8 waves"),
+    (512, 544, 128, 129, False, "shifted last row tile (one own row), partial last column tile, one step per wave"),
+    (256, 1024, 64, 333, True, "fewer steps (4) than waves (8): empty K parts; groups of 64; act-order; ragged M"),
+    (2048, 96, 256, 200, False, "groups of 256 (one group over four steps), N = 3 column blocks"),
+    (768, 160, 768, 767, True, "one group over the whole K, 12 steps on 8 waves (uneven K parts), N = 5 column blocks, act-order"),
+    (4096, 128, 128, 256, False, "deep K: 64 steps"),
+]
+GEOMS = [(21, 8), (22, 8), (23, 8), (24, 8), (21, 4), (22, 4), (23, 4), (24, 4), (41, 4), (42, 4)]
+
+
+def _every_output(q, Lq, W, M, K, dtype, t, what):
+    x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype).to(DEV)
+    with torch.no_grad():
+        y, y2 = q(x, tuning=t), q(x, tuning=t)
+    assert torch.equal(y, y2), f"{what}: not bit-reproducible"
+    ref = x.double() @ W.double() + Lq["bias"].to(DEV).double()
+    rtol = 1e-3 if dtype == torch.float16 else 8e-3
+    scale = float(ref.abs().max())
+    bad = (y.double() - ref).abs() > rtol * scale + rtol * ref.abs()
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} outputs out of tolerance, first {torch.nonzero(bad)[0].tolist()}"
+    hot = torch.zeros(M, K, dtype=dtype, device=DEV)
+    rows = torch.arange(M, device=DEV)
+    hot[rows, (rows * 37 + 5) % K] = 1.0                   # one-hot rows through every tile and K part
+    saved, q._layer.bias = q._layer.bias, None
+    with torch.no_grad():
+        yh = q(hot, tuning=t)
+    q._layer.bias = saved
+    assert torch.equal(yh, W[(rows * 37 + 5) % K]), f"{what}: one-hot rows are not the exact dequantised weight rows"
+
+
+def _layer(K, N, gs, act, dtype, zm, seed):
+    Lq = O.random_quant_layer(K, N, 4, gs, act_order=act, seed=seed, bias=True, dtype=dtype)
+    q = QuantLinear(4, gs, K, N, True, weight_dtype=dtype, zero_mode=zm)
+    q.qweight, q.qzeros, q.scales, q.g_idx, q.bias = Lq["qweight"], Lq["qzeros"], Lq["scales"], Lq["g_idx"], Lq["bias"]
+    q = q.to(DEV)
+    q.post_init()
+    assert q._qweight_tiled is not None
+    # 'auto' = the convention of the reference class the module stands in for (cuda_old wraps, the act-order class does not); a g_idx of ONE group is the
+    # default order whatever was asked for, so the module's own answer is taken, not the case's flag
+    mode = O.ZERO_NOWRAP if q.resolved_zero_mode() == _lib.ZERO_NOWRAP else O.ZERO_WRAP
+    W = O.dequantize(Lq["qweight"], Lq["qzeros"], Lq["scales"], Lq["g_idx"], 4, mode).to(DEV)
+    return q, Lq, W
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}x{c[1]}g{c[2]}M{c[3]}{'act' if c[4] else ''}" for c in CASES])
+def test_panel_forced_every_geometry_every_output(case, dtype):
+    K, N, gs, M, act, _ = case
+    for zm in ("auto", "nowrap"):
+        q, Lq, W = _layer(K, N, gs, act, dtype, zm, K + N + M)
+        ran = 0
+        for geom, kp in GEOMS:
+            if geom // 10 == 4 and M < 128:
+                continue
+            t = _tune(geom, kp)
+            plan = _lib.describe_plan(q._layer, M, t)
+            assert plan["kernel"] == "panel", plan
+            assert int(plan["mt"]) == geom // 10 and plan["tiles"].split("x")[1] == str(-(-N // (32 * (geom % 10)))), plan
+            _every_output(q, Lq, W, M, K, dtype, t, f"{K}x{N} g{gs} M={M} act={act} {zm} {dtype} geom {geom}x{kp}")
+            ran += 1
+        assert ran >= 8
+
+
+# the band itself, by the planner's rule (plan asserted): the review's row counts on three shapes, plain and act-order
+BAND_SHAPES = [(4096, 4096), (4096, 11008), (2048, 5120)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("act", [False, True], ids=["plain", "act"])
+@pytest.mark.parametrize("shape", BAND_SHAPES, ids=[f"{k}x{n}" for k, n in BAND_SHAPES])
+def test_panel_band_default_plan_every_output(shape, act, dtype):
+    K, N = shape
+    q, Lq, W = _layer(K, N, 128, act, dtype, "auto", K + N)
+    planned = 0
+    for M in (129, 192, 256, 384, 512, 767):
+        plan = _lib.describe_plan(q._layer, M, None)
+        planned += plan["kernel"] == "panel"
+        _every_output(q, Lq, W, M, K, dtype, None, f"{K}x{N} M={M} act={act} {dtype} default plan {plan['kernel']}")
+    assert planned >= 3, "the planner never chose the panel kernel in its own band"
