@@ -1921,6 +1921,24 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     pl.use_seq = (L.g_idx != nullptr);
     pl.xperm_bytes = pl.use_seq ? align_up((size_t)M * L.K * 2, 256) : 0;
     const int force_skinny = tune ? tune->reserved[2] : 0;      // experiment knob: 1 = skinny, 2 = tiled
+    // 64 .. ~1024 rows of a layer that carries its decode copy where its tiles fill the chip (panel_pays): whole-K panels of 64 x 32 nt tiles, no exchange
+    // (gemm_panel.hip); lab knobs 52 / 53 force it on / off.  Asked before the rows kernel: from ~96 rows it is the faster of the two (profiles/r06_panel_sweep.log)
+    {
+        const int knob = tune ? tune->reserved[3] : 0;
+        if (knob == GPTQ_LAB_VARIANT_PANEL_ON || (knob != GPTQ_LAB_VARIANT_PANEL_OFF && (!tune || tune->path != 3 || knob == 0) && force_skinny == 0 && panel_pays(L, M))) {
+            const PanelPlan pp = plan_panel(L, M, knob == GPTQ_LAB_VARIANT_PANEL_ON ? tune : nullptr);
+            if (pp.ok) {
+                pl.panel = true;
+                pl.panelp = pp;
+                pl.xnat = pl.use_seq;
+                pl.mt = pp.mt; pl.bk = 64; pl.bm = 32 * pp.mt; pl.bn = 32 * pp.nt; pl.nbm = pp.nbm; pl.nbn = pp.nbn;
+                pl.waves = pp.kp; pl.u = 2; pl.kg = pp.kp;
+                pl.ksplit = 1; pl.ksteps_total = pl.ksteps_per_split = L.K / 64;
+                pl.workspace_bytes = pl.xperm_bytes;
+                return pl;
+            }
+        }
+    }
     // 5 .. ~256 rows of a layer that carries its decode copy: whole-K workgroups, no exchange (gemm_rows.hip); lab knobs 50 / 51 force it on / off
     {
         const int knob = tune ? tune->reserved[3] : 0;
@@ -1933,24 +1951,6 @@ GemmPlan plan_gemm(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
                 pl.mt = rp.rb; pl.bk = 128; pl.bm = 16 * rp.rb; pl.bn = 16 * rp.s; pl.nbm = rp.npm; pl.nbn = rp.nsg;
                 pl.waves = rp.waves; pl.u = 2; pl.kg = 1;
                 pl.ksplit = 1; pl.ksteps_total = pl.ksteps_per_split = L.K / 128;
-                pl.workspace_bytes = pl.xperm_bytes;
-                return pl;
-            }
-        }
-    }
-    // 129 .. ~767 rows (and 128 rows on wide layers) of a layer that carries its decode copy: whole-K panels of 64 x 32 nt tiles, no exchange (gemm_panel.hip);
-    // lab knobs 52 / 53 force it on / off
-    {
-        const int knob = tune ? tune->reserved[3] : 0;
-        if (knob == GPTQ_LAB_VARIANT_PANEL_ON || (knob != GPTQ_LAB_VARIANT_PANEL_OFF && (!tune || tune->path != 3 || knob == 0) && force_skinny == 0 && panel_pays(L, M))) {
-            const PanelPlan pp = plan_panel(L, M, knob == GPTQ_LAB_VARIANT_PANEL_ON ? tune : nullptr);
-            if (pp.ok) {
-                pl.panel = true;
-                pl.panelp = pp;
-                pl.xnat = pl.use_seq;
-                pl.mt = pp.mt; pl.bk = 64; pl.bm = 32 * pp.mt; pl.bn = 32 * pp.nt; pl.nbm = pp.nbm; pl.nbn = pp.nbn;
-                pl.waves = pp.kp; pl.u = 2; pl.kg = pp.kp;
-                pl.ksplit = 1; pl.ksteps_total = pl.ksteps_per_split = L.K / 64;
                 pl.workspace_bytes = pl.xperm_bytes;
                 return pl;
             }

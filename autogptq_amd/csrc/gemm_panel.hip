@@ -39,68 +39,87 @@ bool panel_ok(const gptq_layer_t& L, int M) {
     return M >= 64;
 }
 
-// lab: tuning.path = 3, reserved[3] = GPTQ_LAB_VARIANT_PANEL_ON, reserved[0] = 10 MT + NT (0: the planner's), reserved[1] = KP (0: the planner's)
+// Time model of a launch, us (fit of profiles/r06_panel_sweep_cold.log: 4-bit g128 fp16, rotating HBM-cold layers): a workgroup owns its CU (128 KiB of LDS), so a
+// launch is whole rounds of 256 tiles; a tile costs ~4 us (first loads from HBM, the cross-wave sum, the stores) + its 64-deep steps per wave x (0.40 + 0.50 NT) us
+// (x staging + NT column blocks of dequant and MFMA, two waves per SIMD); + ~1.5 us for the launch itself.
+static double panel_model_us(const gptq_layer_t& L, int M, int nt, long* tiles_out) {
+    const long tiles = (long)((M + 63) / 64) * ((L.N + 32 * nt - 1) / (32 * nt));
+    const long rounds = (tiles + 255) / 256;
+    const int spw = (L.K / 64 + 7) / 8;
+    if (tiles_out) *tiles_out = tiles;
+    return 1.5 + (double)rounds * (4.0 + spw * (0.40 + 0.50 * nt));
+}
+
+// lab: tuning.path = 3, reserved[3] = GPTQ_LAB_VARIANT_PANEL_ON, reserved[0] = 20 + NT (column blocks of 32 per workgroup tile; 0: the planner's)
 PanelPlan plan_panel(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     PanelPlan pl{};
     if (!panel_ok(L, M)) return pl;
-    int mt = 0, nt = 0, kp = 0;
+    int nt = 0;
     if (tune && tune->path == 3) {
         const int g = tune->reserved[0];
-        if (g / 10 == 2 && g % 10 >= 1 && g % 10 <= 4) { mt = 2; nt = g % 10; }
-        if (g / 10 == 4 && g % 10 >= 1 && g % 10 <= 2 && M >= 128) { mt = 4; nt = g % 10; }
-        if (tune->reserved[1] == 4 || tune->reserved[1] == 8) kp = tune->reserved[1];
+        if (g / 10 == 2 && g % 10 >= 1 && g % 10 <= 4) nt = g % 10;
     }
-    if (mt == 4) kp = 4;                                       // (128-row tiles: two 16 KiB x buffers per wave)
-    if (!mt) {
-        // one tile costs ~ (a + b NT) per 64-deep step (x staging + NT column blocks of dequant and MFMA); a launch is rounds of 256 workgroups
+    if (!nt) {
         double best = 1e30;
-        for (int c = 1; c <= 4; ++c) {
-            const long tiles = (long)((M + 63) / 64) * ((L.N + 32 * c - 1) / (32 * c));
-            const long rounds = (tiles + 255) / 256;
-            const double t = (double)rounds * (0.25 + 1.0 * c + 1.5 / (L.K / 1024.0));
+        for (int c = 4; c >= 1; --c) {                          // ties go to the wider tile (fewer pulls of x)
+            const double t = panel_model_us(L, M, c, nullptr);
             if (t < best - 1e-9) { best = t; nt = c; }
         }
-        mt = 2;
     }
-    if (!kp) kp = 8;
     const int steps = L.K / 64;
-    if (kp > steps) kp = steps >= 4 ? 4 : 0;
-    if (!kp) return pl;
-    pl.mt = mt; pl.nt = nt; pl.kp = kp;
-    pl.nbm = (M + 32 * mt - 1) / (32 * mt);
+    pl.mt = 2; pl.nt = nt; pl.kp = 8;
+    pl.nbm = (M + 63) / 64;
     pl.nbn = (L.N + 32 * nt - 1) / (32 * nt);
-    pl.spw = (steps + kp - 1) / kp;
-    const size_t xbytes = (size_t)kp * 2 * (32 * mt) * 128;
-    const int units = 4 * mt * nt, ub = units < 128 / kp ? units : 128 / kp;
-    const size_t red = (size_t)ub * kp * 1024;
+    pl.spw = (steps + pl.kp - 1) / pl.kp;                        // (fewer steps than waves: the last waves run empty)
+    const size_t xbytes = (size_t)pl.kp * 2 * 64 * 128;
+    const int units = 8 * nt, ub = units < 128 / pl.kp ? units : 128 / pl.kp;
+    const size_t red = (size_t)ub * pl.kp * 1024;
     pl.lds_bytes = xbytes > red ? xbytes : red;
-    pl.ok = M >= 32 * mt;
+    pl.ok = true;
     return pl;
 }
 
-// The planner's measured preference (tools/panel_ab.py, profiles/r06_panel_ab.log).
+// The planner's measured preference (tools/panel_ab.py against the planner without this kernel, rotating HBM-cold layers: profiles/r06_panel_sweep_cold.log; us per
+// layer call, before -> this kernel):
+//   4096^2      M = 96 / 128 / 192 / 256 / 320 / 384 / 512 / 640:  13.0 / 13.5 / 17.1 / 18.3 / 27.8 / 28.7 / 35.8 / 39.9  ->  12.3 / 12.2 / 13.9 / 16.2 / 19.3 / 21.9 / 25.7 / 38.1
+//   4096x11008  M = 64 / 128 / 192 / 256 / 320:                    17.4 / 28.4 / 40.8 / 42.8 / 57.4                        ->  15.4 / 21.7 / 35.8 / 40.0 / 45.6
+//   11008x4096  M = 192 / 256 / 320 / 448 / 512:                   36.0 / 40.4 / 58.1 / 65.4 / 63.3                        ->  32.3 / 34.8 / 41.8 / 51.7 / 54.5
+// and 1.1 - 1.4x on 2048^2 (256+ rows), 5120^2 and 8192^2 (up to 256 rows), 5120x13824 / 13824x5120 (up to 256 rows), the 70B shards 1024x8192 and 8192x3584.
+// It LOSES where its tiles leave CUs idle (fewer than ~160 tiles: 4096^2 at 64 rows 0.85x, 8192x1024 and 28672x1024 up to 256 rows 0.5 - 0.87x: the rows kernel keeps
+// those), on deep layers at few rows (11008x4096 at 96 / 128 rows 0.88 / 0.98x against the rows kernel; 28672x1024 at 512 rows 0.91x against the tiled one), against the
+// stream-K kernel where that is the default and the launch is several rounds of tiles (512+ rows on the large shapes: 4096x11008 0.89x, 8192^2 0.91x, 5120x13824
+// 0.85x) -- except on narrow layers, where stream-K has too few 256-column tiles (2048^2, 8192x1024 at 768 rows: 2.0 - 2.5x) -- and on the largest layers.
 bool panel_pays(const gptq_layer_t& L, int M) {
     static const bool lab_off = getenv("GPTQ_LAB_NO_PANEL") != nullptr;      // lab: the planner as it was before this kernel
-    if (lab_off || !panel_ok(L, M)) return false;
-    return false;                                              // (set from the first sweep)
+    if (lab_off || !panel_ok(L, M) || M > 1024) return false;
+    const PanelPlan pp = plan_panel(L, M, nullptr);
+    if (!pp.ok) return false;
+    long tiles = 0;
+    const double est = panel_model_us(L, M, pp.nt, &tiles);
+    const long rounds = (tiles + 255) / 256;
+    if ((double)tiles < 0.62 * (double)(rounds * 256)) return false;
+    const size_t kn = (size_t)L.K * L.N;
+    if (wide_sk_pays(L, M)) {
+        if (L.N <= 2048) return true;
+        const double gf = 2.0 * M * (double)kn * 1e-9;
+        return est < 20.0 + gf / 1.2;                             // stream-K on cold weights: ~20 us of first loads, segment turn-around and fix-up + the K loop at ~1.2 PFLOP/s
+    }
+    if (kn > ((size_t)128 << 20) || L.K > 16384) return false;
+    if (M < 160 && L.K > 8192) return false;
+    if (M < 96 && !(L.N >= 8192 && L.K <= 4096)) return false;      // 64 .. 95 rows: measured on the wide layers only (4096x11008: 172 tiles of 64 x 64 against the rows kernel's 230 workgroups)
+    return true;
 }
 
-template <typename T, int MT, int NT, int KP>
+template <typename T, int NT>
 static hipError_t panel_grant_one() {
-    return hipFuncSetAttribute((const void*)panel::gemm_panel_kernel<T, MT, NT, KP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return hipFuncSetAttribute((const void*)panel::gemm_panel_kernel<T, 2, NT, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 template <typename T>
 static hipError_t panel_grant_t() {
-    hipError_t e = panel_grant_one<T, 2, 1, 4>();
-    if (e == hipSuccess) e = panel_grant_one<T, 2, 2, 4>();
-    if (e == hipSuccess) e = panel_grant_one<T, 2, 3, 4>();
-    if (e == hipSuccess) e = panel_grant_one<T, 2, 4, 4>();
-    if (e == hipSuccess) e = panel_grant_one<T, 2, 1, 8>();
-    if (e == hipSuccess) e = panel_grant_one<T, 2, 2, 8>();
-    if (e == hipSuccess) e = panel_grant_one<T, 2, 3, 8>();
-    if (e == hipSuccess) e = panel_grant_one<T, 2, 4, 8>();
-    if (e == hipSuccess) e = panel_grant_one<T, 4, 1, 4>();
-    if (e == hipSuccess) e = panel_grant_one<T, 4, 2, 4>();
+    hipError_t e = panel_grant_one<T, 1>();
+    if (e == hipSuccess) e = panel_grant_one<T, 2>();
+    if (e == hipSuccess) e = panel_grant_one<T, 3>();
+    if (e == hipSuccess) e = panel_grant_one<T, 4>();
     return e;
 }
 hipError_t init_gemm_panel_device() {
@@ -109,24 +128,18 @@ hipError_t init_gemm_panel_device() {
     return e;
 }
 
-template <typename T, int MT, int NT, int KP>
+template <typename T, int NT>
 static void panel_launch_one(const PanelPlan& pl, const panel::PanelParams& p, hipStream_t st) {
-    hipLaunchKernelGGL((panel::gemm_panel_kernel<T, MT, NT, KP, false>), dim3(pl.nbm * pl.nbn), dim3(64 * KP), pl.lds_bytes, st, p);
+    hipLaunchKernelGGL((panel::gemm_panel_kernel<T, 2, NT, 8, false>), dim3(pl.nbm * pl.nbn), dim3(512), pl.lds_bytes, st, p);
 }
 template <typename T>
 static hipError_t panel_launch_t(const PanelPlan& pl, const panel::PanelParams& p, hipStream_t st) {
-    const int key = pl.mt * 100 + pl.nt * 10 + pl.kp;
-    switch (key) {
-        case 214: panel_launch_one<T, 2, 1, 4>(pl, p, st); break;
-        case 224: panel_launch_one<T, 2, 2, 4>(pl, p, st); break;
-        case 234: panel_launch_one<T, 2, 3, 4>(pl, p, st); break;
-        case 244: panel_launch_one<T, 2, 4, 4>(pl, p, st); break;
-        case 218: panel_launch_one<T, 2, 1, 8>(pl, p, st); break;
-        case 228: panel_launch_one<T, 2, 2, 8>(pl, p, st); break;
-        case 238: panel_launch_one<T, 2, 3, 8>(pl, p, st); break;
-        case 248: panel_launch_one<T, 2, 4, 8>(pl, p, st); break;
-        case 414: panel_launch_one<T, 4, 1, 4>(pl, p, st); break;
-        case 424: panel_launch_one<T, 4, 2, 4>(pl, p, st); break;
+    if (pl.mt != 2 || pl.kp != 8) return hipErrorInvalidValue;
+    switch (pl.nt) {
+        case 1: panel_launch_one<T, 1>(pl, p, st); break;
+        case 2: panel_launch_one<T, 2>(pl, p, st); break;
+        case 3: panel_launch_one<T, 3>(pl, p, st); break;
+        case 4: panel_launch_one<T, 4>(pl, p, st); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

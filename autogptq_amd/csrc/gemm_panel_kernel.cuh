@@ -44,8 +44,8 @@ template <int KP> constexpr int units_per_batch() { return 128 / KP; }      // 1
 
 template <typename T, int MT, int NT, int KP, bool G32>
 __device__ __forceinline__ void panel_body(const PanelParams& p) {
-    constexpr int R = 32 * MT, XB = R * 128, NX = 4 * MT, NW = 3 * NT;
-    constexpr int DW = (KP >= 8 && NT >= 4) ? 2 : 3;           // register sets of packed weights (256 registers per wave with 8 waves: two sets at 4 column blocks)
+    constexpr int R = 32 * MT, XB = R * 128, NX = 4 * MT;
+    constexpr int DW = 3;                                      // register sets of packed weights: W(kt + 2) is issued inside step kt
     constexpr int UNITS = 4 * MT * NT;                         // float4s per lane of the accumulator tile
     constexpr int UB = units_per_batch<KP>() < UNITS ? units_per_batch<KP>() : UNITS;
     static_assert(UB % KP == 0 || UB == UNITS, "every wave sums the same number of units per batch");
@@ -89,18 +89,38 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
 
     struct Buf { u32x4 w[NT]; unsigned cs[NT], cz[NT]; };
     Buf q[DW];
+#pragma unroll
+    for (int j = 0; j < DW; ++j)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) q[j].cs[nt] = q[j].cz[nt] = 0u;
+    const int k0 = wave * p.spw, k1 = min(k0 + p.spw, p.steps);
+    // constants only where a group begins (and at the wave's first step): the two sub-dword loads per column cost the memory pipe as much as the 16-byte weight
+    // load beside them (profiles/r06_panel_ablate.log).  "+v": a step without constants leaves the registers as they are -- no copy can appear at the join
+    const int gmask = (1 << p.gsh) - 1;
+    auto has_c = [&](int kt) -> bool { return G32 || kt == k0 || (kt & gmask) == 0; };
     auto issue_w = [&](int kt, Buf& B) __attribute__((always_inline)) {
-        const int g = G32 ? 2 * kt : min(kt >> p.gsh, p.groups - 1);
+#if defined(GPTQ_PANEL_ABL) && (GPTQ_PANEL_ABL & 4)      // lab: 4 = no weight / constant loads
+        if (kt != 0x7fffffff) return;
+#endif
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const char* wsrc = wbase[nt] + (size_t)kt * 512;  // chunk kt / 2, k-slots 2 (kt & 1) + half
-            const char* csrc = cbase[nt] + (size_t)g * 48;
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B.w[nt]) : "v"(wlane), "s"(wsrc) : "memory");
-            asm volatile("global_load_ushort %0, %1, %2" : "=v"(B.cs[nt]) : "v"(slane), "s"(csrc) : "memory");
-            asm volatile("global_load_ubyte %0, %1, %2" : "=v"(B.cz[nt]) : "v"(zlane), "s"(csrc) : "memory");
+        }
+        if (has_c(kt)) {
+            const int g = G32 ? 2 * kt : min(kt >> p.gsh, p.groups - 1);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const char* csrc = cbase[nt] + (size_t)g * 48;
+                asm volatile("global_load_ushort %0, %1, %2" : "+v"(B.cs[nt]) : "v"(slane), "s"(csrc) : "memory");
+                asm volatile("global_load_ubyte %0, %1, %2" : "+v"(B.cz[nt]) : "v"(zlane), "s"(csrc) : "memory");
+            }
         }
     };
     auto issue_x = [&](int kt, int buf, int i0, int i1) __attribute__((always_inline)) {      // DMAs [i0, i1) of step kt's rows into buffer buf
+#if defined(GPTQ_PANEL_ABL) && (GPTQ_PANEL_ABL & 2)      // lab: 2 = no x DMAs
+        if (kt != 0x7fffffff) return;
+#endif
         const char* xsrc = xrow0 + (size_t)kt * 128;
         const unsigned l0 = __builtin_amdgcn_readfirstlane(xbuf_lds + (unsigned)(buf * XB));
 #pragma unroll
@@ -115,6 +135,7 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
         for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(B.w[nt]), "+v"(B.cs[nt]), "+v"(B.cz[nt])::"memory");
     };
 
+    typename rowsk::Deq1<T> dq[NT];                            // the current group's constants (set up where a group begins)
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -123,7 +144,6 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    const int k0 = wave * p.spw, k1 = min(k0 + p.spw, p.steps);
     if (k0 < k1) {
         const int kl = k1 - 1;
         issue_w(k0, q[0]);
@@ -136,29 +156,59 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
                 if (kt >= k1) break;
                 const int buf = (kt - k0) & 1;
                 const int ktx = min(kt + 1, kl), ktw = min(kt + 2, kl);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+#if !(defined(GPTQ_PANEL_ABL) && (GPTQ_PANEL_ABL & 1))      // lab (tools/ab_unit.sh ... -DGPTQ_PANEL_ABL=n; wrong results by construction): 1 = nobody waits for the step's loads
+                if (has_c(ktx)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NT) : "memory");      // W(kt + 1) stays in flight: with or without constants
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT) : "memory");
+#endif
                 claim(q[j]);
-                typename rowsk::Deq1<T> dq[NT];
+                if (has_c(kt)) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) dq[nt].setup(q[j].cs[nt], q[j].cz[nt]);
+                    for (int nt = 0; nt < NT; ++nt) dq[nt].setup(q[j].cs[nt], q[j].cz[nt]);
+                }
                 const char* xb = xbuf + buf * XB;
-                u32x4 a[2][MT];
+                u32x4 a[2][MT], bq[2];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) a[0][mt] = *(const u32x4*)(xb + mt * 4096 + aoff[0]);
+                bq[0] = dq[0].frag(q[j].w[0][0]);
+                // software pipeline over the 4 NT (MFMA step, column block) pairs: the NEXT pair's B fragment (13 VALU) is dequantised between the MT MFMAs of
+                // this pair -- independent work for the 32 cycles each MFMA holds the matrix pipe (back to back, the second MFMA of a pair stalls the wave
+                // for the first one's passes and the dequant then runs with the pipe idle)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    if (ks + 1 < 4) {
+                for (int i = 0; i < 4 * NT; ++i) {
+                    const int ks = i / NT, nt = i % NT;
+                    if (nt == 0) {
+                        __builtin_amdgcn_sched_barrier(0);     // (the scheduler otherwise strings the MFMAs of one accumulator across the steps: dependent chains)
+                        if (ks + 1 < 4) {
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) a[(ks + 1) & 1][mt] = *(const u32x4*)(xb + mt * 4096 + aoff[ks + 1]);
+                            for (int mt = 0; mt < MT; ++mt) a[(ks + 1) & 1][mt] = *(const u32x4*)(xb + mt * 4096 + aoff[ks + 1]);
+                        }
+                        if (ks == 0) issue_x(ktx, buf ^ 1, 0, NX / 2);
+                        if (ks == 1) issue_x(ktx, buf ^ 1, NX / 2, NX);
+                        if (DW == 3 && ks == 2) issue_w(ktw, q[(j + 2) % DW]);
                     }
-                    if (ks == 0) issue_x(ktx, buf ^ 1, 0, NX / 2);
-                    if (ks == 1) issue_x(ktx, buf ^ 1, NX / 2, NX);
-                    if (DW == 3 && ks == 2) issue_w(ktw, q[(j + 2) % DW]);
+#if defined(GPTQ_PANEL_ABL) && (GPTQ_PANEL_ABL & 8)      // lab: 8 = no dequant math
+                    if (i + 1 < 4 * NT) { const unsigned qq = q[j].w[(i + 1) % NT][(i + 1) / NT]; bq[(i + 1) & 1] = u32x4{qq, qq ^ 0x11111111u, qq ^ 0x22222222u, qq ^ q[j].cs[(i + 1) % NT]}; }
+#else
+                    if (i + 1 < 4 * NT) bq[(i + 1) & 1] = dq[(i + 1) % NT].frag(q[j].w[(i + 1) % NT][(i + 1) / NT]);
+#endif
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const u32x4 bq = dq[nt].frag(q[j].w[nt][ks]);
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = wide::Mma<T>::run(a[ks & 1][mt], bq, acc[mt][nt]);
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = wide::Mma<T>::run(a[ks & 1][mt], bq[i & 1], acc[mt][nt]);
+                    if (i + 1 < 4 * NT) {                     // MFMA, its share of the next fragment's 13 VALU, MFMA, ...
+                        if constexpr (MT == 2) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                        } else {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        }
                     }
                 }
                 if (DW == 2) issue_w(ktw, q[j]);

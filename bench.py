@@ -512,15 +512,15 @@ def bench_batched(device, steps):
                                      "plan": _plan_of(ls, K, N, M)}
             del ls, xs
             torch.cuda.empty_cache()
-    # short prompts (a few hundred rows; round 5: the 64-row form of the same kernel where it beats the tiled one): one row count, two shapes
-    for K, N in ((4096, 4096), (11008, 4096)):
-        M = 256
+    # short prompts / large batches (a few hundred rows; round 6: the whole-K panel kernel, csrc/gemm_panel.hip, where its 64-row tiles fill the chip): 256 rows on
+    # two shapes, 512 rows on all three
+    for M, K, N in ((256, 4096, 4096), (256, 11008, 4096), (512, 4096, 4096), (512, 4096, 11008), (512, 11008, 4096)):
         n = max(4, -(-(320 << 20) // (K * N // 2)))
         ls = [("b", K, N, make_layer(K, N, device, seed=7100 + i)) for i in range(n)]
         xs = {K: (torch.rand(M, K, device=device) - 0.5).half()}
         per = _time_layers(ls, xs, device, max(3, steps // 2))
-        res[f"short_prompt_M{M}_{K}x{N}"] = {"us": round(per * 1e6, 2), "TFLOP_s": round(2 * M * K * N / per / 1e12, 1), "mfma_frac": round(2 * M * K * N / per / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                                              "plan": _plan_of(ls, K, N, M)}
+        res[(f"short_prompt_M{M}_{K}x{N}" if M == 256 else f"M{M}_{K}x{N}")] = {"us": round(per * 1e6, 2), "TFLOP_s": round(2 * M * K * N / per / 1e12, 1),
+                                                                               "mfma_frac": round(2 * M * K * N / per / 1e12 / MFMA_PEAK_TFLOPS, 4), "plan": _plan_of(ls, K, N, M)}
         del ls, xs
         torch.cuda.empty_cache()
     return res

@@ -47,7 +47,7 @@
 #define GPTQ_LAB_VARIANT_WIDE_SK_OFF 49   /* never the stream-K form */
 #define GPTQ_LAB_VARIANT_ROWS_ON 50       /* the exchange-free batched-decode kernel (gemm_rows.hip) wherever it is legal; reserved[0] = row blocks of 16 (1 / 2), reserved[1] = strips per workgroup (0: the planner's) */
 #define GPTQ_LAB_VARIANT_ROWS_OFF 51      /* never that kernel */
-#define GPTQ_LAB_VARIANT_PANEL_ON 52      /* the whole-K panel kernel (gemm_panel.hip) wherever it is legal; reserved[0] = 10 MT + NT (row / column blocks of 32 per workgroup tile; 0: the planner's), reserved[1] = waves = K parts (4 / 8; 0: the planner's) */
+#define GPTQ_LAB_VARIANT_PANEL_ON 52      /* the whole-K panel kernel (gemm_panel.hip) wherever it is legal; reserved[0] = 20 + NT (NT = column blocks of 32 per workgroup tile, 1..4; 0: the planner's) */
 #define GPTQ_LAB_VARIANT_PANEL_OFF 53     /* never that kernel */
 /* (9..24, 32: ablation / timeline / ping-pong variants compiled only into tools/gemmlab with -DGPTQ_GEMM_ABLATIONS) */
 

@@ -139,13 +139,14 @@ def test_config3_int4_g128_desc_act_prefill_2048(K, N, dtype):
 @pytest.mark.parametrize("K,N", LLAMA7B)
 def test_batched_rows_17_to_256_int4_g128_llama7b_shapes(K, N, dtype, act):
     """The row counts between decode and prefill (the reference's kernel switch sits at 8 / 50 rows) on the Llama-7B shapes with the DEFAULT plan: round 5's
-    exchange-free kernel on the decode copy (csrc/gemm_rows.hip) from 5 to 64 rows, to 256 rows on the layers of at most 8192 columns (129+: its 64-row form);
-    gemm_mid_kernel / the tiled kernel elsewhere."""
+    exchange-free kernel on the decode copy (csrc/gemm_rows.hip) from 5 to 64 rows, round 6's whole-K panel kernel (csrc/gemm_panel.hip) above."""
     from autogptq_amd import _lib
     _, q, _, _ = _layer(4, 128, K, N, act, dtype)
     for M in (5, 8, 16, 17, 33, 64, 96, 128, 192, 256):
         plan = _lib.describe_plan(q._layer, M)
-        assert (plan["kernel"] == "rows") == (M <= 64 or N <= 8192), (M, plan)          # (129 .. 256 rows: the 64-row form, 4 bits)
+        # round 6: from 96 rows (64 on the 11008-column layer: 172 tiles) the whole-K panel kernel (csrc/gemm_panel.hip) where its 64-row tiles fill the chip
+        want = "panel" if ((M >= 96 and (K <= 8192 or M >= 160)) or (M == 64 and N == 11008)) else "rows"      # (deep layers at few rows stay with the rows kernel)
+        assert plan["kernel"] == want, (M, plan)
         _check(4, 128, K, N, M, act, dtype)
 
 

@@ -1,4 +1,4 @@
-"""GPU (-m gpu): the whole-K panel kernel (csrc/gemm_panel.hip: 64 x 32 NT (or 128 x 32 NT) workgroup tiles over the whole K, the waves of a workgroup are K
+"""GPU (-m gpu): the whole-K panel kernel (csrc/gemm_panel.hip: 64 x 32 NT workgroup tiles over the whole K, the waves of a workgroup are K
 parts that meet once through LDS, nothing exchanged between workgroups) -- forced with tuning.reserved[3] = GPTQ_LAB_VARIANT_PANEL_ON in every tile geometry
 on shapes chosen for its seams, and by the planner's own rule at the row counts of the band (129 ... 767) on three shapes.
 
@@ -18,9 +18,9 @@ DEV = "cuda:0"
 PANEL_ON = _lib.LAB.VARIANT_PANEL_ON          # include/gptq_mi355x_lab.h
 
 
-def _tune(geom=0, kp=0):
+def _tune(geom=0):
     t = _lib.GptqTuning()
-    t.path, t.reserved[_lib.LAB.GEMM_VARIANT], t.reserved[0], t.reserved[1] = 3, PANEL_ON, geom, kp
+    t.path, t.reserved[_lib.LAB.GEMM_VARIANT], t.reserved[0] = 3, PANEL_ON, geom
     return t
 
 
@@ -28,12 +28,12 @@ def _tune(geom=0, kp=0):
 CASES = [
     (1024, 256, 128, 64, False, "one row tile, 16 steps on 8 waves"),
     (512, 544, 128, 129, False, "shifted last row tile (one own row), partial last column tile, one step per wave"),
-    (256, 1024, 64, 333, True, "fewer steps (4) than waves (8): empty K parts; groups of 64; act-order; ragged M"),
+    (256, 1024, 64, 333, True, "fewer steps (4) than waves (8): empty K parts; groups of 64 (constants every step); act-order; ragged M"),
     (2048, 96, 256, 200, False, "groups of 256 (one group over four steps), N = 3 column blocks"),
     (768, 160, 768, 767, True, "one group over the whole K, 12 steps on 8 waves (uneven K parts), N = 5 column blocks, act-order"),
     (4096, 128, 128, 256, False, "deep K: 64 steps"),
 ]
-GEOMS = [(21, 8), (22, 8), (23, 8), (24, 8), (21, 4), (22, 4), (23, 4), (24, 4), (41, 4), (42, 4)]
+GEOMS = [21, 22, 23, 24]          # 20 + NT: 64 x 32 / 64 / 96 / 128 tiles
 
 
 def _every_output(q, Lq, W, M, K, dtype, t, what):
@@ -76,17 +76,12 @@ def test_panel_forced_every_geometry_every_output(case, dtype):
     K, N, gs, M, act, _ = case
     for zm in ("auto", "nowrap"):
         q, Lq, W = _layer(K, N, gs, act, dtype, zm, K + N + M)
-        ran = 0
-        for geom, kp in GEOMS:
-            if geom // 10 == 4 and M < 128:
-                continue
-            t = _tune(geom, kp)
+        for geom in GEOMS:
+            t = _tune(geom)
             plan = _lib.describe_plan(q._layer, M, t)
             assert plan["kernel"] == "panel", plan
-            assert int(plan["mt"]) == geom // 10 and plan["tiles"].split("x")[1] == str(-(-N // (32 * (geom % 10)))), plan
-            _every_output(q, Lq, W, M, K, dtype, t, f"{K}x{N} g{gs} M={M} act={act} {zm} {dtype} geom {geom}x{kp}")
-            ran += 1
-        assert ran >= 8
+            assert plan["tiles"] == f"{-(-M // 64)}x{-(-N // (32 * (geom % 10)))}", plan
+            _every_output(q, Lq, W, M, K, dtype, t, f"{K}x{N} g{gs} M={M} act={act} {zm} {dtype} geom {geom}")
 
 
 # the band itself, by the planner's rule (plan asserted): the review's row counts on three shapes, plain and act-order

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Round 6: the whole-K panel kernel (csrc/gemm_panel.hip, tuning.reserved[3] = 52, reserved[0] = 10 MT + NT, reserved[1] = KP) against the planner's choice
+"""Round 6: the whole-K panel kernel (csrc/gemm_panel.hip, tuning.reserved[3] = 52, reserved[0] = 20 + NT) against the planner's choice
 without it (53), layer call (incl. the x permute of act-order layers) on rotating layers in a hipGraph, interleaved rounds, minimum per variant; the first
 round of every configuration also compares every output of the two forms.
-Usage: python tools/panel_ab.py [--ms 128,256,512] [--shapes 4096x4096,...] [--geoms 0x0,24x8,24x4,...] [--act 0,1] [--dtype f16]"""
+Usage: python tools/panel_ab.py [--ms 128,256,512] [--shapes 4096x4096,...] [--geoms 0,21,22,23,24] [--act 0,1] [--dtype f16]"""
 import argparse, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,12 +13,12 @@ from autogptq_amd import _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--ms", default="128,192,256,384,512,768")
 ap.add_argument("--shapes", default="4096x4096,4096x11008,11008x4096")
-ap.add_argument("--geoms", default="0x0,21x8,22x8,23x8,24x8,22x4,23x4,24x4,41x4,42x4", help="(10 MT + NT) x KP; 0x0 = the kernel's own planner")
+ap.add_argument("--geoms", default="0,21,22,23,24", help="20 + NT; 0 = the kernel's own planner")
 ap.add_argument("--dtype", default="f16")
 ap.add_argument("--act", default="0")
 ap.add_argument("--gs", type=int, default=128)
 ap.add_argument("--rounds", type=int, default=2)
-ap.add_argument("--layers", type=int, default=8)
+ap.add_argument("--layers", type=int, default=0, help="rotating layers per shape; 0 = enough for > 512 MiB of packed weights (HBM-cold, as bench.py measures), at most 64")
 ap.add_argument("--check", type=int, default=1)
 ap.add_argument("--default-baseline", type=int, default=1)
 a = ap.parse_args()
@@ -39,11 +39,12 @@ for _ in range(3):
     run(warm, xw, None, reps=100)
 del warm, xw
 
-geoms = [tuple(map(int, g.split("x"))) for g in a.geoms.split(",")]
+geoms = [(int(g.split("x")[0]), 0) for g in a.geoms.split(",")]
 for shp in a.shapes.split(","):
     K, N = map(int, shp.split("x"))
     for act in map(int, a.act.split(",")):
-        ls = [make_layer(K, N, dev, gs=a.gs, dtype=dt, seed=i, act_order=bool(act)) for i in range(a.layers)]
+        nl = a.layers or max(4, min(64, (640 << 20) // (K * N // 2)))
+        ls = [make_layer(K, N, dev, gs=a.gs, dtype=dt, seed=i, act_order=bool(act)) for i in range(nl)]
         for M in map(int, a.ms.split(",")):
             x = (torch.rand(M, K, device=dev) - 0.5).to(dt)
             best, bad = {}, {}
@@ -59,7 +60,7 @@ for shp in a.shapes.split(","):
                     d = _lib.describe_plan(ls[0]._layer, M, t)
                     if d.get("kernel") != "panel":
                         continue
-                    key = f"{g}x{kp}" if g else f"auto:{d['mt']}x{d['tiles']}w{d['waves']}"
+                    key = f"{g}" if g else f"auto:{d['mt']}x{d['tiles']}w{d['waves']}"
                     if rnd == 0 and a.check:
                         with torch.no_grad():
                             y = ls[0](x, tuning=t).float()
