@@ -650,6 +650,18 @@ size_t gptq_workspace_bytes_mlp_ex(const gptq_layer_t* gate, const gptq_layer_t*
     return WS_HEADER_BYTES + 2 * mlp_stage_bytes(gate, M) + inner;
 }
 
+// down of gptq_mlp_forward: does its call at M rows run an MFMA GEMM that reads x permuted in NATURAL order of its re-sequenced rows (GemmPlan.xnat)?  Then the
+// SiLU * mul pass writes that permuted x itself.  (Decode rows gather inside the kernel, fp32 and the checkpoint-row kernels have their own orders: unchanged.)
+static bool mlp_fused_permute(const gptq_layer_t* down, int M) {
+    if (!down->g_idx || !down->perm || !down->qweight_seq || down->epilogue != GPTQ_EPI_NONE) return false;
+    if (!silu_mul2_permute_ok(down->K, down->dtype)) return false;
+    const gptq_layer_t* one[1] = {down};
+    gptq_layer_t P;
+    if (want_tiled(one, 1, M, nullptr) || want_stream(down, M, nullptr) || want_stream_seq(down, M, nullptr, &P) || !want_gemm(down, M, nullptr)) return false;      // (forward_impl's order)
+    const GemmPlan pl = plan_gemm(*down, M, nullptr);
+    return pl.supported && pl.use_seq && pl.xnat && !pl.f32 && pl.xperm_bytes > 0;
+}
+
 int gptq_mlp_forward(const gptq_layer_t* gate, const gptq_layer_t* up, const gptq_layer_t* down, const void* x, void* out, int M,
                      void* ws, size_t ws_bytes, void* stream) {
     return gptq_mlp_forward_ex(gate, up, down, x, out, M, ws, ws_bytes, stream, nullptr);
@@ -676,6 +688,18 @@ int gptq_mlp_forward_ex(const gptq_layer_t* gate, const gptq_layer_t* up, const 
     const gptq_layer_t* gu[2] = {gate, up};
     void* outs[2] = {hg, hu};
     if ((rc = forward_multi_core(gu, 2, x, outs, M, inner, stream, nullptr))) return rc;
+    // An act-order `down` whose kernel reads x permuted in natural order (the decode-copy GEMMs: panel / rows / stream-K / wide tiles): SiLU * mul and that
+    // permute are ONE pass into the spot down's own pre-pass would have filled (round 6; the reference's fused MLP, fused_llama_mlp.py:131-306)
+    if (mlp_fused_permute(down, M)) {
+        const GemmPlan pl = plan_gemm(*down, M, nullptr);
+        if (pl.workspace_bytes > inner.body_bytes)
+            return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", gptq_workspace_bytes_mlp_ex(gate, up, down, M, tune), have);
+        hipError_t e = launch_silu_mul2_permute(hg, hu, down->perm, M, down->K, down->dtype, inner.body, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "silu_mul + permute launch (was gptq_init() called on this device?)");
+        e = launch_gemm(*down, pl, inner.body, out, M, inner.header, inner.body, (hipStream_t)stream, /*x_permuted=*/true);
+        if (e != hipSuccess) return hip_fail(e, "gptq_gemm launch (down projection of gptq_mlp_forward)");
+        return GPTQ_OK;
+    }
     hipError_t e = launch_silu_mul2(hg, hu, hg, (size_t)M * gate->N, gate->dtype, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "silu_mul launch");
     return forward_impl(down, hg, out, M, inner, stream, nullptr);
@@ -689,7 +713,8 @@ int gptq_describe_mlp_plan(const gptq_layer_t* gate, const gptq_layer_t* up, con
     if (rc) return rc;
     if (M <= 0) return fail(GPTQ_ERR_SHAPE, "M must be > 0, got %d", M);
     (void)tune;
-    snprintf(out, out_bytes, "kernel=unfused launches=3+ steps=forward_multi(gate,up)|silu_mul|forward(down)");
+    if (mlp_fused_permute(down, M)) snprintf(out, out_bytes, "kernel=unfused launches=3 steps=forward_multi(gate,up)|silu_mul+permute|gemm(down) down_permute=fused");
+    else snprintf(out, out_bytes, "kernel=unfused launches=3+ steps=forward_multi(gate,up)|silu_mul|forward(down) down_permute=%s", (down->g_idx && M > 4) ? "own_pass" : "none");
     return GPTQ_OK;
 }
 

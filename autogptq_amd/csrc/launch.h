@@ -157,6 +157,8 @@ hipError_t launch_unprepack_decode(const uint32_t* tiled, int K, int N, int bits
 bool stream_preferred(const gptq_layer_t& L, int M);                              // single layer: streamed kernel instead of the register one?
 bool multi_preferred(const gptq_layer_t* const* layers, int n, int M);             // several layers sharing x: one streamed launch?
 hipError_t launch_silu_mul2(const void* g, const void* u, void* out, size_t total, int dtype, hipStream_t st);
+bool silu_mul2_permute_ok(int K, int dtype);            // mlp.hip: SiLU * mul and the x permute of an act-order down projection in one pass
+hipError_t launch_silu_mul2_permute(const void* g, const void* u, const int32_t* perm, int M, int K, int dtype, void* out, hipStream_t st);
 hipError_t init_mlp_device();
 // gemm_wide.hip: 128 x 512 prefill tiles, 128 x 128 per wave with the accumulators in AGPRs (4-bit fp16 / bf16; glds: x in k-slot order, staged by LDS DMA)
 bool wide_gemm_ok(const gptq_layer_t& L, int M, bool use_seq, bool xslot_glds);

@@ -100,11 +100,20 @@ def autogptq_post_init(model: nn.Module, use_act_order: bool = False, max_input_
             continue
         if sub.qweight.device.type != "cuda":
             continue
+        dev = sub.qweight.device                      # read BEFORE post_init: release_checkpoint_layout moves qweight to pinned host memory, and the scratch belongs to the layer's GPU
         sub.post_init(tiled=decode_copy, release_checkpoint_layout=release_checkpoint_layout)
         lib = _lib.load()
         # the need is not monotone in M (K splits come and go with the kernel the planner picks): maximum over 1..rows
-        b = int(lib.gptq_workspace_bytes_max(ctypes.byref(sub._layer), rows))
-        need[sub.qweight.device] = max(need.get(sub.qweight.device, 0), b)
+        parts = getattr(sub, "_parts", None)
+        if parts is not None:
+            # fused-QKV g_idx (len n * K): the module runs its n column blocks through forward_multi -- the blocks' own needs and the one-launch need of the group
+            b = max(int(lib.gptq_workspace_bytes_max(ctypes.byref(p._layer), rows)) for p in parts)
+            arr = (ctypes.POINTER(_lib.GptqLayer) * len(parts))(*[ctypes.pointer(p._layer) for p in parts])
+            for m in range(1, rows + 1):                  # host arithmetic only (a few microseconds per query)
+                b = max(b, int(lib.gptq_workspace_bytes_multi(arr, len(parts), m)))
+        else:
+            b = int(lib.gptq_workspace_bytes_max(ctypes.byref(sub._layer), rows))
+        need[dev] = max(need.get(dev, 0), b)
     for dev, b in need.items():
         reserve_workspace(dev, b)
     return model

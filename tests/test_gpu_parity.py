@@ -1105,6 +1105,49 @@ def test_mlp_forward_one_call(M, dtype, bits, act):
         assert torch.equal(m.qweight, b)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_mlp_forward_act_order_down_reads_the_permuted_activations_of_the_silu_pass(dtype):
+    """Round 6: where the act-order `down` of gptq_mlp_forward runs a decode-copy GEMM (x permuted in the natural order of its re-sequenced rows), SiLU * mul and
+    that permute are ONE pass (csrc/mlp.hip silu_mul2_permute_rows4_kernel) -- no permute launch of down's own, one round trip of the [M, I] activations less.
+    The reference's fused MLP hands c_proj the activations in the order its rows are stored in (fused_llama_mlp.py:131-306; exllama's x_map,
+    exllama/cuda_func/q4_matmul.cu:92-126).  Checked: the plan says so at the batched / prefill row counts and not at decode rows (in-kernel gather); the permuted
+    activations left in the workspace are silu(g) * u of the STAGED gate / up outputs gathered through down's perm, entry by entry; the output against the fp64
+    oracle of the whole expression; bit-reproducible; checkpoint tensors untouched."""
+    from autogptq_amd import qlinear_mi355x as qm
+    from autogptq_amd.qlinear_mi355x import mlp_forward
+    K, I, N = 1024, 2048, 1024
+    Ls, (mg, mu, md) = _mlp_layers(K, I, N, 4, 128, dtype, True, 640)
+    before = [m.qweight.clone() for m in (mg, mu, md)]
+    esz = 2
+    for M in (2, 8, 64, 300, 2048):
+        x = (torch.rand(M, K, generator=torch.Generator().manual_seed(M)) - 0.5).to(dtype)
+        with torch.no_grad():
+            y = mlp_forward(mg, mu, md, x.to(DEV))
+            y2 = mlp_forward(mg, mu, md, x.to(DEV))
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2)
+        plan = _lib.describe_mlp_plan(mg._layer, mu._layer, md._layer, M)
+        assert plan["down_permute"] == ("fused" if M > 4 else "none"), (M, plan)
+        if M > 4:
+            ws = qm._WORKSPACE[(torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))][0]
+            sb = (M * I * esz + 255) // 256 * 256
+            o = _lib.WS_HEADER_BYTES
+            g = ws[o:o + M * I * esz].view(dtype).reshape(M, I).float()
+            u = ws[o + sb:o + sb + M * I * esz].view(dtype).reshape(M, I).float()
+            xp = ws[o + 2 * sb:o + 2 * sb + M * I * esz].view(dtype).reshape(M, I)
+            want = (g / (1 + torch.exp(-g)) * u)[:, md._keepalive[6].long()]
+            ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+            assert bool(((xp.float() - want).abs() <= 1.01 * ulp * want.abs() + 1e-7).all()), f"M={M}: the permuted activations are not silu(g) * u gathered through down's perm"
+        ref, gmax = _mlp_oracle(x, Ls, 4, True, dtype)
+        assert gmax > 0.5
+        rtol, atol = {torch.float16: (4e-3, 2e-3), torch.bfloat16: (3e-2, 1.6e-2)}[dtype]
+        scale = float(ref.abs().max())
+        err = (y.double().cpu() - ref).abs()
+        assert bool((err <= rtol * ref.abs() + atol * scale).all()), (M, float(err.max()), scale)
+    for m, b in zip((mg, mu, md), before):
+        assert torch.equal(m.qweight, b)
+
+
 def test_mlp_forward_takes_no_path_override():
     """Round 3's one-launch persistent MLP kernel (tuning.path = 7) was a measured negative result and is a lab now (tools/lab/mlp_ring.hip): the
     product entry point refuses a path override loudly instead of silently running something else, and every product entry point is bit-reproducible

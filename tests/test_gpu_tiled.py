@@ -575,3 +575,48 @@ def test_release_checkpoint_layout_keeps_one_copy_on_the_device(dtype):
     x, _ = _x(16, L["K"], dtype, 5, hot=False)
     with torch.no_grad():
         assert torch.equal(rel2(x), keep(x))
+
+
+def test_autogptq_post_init_on_a_model_with_a_fused_qkv_g_idx_layer_and_with_released_rows():
+    """autogptq_post_init (the model-level entry point, auto_gptq/modeling/_utils.py:380-513 in the reference): (i) a module whose g_idx has n * K entries (the
+    reference's fused q/k/v of act-order projections) is initialised through its n internal column blocks -- their workspace needs are counted, nothing is
+    dereferenced through the module's own (absent) layer struct; (ii) release_checkpoint_layout=True moves qweight to host memory and the scratch is still
+    sized on the LAYER'S GPU, so the forward calls that follow allocate nothing (the scratch tensor of the stream is the one post_init reserved)."""
+    import torch.nn as nn
+    from autogptq_amd import qlinear_mi355x as qm
+    from autogptq_amd.model_utils import autogptq_post_init
+    K = 512
+    Ls = [O.random_quant_layer(K, K, 4, 128, act_order=True, seed=170 + i, bias=True) for i in range(3)]
+    f = QuantLinear(4, 128, K, 3 * K, True)
+    f.qweight = torch.cat([L["qweight"] for L in Ls], dim=1)
+    f.qzeros = torch.cat([L["qzeros"] for L in Ls], dim=1)
+    f.scales = torch.cat([L["scales"] for L in Ls], dim=1)
+    f.g_idx = torch.cat([L["g_idx"] for L in Ls], dim=0)
+    f.bias = torch.cat([L["bias"] for L in Ls], dim=0)
+    Lp = O.random_quant_layer(K, 1024, 4, 128, seed=180, bias=True)
+    p = QuantLinear(4, 128, K, 1024, True)
+    p.qweight, p.qzeros, p.scales, p.g_idx, p.bias = Lp["qweight"], Lp["qzeros"], Lp["scales"], Lp["g_idx"], Lp["bias"]
+
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.qkv, self.proj = f, p
+    model = Block().to(DEV)
+    model = autogptq_post_init(model, use_act_order=True, max_input_length=300, release_checkpoint_layout=True)
+    assert model.qkv._parts is not None and len(model.qkv._parts) == 3
+    assert model.proj._released and model.proj.qweight.device.type == "cpu"
+    idx = torch.device(DEV).index or 0
+    key = (idx, int(torch.cuda.current_stream(DEV).cuda_stream))
+    assert key in qm._WORKSPACE and all(k[0] == idx for k in qm._WORKSPACE), "the scratch was sized on another device than the layers'"
+    reserved = qm._WORKSPACE[key][0]
+    mode = O.reference_zero_mode(True, 4)
+    W = torch.cat([O.dequantize(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], 4, mode) for L in Ls], dim=1).to(DEV)
+    bias = torch.cat([L["bias"] for L in Ls]).to(DEV)
+    Wp = O.dequantize(Lp["qweight"], Lp["qzeros"], Lp["scales"], Lp["g_idx"], 4, O.reference_zero_mode(False, 4)).to(DEV)
+    for M in (1, 4, 40, 200, 300):
+        x, _ = _x(M, K, torch.float16, M, hot=False)
+        with torch.no_grad():
+            y, yp = model.qkv(x), model.proj(x)
+        _assert_all(y, x, W, bias, torch.float16, f"fused q|k|v after autogptq_post_init, M={M}")
+        _assert_all(yp, x, Wp, Lp["bias"].to(DEV), torch.float16, f"released layer after autogptq_post_init, M={M}")
+        assert qm._WORKSPACE[key][0] is reserved, f"forward at M={M} replaced the scratch autogptq_post_init reserved (an allocation on the forward path)"

@@ -836,20 +836,25 @@ def test_batched_decode_rows_kernel_rules():
                 for M in (5, 8, 16, 33, 64):
                     for act in (False, True):
                         d, need = plan(bits, gs, K, N, M, act)
+                        if bits == 4 and gs >= 64 and M == 64 and N >= 8192 and K <= 4096:      # round 6: 64 rows of the wide layers = 172+ tiles of the panel kernel
+                            assert d["kernel"] == "panel", (bits, gs, K, N, M, act, d)
+                            continue
                         assert d["kernel"] == "rows", (bits, gs, K, N, M, act, d)
                         rb, s = int(d["mt"]), int(d["tiles"].split("x")[1])
                         assert rb in (1, 2) and int(d["tiles"].split("x")[0]) == -(-M // (16 * rb)), d      # (the 64-row form only from 129 rows)
                         per = -(-(N // 16) // s)                      # strips per workgroup
                         assert per in (1, 2, 3, 4, 6) and (per != 6 or (bits == 4 and rb == 2)) and not (bits == 8 and rb == 1 and per == 4), d
                         assert need == (65536 + (M * K * 2 + 255) // 256 * 256 if act else 0), (d, need)      # header + permuted x, or nothing
-    for M in (96, 128):
-        assert plan(4, 128, 4096, 4096, M)[0]["kernel"] == "rows" and plan(4, 128, 11008, 4096, M)[0]["kernel"] == "rows"
+    for M in (96, 128):                                          # (round 6: the panel kernel takes 4096^2 from 96 rows; deep layers at few rows stay here)
+        assert plan(4, 128, 4096, 4096, M)[0]["kernel"] == "panel" and plan(4, 128, 11008, 4096, M)[0]["kernel"] == "rows"
+        assert plan(3, 128, 4096, 4096, M)[0]["kernel"] == "rows" and plan(4, 32, 4096, 4096, M)[0]["kernel"] == "rows"      # (no panel form for 3 / 8 bits and 32-wide groups)
         assert plan(4, 128, 4096, 11008, M)[0]["kernel"] != "rows" and plan(4, 128, 8192, 8192, M)[0]["kernel"] != "rows"
     for M in (1, 2, 4):
         assert plan(4, 128, 4096, 4096, M)[0]["kernel"] == "strips"
-    for M in (129, 192, 256):                                    # short prompts: the 64-row form, 4 bits only
-        d = plan(4, 128, 4096, 4096, M)[0]
+    for M in (129, 192, 256):                                    # short prompts: the 64-row form, 4 bits only -- where the panel kernel (round 6) does not take the launch: 32-wide groups
+        d = plan(4, 32, 4096, 4096, M)[0]
         assert d["kernel"] == "rows" and d["mt"] in ("2", "4"), d
+        assert plan(4, 128, 4096, 4096, M)[0]["kernel"] == "panel"
         assert plan(3, 128, 4096, 4096, M)[0]["kernel"] != "rows" and plan(4, 128, 4096, 11008, M)[0]["kernel"] != "rows"
     assert plan(4, 128, 4096, 4096, 257)[0]["kernel"] != "rows" and plan(4, 128, 4096, 4096, 16, copy=False)[0]["kernel"] != "rows"
     assert plan(4, 128, 8192, 28672, 16)[0]["kernel"] != "rows" and plan(4, 128, 512, 4096, 16)[0]["kernel"] != "rows"      # several rounds of workgroups / a small layer
@@ -1001,3 +1006,55 @@ def test_tools_and_bench_parse():
                     if a.name != "*" and a.name not in defined[node.module] and a.name not in submodules.get(node.module, ()):
                         missing.append((os.path.relpath(f, root), node.module, a.name))
     assert not missing, missing
+
+
+def test_panel_kernel_is_planned_where_its_tiles_fill_the_chip():
+    """gptq_describe_plan (host only), round 6: the whole-K panel kernel (csrc/gemm_panel.hip) on layers that carry their decode copy -- chosen where its 64-row
+    tiles fill the 256 CUs (>= ~160 tiles per round) and the measured competitors lose (profiles/r06_panel_sweep_cold.log): 96 ... 767 rows on 4096 -> 4096, up to
+    384 rows on 4096 -> 11008 (stream-K from 512), 160 ... 512 rows on 11008 -> 4096; never without a decode copy, for 3 / 8 bits, 32-wide groups or an epilogue;
+    geometry = the time model's choice (tiles 64 x 32 NT); forced geometries through the lab knob; workspace = the permuted x of act-order layers only."""
+    lib = _lib.load()
+
+    def plan(K, N, M, copy=True, act=False, tune=None, **kw):
+        L = _layer(K=K, N=N, **kw)
+        if copy:
+            L.qweight_tiled = L.qconst_tiled = 0x2000
+            L.tiled_cols = 16
+        if act:
+            L.g_idx = L.qweight_seq = L.perm = 0x1000
+        return _lib.describe_plan(L, M, tune), L
+
+    want = {
+        (4096, 4096): {64: "rows", 96: "panel", 128: "panel", 256: "panel", 512: "panel", 767: "panel", 768: "wide_sk", 2048: "wide_sk"},
+        (4096, 11008): {33: "rows", 64: "panel", 128: "panel", 384: "panel", 512: "wide_sk", 2048: "wide_sk"},
+        (11008, 4096): {64: "rows", 128: "rows", 160: "panel", 512: "panel", 640: "wide_sk"},
+        (8192, 1024): {128: "rows", 256: "rows", 512: "panel", 768: "panel"},
+        (28672, 1024): {256: "rows", 512: "tiled", 768: "panel"},
+        (8192, 28672): {128: "tiled", 256: "tiled", 512: "wide_sk"},
+    }
+    for (K, N), by_m in want.items():
+        for M, kern in by_m.items():
+            p, _ = plan(K, N, M)
+            assert p["kernel"] == kern, (K, N, M, p)
+    # tile geometry: 64 rows x 32 NT columns, NT from the time model (one round of 256 tiles where it exists)
+    assert plan(4096, 4096, 256)[0]["tiles"] == "4x64" and plan(4096, 4096, 512)[0]["tiles"] == "8x32" and plan(4096, 11008, 128)[0]["tiles"] == "2x115"
+    p, _ = plan(4096, 4096, 512)
+    assert (p["mt"], p["bk"], p["waves"], p["ksplit"], p["perm"]) == (2, 64, 8, 1, 0), p
+    # not without the decode copy, not for the other packings / 32-wide groups / a fused epilogue
+    assert plan(4096, 4096, 256, copy=False)[0]["kernel"] != "panel"
+    for kw in (dict(bits=3, group_size=128), dict(bits=8, group_size=128), dict(group_size=32)):
+        assert plan(4096, 4096, 256, **kw)[0]["kernel"] != "panel", kw
+    p, _ = plan(4096, 4096, 256, epilogue=1)                     # a [gate | up] layer: the kernel runs on the plain layer, SiLU * mul is a separate pass over the staged y
+    assert p["kernel"] == "panel" and p["epilogue"] == "separate", p
+    # act-order: x permuted in natural order by the pre-pass; the workspace is that and nothing else
+    p, L = plan(4096, 4096, 300, act=True)
+    assert p["kernel"] == "panel" and p["perm"] == 1, p
+    assert int(lib.gptq_workspace_bytes(ctypes.byref(L), 300)) == 65536 + 300 * 4096 * 2
+    p, L = plan(4096, 4096, 300)
+    assert int(lib.gptq_workspace_bytes(ctypes.byref(L), 300)) == 0
+    # the lab knob forces it (and a geometry) wherever it is legal, and switches it off
+    t = _lib.GptqTuning()
+    t.path, t.reserved[_lib.LAB.GEMM_VARIANT], t.reserved[0] = 3, _lib.LAB.VARIANT_PANEL_ON, 23
+    assert plan(1024, 256, 64, tune=t)[0]["kernel"] == "panel" and plan(1024, 256, 64, tune=t)[0]["tiles"] == "1x3"
+    t.reserved[_lib.LAB.GEMM_VARIANT], t.reserved[0] = _lib.LAB.VARIANT_PANEL_OFF, 0
+    assert plan(4096, 4096, 256, tune=t)[0]["kernel"] != "panel"

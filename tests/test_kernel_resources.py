@@ -74,3 +74,13 @@ def test_hot_kernels_stay_inside_their_register_budget():
     assert len(rows) >= 2 * 3 * (9 + 8 + 8) + 24, len(rows)
     spilled = {n for n, v in rows.items() if (v["spill"] or 0) or (v["scratch"] or 0)}
     assert all("gemm_rows_kernel" in n and "Li8ELi1ELi4E" in n for n in spilled), sorted(spilled)[:4]      # <T, 8, 1, 4, GM> only
+
+
+def test_panel_kernels_hold_their_in_flight_loads_in_registers():
+    """Round 6 (csrc/gemm_panel.hip): 8 waves per workgroup = two per SIMD = 256 registers per lane; the weight / constant loads are inline asm whose results sit in
+    registers across a hand-counted s_waitcnt, so a spilled one would be stored before it has landed: every instantiated form is spill-free and scratch-free."""
+    ks = _kernels()
+    panel = {n: v for n, v in ks.items() if "gemm_panel_kernel" in n}
+    assert len(panel) == 2 * 4, sorted(panel)                        # <T, 2, NT = 1..4, 8, false> x fp16 / bf16
+    for n, v in panel.items():
+        assert (v["vgpr"] or 0) + 0 <= 256 and (v["spill"] or 0) == 0 and (v["scratch"] or 0) == 0, (n, v)
