@@ -714,7 +714,11 @@ int gptq_describe_mlp_plan(const gptq_layer_t* gate, const gptq_layer_t* up, con
     if (M <= 0) return fail(GPTQ_ERR_SHAPE, "M must be > 0, got %d", M);
     (void)tune;
     if (mlp_fused_permute(down, M)) snprintf(out, out_bytes, "kernel=unfused launches=3 steps=forward_multi(gate,up)|silu_mul+permute|gemm(down) down_permute=fused");
-    else snprintf(out, out_bytes, "kernel=unfused launches=3+ steps=forward_multi(gate,up)|silu_mul|forward(down) down_permute=%s", (down->g_idx && M > 4) ? "own_pass" : "none");
+    else {
+        const gptq_layer_t* one[1] = {down};
+        const char* dp = !down->g_idx ? "none" : (want_tiled(one, 1, M, nullptr) ? "in_kernel" : "own_pass");      // (decode rows: the decode kernel gathers x through perm itself)
+        snprintf(out, out_bytes, "kernel=unfused launches=3+ steps=forward_multi(gate,up)|silu_mul|forward(down) down_permute=%s", dp);
+    }
     return GPTQ_OK;
 }
 

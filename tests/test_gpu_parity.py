@@ -1117,6 +1117,8 @@ def test_mlp_forward_act_order_down_reads_the_permuted_activations_of_the_silu_p
     from autogptq_amd.qlinear_mi355x import mlp_forward
     K, I, N = 1024, 2048, 1024
     Ls, (mg, mu, md) = _mlp_layers(K, I, N, 4, 128, dtype, True, 640)
+    for m in (mg, mu, md):
+        m.post_init(tiled=True)                                         # (this file runs with QuantLinear.TILED_DECODE = False: these layers carry their decode copy)
     before = [m.qweight.clone() for m in (mg, mu, md)]
     esz = 2
     for M in (2, 8, 64, 300, 2048):
@@ -1127,8 +1129,11 @@ def test_mlp_forward_act_order_down_reads_the_permuted_activations_of_the_silu_p
         torch.cuda.synchronize()
         assert torch.equal(y, y2)
         plan = _lib.describe_mlp_plan(mg._layer, mu._layer, md._layer, M)
-        assert plan["down_permute"] == ("fused" if M > 4 else "none"), (M, plan)
-        if M > 4:
+        pd = _lib.describe_plan(md._layer, M)
+        fused = pd["path"] == "gemm" and pd["kernel"] in ("rows", "panel", "wide_sk", "wide_copy")      # the decode-copy GEMMs: x permuted in natural order
+        assert (plan["down_permute"] == "fused") == fused, (M, plan, pd)
+        assert fused == (M > 4), (M, pd)                                # (decode rows: the decode kernel gathers x itself)
+        if fused:
             ws = qm._WORKSPACE[(torch.cuda.current_device(), int(torch.cuda.current_stream().cuda_stream))][0]
             sb = (M * I * esz + 255) // 256 * 256
             o = _lib.WS_HEADER_BYTES
