@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.cuh"
@@ -652,7 +653,8 @@ size_t gptq_workspace_bytes_mlp_ex(const gptq_layer_t* gate, const gptq_layer_t*
 
 // down of gptq_mlp_forward: does its call at M rows run an MFMA GEMM that reads x permuted in NATURAL order of its re-sequenced rows (GemmPlan.xnat)?  Then the
 // SiLU * mul pass writes that permuted x itself.  (Decode rows gather inside the kernel, fp32 and the checkpoint-row kernels have their own orders: unchanged.)
-static bool mlp_fused_permute(const gptq_layer_t* down, int M) {
+static bool mlp_fused_permute(const gptq_layer_t* down, int M, const gptq_tuning_t* tune) {
+    if (tune && tune->reserved[3] == GPTQ_LAB_VARIANT_MLP_TWO_PASSES) return false;      // lab (bench.py: the two passes of round 5, interleaved with the default)
     if (!down->g_idx || !down->perm || !down->qweight_seq || down->epilogue != GPTQ_EPI_NONE) return false;
     if (!silu_mul2_permute_ok(down->K, down->dtype)) return false;
     const gptq_layer_t* one[1] = {down};
@@ -690,7 +692,7 @@ int gptq_mlp_forward_ex(const gptq_layer_t* gate, const gptq_layer_t* up, const 
     if ((rc = forward_multi_core(gu, 2, x, outs, M, inner, stream, nullptr))) return rc;
     // An act-order `down` whose kernel reads x permuted in natural order (the decode-copy GEMMs: panel / rows / stream-K / wide tiles): SiLU * mul and that
     // permute are ONE pass into the spot down's own pre-pass would have filled (round 6; the reference's fused MLP, fused_llama_mlp.py:131-306)
-    if (mlp_fused_permute(down, M)) {
+    if (mlp_fused_permute(down, M, tune)) {
         const GemmPlan pl = plan_gemm(*down, M, nullptr);
         if (pl.workspace_bytes > inner.body_bytes)
             return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", gptq_workspace_bytes_mlp_ex(gate, up, down, M, tune), have);
@@ -712,8 +714,7 @@ int gptq_describe_mlp_plan(const gptq_layer_t* gate, const gptq_layer_t* up, con
     int rc = check_mlp(gate, up, down);
     if (rc) return rc;
     if (M <= 0) return fail(GPTQ_ERR_SHAPE, "M must be > 0, got %d", M);
-    (void)tune;
-    if (mlp_fused_permute(down, M)) snprintf(out, out_bytes, "kernel=unfused launches=3 steps=forward_multi(gate,up)|silu_mul+permute|gemm(down) down_permute=fused");
+    if (mlp_fused_permute(down, M, tune)) snprintf(out, out_bytes, "kernel=unfused launches=3 steps=forward_multi(gate,up)|silu_mul+permute|gemm(down) down_permute=fused");
     else {
         const gptq_layer_t* one[1] = {down};
         const char* dp = !down->g_idx ? "none" : (want_tiled(one, 1, M, nullptr) ? "in_kernel" : "own_pass");      // (decode rows: the decode kernel gathers x through perm itself)

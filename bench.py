@@ -187,6 +187,58 @@ def bench_mlp_call(flat_layers, xs, device, steps):
     return res
 
 
+def bench_mlp_prefill(device, steps, M=2048, n_blocks=4):
+    """The gated MLP of act-order (desc_act) Llama-7B blocks at prefill rows through gptq_mlp_forward: round 6 writes silu(g) * u straight in the order down's
+    re-sequenced rows expect (one pass instead of SiLU * mul + down's own permute launch).  Timed against the two passes of round 5 (lab knob 54), interleaved
+    graph replays over rotating blocks; `down_part_us` = the call minus its [gate | up] launches timed on their own."""
+    from autogptq_amd import _lib
+    from autogptq_amd.qlinear_mi355x import mlp_forward, forward_multi
+    blocks = []
+    for b in range(n_blocks):
+        g_ = make_layer(4096, 11008, device, act_order=True, seed=3000 + 3 * b, order_seed=3500 + b)
+        u_ = make_layer(4096, 11008, device, act_order=True, seed=3001 + 3 * b, order_seed=3500 + b)
+        d_ = make_layer(11008, 4096, device, act_order=True, seed=3002 + 3 * b)
+        blocks.append((g_, u_, d_))
+    x = (torch.rand(M, 4096, device=device) - 0.5).half()
+    two = _lib.GptqTuning()
+    two.reserved[_lib.LAB.GEMM_VARIANT] = _lib.LAB.VARIANT_MLP_TWO_PASSES
+    graphs = {}
+    for name, tn in (("fused_permute", None), ("two_passes", two)):
+        with torch.no_grad():
+            for g_, u_, d_ in blocks:
+                mlp_forward(g_, u_, d_, x, tuning=tn)
+        torch.cuda.synchronize(device)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr), torch.no_grad():
+            keep = [mlp_forward(g_, u_, d_, x, tuning=tn) for g_, u_, d_ in blocks]
+        graphs[name] = (gr, keep)
+    with torch.no_grad():
+        for g_, u_, _ in blocks:
+            forward_multi([g_, u_], x)
+    torch.cuda.synchronize(device)
+    gu = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gu), torch.no_grad():
+        keep_gu = [forward_multi([g_, u_], x) for g_, u_, _ in blocks]
+    graphs["gate_up_only"] = (gu, keep_gu)
+    best = {}
+    reps = max(3, steps // 2)
+    for _ in range(3):                                    # interleaved rounds, minimum per variant
+        for name, (gr, _) in graphs.items():
+            gr.replay()
+            _, ev = time_graph(gr, reps, device)
+            best[name] = min(best.get(name, 1e9), ev / (reps * len(blocks)))
+    res = {"M": M, "blocks": len(blocks), "plan": _lib.describe_mlp_plan(blocks[0][0]._layer, blocks[0][1]._layer, blocks[0][2]._layer, M),
+           "us_per_mlp": round(best["fused_permute"] * 1e6, 2), "us_per_mlp_two_passes": round(best["two_passes"] * 1e6, 2),
+           "gate_up_us": round(best["gate_up_only"] * 1e6, 2),
+           "down_part_us": round((best["fused_permute"] - best["gate_up_only"]) * 1e6, 2), "down_part_us_two_passes": round((best["two_passes"] - best["gate_up_only"]) * 1e6, 2),
+           "TFLOP_s": round(2 * M * 3 * 4096 * 11008 / best["fused_permute"] / 1e12, 1)}
+    same = all(torch.equal(a, b) for a, b in zip(graphs["fused_permute"][1], graphs["two_passes"][1]))
+    res["fused_equals_two_passes_bitwise"] = bool(same)
+    del graphs, blocks
+    torch.cuda.empty_cache()
+    return res
+
+
 def capture(layers, xs, device):
     """Capture one forward of every layer into a graph; returns (graph, keepalive outputs)."""
     from autogptq_amd.qlinear_mi355x import reserve_workspace
@@ -268,6 +320,23 @@ def time_graph(g, reps, device, dist_barrier=None):
         dist_barrier()
     t1 = time.perf_counter()
     return t1 - t0, e0.elapsed_time(e1) * 1e-3
+
+
+def time_graph_each(g, reps, device):
+    """Seconds of each of `reps` replays (HIP events between consecutive replays): the spread behind a mean (p10 / p50 / p90 per launch type)."""
+    torch.cuda.synchronize(device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        g.replay()
+        ev[i + 1].record()
+    torch.cuda.synchronize(device)
+    return [ev[i].elapsed_time(ev[i + 1]) * 1e-3 for i in range(reps)]
+
+
+def _pctl(v, q):
+    v = sorted(v)
+    return v[min(len(v) - 1, max(0, int(round(q * (len(v) - 1)))))]
 
 
 def pmc_traffic(kernel, K, N, M, exact=False):
@@ -577,23 +646,45 @@ def cpu_baseline(M, act_order, budget_s=20.0):
     torch.set_num_threads(threads)
     total_b, total_t, reps_done = 0, 0.0, []
     per_shape = budget_s / 3
+    # Where the reference tree is present (the build container; it does not travel to the GPU box) its OWN class is what is timed -- kind "reference":
+    # auto_gptq/nn_modules/qlinear/qlinear_cuda_old.py (qlinear_cuda.py for act-order) loaded by file path, as tools/time_reference_cpu.py does.
+    ref_cls = None
+    ref_root = os.environ.get("GPTQ_REFERENCE", "/root/reference")
+    ref_file = os.path.join(ref_root, "auto_gptq/nn_modules/qlinear", "qlinear_cuda.py" if act_order else "qlinear_cuda_old.py")
+    if os.path.exists(ref_file):
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("ref_qlinear_for_bench", ref_file)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            ref_cls = mod.QuantLinear
+        except Exception:
+            ref_cls = None
     for K, N in ((4096, 4096), (4096, 11008), (11008, 4096)):
         L = O.random_quant_layer(K, N, 4, 128, act_order=act_order, seed=1)
         x = (torch.rand(M, K) - 0.5).half()
         mode = O.reference_zero_mode(act_order, 4)
         gi = L["g_idx"] if act_order else None
-        O.forward_fast(x, L["qweight"], L["qzeros"], L["scales"], gi, None, 4, mode)   # warm-up
-        n, t_acc = 0, 0.0
-        while t_acc < per_shape and n < 200:                         # ~ 15-20 s of host work in total
-            t0 = time.perf_counter()
-            O.forward_fast(x, L["qweight"], L["qzeros"], L["scales"], gi, None, 4, mode)
-            t_acc += time.perf_counter() - t0
-            n += 1
+        if ref_cls is not None:
+            q = ref_cls(4, 128, K, N, False)
+            q.qweight, q.qzeros, q.scales, q.g_idx = L["qweight"], L["qzeros"], L["scales"], L["g_idx"]
+            fwd = lambda: q(x)                                        # noqa: E731
+        else:
+            fwd = lambda: O.forward_fast(x, L["qweight"], L["qzeros"], L["scales"], gi, None, 4, mode)      # noqa: E731
+        with torch.no_grad():
+            fwd()                                                    # warm-up
+            n, t_acc = 0, 0.0
+            while t_acc < per_shape and n < 200:                     # ~ 15-20 s of host work in total
+                t0 = time.perf_counter()
+                fwd()
+                t_acc += time.perf_counter() - t0
+                n += 1
         total_b += n * algorithmic_bytes(K, N, M, act_order=act_order)
         total_t += t_acc
         reps_done.append(f"{K}x{N}x{n}")
-    return {"value": round(total_b / total_t / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
-            "sample": "oracle.forward_fast = the reference's own broadcast shift+mask unpack (qlinear_cuda_old.py:295-349) + torch.matmul, "
+    return {"value": round(total_b / total_t / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "reference" if ref_cls is not None else "port",
+            "sample": (("the reference's own QuantLinear.forward (%s, loaded by path), " % os.path.basename(ref_file)) if ref_cls is not None else
+                       "oracle.forward_fast = the reference's own broadcast shift+mask unpack (qlinear_cuda_old.py:295-349) + torch.matmul, ") +
                       "torch CPU fp16, M=%d, shapes x reps: %s" % (M, ", ".join(reps_done)),
             "ms_per_layer_mean": round(1e3 * total_t / sum(int(r.split('x')[2]) for r in reps_done), 2),
             # the reference CLASS itself (qlinear_cuda_old.QuantLinear.forward, imported from /root/reference) timed in the 8-core build container,
@@ -854,7 +945,7 @@ def main():
         for ent in layers:
             by_type.setdefault((ent[0] if isinstance(ent[3], list) else "", ent[1], ent[2]), []).append(ent)
         best = None
-        per_type = {}
+        per_type, spread = {}, {}
         for (gname, K, N), ls in by_type.items():
             gg, oo = capture(ls, xs, device)
             settle(gg, device)
@@ -865,6 +956,8 @@ def main():
             ent = dict(K=K, N=N, per_launch_s=per, share=share, n=len(ls), gname=gname, bytes=entry_bytes(ls[0], M, act_order),
                        kernel=_kernel_of(ls[0], M))
             per_type[(gname + ":" if gname else "") + f"{K}x{N}"] = round(per * 1e6, 3)
+            each = [t / len(ls) for t in time_graph_each(gg, max(20, 4 * reps), device)]      # per launch, one value per replay of the type's graph
+            spread[(gname + ":" if gname else "") + f"{K}x{N}"] = [round(_pctl(each, q) * 1e6, 3) for q in (0.1, 0.5, 0.9)]
             if best is None or share > best["share"]:
                 best = ent
             del gg, oo
@@ -884,6 +977,7 @@ def main():
         roof["shape"] = (f"{best['gname']}: " if best["gname"] else "") + f"K={K} N={N} M={M}" + (" (layers of one gptq_forward_multi launch)" if best["gname"] else "")
         roof["us_per_launch_events"] = round(best["per_launch_s"] * 1e6, 3)
         roof["us_per_launch_by_shape"] = per_type
+        roof["us_per_launch_p10_p50_p90_by_shape"] = spread
         roof["algorithmic_bytes_per_launch"] = best["bytes"]
         if prefill and act_order:
             roof["note"] = "per-launch time includes the x column-permute launch of act-order layers (rocprof splits them: profiles/)"
@@ -993,6 +1087,7 @@ def main():
                 out["fused_callers"] = {"error": repr(e)[:300]}
         if not prefill and world == 1 and not args.no_extras:
             for name, fn in (("prefill", lambda: bench_prefill(device, max(3, args.steps // 4))),
+                             ("mlp_prefill", lambda: bench_mlp_prefill(device, max(3, args.steps // 4))),
                              ("config5", lambda: bench_config5(device, args.steps)),
                              ("batched_decode", lambda: bench_batched(device, args.steps))):
                 try:
@@ -1038,6 +1133,13 @@ def main():
             # ... and once more as FLAT scalars: a parser that keeps only scalar members of `roofline` still records the second headline
             try:
                 roof["stack_frac"] = round(out["value"] / HBM_PEAK_GBS, 4)
+                if not prefill and roof.get("bound") == "hbm":
+                    # the line's fraction is the WHOLE STACK's (every launch type, launch boundaries included: what a decoded token pays); the dominant
+                    # launch type's own figures -- the ones rocprof's average duration of that kernel has to agree with -- stay beside it
+                    roof["dominant_launch_frac"], roof["dominant_launch_achieved"] = roof["frac"], roof["achieved"]
+                    roof["frac"], roof["achieved"] = roof["stack_frac"], round(out["value"], 1)
+                    roof["frac_is"] = "stack (all launch types of a step / 8 TB/s); dominant_launch_* = the [gate|up] launch alone (us_per_launch_events)"
+
                 roof["stack_GB_per_s"] = out["value"]
                 for nm, v in (roof.get("us_per_launch_by_shape") or {}).items():
                     roof["us_" + nm.replace(":", "_")] = v
@@ -1092,6 +1194,15 @@ def main():
                 if isinstance(mc, dict) and isinstance(mc.get("default_three_steps"), dict) and "us_per_mlp" in mc["default_three_steps"]:
                     roof["mlp_call_us"] = mc["default_three_steps"]["us_per_mlp"]
                     roof["mlp_call_frac"] = mc["default_three_steps"]["frac"]
+                mp = out.get("mlp_prefill")
+                if isinstance(mp, dict) and "us_per_mlp" in mp:      # desc_act MLP at 2048 rows through gptq_mlp_forward: down without a permute launch of its own
+                    for k in ("us_per_mlp", "us_per_mlp_two_passes", "down_part_us", "down_part_us_two_passes"):
+                        roof["mlp_prefill_" + k] = mp[k]
+                bd2 = out.get("batched_decode")
+                if isinstance(bd2, dict):
+                    for k in ("short_prompt_M256_4096x4096", "M512_4096x4096", "M512_4096x11008", "M512_11008x4096", "M128_4096x11008", "M128_4096x4096"):
+                        if isinstance(bd2.get(k), dict) and "us" in bd2[k]:
+                            roof[k.lower() + "_us"] = bd2[k]["us"]
             except Exception as e:
                 roof["flat_keys_error"] = repr(e)[:200]
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (bounded sample, ~25 s of host time)

@@ -49,6 +49,7 @@
 #define GPTQ_LAB_VARIANT_ROWS_OFF 51      /* never that kernel */
 #define GPTQ_LAB_VARIANT_PANEL_ON 52      /* the whole-K panel kernel (gemm_panel.hip) wherever it is legal; reserved[0] = 20 + NT (NT = column blocks of 32 per workgroup tile, 1..4; 0: the planner's) */
 #define GPTQ_LAB_VARIANT_PANEL_OFF 53     /* never that kernel */
+#define GPTQ_LAB_VARIANT_MLP_TWO_PASSES 54 /* gptq_mlp_forward_ex (path = 0): SiLU * mul and the x permute of an act-order down projection as the two passes of round 5 */
 /* (9..24, 32: ablation / timeline / ping-pong variants compiled only into tools/gemmlab with -DGPTQ_GEMM_ABLATIONS) */
 
 #endif /* GPTQ_MI355X_LAB_H */
