@@ -833,6 +833,94 @@ def bench_tp(device, rank, world, steps, peer_store=False):
     return res
 
 
+LLAMA70B_BLOCK = [("q_proj", 8192, 8192), ("k_proj", 8192, 1024), ("v_proj", 8192, 1024), ("o_proj", 8192, 8192),
+                  ("gate_proj", 8192, 28672), ("up_proj", 8192, 28672), ("down_proj", 28672, 8192)]
+
+
+def bench_tp_stack(device, rank, world, n_blocks, M, steps, warmup, exchange="all_gather"):
+    """BASELINE config 4 as a STACK (round 6: the N > 1 headline): the seven quantized linears of `n_blocks` Llama-2-70B decoder blocks (GQA: 1024-column k / v),
+    every layer split over out_features across the ranks (north_star: "the per-layer matmul shards naturally over out_features ... a single RCCL all-gather") --
+    rank r holds columns [r N / T, (r + 1) N / T) of every layer, runs its shard's kernel and the layer's outputs are all-gathered.  One step = M rows through all
+    7 n_blocks layers, ONE hipGraph per rank (the collectives captured with the kernels: RCCL captures like any other stream work); `steps` replays between
+    barrier + synchronize, MAX over ranks.  value = the algorithmic bytes of ALL shards per second (whole job).  The same graph WITHOUT the exchange is timed
+    beside it: what the all-gathers cost.  Falls back to eager calls when a capture fails (then launch-bound, and says so)."""
+    import torch.distributed as dist
+    from autogptq_amd.tensor_parallel import ColumnParallelQuantLinear
+    mods, shard_bytes = [], 0
+    for b in range(n_blocks):
+        for i, (name, K, N) in enumerate(LLAMA70B_BLOCK):
+            local = make_layer(K, N // world, device, seed=(b * 16 + i) * 64 + rank)
+            mods.append((K, local, ColumnParallelQuantLinear(local, N, exchange=exchange, max_rows=max(1, M))))
+            shard_bytes += algorithmic_bytes(K, N // world, M)
+    xs = {K: (torch.rand(M, K, device=device) - 0.5).half() for K in (8192, 28672)}
+
+    def step_with():
+        return [m(xs[K]) for K, _, m in mods]
+
+    def step_local():
+        return [l(xs[K]) for K, l, _ in mods]
+
+    def run(fn):
+        """(seconds per step, max over ranks; 'graph' | 'eager: <why>')"""
+        how, g, keep = "graph", None, None
+        ok = 1
+        try:
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side), torch.no_grad():
+                fn()
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize(device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side), torch.no_grad():
+                keep = fn()
+        except Exception as e:
+            ok, how = 0, "eager: capture failed (" + repr(e)[:120] + ")"
+        flag = torch.tensor([ok], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        use_graph = int(flag.item()) == 1
+        if not use_graph and ok:
+            how = "eager: capture failed on another rank"
+        with torch.no_grad():
+            one = (lambda: g.replay()) if use_graph else fn
+            for _ in range(max(1, warmup)):
+                one()
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            wall = time.perf_counter() - t0
+        t = torch.tensor([wall], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        del keep
+        return t.item() / steps, how
+
+    t_with, how_with = run(step_with)
+    t_loc, how_loc = run(step_local)
+    devs = [None] * world
+    dist.all_gather_object(devs, {"rank": rank, "device": str(device), "name": torch.cuda.get_device_name(device),
+                                  "pci": getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None)})
+    res = {"workload": "Llama-2-70B linear shapes (8192->8192 x2, 8192->1024 x2 (GQA k / v), 8192->28672 x2, 28672->8192) x %d blocks = %d layers, int4 g128, "
+                       "every layer split over out_features across %d ranks + one all-gather per layer, M=%d rows per step" % (n_blocks, len(mods), world, M),
+           "tp": world, "blocks": n_blocks, "layers": len(mods), "rows_per_step": M, "exchange": exchange,
+           "backend": dist.get_backend(), "nccl_world": dist.get_world_size(), "rank_devices": devs,
+           "ms_per_step": round(1e3 * t_with, 4), "ms_per_step_local_kernels_only": round(1e3 * t_loc, 4),
+           "exchange_ms_per_step": round(1e3 * (t_with - t_loc), 4), "exchange_share": round(max(0.0, t_with - t_loc) / t_with, 4),
+           "timed_as": how_with, "local_timed_as": how_loc,
+           "algorithmic_bytes_per_step_per_rank": shard_bytes,
+           "GB_per_s_per_gpu": round(shard_bytes / t_with / 1e9, 1), "GB_per_s": round(world * shard_bytes / t_with / 1e9, 1),
+           "GB_per_s_local_kernels_only": round(world * shard_bytes / t_loc / 1e9, 1),
+           "frac_per_gpu": round(shard_bytes / t_with / 1e9 / HBM_PEAK_GBS, 4),
+           "tokens_per_s": round(M / t_with, 1)}
+    del mods, xs
+    torch.cuda.empty_cache()
+    return res
+
+
 def _watchdog(seconds: float):
     """A wedged GPU call never returns to Python; a timer thread (the GIL is released inside HIP calls) ends the process
     instead of letting the launcher's own limit expire on a hung box."""
@@ -889,6 +977,8 @@ def main():
     ap.add_argument("--no-fused", action="store_true", help="skip the extra fused-callers measurement (decode, 1 GPU only)")
     ap.add_argument("--per-layer", action="store_true", help="decode: 224 separate launches per step (no gptq_forward_multi grouping)")
     ap.add_argument("--no-extras", action="store_true", help="decode, 1 GPU: skip the prefill / config5 / eager blocks of the default line")
+    ap.add_argument("--tp-blocks", type=int, default=16, help="N > 1: Llama-2-70B decoder blocks in the tensor-parallel stack (80 = the whole model)")
+    ap.add_argument("--no-tp-layers", action="store_true", help="N > 1: skip the per-layer tensor-parallel entries (roofline.tp<N>_attn_* ...), keep the stack")
     ap.add_argument("--tp-exchange", default="all_gather", choices=["all_gather", "peer_store"],
                     help="tp block: also time the experimental direct peer-store exchange (csrc/peer.hip) next to the collective")
     args = ap.parse_args()
@@ -1014,7 +1104,7 @@ def main():
     # The tensor-parallel block is extra information: it runs with the headline already built, under a deadline of its own -- a hung or failed
     # collective (one rank raising inside a capture while the others wait) costs the `tp` object, never the line the driver reads.
     if world > 1 and not args.no_tp and not prefill:
-        tp_limit = float(os.environ.get("BENCH_TP_DEADLINE_S", "150"))
+        tp_limit = float(os.environ.get("BENCH_TP_DEADLINE_S", "240"))
 
         def tp_expired():
             if rank == 0:
@@ -1026,7 +1116,14 @@ def main():
             os._exit(0)
         finish = _deadline(tp_limit, tp_expired)
         try:
-            tp = bench_tp(device, rank, world, 50, peer_store=(args.tp_exchange == "peer_store"))
+            tp = {}
+            # the N > 1 HEADLINE (round 6): the tensor-parallel stack of BASELINE config 4 -- north_star's partitioning, timed with its exchange
+            try:
+                tp["stack"] = bench_tp_stack(device, rank, world, args.tp_blocks, M, args.steps, args.warmup, exchange=args.tp_exchange)
+            except Exception as e:
+                tp["stack"] = {"error": repr(e)[:300]}
+            if not args.no_tp_layers:
+                tp.update(bench_tp(device, rank, world, 50, peer_store=(args.tp_exchange == "peer_store")))
         except Exception as e:                       # the headline line must still be printed
             tp = {"error": repr(e)[:300]}
         if not finish():
@@ -1053,7 +1150,26 @@ def main():
                             roof[pre + short + "_us"] = w_
                         if short == "attn" and w_ is not None and l_ is not None:
                             roof[pre + "local_us"], roof[pre + "allgather_us"] = l_, round(w_ - l_, 2)
-                    out["config"]["parallelism"] = f"dp{world} (headline: one token per rank through its own stack) + tp{world} entries for BASELINE config 4 in roofline.tp{world}_*"
+                    st = tp.get("stack")
+                    if isinstance(st, dict) and "GB_per_s" in st:
+                        # The tensor-parallel stack becomes the line's value; the data-parallel replicas (each rank its own Llama-7B stack: trivially linear) move
+                        # to `dp_replicas`.  Scaling is STRONG: the model is fixed, every added rank takes a smaller shard of every layer.
+                        out["dp_replicas"] = {k: out[k] for k in ("value", "unit", "ms_per_step", "tokens_per_s", "algorithmic_bytes_per_step") if k in out}
+                        out["dp_replicas"]["workload"] = out["config"]["workload"]
+                        out["value"], out["ms_per_step"], out["tokens_per_s"] = st["GB_per_s"], st["ms_per_step"], st["tokens_per_s"]
+                        out["algorithmic_bytes_per_step"] = st["algorithmic_bytes_per_step_per_rank"] * world
+                        out["scaling"] = "strong"
+                        out["metric"] = "int4 g128 QuantLinear fwd GB/s + tokens/s, Llama-2-70B shapes split over out_features (TP=%d) + one all-gather per layer" % world
+                        out["config"] = {"workload": st["workload"], "rows_per_step": M, "layers": st["layers"], "launches": st["layers"],
+                                         "parallelism": f"tp{world}", "exchange": st["exchange"], "backend": st["backend"], "nccl_world": st["nccl_world"],
+                                         "rank_devices": st["rank_devices"], "timed_as": st["timed_as"]}
+                        out["tokens_per_s_note"] = "linear-only (the %d quantized linears of %d Llama-2-70B blocks; no attention/norm)" % (st["layers"], st["blocks"])
+                        for k in ("ms_per_step", "ms_per_step_local_kernels_only", "exchange_ms_per_step", "exchange_share", "GB_per_s", "GB_per_s_per_gpu",
+                                  "GB_per_s_local_kernels_only", "frac_per_gpu"):
+                            roof[pre + "stack_" + k] = st[k]
+                        roof["dp_value_GB_per_s"] = out["dp_replicas"].get("value")
+                    else:
+                        out["config"]["parallelism"] = f"dp{world} (the tensor-parallel stack failed: {str((st or {}).get('error'))[:120]}); tp{world} layer entries in roofline.tp{world}_*"
                 except Exception as e:
                     roof["tp_flat_keys_error"] = repr(e)[:200]
 

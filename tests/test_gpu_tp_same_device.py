@@ -80,3 +80,35 @@ def test_two_ranks_one_gpu_column_row_mlp_and_gathered_attention(M):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _, _ in res), res
+
+
+def test_bench_two_ranks_headline_is_the_tensor_parallel_stack():
+    """`bench.py --gpus 2` (round 6): the line's `value` is the TENSOR-PARALLEL stack of BASELINE config 4 (Llama-2-70B shapes, every layer split over
+    out_features + one all-gather per layer: north_star's partitioning), the data-parallel replicas are a secondary object, and the line says what the process
+    group saw (world size, device per rank, exchange, backend).  Run exactly as the driver launches it -- torch.distributed.run, one process per rank -- with both
+    ranks on cuda:0 and a gloo control plane (RCCL refuses two ranks on one GPU); the JSON shape is what is asserted, no multi-GPU number is claimed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo", "--blocks", "1", "--tp-blocks", "1", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-tp-layers", "--no-fused", "--no-extras"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["unit"] == "GB/s" and d["value"] > 0 and d["higher_is_better"] is True, d
+    cfg = d["config"]
+    assert cfg["parallelism"] == "tp2" and cfg["nccl_world"] == 2 and cfg["backend"] == "gloo" and cfg["exchange"] == "all_gather", cfg
+    assert len(cfg["rank_devices"]) == 2 and {e["rank"] for e in cfg["rank_devices"]} == {0, 1} and all(e["device"] == "cuda:0" for e in cfg["rank_devices"]), cfg
+    assert "Llama-2-70B" in cfg["workload"] and cfg["layers"] == 7 and "TP=2" in d["metric"], (cfg, d["metric"])
+    st = d["tp"]["stack"]
+    assert abs(d["value"] - st["GB_per_s"]) < 1e-6 and abs(d["ms_per_step"] - st["ms_per_step"]) < 1e-9
+    assert st["ms_per_step"] >= st["ms_per_step_local_kernels_only"] * 0.5 and st["algorithmic_bytes_per_step_per_rank"] * 2 == d["algorithmic_bytes_per_step"]
+    dp = d["dp_replicas"]
+    assert dp["unit"] == "GB/s" and dp["value"] > 0 and "Llama-7B" in dp["workload"]
+    roof = d["roofline"]
+    for k in ("tp2_stack_ms_per_step", "tp2_stack_exchange_ms_per_step", "tp2_stack_GB_per_s", "tp2_stack_GB_per_s_per_gpu", "dp_value_GB_per_s"):
+        assert k in roof, (k, sorted(roof)[:40])
