@@ -61,6 +61,20 @@ bool wide_sk_pays(const gptq_layer_t& L, int M) {
     return M >= 768 || (M >= 512 && (size_t)L.K * L.N >= ((size_t)32 << 20));
 }
 
+namespace mlpk { extern int g_cu_count[64]; }                 // per device ordinal, filled by gptq_init (mlp.hip); 0 = not initialised
+
+// One persistent workgroup per CU: the grid is the largest power of two <= the CU count of the calling thread's current device (256 on an MI355X; a partitioned
+// or smaller device gets a smaller grid, so that a finisher's bounded wait never depends on publisher workgroups that are not resident yet).  Before gptq_init()
+// has recorded the count (host-only plan queries): 256.
+static int wide_sk_lg_nwg_cap() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) cus = mlpk::g_cu_count[dev];
+    if (cus <= 0 || cus > 256) cus = 256;
+    int lg = 0;
+    while ((2 << lg) <= cus) ++lg;
+    return lg;
+}
+
 WideSkGeom wide_sk_geom(const gptq_layer_t& L, int M) {
     WideSkGeom g{};
     g.nbm = (M + 127) / 128;
@@ -68,7 +82,7 @@ WideSkGeom wide_sk_geom(const gptq_layer_t& L, int M) {
     g.upt = L.K / 256;
     const long units = (long)g.nbm * g.nbn * g.upt;
     g.units_total = (int)units;
-    g.lg_nwg = 8;                                             // one workgroup per CU
+    g.lg_nwg = wide_sk_lg_nwg_cap();                          // one workgroup per CU
     while (g.lg_nwg > 0 && (1L << g.lg_nwg) > units) --g.lg_nwg;
     // does any range boundary fall inside a tile?  (then pieces are published: 128 KiB per workgroup behind the permuted x)
     bool cut = false;

@@ -624,7 +624,12 @@ def forward_multi(layers, x: torch.Tensor, tuning: "_lib.GptqTuning | None" = No
     # launch here takes 4.5 - 12 us, and the reference's callers are eager (generate() under inference_mode) -- per call only what depends on x remains.
     a = layers[0]
     n = len(layers)
-    if any(getattr(l, "_released", False) for l in layers) and x.numel() // max(1, a.infeatures) > 4:
+    released = any(getattr(l, "_released", False) for l in layers)
+    if released and tuning is not None:
+        # a forced kernel family may read the packed ROWS, which released layers only have in the one shared scratch (whichever layer was rebuilt last):
+        # the grouped entry points refuse the override instead of returning another layer's weights (single calls rebuild the rows: QuantLinear.forward)
+        raise RuntimeError("forward_multi: layers with release_checkpoint_layout=True take no tuning override in the grouped entry points; call them one by one")
+    if released and x.numel() // max(1, a.infeatures) > 4:
         # layers whose checkpoint rows left the HBM share ONE rows scratch: beyond the decode rows (which run from the copies) they are called one by one
         return [l(x, tuning) for l in layers]
     key = tuple([id(l._layer) for l in layers]) if a._layer is not None else None
@@ -718,9 +723,12 @@ def mlp_forward(gate: QuantLinear, up: QuantLinear, down: QuantLinear, x: torch.
     for l in (gate, up, down):
         if l._layer is None:
             l.post_init()
-    if any(getattr(l, "_released", False) for l in (gate, up, down)) and x.numel() // max(1, gate.infeatures) > 4:
-        g, u = forward_multi([gate, up], x)              # released layers (one shared rows scratch): composed from single calls
-        return down(torch.nn.functional.silu(g) * u)
+    if any(getattr(l, "_released", False) for l in (gate, up, down)):
+        if tuning is not None:
+            raise RuntimeError("mlp_forward: layers with release_checkpoint_layout=True take no tuning override")
+        if x.numel() // max(1, gate.infeatures) > 4:
+            g, u = forward_multi([gate, up], x)          # released layers (one shared rows scratch): composed from single calls
+            return down(torch.nn.functional.silu(g) * u)
     dev = gate._dev
     if x.device != dev:
         raise RuntimeError(f"mi355x mlp_forward: input is on {x.device}, the layers on {dev}")

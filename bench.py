@@ -1301,8 +1301,6 @@ def main():
                     for k in ("host_us_per_call", "us_per_call", "GB_per_s"):
                         if k in eg:
                             roof["eager_" + k] = eg[k]
-                    if "host_us_per_call" in eg:
-                        roof["eager_us_per_call"] = eg["host_us_per_call"]
                 fc = out.get("fused_callers")
                 if isinstance(fc, dict) and "ms_per_step" in fc:
                     roof["fused_ms_per_step"] = fc["ms_per_step"]
