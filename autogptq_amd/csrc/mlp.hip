@@ -24,14 +24,14 @@ __global__ void __launch_bounds__(256) silu_mul2_kernel(const T* __restrict__ g,
 // permute_rows4_kernel<false>: FOUR rows per workgroup held interleaved in LDS ([k][4 rows], 8 bytes per k) so that one ds_read_b64 per index fetches all four
 // rows' values; the load phase computes silu(g) * u on fp32 and rounds once (the arithmetic of silu_mul2_kernel: the same bits as the two passes).
 template <typename T>
-__global__ void __launch_bounds__(256) silu_mul2_permute_rows4_kernel(const unsigned short* __restrict__ g, const unsigned short* __restrict__ u, const int* __restrict__ perm,
+__global__ void __launch_bounds__(1024) silu_mul2_permute_rows4_kernel(const unsigned short* __restrict__ g, const unsigned short* __restrict__ u, const int* __restrict__ perm,
                                                                       int M, int K, unsigned short* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];                // [K][4] values
     const int m0 = blockIdx.x * 4;
     size_t ro[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) ro[r] = (size_t)min(m0 + r, M - 1) * K;
-    for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+    for (int i = threadIdx.x * 8; i < K; i += (int)blockDim.x * 8) {
         u32x4 v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) silu_mul2_permute_rows4_kernel(const unsi
         for (int w = 0; w < 4; ++w) *(u32x4*)(smem + (size_t)i * 8 + w * 16) = o[w];
     }
     __syncthreads();
-    for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+    for (int i = threadIdx.x * 8; i < K; i += (int)blockDim.x * 8) {
         const u32x4 p0 = *(const u32x4*)(perm + i), p1 = *(const u32x4*)(perm + i + 4);
         u32x2 gg[8];                                                            // gg[j] = the four rows' values at source index j of this piece
 #pragma unroll
@@ -101,7 +101,7 @@ hipError_t launch_silu_mul2(const void* g, const void* u, void* out, size_t tota
 bool silu_mul2_permute_ok(int K, int dtype) { return (dtype == GPTQ_F16 || dtype == GPTQ_BF16) && K % 8 == 0 && (size_t)K * 8 <= 160 * 1024; }
 hipError_t launch_silu_mul2_permute(const void* g, const void* u, const int32_t* perm, int M, int K, int dtype, void* out, hipStream_t st) {
     if (!silu_mul2_permute_ok(K, dtype) || M <= 0) return hipErrorInvalidValue;
-    const dim3 grid((M + 3) / 4), block(256);
+    const dim3 grid((M + 3) / 4), block(K >= 8192 ? 1024 : 512);      // one workgroup per CU at K = 11008 (88 KiB of LDS): 16 waves keep enough loads in flight
     if (dtype == GPTQ_F16)
         hipLaunchKernelGGL(silu_mul2_permute_rows4_kernel<f16>, grid, block, (size_t)K * 8, st, (const unsigned short*)g, (const unsigned short*)u, perm, M, K, (unsigned short*)out);
     else
