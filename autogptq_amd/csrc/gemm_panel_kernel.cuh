@@ -55,6 +55,7 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
     const int l31 = lane & 31, half = lane >> 5;
     const int Lb = xcd_remap(blockIdx.x, gridDim.x);
     const int bm = Lb % p.nbm, bn = Lb / p.nbm;               // consecutive workgroups (one XCD): the same columns (weights), the next rows
+    // (bands of 4 row tiles -- an XCD = 4 x 8 instead of 8 x 4 tiles, 20 % less L2 fill: measured within 1 %, tools/session_r06_panel2.sh)
     const int m0 = min(bm * R, p.M - R), m_lo = bm * R;        // the last row tile is shifted up to end at row M and stores only its own rows
     const int n0 = bn * 32 * NT;
 

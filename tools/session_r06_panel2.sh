@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6: same-session A/B of two builds of the panel kernel (product vs tools/libgptq_A.so)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-ARGS="--ms 256,512 --shapes 4096x4096,4096x11008 --geoms 21x8,22x8,23x8,24x8,22x4,24x4 --check 1 --rounds 2"
+ARGS="--ms 256,384,512 --shapes 4096x4096,4096x11008,11008x4096 --geoms 0,22,24 --check 1 --rounds 2"
 for rep in 1 2; do
   for lib in product A ${EXTRA_LIBS}; do
     if [ "$lib" = product ]; then unset GPTQ_MI355X_LIB; else export GPTQ_MI355X_LIB=$PWD/tools/libgptq_$lib.so; fi
