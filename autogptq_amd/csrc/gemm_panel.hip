@@ -30,12 +30,12 @@ static int panel_gsh(const gptq_layer_t& L) {                 // group of the 64
 }
 
 bool panel_ok(const gptq_layer_t& L, int M) {
-    if (L.bits != 4 || (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16)) return false;
+    if ((L.bits != 4 && L.bits != 3 && L.bits != 8) || (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16)) return false;
     if (L.qweight_tiled == nullptr || L.qconst_tiled == nullptr || L.tiled_cols != GPTQ_STRIP_COLS) return false;
     if (L.g_idx != nullptr && !(L.perm && L.qweight_seq)) return false;
     if (L.K % 128 || L.N % 32 || L.epilogue != GPTQ_EPI_NONE) return false;
     const int gsh = panel_gsh(L);
-    if (gsh == -1 || gsh == -2) return false;                  // (32-wide groups: not instantiated)
+    if (gsh == -1) return false;
     return M >= 64;
 }
 
@@ -47,7 +47,11 @@ static double panel_model_us(const gptq_layer_t& L, int M, int nt, long* tiles_o
     const long rounds = (tiles + 255) / 256;
     const int spw = (L.K / 64 + 7) / 8;
     if (tiles_out) *tiles_out = tiles;
-    return 1.5 + (double)rounds * (4.0 + spw * (0.40 + 0.50 * nt));
+    // 3 bits measured like 4 (profiles/r06_panel_b38.log); 8 bits: twice the packed bytes per step (+ ~10 %); 32-wide groups: constants every step; a 32-column
+    // tile is bound by its pull of x (64 rows x K per 32 columns): ~1.05 us per step whatever the packing
+    const double per_nt = (L.bits == 8 ? 0.55 : 0.50) + (L.group_size == 32 ? 0.02 : 0.0);
+    const double step = 0.40 + per_nt * nt;
+    return 1.5 + (double)rounds * (4.0 + spw * (nt == 1 && step < 1.05 ? 1.05 : step));
 }
 
 // lab: tuning.path = 3, reserved[3] = GPTQ_LAB_VARIANT_PANEL_ON, reserved[0] = 20 + NT (column blocks of 32 per workgroup tile; 0: the planner's)
@@ -57,11 +61,11 @@ PanelPlan plan_panel(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     int nt = 0;
     if (tune && tune->path == 3) {
         const int g = tune->reserved[0];
-        if (g / 10 == 2 && g % 10 >= 1 && g % 10 <= 4) nt = g % 10;
+        if (g / 10 == 2 && g % 10 >= 1 && g % 10 <= (L.bits == 8 ? 3 : 4)) nt = g % 10;
     }
     if (!nt) {
         double best = 1e30;
-        for (int c = 4; c >= 1; --c) {                          // ties go to the wider tile (fewer pulls of x)
+        for (int c = (L.bits == 8 ? 3 : 4); c >= 1; --c) {      // ties go to the wider tile (fewer pulls of x); 8 bits: three register sets of 8 words per column block leave room for 3 blocks
             const double t = panel_model_us(L, M, c, nullptr);
             if (t < best - 1e-9) { best = t; nt = c; }
         }
@@ -102,7 +106,10 @@ bool panel_pays(const gptq_layer_t& L, int M) {
     if (wide_sk_pays(L, M)) {
         if (L.N <= 2048) return true;
         const double gf = 2.0 * M * (double)kn * 1e-9;
-        return est < 20.0 + gf / 1.2;                             // stream-K on cold weights: ~20 us of first loads, segment turn-around and fix-up + the K loop at ~1.2 PFLOP/s
+        // stream-K on cold weights: ~20 us of first loads, segment turn-around and fix-up + the K loop at ~1.2 PFLOP/s; its 3-bit / 32-wide-group forms start earlier
+        // (256+ rows) and cost ~24 us + the loop, the 8-bit form ~27 us (r06_panel_b38.log: 4096x11008 at 256 / 384 / 512 rows int3 g32 43.2 / 52.0 / 60.3, int8 48.5 / 58.5 / 68.8)
+        const double fixed = L.bits == 8 ? 27.0 : ((L.bits == 3 || L.group_size == 32) ? 24.0 : 20.0);
+        return est < fixed + gf / 1.2;
     }
     if (kn > ((size_t)128 << 20) || L.K > 16384) return false;
     if (M < 160 && L.K > 8192) return false;
@@ -110,16 +117,26 @@ bool panel_pays(const gptq_layer_t& L, int M) {
     return true;
 }
 
-template <typename T, int NT>
+template <typename T, int BITS, int NT, bool G32>
 static hipError_t panel_grant_one() {
-    return hipFuncSetAttribute((const void*)panel::gemm_panel_kernel<T, 2, NT, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return hipFuncSetAttribute((const void*)panel::gemm_panel_kernel<T, BITS, NT, G32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <typename T, int BITS, bool G32>
+static hipError_t panel_grant_nt() {
+    hipError_t e = panel_grant_one<T, BITS, 1, G32>();
+    if (e == hipSuccess) e = panel_grant_one<T, BITS, 2, G32>();
+    if (e == hipSuccess) e = panel_grant_one<T, BITS, 3, G32>();
+    if constexpr (BITS != 8) { if (e == hipSuccess) e = panel_grant_one<T, BITS, 4, G32>(); }
+    return e;
 }
 template <typename T>
 static hipError_t panel_grant_t() {
-    hipError_t e = panel_grant_one<T, 1>();
-    if (e == hipSuccess) e = panel_grant_one<T, 2>();
-    if (e == hipSuccess) e = panel_grant_one<T, 3>();
-    if (e == hipSuccess) e = panel_grant_one<T, 4>();
+    hipError_t e = panel_grant_nt<T, 4, false>();
+    if (e == hipSuccess) e = panel_grant_nt<T, 4, true>();
+    if (e == hipSuccess) e = panel_grant_nt<T, 3, false>();
+    if (e == hipSuccess) e = panel_grant_nt<T, 3, true>();
+    if (e == hipSuccess) e = panel_grant_nt<T, 8, false>();
+    if (e == hipSuccess) e = panel_grant_nt<T, 8, true>();
     return e;
 }
 hipError_t init_gemm_panel_device() {
@@ -128,21 +145,27 @@ hipError_t init_gemm_panel_device() {
     return e;
 }
 
-template <typename T, int NT>
+template <typename T, int BITS, int NT, bool G32>
 static void panel_launch_one(const PanelPlan& pl, const panel::PanelParams& p, hipStream_t st) {
-    hipLaunchKernelGGL((panel::gemm_panel_kernel<T, 2, NT, 8, false>), dim3(pl.nbm * pl.nbn), dim3(512), pl.lds_bytes, st, p);
+    hipLaunchKernelGGL((panel::gemm_panel_kernel<T, BITS, NT, G32>), dim3(pl.nbm * pl.nbn), dim3(512), pl.lds_bytes, st, p);
 }
-template <typename T>
-static hipError_t panel_launch_t(const PanelPlan& pl, const panel::PanelParams& p, hipStream_t st) {
-    if (pl.mt != 2 || pl.kp != 8) return hipErrorInvalidValue;
+template <typename T, int BITS, bool G32>
+static hipError_t panel_launch_nt(const PanelPlan& pl, const panel::PanelParams& p, hipStream_t st) {
     switch (pl.nt) {
-        case 1: panel_launch_one<T, 1>(pl, p, st); break;
-        case 2: panel_launch_one<T, 2>(pl, p, st); break;
-        case 3: panel_launch_one<T, 3>(pl, p, st); break;
-        case 4: panel_launch_one<T, 4>(pl, p, st); break;
+        case 1: panel_launch_one<T, BITS, 1, G32>(pl, p, st); break;
+        case 2: panel_launch_one<T, BITS, 2, G32>(pl, p, st); break;
+        case 3: panel_launch_one<T, BITS, 3, G32>(pl, p, st); break;
+        case 4: if constexpr (BITS != 8) { panel_launch_one<T, BITS, 4, G32>(pl, p, st); break; } else return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+template <typename T>
+static hipError_t panel_launch_t(int bits, bool g32, const PanelPlan& pl, const panel::PanelParams& p, hipStream_t st) {
+    if (pl.mt != 2 || pl.kp != 8) return hipErrorInvalidValue;
+    if (bits == 4) return g32 ? panel_launch_nt<T, 4, true>(pl, p, st) : panel_launch_nt<T, 4, false>(pl, p, st);
+    if (bits == 3) return g32 ? panel_launch_nt<T, 3, true>(pl, p, st) : panel_launch_nt<T, 3, false>(pl, p, st);
+    return g32 ? panel_launch_nt<T, 8, true>(pl, p, st) : panel_launch_nt<T, 8, false>(pl, p, st);
 }
 
 hipError_t launch_gemm_panel(const gptq_layer_t& L, const PanelPlan& pl, const void* x, void* out, int M, hipStream_t st) {
@@ -151,11 +174,12 @@ hipError_t launch_gemm_panel(const gptq_layer_t& L, const PanelPlan& pl, const v
     p.qweight = L.qweight_tiled; p.qconst = (const char*)L.qconst_tiled; p.bias = L.bias; p.x = x; p.out = out;
     p.M = M; p.K = L.K; p.N = L.N;
     p.nbm = pl.nbm; p.nbn = pl.nbn;
-    p.chunks = L.K / 128;
+    p.chunks = L.bits == 8 ? L.K / 64 : L.K / 128;           // the decode copy's chunks: 4 k-slots of 32 (8 bits: 16) values
     p.groups = (L.K + L.group_size - 1) / L.group_size;
-    p.gsh = panel_gsh(L);
+    const int gsh = panel_gsh(L);
+    p.gsh = gsh < 0 ? 0 : gsh;                                 // (32-wide groups: group 2 kt + lane half, in the kernel)
     p.steps = L.K / 64; p.spw = pl.spw;
-    return L.dtype == GPTQ_F16 ? panel_launch_t<f16>(pl, p, st) : panel_launch_t<bf16>(pl, p, st);
+    return L.dtype == GPTQ_F16 ? panel_launch_t<f16>(L.bits, gsh == -2, pl, p, st) : panel_launch_t<bf16>(L.bits, gsh == -2, pl, p, st);
 }
 
 }  // namespace gptq

@@ -34,7 +34,7 @@ struct PanelParams {
     void* out;
     int M, K, N;
     int nbm, nbn;                 // row tiles, column tiles
-    int chunks;                   // 128-deep chunks of the copy per strip
+    int chunks;                   // chunks of the copy per strip (128-deep; 8 bits: 64-deep)
     int groups;
     int gsh;                      // group of the 64-deep step kt = min(kt >> gsh, groups - 1)   (32-wide groups: 2 kt + lane half)
     int steps, spw;               // K / 64; steps per wave
@@ -42,9 +42,15 @@ struct PanelParams {
 
 template <int KP> constexpr int units_per_batch() { return 128 / KP; }      // 1 KiB per (unit, wave): 128 KiB of LDS per batch of the cross-wave sum
 
-template <typename T, int MT, int NT, int KP, bool G32>
+template <typename T, int BITS, int MT, int NT, int KP, bool G32>
 __device__ __forceinline__ void panel_body(const PanelParams& p) {
     constexpr int R = 32 * MT, XB = R * 128, NX = 4 * MT;
+    // the decode copy per packing (gptq_mi355x.h): 4 bits: 128-deep chunks of 1024 bytes, a lane's k-slot = 16 bytes; 3 bits: 768-byte chunks, 12 bytes; 8 bits: 64-deep
+    // chunks of 1024 bytes, a k-slot = 16 k = 16 bytes -- the lane's 32 k of a step are k-slots 2 half, 2 half + 1 of chunk kt: two 16-byte loads
+    constexpr int NH = BITS == 8 ? 2 : 1;                      // 16-byte (12-byte) loads per column block and step
+    constexpr unsigned STEP_B = BITS == 3 ? 384u : (BITS == 8 ? 1024u : 512u), SLOT_B = BITS == 3 ? 192u : (BITS == 8 ? 512u : 256u), COL_B = BITS == 3 ? 12u : 16u;
+    constexpr unsigned STRIP_CH = BITS == 3 ? 768u : 1024u, REC = BITS == 8 ? 64u : 48u;
+    constexpr int NWL = NT * NH;                               // weight loads of a step; + 2 NT where constants are loaded
     constexpr int DW = 3;                                      // register sets of packed weights: W(kt + 2) is issued inside step kt
     constexpr int UNITS = 4 * MT * NT;                         // float4s per lane of the accumulator tile
     constexpr int UB = units_per_batch<KP>() < UNITS ? units_per_batch<KP>() : UNITS;
@@ -65,12 +71,12 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
     for (int nt = 0; nt < NT; ++nt) {
         int nb = n0 + 32 * nt;
         if (nb >= p.N) nb = n0;                                // a column block past N (N % 32 == 0: in or out as a whole) re-reads block 0 and is not stored
-        wbase[nt] = (const char*)p.qweight + (size_t)(nb >> 4) * p.chunks * 1024;
-        cbase[nt] = p.qconst + (size_t)(nb >> 4) * p.groups * 48;
+        wbase[nt] = (const char*)p.qweight + (size_t)(nb >> 4) * p.chunks * STRIP_CH;
+        cbase[nt] = p.qconst + (size_t)(nb >> 4) * p.groups * REC;
     }
-    const unsigned wlane = (unsigned)(l31 >> 4) * (unsigned)p.chunks * 1024u + (unsigned)half * 256u + (unsigned)(l31 & 15) * 16u;
-    const unsigned clane = (unsigned)(l31 >> 4) * (unsigned)p.groups * 48u + (G32 ? (unsigned)half * 48u : 0u);
-    const unsigned slane = clane + (unsigned)(l31 & 15) * 2u, zlane = clane + 32u + (unsigned)(l31 & 15);
+    const unsigned wlane = (unsigned)(l31 >> 4) * (unsigned)p.chunks * STRIP_CH + (unsigned)half * SLOT_B + (unsigned)(l31 & 15) * COL_B;
+    const unsigned clane = (unsigned)(l31 >> 4) * (unsigned)p.groups * REC + (G32 ? (unsigned)half * REC : 0u);
+    const unsigned slane = clane + (unsigned)(l31 & 15) * 2u, zlane = clane + 32u + (unsigned)(l31 & 15) * (BITS == 8 ? 2u : 1u);
 
     char* const xbuf = smem + (size_t)wave * 2 * XB;
     const unsigned xbuf_lds = lds_addr_of(xbuf);
@@ -88,12 +94,19 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) aoff[ks] = (unsigned)(l31 * 128 + (((half * 4 + ks) ^ ((l31 >> 1) & 7)) * 16));
 
-    struct Buf { u32x4 w[NT]; unsigned cs[NT], cz[NT]; };
+    using WV = std::conditional_t<BITS == 3, wide::u32x3, u32x4>;      // a lane's words of one load (written by ONE instruction)
+    struct Buf { WV w[NT][NH]; unsigned cs[NT], cz[NT]; };
     Buf q[DW];
+    // Every constant register starts as ITS OWN opaque definition: initialised from one shared zero, the compiler kept scale and zero-point of a set in ONE register
+    // up to the first load and split them with a v_mov BEHIND that load's asm -- a copy of a register whose load had not landed (8-bit g64 form: outputs that
+    // differed from run to run).  tools/isa_inflight_lint.py checks the built kernels for any read of a load's destination in front of the next s_waitcnt.
 #pragma unroll
     for (int j = 0; j < DW; ++j)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) q[j].cs[nt] = q[j].cz[nt] = 0u;
+        for (int nt = 0; nt < NT; ++nt) {
+            asm volatile("v_mov_b32 %0, 0" : "=v"(q[j].cs[nt]));
+            asm volatile("v_mov_b32 %0, 0" : "=v"(q[j].cz[nt]));
+        }
     const int k0 = wave * p.spw, k1 = min(k0 + p.spw, p.steps);
     // constants only where a group begins (and at the wave's first step): the two sub-dword loads per column cost the memory pipe as much as the 16-byte weight
     // load beside them (profiles/r06_panel_ablate.log).  "+v": a step without constants leaves the registers as they are -- no copy can appear at the join
@@ -105,16 +118,19 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
 #endif
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const char* wsrc = wbase[nt] + (size_t)kt * 512;  // chunk kt / 2, k-slots 2 (kt & 1) + half
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B.w[nt]) : "v"(wlane), "s"(wsrc) : "memory");
+            const char* wsrc = wbase[nt] + (size_t)kt * STEP_B;      // 3 / 4 bits: chunk kt / 2, k-slots 2 (kt & 1) + half; 8 bits: chunk kt, k-slots 2 half, + 1
+            if constexpr (BITS == 3) asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(B.w[nt][0]) : "v"(wlane), "s"(wsrc) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B.w[nt][0]) : "v"(wlane), "s"(wsrc) : "memory");
+            if constexpr (BITS == 8) asm volatile("global_load_dwordx4 %0, %1, %2 offset:256" : "=v"(B.w[nt][1]) : "v"(wlane), "s"(wsrc) : "memory");
         }
         if (has_c(kt)) {
             const int g = G32 ? 2 * kt : min(kt >> p.gsh, p.groups - 1);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const char* csrc = cbase[nt] + (size_t)g * 48;
+                const char* csrc = cbase[nt] + (size_t)g * REC;
                 asm volatile("global_load_ushort %0, %1, %2" : "+v"(B.cs[nt]) : "v"(slane), "s"(csrc) : "memory");
-                asm volatile("global_load_ubyte %0, %1, %2" : "+v"(B.cz[nt]) : "v"(zlane), "s"(csrc) : "memory");
+                if constexpr (BITS == 8) asm volatile("global_load_ushort %0, %1, %2" : "+v"(B.cz[nt]) : "v"(zlane), "s"(csrc) : "memory");
+                else asm volatile("global_load_ubyte %0, %1, %2" : "+v"(B.cz[nt]) : "v"(zlane), "s"(csrc) : "memory");
             }
         }
     };
@@ -133,10 +149,14 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
     // the registers pass through a statement behind the wait so that no use of them is scheduled in front of it
     auto claim = [&](Buf& B) __attribute__((always_inline)) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(B.w[nt]), "+v"(B.cs[nt]), "+v"(B.cz[nt])::"memory");
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) asm volatile("" : "+v"(B.w[nt][h])::"memory");
+            asm volatile("" : "+v"(B.cs[nt]), "+v"(B.cz[nt])::"memory");
+        }
     };
 
-    typename rowsk::Deq1<T> dq[NT];                            // the current group's constants (set up where a group begins)
+    typename rowsk::DeqSel<T, BITS>::type dq[NT];              // the current group's constants (set up where a group begins)
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -158,8 +178,8 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
                 const int buf = (kt - k0) & 1;
                 const int ktx = min(kt + 1, kl), ktw = min(kt + 2, kl);
 #if !(defined(GPTQ_PANEL_ABL) && (GPTQ_PANEL_ABL & 1))      // lab (tools/ab_unit.sh ... -DGPTQ_PANEL_ABL=n; wrong results by construction): 1 = nobody waits for the step's loads
-                if (has_c(ktx)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NT) : "memory");      // W(kt + 1) stays in flight: with or without constants
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT) : "memory");
+                if (has_c(ktx)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWL + 2 * NT) : "memory");      // W(kt + 1) stays in flight: with or without constants
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWL) : "memory");
 #endif
                 claim(q[j]);
                 if (has_c(kt)) {
@@ -167,10 +187,16 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
                     for (int nt = 0; nt < NT; ++nt) dq[nt].setup(q[j].cs[nt], q[j].cz[nt]);
                 }
                 const char* xb = xbuf + buf * XB;
+                // the 8 weights k = 32 half + 8 ks + 0..7 of column block nt, dequantised (bit-exact W)
+                auto frag_of = [&](int nt, int ks) __attribute__((always_inline)) -> u32x4 {
+                    if constexpr (BITS == 4) return dq[nt].frag(q[j].w[nt][0][ks]);
+                    else if constexpr (BITS == 3) return dq[nt].frag(q[j].w[nt][0], ks);
+                    else return dq[nt].frag(q[j].w[nt][ks >> 1][2 * (ks & 1)], q[j].w[nt][ks >> 1][2 * (ks & 1) + 1]);
+                };
                 u32x4 a[2][MT], bq[2];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) a[0][mt] = *(const u32x4*)(xb + mt * 4096 + aoff[0]);
-                bq[0] = dq[0].frag(q[j].w[0][0]);
+                bq[0] = frag_of(0, 0);
                 // software pipeline over the 4 NT (MFMA step, column block) pairs: the NEXT pair's B fragment (13 VALU) is dequantised between the MT MFMAs of
                 // this pair -- independent work for the 32 cycles each MFMA holds the matrix pipe (back to back, the second MFMA of a pair stalls the wave
                 // for the first one's passes and the dequant then runs with the pipe idle)
@@ -188,9 +214,9 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
                         if (DW == 3 && ks == 2) issue_w(ktw, q[(j + 2) % DW]);
                     }
 #if defined(GPTQ_PANEL_ABL) && (GPTQ_PANEL_ABL & 8)      // lab: 8 = no dequant math
-                    if (i + 1 < 4 * NT) { const unsigned qq = q[j].w[(i + 1) % NT][(i + 1) / NT]; bq[(i + 1) & 1] = u32x4{qq, qq ^ 0x11111111u, qq ^ 0x22222222u, qq ^ q[j].cs[(i + 1) % NT]}; }
+                    if (i + 1 < 4 * NT) { const unsigned qq = q[j].w[(i + 1) % NT][0][((i + 1) / NT) % 3]; bq[(i + 1) & 1] = u32x4{qq, qq ^ 0x11111111u, qq ^ 0x22222222u, qq ^ q[j].cs[(i + 1) % NT]}; }
 #else
-                    if (i + 1 < 4 * NT) bq[(i + 1) & 1] = dq[(i + 1) % NT].frag(q[j].w[(i + 1) % NT][(i + 1) / NT]);
+                    if (i + 1 < 4 * NT) bq[(i + 1) & 1] = frag_of((i + 1) % NT, (i + 1) / NT);
 #endif
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = wide::Mma<T>::run(a[ks & 1][mt], bq[i & 1], acc[mt][nt]);
@@ -258,9 +284,9 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
     }
 }
 
-template <typename T, int MT, int NT, int KP, bool G32>
-__global__ void __launch_bounds__(64 * KP, 1) gemm_panel_kernel(PanelParams p) {
-    panel_body<T, MT, NT, KP, G32>(p);
+template <typename T, int BITS, int NT, bool G32>
+__global__ void __launch_bounds__(512, 1) gemm_panel_kernel(PanelParams p) {
+    panel_body<T, BITS, 2, NT, 8, G32>(p);
 }
 
 }  // namespace panel

@@ -56,9 +56,9 @@ def _every_output(q, Lq, W, M, K, dtype, t, what):
     assert torch.equal(yh, W[(rows * 37 + 5) % K]), f"{what}: one-hot rows are not the exact dequantised weight rows"
 
 
-def _layer(K, N, gs, act, dtype, zm, seed):
-    Lq = O.random_quant_layer(K, N, 4, gs, act_order=act, seed=seed, bias=True, dtype=dtype)
-    q = QuantLinear(4, gs, K, N, True, weight_dtype=dtype, zero_mode=zm)
+def _layer(K, N, gs, act, dtype, zm, seed, bits=4):
+    Lq = O.random_quant_layer(K, N, bits, gs, act_order=act, seed=seed, bias=True, dtype=dtype)
+    q = QuantLinear(bits, gs, K, N, True, weight_dtype=dtype, zero_mode=zm)
     q.qweight, q.qzeros, q.scales, q.g_idx, q.bias = Lq["qweight"], Lq["qzeros"], Lq["scales"], Lq["g_idx"], Lq["bias"]
     q = q.to(DEV)
     q.post_init()
@@ -66,7 +66,7 @@ def _layer(K, N, gs, act, dtype, zm, seed):
     # 'auto' = the convention of the reference class the module stands in for (cuda_old wraps, the act-order class does not); a g_idx of ONE group is the
     # default order whatever was asked for, so the module's own answer is taken, not the case's flag
     mode = O.ZERO_NOWRAP if q.resolved_zero_mode() == _lib.ZERO_NOWRAP else O.ZERO_WRAP
-    W = O.dequantize(Lq["qweight"], Lq["qzeros"], Lq["scales"], Lq["g_idx"], 4, mode).to(DEV)
+    W = O.dequantize(Lq["qweight"], Lq["qzeros"], Lq["scales"], Lq["g_idx"], bits, mode).to(DEV)
     return q, Lq, W
 
 
@@ -82,6 +82,31 @@ def test_panel_forced_every_geometry_every_output(case, dtype):
             assert plan["kernel"] == "panel", plan
             assert plan["tiles"] == f"{-(-M // 64)}x{-(-N // (32 * (geom % 10)))}", plan
             _every_output(q, Lq, W, M, K, dtype, t, f"{K}x{N} g{gs} M={M} act={act} {zm} {dtype} geom {geom}")
+
+
+# the other packings of the decode copy and 32-wide groups (BASELINE config 5 is int3 / int8 at group_size 32): (bits, K, N, group_size, M, act_order)
+CASES_B38 = [
+    (3, 512, 544, 32, 129, False, "3 bits, 32-wide groups (each half of the wave on its own group, constants every step), shifted last row tile, partial last column tile"),
+    (3, 1024, 256, 128, 200, True, "3 bits, groups of 128 (constants every second step), act-order"),
+    (3, 768, 160, 64, 333, False, "3 bits, groups of 64, 12 steps on 8 waves"),
+    (8, 512, 544, 32, 129, False, "8 bits (two 16-byte loads per column block and step), 32-wide groups"),
+    (8, 1024, 256, 128, 200, True, "8 bits, groups of 128, act-order"),
+    (8, 768, 160, 64, 333, False, "8 bits, groups of 64"),
+    (4, 1024, 544, 32, 333, True, "4 bits on 32-wide groups, act-order"),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("case", CASES_B38, ids=[f"int{c[0]}_{c[1]}x{c[2]}g{c[3]}M{c[4]}{'act' if c[5] else ''}" for c in CASES_B38])
+def test_panel_3bit_8bit_and_g32_every_geometry_every_output(case, dtype):
+    bits, K, N, gs, M, act, _ = case
+    for zm in ("auto", "nowrap"):
+        q, Lq, W = _layer(K, N, gs, act, dtype, zm, K + N + M + bits, bits=bits)
+        for geom in (GEOMS[:3] if bits == 8 else GEOMS):          # (8 bits: up to three column blocks per tile)
+            t = _tune(geom)
+            plan = _lib.describe_plan(q._layer, M, t)
+            assert plan["kernel"] == "panel" and plan["tiles"] == f"{-(-M // 64)}x{-(-N // (32 * (geom % 10)))}", plan
+            _every_output(q, Lq, W, M, K, dtype, t, f"int{bits} {K}x{N} g{gs} M={M} act={act} {zm} {dtype} geom {geom}")
 
 
 # the band itself, by the planner's rule (plan asserted): the review's row counts on three shapes, plain and act-order

@@ -802,9 +802,11 @@ def test_stream_k_prefill_rules_for_every_packing():
                 assert plan(bits, 32, K, N, 2048, dtype=dtype)[0]["kernel"] == "wide_sk"
             assert plan(bits, 32, K, N, 2048, act=True)[0]["kernel"] == "wide_sk"
             assert plan(bits, 128, K, N, 4096)[0]["kernel"] == "wide_sk"               # no 128 x 512 form for these widths
-            assert plan(bits, 32, K, N, 512)[0]["kernel"] == "wide_sk"
-            assert plan(bits, 32, K, N, 384)[0]["kernel"] == ("wide_sk" if K * N >= 32 << 20 else "tiled")
-            assert plan(bits, 32, K, N, 256)[0]["kernel"] == ("wide_sk" if (K, N) == (4096, 11008) else "tiled")
+            # round 6: below ~512 rows the whole-K panel kernel takes these layers where its tiles fill the chip and its time model beats stream-K's
+            # (profiles/r06_panel_b38.log): one round of 64 x 128 tiles at 512 rows on 4096^2 and (3 bits) 11008x4096, 256 rows everywhere
+            assert plan(bits, 32, K, N, 512)[0]["kernel"] == ("panel" if (K, N) == (4096, 4096) or ((K, N) == (11008, 4096) and bits == 3) else "wide_sk")
+            assert plan(bits, 32, K, N, 384)[0]["kernel"] == ("wide_sk" if K * N >= 32 << 20 else "panel")
+            assert plan(bits, 32, K, N, 256)[0]["kernel"] == "panel"
             assert plan(bits, 32, K, N, 128)[0]["kernel"] != "wide_sk"
         assert plan(4, 32, K, N, 2048)[0]["kernel"] == "wide_sk"                       # 4 bits on 32-wide groups: each half of the wave on its own group
     assert plan(4, 96, 4032, 4096, 2048)[0]["kernel"] != "wide_sk"                     # groups of 96: not a group mode of the kernel
@@ -836,7 +838,7 @@ def test_batched_decode_rows_kernel_rules():
                 for M in (5, 8, 16, 33, 64):
                     for act in (False, True):
                         d, need = plan(bits, gs, K, N, M, act)
-                        if bits == 4 and gs >= 64 and M == 64 and N >= 8192 and K <= 4096:      # round 6: 64 rows of the wide layers = 172+ tiles of the panel kernel
+                        if M == 64 and N >= 8192 and K <= 4096:      # round 6: 64 rows of the wide layers = 172+ tiles of the panel kernel (every packing of the copy)
                             assert d["kernel"] == "panel", (bits, gs, K, N, M, act, d)
                             continue
                         assert d["kernel"] == "rows", (bits, gs, K, N, M, act, d)
@@ -847,14 +849,13 @@ def test_batched_decode_rows_kernel_rules():
                         assert need == (65536 + (M * K * 2 + 255) // 256 * 256 if act else 0), (d, need)      # header + permuted x, or nothing
     for M in (96, 128):                                          # (round 6: the panel kernel takes 4096^2 from 96 rows; deep layers at few rows stay here)
         assert plan(4, 128, 4096, 4096, M)[0]["kernel"] == "panel" and plan(4, 128, 11008, 4096, M)[0]["kernel"] == "rows"
-        assert plan(3, 128, 4096, 4096, M)[0]["kernel"] == "rows" and plan(4, 32, 4096, 4096, M)[0]["kernel"] == "rows"      # (no panel form for 3 / 8 bits and 32-wide groups)
+        assert plan(3, 128, 4096, 4096, M)[0]["kernel"] == "panel" and plan(8, 32, 4096, 4096, M)[0]["kernel"] == "panel"      # (3 / 8 bits and 32-wide groups too)
+        assert plan(3, 32, 11008, 4096, M)[0]["kernel"] == "rows"
         assert plan(4, 128, 4096, 11008, M)[0]["kernel"] != "rows" and plan(4, 128, 8192, 8192, M)[0]["kernel"] != "rows"
     for M in (1, 2, 4):
         assert plan(4, 128, 4096, 4096, M)[0]["kernel"] == "strips"
-    for M in (129, 192, 256):                                    # short prompts: the 64-row form, 4 bits only -- where the panel kernel (round 6) does not take the launch: 32-wide groups
-        d = plan(4, 32, 4096, 4096, M)[0]
-        assert d["kernel"] == "rows" and d["mt"] in ("2", "4"), d
-        assert plan(4, 128, 4096, 4096, M)[0]["kernel"] == "panel"
+    for M in (129, 192, 256):                                    # short prompts: the panel kernel (round 6); the 64-row form of this kernel where the panel kernel has no form (groups of 96)
+        assert plan(4, 128, 4096, 4096, M)[0]["kernel"] == "panel" and plan(4, 32, 4096, 4096, M)[0]["kernel"] == "panel"
         assert plan(3, 128, 4096, 4096, M)[0]["kernel"] != "rows" and plan(4, 128, 4096, 11008, M)[0]["kernel"] != "rows"
     assert plan(4, 128, 4096, 4096, 257)[0]["kernel"] != "rows" and plan(4, 128, 4096, 4096, 16, copy=False)[0]["kernel"] != "rows"
     assert plan(4, 128, 8192, 28672, 16)[0]["kernel"] != "rows" and plan(4, 128, 512, 4096, 16)[0]["kernel"] != "rows"      # several rounds of workgroups / a small layer
@@ -1011,7 +1012,7 @@ def test_tools_and_bench_parse():
 def test_panel_kernel_is_planned_where_its_tiles_fill_the_chip():
     """gptq_describe_plan (host only), round 6: the whole-K panel kernel (csrc/gemm_panel.hip) on layers that carry their decode copy -- chosen where its 64-row
     tiles fill the 256 CUs (>= ~160 tiles per round) and the measured competitors lose (profiles/r06_panel_sweep_cold.log): 96 ... 767 rows on 4096 -> 4096, up to
-    384 rows on 4096 -> 11008 (stream-K from 512), 160 ... 512 rows on 11008 -> 4096; never without a decode copy, for 3 / 8 bits, 32-wide groups or an epilogue;
+    384 rows on 4096 -> 11008 (stream-K from 512), 160 ... 512 rows on 11008 -> 4096; never without a decode copy or for groups that are no power-of-two multiple of 32; 3-, 4- and 8-bit, 32-wide groups included;
     geometry = the time model's choice (tiles 64 x 32 NT); forced geometries through the lab knob; workspace = the permuted x of act-order layers only."""
     lib = _lib.load()
 
@@ -1042,8 +1043,10 @@ def test_panel_kernel_is_planned_where_its_tiles_fill_the_chip():
     assert (p["mt"], p["bk"], p["waves"], p["ksplit"], p["perm"]) == (2, 64, 8, 1, 0), p
     # not without the decode copy, not for the other packings / 32-wide groups / a fused epilogue
     assert plan(4096, 4096, 256, copy=False)[0]["kernel"] != "panel"
-    for kw in (dict(bits=3, group_size=128), dict(bits=8, group_size=128), dict(group_size=32)):
-        assert plan(4096, 4096, 256, **kw)[0]["kernel"] != "panel", kw
+    for kw in (dict(bits=3, group_size=128), dict(bits=8, group_size=128), dict(group_size=32), dict(bits=3, group_size=32)):      # every packing of the copy, 32-wide groups
+        assert plan(4096, 4096, 256, **kw)[0]["kernel"] == "panel", kw
+    assert plan(4096, 4096, 256, bits=2, group_size=128, copy=False)[0]["kernel"] != "panel" and plan(4032, 4096, 256, group_size=96)[0]["kernel"] != "panel"
+    assert plan(4096, 4096, 256, bits=8, group_size=128)[0]["tiles"] in ("4x64", "4x43", "4x128")      # (8 bits: at most three column blocks per tile)
     p, _ = plan(4096, 4096, 256, epilogue=1)                     # a [gate | up] layer: the kernel runs on the plain layer, SiLU * mul is a separate pass over the staged y
     assert p["kernel"] == "panel" and p["epilogue"] == "separate", p
     # act-order: x permuted in natural order by the pre-pass; the workspace is that and nothing else

@@ -81,6 +81,40 @@ def test_panel_kernels_hold_their_in_flight_loads_in_registers():
     registers across a hand-counted s_waitcnt, so a spilled one would be stored before it has landed: every instantiated form is spill-free and scratch-free."""
     ks = _kernels()
     panel = {n: v for n, v in ks.items() if "gemm_panel_kernel" in n}
-    assert len(panel) == 2 * 4, sorted(panel)                        # <T, 2, NT = 1..4, 8, false> x fp16 / bf16
+    assert len(panel) == 2 * (4 + 4 + 3) * 2, sorted(panel)          # <T, BITS, NT, G32>: fp16 / bf16 x (3 / 4 bits: NT = 1..4, 8 bits: NT = 1..3) x (groups of 64+, 32-wide groups)
     for n, v in panel.items():
         assert (v["vgpr"] or 0) + 0 <= 256 and (v["spill"] or 0) == 0 and (v["scratch"] or 0) == 0, (n, v)
+
+
+def test_no_instruction_touches_a_register_whose_asm_load_is_in_flight():
+    """The panel kernel's loads are inline asm behind hand-counted s_waitcnt: the compiler does not know they are loads and may copy a destination register before the
+    data has landed (round 6: a v_mov at a control-flow join gave the 8-bit form outputs that differed from run to run).  The built code objects are disassembled and
+    linted (tools/isa_inflight_lint.py): between a global_load and the next s_waitcnt vmcnt nothing reads or writes the load's destination."""
+    import importlib.util
+    tools = [os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not os.path.exists(SO) or not all(os.path.exists(t) for t in tools):
+        pytest.skip("built library or ROCm LLVM tools not present")
+    spec = importlib.util.spec_from_file_location("isa_inflight_lint", os.path.join(ROOT, "tools", "isa_inflight_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    seen = 0
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.check_call([tools[0], f"--dump-section=.hip_fatbin={fat}", SO, os.path.join(d, "copy.so")])
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+        for i, a in enumerate(starts):
+            chunk = blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)]
+            if b"gemm_panel_kernel" not in chunk:
+                continue
+            part, co = os.path.join(d, f"b{i}.bin"), os.path.join(d, f"co{i}.o")
+            open(part, "wb").write(chunk)
+            r = subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={part}", f"--output={co}"], capture_output=True)
+            if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
+                continue
+            asm = subprocess.run([tools[2], "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+            n = len(re.findall(r"gemm_panel_kernel\w*>?:", asm))
+            seen += n
+            bad = lint.lint(asm, "gemm_panel_kernel")
+            assert not bad, bad[:5]
+    assert seen >= 44, seen

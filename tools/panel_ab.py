@@ -17,6 +17,7 @@ ap.add_argument("--geoms", default="0,21,22,23,24", help="20 + NT; 0 = the kerne
 ap.add_argument("--dtype", default="f16")
 ap.add_argument("--act", default="0")
 ap.add_argument("--gs", type=int, default=128)
+ap.add_argument("--bits", type=int, default=4)
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--layers", type=int, default=0, help="rotating layers per shape; 0 = enough for > 512 MiB of packed weights (HBM-cold, as bench.py measures), at most 64")
 ap.add_argument("--check", type=int, default=1)
@@ -43,8 +44,8 @@ geoms = [(int(g.split("x")[0]), 0) for g in a.geoms.split(",")]
 for shp in a.shapes.split(","):
     K, N = map(int, shp.split("x"))
     for act in map(int, a.act.split(",")):
-        nl = a.layers or max(4, min(64, (640 << 20) // (K * N // 2)))
-        ls = [make_layer(K, N, dev, gs=a.gs, dtype=dt, seed=i, act_order=bool(act)) for i in range(nl)]
+        nl = a.layers or max(4, min(64, (640 << 20) // (K * N * a.bits // 8)))
+        ls = [make_layer(K, N, dev, bits=a.bits, gs=a.gs, dtype=dt, seed=i, act_order=bool(act)) for i in range(nl)]
         for M in map(int, a.ms.split(",")):
             x = (torch.rand(M, K, device=dev) - 0.5).to(dt)
             best, bad = {}, {}
@@ -71,7 +72,7 @@ for shp in a.shapes.split(","):
             w = best.pop("without")
             kb = min(best, key=best.get) if best else None
             tf = 2.0 * M * K * N / 1e12
-            print(f"g{a.gs} {K}x{N} M={M:4d} {a.dtype} act={act} | without [{kname:9s}] {w * 1e6:7.2f} us | " +
+            print(f"int{a.bits} g{a.gs} {K}x{N} M={M:4d} {a.dtype} act={act} | without [{kname:9s}] {w * 1e6:7.2f} us | " +
                   " ".join(f"{k} {v * 1e6:6.2f}" for k, v in best.items()) +
                   (f" | best {kb} {best[kb] * 1e6:6.2f} us {tf / best[kb]:5.0f} TF {w / best[kb]:5.2f}x" if kb else "") +
                   (f" | MISMATCH {bad}" if bad else ""), flush=True)
