@@ -97,7 +97,7 @@ def test_no_instruction_touches_a_register_whose_asm_load_is_in_flight():
     spec = importlib.util.spec_from_file_location("isa_inflight_lint", os.path.join(ROOT, "tools", "isa_inflight_lint.py"))
     lint = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lint)
-    seen = 0
+    seen = rows_seen = 0
     with tempfile.TemporaryDirectory() as d:
         fat = os.path.join(d, "fat.bin")
         subprocess.check_call([tools[0], f"--dump-section=.hip_fatbin={fat}", SO, os.path.join(d, "copy.so")])
@@ -105,7 +105,7 @@ def test_no_instruction_touches_a_register_whose_asm_load_is_in_flight():
         starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
         for i, a in enumerate(starts):
             chunk = blob[a:starts[i + 1] if i + 1 < len(starts) else len(blob)]
-            if b"gemm_panel_kernel" not in chunk:
+            if b"gemm_panel_kernel" not in chunk and b"gemm_rows" not in chunk:      # the two kernel families built on this technique
                 continue
             part, co = os.path.join(d, f"b{i}.bin"), os.path.join(d, f"co{i}.o")
             open(part, "wb").write(chunk)
@@ -113,8 +113,9 @@ def test_no_instruction_touches_a_register_whose_asm_load_is_in_flight():
             if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
                 continue
             asm = subprocess.run([tools[2], "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
-            n = len(re.findall(r"gemm_panel_kernel\w*>?:", asm))
-            seen += n
-            bad = lint.lint(asm, "gemm_panel_kernel")
-            assert not bad, bad[:5]
-    assert seen >= 44, seen
+            seen += len(re.findall(r"gemm_panel_kernel\w*>?:", asm))
+            rows_seen += len(re.findall(r"gemm_rows(?:64)?_kernel\w*>?:", asm))
+            for fam in ("gemm_panel_kernel", "gemm_rows"):
+                bad = lint.lint(asm, fam)
+                assert not bad, bad[:5]
+    assert seen >= 44 and rows_seen >= 150, (seen, rows_seen)

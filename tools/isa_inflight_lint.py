@@ -2,7 +2,8 @@
 """Lint for kernels whose loads are inline asm with hand-counted s_waitcnt (gemm_panel_kernel.cuh, gemm_rows_kernel.cuh): in a `hipcc -S` listing (or an
 llvm-objdump disassembly) no instruction may READ a VGPR that a global_load wrote until an `s_waitcnt vmcnt(...)` has been passed -- the compiler does not know the
 asm is a load and is free to copy its destination (a v_mov at a control-flow join, a live-range split): the copy reads a register the load has not landed in.
-Straight-line scan per kernel (labels and branches ignored: conservative in both directions, good enough to catch the copies that bit round 6).
+Straight-line scan per kernel in listing order (conditional branches ignored, the state is dropped behind an unconditional branch: optimistic there,
+conservative elsewhere -- good enough to catch the copies that bit round 6).
 Usage: python tools/isa_inflight_lint.py file.s [--match gemm_panel_kernel]    exit status 1 if anything is flagged."""
 import re
 import sys
@@ -37,6 +38,9 @@ def lint(text, match):
             continue
         if op == "s_endpgm":
             kernel = None
+            continue
+        if op in ("s_branch", "s_setpc_b64"):
+            pending = {}                                   # what follows in the listing is not reached by falling through: its predecessors are elsewhere (optimistic)
             continue
         if op.startswith("global_load") and "lds" not in op and ops:
             reads = set().union(*[regs_of(o) for o in ops[1:]]) if len(ops) > 1 else set()
