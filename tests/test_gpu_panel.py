@@ -32,6 +32,9 @@ CASES = [
     (2048, 96, 256, 200, False, "groups of 256 (one group over four steps), N = 3 column blocks"),
     (768, 160, 768, 767, True, "one group over the whole K, 12 steps on 8 waves (uneven K parts), N = 5 column blocks, act-order"),
     (4096, 128, 128, 256, False, "deep K: 64 steps"),
+    (128, 32, 128, 64, False, "the smallest legal layer: two steps (six idle waves), ONE column block (wider tiles re-read block 0 for their other blocks and store nothing for them)"),
+    (128, 4128, 64, 1000, True, "two steps, 129 column blocks, 16 row tiles, act-order"),
+    (16384, 64, 128, 100, False, "very deep K: 256 steps, 32 per wave"),
 ]
 GEOMS = [21, 22, 23, 24]          # 20 + NT: 64 x 32 / 64 / 96 / 128 tiles
 
