@@ -209,9 +209,22 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
 #pragma unroll
                             for (int mt = 0; mt < MT; ++mt) a[(ks + 1) & 1][mt] = *(const u32x4*)(xb + mt * 4096 + aoff[ks + 1]);
                         }
+#if defined(GPTQ_PANEL_LAB_XISSUE) && GPTQ_PANEL_LAB_XISSUE == 1      // lab: all of the next step's x DMAs under MFMA step 0, the weights under step 1
+                        if (ks == 0) issue_x(ktx, buf ^ 1, 0, NX);
+                        if (DW == 3 && ks == 1) issue_w(ktw, q[(j + 2) % DW]);
+#elif defined(GPTQ_PANEL_LAB_XISSUE) && GPTQ_PANEL_LAB_XISSUE == 2    // lab: a third of the DMAs per MFMA step 0..2, the weights under step 3
+                        if (ks == 0) issue_x(ktx, buf ^ 1, 0, 3);
+                        if (ks == 1) issue_x(ktx, buf ^ 1, 3, 6);
+                        if (ks == 2) issue_x(ktx, buf ^ 1, 6, NX);
+                        if (DW == 3 && ks == 3) issue_w(ktw, q[(j + 2) % DW]);
+#else
                         if (ks == 0) issue_x(ktx, buf ^ 1, 0, NX / 2);
                         if (ks == 1) issue_x(ktx, buf ^ 1, NX / 2, NX);
                         if (DW == 3 && ks == 2) issue_w(ktw, q[(j + 2) % DW]);
+#endif
+#if defined(GPTQ_PANEL_LAB_PRIO)                                    // lab: the wave inside its MFMA pairs outranks its SIMD partner
+                        if (ks == 0) __builtin_amdgcn_s_setprio(1);
+#endif
                     }
 #if defined(GPTQ_PANEL_ABL) && (GPTQ_PANEL_ABL & 8)      // lab: 8 = no dequant math
                     if (i + 1 < 4 * NT) { const unsigned qq = q[j].w[(i + 1) % NT][0][((i + 1) / NT) % 3]; bq[(i + 1) & 1] = u32x4{qq, qq ^ 0x11111111u, qq ^ 0x22222222u, qq ^ q[j].cs[(i + 1) % NT]}; }
@@ -238,6 +251,9 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
                         }
                     }
                 }
+#if defined(GPTQ_PANEL_LAB_PRIO)
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 if (DW == 2) issue_w(ktw, q[j]);
             }
         }
