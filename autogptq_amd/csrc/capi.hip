@@ -321,10 +321,12 @@ static int gemv_core(const gptq_layer_t* L, const void* x, void* out, int M, con
     if (tune && tune->path == 5 && !pl.mfma && !pl.mfmag)
         return fail(GPTQ_ERR_UNSUPPORTED, "matrix-core GEMV needs fp16 / bf16, groups of whole packing units (4-bit: a power-of-two group_size >= 8), "
                                           "16-column strips for 2/3/8-bit and no raw act-order g_idx");
-    if (tune && tune->path == 4 && !pl.direct)
-        return fail(GPTQ_ERR_UNSUPPORTED, "direct GEMV needs bits=4, fp16, no act-order and a power-of-two group_size >= 8");
-    if (tune && tune->path == 2 && (!pl.fast || pl.mfma || pl.direct))
-        return fail(GPTQ_ERR_UNSUPPORTED, "fast GEMV needs bits=4, fp16 and sequential (or re-sequenced) groups");
+    if (pl.mfma && pl.ln != 4 && (L->dtype != GPTQ_F16 || pl.mt > 4 || pl.use_seq || pl.pair || (pl.ln != 8 && pl.ln != 16)))
+        return fail(GPTQ_ERR_UNSUPPORTED, "matrix-core GEMV: 32- / 64-column strips (lanes_n = 8 / 16) exist for plain fp16 layers at up to 4 rows only");
+    if (!pl.mfma && !pl.mfmag && pl.ln != 4 && pl.ln != 16 && !(pl.ln == 8 && L->dtype == GPTQ_F32))
+        return fail(GPTQ_ERR_UNSUPPORTED, "fp32-math GEMV: strips of 16 or 64 columns only (lanes_n = 4 / 16; fp32 layers also 8)");
+    if (tune && (tune->path == 2 || tune->path == 4))
+        return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = %d (round 1's LDS-staged / v_dot2 comparison GEMVs) was retired in round 6", tune->path);
     if (pl.workspace_bytes > 0 && wv.body_bytes < pl.workspace_bytes)
         return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + pl.workspace_bytes, wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0);
     hipError_t e = launch_gemv(*L, pl, x, out, M, wv.body, (hipStream_t)stream);
@@ -872,6 +874,7 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
     int rc = check_layer(L);
     if (rc) return rc;
     if (M <= 0) return fail(GPTQ_ERR_SHAPE, "M must be > 0, got %d", M);
+    if (tune && (tune->path == 2 || tune->path == 4)) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = %d was retired in round 6", tune->path);
     if (tiled_pair_call(L, M, tune)) {
         const gptq_layer_t* one[1] = {L};
         const TiledPlan tp = plan_tiled(one, 1, M, tune);
@@ -910,7 +913,7 @@ int gptq_describe_plan(const gptq_layer_t* L, int M, const gptq_tuning_t* tune, 
                  unfused_epilogue ? "separate" : "none");
     } else {
         const GemvPlan v = plan_gemv(Lc, M, tune);
-        const char* kern = v.mfma ? "mfma" : (v.mfmag ? "mfma_generic" : (v.direct ? "direct" : (v.fast ? "lds_staged" : "generic")));
+        const char* kern = v.mfma ? "mfma" : (v.mfmag ? "mfma_generic" : "generic");
         snprintf(out, out_bytes, "path=gemv kernel=%s ln=%d waves=%d u=%d ksplit=%d mt=%d strips=%d pair=%d perm=%d epilogue=%s%s", kern, v.ln,
                  v.waves, v.u, v.ksplit, v.mt, v.strips, v.pair ? 1 : 0, v.xperm ? 2 : (v.use_seq ? 1 : 0),
                  v.pair ? "fused" : (unfused_epilogue ? "separate" : "none"), v.magic ? " deq=magic" : "");

@@ -1763,7 +1763,7 @@ template <typename T> static hipError_t grant_stream64_t() {
     auto acc = [&](hipError_t r) { if (e == hipSuccess) e = r; };
     acc(grant_stream64<T, 1, 2>()); acc(grant_stream64<T, 1, 4>()); acc(grant_stream64<T, 1, 8>());
     acc(grant_stream64<T, 2, 2>()); acc(grant_stream64<T, 2, 4>());
-    acc(grant_stream64<T, 4, 1>()); acc(grant_stream64<T, 4, 2>()); acc(grant_stream64<T, 4, 4>());
+    acc(grant_stream64<T, 4, 1>());
     return e;
 }
 
@@ -1836,7 +1836,7 @@ Stream64Plan plan_stream64(const gptq_layer_t* const* Ls, int n, int M, const gp
     int u = (tune && tune->reserved[0] > 0) ? tune->reserved[0] : (pl.mt == 4 ? 1 : 2);   // 4 row tiles: two pipelined passes of ONE K-step each (U = 2 spills 44 registers)
     if (pl.mt == 1) u = u >= 8 ? 8 : (u >= 4 ? 4 : 2);
     else if (pl.mt == 2) u = u >= 4 ? 4 : 2;
-    else u = u >= 4 ? 4 : (u >= 2 ? 2 : 1);
+    else u = 1;                                   // (the 2- / 4-step forms of 4 row tiles spilled 44..150 registers: retired)
     pl.u = u;
     const size_t land = (size_t)waves * u * 1024 * (pl.mt > 1 ? 2 : 1), slabs = (size_t)waves * pl.mt * 4096;     // 2+ row tiles: pipelined passes, two landing areas
     pl.lds_bytes = (land > slabs ? land : slabs) + 16;
@@ -1864,8 +1864,6 @@ static hipError_t launch_stream64_t(const Stream64Plan& pl, const S64Params& p, 
         case 32 + 2: return launch_stream64_one<T, 2, 2>(pl, p, st);
         case 32 + 4: return launch_stream64_one<T, 2, 4>(pl, p, st);
         case 64 + 1: return launch_stream64_one<T, 4, 1>(pl, p, st);
-        case 64 + 2: return launch_stream64_one<T, 4, 2>(pl, p, st);
-        case 64 + 4: return launch_stream64_one<T, 4, 4>(pl, p, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -2201,7 +2199,9 @@ static hipError_t launch_skinny(const GemmPlan& pl, const GemmParams& p, hipStre
     switch (pl.mt) {
         case 1: return u4 ? launch_skinny_one<BITS, T, 1, 4>(pl, p, st) : launch_skinny_one<BITS, T, 1, 2>(pl, p, st);
         case 2: return u4 ? launch_skinny_one<BITS, T, 2, 4>(pl, p, st) : launch_skinny_one<BITS, T, 2, 2>(pl, p, st);
-        case 4: return u4 ? launch_skinny_one<BITS, T, 4, 4>(pl, p, st) : launch_skinny_one<BITS, T, 4, 2>(pl, p, st);
+        case 4:      // (3 bits, 64 rows: four unrolled steps spill 3..9 registers -- two at a time, which every group that allows four allows too)
+            if constexpr (BITS == 3) return launch_skinny_one<BITS, T, 4, 2>(pl, p, st);
+            else return u4 ? launch_skinny_one<BITS, T, 4, 4>(pl, p, st) : launch_skinny_one<BITS, T, 4, 2>(pl, p, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -508,7 +508,7 @@ static hipError_t rows_grant_s() {
     hipError_t e = rows_grant_one<T, BITS, RB, 1, GM>();
     if (e == hipSuccess) e = rows_grant_one<T, BITS, RB, 2, GM>();
     if (e == hipSuccess) e = rows_grant_one<T, BITS, RB, 3, GM>();
-    if (e == hipSuccess) e = rows_grant_one<T, BITS, RB, 4, GM>();
+    if constexpr (!(BITS == 8 && RB == 1)) { if (e == hipSuccess) e = rows_grant_one<T, BITS, RB, 4, GM>(); }
     if constexpr (RB == 2 && BITS == 4) { if (e == hipSuccess) e = rows_grant_one<T, BITS, RB, 6, GM>(); }      // (RB = 1: 6 strips spill at 128 registers; 8 spill in either form)
     return e;
 }
@@ -548,7 +548,7 @@ static hipError_t rows_launch_s(const RowsPlan& pl, const rowsk::RowsParams& p, 
         case 1: rows_launch_one<T, BITS, RB, 1, GM>(pl, p, st); break;
         case 2: rows_launch_one<T, BITS, RB, 2, GM>(pl, p, st); break;
         case 3: rows_launch_one<T, BITS, RB, 3, GM>(pl, p, st); break;
-        case 4: rows_launch_one<T, BITS, RB, 4, GM>(pl, p, st); break;
+        case 4: if constexpr (!(BITS == 8 && RB == 1)) { rows_launch_one<T, BITS, RB, 4, GM>(pl, p, st); break; } else return hipErrorInvalidValue;      // (8 bits, one row block, four strips: spills -- plan_rows never asks for it)
         case 6: if constexpr (RB == 2 && BITS == 4) { rows_launch_one<T, BITS, RB, 6, GM>(pl, p, st); break; } else return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }

@@ -22,8 +22,8 @@
 //    time with the fp16 magic number (MagicF16: 16-bit windows of the 3-bit stream at multiples of 15 bits line up in both halves of a
 //    register), everything else field by field.  Act-order layers of these packings: x permuted once by the column-permute pre-pass.
 //    fp32 I/O, raw (non-uniform) act-order g_idx, odd group sizes: gemv_generic_kernel (fp32 FMA, x in LDS).
-//    gemv_q4_f16_direct_kernel (v_dot2 reduction) and gemv_q4_f16_kernel (LDS-staged x / group constants,
-//    the first working path of round 1) are kept as comparison variants behind tuning.path = 4 / 2.
+//    (Round 1's LDS-staged kernel and the v_dot2 register kernel -- comparison variants behind tuning.path = 2 / 4 -- were retired in
+//    round 6: no default plan could reach them; 4-bit fp16 layers whose groups are not a power of two go to gemv_generic_kernel.)
 //  * act-order layers read the group-sorted side copy of qweight; x is gathered through perm[] (whole row
 //    staged in LDS once, rows pulled with ds_bpermute), which is the whole cost of act-order on this path.
 //  * K reduction: row slots by DPP rotates / ds_bpermute, waves through LDS in fixed order (the kernel's
@@ -36,433 +36,9 @@
 
 namespace gptq {
 
-struct GemvParams {
-    const unsigned* qweight;
-    const unsigned* qzeros;
-    const void* scales;
-    const int* g_idx;   // per-k groups (PERK mode) or nullptr
-    const int* perm;    // x gather for re-sequenced act-order layers, or nullptr
-    const void* bias;
-    const void* x;
-    void* out;
-    float* partial;     // [ksplit][M][N] when ksplit > 1
-    int M, K, N, group_size, zero_mode;
-    int units_total, units_per_split, chunk_units, ksplit;
-    int gu_shift;       // log2(group_size / 8) or -1 (fast path)
-    int pair_off;       // SILU_MUL epilogue: column distance between the gate and the up half (N / 2), else 0
-};
-
-// ---- shared epilogue: reduce row slots (shuffles), waves (LDS), then write ------------------
-template <typename T, int LN, int MT>
-__device__ __forceinline__ void reduce_and_store(float (&acc)[MT][4], float* red, const GemvParams& p,
-                                                 int strip, int m0) {
-    constexpr int CT = LN * 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float v = acc[m][c];
-#pragma unroll
-            for (int off = LN; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-            acc[m][c] = v;
-        }
-    __syncthreads();  // everyone is done reading the x chunk that aliases `red`
-    if (lane < LN) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) red[(wave * MT + m) * CT + lane * 4 + c] = acc[m][c];
-    }
-    __syncthreads();
-    for (int i = tid; i < MT * CT; i += blockDim.x) {
-        const int m = i / CT, c = i % CT;
-        const int n = strip * CT + c, row = m0 + m;
-        if (n >= p.N || row >= p.M) continue;
-        float s = 0.f;
-        for (int w = 0; w < W; ++w) s += red[(w * MT + m) * CT + c];
-        if (p.ksplit > 1) {
-            p.partial[((size_t)blockIdx.y * p.M + row) * p.N + n] = s;
-        } else {
-            if (p.bias) s += DType<T>::to_f32(((const T*)p.bias)[n]);
-            ((T*)p.out)[(size_t)row * p.N + n] = DType<T>::from_f32(s);
-        }
-    }
-}
-
-// ---- generic kernel: any bits / dtype / group structure, fp32 math -------------------------
-// PERK = false: one (scale, zero) per packed unit and column (sequential groups, unit inside a
-//               group);  PERK = true: group looked up per k (raw act-order g_idx, odd group sizes).
-template <int BITS, typename T, int LN, int MT, bool PERK>
-__global__ void __launch_bounds__(1024) gemv_generic_kernel(GemvParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xs = (float*)smem;
-    constexpr int UW = Pack<BITS>::words, KPU = Pack<BITS>::vals, WR = 64 / LN, CT = LN * 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
-    const int cl = lane % LN, rs = lane / LN;
-    const int strip = xcd_remap(blockIdx.x, gridDim.x);
-    const int n0 = strip * CT + cl * 4;
-    const bool col_ok = n0 < p.N;
-    const int m0 = blockIdx.z * MT;
-    const int ub = blockIdx.y * p.units_per_split;
-    const int ue = min(ub + p.units_per_split, p.units_total);
-    const int xstride = p.chunk_units * KPU;
-    const T* __restrict__ x = (const T*)p.x;
-    const T* __restrict__ scales = (const T*)p.scales;
-    const int zrow_words = p.N / 32 * BITS;
-
-    float acc[MT][4];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[m][c] = 0.f;
-
-    for (int cb = ub; cb < ue; cb += p.chunk_units) {
-        const int ce = min(cb + p.chunk_units, ue);
-        const int kc = (ce - cb) * KPU, kbase = cb * KPU;
-        if (cb != ub) __syncthreads();
-        for (int i = tid; i < MT * kc; i += blockDim.x) {
-            const int m = i / kc, kk = i - m * kc;
-            const int k = kbase + kk;
-            const int src = p.perm ? p.perm[k] : k;
-            xs[m * xstride + kk] = (m0 + m < p.M) ? DType<T>::to_f32(x[(size_t)(m0 + m) * p.K + src]) : 0.f;
-        }
-        __syncthreads();
-        for (int it = 0;; ++it) {
-            const int ubase = cb + (it * W + wave) * WR;
-            if (ubase >= ce) break;
-            const int u = ubase + rs;
-            if (u >= ce || !col_ok) continue;
-            u32x4 q[UW];
-#pragma unroll
-            for (int w = 0; w < UW; ++w)
-                q[w] = *(const u32x4*)(p.qweight + (size_t)(u * UW + w) * p.N + n0);
-            const int k0 = u * KPU;
-            const float* xk = xs + (k0 - kbase);
-            if constexpr (!PERK) {
-                const int g = k0 / p.group_size;
-                float s[4];
-                int z[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) s[c] = DType<T>::to_f32(scales[(size_t)g * p.N + n0 + c]);
-                zero_points4(p.qzeros + (size_t)g * zrow_words, n0, BITS, p.zero_mode, z);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    unsigned w[UW];
-#pragma unroll
-                    for (int i = 0; i < UW; ++i) w[i] = q[i][c];
-                    float d[MT];
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) d[m] = 0.f;
-                    // w - z in integers (exact), like the reference's (weight - zeros): a layer whose fields equal their
-                    // zero-point gives exactly 0, with no cancellation between sum(x*w) and z*sum(x)
-                    [&]<int... V>(std::integer_sequence<int, V...>) {
-                        (([&] {
-                             const float wf = (float)((int)unit_field<BITS, V>(w) - z[c]);
-#pragma unroll
-                             for (int m = 0; m < MT; ++m) d[m] = fmaf(xk[m * xstride + V], wf, d[m]);
-                         }()),
-                         ...);
-                    }(std::make_integer_sequence<int, KPU>{});
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) acc[m][c] = fmaf(s[c], d[m], acc[m][c]);
-                }
-            } else {
-                [&]<int... V>(std::integer_sequence<int, V...>) {
-                    (([&] {
-                         const int k = k0 + V;
-                         const int g = p.g_idx ? p.g_idx[k] : k / p.group_size;
-                         int z[4];
-                         zero_points4(p.qzeros + (size_t)g * zrow_words, n0, BITS, p.zero_mode, z);
-#pragma unroll
-                         for (int c = 0; c < 4; ++c) {
-                             unsigned w[UW];
-#pragma unroll
-                             for (int i = 0; i < UW; ++i) w[i] = q[i][c];
-                             const float s = DType<T>::to_f32(scales[(size_t)g * p.N + n0 + c]);
-                             const float dq = s * (float)((int)unit_field<BITS, V>(w) - z[c]);
-#pragma unroll
-                             for (int m = 0; m < MT; ++m) acc[m][c] = fmaf(xk[m * xstride + V], dq, acc[m][c]);
-                         }
-                     }()),
-                     ...);
-                }(std::make_integer_sequence<int, KPU>{});
-            }
-        }
-    }
-    reduce_and_store<T, LN, MT>(acc, (float*)smem, p, strip, m0);
-}
-
-// ---- fast kernel: 4-bit, fp16, sequential groups (or re-sequenced act-order via perm) -------
-// LDS per K-chunk (all accesses typed u32x4/u32x2 -- no type punning through memory):
-//   xs [MT][chunk_units]      u32x4 : 8 fp16 of x per packed row, stored as pairs (0,4)(1,5)(2,6)(3,7)
-//   sz [chunk_groups][CT]     u32x2 : { half2(-(1024+z), -(1024+z)) bits , scale as fp32 bits }
-// Per lane: all weight loads of the chunk are issued first (U deep, nontemporal), then the
-// workgroup stages x / scale / zero constants, one barrier, then the lanes consume their units.
-template <int LN, int MT, int U>
-__global__ void __launch_bounds__(1024) gemv_q4_f16_kernel(GemvParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int WR = 64 / LN, CT = LN * 4;
-    u32x4* xs = (u32x4*)smem;
-    u32x2* sz = (u32x2*)(smem + (size_t)MT * p.chunk_units * 16);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
-    const int cl = lane % LN, rs = lane / LN;
-    const int strip = xcd_remap(blockIdx.x, gridDim.x);
-    const int n0 = strip * CT + cl * 4;
-    const bool col_ok = n0 < p.N;
-    const int nload = col_ok ? n0 : 0;
-    const int m0 = blockIdx.z * MT;
-    const int ub = blockIdx.y * p.units_per_split;
-    const int ue = min(ub + p.units_per_split, p.units_total);
-    const f16* __restrict__ x = (const f16*)p.x;
-    const f16* __restrict__ scales = (const f16*)p.scales;
-    const int zrow_words = p.N >> 3;
-    const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
-    const int gunits = p.group_size >> 3;   // packed rows per group
-    const int gshift = p.gu_shift;
-
-    float acc[MT][4];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[m][c] = 0.f;
-
-    for (int cb = ub; cb < ue; cb += p.chunk_units) {
-        const int ce = min(cb + p.chunk_units, ue);
-        const int nu = ce - cb;
-        const int g_first = gshift >= 0 ? (cb >> gshift) : (cb / gunits);
-        const int g_last = gshift >= 0 ? ((ce - 1) >> gshift) : ((ce - 1) / gunits);
-        const int ng = g_last - g_first + 1;
-        const int row_step = W * WR;
-        for (int base = cb; base < ce; base += U * row_step) {
-            // -- 1. weights first: U independent 16-B loads per lane, all in flight ---------------
-            u32x4 q[U];
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const int u = base + j * row_step + wave * WR + rs;
-                const int ul = min(u, ce - 1);
-                q[j] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)ul * p.N + nload));
-            }
-            // -- 2. first pass of the chunk: stage x and the (scale, zero) constants ---------------
-            if (base == cb) {
-                if (cb != ub) __syncthreads();
-                for (int i = tid; i < MT * nu; i += blockDim.x) {
-                    const int m = i / nu, ul = i - m * nu;
-                    const int k0 = (cb + ul) * 8;
-                    u32x4 o = {0u, 0u, 0u, 0u};
-                    if (m0 + m < p.M) {
-                        const f16* xr = x + (size_t)(m0 + m) * p.K;
-                        unsigned short h[8];
-                        if (p.perm) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) h[j] = as_u16(xr[p.perm[k0 + j]]);
-                        } else {
-                            const u32x4 t = *(const u32x4*)(xr + k0);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { h[2 * j] = (unsigned short)(t[j] & 0xffffu); h[2 * j + 1] = (unsigned short)(t[j] >> 16); }
-                        }
-                        o[0] = (unsigned)h[0] | ((unsigned)h[4] << 16);
-                        o[1] = (unsigned)h[1] | ((unsigned)h[5] << 16);
-                        o[2] = (unsigned)h[2] | ((unsigned)h[6] << 16);
-                        o[3] = (unsigned)h[3] | ((unsigned)h[7] << 16);
-                    }
-                    xs[m * p.chunk_units + ul] = o;
-                }
-                for (int i = tid; i < ng * LN; i += blockDim.x) {
-                    const int gl = i / LN, c4 = i - gl * LN;
-                    const int g = g_first + gl;
-                    const int nn = strip * CT + c4 * 4;
-                    if (nn < p.N) {
-                        const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * p.N + nn);
-                        const unsigned zw = p.qzeros[(size_t)g * zrow_words + (nn >> 3)] >> ((nn & 7) * 4);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const unsigned z = (((zw >> (4 * c)) & 15u) + 1u) & zmask;
-                            const unsigned sh = (c & 1) ? (sraw[c >> 1] >> 16) : (sraw[c >> 1] & 0xffffu);
-                            const float sf = (float)as_f16((unsigned short)sh);
-                            u32x2 e = {z * 0x00010001u + 0xE400E400u, as_u32(sf)};
-                            sz[(gl * CT) + c4 * 4 + c] = e;
-                        }
-                    }
-                }
-                __syncthreads();
-            }
-            // -- 3. consume -----------------------------------------------------------------------
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const int u = base + j * row_step + wave * WR + rs;
-                if (u >= ce || !col_ok) continue;
-                const u32x4 qv = q[j];
-                const int gl = (gshift >= 0 ? (u >> gshift) : (u / gunits)) - g_first;
-                const u32x4 e01 = *(const u32x4*)(sz + gl * CT + cl * 4);
-                const u32x4 e23 = *(const u32x4*)(sz + gl * CT + cl * 4 + 2);
-                const unsigned c1b[4] = {e01[0], e01[2], e23[0], e23[2]};
-                const float sc[4] = {as_f32(e01[1]), as_f32(e01[3]), as_f32(e23[1]), as_f32(e23[3])};
-                f16x2 xa[MT][4];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const u32x4 xv = xs[m * p.chunk_units + (u - cb)];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) xa[m][i] = as_f16x2(xv[i]);
-                }
-                const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
-                const f16x2 k960 = {(f16)960.f, (f16)960.f};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f16x2 c1 = as_f16x2(c1b[c]);   // -(1024+z)
-                    const f16x2 c2 = c1 + k960;                            // -(64+z), exact
-                    const unsigned qw = qv[c], q8 = qw >> 8;
-                    const f16x2 h0 = as_f16x2((qw & 0x000f000fu) | 0x64006400u) + c1;                 // k0,k4
-                    const f16x2 h1 = as_f16x2((qw & 0x00f000f0u) | 0x64006400u) * r16 + c2;           // k1,k5
-                    const f16x2 h2 = as_f16x2((q8 & 0x000f000fu) | 0x64006400u) + c1;                 // k2,k6
-                    const f16x2 h3 = as_f16x2((q8 & 0x00f000f0u) | 0x64006400u) * r16 + c2;           // k3,k7
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        float d = __builtin_amdgcn_fdot2(h0, xa[m][0], 0.f, false);
-                        d = __builtin_amdgcn_fdot2(h1, xa[m][1], d, false);
-                        d = __builtin_amdgcn_fdot2(h2, xa[m][2], d, false);
-                        d = __builtin_amdgcn_fdot2(h3, xa[m][3], d, false);
-                        acc[m][c] = fmaf(sc[c], d, acc[m][c]);
-                    }
-                }
-            }
-        }
-    }
-    reduce_and_store<f16, LN, MT>(acc, (float*)smem, p, strip, m0);
-}
-
-// ---- direct kernel: 4-bit, fp16, sequential groups, NO LDS staging ----------------------------
-// Same decomposition as gemv_q4_f16_kernel, but nothing is staged before the math: each lane loads,
-// next to its U packed rows (16 B each, nontemporal), the 8 fp16 of x those rows multiply (16 B, L1/L2
-// resident) and ONE (scales, zeros) pair for its 4 columns -- the lane's U rows are consecutive and lie
-// in one group.  All loads are issued back to back, then the lane computes out of registers; the only
-// workgroup-level step is the final cross-wave sum (one barrier in the whole kernel).
-template <int LN, int MT, int U>
-__global__ void __launch_bounds__(1024) gemv_q4_f16_direct_kernel(GemvParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = (float*)smem;
-    constexpr int WR = 64 / LN, CT = LN * 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
-    const int cl = lane % LN, rs = lane / LN;
-    const int strip = xcd_remap(blockIdx.x, gridDim.x);
-    const int n0 = strip * CT + cl * 4;
-    const bool col_ok = n0 < p.N;
-    const int nload = col_ok ? n0 : 0;
-    const int m0 = blockIdx.z * MT;
-    const int ub = blockIdx.y * p.units_per_split;
-    const int ue = min(ub + p.units_per_split, p.units_total);
-    const f16* __restrict__ x = (const f16*)p.x;
-    const f16* __restrict__ scales = (const f16*)p.scales;
-    const int zrow_words = p.N >> 3;
-    const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
-    const int gshift = p.gu_shift;          // log2(packed rows per group); the launcher guarantees it exists
-
-    float acc[MT][4];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[m][c] = 0.f;
-
-    const int rows_per_iter = W * WR * U;
-    for (int base = ub; base < ue; base += rows_per_iter) {
-        const int u0 = base + (wave * WR + rs) * U;        // this lane's first row of the iteration
-        // -- 1. every load of the iteration, back to back ---------------------------------------
-        const int g = min(u0, ue - 1) >> gshift;
-        const u32x2 sraw = *(const u32x2*)(scales + (size_t)g * p.N + nload);
-        const unsigned zw = p.qzeros[(size_t)g * zrow_words + (nload >> 3)] >> ((nload & 7) * 4);
-        u32x4 xr[MT][U];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const f16* xrow = x + (size_t)min(m0 + m, p.M - 1) * p.K;
-#pragma unroll
-            for (int j = 0; j < U; ++j) xr[m][j] = *(const u32x4*)(xrow + (size_t)min(u0 + j, ue - 1) * 8);
-        }
-        u32x4 q[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int ul = min(u0 + j, ue - 1);
-            q[j] = __builtin_nontemporal_load((const u32x4*)(p.qweight + (size_t)ul * p.N + nload));
-        }
-        // -- 2. per-column constants -------------------------------------------------------------
-        f16x2 c1[4], c2[4];
-        float sc[4];
-        const f16x2 k960 = {(f16)960.f, (f16)960.f};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const unsigned z = (((zw >> (4 * c)) & 15u) + 1u) & zmask;
-            c1[c] = as_f16x2(z * 0x00010001u + 0xE400E400u);    // -(1024+z)
-            c2[c] = c1[c] + k960;                               // -(64+z)
-            const unsigned sh = (c & 1) ? (sraw[c >> 1] >> 16) : (sraw[c >> 1] & 0xffffu);
-            sc[c] = (float)as_f16((unsigned short)sh);
-        }
-        // -- 3. math out of registers ------------------------------------------------------------
-        const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f};
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            if (u0 + j >= ue) continue;                         // tail rows (clamped loads) contribute nothing
-            const u32x4 qv = q[j];
-            f16x2 xa[MT][4];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const u32x4 t = xr[m][j];                       // (x0,x1)(x2,x3)(x4,x5)(x6,x7) -> (0,4)(1,5)(2,6)(3,7)
-                xa[m][0] = as_f16x2(__builtin_amdgcn_perm(t[2], t[0], 0x05040100u));
-                xa[m][1] = as_f16x2(__builtin_amdgcn_perm(t[2], t[0], 0x07060302u));
-                xa[m][2] = as_f16x2(__builtin_amdgcn_perm(t[3], t[1], 0x05040100u));
-                xa[m][3] = as_f16x2(__builtin_amdgcn_perm(t[3], t[1], 0x07060302u));
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const unsigned qw = qv[c], q8 = qw >> 8;
-                const f16x2 h0 = as_f16x2((qw & 0x000f000fu) | 0x64006400u) + c1[c];
-                const f16x2 h1 = as_f16x2((qw & 0x00f000f0u) | 0x64006400u) * r16 + c2[c];
-                const f16x2 h2 = as_f16x2((q8 & 0x000f000fu) | 0x64006400u) + c1[c];
-                const f16x2 h3 = as_f16x2((q8 & 0x00f000f0u) | 0x64006400u) * r16 + c2[c];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    float d = __builtin_amdgcn_fdot2(h0, xa[m][0], 0.f, false);
-                    d = __builtin_amdgcn_fdot2(h1, xa[m][1], d, false);
-                    d = __builtin_amdgcn_fdot2(h2, xa[m][2], d, false);
-                    d = __builtin_amdgcn_fdot2(h3, xa[m][3], d, false);
-                    acc[m][c] = fmaf(sc[c], d, acc[m][c]);
-                }
-            }
-        }
-    }
-    // ---- reduce: row slots by shuffles, waves through LDS (the kernel's only barrier), write ----
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float v = acc[m][c];
-#pragma unroll
-            for (int off = LN; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-            acc[m][c] = v;
-        }
-    if (lane < LN) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            f32x4 v = {acc[m][0], acc[m][1], acc[m][2], acc[m][3]};
-            *(f32x4*)(red + (wave * MT + m) * CT + lane * 4) = v;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < MT * CT; i += blockDim.x) {
-        const int m = i / CT, c = i % CT;
-        const int n = strip * CT + c, row = m0 + m;
-        if (n >= p.N || row >= p.M) continue;
-        float s = 0.f;
-        for (int w = 0; w < W; ++w) s += red[(w * MT + m) * CT + c];
-        if (p.ksplit > 1) {
-            p.partial[((size_t)blockIdx.y * p.M + row) * p.N + n] = s;
-        } else {
-            if (p.bias) s += (float)((const f16*)p.bias)[n];
-            ((f16*)p.out)[(size_t)row * p.N + n] = (f16)s;
-        }
-    }
-}
 
 // ---- matrix-core GEMV: 4-bit, fp16, sequential groups -------------------------------------------
-// Same load structure as the direct kernel, but the k-reduction runs on the matrix core:
+// Every lane loads its U packed rows, the x they multiply and one (scales, zeros) pair straight into registers; the k-reduction runs on the matrix core:
 // v_mfma_f32_4x4x4_16b_f16 is 16 independent 4x4x4 products, one per aligned group of 4 lanes -- and an
 // aligned group of 4 lanes here is exactly one packed row x 16 columns.  Lane j of a group supplies B = 4
 // consecutive-slot k of ITS OWN column, lane i supplies A = the same 4 k of x row i, and lane j receives
@@ -957,11 +533,9 @@ __global__ void __launch_bounds__(1024, WPS) gemv_q4_stream_kernel(GemvStreamPar
     const unsigned zmask = (p.zero_mode == GPTQ_ZERO_WRAP) ? 15u : 31u;
     const int gshift = p.gu_shift;
 
-    float acc[4][MT];
+    f32x4 acc[MT];                 // [row of x] = the lane's 4 columns (whole-vector accesses only: a float[4][MT] was half-promoted, the rest sat in scratch)
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[c][m] = 0.f;
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int rows_per_iter = W * WR * U;
     for (int base = ub; base < ue; base += rows_per_iter) {
@@ -1058,11 +632,11 @@ __global__ void __launch_bounds__(1024, WPS) gemv_q4_stream_kernel(GemvStreamPar
             const unsigned sh = (c & 1) ? (sw >> 16) : (sw & 0xffffu);
             const float sc = DType<T>::to_f32(__builtin_bit_cast(T, (unsigned short)sh));
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[c][m] = fmaf(sc, accg[c][m], acc[c][m]);
+            for (int m = 0; m < MT; ++m) acc[m][c] = fmaf(sc, accg[c][m], acc[m][c]);
         }
     }
 #if defined(GPTQ_STREAM_ABL) && (GPTQ_STREAM_ABL & 8)
-    if (acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] == 1.2345f) ((T*)sg.out)[n0] = DType<T>::from_f32(acc[0][0]);
+    if (acc[0][0] + acc[0][1] + acc[0][2] + acc[0][3] == 1.2345f) ((T*)sg.out)[n0] = DType<T>::from_f32(acc[0][0]);
     return;
 #endif
     stream_epilogue<LN, MT, T>(acc, p, sg, strip, sidx, ks, N, red);
@@ -1108,11 +682,9 @@ __global__ void __launch_bounds__(1024, 4) gemv_qx_stream_kernel(GemvStreamParam
     const int gshift = p.gu_shift;
     constexpr unsigned maxq = (1u << BITS) - 1u;
 
-    float acc[4][MT];
+    f32x4 acc[MT];                 // [row of x] = the lane's 4 columns (whole-vector accesses only: a float[4][MT] was half-promoted, the rest sat in scratch)
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[c][m] = 0.f;
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     MagicConsts mk;
     mk.init();
 
@@ -1190,7 +762,7 @@ __global__ void __launch_bounds__(1024, 4) gemv_qx_stream_kernel(GemvStreamParam
             const unsigned sh = (c & 1) ? (sraw[c >> 1] >> 16) : (sraw[c >> 1] & 0xffffu);
             const float sc = DType<T>::to_f32(__builtin_bit_cast(T, (unsigned short)sh));
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[c][m] = fmaf(sc, accg[c][m], acc[c][m]);
+            for (int m = 0; m < MT; ++m) acc[m][c] = fmaf(sc, accg[c][m], acc[m][c]);
         }
     }
     stream_epilogue<LN, MT, T>(acc, p, sg, strip, sidx, ks, N, red);
@@ -1411,7 +983,7 @@ GemvPlan plan_gemv(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     if (L.epilogue == GPTQ_EPI_SILU_MUL) {
         // fused epilogue: the workgroup grid covers the N/2 output columns; only the matrix-core kernel implements it
         GemvPlan pl = plan_gemv_n(L, M, tune, L.N / 2);
-        if (pl.mfma && pl.ksplit == 1 && pl.ln == 4 && M <= 8) {
+        if (pl.mfma && pl.ksplit == 1 && pl.ln == 4 && M <= 4) {      // (5..8 rows: the unfused call -- the 8-row PAIR forms spilled and lost to it)
             pl.pair = true;
             if (pl.u > 2) pl.u = 2;
             pl.lds_bytes *= 2;
@@ -1454,20 +1026,16 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
     const bool seq = (L.g_idx == nullptr) || (L.qweight_seq != nullptr && L.perm != nullptr);
     pl.perk = !(uniform_groups && seq);
     pl.use_seq = (L.g_idx != nullptr) && !pl.perk;
-    pl.fast = (L.bits == 4 && L.dtype == GPTQ_F16 && !pl.perk);
-    if (path == 1) pl.fast = false;
-    // register-direct variants (no LDS staging): power-of-two packed rows per group, no x gather
+    // matrix-core kernels (no LDS staging): power-of-two packed rows per group
     const int gu = L.group_size / 8;
     const bool q4_16 = L.bits == 4 && !pl.perk && path != 1 && (L.dtype == GPTQ_F16 || L.dtype == GPTQ_BF16);
     const bool pow2_groups = q4_16 && gu > 0 && (gu & (gu - 1)) == 0;
     const bool ln_ok = !(tune && tune->lanes_n && tune->lanes_n != 4);
     // default for 4-bit fp16 / bf16 layers; act-order layers (x gathered through perm) and bf16 only with 16-column strips
-    const bool ln_wide = tune && (tune->lanes_n == 8 || tune->lanes_n == 16);      // bf16: 16/32/64-column strips (plain layers)
     pl.mfma = pow2_groups && (path == 0 || path == 5) && (!pl.use_seq || (ln_ok && L.K <= 24576)) &&
-              (L.dtype == GPTQ_F16 || ln_ok || (ln_wide && !pl.use_seq));
-    pl.direct = pow2_groups && L.dtype == GPTQ_F16 && !pl.use_seq && path == 4;
+              (L.dtype == GPTQ_F16 || ln_ok);
     // the other packings (and 4-bit bf16): matrix-core kernel with integer field extraction; 16-column strips only
-    pl.mfmag = !pl.mfma && !pl.direct && (path == 0 || path == 5) && !pl.perk && !pl.use_seq && ln_ok &&
+    pl.mfmag = !pl.mfma && (path == 0 || path == 5) && !pl.perk && !pl.use_seq && ln_ok &&
                (L.dtype == GPTQ_F16 || L.dtype == GPTQ_BF16) && !(L.bits == 4 && L.dtype == GPTQ_F16);
     if (pl.mfma) {                 // the matrix core handles 4 rows of x per pass, whatever M is
         pl.mt = M >= 5 ? 8 : (M >= 3 ? 4 : M);         // 8 = two groups of 4 rows in one pass
@@ -1486,15 +1054,14 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
         }
     } else {
         pl.mt = pick_mt(M);
-        if (pl.direct && pl.mt > 4) pl.mt = 4;
-        if (!pl.fast && pl.mt > 4) pl.mt = 4;
-        if (!pl.fast && L.bits == 3) pl.mt = pl.perk ? 1 : (pl.mt > 2 ? 2 : pl.mt);   // 32 fields per unit: more rows of x spill
+        if (pl.mt > 4) pl.mt = 4;
+        if (L.bits == 3) pl.mt = pl.perk ? 1 : (pl.mt > 2 ? 2 : pl.mt);   // 32 fields per unit: more rows of x spill
         pl.mtiles = (M + pl.mt - 1) / pl.mt;
     }
 
     int ln = (tune && tune->lanes_n) ? tune->lanes_n : 0;
     if (!ln) {
-        if (pl.mfma || pl.direct || pl.mfmag) {
+        if (pl.mfma || pl.mfmag) {
             // measured (tools/gemvlab, tools/membench): without a K split the 16-column strip wins on every
             // Llama shape -- a second (reduce) launch costs more than the 64-byte row segments do
             ln = 4;
@@ -1519,6 +1086,7 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
         } else {
             ln = 4;   // widest strip that still gives >= 256 workgroups; else the narrowest (16 columns)
             for (int cand : {16, 8}) {
+                if (cand == 8 && L.dtype != GPTQ_F32) continue;       // 32-column strips: instantiated for fp32 layers only
                 const int strips = (N_cols + cand * 4 - 1) / (cand * 4);
                 if (strips * pl.mtiles >= 256) { ln = cand; break; }
             }
@@ -1572,7 +1140,7 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
         pl.lds_bytes = rbytes;
         return pl;
     }
-    if (pl.mfma || pl.direct) {
+    if (pl.mfma) {
         // consecutive packed rows per lane and iteration: same group, so one (scales, zeros) fetch serves them
         const int per_lane = (pl.units_per_split + rows_per_iter - 1) / rows_per_iter;
         int want = pl.units_per_split >= 1024 ? 1 : 2;             // long K: more, shorter iterations pipeline better
@@ -1581,7 +1149,7 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
         // act-order: the x gather is a dependent round trip per iteration -> few iterations; bf16 pays conversions per row, U = 2
         if (pl.use_seq) want = act_m1 ? ((L.dtype == GPTQ_BF16 && L.K <= 8192) ? 2 : 4) : 2;
         int u = 1;
-        while (u * 2 <= per_lane && u * 2 <= gu && u * 2 <= 8 && (pl.mfma || u * 2 * pl.mt <= 8) &&
+        while (u * 2 <= per_lane && u * 2 <= gu && u * 2 <= 4 && 
                pl.units_per_split % (u * 2) == 0 && (tune && tune->reserved[0] > 0 ? u * 2 <= tune->reserved[0] : u * 2 <= want))
             u *= 2;
         pl.u = u;
@@ -1590,89 +1158,16 @@ static GemvPlan plan_gemv_n(const gptq_layer_t& L, int M, const gptq_tuning_t* t
         if (pl.mfma && pl.use_seq && pl.mt == 1) pl.lds_bytes += (size_t)L.K * 2;   // whole x row for the LDS gather
         return pl;
     }
-    // LDS-staged kernels: x tile (+ for the fast path the per-group constants) per K-chunk, kept <= 64 KiB
-    const int gunits = (pl.fast && L.group_size >= kpu) ? L.group_size / kpu : 1;
+    // gemv_generic_kernel: x tile in LDS per K-chunk, kept <= 64 KiB
     auto lds_for = [&](int cu) -> size_t {
-        if (pl.fast) return (size_t)pl.mt * cu * 16 + (size_t)(cu / gunits + 2) * ln * 4 * 8;
         return (size_t)pl.mt * cu * kpu * 4;
     };
     int cu = pl.units_per_split;
     while (cu > rows_per_iter && lds_for(cu) > 64 * 1024) cu = ((cu / 2 + rows_per_iter - 1) / rows_per_iter) * rows_per_iter;
-    if (pl.fast && cu < pl.units_per_split && cu > gunits) cu = (cu / gunits) * gunits;   // chunk on group boundaries
     pl.chunk_units = cu;
     const size_t xbytes = lds_for(cu);
     pl.lds_bytes = xbytes > rbytes ? xbytes : rbytes;
     return pl;
-}
-
-template <int BITS, typename T, int LN, int MT>
-static hipError_t launch_generic_ln(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
-    dim3 grid(pl.strips, pl.ksplit, pl.mtiles), block(pl.waves * 64);
-    if (pl.perk)
-        hipLaunchKernelGGL((gemv_generic_kernel<BITS, T, LN, MT, true>), grid, block, pl.lds_bytes, st, p);
-    else
-        hipLaunchKernelGGL((gemv_generic_kernel<BITS, T, LN, MT, false>), grid, block, pl.lds_bytes, st, p);
-    return hipGetLastError();
-}
-
-template <int BITS, typename T, int MT>
-static hipError_t launch_generic_mt(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
-    switch (pl.ln) {
-        case 4: return launch_generic_ln<BITS, T, 4, MT>(pl, p, st);
-        case 8: return launch_generic_ln<BITS, T, 8, MT>(pl, p, st);
-        case 16: return launch_generic_ln<BITS, T, 16, MT>(pl, p, st);
-        case 64: return launch_generic_ln<BITS, T, 64, MT>(pl, p, st);
-        default: return hipErrorInvalidValue;
-    }
-}
-
-template <int BITS, typename T>
-static hipError_t launch_generic_bits(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
-    switch (pl.mt) {
-        case 1: return launch_generic_mt<BITS, T, 1>(pl, p, st);
-        case 2: return launch_generic_mt<BITS, T, 2>(pl, p, st);
-        case 4: return launch_generic_mt<BITS, T, 4>(pl, p, st);
-        default: return hipErrorInvalidValue;
-    }
-}
-
-template <typename T>
-static hipError_t launch_generic(const gptq_layer_t& L, const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
-    switch (L.bits) {
-        case 2: return launch_generic_bits<2, T>(pl, p, st);
-        case 3: return launch_generic_bits<3, T>(pl, p, st);
-        case 4: return launch_generic_bits<4, T>(pl, p, st);
-        case 8: return launch_generic_bits<8, T>(pl, p, st);
-        default: return hipErrorInvalidValue;
-    }
-}
-
-template <int LN, int MT>
-static hipError_t launch_fast_u(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
-    dim3 grid(pl.strips, pl.ksplit, pl.mtiles), block(pl.waves * 64);
-    const int per_lane = (pl.chunk_units + (64 / LN) * pl.waves - 1) / ((64 / LN) * pl.waves);
-    if (per_lane <= 1)
-        hipLaunchKernelGGL((gemv_q4_f16_kernel<LN, MT, 1>), grid, block, pl.lds_bytes, st, p);
-    else if (per_lane <= 2)
-        hipLaunchKernelGGL((gemv_q4_f16_kernel<LN, MT, 2>), grid, block, pl.lds_bytes, st, p);
-    else if (per_lane <= 4)
-        hipLaunchKernelGGL((gemv_q4_f16_kernel<LN, MT, 4>), grid, block, pl.lds_bytes, st, p);
-    else
-        hipLaunchKernelGGL((gemv_q4_f16_kernel<LN, MT, 8>), grid, block, pl.lds_bytes, st, p);
-    return hipGetLastError();
-}
-
-template <int LN, int MT>
-static hipError_t launch_direct_u(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
-    dim3 grid(pl.strips, pl.ksplit, pl.mtiles), block(pl.waves * 64);
-    switch (pl.u) {
-        case 1: hipLaunchKernelGGL((gemv_q4_f16_direct_kernel<LN, MT, 1>), grid, block, pl.lds_bytes, st, p); break;
-        case 2: if constexpr (MT <= 4) { hipLaunchKernelGGL((gemv_q4_f16_direct_kernel<LN, MT, 2>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
-        case 4: if constexpr (MT <= 2) { hipLaunchKernelGGL((gemv_q4_f16_direct_kernel<LN, MT, 4>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
-        case 8: if constexpr (MT <= 1) { hipLaunchKernelGGL((gemv_q4_f16_direct_kernel<LN, MT, 8>), grid, block, pl.lds_bytes, st, p); break; } return hipErrorInvalidValue;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
 }
 
 template <int LN, int MT, typename T>
@@ -1681,8 +1176,12 @@ static hipError_t launch_mfma_u(const GemvPlan& pl, const GemvParams& p, hipStre
     if (pl.use_seq) {
         if constexpr (LN == 4) {
             if (pl.pair) {
-                if (pl.u == 1) hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, true, true, T>), grid, block, pl.lds_bytes, st, p);
-                else hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, true, true, T>), grid, block, pl.lds_bytes, st, p);
+                if constexpr (MT <= 4) {
+                    if (pl.u == 1) hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, true, true, T>), grid, block, pl.lds_bytes, st, p);
+                    else hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, true, true, T>), grid, block, pl.lds_bytes, st, p);
+                } else {
+                    return hipErrorInvalidValue;
+                }
             } else if (pl.u == 1) {
                 hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, false, true, T>), grid, block, pl.lds_bytes, st, p);
             } else if (pl.u == 2) {
@@ -1690,7 +1189,7 @@ static hipError_t launch_mfma_u(const GemvPlan& pl, const GemvParams& p, hipStre
             } else if (pl.u == 4) {
                 hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 4, false, true, T>), grid, block, pl.lds_bytes, st, p);
             } else {
-                hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 8, false, true, T>), grid, block, pl.lds_bytes, st, p);
+                return hipErrorInvalidValue;
             }
             return hipGetLastError();
         } else {
@@ -1698,7 +1197,7 @@ static hipError_t launch_mfma_u(const GemvPlan& pl, const GemvParams& p, hipStre
         }
     }
     if (pl.pair) {
-        if constexpr (LN == 4) {
+        if constexpr (LN == 4 && MT <= 4) {
             if (pl.u == 1) hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, true, false, T>), grid, block, pl.lds_bytes, st, p);
             else hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, true, false, T>), grid, block, pl.lds_bytes, st, p);
             return hipGetLastError();
@@ -1710,30 +1209,21 @@ static hipError_t launch_mfma_u(const GemvPlan& pl, const GemvParams& p, hipStre
         case 1: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 1, false, false, T>), grid, block, pl.lds_bytes, st, p); break;
         case 2: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 2, false, false, T>), grid, block, pl.lds_bytes, st, p); break;
         case 4: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 4, false, false, T>), grid, block, pl.lds_bytes, st, p); break;
-        case 8: hipLaunchKernelGGL((gemv_q4_f16_mfma_kernel<LN, MT, 8, false, false, T>), grid, block, pl.lds_bytes, st, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
+// 16-column strips always; 32- / 64-column strips: fp16 plain layers at up to 4 rows (the planner's choice from 8192 / 12288 columns up)
 template <int MT, typename T>
 static hipError_t launch_mfma_mt(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
-    if constexpr (std::is_same_v<T, bf16>) {
-        switch (pl.ln) {
-            case 4: return launch_mfma_u<4, MT, T>(pl, p, st);
-            case 8: return (pl.use_seq || pl.pair) ? hipErrorInvalidValue : launch_mfma_u<8, MT, T>(pl, p, st);
-            case 16: return (pl.use_seq || pl.pair) ? hipErrorInvalidValue : launch_mfma_u<16, MT, T>(pl, p, st);
-            default: return hipErrorInvalidValue;
-        }
-    } else {
-        switch (pl.ln) {
-            case 4: return launch_mfma_u<4, MT, T>(pl, p, st);
-            case 8: return launch_mfma_u<8, MT, T>(pl, p, st);
-            case 16: return launch_mfma_u<16, MT, T>(pl, p, st);
-            case 64: return launch_mfma_u<64, MT, T>(pl, p, st);
-            default: return hipErrorInvalidValue;
-        }
+    if (pl.ln == 4) return launch_mfma_u<4, MT, T>(pl, p, st);
+    if constexpr (std::is_same_v<T, f16> && MT <= 4) {
+        if (pl.use_seq || pl.pair) return hipErrorInvalidValue;
+        if (pl.ln == 8) return launch_mfma_u<8, MT, T>(pl, p, st);
+        if (pl.ln == 16) return launch_mfma_u<16, MT, T>(pl, p, st);
     }
+    return hipErrorInvalidValue;
 }
 
 template <typename T>
@@ -1797,28 +1287,6 @@ static hipError_t launch_mfmag(const gptq_layer_t& L, const GemvPlan& pl, const 
         case 3: return launch_mfmag_mt<3, T>(pl, p, st);
         case 4: if constexpr (std::is_same_v<T, bf16>) return launch_mfmag_mt<4, T>(pl, p, st); else return hipErrorInvalidValue;
         case 8: return launch_mfmag_mt<8, T>(pl, p, st);
-        default: return hipErrorInvalidValue;
-    }
-}
-
-template <int MT>
-static hipError_t launch_direct_mt(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
-    switch (pl.ln) {
-        case 4: return launch_direct_u<4, MT>(pl, p, st);
-        case 8: return launch_direct_u<8, MT>(pl, p, st);
-        case 16: return launch_direct_u<16, MT>(pl, p, st);
-        case 64: return launch_direct_u<64, MT>(pl, p, st);
-        default: return hipErrorInvalidValue;
-    }
-}
-
-template <int MT>
-static hipError_t launch_fast_mt(const GemvPlan& pl, const GemvParams& p, hipStream_t st) {
-    switch (pl.ln) {
-        case 4: return launch_fast_u<4, MT>(pl, p, st);
-        case 8: return launch_fast_u<8, MT>(pl, p, st);
-        case 16: return launch_fast_u<16, MT>(pl, p, st);
-        case 64: return launch_fast_u<64, MT>(pl, p, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -1979,7 +1447,7 @@ StreamPlan plan_stream(const gptq_layer_t* const* Ls, int n, int M, const gptq_t
             while (waves > 1 && (waves / 2) * wr * u >= ups) waves /= 2;
         }
     }
-    if (q4 ? (u != 2 && u != 4 && u != 8) : (A.bits != 3 ? (u != 2 && u != 4 && u != 8) : (u != 1 && u != 2))) return pl;
+    if (q4 ? (u != 2 && u != 4 && u != 8) : (A.bits != 3 ? (u != 2 && u != 4) : (u != 1 && u != 2))) return pl;      // (2- / 8-bit: the 8-unit forms were lab-only and spilled)
     if (waves < 1 || waves > 16 || u > ucap || pl.units_total % u) return pl;
     ups = (ups + u - 1) / u * u;                        // a lane's U rows start on a multiple of U: slices do too
     pl.units_per_split = ups;
@@ -2044,7 +1512,6 @@ static hipError_t launch_qx_u(const StreamPlan& pl, const GemvStreamParams& p, h
         switch (pl.u) {
             case 2: return launch_qx_one<BITS, LN, MT, 2>(pl, p, st);
             case 4: return launch_qx_one<BITS, LN, MT, 4>(pl, p, st);
-            case 8: return launch_qx_one<BITS, LN, MT, 8>(pl, p, st);
             default: return hipErrorInvalidValue;
         }
     } else {
@@ -2117,10 +1584,10 @@ hipError_t init_gemv_device() {
     acc(grant_stream<4, 1, bf16>()); acc(grant_stream<4, 2, bf16>()); acc(grant_stream<4, 4, bf16>());
     acc(grant_stream<16, 1, bf16>()); acc(grant_stream<16, 2, bf16>()); acc(grant_stream<16, 4, bf16>());
     auto grant_qx = [&](auto kern) { acc(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); };
-    grant_qx(gemv_qx_stream_kernel<8, 4, 1, 8>); grant_qx(gemv_qx_stream_kernel<8, 4, 2, 8>); grant_qx(gemv_qx_stream_kernel<8, 4, 4, 8>);
-    grant_qx(gemv_qx_stream_kernel<8, 8, 1, 8>); grant_qx(gemv_qx_stream_kernel<8, 8, 2, 8>); grant_qx(gemv_qx_stream_kernel<8, 8, 4, 8>);
-    grant_qx(gemv_qx_stream_kernel<2, 4, 1, 8>); grant_qx(gemv_qx_stream_kernel<2, 4, 2, 8>); grant_qx(gemv_qx_stream_kernel<2, 4, 4, 8>);
-    grant_qx(gemv_qx_stream_kernel<2, 8, 1, 8>); grant_qx(gemv_qx_stream_kernel<2, 8, 2, 8>); grant_qx(gemv_qx_stream_kernel<2, 8, 4, 8>);
+    grant_qx(gemv_qx_stream_kernel<8, 4, 1, 4>); grant_qx(gemv_qx_stream_kernel<8, 4, 2, 4>); grant_qx(gemv_qx_stream_kernel<8, 4, 4, 4>);
+    grant_qx(gemv_qx_stream_kernel<8, 8, 1, 4>); grant_qx(gemv_qx_stream_kernel<8, 8, 2, 4>); grant_qx(gemv_qx_stream_kernel<8, 8, 4, 4>);
+    grant_qx(gemv_qx_stream_kernel<2, 4, 1, 4>); grant_qx(gemv_qx_stream_kernel<2, 4, 2, 4>); grant_qx(gemv_qx_stream_kernel<2, 4, 4, 4>);
+    grant_qx(gemv_qx_stream_kernel<2, 8, 1, 4>); grant_qx(gemv_qx_stream_kernel<2, 8, 2, 4>); grant_qx(gemv_qx_stream_kernel<2, 8, 4, 4>);
     grant_qx(gemv_qx_stream_kernel<3, 4, 1, 2>); grant_qx(gemv_qx_stream_kernel<3, 4, 2, 2>); grant_qx(gemv_qx_stream_kernel<3, 4, 4, 2>);
     grant_qx(gemv_qx_stream_kernel<3, 8, 1, 2>); grant_qx(gemv_qx_stream_kernel<3, 8, 2, 2>); grant_qx(gemv_qx_stream_kernel<3, 8, 4, 2>);
     return e;
@@ -2150,7 +1617,7 @@ hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x,
     p.chunk_units = pl.chunk_units; p.ksplit = pl.ksplit;
     {
         const int gu = L.group_size / 8;
-        p.gu_shift = ((pl.fast || pl.mfma) && gu > 0 && (gu & (gu - 1)) == 0) ? __builtin_ctz((unsigned)gu) : -1;
+        p.gu_shift = (pl.mfma && gu > 0 && (gu & (gu - 1)) == 0) ? __builtin_ctz((unsigned)gu) : -1;
     }
 
     hipError_t e;
@@ -2158,29 +1625,8 @@ hipError_t launch_gemv(const gptq_layer_t& L, const GemvPlan& pl, const void* x,
         e = (L.dtype == GPTQ_F16) ? launch_mfmag<f16>(L, pl, p, st) : launch_mfmag<bf16>(L, pl, p, st);
     } else if (pl.mfma) {
         e = (L.dtype == GPTQ_BF16) ? launch_mfma_t<bf16>(pl, p, st) : launch_mfma_t<f16>(pl, p, st);
-    } else if (pl.direct) {
-        switch (pl.mt) {
-            case 1: e = launch_direct_mt<1>(pl, p, st); break;
-            case 2: e = launch_direct_mt<2>(pl, p, st); break;
-            case 4: e = launch_direct_mt<4>(pl, p, st); break;
-            case 8: e = launch_direct_mt<8>(pl, p, st); break;
-            default: e = hipErrorInvalidValue;
-        }
-    } else if (pl.fast) {
-        switch (pl.mt) {
-            case 1: e = launch_fast_mt<1>(pl, p, st); break;
-            case 2: e = launch_fast_mt<2>(pl, p, st); break;
-            case 4: e = launch_fast_mt<4>(pl, p, st); break;
-            case 8: e = launch_fast_mt<8>(pl, p, st); break;
-            default: e = hipErrorInvalidValue;
-        }
     } else {
-        switch (L.dtype) {
-            case GPTQ_F16: e = launch_generic<f16>(L, pl, p, st); break;
-            case GPTQ_BF16: e = launch_generic<bf16>(L, pl, p, st); break;
-            case GPTQ_F32: e = launch_generic<float>(L, pl, p, st); break;
-            default: e = hipErrorInvalidValue;
-        }
+        e = launch_gemv_generic(L, pl, p, st);      // gemv_generic.hip
     }
     if (e != hipSuccess) return e;
     if (pl.ksplit > 1) {

@@ -7,6 +7,25 @@
 
 namespace gptq {
 
+// kernel arguments of the checkpoint-layout GEMVs (gemv.hip, gemv_generic.hip)
+struct GemvParams {
+    const unsigned* qweight;
+    const unsigned* qzeros;
+    const void* scales;
+    const int* g_idx;   // per-k groups (PERK mode) or nullptr
+    const int* perm;    // x gather for re-sequenced act-order layers, or nullptr
+    const void* bias;
+    const void* x;
+    void* out;
+    float* partial;     // [ksplit][M][N] when ksplit > 1
+    int M, K, N, group_size, zero_mode;
+    int units_total, units_per_split, chunk_units, ksplit;
+    int gu_shift;       // log2(group_size / 8) or -1 (matrix-core 4-bit kernel)
+    int pair_off;       // SILU_MUL epilogue: column distance between the gate and the up half (N / 2), else 0
+};
+// gemv_generic.hip: fp32-math GEMV for any bits / dtype / group structure (fp32 layers, raw act-order g_idx, odd group sizes)
+hipError_t launch_gemv_generic(const gptq_layer_t& L, const GemvPlan& pl, const GemvParams& p, hipStream_t st);
+
 // Sum over the 64/LN row slots of a wave (lanes l, l+LN, l+2LN, ...): DPP rotates inside a 16-lane row,
 // ds_bpermute across rows.  Every lane ends up with the total.
 template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
@@ -158,7 +177,7 @@ __device__ __forceinline__ void stream_finish(const PP& p, const SG& sg, int str
 }
 
 template <int LN, int MT, typename T>
-__device__ __forceinline__ void stream_epilogue(float (&acc)[4][MT], const GemvStreamParams& p, const GemvSeg& sg, int strip, int sidx, int ks, int N,
+__device__ __forceinline__ void stream_epilogue(f32x4 (&acc)[MT], const GemvStreamParams& p, const GemvSeg& sg, int strip, int sidx, int ks, int N,
                                                 float* red) {
     constexpr int CT = LN * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, W = blockDim.x >> 6;
@@ -166,14 +185,11 @@ __device__ __forceinline__ void stream_epilogue(float (&acc)[4][MT], const GemvS
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c][m] = row_slot_sum<LN>(acc[c][m]);
+        for (int c = 0; c < 4; ++c) acc[m][c] = row_slot_sum<LN>(acc[m][c]);
     constexpr int E = MT * CT, ES = E + 4;                                    // slab stride padded by 16 B: the W partials of an entry spread over banks
     if (lane < LN) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            f32x4 v = {acc[0][m], acc[1][m], acc[2][m], acc[3][m]};
-            *(f32x4*)(red + wave * ES + m * CT + lane * 4) = v;
-        }
+        for (int m = 0; m < MT; ++m) *(f32x4*)(red + wave * ES + m * CT + lane * 4) = acc[m];
     }
     __syncthreads();
     stream_finish<CT, MT, T>(p, sg, strip, sidx, ks, N, red);

@@ -9,9 +9,8 @@ namespace gptq {
 struct GemvPlan {
     int ln, waves, ksplit, strips, mt, mtiles;
     int units_total, units_per_split, chunk_units;
-    bool fast, perk, use_seq;
-    bool direct;   // fast path without LDS staging (x / scales / zeros straight from L2)
-    bool mfma;     // direct path with the k-reduction on v_mfma_f32_4x4x4_16b_f16
+    bool perk, use_seq;
+    bool mfma;     // 4-bit fp16 / bf16 register kernel with the k-reduction on v_mfma_f32_4x4x4_16b_f16
     bool mfmag;    // matrix-core kernel for the other packings / bf16 (gemv_mfma_generic_kernel)
     bool magic;    // ... with the packed magic-number field decode (3- / 8-bit fp16)
     bool pair;     // mfma path with the fused SILU_MUL epilogue (gate/up halves walked by the same workgroup)

@@ -137,9 +137,9 @@ typedef struct gptq_layer_t {
 typedef enum gptq_path_t {
     GPTQ_PATH_AUTO = 0,           /* the planner's choice */
     GPTQ_PATH_GEMV_GENERIC = 1,   /* fp32-math GEMV: any bits / dtype / raw act-order g_idx */
-    GPTQ_PATH_GEMV_LDS = 2,       /* round-1 LDS-staged 4-bit fp16 GEMV (comparison variant) */
+    GPTQ_PATH_GEMV_LDS = 2,       /* RETIRED in round 6 (round-1 LDS-staged comparison GEMV): GPTQ_ERR_UNSUPPORTED */
     GPTQ_PATH_GEMM = 3,           /* the MFMA GEMMs (tiled, wide, strips, 17..256-row kernel: the planner picks among them) */
-    GPTQ_PATH_GEMV_DIRECT = 4,    /* register GEMV with the v_dot2 reduction (comparison variant) */
+    GPTQ_PATH_GEMV_DIRECT = 4,    /* RETIRED in round 6 (v_dot2 comparison GEMV): GPTQ_ERR_UNSUPPORTED */
     GPTQ_PATH_GEMV_MFMA = 5,      /* matrix-core GEMV on the checkpoint layout (4-bit fp16 / bf16 kernel, or the 2/3/8-bit one) */
     GPTQ_PATH_GEMV_STREAM = 6,    /* streamed (LDS-DMA) GEMV on the checkpoint layout */
     GPTQ_PATH_GEMV_DECODE_COPY = 8 /* decode kernel on the load-time decode copy (qweight_tiled / qconst_tiled): M <= 8; the planner's own choice up to 4 rows, and at

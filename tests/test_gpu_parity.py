@@ -227,21 +227,30 @@ def test_magic_number_decode_3_and_8_bit(bits, gs, K, N, M):
 
 
 @pytest.mark.parametrize("ln,waves,ksplit", [(4, 16, 1), (4, 4, 1), (8, 8, 2), (16, 16, 4), (64, 4, 8), (64, 1, 1), (4, 2, 3)])
-@pytest.mark.parametrize("path", [1, 2, 4, 5])
+@pytest.mark.parametrize("path", [1, 5])
 def test_forward_launch_shapes_agree(ln, waves, ksplit, path):
-    """Every launch shape (strip width, waves, K split) of both GEMV kernels gives the same answer
-    (up to fp32 summation order) and is run-to-run bit-reproducible."""
+    """Every launch shape (strip width, waves, K split) of both checkpoint-layout GEMV kernels (1: fp32 math, 5: matrix core) gives the same answer
+    (up to fp32 summation order) and is run-to-run bit-reproducible.  Round 6 cut the instantiations to what a plan can ask for: the fp32-math kernel has
+    strips of 16 or 64 columns (lanes_n = 4 / 16), the matrix-core kernel up to 64 (lanes_n = 4 / 8 / 16); everything else -- and round 1's comparison
+    kernels, tuning.path = 2 / 4 -- is refused with GPTQ_ERR_UNSUPPORTED, never silently replaced."""
     K, N, M = 2048, 1024, 2
     L = O.random_quant_layer(K, N, 4, 128, seed=5, bias=True)
     x = (torch.rand(M, K, generator=torch.Generator().manual_seed(1)) - 0.5).half()
     q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, 128)
     y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], L["bias"], 4, O.ZERO_WRAP)
     t = _tuning(lanes_n=ln, waves=waves, ksplit=ksplit, path=path)
+    if ln not in ((4, 16) if path == 1 else (4, 8, 16)):
+        with pytest.raises(_lib.GptqError, match="lanes_n"):
+            q(x.to(DEV), tuning=t)
+        return
     with torch.no_grad():
         y1 = q(x.to(DEV), tuning=t)
         y2 = q(x.to(DEV), tuning=t)
     assert torch.equal(y1, y2)
     _assert_close(y1, y64, y64, torch.float16, K, f"ln={ln} waves={waves} ksplit={ksplit}")
+    for retired in (2, 4):
+        with pytest.raises(_lib.GptqError, match="retired"):
+            q(x.to(DEV), tuning=_tuning(path=retired))
 
 
 def test_act_order_resequencing_is_bit_exact():
@@ -842,7 +851,7 @@ def test_strip16_batched_decode_kernel(M, K, N, gs, act, dtype):
 
 
 def test_gemm_matches_gemv_paths():
-    """The three kernels (generic GEMV, fast GEMV, MFMA GEMM) are three summation orders of the same
+    """The three kernel families (fp32-math GEMV, matrix-core GEMV, MFMA GEMM) are three summation orders of the same
     exactly-dequantised products."""
     K, N, M = 1024, 512, 8
     L = O.random_quant_layer(K, N, 4, 128, seed=21)
@@ -850,7 +859,7 @@ def test_gemm_matches_gemv_paths():
     q = _module_from(L["qweight"], L["qzeros"], L["scales"], L["g_idx"], None, 4, 128)
     y64 = O.forward_f64(x, L["qweight"], L["qzeros"], L["scales"], L["g_idx"], None, 4, O.ZERO_WRAP)
     with torch.no_grad():
-        ys = [q(x.to(DEV), tuning=_tuning(path=p)) for p in (1, 2, 3, 4, 5)]
+        ys = [q(x.to(DEV), tuning=_tuning(path=p)) for p in (1, 3, 5)]
     for y in ys:
         _assert_close(y, y64, y64, torch.float16, K, "path agreement")
 
@@ -916,9 +925,9 @@ def test_matrix_core_gemv_bf16(gs, K, N, M, act):
 
 @pytest.mark.parametrize("gs,K,N,M", [(128, 1024, 1024, 1), (128, 2048, 512, 3), (32, 512, 768, 2), (64, 1024, 96, 5),
                                      (128, 4096, 256, 8), (1024, 1024, 256, 4), (128, 11008, 64, 1)])
-@pytest.mark.parametrize("path", [4, 5])
+@pytest.mark.parametrize("path", [5])
 def test_direct_gemv_vs_oracle(gs, K, N, M, path):
-    """The no-LDS-staging q4/fp16 GEMVs (tuning.path = 4: VALU dot products, 5: matrix core): x / scales /
+    """The no-LDS-staging q4/fp16 GEMV (tuning.path = 5: matrix core; the v_dot2 variant, path = 4, was retired in round 6): x / scales /
     zeros read straight from L2."""
     L = O.random_quant_layer(K, N, 4, gs, seed=K + N + M, bias=True)
     x = (torch.rand(M, K, generator=torch.Generator().manual_seed(9)) - 0.5).half()
@@ -1417,7 +1426,14 @@ def test_wide_layers_take_wide_strips(K, N, M, dtype):
     with torch.no_grad():
         y, yb = q(x.to(DEV)), q(x.to(DEV))
         y4 = q(x.to(DEV), tuning=_tuning(path=5, lanes_n=4))
-        y16 = q(x.to(DEV), tuning=_tuning(path=5, lanes_n=16))
+        # 64-column strips exist where the planner itself can choose them: fp16, up to 4 rows (round 6); bf16 / 5+ rows are refused, not replaced
+        if dtype == torch.float16 and M <= 4:
+            y16 = q(x.to(DEV), tuning=_tuning(path=5, lanes_n=16))
+        else:
+            y16 = y4
+            if dtype == torch.float16:
+                with pytest.raises(_lib.GptqError, match="lanes_n"):
+                    q(x.to(DEV), tuning=_tuning(path=5, lanes_n=16))
     assert torch.equal(y, yb)
     for t, what in ((y, "auto"), (y4, "16-column strips"), (y16, "64-column strips")):
         _assert_close(t, y64, y64, dtype, K, what)
@@ -1567,9 +1583,9 @@ def test_streamed_gemv_vs_oracle(K, N, gs, M, ln, waves, u, ksplit, dtype):
         _assert_close(y1, ref, ref, dtype, K, f"streamed gemv ln={ln} waves={waves} u={u} ksplit={ksplit}")
 
 
-@pytest.mark.parametrize("bits,ln,waves,u,ksplit", [(8, 4, 16, 4, 1), (8, 4, 4, 2, 1), (8, 8, 8, 8, 2), (8, 4, 8, 8, 3), (8, 8, 2, 4, 1),
+@pytest.mark.parametrize("bits,ln,waves,u,ksplit", [(8, 4, 16, 4, 1), (8, 4, 4, 2, 1), (8, 8, 8, 4, 2), (8, 4, 8, 4, 3), (8, 8, 2, 4, 1),
                                                     (3, 4, 16, 1, 1), (3, 4, 4, 1, 2), (3, 8, 8, 1, 1), (3, 4, 8, 2, 1), (3, 8, 4, 2, 4),
-                                                    (2, 4, 16, 2, 1), (2, 8, 4, 4, 2), (2, 4, 8, 8, 1), (2, 8, 8, 2, 3)])
+                                                    (2, 4, 16, 2, 1), (2, 8, 4, 4, 2), (2, 4, 8, 4, 1), (2, 8, 8, 2, 3)])      # (8 units per lane: lab-only forms, retired in round 6)
 @pytest.mark.parametrize("K,N,gs,M", [(1024, 512, 32, 1), (2048, 96, 64, 3), (4096, 1056, 128, 4), (512, 2048, 32, 2), (11008, 256, 32, 1)])
 def test_streamed_gemv_3_and_8_bit(K, N, gs, M, bits, ln, waves, u, ksplit):
     """gemv_qx_stream_kernel (tuning.path = 6 on 3- / 8-bit fp16 layers): the packing units (one word of 4 values / three words of 32) by LDS DMA,

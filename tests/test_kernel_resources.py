@@ -71,9 +71,25 @@ def test_hot_kernels_stay_inside_their_register_budget():
     # s_waitcnt -- a spilled one would be stored before it has landed.  Every form the planner (or the lab knob) can launch is spill-free; the one geometry
     # that is not (8 bits, one row block, four strips) is refused by plan_rows.
     rows = {n: v for n, v in ks.items() if "gemm_rows_kernel" in n or "gemm_rows64_kernel" in n}
-    assert len(rows) >= 2 * 3 * (9 + 8 + 8) + 24, len(rows)
+    assert len(rows) >= 144 + 24, len(rows)
     spilled = {n for n, v in rows.items() if (v["spill"] or 0) or (v["scratch"] or 0)}
-    assert all("gemm_rows_kernel" in n and "Li8ELi1ELi4E" in n for n in spilled), sorted(spilled)[:4]      # <T, 8, 1, 4, GM> only
+    assert not spilled, sorted(spilled)[:4]      # (the one geometry that spilled -- <T, 8, 1, 4, GM> -- is no longer instantiated: round 6)
+
+
+def test_no_kernel_of_the_library_touches_scratch():
+    """Round 6 (review item: 175 spilling instantiations among 1,714, among them the defaults for fp32 layers, 2-bit and layers without a decode copy): the
+    checkpoint-layout families were cut to what a plan can ask for, the per-k (raw act-order) form of gemv_generic_kernel walks a unit's values in a rolled loop
+    instead of parking 32 dependent load chains in scratch, the streamed GEMVs keep their accumulators as one vector per row of x, and the spilling geometries of
+    the skinny / stream64 / rows / matrix-core GEMV families are gone.  So the rule is no longer per family: NO kernel in the library spills or has a private
+    segment -- whatever plan (default or forced) selects it -- except the 128 x 512 whole-round prefill kernel, which lives in all 512 registers of a lane by
+    design and may spill a handful (<= 4 registers, <= 32 bytes).  Also guards the instantiation count and the library size against growing back."""
+    ks = _kernels()
+    bad = {n: (v["spill"], v["scratch"]) for n, v in ks.items() if ((v["spill"] or 0) or (v["scratch"] or 0)) and "gemm_wide_kernel" not in n}
+    assert not bad, list(bad.items())[:6]
+    assert len(ks) <= 1400, len(ks)                                  # 1,714 at the end of round 5
+    assert os.path.getsize(SO) <= 17 * 2 ** 20, os.path.getsize(SO)  # 19.9 MB at the end of round 5
+    for fam in ("gemv_q4_f16_kernel", "gemv_q4_f16_direct_kernel"):      # round 1's comparison GEMVs (tuning.path = 2 / 4): retired
+        assert not any(fam + "I" in n for n in ks), fam
 
 
 def test_panel_kernels_hold_their_in_flight_loads_in_registers():
