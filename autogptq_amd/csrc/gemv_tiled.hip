@@ -155,8 +155,7 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
     }
     if (pair && (waves & 1)) return pl;
     if (nstr > 1 && waves % nstr != 0) return pl;
-    if (waves < 1 || waves > 16 || (u != 1 && u != 2 && u != 4 && u != 8)) return pl;
-    if ((A.bits != 4 || A.g_idx || pl.mt > 4 || pair || nstr > 1) && u != 2 && u != 4) return pl;     // the 3- / 8-bit, the act-order and the 5..8-row forms are compiled for 2 and 4 chunks in flight
+    if (waves < 1 || waves > 16 || (u != 2 && u != 4)) return pl;                // 2 or 4 chunks per wave in flight (the 1- / 8-chunk forms were lab-only: retired in round 6)
     pl.waves = waves;
     pl.u = u;
     pl.xstride = cps * cke * 2 + 16;

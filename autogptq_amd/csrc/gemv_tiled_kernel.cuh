@@ -201,12 +201,27 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
     // Same-session A/B against the round-4 forms (tools/lab/tiled_noxs.sh, profiles/r05_bf16_vs_f16.log; bf16 behind fp16): 1 row 6 - 13 % -> 2 - 7 %, 2 rows
     // 11 - 27 % -> 6 - 17 %; at 3 - 4 rows the per-workgroup pass over x costs more than converting the weight pairs does (13 - 48 % -> 19 - 75 %): those keep
     // the bf16 matrix core with converted weights.
+    // Round 6, 4-bit bf16 layers at 3 - 4 rows (ZM): the zero-point goes to the matrix core too.  The B operand is the raw biased pair (bias + w_k, bias + w_k+1)
+    // -- bias = 128 as bf16, 1024 as fp16: (q >> 4 i) & 0x000f000f | pattern, 7 VALU per packed word -- and a SECOND accumulator chain multiplies the same x
+    // by the constant pair -(bias + z): sum x (bias + w) + sum x (-(bias + z)) = sum x (w - z).  No pass over x per workgroup (XS's run sums), no block-floating
+    // rewrite (XC), no conversion of decoded pairs (the 3..4-row bf16 form: 25 VALU per word).  A one-hot row returns (bias + w) - (bias + z) = w - z exactly; a
+    // layer whose fields equal their zero-points gives exactly 0 (the two chains are the same instruction sequence on negated operands: their sums are exact
+    // negatives); everywhere else the cancellation costs log2(bias / 8) bits of the fp32 run sums (4 for bf16, 7 for fp16: 2^-17 relative, below either type's ulp).
+    // Same-session A/B (tools/session_r06_zm.sh, profiles/r06_zm_ab.log; us, bf16 product -> this form | fp16): 4 rows 4096^2 5.96 -> 5.24 | 5.2, 4096 -> 11008
+    // 10.1 -> 8.4 | 8.4, 11008 -> 4096 11.1 -> 9.0 | 8.7, q|k|v 10.3 -> 8.8 | 8.7, gate|up 16.1 -> 14.2 | 12.6: bf16 19 - 30 % -> 0 - 3 % (gate|up 13 %) behind fp16.
+    // NOT at 1 - 2 rows (twice the matrix-core instructions: even on single layers, 14 - 17 % slower than the run-sum form on the 1376-strip gate|up launch) and
+    // NOT for fp16 (its 13-VALU exact form is faster: 4096 -> 11008 7.2 -> 7.7, gate|up 12.3 -> 14.3).
+#if defined(GPTQ_TILED_ZM)                                                          // lab: 1 = bf16 layers at 1..4 rows, 2 = fp16 layers too (A/B builds: tools/ab_tiled.sh)
+    constexpr bool ZM = BITS == 4 && MT <= 4 && (GPTQ_TILED_ZM == 2 || (GPTQ_TILED_ZM == 1 && BF));
+#else
+    constexpr bool ZM = BITS == 4 && MT == 4 && BF;
+#endif
 #ifdef GPTQ_TILED_NO_XS                                                            // lab: the round-4 bf16 forms (A/B build: tools/lab/tiled_noxs.sh)
     constexpr bool XS = false;
 #else
-    constexpr bool XS = BF && BITS == 4 && MT <= 2;
+    constexpr bool XS = BF && BITS == 4 && MT <= 2 && !ZM;
 #endif
-    constexpr bool XC = BF && MT <= 2 && !XS;
+    constexpr bool XC = BF && MT <= 2 && !XS && !ZM;
     using MM = std::conditional_t<XC, f16, T>;                                    // the matrix core's operand type
     constexpr int ES = MT * 16 + 4;
     float* const xe = red + W * ES;                                               // [runs of the slice][4 rows] inverse factors (bf16 layers only; planned for)
@@ -319,7 +334,21 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
                 accg = Mma4<MM>::run(u32x2{xa[pc][hf * 2], xa[pc][hf * 2 + 1]}, u32x2{b0, b1}, accg);
                 if constexpr (MT > 4) accg2 = Mma4<MM>::run(u32x2{xb[pc][hf * 2], xb[pc][hf * 2 + 1]}, u32x2{b0, b1}, accg2);
             };
-            if constexpr (BITS == 4 && XS) {
+            if constexpr (BITS == 4 && ZM) {
+                unsigned mgz;
+                asm("v_mov_b32 %0, %1" : "=v"(mgz) : "n"(BF ? 0x43004300 : 0x64006400));     // bias twice: bf16 128 / fp16 1024 (ulp 1 in either)
+                const unsigned nz = z * 0x00010001u + (BF ? 0xC300C300u : 0xE400E400u);     // -(bias + z) twice (z <= 16: exact)
+                f32x4 accz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const unsigned qw = qv[w];
+                    mm(w, 0, (qw & m_lo) | mgz, ((qw >> 4) & m_lo) | mgz);                  // (k0, k1) (k2, k3): stored nibbles 0 | 4, 1 | 5
+                    mm(w, 1, ((qw >> 8) & m_lo) | mgz, ((qw >> 12) & m_lo) | mgz);          // (k4, k5) (k6, k7)
+                    accz = Mma4<MM>::run(u32x2{xa[w][0], xa[w][1]}, u32x2{nz, nz}, accz);
+                    accz = Mma4<MM>::run(u32x2{xa[w][2], xa[w][3]}, u32x2{nz, nz}, accz);
+                }
+                accg += accz;
+            } else if constexpr (BITS == 4 && XS) {
                 unsigned magicb;
                 asm("v_mov_b32 %0, 0x43004300" : "=v"(magicb));                   // bf16 128.0 twice: its 7 mantissa bits take a 4-bit field with an ulp of 1
 #pragma unroll
@@ -459,10 +488,8 @@ static hipError_t launch_tiled_one(const TiledPlan& pl, const TiledParams& p, hi
 template <int BITS, int MT, typename T, int XM>
 static hipError_t launch_tiled_u(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
     switch (pl.u) {
-        case 1: if constexpr (BITS == 4 && XM == 0 && MT <= 4) return launch_tiled_one<BITS, MT, 1, T, XM>(pl, p, st); else return hipErrorInvalidValue;
         case 2: return launch_tiled_one<BITS, MT, 2, T, XM>(pl, p, st);
         case 4: return launch_tiled_one<BITS, MT, 4, T, XM>(pl, p, st);
-        case 8: if constexpr (BITS == 4 && XM == 0 && MT <= 4) return launch_tiled_one<BITS, MT, 8, T, XM>(pl, p, st); else return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }
@@ -501,9 +528,7 @@ static hipError_t grant_tiled_lds() {
             grant(gemv_tiled_kernel<B, MT, U, f16, 16, XM>); grant(gemv_tiled_kernel<B, MT, U, f16, 8, XM>);
             grant(gemv_tiled_kernel<B, MT, U, bf16, 16, XM>); grant(gemv_tiled_kernel<B, MT, U, bf16, 8, XM>);
         };
-        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-        using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
-        if constexpr (XM == 0 && MT <= 4) { grant_u(I4{}, I1{}); grant_u(I4{}, I8{}); }          // 1 and 8 chunks in flight: sweep geometries of the plain 4-bit form only
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
         grant_u(I4{}, I2{}); grant_u(I4{}, I4{});
         grant_u(I8{}, I2{}); grant_u(I8{}, I4{}); grant_u(I3{}, I2{}); grant_u(I3{}, I4{});
     };
