@@ -822,7 +822,7 @@ static int decode_copy_source(const gptq_layer_t* L, gptq_layer_t* S) {
     // a plain [gate | up] layer with the fused epilogue gets a copy too (round 5: its decode kernel pairs strip s of the two halves); act-order ones do not
     if (L->epilogue != GPTQ_EPI_NONE && (L->g_idx != nullptr || L->N % (2 * GPTQ_STRIP_COLS) != 0)) S->epilogue = -1;
     if (S->epilogue == -1 || !tiled_layer_ok(*S))
-        return fail(GPTQ_ERR_UNSUPPORTED, "the decode copy needs a 3-, 4- or 8-bit fp16/bf16 layer, group_size a power-of-two multiple of 32 (16 at 8 bits) or >= K, "
+        return fail(GPTQ_ERR_UNSUPPORTED, "the decode copy needs a 2-, 3-, 4- or 8-bit fp16/bf16 layer (2 bits: no fused epilogue), group_size a power-of-two multiple of 32 (16 at 8 bits) or >= K, "
                                           "and for act-order layers qweight_seq + perm (bits=%d dtype=%d group_size=%d)", L->bits, L->dtype, L->group_size);
     return GPTQ_OK;
 }
@@ -851,7 +851,7 @@ int gptq_prepack_decode(const gptq_layer_t* L, uint32_t* tiled_out, void* const_
 
 int gptq_unprepack_decode(const uint32_t* qweight_tiled, int K, int N, int bits, uint32_t* qweight_out, void* stream) {
     if (!qweight_tiled || !qweight_out) return fail(GPTQ_ERR_NULL, "qweight_tiled/qweight_out must be non-NULL");
-    if (bits != 3 && bits != 4 && bits != 8) return fail(GPTQ_ERR_UNSUPPORTED, "the decode copy exists for 3-, 4- and 8-bit layers (got %d)", bits);
+    if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return fail(GPTQ_ERR_UNSUPPORTED, "the decode copy exists for 2-, 3-, 4- and 8-bit layers (got %d)", bits);
     if (K <= 0 || N <= 0 || K % 32 || N % GPTQ_STRIP_COLS) return fail(GPTQ_ERR_SHAPE, "K (%d) must be a positive multiple of 32 and N (%d) of %d", K, N, GPTQ_STRIP_COLS);
     if ((const void*)qweight_tiled == (const void*)qweight_out) return fail(GPTQ_ERR_UNSUPPORTED, "gptq_unprepack_decode does not work in place");
     hipError_t e = launch_unprepack_decode(qweight_tiled, K, N, bits, qweight_out, (hipStream_t)stream);

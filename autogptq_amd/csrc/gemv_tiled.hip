@@ -43,7 +43,7 @@ hipError_t init_gemv_tiled_multi_device();
 
 // ---- plan + launch ---------------------------------------------------------------------------------------------------------------------
 static int tiled_kpl(int bits) { return bits == 8 ? 16 : 32; }          // k per lane and chunk
-static int tiled_chunk_bytes(int bits) { return bits == 3 ? 768 : 1024; }
+static int tiled_chunk_bytes(int bits) { return bits == 3 ? 768 : (bits == 2 ? 512 : 1024); }
 static int tiled_rec_bytes(int bits) { return bits == 8 ? 64 : 48; }
 
 // A [gate | up] layer with the SILU_MUL epilogue: a plain (no act-order) layer whose halves are whole strips
@@ -51,7 +51,8 @@ static bool tiled_pair_layer(const gptq_layer_t& L) { return L.epilogue == GPTQ_
 
 bool tiled_layer_ok(const gptq_layer_t& L) {
     if (!L.qweight_tiled || !L.qconst_tiled || L.tiled_cols != GPTQ_STRIP_COLS || (L.epilogue != GPTQ_EPI_NONE && !tiled_pair_layer(L))) return false;
-    if (L.bits != 4 && L.bits != 8 && L.bits != 3) return false;
+    if (L.bits != 4 && L.bits != 8 && L.bits != 3 && L.bits != 2) return false;
+    if (L.bits == 2 && L.epilogue != GPTQ_EPI_NONE) return false;                 // 2 bits (round 6): the plain and the act-order decode forms, up to 4 rows
     if (L.g_idx != nullptr && !(L.perm && L.qweight_seq)) return false;           // act-order: only with the re-sequenced rows (the copy is made of them) and perm
     if (L.dtype != GPTQ_F16 && L.dtype != GPTQ_BF16) return false;
     if (L.K % 32 || L.N % GPTQ_STRIP_COLS) return false;
@@ -72,6 +73,7 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
     TiledPlan pl{};
     if (n < 1 || n > 4 || M < 1 || M > 8) return pl;
     const gptq_layer_t& A = *Ls[0];
+    if (A.bits == 2 && M > 4) return pl;                                          // 2 bits: no 5..8-row form
     int strips = 0, nsum = 0;
     const bool pair = A.epilogue == GPTQ_EPI_SILU_MUL;                             // one [gate | up] layer: a workgroup per PAIR of strips, M <= 4, no K slices
     if (pair && (n != 1 || M > 4)) return pl;
@@ -87,7 +89,7 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
     // Strips per workgroup (gemv_tiled_multi.hip): 3..8 rows of plain layers whose widths are whole groups of strips and that need no K slices -- every strip
     // staging its own rows of x is what those forms lose on layers of many strips.  tuning.reserved[GPTQ_LAB_OPT] = 1 / 2 / 4 (with path = 8) forces the count.
     int nstr = 1;
-    if (!pair && M >= 3 && !A.g_idx) {
+    if (!pair && M >= 3 && !A.g_idx && A.bits != 2) {
         // measured (tools/multi_strip_ab.py, profiles/r05_multi_strip_ab.log, us, 1 / 2 / 4 strips per workgroup): gate|up M = 4 13.2 / 12.6 / 16.5, M = 8 21.2 / 16.5 / 21.4
         // (the batched-decode kernel on the checkpoint rows: 17.3); q|k|v M = 8 12.8 / 11.2 / 11.3 (10.8); 4096x11008 M = 8 12.2 / 11.0 / 11.0 (10.5); 3..4 rows
         // on launches below ~1000 strips lose 0.7 - 1 us -- two strips per workgroup from 1024 strips up, else one
@@ -210,7 +212,7 @@ hipError_t launch_tiled(const gptq_layer_t* const* Ls, const TiledPlan& pl, cons
     p.waves = pl.waves;
     p.xraw_off = pl.xraw_off;
     if (pg) {                                                                     // plain layers, 2 or 4 chunks per wave in flight (the compiled forms)
-        if (A.g_idx || (pl.u != 2 && pl.u != 4)) return hipErrorInvalidValue;
+        if (A.g_idx || A.bits == 2 || (pl.u != 2 && pl.u != 4)) return hipErrorInvalidValue;
         return launch_tiled_peer(pl, p, A.dtype, st);                             // gemv_tiled_peer.hip
     }
     if (pl.pair) return (pl.u == 2 || pl.u == 4) ? launch_tiled_pair(pl, p, A.dtype, st) : hipErrorInvalidValue;   // gemv_tiled_pair.hip

@@ -51,6 +51,7 @@ template <int BITS> struct TiledFmt;
 template <> struct TiledFmt<4> { static constexpr int WPL = 4, KPL = 32, REC = 48, ZB = 1; };
 template <> struct TiledFmt<8> { static constexpr int WPL = 4, KPL = 16, REC = 64, ZB = 2; };
 template <> struct TiledFmt<3> { static constexpr int WPL = 3, KPL = 32, REC = 48, ZB = 1; };
+template <> struct TiledFmt<2> { static constexpr int WPL = 2, KPL = 32, REC = 48, ZB = 1; };      // (round 6) 2 words = 32 k; word w: pair p = (k 16w + 2p, k 16w + 2p + 1) at bit 2p of its halves
 
 template <int N_> struct WordsOf { typedef unsigned type __attribute__((ext_vector_type(N_))); };
 
@@ -80,6 +81,12 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
     asm("s_mov_b32 %0, 0x00f000f0" : "=s"(m_hi));
     asm("s_mov_b32 %0, 0x00ff00ff" : "=s"(m_b));
     asm("v_mov_b32 %0, 0x64006400" : "=v"(magic));
+    unsigned m2a, m2b, m2c, m2d, m2e;
+    asm("s_mov_b32 %0, 0x00030003" : "=s"(m2a));
+    asm("s_mov_b32 %0, 0x000c000c" : "=s"(m2b));
+    asm("s_mov_b32 %0, 0x00300030" : "=s"(m2c));
+    asm("s_mov_b32 %0, 0x00c000c0" : "=s"(m2d));
+    asm("s_mov_b32 %0, 0x03000300" : "=s"(m2e));
     unsigned m3a, m3b, m3c;
     asm("s_mov_b32 %0, 0x00070007" : "=s"(m3a));
     asm("s_mov_b32 %0, 0x00380038" : "=s"(m3b));
@@ -283,6 +290,7 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
     for (int m = 0; m < MT; ++m) acc[m] = 0.f;
     const f16x2 k960 = {(f16)960.f, (f16)960.f}, k896 = {(f16)896.f, (f16)896.f}, k1008 = {(f16)1008.f, (f16)1008.f};
     const f16x2 r16 = {(f16)0.0625f, (f16)0.0625f}, r8 = {(f16)0.125f, (f16)0.125f}, r64 = {(f16)0.015625f, (f16)0.015625f};
+    const f16x2 k768 = {(f16)768.f, (f16)768.f}, k1020 = {(f16)1020.f, (f16)1020.f}, r4 = {(f16)0.25f, (f16)0.25f}, r256 = {(f16)0.00390625f, (f16)0.00390625f};
     auto bits_of = [&](f16x2 hv) -> unsigned {                                    // the pair as the matrix core takes it: fp16 (also bf16 layers behind x_to_f16), or
         if constexpr (BF && !XC) {                                                // fp16 -> fp32 -> bf16 (exact: small integers)
             const bf16x2 o = {(bf16)(float)hv[0], (bf16)(float)hv[1]};
@@ -368,6 +376,26 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
                     const f16x2 h3 = as_f16x2((q8 & m_hi) | magic) * r16 + c2;    // k6,k7  (3 and 7)
                     mm(w, 0, bits_of(h0), bits_of(h1));
                     mm(w, 1, bits_of(h2), bits_of(h3));
+                }
+            } else if constexpr (BITS == 2) {
+                // 16 fields per word: the fp16 mantissa takes the five pairs at bits 0..9 in place (1024 + 4^p w, times 4^-p, minus (1024 / 4^p + z): exact), the
+                // three at bits 10..15 come down by a shift first -- 17 VALU per 16 k
+                const f16x2 c4 = c1 + k768, c16 = c1 + k960, c64 = c1 + k1008, c256 = c1 + k1020;     // -(256 + z), -(64 + z), -(16 + z), -(4 + z)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const unsigned t = qv[w], t10 = t >> 10;
+                    const unsigned p0 = bits_of(as_f16x2((t & m2a) | magic) + c1);
+                    const unsigned p1 = bits_of(as_f16x2((t & m2b) | magic) * r4 + c4);
+                    const unsigned p2 = bits_of(as_f16x2((t & m2c) | magic) * r16 + c16);
+                    const unsigned p3 = bits_of(as_f16x2((t & m2d) | magic) * r64 + c64);
+                    const unsigned p4 = bits_of(as_f16x2((t & m2e) | magic) * r256 + c256);
+                    const unsigned p5 = bits_of(as_f16x2((t10 & m2a) | magic) + c1);
+                    const unsigned p6 = bits_of(as_f16x2((t10 & m2b) | magic) * r4 + c4);
+                    const unsigned p7 = bits_of(as_f16x2((t10 & m2c) | magic) * r16 + c16);
+                    mm(2 * w, 0, p0, p1);
+                    mm(2 * w, 1, p2, p3);
+                    mm(2 * w + 1, 0, p4, p5);
+                    mm(2 * w + 1, 1, p6, p7);
                 }
             } else if constexpr (BITS == 8) {
 #pragma unroll
@@ -502,7 +530,7 @@ static hipError_t launch_tiled_mt(const TiledPlan& pl, const TiledParams& p, hip
         case 1: if constexpr (XM != 5 && XM != 6) return launch_tiled_u<BITS, 1, T, XM>(pl, p, st); else return hipErrorInvalidValue;
         case 2: if constexpr (XM != 5 && XM != 6) return launch_tiled_u<BITS, 2, T, XM>(pl, p, st); else return hipErrorInvalidValue;
         case 4: return launch_tiled_u<BITS, 4, T, XM>(pl, p, st);
-        case 8: if constexpr (XM != 3 && XM != 4) return launch_tiled_u<BITS, 8, T, XM>(pl, p, st); else return hipErrorInvalidValue;      // 5..8 rows: plain, act-order and multi-strip forms
+        case 8: if constexpr (XM != 3 && XM != 4 && BITS != 2) return launch_tiled_u<BITS, 8, T, XM>(pl, p, st); else return hipErrorInvalidValue;      // 5..8 rows: plain, act-order and multi-strip forms
         default: return hipErrorInvalidValue;
     }
 }
@@ -512,6 +540,9 @@ static hipError_t launch_tiled_bits(const TiledPlan& pl, const TiledParams& p, h
         case 4: return launch_tiled_mt<4, T, XM>(pl, p, st);
         case 8: return launch_tiled_mt<8, T, XM>(pl, p, st);
         case 3: return launch_tiled_mt<3, T, XM>(pl, p, st);
+        case 2:                                                                   // 2 bits (round 6): plain and act-order forms, up to 4 rows
+            if constexpr (XM == 0 || XM == 1) { if (pl.mt <= 4) return launch_tiled_mt<2, T, XM>(pl, p, st); }
+            return hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }
@@ -531,6 +562,7 @@ static hipError_t grant_tiled_lds() {
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
         grant_u(I4{}, I2{}); grant_u(I4{}, I4{});
         grant_u(I8{}, I2{}); grant_u(I8{}, I4{}); grant_u(I3{}, I2{}); grant_u(I3{}, I4{});
+        if constexpr ((XM == 0 || XM == 1) && MT <= 4) { grant_u(I2{}, I2{}); grant_u(I2{}, I4{}); }
     };
     if constexpr (XM != 5 && XM != 6) { grant_mt(std::integral_constant<int, 1>{}); grant_mt(std::integral_constant<int, 2>{}); }
     grant_mt(std::integral_constant<int, 4>{});

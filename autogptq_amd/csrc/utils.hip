@@ -241,16 +241,17 @@ __global__ void __launch_bounds__(256) resequence_kernel(const unsigned* __restr
     }
 }
 
-// ---- the decode copy of a 3/4/8-bit layer (layouts: include/gptq_mi355x.h, gptq_layer_t.qweight_tiled / qconst_tiled; consumer: gemv_tiled.hip) --------
+// ---- the decode copy of a 2/3/4/8-bit layer (layouts: include/gptq_mi355x.h, gptq_layer_t.qweight_tiled / qconst_tiled; consumer: gemv_tiled.hip) --------
 // Load time only.  One workgroup = one chunk (4 k-slots x 16 columns, a lane's WPL words adjacent); one thread = one stored word, built field by field
 // from the checkpoint's bit stream of its column (stream_field: the 3-bit straddlers are resolved HERE, the decode kernel never sees one).
 //   4-bit  stored nibble p of word w = k 8w + {0, 2, 4, 6, 1, 3, 5, 7}[p]: (q & 0x000f000f) then picks (k0, k1), (q & 0x00f000f0) (k2, k3), and the
 //          same on q >> 8 (k4, k5), (k6, k7) -- the order x lies in memory
 //   8-bit  stored byte p of word w = k 4w + {0, 2, 1, 3}[p]: (q & 0x00ff00ff) = (k0, k1), the same on q >> 8 = (k2, k3)
 //   3-bit  word j of the lane's three: pair 5j + i (i = 0..4) = (k 2p, k 2p + 1) at bit 3i of the low / high 16 bits; bit 15 / 31 = bit j of k30 / k31
+//   2-bit  (round 6) a lane holds TWO words = 32 k: word w holds pair p (p = 0..7) = (k 16w + 2p, k 16w + 2p + 1) at bit 2p of its low / high 16 bits
 template <int BITS>
 __global__ void __launch_bounds__(256) prepack_decode_weights_kernel(const unsigned* __restrict__ q, int K, int N, int chunks, unsigned* __restrict__ out) {
-    constexpr int WPL = BITS == 3 ? 3 : 4, KPL = BITS == 8 ? 16 : 32, CKE = 4 * KPL;
+    constexpr int WPL = BITS == 3 ? 3 : (BITS == 2 ? 2 : 4), KPL = BITS == 8 ? 16 : 32, CKE = 4 * KPL;
     const int c = blockIdx.x, s = blockIdx.y, t = threadIdx.x;
     const int col = t & 15, w = (t >> 4) % WPL, kb = (t >> 4) / WPL;              // reads of one k run over 16 adjacent columns
     if (kb >= 4) return;
@@ -269,6 +270,12 @@ __global__ void __launch_bounds__(256) prepack_decode_weights_kernel(const unsig
         constexpr int order[4] = {0, 2, 1, 3};
 #pragma unroll
         for (int p = 0; p < 4; ++p) v |= val(k0 + 4 * w + order[p]) << (8 * p);
+    } else if constexpr (BITS == 2) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            v |= val(k0 + 16 * w + 2 * p) << (2 * p);
+            v |= val(k0 + 16 * w + 2 * p + 1) << (16 + 2 * p);
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
@@ -287,7 +294,7 @@ __global__ void __launch_bounds__(256) prepack_decode_weights_kernel(const unsig
 // (q4_matrix.cu:160, q_matrix.cu:149) keep ONE copy of the weights on the device.
 template <int BITS>
 __global__ void __launch_bounds__(256) unprepack_decode_weights_kernel(const unsigned* __restrict__ t, int K, int N, int chunks, unsigned* __restrict__ out) {
-    constexpr int WPL = BITS == 3 ? 3 : 4, KPL = BITS == 8 ? 16 : 32, CKE = 4 * KPL;
+    constexpr int WPL = BITS == 3 ? 3 : (BITS == 2 ? 2 : 4), KPL = BITS == 8 ? 16 : 32, CKE = 4 * KPL;
     const int n = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;          // output word (row r, column n)
     if (n >= N) return;
     const int s = n >> 4, col = n & 15;
@@ -300,6 +307,9 @@ __global__ void __launch_bounds__(256) unprepack_decode_weights_kernel(const uns
         } else if constexpr (BITS == 8) {
             const int i = j & 3, p = i == 1 ? 2 : (i == 2 ? 1 : i);              // stored byte order k0 k2 k1 k3
             return (lw[j >> 2] >> (8 * p)) & 255u;
+        } else if constexpr (BITS == 2) {
+            const int i = j & 15;                                                // pair i >> 1 at bit 2 (i >> 1) of the low (even k) / high (odd k) half
+            return (lw[j >> 4] >> (2 * (i >> 1) + 16 * (i & 1))) & 3u;
         } else {
             const int pr = j >> 1, hi = (j & 1) * 16;
             if (pr < 15) return (lw[pr / 5] >> (3 * (pr % 5) + hi)) & 7u;
@@ -436,6 +446,7 @@ hipError_t launch_unprepack_decode(const uint32_t* tiled, int K, int N, int bits
         case 4: hipLaunchKernelGGL(unprepack_decode_weights_kernel<4>, grid, dim3(256), 0, st, tiled, K, N, chunks, qweight_out); break;
         case 8: hipLaunchKernelGGL(unprepack_decode_weights_kernel<8>, grid, dim3(256), 0, st, tiled, K, N, chunks, qweight_out); break;
         case 3: hipLaunchKernelGGL(unprepack_decode_weights_kernel<3>, grid, dim3(256), 0, st, tiled, K, N, chunks, qweight_out); break;
+        case 2: hipLaunchKernelGGL(unprepack_decode_weights_kernel<2>, grid, dim3(256), 0, st, tiled, K, N, chunks, qweight_out); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -449,6 +460,7 @@ hipError_t launch_prepack_decode(const uint32_t* qweight, const uint32_t* qzeros
         case 4: hipLaunchKernelGGL(prepack_decode_weights_kernel<4>, grid, dim3(256), 0, st, qweight, K, N, chunks, tiled_out); break;
         case 8: hipLaunchKernelGGL(prepack_decode_weights_kernel<8>, grid, dim3(256), 0, st, qweight, K, N, chunks, tiled_out); break;
         case 3: hipLaunchKernelGGL(prepack_decode_weights_kernel<3>, grid, dim3(192), 0, st, qweight, K, N, chunks, tiled_out); break;
+        case 2: hipLaunchKernelGGL(prepack_decode_weights_kernel<2>, grid, dim3(128), 0, st, qweight, K, N, chunks, tiled_out); break;
         default: return hipErrorInvalidValue;
     }
     hipError_t e = hipGetLastError();

@@ -281,7 +281,7 @@ class QuantLinear(nn.Module):
         qweight_tiled = qconst_tiled = None
         if tiled is None:
             tiled = self.TILED_DECODE
-        if tiled and self.bits in (3, 4, 8):             # act-order layers: a copy of the re-sequenced rows (qweight_seq above); [gate | up] layers with the fused epilogue: the C side decides
+        if tiled:                                        # (every bit width since round 6: the C side decides which layers qualify)  act-order layers: a copy of the re-sequenced rows (qweight_seq above); [gate | up] layers with the fused epilogue: the C side decides
             tb, cb = ctypes.c_size_t(0), ctypes.c_size_t(0)
             if lib.gptq_prepack_decode_bytes(ctypes.byref(L), ctypes.byref(tb), ctypes.byref(cb)) == 0:      # a layer that does not qualify simply has none
                 qweight_tiled = torch.empty(tb.value, dtype=torch.uint8, device=dev)
@@ -333,7 +333,7 @@ class QuantLinear(nn.Module):
         need = self._rows_need.get(M) if tuning is None else None
         if need is None:
             d = _lib.describe_plan(self._layer, M, tuning)
-            need = not (d.get("kernel") in ("strips", "rows", "wide_sk", "wide_copy"))          # the kernels that read the decode copy
+            need = not (d.get("kernel") in ("strips", "rows", "panel", "wide_sk", "wide_copy"))          # the kernels that read the decode copy
             if tuning is None:
                 self._rows_need[M] = need
         if need:

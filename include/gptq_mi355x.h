@@ -113,18 +113,20 @@ typedef struct gptq_layer_t {
     const int32_t  *perm;         /* [K] or NULL */
     int32_t epilogue;             /* gptq_epilogue_t; with SILU_MUL `out` is [M, N/2] */
     int32_t tiled_cols;           /* GPTQ_STRIP_COLS when the two side buffers below are given, else 0 */
-    /* Optional derived (post_init) DECODE COPY of a 3-, 4- or 8-bit layer, built by gptq_prepack_decode (sizes: gptq_prepack_decode_bytes); both NULL =
+    /* Optional derived (post_init) DECODE COPY of a 2-, 3-, 4- or 8-bit layer, built by gptq_prepack_decode (sizes: gptq_prepack_decode_bytes); both NULL =
      * decode streams the checkpoint layout.  With w[k][n] the layer's unpacked integers (rows taken from qweight_seq when the layer has one, else qweight;
-     * k past K read as 0), KPL = 32 (16 at 8 bits) and WPL = 4 (3 at 3 bits):
+     * k past K read as 0), KPL = 32 (16 at 8 bits) and WPL = 4 (3 at 3 bits, 2 at 2 bits):
      *   qweight_tiled [strip s of 16 columns][chunk c of 4 KPL k][k-slot kb 0..3][column 0..15][word 0..WPL-1]: the lane (kb, col) holds the KPL consecutive
      *                 k from k0 = 4 KPL c + KPL kb of column 16 s + col, re-encoded so that masking a word in place yields (k, k + 1) pairs in the order x lies:
      *                   4 bits  word w, stored nibble p = w[k0 + 8 w + {0,2,4,6,1,3,5,7}[p]]     (= a nibble shuffle of qweight[16 c + 4 kb + w][16 s + col])
      *                   8 bits  word w, stored byte p   = w[k0 + 4 w + {0,2,1,3}[p]]
      *                   3 bits  word j: pair p = 5 j + i (i = 0..4) at bit 3 i of the low (k0 + 2 p) and high (k0 + 2 p + 1) 16 bits; bit 15 / 31 = bit j of
      *                           w[k0 + 30] / w[k0 + 31] -- the checkpoint's word-straddling values are resolved here, once
-     *                 A strip is one contiguous run, a chunk one contiguous 1024 (3 bits: 768) bytes = one wave load;
+     *                   2 bits  (round 6) word w: pair p (0..7) at bit 2 p of the low (k0 + 16 w + 2 p) and high (k0 + 16 w + 2 p + 1) 16 bits; read by the
+     *                           decode kernel only (plain and act-order layers, up to 4 rows; no fused epilogue) -- the batched / prefill kernels keep the checkpoint rows
+     *                 A strip is one contiguous run, a chunk one contiguous 1024 (3 bits: 768, 2 bits: 512) bytes = one wave load;
      *   qconst_tiled  [strip][group g][REC bytes] = 16 scales (layer dtype) at byte 0, then from byte 32 the 16 zero-points AS USED (zero_mode applied):
-     *                 uint8 each, REC = 48, at 3 / 4 bits; uint16 each, REC = 64, at 8 bits (no-wrap reaches 256).
+     *                 uint8 each, REC = 48, at 2 / 3 / 4 bits; uint16 each, REC = 64, at 8 bits (no-wrap reaches 256).
      * The reference re-lays its weights at load time in every fast backend (exllamav2 q_matrix.cu:19-42,149; exllama q4_matrix.cu:105-169;
      * marlin_repack.cu:8-92 + the scale permutation of qlinear_marlin.py:133-176), in place; here the checkpoint tensors are left as they are. */
     const uint32_t *qweight_tiled;
@@ -262,10 +264,10 @@ int gptq_validate_g_idx(const int32_t *g_idx_host, int K, int G);
 /* qweight_seq[row-order = perm] from qweight; device pointers. */
 int gptq_resequence_qweight(const uint32_t *qweight, const int32_t *perm, int K, int N, int bits,
                             uint32_t *qweight_seq_out, void *stream);
-/* The decode copy of a 3-, 4- or 8-bit layer (layouts: gptq_layer_t.qweight_tiled / qconst_tiled): exact integer re-arrangements of the packed fields, the
+/* The decode copy of a 2-, 3-, 4- or 8-bit layer (layouts: gptq_layer_t.qweight_tiled / qconst_tiled): exact integer re-arrangements of the packed fields, the
  * scales (bit copies) and the zero-points (the value the kernels subtract, zero_mode applied), written to caller-owned buffers of
  * gptq_prepack_decode_bytes() bytes.  Source: layer->qweight_seq when present, else layer->qweight; layer->qweight_tiled / qconst_tiled / tiled_cols
- * are ignored.  Needs bits 3 / 4 / 8, fp16 / bf16, group_size = KPL times a power of two (or group_size >= K), K % 32 == 0, N % 16 == 0, no raw act-order;
+ * are ignored.  Needs bits 2 / 3 / 4 / 8 (2 bits: no fused epilogue), fp16 / bf16, group_size = KPL times a power of two (or group_size >= K), K % 32 == 0, N % 16 == 0, no raw act-order;
  * otherwise GPTQ_ERR_UNSUPPORTED (and sizes 0).  The role of the reference's load-time re-layouts -- exllamav2 shuffle_kernel
  * (exllamav2/cuda/q_matrix.cu:19-42, called :149), exllama make_sequential (exllama/cuda_func/q4_matrix.cu:105-169), Marlin's repack kernel
  * (marlin/marlin_repack.cu:8-92) -- without touching the checkpoint tensors. */

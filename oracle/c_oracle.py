@@ -69,7 +69,7 @@ def decode_copy_weights(qweight: np.ndarray, bits: int) -> np.ndarray:
     """uint32 [N/16, chunks, 4, 16, WPL] (include/gptq_mi355x.h: qweight_tiled)."""
     q = np.ascontiguousarray(qweight, dtype=np.int32)
     K, N = q.shape[0] * 32 // bits, q.shape[1]
-    kpl, wpl = (16 if bits == 8 else 32), (3 if bits == 3 else 4)
+    kpl, wpl = (16 if bits == 8 else 32), (3 if bits == 3 else (2 if bits == 2 else 4))
     out = np.empty((N // 16, -(-K // (4 * kpl)), 4, 16, wpl), np.uint32)
     rc = lib().gptq_oracle_decode_copy_weights(_p(q, ctypes.c_int32), K, N, bits, _p(out, ctypes.c_uint32))
     assert rc == 0

@@ -88,7 +88,7 @@ int gptq_oracle_forward_f64(const float *x, const int32_t *qweight, const int32_
  * device kernels.
  *
  * A lane owns KPL consecutive k (32; 16 at 8 bits) of one column and stores them in WPL words
- * (4; 3 at 3 bits).  lane_value_of_bit answers: stored bit b of word j of a lane is bit *vb of
+ * (4; 3 at 3 bits; 2 at 2 bits).  lane_value_of_bit answers: stored bit b of word j of a lane is bit *vb of
  * the lane's value number *vk.
  * ------------------------------------------------------------------------------------------ */
 static void lane_value_of_bit(int bits, int j, int b, int *vk, int *vb)
@@ -101,6 +101,10 @@ static void lane_value_of_bit(int bits, int j, int b, int *vk, int *vb)
         int p = b >> 3;
         *vk = 4 * j + (p == 1 ? 2 : p == 2 ? 1 : p);
         *vb = b & 7;
+    } else if (bits == 2) {              /* word j: bit pair 2 p of the low / high half = k 16 j + 2 p / + 2 p + 1 */
+        int half = b >> 4, r = b & 15;
+        *vk = 16 * j + 2 * (r >> 1) + half;
+        *vb = r & 1;
     } else {                             /* 3 bits: halves hold the even / odd k of pairs 5 j .. 5 j + 4; bit 15 / 31 = bit j of k 30 / 31 */
         int half = b >> 4, r = b & 15;
         if (r == 15) { *vk = 30 + half; *vb = j; }
@@ -111,8 +115,8 @@ static void lane_value_of_bit(int bits, int j, int b, int *vk, int *vb)
 /* out: uint32 [N/16][chunks][4][16][WPL], chunks = ceil(K / (4 KPL)); k >= K read as 0 */
 int gptq_oracle_decode_copy_weights(const int32_t *qweight, int K, int N, int bits, uint32_t *out)
 {
-    if (!(bits == 3 || bits == 4 || bits == 8) || K % 32 || N % 16) return 1;
-    const int kpl = bits == 8 ? 16 : 32, wpl = bits == 3 ? 3 : 4;
+    if (!(bits == 2 || bits == 3 || bits == 4 || bits == 8) || K % 32 || N % 16) return 1;
+    const int kpl = bits == 8 ? 16 : 32, wpl = bits == 3 ? 3 : (bits == 2 ? 2 : 4);
     const int chunks = (K + 4 * kpl - 1) / (4 * kpl);
     size_t o = 0;
     for (int s = 0; s < N / 16; ++s)
@@ -139,7 +143,7 @@ int gptq_oracle_decode_copy_weights(const int32_t *qweight, int K, int N, int bi
 int gptq_oracle_decode_copy_consts(const int32_t *qzeros, const uint16_t *scale_bits, int G, int N, int bits,
                                    int zero_mode, uint8_t *out)
 {
-    if (!(bits == 3 || bits == 4 || bits == 8) || N % 32) return 1;
+    if (!(bits == 2 || bits == 3 || bits == 4 || bits == 8) || N % 32) return 1;
     const int rec = bits == 8 ? 64 : 48;
     const size_t row_words = (size_t)N / 32 * bits;
     for (int s = 0; s < N / 16; ++s)

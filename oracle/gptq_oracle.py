@@ -367,6 +367,13 @@ _BYTE_ORDER = (0, 2, 1, 3)                  # 8-bit: stored byte p holds source 
 
 def _decode_copy_lane_words(v: np.ndarray, bits: int) -> np.ndarray:
     """v: uint32 [..., KPL] = the KPL consecutive k a lane owns (32; 16 at 8 bits) -> uint32 [..., WPL] stored words (include/gptq_mi355x.h, qweight_tiled)."""
+    if bits == 2:                                            # two words: word w holds pair p = (k 16 w + 2 p, k 16 w + 2 p + 1) at bit 2 p of its low / high half
+        out = np.zeros(v.shape[:-1] + (2,), dtype=np.uint32)
+        for w in range(2):
+            for p in range(8):
+                out[..., w] |= v[..., 16 * w + 2 * p] << np.uint32(2 * p)
+                out[..., w] |= v[..., 16 * w + 2 * p + 1] << np.uint32(16 + 2 * p)
+        return out
     if bits == 4:
         out = np.zeros(v.shape[:-1] + (4,), dtype=np.uint32)
         for w in range(4):
@@ -393,9 +400,9 @@ def _decode_copy_lane_words(v: np.ndarray, bits: int) -> np.ndarray:
 
 def decode_copy_weights(qweight: torch.Tensor, bits: int = 4) -> torch.Tensor:
     """int32 [K/32*bits, N] -> int32 [N/16, chunks, 4 (k-slot), 16 (column), WPL (word)]: the lane (kb, col) of chunk c of strip s holds the KPL
-    consecutive k from c * 4 KPL + kb * KPL of column 16 s + col (KPL = 32, 16 at 8 bits; WPL = 4, 3 at 3 bits), re-encoded per
+    consecutive k from c * 4 KPL + kb * KPL of column 16 s + col (KPL = 32, 16 at 8 bits; WPL = 4, 3 at 3 bits, 2 at 2 bits), re-encoded per
     _decode_copy_lane_words; k past K read as 0.  At 4 bits this is nibble_pair_order(qweight[16c + 4kb + w, 16s + col])."""
-    assert bits in (3, 4, 8)
+    assert bits in (2, 3, 4, 8)
     w = unpack_weights(qweight, bits).astype(np.uint32)                  # [K, N]
     K, N = w.shape
     kpl = 16 if bits == 8 else 32
@@ -420,7 +427,7 @@ def decode_copy_weights_inverse(tiled: torch.Tensor, K: int) -> torch.Tensor:
 
 def decode_copy_consts(qzeros: torch.Tensor, scales: torch.Tensor, zero_mode: str, bits: int = 4) -> torch.Tensor:
     """uint8 [N/16, G, REC]: 16 scales (bit copies, 2 bytes each, little endian) at byte 0, then the 16 zero-points as used in dequant from byte 32:
-    one byte each (REC = 48) at 3 / 4 bits, two bytes each (REC = 64) at 8 bits, where nowrap reaches 256."""
+    one byte each (REC = 48) at 2 / 3 / 4 bits, two bytes each (REC = 64) at 8 bits, where nowrap reaches 256."""
     z = unpack_zeros(qzeros, bits, zero_mode)                                               # [G, N]
     G, N = z.shape
     sb = scales.cpu().contiguous().view(torch.int16).numpy().view(np.uint8).reshape(G, N, 2)

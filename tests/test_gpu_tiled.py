@@ -91,19 +91,20 @@ def test_prepack_decode_is_the_oracle_restatement(K, N, gs, dtype):
     # argument errors surface as RuntimeError with the C ABI's message (the reference: TORCH_CHECK, exllama_ext.cpp:49-71)
     with pytest.raises(_lib.GptqError, match="in place"):
         _lib.check(lib.gptq_prepack_decode(C.byref(q._layer), q.qweight.data_ptr(), q._qconst_tiled.data_ptr(), None))
-    L2 = O.random_quant_layer(256, 64, 2, 32, seed=1)
-    q2 = QuantLinear(2, 32, 256, 64, False)
+    L2 = O.random_quant_layer(256, 64, 4, 32, seed=1, dtype=torch.float32)
+    q2 = QuantLinear(4, 32, 256, 64, False, weight_dtype=torch.float32)
     q2.qweight, q2.qzeros, q2.scales, q2.g_idx = L2["qweight"], L2["qzeros"], L2["scales"], L2["g_idx"]
     q2 = q2.to(DEV)
     q2.post_init()
-    assert q2._qweight_tiled is None                                        # 2-bit layers have no decode copy
+    assert q2._qweight_tiled is None                                        # fp32 layers have no decode copy (2-bit fp16 / bf16 layers got one in round 6)
     with pytest.raises(_lib.GptqError, match="decode copy"):
         _lib.check(lib.gptq_prepack_decode_bytes(C.byref(q2._layer), C.byref(tb), C.byref(cb)))
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
 @pytest.mark.parametrize("bits,K,N,gs", [(3, 256, 128, 128), (3, 160, 64, 32), (3, 4096, 1024, 128), (3, 1056, 64, 1056), (3, 2112, 1024, 64),
-                                         (8, 256, 128, 128), (8, 160, 64, 16), (8, 4096, 1024, 128), (8, 1056, 64, 1056), (8, 2080, 1024, 32)])
+                                         (8, 256, 128, 128), (8, 160, 64, 16), (8, 4096, 1024, 128), (8, 1056, 64, 1056), (8, 2080, 1024, 32),
+                                         (2, 256, 128, 128), (2, 160, 64, 32), (2, 4096, 1024, 128), (2, 1056, 64, 1056), (2, 2112, 1024, 64)])
 def test_prepack_decode_3_and_8_bit_is_the_oracle_restatement(bits, K, N, gs, dtype):
     """The same for the 3-bit (three words per 32 k, no straddlers left) and 8-bit (16 k per lane, 2-byte zero-points) copies."""
     import ctypes as C
@@ -125,7 +126,8 @@ def test_prepack_decode_3_and_8_bit_is_the_oracle_restatement(bits, K, N, gs, dt
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
 @pytest.mark.parametrize("bits,K,N,gs", [(3, 1024, 512, 128), (3, 4160, 256, 32), (3, 2112, 1024, 64), (3, 96, 64, 32), (3, 1056, 64, 1056), (3, 4096, 4096, 128),
                                          (8, 1024, 512, 128), (8, 4128, 256, 16), (8, 2080, 1024, 32), (8, 96, 64, 32), (8, 1056, 64, 1056), (8, 4096, 4096, 128),
-                                         (8, 512, 2048, 256), (3, 28672, 32, 128)])
+                                         (8, 512, 2048, 256), (3, 28672, 32, 128),
+                                         (2, 1024, 512, 128), (2, 4160, 256, 32), (2, 2112, 1024, 64), (2, 96, 64, 32), (2, 1056, 64, 1056), (2, 4096, 4096, 128), (2, 28672, 32, 128)])
 def test_tiled_decode_3_and_8_bit(bits, K, N, gs, dtype):
     """Every output of the 3- and 8-bit decode-copy kernels (BASELINE config 5's packings): default plan, forced geometries, K slices, 1..4 rows, both
     zero-point conventions (8-bit nowrap reaches z = 256: the 2-byte field), one-hot rows exact."""
@@ -148,7 +150,7 @@ def test_tiled_decode_3_and_8_bit(bits, K, N, gs, dtype):
             q._layer.bias = saved
 
 
-@pytest.mark.parametrize("bits", [3, 8])
+@pytest.mark.parametrize("bits", [2, 3, 8])
 def test_tiled_multi_layer_launch_3_and_8_bit(bits):
     K = 2048
     widths = (512, 288, 64)
@@ -281,7 +283,8 @@ def test_tiled_multi_layer_launch(dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
 @pytest.mark.parametrize("bits,K,N,gs", [(4, 1024, 512, 128), (4, 4096, 4096, 128), (4, 4160, 256, 32), (4, 2112, 1024, 64), (4, 96, 64, 32), (4, 11008, 256, 128),
-                                         (4, 28672, 32, 128), (3, 2048, 512, 128), (3, 4096, 1024, 32), (8, 2048, 512, 128), (8, 4128, 256, 16)])
+                                         (4, 28672, 32, 128), (3, 2048, 512, 128), (3, 4096, 1024, 32), (8, 2048, 512, 128), (8, 4128, 256, 16),
+                                         (2, 2048, 512, 128), (2, 4160, 256, 32)])
 def test_tiled_decode_act_order(bits, K, N, gs, dtype):
     """Act-order (desc_act=True) layers through the decode-copy kernel: the copy holds the re-sequenced rows, the workgroup gathers x[perm[i]] while it stages
     x.  Every output against x (fp64) @ W_oracle (fp64) with the act-order class's zero convention, one-hot rows exact (a one at ORIGINAL position k must
@@ -520,7 +523,8 @@ def test_several_strips_per_workgroup_behind_one_staged_x(nstr, dtype):
     assert int(d["strips"]) == 6400 // 16, d
 
 
-@pytest.mark.parametrize("bits,K,N,gs", [(4, 4096, 4096, 128), (4, 160, 64, 32), (8, 2112, 1024, 64), (3, 1056, 64, 1056), (3, 4096, 256, 32), (8, 96, 32, 32)])
+@pytest.mark.parametrize("bits,K,N,gs", [(4, 4096, 4096, 128), (4, 160, 64, 32), (8, 2112, 1024, 64), (3, 1056, 64, 1056), (3, 4096, 256, 32), (8, 96, 32, 32),
+                                         (2, 4096, 1024, 128), (2, 160, 64, 32)])
 def test_unprepack_decode_is_the_exact_inverse(bits, K, N, gs):
     """gptq_unprepack_decode(gptq_prepack_decode(qweight)) == qweight, bit for bit, for every packing with a decode copy (ragged last chunks, the 3-bit
     straddlers); at 4 bits also the oracle's own inverse (decode_copy_weights_inverse)."""

@@ -735,14 +735,14 @@ def test_planner_fuzz_layers_with_a_decode_copy():
         rc = lib.gptq_prepack_decode_bytes(ctypes.byref(L), ctypes.byref(tb), ctypes.byref(cb))
         kpl = 16 if bits == 8 else 32
         # [gate | up] layers with the fused epilogue: plain ones get a copy too (round 5: the pair form of the decode kernel), act-order ones do not
-        can = (bits in (3, 4, 8) and L.dtype in (0, 1) and (L.epilogue == 0 or (act == 0 and N % 64 == 0)) and K % 32 == 0 and N % 32 == 0 and gs % kpl == 0
+        can = (L.dtype in (0, 1) and (L.epilogue == 0 or (bits != 2 and act == 0 and N % 64 == 0)) and K % 32 == 0 and N % 32 == 0 and gs % kpl == 0
                and act != 1 and (gs >= K or ((gs // kpl) & (gs // kpl - 1)) == 0))
         if not can:
             assert rc != 0 and tb.value == 0 and cb.value == 0, (rc, K, N, bits, gs, act)
             continue
         assert rc == 0, (lib.gptq_last_error(), K, N, bits, gs, act)
         cke = 4 * kpl
-        assert tb.value == -(-K // cke) * (768 if bits == 3 else 1024) * (N // 16)
+        assert tb.value == -(-K // cke) * (768 if bits == 3 else (512 if bits == 2 else 1024)) * (N // 16)
         assert cb.value == -(-K // gs) * (64 if bits == 8 else 48) * (N // 16)
         L.qweight_tiled = L.qconst_tiled = 0x2000
         L.tiled_cols = 16
@@ -904,18 +904,18 @@ def test_decode_copy_restatement_matches_the_header_definition():
                 assert np.array_equal(rec[32:], z[g, 16 * s_:16 * s_ + 16].astype(np.uint8))
 
 
-@pytest.mark.parametrize("bits", [3, 8])
+@pytest.mark.parametrize("bits", [2, 3, 8])
 def test_decode_copy_restatement_3_and_8_bit(bits):
     """The 3- and 8-bit decode copies (include/gptq_mi355x.h): the masks the decode kernel applies to a stored word yield the reference's unpacked values
     (oracle.unpack_weights = qlinear_cuda.py:250-290) in k order -- 8-bit (q & 0x00ff00ff) = (k0, k1), (q >> 8 & ...) = (k2, k3); 3-bit five fields per 16-bit
     half at bits 0, 3, .. 12 with pair p = 5 j + i = (k 2p, k 2p + 1), and (k30, k31) from bits 15 / 31 of the three words -- with a ragged last chunk."""
     import numpy as np
 
-    K, N, gs = (160, 32, 32) if bits == 3 else (80 * 2, 32, 16)
+    K, N, gs = (160, 32, 32) if bits in (2, 3) else (80 * 2, 32, 16)      # (2 bits, round 6: pair p of word w = (k 16w + 2p, k 16w + 2p + 1) at bit 2p of the halves)
     L = O.random_quant_layer(K, N, bits, gs, seed=3)
     w = O.unpack_weights(L["qweight"], bits)
     t = O.decode_copy_weights(L["qweight"], bits).numpy().view(np.uint32)
-    kpl, wpl = (16, 4) if bits == 8 else (32, 3)
+    kpl, wpl = (16, 4) if bits == 8 else (32, 3 if bits == 3 else 2)
     chunks = -(-K // (4 * kpl))
     assert t.shape == (N // 16, chunks, 4, 16, wpl)
     for s_ in range(N // 16):
@@ -928,6 +928,11 @@ def test_decode_copy_restatement_3_and_8_bit(bits):
                         got = []
                         for q in words:
                             got += [q & 0xFF, (q >> 16) & 0xFF, (q >> 8) & 0xFF, (q >> 24) & 0xFF]
+                    elif bits == 2:
+                        got = []
+                        for q in words:                      # the kernel's masks: 0x00030003 << 2p on the word (p = 0..4) and on the word >> 10 (p = 5..7)
+                            for p in range(8):
+                                got += [(q >> (2 * p)) & 3, (q >> (16 + 2 * p)) & 3]
                     else:
                         pairs = []
                         for q in words:

@@ -146,7 +146,8 @@ def test_c_oracle_random_words(bits):
                               O.unpack_zeros(L["qzeros"], bits, mode))
 
 
-@pytest.mark.parametrize("bits,K,N,gs", [(4, 256, 128, 64), (4, 160, 64, 32), (3, 256, 64, 128), (3, 96, 32, 32), (8, 128, 64, 64), (8, 96, 32, 32)])
+@pytest.mark.parametrize("bits,K,N,gs", [(4, 256, 128, 64), (4, 160, 64, 32), (3, 256, 64, 128), (3, 96, 32, 32), (8, 128, 64, 64), (8, 96, 32, 32),
+                                         (2, 256, 64, 64), (2, 160, 32, 32)])
 def test_c_oracle_decode_copy_matches_the_numpy_restatement(bits, K, N, gs):
     """The decode copy (include/gptq_mi355x.h, gptq_prepack_decode) stated twice: source-first with reshapes in gptq_oracle.py, destination-first bit by
     bit in gptq_oracle.c; ragged K (a last chunk that is part padding) included.  The device kernels are pinned to the numpy one in tests/test_gpu_tiled.py."""
