@@ -592,6 +592,18 @@ def bench_batched(device, steps):
                                                                                "mfma_frac": round(2 * M * K * N / per / 1e12 / MFMA_PEAK_TFLOPS, 4), "plan": _plan_of(ls, K, N, M)}
         del ls, xs
         torch.cuda.empty_cache()
+    # round 6: the other decode forms of the copy -- bf16 layers at 1 / 4 rows (4 rows: the zero-point on the matrix core) and 2-bit layers (their own copy since
+    # round 6), 4096 -> 11008, HBM-cold rotating layers
+    for tag, bits, dt, M in (("bf16_M1", 4, torch.bfloat16, 1), ("bf16_M4", 4, torch.bfloat16, 4), ("f16_M4", 4, torch.float16, 4), ("int2_M1", 2, torch.float16, 1), ("int2_M4", 2, torch.float16, 4)):
+        K, N = 4096, 11008
+        n = max(4, -(-(320 << 20) // (K * N * bits // 8)))
+        ls = [("b", K, N, make_layer(K, N, device, bits=bits, dtype=dt, seed=7200 + i)) for i in range(n)]
+        xs = {K: (torch.rand(M, K, device=device) - 0.5).to(dt)}
+        per = _time_layers(ls, xs, device, max(3, steps // 2))
+        ab = algorithmic_bytes(K, N, M, bits=bits)
+        res[f"{tag}_{K}x{N}"] = {"us": round(per * 1e6, 2), "GB_per_s": round(ab / per / 1e9, 1), "frac": round(ab / per / 1e9 / HBM_PEAK_GBS, 4), "plan": _plan_of(ls, K, N, M)}
+        del ls, xs
+        torch.cuda.empty_cache()
     return res
 
 
