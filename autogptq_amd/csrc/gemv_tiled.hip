@@ -160,6 +160,7 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
     if (waves < 1 || waves > 16 || (u != 2 && u != 4)) return pl;                // 2 or 4 chunks per wave in flight (the 1- / 8-chunk forms were lab-only: retired in round 6)
     pl.waves = waves;
     pl.u = u;
+    pl.zm2 = A.bits == 4 && A.dtype == GPTQ_BF16 && pl.mt == 2 && (long)strips * pl.ksplit < 1024;      // profiles/r06_zm_ab.log
     pl.xstride = cps * cke * 2 + 16;
     pl.lds_bytes = lds_need(pl.ksplit, waves);
     pl.xraw_off = A.g_idx ? (int)((pl.lds_bytes - ((size_t)pl.mt * ((size_t)A.K * 2 + 16) + 16) + 15) & ~(size_t)15) : 0;

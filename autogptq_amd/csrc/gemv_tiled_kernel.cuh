@@ -59,7 +59,7 @@ template <int N_> struct WordsOf { typedef unsigned type __attribute__((ext_vect
 // x rows (whole K) into the LDS and gathers its slice through perm LDS -> LDS (one more barrier; + M (2 K + 16) bytes of LDS); the rest is the plain kernel.
 // (XM = 2 was a GATED form -- the down projection of an MLP forming silu(g) * u while staging its input: correct, and no faster than the elementwise launch it
 // removed (20.6 against 20.0 us per Llama-7B MLP: every workgroup repeats the activation); not kept.)
-template <int BITS, int MT, int U, typename T, int MAXW, int XM = 0>
+template <int BITS, int MT, int U, typename T, int MAXW, int XM = 0, int ZM2 = 0>
 __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kernel(TiledParams p) {
     constexpr bool BF = std::is_same_v<T, bf16>;
     constexpr bool ACT = XM == 1, PEER = XM == 3;          // 3: plain staging + the tensor-parallel epilogue (gemv_tiled_peer.hip)
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
     // Same-session A/B against the round-4 forms (tools/lab/tiled_noxs.sh, profiles/r05_bf16_vs_f16.log; bf16 behind fp16): 1 row 6 - 13 % -> 2 - 7 %, 2 rows
     // 11 - 27 % -> 6 - 17 %; at 3 - 4 rows the per-workgroup pass over x costs more than converting the weight pairs does (13 - 48 % -> 19 - 75 %): those keep
     // the bf16 matrix core with converted weights.
-    // Round 6, 4-bit bf16 layers at 3 - 4 rows (ZM): the zero-point goes to the matrix core too.  The B operand is the raw biased pair (bias + w_k, bias + w_k+1)
+    // Round 6, 4-bit bf16 layers at 3 - 4 rows, and at 2 rows in launches below 1024 workgroups (ZM): the zero-point goes to the matrix core too.  The B operand is the raw biased pair (bias + w_k, bias + w_k+1)
     // -- bias = 128 as bf16, 1024 as fp16: (q >> 4 i) & 0x000f000f | pattern, 7 VALU per packed word -- and a SECOND accumulator chain multiplies the same x
     // by the constant pair -(bias + z): sum x (bias + w) + sum x (-(bias + z)) = sum x (w - z).  No pass over x per workgroup (XS's run sums), no block-floating
     // rewrite (XC), no conversion of decoded pairs (the 3..4-row bf16 form: 25 VALU per word).  A one-hot row returns (bias + w) - (bias + z) = w - z exactly; a
@@ -216,12 +216,13 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
     // negatives); everywhere else the cancellation costs log2(bias / 8) bits of the fp32 run sums (4 for bf16, 7 for fp16: 2^-17 relative, below either type's ulp).
     // Same-session A/B (tools/session_r06_zm.sh, profiles/r06_zm_ab.log; us, bf16 product -> this form | fp16): 4 rows 4096^2 5.96 -> 5.24 | 5.2, 4096 -> 11008
     // 10.1 -> 8.4 | 8.4, 11008 -> 4096 11.1 -> 9.0 | 8.7, q|k|v 10.3 -> 8.8 | 8.7, gate|up 16.1 -> 14.2 | 12.6: bf16 19 - 30 % -> 0 - 3 % (gate|up 13 %) behind fp16.
-    // NOT at 1 - 2 rows (twice the matrix-core instructions: even on single layers, 14 - 17 % slower than the run-sum form on the 1376-strip gate|up launch) and
+    // NOT at 1 row, nor at 2 rows in launches of 1024+ workgroups (twice the matrix-core instructions: 11 - 17 % slower than the run-sum form on the 1376-strip gate|up launch) and
     // NOT for fp16 (its 13-VALU exact form is faster: 4096 -> 11008 7.2 -> 7.7, gate|up 12.3 -> 14.3).
 #if defined(GPTQ_TILED_ZM)                                                          // lab: 1 = bf16 layers at 1..4 rows, 2 = fp16 layers too (A/B builds: tools/ab_tiled.sh)
     constexpr bool ZM = BITS == 4 && MT <= 4 && (GPTQ_TILED_ZM == 2 || (GPTQ_TILED_ZM == 1 && BF));
 #else
-    constexpr bool ZM = BITS == 4 && MT == 4 && BF;
+    constexpr bool ZM = BITS == 4 && BF && (MT == 4 || (MT == 2 && ZM2 == 1));      // 2 rows: where the planner asks (launches below 1024 workgroups: 4096 -> 11008 8.9 -> 8.4 us,
+                                                                                    // 11008 -> 4096 9.3 -> 8.2, q|k|v 9.3 -> 8.8; the 1376-strip gate|up launch 13.3 -> 14.8: stays on the run sums)
 #endif
 #ifdef GPTQ_TILED_NO_XS                                                            // lab: the round-4 bf16 forms (A/B build: tools/lab/tiled_noxs.sh)
     constexpr bool XS = false;
@@ -507,6 +508,15 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
 // Two compilations per (BITS, MT, U, T, XM): workgroups of up to 16 waves (<= 128 VGPRs) and of up to 8 waves.
 template <int BITS, int MT, int U, typename T, int XM>
 static hipError_t launch_tiled_one(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
+    if constexpr (BITS == 4 && MT == 2 && std::is_same_v<T, bf16> && (XM == 0 || XM == 1)) {      // plain and act-order forms
+        if (pl.zm2) {
+            if (pl.waves > 8)
+                hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 16, XM, 1>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+            else
+                hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 8, XM, 1>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+            return hipGetLastError();
+        }
+    }
     if (pl.waves > 8)
         hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 16, XM>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
     else
@@ -558,6 +568,7 @@ static hipError_t grant_tiled_lds() {
             constexpr int B = decltype(bu)::value, U = decltype(uu)::value;
             grant(gemv_tiled_kernel<B, MT, U, f16, 16, XM>); grant(gemv_tiled_kernel<B, MT, U, f16, 8, XM>);
             grant(gemv_tiled_kernel<B, MT, U, bf16, 16, XM>); grant(gemv_tiled_kernel<B, MT, U, bf16, 8, XM>);
+            if constexpr (B == 4 && MT == 2 && (XM == 0 || XM == 1)) { grant(gemv_tiled_kernel<B, MT, U, bf16, 16, XM, 1>); grant(gemv_tiled_kernel<B, MT, U, bf16, 8, XM, 1>); }
         };
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
         grant_u(I4{}, I2{}); grant_u(I4{}, I4{});

@@ -141,6 +141,7 @@ struct TiledPlan {
     int nseg, bits, waves, u, mt, ksplit, chunks_total, chunks_per_split, strips_total, nsum, groups, xstride, xraw_off;
     size_t lds_bytes;
     size_t partial_bytes;    // behind the header: [ksplit - 1][M][nsum] granules when ksplit > 1
+    bool zm2;                // bf16 4-bit layers at 2 rows, launches below 1024 workgroups: the zero-point on the matrix core (gemv_tiled_kernel<..., ZM2 = 1>)
 };
 bool tiled_layer_ok(const gptq_layer_t& L);
 TiledPlan plan_tiled(const gptq_layer_t* const* layers, int n, int M, const gptq_tuning_t* tune);
