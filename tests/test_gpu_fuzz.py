@@ -126,12 +126,48 @@ def test_random_multi_layer_launches_against_the_oracle(seed):
             _close(y, y64, dtype, K, f"multi int{bits} g{gs} K={K} widths={widths} M={M} {dtype} copy={tiled}")
 
 
+@pytest.mark.parametrize("seed", range(80))
+def test_random_forced_plans_are_correct_or_refused(seed):
+    """tuning structs drawn at random (kernel family, strip width, waves, K slices): a forced plan either runs and matches the oracle, or the call is REFUSED
+    with a GptqError (GPTQ_ERR_UNSUPPORTED / _WORKSPACE: 'does not fit' is an error, never a silent fallback and never a wrong answer)."""
+    rnd = random.Random(7000 + seed)
+    bits, dtype, K, N, gs, act, tiled, epi, Ms = _draw(rnd, False)
+    if dtype == torch.float32:
+        dtype = torch.float16
+    L = O.random_quant_layer(K, N, bits, gs, act_order=act, dtype=dtype, seed=seed, bias=True)
+    L.setdefault("act_order", act)
+    zm = "nowrap" if act else rnd.choice(("wrap", "nowrap"))
+    try:
+        q = _module(L, bits, gs, dtype, tiled, "none", zm)
+    except (_lib.GptqError, ValueError) as e:
+        pytest.skip(f"refused at post_init: {e}")
+    W64 = _w64(L, bits, O.ZERO_NOWRAP if zm == "nowrap" else O.ZERO_WRAP)
+    ran = 0
+    for M in Ms[:4]:
+        t = _lib.GptqTuning()
+        t.path = rnd.choice((0, 1, 3, 5, 6, 8))
+        t.lanes_n = rnd.choice((0, 0, 4, 8, 16))
+        t.waves = rnd.choice((0, 0, 2, 4, 8, 16))
+        t.ksplit = rnd.choice((0, 0, 1, 2, 4))
+        x = (torch.rand(M, K, generator=torch.Generator().manual_seed(seed + M)) - 0.5).to(dtype)
+        y64 = x.double() @ W64 + L["bias"].double()
+        try:
+            with torch.no_grad():
+                y = q(x.to(DEV), tuning=t)
+        except _lib.GptqError:
+            continue
+        ran += 1
+        _close(y, y64, dtype, K, f"forced path={t.path} ln={t.lanes_n} waves={t.waves} ks={t.ksplit}: int{bits} g{gs} {K}x{N} M={M} {dtype} act={act} copy={tiled}")
+    SEEN["forced_ran"] = SEEN.get("forced_ran", 0) + ran
+
+
 def test_the_fuzz_reached_every_kernel_family():
     """Runs last in this file: the default plans above must have landed on the decode-copy kernel, the batched-decode and panel kernels, the fp32-math GEMV,
     a matrix-core GEMV on the checkpoint rows and at least one MFMA GEMM -- otherwise the draw has drifted away from what it is meant to cover."""
-    if not SEEN:
+    if not (set(SEEN) - {"forced_ran"}):
         pytest.skip("run together with the fuzz cases")
     need = {"strips", "generic", "rows"}
     assert need <= set(SEEN), SEEN
     assert {"mfma", "mfma_generic", "stream"} & set(SEEN), SEEN
     assert {"tiled", "wide_sk", "panel", "mid", "stream64", "skinny64", "strip16", "f32_mfma"} & set(SEEN), SEEN
+    assert SEEN.get("forced_ran", 1) > 0, SEEN
