@@ -89,12 +89,13 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
     // Strips per workgroup (gemv_tiled_multi.hip): 3..8 rows of plain layers whose widths are whole groups of strips and that need no K slices -- every strip
     // staging its own rows of x is what those forms lose on layers of many strips.  tuning.reserved[GPTQ_LAB_OPT] = 1 / 2 / 4 (with path = 8) forces the count.
     int nstr = 1;
-    if (!pair && M >= 3 && !A.g_idx && A.bits != 2) {
+    const int multi_from = A.bits == 4 ? 1 : 3;       // 4-bit layers: also at 1 - 2 rows (two strips only)
+    if (!pair && M >= multi_from && !A.g_idx && A.bits != 2) {
         // measured (tools/multi_strip_ab.py, profiles/r05_multi_strip_ab.log, us, 1 / 2 / 4 strips per workgroup): gate|up M = 4 13.2 / 12.6 / 16.5, M = 8 21.2 / 16.5 / 21.4
         // (the batched-decode kernel on the checkpoint rows: 17.3); q|k|v M = 8 12.8 / 11.2 / 11.3 (10.8); 4096x11008 M = 8 12.2 / 11.0 / 11.0 (10.5); 3..4 rows
         // on launches below ~1000 strips lose 0.7 - 1 us -- two strips per workgroup from 1024 strips up, else one
         const int want = (tune && tune->path == 8 && tune->reserved[1]) ? tune->reserved[1] : (strips >= 1024 ? 2 : 1);
-        if (want == 2 || want == 4) {
+        if (want == 2 || (want == 4 && M >= 3)) {
             nstr = want;
             for (int i = 0; i < n; ++i)
                 if (Ls[i]->N % (GPTQ_STRIP_COLS * want) != 0) nstr = 1;
@@ -156,6 +157,7 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         while (waves > per && (waves / (2 * per)) * u >= cps) waves /= 2;
     }
     if (pair && (waves & 1)) return pl;
+    if (nstr > 1 && pl.mt <= 2 && (waves > 8 || u != 4)) return pl;              // the 1 - 2-row two-strip form is compiled for its planned geometry only
     if (nstr > 1 && waves % nstr != 0) return pl;
     if (waves < 1 || waves > 16 || (u != 2 && u != 4)) return pl;                // 2 or 4 chunks per wave in flight (the 1- / 8-chunk forms were lab-only: retired in round 6)
     pl.waves = waves;

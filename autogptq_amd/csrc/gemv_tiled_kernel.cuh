@@ -517,28 +517,33 @@ static hipError_t launch_tiled_one(const TiledPlan& pl, const TiledParams& p, hi
             return hipGetLastError();
         }
     }
-    if (pl.waves > 8)
-        hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 16, XM>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
-    else
+    if (pl.waves > 8) {
+        if constexpr (XM == 6 && MT <= 2) return hipErrorInvalidValue;            // the 1 - 2-row two-strip form: 8 waves (the planner's geometry)
+        else hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 16, XM>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+    } else {
         hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 8, XM>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+    }
     return hipGetLastError();
 }
 template <int BITS, int MT, typename T, int XM>
 static hipError_t launch_tiled_u(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
     switch (pl.u) {
-        case 2: return launch_tiled_one<BITS, MT, 2, T, XM>(pl, p, st);
+        case 2: if constexpr (!(XM == 6 && MT <= 2)) return launch_tiled_one<BITS, MT, 2, T, XM>(pl, p, st); else return hipErrorInvalidValue;
         case 4: return launch_tiled_one<BITS, MT, 4, T, XM>(pl, p, st);
         default: return hipErrorInvalidValue;
     }
 }
 template <int BITS, typename T, int XM>
 static hipError_t launch_tiled_mt(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
-    if constexpr (XM == 5 || XM == 6) {                                           // multi-strip workgroups: the 3..4-row and 5..8-row forms only
+    // multi-strip workgroups: the 3..4-row and 5..8-row forms; round 6: two strips per workgroup also at 1 - 2 rows of 4-bit layers (the planner's own geometry only:
+    // 8 waves x 4 chunks) -- the 1376-strip gate|up launch 11.8 -> 11.5 us (profiles/r06_multi_low_ab.log)
+    constexpr bool LOW_OK = XM != 5 && (XM != 6 || BITS == 4);
+    if constexpr (!LOW_OK) {
         if (pl.mt != 4 && pl.mt != 8) return hipErrorInvalidValue;
     }
     switch (pl.mt) {
-        case 1: if constexpr (XM != 5 && XM != 6) return launch_tiled_u<BITS, 1, T, XM>(pl, p, st); else return hipErrorInvalidValue;
-        case 2: if constexpr (XM != 5 && XM != 6) return launch_tiled_u<BITS, 2, T, XM>(pl, p, st); else return hipErrorInvalidValue;
+        case 1: if constexpr (LOW_OK) return launch_tiled_u<BITS, 1, T, XM>(pl, p, st); else return hipErrorInvalidValue;
+        case 2: if constexpr (LOW_OK) return launch_tiled_u<BITS, 2, T, XM>(pl, p, st); else return hipErrorInvalidValue;
         case 4: return launch_tiled_u<BITS, 4, T, XM>(pl, p, st);
         case 8: if constexpr (XM != 3 && XM != 4 && BITS != 2) return launch_tiled_u<BITS, 8, T, XM>(pl, p, st); else return hipErrorInvalidValue;      // 5..8 rows: plain, act-order and multi-strip forms
         default: return hipErrorInvalidValue;
@@ -576,6 +581,10 @@ static hipError_t grant_tiled_lds() {
         if constexpr ((XM == 0 || XM == 1) && MT <= 4) { grant_u(I2{}, I2{}); grant_u(I2{}, I4{}); }
     };
     if constexpr (XM != 5 && XM != 6) { grant_mt(std::integral_constant<int, 1>{}); grant_mt(std::integral_constant<int, 2>{}); }
+    if constexpr (XM == 6) {                                                      // the 1 - 2-row two-strip form (4 bits, 8 waves x 4 chunks)
+        grant(gemv_tiled_kernel<4, 1, 4, f16, 8, 6>); grant(gemv_tiled_kernel<4, 1, 4, bf16, 8, 6>);
+        grant(gemv_tiled_kernel<4, 2, 4, f16, 8, 6>); grant(gemv_tiled_kernel<4, 2, 4, bf16, 8, 6>);
+    }
     grant_mt(std::integral_constant<int, 4>{});
     if constexpr (XM != 3 && XM != 4) grant_mt(std::integral_constant<int, 8>{});
     return e;

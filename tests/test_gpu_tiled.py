@@ -495,7 +495,7 @@ def test_several_strips_per_workgroup_behind_one_staged_x(nstr, dtype):
     K = 1024
     made = [_layer(K, N, 128, dtype, 300 + i, bias=True) for i, N in enumerate((6400, 1024, 1024))]
     layers = [m[1] for m in made]
-    for M in (3, 4, 5, 8):
+    for M in ((1, 2, 3, 4, 5, 8) if nstr == 2 else (3, 4, 5, 8)):                # round 6: two strips per workgroup also at 1 - 2 rows (4-bit layers)
         x, ks = _x(M, K, dtype, M)
         t = _tune()
         t.reserved[LAB.OPT] = nstr
