@@ -42,6 +42,7 @@ hipError_t launch_tiled_multi(const TiledPlan& pl, const TiledParams& p, int dty
 hipError_t init_gemv_tiled_multi_device();
 
 // ---- plan + launch ---------------------------------------------------------------------------------------------------------------------
+int tiled_max_waves(int u, int nstr) { return (u == 2 || nstr == 4) ? 16 : 8; }       // = tiled_maxw<U, XM>() of gemv_tiled_kernel.cuh: the launch bound each depth is compiled for
 static int tiled_kpl(int bits) { return bits == 8 ? 16 : 32; }          // k per lane and chunk
 static int tiled_chunk_bytes(int bits) { return bits == 3 ? 768 : (bits == 2 ? 512 : 1024); }
 static int tiled_rec_bytes(int bits) { return bits == 8 ? 64 : 48; }
@@ -160,6 +161,7 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
     if (nstr > 1 && pl.mt <= 2 && (waves > 8 || u != 4)) return pl;              // the 1 - 2-row two-strip form is compiled for its planned geometry only
     if (nstr > 1 && waves % nstr != 0) return pl;
     if (waves < 1 || waves > 16 || (u != 2 && u != 4)) return pl;                // 2 or 4 chunks per wave in flight (the 1- / 8-chunk forms were lab-only: retired in round 6)
+    if (waves > tiled_max_waves(u, nstr)) return pl;                              // 4 chunks in flight: workgroups of at most 8 waves (one compilation per depth; only a forced geometry gets here)
     pl.waves = waves;
     pl.u = u;
     pl.zm2 = A.bits == 4 && A.dtype == GPTQ_BF16 && pl.mt == 2 && (long)strips * pl.ksplit < 1024;      // profiles/r06_zm_ab.log

@@ -505,24 +505,23 @@ __global__ void __launch_bounds__(MAXW * 64, MAXW == 16 ? 4 : 2) gemv_tiled_kern
     }
 }
 
-// Two compilations per (BITS, MT, U, T, XM): workgroups of up to 16 waves (<= 128 VGPRs) and of up to 8 waves.
+// ONE compilation per (BITS, MT, U, T, XM) (round 6: there were two -- workgroups of up to 16 and of up to 8 waves -- that differed by a register or two, every
+// form fits 128 VGPRs): the launch bound is the one the planner's geometry of that depth uses -- 2 chunks in flight: 16-wave workgroups (<= 320 workgroups:
+// one per CU); 4 chunks in flight: 4- or 8-wave workgroups, except the four-strip form (XM = 5: 16 waves = 4 strips x 4 waves).  A forced (waves, depth)
+// outside its compilation is refused by plan_tiled.
+template <int U, int XM> constexpr int tiled_maxw() { return (U == 2 || XM == 5) ? 16 : 8; }
+int tiled_max_waves(int u, int nstr);                                             // the same rule for the planner (gemv_tiled.hip)
 template <int BITS, int MT, int U, typename T, int XM>
 static hipError_t launch_tiled_one(const TiledPlan& pl, const TiledParams& p, hipStream_t st) {
+    constexpr int MAXW = tiled_maxw<U, XM>();
+    if (pl.waves > MAXW) return hipErrorInvalidValue;
     if constexpr (BITS == 4 && MT == 2 && std::is_same_v<T, bf16> && (XM == 0 || XM == 1)) {      // plain and act-order forms
         if (pl.zm2) {
-            if (pl.waves > 8)
-                hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 16, XM, 1>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
-            else
-                hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 8, XM, 1>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
+            hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, MAXW, XM, 1>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
             return hipGetLastError();
         }
     }
-    if (pl.waves > 8) {
-        if constexpr (XM == 6 && MT <= 2) return hipErrorInvalidValue;            // the 1 - 2-row two-strip form: 8 waves (the planner's geometry)
-        else hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 16, XM>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
-    } else {
-        hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, 8, XM>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
-    }
+    hipLaunchKernelGGL((gemv_tiled_kernel<BITS, MT, U, T, MAXW, XM>), dim3(pl.strips_total * pl.ksplit), dim3(pl.waves * 64), pl.lds_bytes, st, p);
     return hipGetLastError();
 }
 template <int BITS, int MT, typename T, int XM>
@@ -571,9 +570,9 @@ static hipError_t grant_tiled_lds() {
         constexpr int MT = decltype(mt)::value;
         auto grant_u = [&](auto bu, auto uu) {
             constexpr int B = decltype(bu)::value, U = decltype(uu)::value;
-            grant(gemv_tiled_kernel<B, MT, U, f16, 16, XM>); grant(gemv_tiled_kernel<B, MT, U, f16, 8, XM>);
-            grant(gemv_tiled_kernel<B, MT, U, bf16, 16, XM>); grant(gemv_tiled_kernel<B, MT, U, bf16, 8, XM>);
-            if constexpr (B == 4 && MT == 2 && (XM == 0 || XM == 1)) { grant(gemv_tiled_kernel<B, MT, U, bf16, 16, XM, 1>); grant(gemv_tiled_kernel<B, MT, U, bf16, 8, XM, 1>); }
+            constexpr int MAXW = tiled_maxw<U, XM>();
+            grant(gemv_tiled_kernel<B, MT, U, f16, MAXW, XM>); grant(gemv_tiled_kernel<B, MT, U, bf16, MAXW, XM>);
+            if constexpr (B == 4 && MT == 2 && (XM == 0 || XM == 1)) grant(gemv_tiled_kernel<B, MT, U, bf16, MAXW, XM, 1>);
         };
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
         grant_u(I4{}, I2{}); grant_u(I4{}, I4{});

@@ -220,10 +220,10 @@ def test_tiled_decode_default_plan(K, N, gs, dtype):
                     assert torch.equal(y0[r], W[k]), f"one-hot row {r} (k={k}) is not the oracle's W[k], M={M} {K}x{N} g{gs}"
 
 
-@pytest.mark.parametrize("waves,u", [(16, 2), (16, 4), (8, 2), (8, 4), (4, 2), (4, 4), (2, 4), (1, 2), (3, 4)])
+@pytest.mark.parametrize("waves,u", [(16, 2), (8, 2), (8, 4), (4, 2), (4, 4), (2, 4), (1, 2), (3, 4)])
 def test_tiled_decode_forced_geometries(waves, u):
     """Every (waves, chunks per wave) the planner or a sweep can ask for, incl. workgroups that walk their strip in several passes and ones larger
-    than the strip."""
+    than the strip.  (16 waves x 4 chunks is no longer compiled for single-strip workgroups -- the next test.)"""
     for (K, N, gs), dtype in (((2048, 256, 128), torch.float16), ((4160, 64, 64), torch.bfloat16)):
         L, q, W = _layer(K, N, gs, dtype, waves * 31 + u)
         for M in (1, 4):
@@ -235,6 +235,18 @@ def test_tiled_decode_forced_geometries(waves, u):
             for r, k in hot:
                 assert torch.equal(y[r], W[k])
             _assert_all(y, x, W, None, dtype, f"tiled waves={waves} u={u} {K}x{N} M={M}")
+
+
+def test_tiled_decode_geometry_outside_its_compilation_is_refused():
+    """Round 6: every decode-copy form is compiled ONCE -- 2 chunks in flight for workgroups of up to 16 waves, 4 chunks for up to 8 (the planner's
+    geometries; the two compilations per form of rounds 4-5 differed by a register or two).  A forced 16 x 4 is refused by the planner (status, message,
+    nothing launched); the default plan of the same layer runs."""
+    L, q, W = _layer(2048, 256, 128, torch.float16, 5)
+    x, _ = _x(2, 2048, torch.float16, 3)
+    with pytest.raises(_lib.GptqError):
+        q(x, tuning=_tune(16, 4))
+    with torch.no_grad():
+        _assert_all(q(x), x, W, None, torch.float16, "default after a refused geometry")
 
 
 @pytest.mark.parametrize("ks", [2, 3, 4, 8])

@@ -50,8 +50,8 @@ def test_hot_kernels_stay_inside_their_register_budget():
     ks = _kernels()
     tiled = {n: v for n, v in ks.items() if "gemv_tiled_kernel" in n}
     # plain (XM = 0), act-order (1) and tensor-parallel (3) forms x 3 packings x 3 row counts (+ the 5..8-row form of the plain and act-order kernels) x chunk
-    # depths x 2 dtypes x 2 workgroup sizes
-    assert len(tiled) >= 288, len(tiled)
+    # depths x 2 dtypes -- ONE compilation each since round 6 (the 8- and the 16-wave compilations of a form differed by a register or two: tiled_maxw)
+    assert 200 <= len(tiled) <= 260, len(tiled)
     bad = {n: v for n, v in tiled.items() if v["spill"] or v["scratch"]}
     assert not bad, f"decode-copy kernels touching scratch: {list(bad.items())[:4]}"
     assert all(v["vgpr"] <= 128 for v in tiled.values())             # 16-wave workgroups: 4 waves per SIMD
@@ -86,7 +86,7 @@ def test_no_kernel_of_the_library_touches_scratch():
     ks = _kernels()
     bad = {n: (v["spill"], v["scratch"]) for n, v in ks.items() if ((v["spill"] or 0) or (v["scratch"] or 0)) and "gemm_wide_kernel" not in n}
     assert not bad, list(bad.items())[:6]
-    assert len(ks) <= 1400, len(ks)                                  # 1,714 at the end of round 5
+    assert len(ks) <= 1160, len(ks)                                  # 1,714 at the end of round 5; 1,153 once every decode-copy form is compiled once
     assert os.path.getsize(SO) <= 17 * 2 ** 20, os.path.getsize(SO)  # 19.9 MB at the end of round 5
     for fam in ("gemv_q4_f16_kernel", "gemv_q4_f16_direct_kernel"):      # round 1's comparison GEMVs (tuning.path = 2 / 4): retired
         assert not any(fam + "I" in n for n in ks), fam
