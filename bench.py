@@ -646,10 +646,13 @@ def bench_eager(layers, xs, device, steps):
             "note": "eager calls (torch.empty + C-ABI call + launch per call), no hipGraph; median of 5 passes, cyclic GC off while timing"}
 
 
-def cpu_baseline(M, act_order, budget_s=20.0):
+def cpu_baseline(M, act_order, budget_s=20.0, device=None):
     """Time the oracle (a port of the reference's pure-PyTorch CPU QuantLinear.forward: materialise
     the unpacked ints, dequantise, torch.matmul) on the host cores, on a bounded sample: the three
-    distinct Llama-7B layer shapes, a few repetitions each."""
+    distinct Llama-7B layer shapes, a few repetitions each.  With a device: the SAME three layers and inputs also go through the product's
+    default plan (the kernels the headline times) and every output is compared with what the CPU computed -- the oracle as the checker of
+    the measured path ("gpu_vs_cpu"), at the reference's own tolerance for this comparison (tests/test_q4.py: 1e-3 relative + absolute on
+    outputs of this size)."""
     from oracle import gptq_oracle as O
 
     # the reference class was timed on 8 threads in the build container (BASELINE.md section 5); 128 threads make these small tensor ops
@@ -657,6 +660,8 @@ def cpu_baseline(M, act_order, budget_s=20.0):
     threads = min(16, torch.get_num_threads())
     torch.set_num_threads(threads)
     total_b, total_t, reps_done = 0, 0.0, []
+    gpu_check = {"shapes": 0, "outputs": 0, "max_err_over_max_out": 0.0, "tolerance": "1e-3 * max|y_cpu| + 1e-3 * |y_cpu| per output", "ok": True,
+                 "what": "the product's default plan on the same layers and inputs, every output against the CPU result timed here"}
     per_shape = budget_s / 3
     # Where the reference tree is present (the build container; it does not travel to the GPU box) its OWN class is what is timed -- kind "reference":
     # auto_gptq/nn_modules/qlinear/qlinear_cuda_old.py (qlinear_cuda.py for act-order) loaded by file path, as tools/time_reference_cpu.py does.
@@ -694,14 +699,66 @@ def cpu_baseline(M, act_order, budget_s=20.0):
         total_b += n * algorithmic_bytes(K, N, M, act_order=act_order)
         total_t += t_acc
         reps_done.append(f"{K}x{N}x{n}")
+        if device is not None:
+            try:
+                import autogptq_amd
+                with torch.no_grad():
+                    y_cpu = fwd().float()
+                    g = autogptq_amd.QuantLinear(4, 128, K, N, False)
+                    g.qweight, g.qzeros, g.scales, g.g_idx = L["qweight"].clone(), L["qzeros"].clone(), L["scales"].clone(), L["g_idx"].clone()
+                    g = g.to(device)
+                    g.post_init()
+                    y_gpu = g(x.to(device)).float().cpu()
+                    del g
+                err = (y_gpu - y_cpu).abs()
+                bound = 1e-3 * float(y_cpu.abs().max()) + 1e-3 * y_cpu.abs()
+                gpu_check["shapes"] += 1
+                gpu_check["outputs"] += int(err.numel())
+                gpu_check["max_err_over_max_out"] = round(max(gpu_check["max_err_over_max_out"], float(err.max()) / (float(y_cpu.abs().max()) or 1.0)), 6)
+                gpu_check["ok"] = bool(gpu_check["ok"] and bool((err <= bound).all()))
+            except Exception as e:
+                gpu_check["error"] = repr(e)[:200]
+                gpu_check["ok"] = False
+    # SURVEY 8(d) "reference CPU path timed beside it": also one thread, and fp32 inputs (the reference's CPU path computes in the input's type), on
+    # 4096 x 4096: 3 warm-ups + 10 repetitions each, wall clock, ms per forward (median)
+    extra = {}
+    try:
+        K = N = 4096
+        L = O.random_quant_layer(K, N, 4, 128, act_order=act_order, seed=1)
+        mode = O.reference_zero_mode(act_order, 4)
+        gi = L["g_idx"] if act_order else None
+
+        def timed_ms(xin, scales, nthreads):
+            torch.set_num_threads(nthreads)
+            f = lambda: O.forward_fast(xin, L["qweight"], L["qzeros"], scales, gi, None, 4, mode)      # noqa: E731
+            with torch.no_grad():
+                for _ in range(3):
+                    f()
+                ts = []
+                for _ in range(10):
+                    t0 = time.perf_counter()
+                    f()
+                    ts.append(time.perf_counter() - t0)
+            return round(1e3 * sorted(ts)[len(ts) // 2], 2)
+        x16 = (torch.rand(M, K) - 0.5).half()
+        extra["ms_4096x4096_fp16_threads_%d" % threads] = timed_ms(x16, L["scales"], threads)
+        extra["ms_4096x4096_fp16_threads_1"] = timed_ms(x16, L["scales"], 1)
+        extra["ms_4096x4096_fp32_threads_%d" % threads] = timed_ms(x16.float(), L["scales"].float(), threads)
+        extra["ms_4096x4096_fp32_threads_1"] = timed_ms(x16.float(), L["scales"].float(), 1)
+    except Exception as e:
+        extra["error"] = repr(e)[:200]
+    finally:
+        torch.set_num_threads(threads)
     return {"value": round(total_b / total_t / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "reference" if ref_cls is not None else "port",
+            "protocol_8d": extra,
             "sample": (("the reference's own QuantLinear.forward (%s, loaded by path), " % os.path.basename(ref_file)) if ref_cls is not None else
                        "oracle.forward_fast = the reference's own broadcast shift+mask unpack (qlinear_cuda_old.py:295-349) + torch.matmul, ") +
                       "torch CPU fp16, M=%d, shapes x reps: %s" % (M, ", ".join(reps_done)),
             "ms_per_layer_mean": round(1e3 * total_t / sum(int(r.split('x')[2]) for r in reps_done), 2),
             # the reference CLASS itself (qlinear_cuda_old.QuantLinear.forward, imported from /root/reference) timed in the 8-core build container,
             # ms per forward on 4096x4096 / 4096x11008 / 11008x4096: it cannot run on the GPU box, so this port is what is timed here
-            "reference_class_ms_build_container": [30.4, 768, 305]}
+            "reference_class_ms_build_container": [30.4, 768, 305],
+            **({"gpu_vs_cpu": gpu_check} if device is not None else {})}
 
 
 def bench_tp(device, rank, world, steps, peer_store=False):
@@ -1332,7 +1389,7 @@ def main():
             except Exception as e:
                 roof["flat_keys_error"] = repr(e)[:200]
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only (bounded sample, ~25 s of host time)
-            out["cpu_baseline"] = cpu_baseline(1 if not prefill else 16, act_order)
+            out["cpu_baseline"] = cpu_baseline(1 if not prefill else 16, act_order, device=device)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
