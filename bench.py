@@ -607,6 +607,31 @@ def bench_batched(device, steps):
     return res
 
 
+def bench_warm_l3(device, steps, M=1):
+    """"warm / L3 number reported separately".  ONE decoder block (its seven layers = 105 MB of packed weights: inside the 256 MiB Infinity
+    Cache) as the same four launches the headline times, replayed back to back -- from the second replay on the weights come out of the cache, not the HBM.
+    us per launch type (16 copies of the block's four launches per graph, median of `steps`+ replays) and the block's GB/s; the headline (cold, 224
+    distinct layers = 3.37 GB) is the number to compare against: the difference is what the HBM costs the decode launches over the cache."""
+    layers, xs = build_stack(device, 1, M, False)
+    grouped = group_stack(layers)
+    out = {"rows_per_step": M, "resident_bytes": int(sum(entry_bytes(e, M) for e in grouped)), "us_per_launch_by_shape": {}}
+    total = 0.0
+    for ent in grouped:
+        name, K, N, q = ent
+        g, o = capture([ent] * 16, xs, device)
+        settle(g, device)
+        ts = time_graph_each(g, max(20, steps), device)
+        us = 1e6 * _pctl(ts, 0.5) / 16
+        key = f"{name}:{K}x{N}" if isinstance(q, list) else f"{K}x{N}"
+        out["us_per_launch_by_shape"][key] = round(us, 3)
+        total += us
+        del g, o
+    out["us_per_block"] = round(total, 3)
+    out["GB_per_s"] = round(out["resident_bytes"] / (total * 1e-6) / 1e9, 1)
+    out["frac_of_hbm_peak"] = round(out["GB_per_s"] / HBM_PEAK_GBS, 4)
+    return out
+
+
 def bench_eager(layers, xs, device, steps):
     """The same 224 layers called one by one through QuantLinear.forward with no graph: what the reference's callers do
     (generate() under inference_mode, auto_gptq/modeling/_base.py:415-418).  Wall clock per call incl. Python + ctypes."""
@@ -1274,7 +1299,8 @@ def main():
             for name, fn in (("prefill", lambda: bench_prefill(device, max(3, args.steps // 4))),
                              ("mlp_prefill", lambda: bench_mlp_prefill(device, max(3, args.steps // 4))),
                              ("config5", lambda: bench_config5(device, args.steps)),
-                             ("batched_decode", lambda: bench_batched(device, args.steps))):
+                             ("batched_decode", lambda: bench_batched(device, args.steps)),
+                             ("warm_l3", lambda: bench_warm_l3(device, args.steps))):
                 try:
                     torch.cuda.empty_cache()
                     out[name] = fn()
@@ -1381,6 +1407,10 @@ def main():
                 if isinstance(mp, dict) and "us_per_mlp" in mp:      # desc_act MLP at 2048 rows through gptq_mlp_forward: down without a permute launch of its own
                     for k in ("us_per_mlp", "us_per_mlp_two_passes", "down_part_us", "down_part_us_two_passes"):
                         roof["mlp_prefill_" + k] = mp[k]
+                wl = out.get("warm_l3")
+                if isinstance(wl, dict) and "GB_per_s" in wl:      # the cache-warm number beside the cold headline
+                    roof["warm_l3_GB_per_s"] = wl["GB_per_s"]
+                    roof["warm_l3_us_per_launch_by_shape"] = wl["us_per_launch_by_shape"]
                 bd2 = out.get("batched_decode")
                 if isinstance(bd2, dict):
                     for k in ("short_prompt_M256_4096x4096", "M512_4096x4096", "M512_4096x11008", "M512_11008x4096", "M128_4096x11008", "M128_4096x4096"):
