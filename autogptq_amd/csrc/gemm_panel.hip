@@ -113,7 +113,10 @@ bool panel_pays(const gptq_layer_t& L, int M) {
     }
     if (kn > ((size_t)128 << 20) || L.K > 16384) return false;
     if (M < 160 && L.K > 8192) return false;
-    if (M < 96 && !(L.N >= 8192 && L.K <= 4096)) return false;      // 64 .. 95 rows: measured on the wide layers only (4096x11008: 172 tiles of 64 x 64 against the rows kernel's 230 workgroups)
+    // 64 .. 95 rows: the wide layers (4096x11008: 172 tiles of 64 x 64 against the rows kernel's 230 workgroups), and -- from 65 rows, i.e. two row panels -- wherever
+    // the tiles fill a round (profiles/r06_panel_65_95.log, panel against the default: 4096^2 1.07 - 1.10x, 2048x4096 1.15x, 8192^2 1.08 - 1.20x, 5120x13824 1.09 - 1.14x;
+    // 160 tiles of 256: 5120^2 0.87x, 13824x5120 0.93x; half a round or less: 2048^2 0.98x, 4096x2048 0.82x, 8192x1024 0.62x -- those keep the rows kernel)
+    if (M < 96 && !(L.N >= 8192 && L.K <= 4096) && (M <= 64 || (double)tiles < 0.8 * (double)(rounds * 256))) return false;
     return true;
 }
 
