@@ -36,7 +36,7 @@ bool panel_ok(const gptq_layer_t& L, int M) {
     if (L.K % 128 || L.N % 32 || L.epilogue != GPTQ_EPI_NONE) return false;
     const int gsh = panel_gsh(L);
     if (gsh == -1) return false;
-    return M >= 64;
+    return M >= 33;                                                // (below a full 64-row panel: the x DMAs past the last row re-read it, gemm_panel_kernel.cuh)
 }
 
 // Time model of a launch, us (fit of profiles/r06_panel_sweep_cold.log: 4-bit g128 fp16, rotating HBM-cold layers): a workgroup owns its CU (128 KiB of LDS), so a
@@ -62,10 +62,11 @@ PanelPlan plan_panel(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
     if (tune && tune->path == 3) {
         const int g = tune->reserved[0];
         if (g / 10 == 2 && g % 10 >= 1 && g % 10 <= (L.bits == 8 ? 3 : 4)) nt = g % 10;
+        if (nt == 4 && M < 64) return pl;                       // a partial single panel: tiles of up to three column blocks (the four-block forms have no register for the clamped x rows)
     }
     if (!nt) {
         double best = 1e30;
-        for (int c = (L.bits == 8 ? 3 : 4); c >= 1; --c) {      // ties go to the wider tile (fewer pulls of x); 8 bits: three register sets of 8 words per column block leave room for 3 blocks
+        for (int c = (L.bits == 8 || M < 64 ? 3 : 4); c >= 1; --c) {      // ties go to the wider tile (fewer pulls of x); 8 bits: three register sets of 8 words per column block leave room for 3 blocks
             const double t = panel_model_us(L, M, c, nullptr);
             if (t < best - 1e-9) { best = t; nt = c; }
         }
@@ -116,6 +117,8 @@ bool panel_pays(const gptq_layer_t& L, int M) {
     // 64 .. 95 rows: the wide layers (4096x11008: 172 tiles of 64 x 64 against the rows kernel's 230 workgroups), and -- from 65 rows, i.e. two row panels -- wherever
     // the tiles fill a round (profiles/r06_panel_65_95.log, panel against the default: 4096^2 1.07 - 1.10x, 2048x4096 1.15x, 8192^2 1.08 - 1.20x, 5120x13824 1.09 - 1.14x;
     // 160 tiles of 256: 5120^2 0.87x, 13824x5120 0.93x; half a round or less: 2048^2 0.98x, 4096x2048 0.82x, 8192x1024 0.62x -- those keep the rows kernel)
+    // 33 .. 63 rows: ONE partial panel where the rows kernel needs two row tiles = two rounds of workgroups -- the wide layers only (profiles/r06_m_sweep*.log,
+    // 4096x11008 at 48 against 64 rows: int4 16.9 / 15.2, act-order 19.6 / 18.5, int3 g32 20.1 / 16.0, int8 g32 23.8 / 19.8 us)
     if (M < 96 && !(L.N >= 8192 && L.K <= 4096) && (M <= 64 || (double)tiles < 0.8 * (double)(rounds * 256))) return false;
     return true;
 }

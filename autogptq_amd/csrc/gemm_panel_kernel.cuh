@@ -62,7 +62,18 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
     const int Lb = xcd_remap(blockIdx.x, gridDim.x);
     const int bm = Lb % p.nbm, bn = Lb / p.nbm;               // consecutive workgroups (one XCD): the same columns (weights), the next rows
     // (bands of 4 row tiles -- an XCD = 4 x 8 instead of 8 x 4 tiles, 20 % less L2 fill: measured within 1 %, tools/session_r06_panel2.sh)
-    const int m0 = min(bm * R, p.M - R), m_lo = bm * R;        // the last row tile is shifted up to end at row M and stores only its own rows
+    const int m0 = max(0, min(bm * R, p.M - R)), m_lo = bm * R;   // the last row tile is shifted up to end at row M and stores only its own rows
+    // Fewer than R rows in all (33 .. 63 rows on wide layers: one partial panel): the x DMAs past the last row re-read it -- DMA i fetches rows 8 min(i, imax) +
+    // min(r8, rlast) -- so nothing outside x is touched; the rows of the tile past M hold a copy of row M - 1 and are not stored.  A full tile: imax = rlast = 7, the
+    // same addresses as before.
+    // (tiles of up to three column blocks: the four-block forms live in all 256 registers and take 64+ rows only -- plan_panel)
+#ifdef GPTQ_PANEL_NO_PART                                      // lab: the kernel as it was before partial panels (same-session A/B of the full-tile path)
+    constexpr bool PART = false;
+#else
+    constexpr bool PART = NT <= 3;
+#endif
+    const int rows_here = PART ? min(R, p.M) : R;
+    const int imax = __builtin_amdgcn_readfirstlane((rows_here - 1) >> 3), rlast = (rows_here - 1) & 7;
     const int n0 = bn * 32 * NT;
 
     const char* wbase[NT];
@@ -86,6 +97,14 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
     for (int par = 0; par < 2; ++par) {
         const unsigned r8 = (unsigned)lane >> 3, kc = (unsigned)lane & 7u;
         xoff[par] = r8 * (unsigned)p.K * 2u + ((kc ^ (4u * par + (r8 >> 1))) * 16u);
+    }
+    unsigned xoff_last[2];
+    if constexpr (PART) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const unsigned r8 = (unsigned)lane >> 3, kc = (unsigned)lane & 7u;
+            xoff_last[par] = min(r8, (unsigned)rlast) * (unsigned)p.K * 2u + ((kc ^ (4u * par + (r8 >> 1))) * 16u);      // (the swizzle follows the LDS row, the address the clamped source row)
+        }
     }
     const char* const xrow0 = (const char*)p.x + (size_t)m0 * p.K * 2;
     const size_t x8 = (size_t)8 * p.K * 2;
@@ -142,8 +161,13 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
         const unsigned l0 = __builtin_amdgcn_readfirstlane(xbuf_lds + (unsigned)(buf * XB));
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
-            const unsigned xo = xoff[i & 1];
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l0 + (unsigned)(i * 1024)), "v"(xo), "s"(xsrc + (size_t)i * x8) : "memory");
+            if constexpr (PART) {
+                const unsigned xo = i >= imax ? xoff_last[i & 1] : xoff[i & 1];
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l0 + (unsigned)(i * 1024)), "v"(xo), "s"(xsrc + (size_t)min(i, imax) * x8) : "memory");
+            } else {
+                const unsigned xo = xoff[i & 1];
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l0 + (unsigned)(i * 1024)), "v"(xo), "s"(xsrc + (size_t)i * x8) : "memory");
+            }
         }
     };
     // the registers pass through a statement behind the wait so that no use of them is scheduled in front of it
@@ -294,7 +318,7 @@ __device__ __forceinline__ void panel_body(const PanelParams& p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + 32 * mt + 8 * rq + 4 * half + i;
-                if (m >= m_lo) ((T*)p.out)[(size_t)m * p.N + n] = DType<T>::from_f32(v[i] + bv);
+                if (m >= m_lo && m < p.M) ((T*)p.out)[(size_t)m * p.N + n] = DType<T>::from_f32(v[i] + bv);
             }
         }
     }

@@ -129,3 +129,40 @@ def test_panel_band_default_plan_every_output(shape, act, dtype):
         want = "wide_sk" if (N == 11008 and M >= 512) else "panel"
         assert plan["kernel"] == want, (K, N, M, plan)
         _every_output(q, Lq, W, M, K, dtype, None, f"{K}x{N} M={M} act={act} {dtype} default plan {plan['kernel']}")
+
+
+# ONE partial panel (33 .. 63 rows): the x DMAs past the last row re-read it (rows 8 min(i, imax) + min(r8, rlast)), the rows past M are computed on a copy of
+# row M - 1 and never stored.  x is allocated EXACTLY M rows inside a guard: the rows behind it hold NaN, and a read past row M - 1 would show as NaN in a stored
+# output only if it were a row < M -- so the check on reads is the address arithmetic itself (every output, one-hot rows) plus rows_here = 33 .. 63 over every residue
+# of 8.  (bits, K, N, group_size, act_order)
+PARTIAL = [(4, 1024, 256, 128, False), (4, 512, 544, 64, True), (3, 1024, 256, 32, False), (8, 768, 160, 64, True), (4, 4096, 128, 128, False)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("case", PARTIAL, ids=[f"int{c[0]}_{c[1]}x{c[2]}g{c[3]}{'act' if c[4] else ''}" for c in PARTIAL])
+def test_panel_partial_single_panel_every_output(case, dtype):
+    bits, K, N, gs, act = case
+    q, Lq, W = _layer(K, N, gs, act, dtype, "auto", K + N + bits + 1, bits=bits)
+    for M in (33, 34, 39, 40, 41, 47, 48, 55, 56, 57, 63):
+        for geom in (21, 22, 23):                                  # (four column blocks: 64+ rows only)
+            t = _tune(geom)
+            plan = _lib.describe_plan(q._layer, M, t)
+            assert plan["kernel"] == "panel" and plan["tiles"] == f"1x{-(-N // (32 * (geom % 10)))}", plan
+            _every_output(q, Lq, W, M, K, dtype, t, f"int{bits} {K}x{N} g{gs} M={M} act={act} {dtype} geom {geom} (partial panel)")
+    assert _lib.describe_plan(q._layer, 32, _tune(21))["kernel"] != "panel"           # 32 rows: not this kernel's (the rows kernel's one 32-row tile)
+    if bits != 8:
+        assert _lib.describe_plan(q._layer, 48, _tune(24))["kernel"] != "panel"       # four column blocks: 64+ rows
+
+
+@pytest.mark.parametrize("bits,gs", [(4, 128), (3, 32), (8, 32)])
+def test_panel_partial_panel_is_the_default_on_the_wide_layer(bits, gs):
+    """33 .. 63 rows on 4096 -> 11008 (172 tiles of 64 x 64 in ONE round where the rows kernel needs two rounds of row tiles): planned, every output; 32 rows and
+    the square layer keep the rows kernel."""
+    q, Lq, W = _layer(4096, 11008, gs, False, torch.float16, "auto", 11, bits=bits)
+    for M in (33, 48, 63):
+        plan = _lib.describe_plan(q._layer, M, None)
+        assert plan["kernel"] == "panel" and plan["tiles"].startswith("1x"), (M, plan)
+        _every_output(q, Lq, W, M, 4096, torch.float16, None, f"int{bits} g{gs} 4096x11008 M={M} default plan")
+    assert _lib.describe_plan(q._layer, 32, None)["kernel"] == "rows"
+    q2, _, _ = _layer(4096, 4096, gs, False, torch.float16, "auto", 12, bits=bits)
+    assert _lib.describe_plan(q2._layer, 48, None)["kernel"] == "rows"

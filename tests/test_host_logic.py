@@ -838,7 +838,7 @@ def test_batched_decode_rows_kernel_rules():
                 for M in (5, 8, 16, 33, 64):
                     for act in (False, True):
                         d, need = plan(bits, gs, K, N, M, act)
-                        if M == 64 and N >= 8192 and K <= 4096:      # round 6: 64 rows of the wide layers = 172+ tiles of the panel kernel (every packing of the copy)
+                        if M >= 33 and N >= 8192 and K <= 4096:      # round 6: 33 .. 64 rows of the wide layers = ONE (partial) row panel, 172+ tiles of the panel kernel (every packing of the copy)
                             assert d["kernel"] == "panel", (bits, gs, K, N, M, act, d)
                             continue
                         assert d["kernel"] == "rows", (bits, gs, K, N, M, act, d)
@@ -1031,9 +1031,12 @@ def test_panel_kernel_is_planned_where_its_tiles_fill_the_chip():
         return _lib.describe_plan(L, M, tune), L
 
     want = {
-        (4096, 4096): {64: "rows", 96: "panel", 128: "panel", 256: "panel", 512: "panel", 767: "panel", 768: "wide_sk", 2048: "wide_sk"},
-        (4096, 11008): {33: "rows", 64: "panel", 128: "panel", 384: "panel", 512: "wide_sk", 2048: "wide_sk"},
-        (11008, 4096): {64: "rows", 128: "rows", 160: "panel", 512: "panel", 640: "wide_sk"},
+        (4096, 4096): {48: "rows", 64: "rows", 65: "panel", 96: "panel", 128: "panel", 256: "panel", 512: "panel", 767: "panel", 768: "wide_sk", 2048: "wide_sk"},      # from 65 rows = two row panels = 256 tiles
+        (4096, 11008): {32: "rows", 33: "panel", 48: "panel", 64: "panel", 128: "panel", 384: "panel", 512: "wide_sk", 2048: "wide_sk"},                              # 33 .. 63 rows: one partial panel (172 tiles) against two rounds of row tiles
+        (11008, 4096): {64: "rows", 80: "rows", 128: "rows", 160: "panel", 512: "panel", 640: "wide_sk"},
+        (5120, 5120): {80: "rows"},                                 # 160 tiles of 256: the rows kernel keeps 65 .. 95 rows (profiles/r06_panel_65_95.log: 0.87x)
+        (2048, 4096): {64: "rows", 80: "panel"},
+        (8192, 8192): {80: "panel"},
         (8192, 1024): {128: "rows", 256: "rows", 512: "panel", 768: "panel"},
         (28672, 1024): {256: "rows", 512: "tiled", 768: "panel"},
         (8192, 28672): {128: "tiled", 256: "tiled", 512: "wide_sk"},
