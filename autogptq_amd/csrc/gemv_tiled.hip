@@ -148,8 +148,13 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         // tools/tiled_sweep.py on MI355X (profiles/r04_tiled_sweep_*.log, us per launch, rotating HBM-cold layers in a hipGraph): one 16-wave workgroup per CU
         // with 2 chunks per wave in flight for the <= 256-strip launches (4096^2 4.43, 11008x4096 7.41; 8 waves x 4: 4.50 / 7.68), 4 waves x 4 chunks where
         // several workgroups share a CU (4096x11008 7.13, q|k|v 7.50, gate|up 11.11; 8 waves x 4: 7.69 / 8.21 / 12.44)
+        // Round 6 (tools/strips_geom_sweep.py, profiles/r06_strips_geom_sweep*.log: the 13B / 30B / 70B shapes): 257 .. 512 workgroups as 8 waves x 2 chunks -- two
+        // co-resident workgroups per CU, ONE round -- where 16-wave workgroups ran a second round for the last few strips (5120^2, 320 strips, M = 1 / 4:
+        // 9.06 / 10.66 -> 6.14 / 7.43 us; 13824x5120 14.7 -> 11.8) and 4-wave ones lost 2 - 12 % (6656^2 9.06 -> 8.00, 7168^2 8.84 -> 8.14, 17920x6656 16.4 -> 15.4,
+        // 4096x6144 5.77 -> 5.54; 512 workgroups: 8192^2 / 4096x8192 / 28672x8192 equal or + 3 %); up to 256 (one per CU) and from 513 on nothing changes
         const int wgs = strips * pl.ksplit;
-        if (wgs <= 320) { waves = 16; u = 2; }
+        if (wgs <= 256) { waves = 16; u = 2; }
+        else if (wgs <= 512) { waves = 8; u = 2; }
         else { waves = 4; u = 4; }
         if (pl.mt > 4) { waves = 8; u = 4; }                                      // 5..8 rows, 4096^2: 6.62 us (4 x 4: 6.82, 16 x 2: 6.92)
         if (pair && waves == 4) waves = 8;                                        // two strips per workgroup: the 4-wave form's work per wave
