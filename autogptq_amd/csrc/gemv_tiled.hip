@@ -159,6 +159,9 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         if (pl.mt > 4) { waves = 8; u = 4; }                                      // 5..8 rows, 4096^2: 6.62 us (4 x 4: 6.82, 16 x 2: 6.92)
         if (pair && waves == 4) waves = 8;                                        // two strips per workgroup: the 4-wave form's work per wave
         if (nstr > 1) { waves = nstr == 4 ? 16 : 8; u = 4; }                      // four (two) strips x four waves x four chunks in flight
+        // 1 - 2 rows, two strips: TWO waves per strip up to K = 7168 (profiles/r06_strips_geom_sweep3.log, 8 -> 4 waves: 4096x22016 11.7 -> 11.5, 5120x27648 19.2 -> 16.9,
+        // 6656x17920 M = 2 18.9 -> 16.9, 4096x16384 9.7 -> 9.3 us; 8192x28672 24.4 -> 25.5: deeper layers keep four)
+        if (nstr == 2 && pl.mt <= 2 && A.K <= 7168) waves = 4;
         const int per = pair ? 2 : nstr;
         while (waves > per && (waves / (2 * per)) * u >= cps) waves /= 2;
     }

@@ -144,8 +144,8 @@ def test_batched_rows_17_to_256_int4_g128_llama7b_shapes(K, N, dtype, act):
     _, q, _, _ = _layer(4, 128, K, N, act, dtype)
     for M in (5, 8, 16, 17, 33, 64, 96, 128, 192, 256):
         plan = _lib.describe_plan(q._layer, M)
-        # round 6: from 96 rows (64 on the 11008-column layer: 172 tiles) the whole-K panel kernel (csrc/gemm_panel.hip) where its 64-row tiles fill the chip
-        want = "panel" if ((M >= 96 and (K <= 8192 or M >= 160)) or (M == 64 and N == 11008)) else "rows"      # (deep layers at few rows stay with the rows kernel)
+        # round 6: from 96 rows (33 on the 11008-column layer: ONE row panel, partial below 64 rows, 172 tiles) the whole-K panel kernel (csrc/gemm_panel.hip) where its 64-row tiles fill the chip
+        want = "panel" if ((M >= 96 and (K <= 8192 or M >= 160)) or (33 <= M <= 64 and N == 11008)) else "rows"      # (deep layers at few rows stay with the rows kernel)
         assert plan["kernel"] == want, (M, plan)
         _check(4, 128, K, N, M, act, dtype)
 
