@@ -494,7 +494,7 @@ size_t gptq_workspace_bytes_multi_ex(const gptq_layer_t* const* layers, int n_la
     for (int i = 0; i < n_layers; ++i)
         if (check_layer(layers[i]) != GPTQ_OK) return 0;
     size_t need = 0;
-    if (want_tiled(layers, n_layers, M, tune) && (multi_preferred(layers, n_layers, M) || (tune && tune->path == 8))) {
+    if (want_tiled(layers, n_layers, M, tune) && (n_layers >= 2 || (tune && tune->path == 8))) {
         const TiledPlan tp = plan_tiled(layers, n_layers, M, tune);
         return tp.partial_bytes ? WS_HEADER_BYTES + tp.partial_bytes : 0;
     }
@@ -538,7 +538,9 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
     // 11.1 for the batched-decode kernel, gate|up 12.9 against 18.9)
     {
         TiledPlan tp;
-        if (want_tiled(layers, n_layers, M, tune, &tp) && (multi_preferred(layers, n_layers, M) || (tune && tune->path == 8)))
+        // (no byte cap on the group for this kernel -- multi_preferred's 128 MB was measured on the round-2 kernels: 70B gate|up, 235 MB, M = 1 / 4 one by one
+        // 48.5 / 57.3 us, ONE decode-copy launch 42.2 / 50.9: profiles/r06_multi_geom_sweep.log)
+        if (want_tiled(layers, n_layers, M, tune, &tp) && (n_layers >= 2 || (tune && tune->path == 8)))
             return tiled_call(layers, n_layers, x, outs, M, wv, stream, tune, &tp);
     }
     if (tune && tune->path == 8) return fail(GPTQ_ERR_UNSUPPORTED, "tuning.path = 8: these layers do not fit one decode-copy launch (1..4 layers of one packing with qweight_tiled, all plain or all act-order, M <= 8)");

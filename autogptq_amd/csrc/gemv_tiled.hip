@@ -95,7 +95,14 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         // measured (tools/multi_strip_ab.py, profiles/r05_multi_strip_ab.log, us, 1 / 2 / 4 strips per workgroup): gate|up M = 4 13.2 / 12.6 / 16.5, M = 8 21.2 / 16.5 / 21.4
         // (the batched-decode kernel on the checkpoint rows: 17.3); q|k|v M = 8 12.8 / 11.2 / 11.3 (10.8); 4096x11008 M = 8 12.2 / 11.0 / 11.0 (10.5); 3..4 rows
         // on launches below ~1000 strips lose 0.7 - 1 us -- two strips per workgroup from 1024 strips up, else one
-        const int want = (tune && tune->path == 8 && tune->reserved[1]) ? tune->reserved[1] : (strips >= 1024 ? 2 : 1);
+        // Round 6 (tools/multi_geom_sweep.py, profiles/r06_multi_geom_sweep.log): also from 768 strips where a strip's chunks do not divide into passes of the
+        // one-strip form (4 waves x 4 chunks = 16 per pass) but do into the two-strip form's (2 waves x 4 = 8): K = 5120 is 40 chunks = 2.5 passes of 16 --
+        // 13B q|k|v (960 strips) M = 1 / 2 / 4: 12.3 / 12.6 / 14.1 -> 10.6 / 11.4 / 13.0 us, 5120x13824 (864) 11.2 -> 10.2; K = 4096 (32 chunks: whole passes either
+        // way) LOSES 7 % with two strips below 1024 (q|k|v 7B, 4096x12288) and keeps one
+        const int cke0 = 4 * tiled_kpl(A.bits), chunks0 = (A.K + cke0 - 1) / cke0;
+        const double waste1 = (double)((chunks0 + 15) / 16 * 16) / chunks0, waste2 = (double)((chunks0 + 7) / 8 * 8) / chunks0;
+        const bool uneven = strips >= 768 && M <= 4 && A.bits == 4 && waste1 - waste2 >= 0.1;
+        const int want = (tune && tune->path == 8 && tune->reserved[1]) ? tune->reserved[1] : ((strips >= 1024 || uneven) ? 2 : 1);
         if (want == 2 || (want == 4 && M >= 3)) {
             nstr = want;
             for (int i = 0; i < n; ++i)
@@ -162,6 +169,10 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         // 1 - 2 rows, two strips: TWO waves per strip up to K = 7168 (profiles/r06_strips_geom_sweep3.log, 8 -> 4 waves: 4096x22016 11.7 -> 11.5, 5120x27648 19.2 -> 16.9,
         // 6656x17920 M = 2 18.9 -> 16.9, 4096x16384 9.7 -> 9.3 us; 8192x28672 24.4 -> 25.5: deeper layers keep four)
         if (nstr == 2 && pl.mt <= 2 && A.K <= 7168) waves = 4;
+        // 3 - 4 rows of a deep layer, one strip per workgroup: the staged x (4 rows x K) is what limits the workgroups of a CU -- 4-wave workgroups of K = 6656+
+        // leave it at 8 waves (two workgroups in 160 KiB); 8-wave workgroups keep 16 (profiles/r06_multi_geom_sweep.log, 4 -> 8 waves: 70B q|k|v 15.7 -> 13.3 us,
+        // 30B q|k|v 23.2 -> 20.4; K = 5120 holds three 4-wave workgroups and LOSES with 8 waves: 14.1 -> 16.0)
+        if (pl.mt == 4 && waves == 4 && !pair && nstr == 1 && ((size_t)160 * 1024 / lds_need(ks, 4)) * 4 < 12) waves = 8;
         const int per = pair ? 2 : nstr;
         while (waves > per && (waves / (2 * per)) * u >= cps) waves /= 2;
     }
