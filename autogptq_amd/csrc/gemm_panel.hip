@@ -96,7 +96,9 @@ PanelPlan plan_panel(const gptq_layer_t& L, int M, const gptq_tuning_t* tune) {
 // 0.85x) -- except on narrow layers, where stream-K has too few 256-column tiles (2048^2, 8192x1024 at 768 rows: 2.0 - 2.5x) -- and on the largest layers.
 bool panel_pays(const gptq_layer_t& L, int M) {
     static const bool lab_off = getenv("GPTQ_LAB_NO_PANEL") != nullptr;      // lab: the planner as it was before this kernel
-    if (lab_off || !panel_ok(L, M) || M > 1024) return false;
+    // (the narrowest layers -- the 70B attention shard at TP = 8: stream-K has four column tiles -- up to 1536 rows: 8192x1024 at 1536 rows 47.6 -> 37.8 us; 2048 columns or
+    // K = 28672 measured equal or worse and keep 1024: profiles/r06_m_sweep_prefill.log)
+    if (lab_off || !panel_ok(L, M) || M > ((L.N <= 1024 && L.K <= 8192) ? 1536 : 1024)) return false;
     const PanelPlan pp = plan_panel(L, M, nullptr);
     if (!pp.ok) return false;
     long tiles = 0;

@@ -35,6 +35,7 @@ CASES = [
     (128, 32, 128, 64, False, "the smallest legal layer: two steps (six idle waves), ONE column block (wider tiles re-read block 0 for their other blocks and store nothing for them)"),
     (128, 4128, 64, 1000, True, "two steps, 129 column blocks, 16 row tiles, act-order"),
     (16384, 64, 128, 100, False, "very deep K: 256 steps, 32 per wave"),
+    (512, 1024, 128, 1500, False, "24 row tiles (the planner takes 8192x1024 up to 1536 rows), shifted last tile"),
 ]
 GEOMS = [21, 22, 23, 24]          # 20 + NT: 64 x 32 / 64 / 96 / 128 tiles
 

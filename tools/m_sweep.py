@@ -30,7 +30,8 @@ for shp in args.shapes.split(","):
         per = bench._time_layers(ls, xs, dev, 6) * 1e6
         plan = bench._plan_dict(ls, K, N, M)
         flag = "   <-- faster than the previous (smaller) row count" if prev is not None and per < prev * 0.97 else ""
-        print(f"   M={M:5d}: {per:8.2f} us   {plan.get('kernel', '?'):9s} tiles={plan.get('tiles', plan.get('strips', ''))} waves={plan.get('waves')} u={plan.get('u')}{flag}", flush=True)
+        tf = 2.0 * M * K * N / per / 1e6
+        print(f"   M={M:5d}: {per:8.2f} us  {tf:7.1f} TF  {plan.get('kernel', '?'):9s} tiles={plan.get('tiles', plan.get('strips', ''))} waves={plan.get('waves')} u={plan.get('u')}{flag}", flush=True)
         prev = per
     del ls
     torch.cuda.empty_cache()
