@@ -489,6 +489,21 @@ static bool want_mid_multi(const gptq_layer_t* const* layers, int n, int M, cons
     return mp.ok && (mp.pays || forced);
 }
 
+// 33+ rows of a group whose weights are mostly (>= 3/4) in layers the panel kernel takes with well-filled rounds: the layers run ONE BY ONE -- the multi-layer
+// forms of the rows / mid / stream64 kernels were fitted before that kernel existed and lose to it (tools/multi_rows_sweep.py, profiles/r06_multi_rows_sweep.log, group
+// call -> one by one: 8B gate|up at 64 rows 45.7 -> 32.8 us, 70B q|k|v at 128 rows 59.5 -> 46.9, 70B TP8 gate|up at 128 rows 42.0 -> 37.9; 13B q|k|v at 128 rows --
+// 160 tiles of 256 per layer -- keeps its group launch: 45.0 against 52.8)
+static bool separate_panels_pay(const gptq_layer_t* const* layers, int n, int M) {
+    if (n < 2 || M < 33) return false;
+    size_t all = 0, paneled = 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t kn = (size_t)layers[i]->K * layers[i]->N;
+        all += kn;
+        if (layers[i]->epilogue == GPTQ_EPI_NONE && want_gemm(layers[i], M, nullptr) && panel_pays_filled(*layers[i], M)) paneled += kn;
+    }
+    return paneled * 4 >= all * 3;
+}
+
 size_t gptq_workspace_bytes_multi_ex(const gptq_layer_t* const* layers, int n_layers, int M, const gptq_tuning_t* tune) {
     if (!layers || n_layers <= 0 || M <= 0) return 0;
     for (int i = 0; i < n_layers; ++i)
@@ -498,9 +513,14 @@ size_t gptq_workspace_bytes_multi_ex(const gptq_layer_t* const* layers, int n_la
         const TiledPlan tp = plan_tiled(layers, n_layers, M, tune);
         return tp.partial_bytes ? WS_HEADER_BYTES + tp.partial_bytes : 0;
     }
-    if (n_layers >= 2 && ((tune && tune->path == 3 && tune->reserved[3] == GPTQ_LAB_VARIANT_ROWS_ON && rows_multi_ok(layers, n_layers, M)) || (!tune && rows_multi_pays(layers, n_layers, M))) &&
+    const bool separate = !tune && separate_panels_pay(layers, n_layers, M);
+    if (!separate && n_layers >= 2 && ((tune && tune->path == 3 && tune->reserved[3] == GPTQ_LAB_VARIANT_ROWS_ON && rows_multi_ok(layers, n_layers, M)) || (!tune && rows_multi_pays(layers, n_layers, M))) &&
         plan_rows_multi(layers, n_layers, M, nullptr).ok)
         return layers[0]->g_idx ? WS_HEADER_BYTES + xperm16_bytes(layers[0], M) : 0;      // gemm_rows.hip over all layers: nothing but the permuted x of act-order layers
+    if (separate) {
+        for (int i = 0; i < n_layers; ++i) need = std::max(need, gptq_workspace_bytes_ex(layers[i], M, nullptr));
+        return need;
+    }
     if (want_mid_multi(layers, n_layers, M, tune)) {
         const MidPlan mp = plan_mid(layers, n_layers, M, tune);
         return mp.partial_bytes ? WS_HEADER_BYTES + mp.partial_bytes : 0;
@@ -547,7 +567,8 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
     // 5 .. 128 rows on layers that carry the decode copy: the exchange-free kernel over the strip groups of all layers (gemm_rows.hip); act-order layers of
     // ONE order (the same perm pointer: QuantLinear.share_act_order) read one permuted x
     const bool rows_forced = tune && tune->path == 3 && tune->reserved[3] == GPTQ_LAB_VARIANT_ROWS_ON && rows_multi_ok(layers, n_layers, M);      // lab knob 50
-    if (n_layers >= 2 && (rows_forced || (!tune && rows_multi_pays(layers, n_layers, M)))) {
+    const bool separate = !tune && separate_panels_pay(layers, n_layers, M);
+    if (n_layers >= 2 && (rows_forced || (!tune && !separate && rows_multi_pays(layers, n_layers, M)))) {
         const RowsPlan rp = plan_rows_multi(layers, n_layers, M, nullptr);
         if (rp.ok) {
             const void* xin = x;
@@ -563,7 +584,7 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
             return GPTQ_OK;
         }
     }
-    if (want_mid_multi(layers, n_layers, M, tune)) {
+    if (!separate && want_mid_multi(layers, n_layers, M, tune)) {
         const MidPlan mp = plan_mid(layers, n_layers, M, tune);
         if (mp.partial_bytes > 0 && wv.body_bytes < mp.partial_bytes)
             return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + mp.partial_bytes, wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0);
@@ -571,7 +592,7 @@ static int forward_multi_core(const gptq_layer_t* const* layers, int n_layers, c
         if (e != hipSuccess) return hip_fail(e, "gptq 17..128-row launch (needs > 64 KiB of LDS: was gptq_init() called on this device?)");
         return GPTQ_OK;
     }
-    if (want_stream64_multi(layers, n_layers, M, tune)) {
+    if (!separate && want_stream64_multi(layers, n_layers, M, tune)) {
         const Stream64Plan sp = plan_stream64(layers, n_layers, M, tune);
         if (sp.partial_bytes > 0 && wv.body_bytes < sp.partial_bytes)
             return fail(GPTQ_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", WS_HEADER_BYTES + sp.partial_bytes, wv.header ? WS_HEADER_BYTES + wv.body_bytes : (size_t)0);

@@ -125,6 +125,16 @@ bool panel_pays(const gptq_layer_t& L, int M) {
     return true;
 }
 
+// The planner's own choice AND tiles that fill their rounds (>= 0.8): what a group call compares its one-launch kernels with (capi.hip, separate_panels_pay)
+bool panel_pays_filled(const gptq_layer_t& L, int M) {
+    if (!panel_pays(L, M)) return false;
+    const PanelPlan pp = plan_panel(L, M, nullptr);
+    long tiles = 0;
+    panel_model_us(L, M, pp.nt, &tiles);
+    const long rounds = (tiles + 255) / 256;
+    return (double)tiles >= 0.8 * (double)(rounds * 256);
+}
+
 template <typename T, int BITS, int NT, bool G32>
 static hipError_t panel_grant_one() {
     return hipFuncSetAttribute((const void*)panel::gemm_panel_kernel<T, BITS, NT, G32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -73,6 +73,7 @@ struct PanelPlan {
 };
 bool panel_ok(const gptq_layer_t& L, int M);
 bool panel_pays(const gptq_layer_t& L, int M);
+bool panel_pays_filled(const gptq_layer_t& L, int M);
 PanelPlan plan_panel(const gptq_layer_t& L, int M, const gptq_tuning_t* tune);
 hipError_t launch_gemm_panel(const gptq_layer_t& L, const PanelPlan& pl, const void* x, void* out, int M, hipStream_t st);
 hipError_t init_gemm_panel_device();
