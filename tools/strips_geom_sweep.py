@@ -14,6 +14,9 @@ from autogptq_amd import _lib  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default="5120x5120,13824x5120,5120x13824,8192x8192,6656x6656,17920x6656,6656x17920")
 ap.add_argument("--ms", default="1,2,4")
+ap.add_argument("--act", action="store_true")
+ap.add_argument("--bits", type=int, default=4)
+ap.add_argument("--gs", type=int, default=128)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 
@@ -47,8 +50,8 @@ def time_layers(ls, x, t, reps=6):
 
 for shp in args.shapes.split(","):
     K, N = (int(v) for v in shp.split("x"))
-    n = max(4, -(-(320 << 20) // (K * N // 2)))
-    ls = [("b", K, N, bench.make_layer(K, N, dev, seed=9300 + i)) for i in range(n)]
+    n = max(4, -(-(320 << 20) // (K * N * args.bits // 8)))
+    ls = [("b", K, N, bench.make_layer(K, N, dev, bits=args.bits, gs=args.gs, act_order=args.act, seed=9300 + i)) for i in range(n)]
     for M in (int(m) for m in args.ms.split(",")):
         x = (torch.rand(M, K, device=dev) - 0.5).half()
         base, _ = time_layers(ls, x, None)
