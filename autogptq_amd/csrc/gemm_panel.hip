@@ -36,7 +36,7 @@ bool panel_ok(const gptq_layer_t& L, int M) {
     if (L.K % 128 || L.N % 32 || L.epilogue != GPTQ_EPI_NONE) return false;
     const int gsh = panel_gsh(L);
     if (gsh == -1) return false;
-    return M >= 33;                                                // (below a full 64-row panel: the x DMAs past the last row re-read it, gemm_panel_kernel.cuh)
+    return M >= 17;                                                // (below a full 64-row panel: the x DMAs past the last row re-read it, gemm_panel_kernel.cuh)
 }
 
 // Time model of a launch, us (fit of profiles/r06_panel_sweep_cold.log: 4-bit g128 fp16, rotating HBM-cold layers): a workgroup owns its CU (128 KiB of LDS), so a
@@ -114,6 +114,12 @@ bool panel_pays(const gptq_layer_t& L, int M) {
         const double fixed = L.bits == 8 ? 27.0 : ((L.bits == 3 || L.group_size == 32) ? 24.0 : 20.0);
         return est < fixed + gf / 1.2;
     }
+    // ONE (partial) row panel, 17 .. 64 rows, on the WIDE layers of every family (N >= 8192, K <= 8192; tools/panel_ab.py, profiles/r06_panel_big.log, default -> panel at
+    // 40 / 64 rows): 5120x13824 28.3 / 29.9 -> 18.2 / 20.5 us, 6656x17920 57.0 / 58.2 -> 26.9 / 29.0, 8192x28672 72.5 / 73.9 -> 48.2 / 42.6 (the round-2 tiled kernel
+    // served those: the rows kernel stops at 64 Mi weights), 8192^2 21.1 / 21.9 -> 18.9 / 22.5; 17 .. 32 rows only where the rows kernel does not serve the layer
+    // (4096x11008 at 32 rows: rows 13.5, one partial panel 13.4)
+    if (M <= 64 && L.N >= 8192 && L.K <= 8192) return M >= 33 || !rows_pays(L, M);
+    if (M < 33) return false;
     if (kn > ((size_t)128 << 20) || L.K > 16384) return false;
     if (M < 160 && L.K > 8192) return false;
     // 64 .. 95 rows: the wide layers (4096x11008: 172 tiles of 64 x 64 against the rows kernel's 230 workgroups), and -- from 65 rows, i.e. two row panels -- wherever

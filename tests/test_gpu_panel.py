@@ -144,13 +144,13 @@ PARTIAL = [(4, 1024, 256, 128, False), (4, 512, 544, 64, True), (3, 1024, 256, 3
 def test_panel_partial_single_panel_every_output(case, dtype):
     bits, K, N, gs, act = case
     q, Lq, W = _layer(K, N, gs, act, dtype, "auto", K + N + bits + 1, bits=bits)
-    for M in (33, 34, 39, 40, 41, 47, 48, 55, 56, 57, 63):
+    for M in (17, 24, 25, 32, 33, 34, 39, 40, 41, 47, 48, 55, 56, 57, 63):
         for geom in (21, 22, 23):                                  # (four column blocks: 64+ rows only)
             t = _tune(geom)
             plan = _lib.describe_plan(q._layer, M, t)
             assert plan["kernel"] == "panel" and plan["tiles"] == f"1x{-(-N // (32 * (geom % 10)))}", plan
             _every_output(q, Lq, W, M, K, dtype, t, f"int{bits} {K}x{N} g{gs} M={M} act={act} {dtype} geom {geom} (partial panel)")
-    assert _lib.describe_plan(q._layer, 32, _tune(21))["kernel"] != "panel"           # 32 rows: not this kernel's (the rows kernel's one 32-row tile)
+    assert _lib.describe_plan(q._layer, 16, _tune(21))["kernel"] != "panel"           # 16 rows: not this kernel's (one 16-row tile of the rows kernel)
     if bits != 8:
         assert _lib.describe_plan(q._layer, 48, _tune(24))["kernel"] != "panel"       # four column blocks: 64+ rows
 

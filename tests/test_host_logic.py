@@ -838,7 +838,7 @@ def test_batched_decode_rows_kernel_rules():
                 for M in (5, 8, 16, 33, 64):
                     for act in (False, True):
                         d, need = plan(bits, gs, K, N, M, act)
-                        if M >= 33 and N >= 8192 and K <= 4096:      # round 6: 33 .. 64 rows of the wide layers = ONE (partial) row panel, 172+ tiles of the panel kernel (every packing of the copy)
+                        if M >= 33 and N >= 8192 and K <= 8192:      # round 6: 33 .. 64 rows of the wide layers = ONE (partial) row panel, 172+ tiles of the panel kernel (every packing of the copy)
                             assert d["kernel"] == "panel", (bits, gs, K, N, M, act, d)
                             continue
                         assert d["kernel"] == "rows", (bits, gs, K, N, M, act, d)
