@@ -9,6 +9,7 @@ name + grid so the three Llama-7B layer shapes of bench.py are told apart:
   grid.x (threads) / workgroup = column strips  ->  N = strips * 16 for the 16-column-strip decode kernels.
 """
 import argparse
+import re
 import json
 import os
 import sqlite3
@@ -57,7 +58,10 @@ def main():
         if "gemv_tiled_kernel" in name:
             # decode-copy kernel (round 4): one 16-column strip per workgroup -> N = strips * 16 (a multi-layer launch: the summed width); the staged x
             # (K * 2 bytes of LDS) tells the 4096-deep layers from the 11008-deep one
-            ent["N"], ent["M"] = blocks * 16, args.m
+            # (two / four strips per workgroup -- x mode 6 / 5 -- and the [gate | up] pair form -- 4: a workgroup covers 32 / 64 columns)
+            xm = re.search(r"gemv_tiled_kernel<\s*\d+,\s*\d+,\s*\d+,\s*\w+,\s*\d+,\s*(\d+)", name)
+            tiled_mult = {"6": 2, "5": 4, "4": 2}.get(xm.group(1), 1) if xm else 1
+            ent["N"], ent["M"] = blocks * 16 * tiled_mult, args.m
             ent["K"] = 11008 if lds and lds > 20000 else 4096
         if "gemv_q4_stream_kernel" in name:
             # streamed GEMV: (workgroups, threads) -> launch; multi-layer launches are labelled with the summed width
@@ -66,7 +70,7 @@ def main():
                 ent["K"], ent["N"] = geo[(blocks, wg)]
                 ent["M"] = args.m
         for K, N in shapes:
-            if blocks * 16 == N and "gemv" in name and "stream" not in name:
+            if blocks * 16 == N and "gemv" in name and "stream" not in name and not ("gemv_tiled_kernel" in name and ent["N"] != N):
                 ent["N"], ent["M"] = N, args.m
                 cands = [k for k, n2 in shapes if n2 == N]
                 ent["K_candidates"] = cands
