@@ -836,8 +836,9 @@ MidPlan plan_mid(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_
         pl.ok = true;
         return pl;
     }
+    // (late round 6, tools/mid_band_sweep.py: beyond 128 Mi weights the 128 x 256-tile kernel wins above 64 rows -- 28672x8192 at 96 rows 85.2 against 69.3 us)
     pl.pays = M >= 17 && (M <= 128 || pl.row_blocks > 1) && !(M > 64 && strips >= 160) && !(M > 32 && nmax >= 12288) && !(M > 32 && strips < 32) &&
-              !(M > 96 && strips != 64 && pl.row_blocks == 1);
+              !(M > 96 && strips != 64 && pl.row_blocks == 1) && !(M > 64 && (size_t)A.K * nmax > ((size_t)128 << 20));
     pl.ok = true;
     return pl;
 }

@@ -120,7 +120,10 @@ bool panel_pays(const gptq_layer_t& L, int M) {
     // (4096x11008 at 32 rows: rows 13.5, one partial panel 13.4)
     if (M <= 64 && L.N >= 8192 && L.K <= 8192) return M >= 33 || !rows_pays(L, M);
     if (M < 33) return false;
-    if (kn > ((size_t)128 << 20) || L.K > 16384) return false;
+    // deep layers at 160 .. 255 rows: also beyond 128 Mi weights / K = 16384 (tools/mid_band_sweep.py at 192 rows, 128 x 256 tiles -> this kernel: 17920x6656 75.9 -> 58.9 us,
+    // 28672x8192 120.7 -> 107.9; 256 rows equal; the WIDE 8192x28672 keeps the tiled / stream-K kernels: 256 rows 150 against 118)
+    const bool deep_mid = L.K > 8192 && L.N <= 8192 && M >= 160 && M < 256 && kn <= ((size_t)256 << 20) && L.K <= 32768;
+    if ((kn > ((size_t)128 << 20) || L.K > 16384) && !deep_mid) return false;
     if (M < 160 && L.K > 8192) return false;
     // 64 .. 95 rows: the wide layers (4096x11008: 172 tiles of 64 x 64 against the rows kernel's 230 workgroups), and -- from 65 rows, i.e. two row panels -- wherever
     // the tiles fill a round (profiles/r06_panel_65_95.log, panel against the default: 4096^2 1.07 - 1.10x, 2048x4096 1.15x, 8192^2 1.08 - 1.20x, 5120x13824 1.09 - 1.14x;

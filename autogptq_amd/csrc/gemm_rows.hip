@@ -57,8 +57,17 @@ bool rows_pays(const gptq_layer_t& L, int M) {
     static const bool lab_off = getenv("GPTQ_LAB_NO_ROWS") != nullptr;      // lab (tools/session_r05_rows2.sh): the planner as it was before this kernel
     if (lab_off || !rows_ok(L, M)) return false;
     const size_t kn = (size_t)L.K * L.N;
-    if (M < 5 || M > 512 || L.K < 1024 || L.N < 1024 || kn > ((size_t)64 << 20)) return false;
+    if (M < 5 || M > 512 || L.K < 1024 || L.N < 1024) return false;
+    // DEEP layers (K > 8192: the down projections of the 13B / 30B / 70B / 8B families, which the panel kernel leaves alone below 160 rows), late round 6
+    // (tools/mid_band_sweep.py, profiles/r06_mid_band_sweep.log, default -> this kernel, us): beyond 64 Mi weights 33 .. 64 rows (28672x8192 at 48 / 64 rows 77.3 / 73.7 ->
+    // 56.0 / 56.8, 17920x6656 40.1 / 45.3 -> 35.3 / 36.6, 13824x5120 25.5 / 28.4 -> 24.4 / 25.5) and up to 128 rows up to 128 Mi weights (17920x6656 at 96 rows 58.4 ->
+    // 45.5, 13824x5120 at 96 / 128 rows 35.9 / 42.3 -> 28.7 / 38.6, 14336x4096 31.3 / 35.2 -> 28.7 / 29.2); at 8 .. 32 rows the largest layers keep the older kernels (equal
+    // or 0.7 - 0.9x: round 5's sweep), and so do the WIDE ones at any row count (8192x28672 at 48 rows: 72 against the panel kernel's 51)
+    const bool deep = L.K > 8192;
+    // (17920x6656 at 128 rows: 65.8 against the tiled kernel's 51.2 -- up to 96 rows there, 128 only up to 80 Mi weights)
+    if (kn > ((size_t)64 << 20)) return deep && M >= 33 && (M <= 64 || (M <= 96 && kn <= ((size_t)128 << 20)) || (M <= 128 && kn <= ((size_t)80 << 20)));
     if (M <= 64) return true;
+    if (deep && M <= 128 && L.N <= 8192) return true;
     if (kn > (size_t)46000000 || L.N > 8192) return false;
     // 129 .. 256 rows (short prompts): the 64-row form (4 bits: gemm_rows64_kernel, half the dequant replication) -- 4096^2 M = 160 / 192 / 256 17.0 / 18.5 / 18.8 ->
     // 14.9 - 16.6 us, 11008x4096 38.5 / 38.7 / 39.5 -> 29.4 - 34.2; 4096x11008 1.0x, 320+ rows 0.6 - 1.06x (the tiled / stream-K prefill kernels keep those)

@@ -150,6 +150,20 @@ def test_batched_rows_17_to_256_int4_g128_llama7b_shapes(K, N, dtype, act):
         _check(4, 128, K, N, M, act, dtype)
 
 
+@pytest.mark.parametrize("act", [False, True], ids=["seq", "act"])
+@pytest.mark.parametrize("K,N,plans", [(13824, 5120, {24: "mid", 48: "rows", 96: "rows", 128: "rows", 192: "panel"}), (17920, 6656, {64: "rows", 96: "rows", 192: "panel"})])
+def test_deep_down_projections_13b_30b_mid_band(K, N, plans, act):
+    """Late round 6 (tools/mid_band_sweep.py): the DEEP layers of the larger families (K > 8192: Llama-13B / 30B down projections) at 33 ... 255 rows -- the exchange-free
+    rows kernel beyond its 64 Mi-weight limit (33 .. 128 rows), the panel kernel beyond K = 16384 at 160 .. 255 rows; plan asserted, every output against the fp64
+    oracle product, one-hot rows exact, bit-reproducible."""
+    from autogptq_amd import _lib
+    _, q, _, _ = _layer(4, 128, K, N, act, torch.float16)
+    for M, want in plans.items():
+        plan = _lib.describe_plan(q._layer, M)
+        assert plan["kernel"] == want, (K, N, M, plan)
+        _check(4, 128, K, N, M, act, torch.float16)
+
+
 def test_north_star_m4096_4096x4096():
     """north_star's second target: batch x seq = 4096 rows on 4096 -> 4096, int4 g128."""
     _check(4, 128, 4096, 4096, 4096, False, torch.float16)
