@@ -65,6 +65,9 @@ bool rows_pays(const gptq_layer_t& L, int M) {
     // or 0.7 - 0.9x: round 5's sweep), and so do the WIDE ones at any row count (8192x28672 at 48 rows: 72 against the panel kernel's 51)
     const bool deep = L.K > 8192;
     // (17920x6656 at 128 rows: 65.8 against the tiled kernel's 51.2 -- up to 96 rows there, 128 only up to 80 Mi weights)
+    // the WIDE largest layers (N >= 8192) at 17 .. 32 rows: 8192x28672 at 24 / 32 rows 41.8 / 42.7 us against 46.8 / 47.7 (one partial row panel) and 45.4 - 50.6 (the older
+    // kernels), 6656x17920 24.1 / 24.9 against 26.6 / 25.7; from 33 rows the panel kernel has them
+    if (kn > ((size_t)64 << 20) && !deep) return L.N >= 8192 && M >= 17 && M <= 32;
     if (kn > ((size_t)64 << 20)) return deep && M >= 33 && (M <= 64 || (M <= 96 && kn <= ((size_t)128 << 20)) || (M <= 128 && kn <= ((size_t)80 << 20)));
     if (M <= 64) return true;
     if (deep && M <= 128 && L.N <= 8192) return true;
