@@ -130,7 +130,8 @@ bool panel_pays(const gptq_layer_t& L, int M) {
     // 160 tiles of 256: 5120^2 0.87x, 13824x5120 0.93x; half a round or less: 2048^2 0.98x, 4096x2048 0.82x, 8192x1024 0.62x -- those keep the rows kernel)
     // 33 .. 63 rows: ONE partial panel where the rows kernel needs two row tiles = two rounds of workgroups -- the wide layers only (profiles/r06_m_sweep*.log,
     // 4096x11008 at 48 against 64 rows: int4 16.9 / 15.2, act-order 19.6 / 18.5, int3 g32 20.1 / 16.0, int8 g32 23.8 / 19.8 us)
-    if (M < 96 && !(L.N >= 8192 && L.K <= 4096) && (M <= 64 || (double)tiles < 0.8 * (double)(rounds * 256))) return false;
+    if (M <= 96 && !(L.N >= 8192 && L.K <= 4096) && (M <= 64 || (double)tiles < 0.8 * (double)(rounds * 256))) return false;      // (96 rows included: 5120^2 17.5 against the rows kernel's 14.7)
+    if (M <= 96 && L.K >= 8192 && rows_pays(L, M)) return false;          // K = 8192 where the rows kernel is the alternative: 8192x3584 at 96 rows 18.7 against 16.1 (8192^2: rows stop at 64 -- this kernel)
     return true;
 }
 

@@ -63,11 +63,14 @@ bool rows_pays(const gptq_layer_t& L, int M) {
     // 56.0 / 56.8, 17920x6656 40.1 / 45.3 -> 35.3 / 36.6, 13824x5120 25.5 / 28.4 -> 24.4 / 25.5) and up to 128 rows up to 128 Mi weights (17920x6656 at 96 rows 58.4 ->
     // 45.5, 13824x5120 at 96 / 128 rows 35.9 / 42.3 -> 28.7 / 38.6, 14336x4096 31.3 / 35.2 -> 28.7 / 29.2); at 8 .. 32 rows the largest layers keep the older kernels (equal
     // or 0.7 - 0.9x: round 5's sweep), and so do the WIDE ones at any row count (8192x28672 at 48 rows: 72 against the panel kernel's 51)
+    // the widest K <= 4096 layers (N >= 14336: the 8B gate / up projections, fused [gate | up] layers) at up to 32 rows (tools/mid_band_sweep.py, r06_mid_band_sweep3.log):
+    // 5 .. 16 rows 12.3 - 13.6 us here against 10.7 - 11.1 on the 64-column-strip kernel, 17 .. 32 rows 15.5 - 17.0 against 13.7 - 14.8 as one partial row panel
+    if (L.N >= 14336 && L.K <= 4096 && M <= 32) return false;
     const bool deep = L.K > 8192;
     // (17920x6656 at 128 rows: 65.8 against the tiled kernel's 51.2 -- up to 96 rows there, 128 only up to 80 Mi weights)
     // the WIDE largest layers (N >= 8192) at 17 .. 32 rows: 8192x28672 at 24 / 32 rows 41.8 / 42.7 us against 46.8 / 47.7 (one partial row panel) and 45.4 - 50.6 (the older
     // kernels), 6656x17920 24.1 / 24.9 against 26.6 / 25.7; from 33 rows the panel kernel has them
-    if (kn > ((size_t)64 << 20) && !deep) return L.N >= 8192 && M >= 17 && M <= 32;
+    if (kn > ((size_t)64 << 20) && !deep) return L.N >= 8192 && L.K > 4096 && M >= 17 && M <= 32;
     if (kn > ((size_t)64 << 20)) return deep && M >= 33 && (M <= 64 || (M <= 96 && kn <= ((size_t)128 << 20)) || (M <= 128 && kn <= ((size_t)80 << 20)));
     if (M <= 64) return true;
     if (deep && M <= 128 && L.N <= 8192) return true;
