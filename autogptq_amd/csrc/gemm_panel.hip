@@ -124,7 +124,9 @@ bool panel_pays(const gptq_layer_t& L, int M) {
     // 28672x8192 120.7 -> 107.9; 256 rows equal; the WIDE 8192x28672 keeps the tiled / stream-K kernels: 256 rows 150 against 118)
     const bool deep_mid = L.K > 8192 && L.N <= 8192 && M >= 160 && M < 256 && kn <= ((size_t)256 << 20) && L.K <= 32768;
     if ((kn > ((size_t)128 << 20) || L.K > 16384) && !deep_mid) return false;
-    if (M < 160 && L.K > 8192) return false;
+    // (deep layers of 64 .. 80 Mi weights at 128 .. 159 rows: 13824x5120 at 128 rows int4 / int3 g32 / int8 g32 37.3 / 37.9 / 47.5 us against 36.4 / 45.9 / 57.0 on the rows
+    // kernel and 42.3 on the 128 x 256-tile one)
+    if (M < 160 && L.K > 8192 && !(M >= 128 && kn > ((size_t)64 << 20) && kn <= ((size_t)80 << 20))) return false;
     // 64 .. 95 rows: the wide layers (4096x11008: 172 tiles of 64 x 64 against the rows kernel's 230 workgroups), and -- from 65 rows, i.e. two row panels -- wherever
     // the tiles fill a round (profiles/r06_panel_65_95.log, panel against the default: 4096^2 1.07 - 1.10x, 2048x4096 1.15x, 8192^2 1.08 - 1.20x, 5120x13824 1.09 - 1.14x;
     // 160 tiles of 256: 5120^2 0.87x, 13824x5120 0.93x; half a round or less: 2048^2 0.98x, 4096x2048 0.82x, 8192x1024 0.62x -- those keep the rows kernel)

@@ -66,12 +66,16 @@ bool rows_pays(const gptq_layer_t& L, int M) {
     // the widest K <= 4096 layers (N >= 14336: the 8B gate / up projections, fused [gate | up] layers) at up to 32 rows (tools/mid_band_sweep.py, r06_mid_band_sweep3.log):
     // 5 .. 16 rows 12.3 - 13.6 us here against 10.7 - 11.1 on the 64-column-strip kernel, 17 .. 32 rows 15.5 - 17.0 against 13.7 - 14.8 as one partial row panel
     if (L.N >= 14336 && L.K <= 4096 && M <= 32) return false;
+    // act-order layers of K >= 8192 at up to 16 rows: the permute pre-pass + this kernel 17.6 / 18.6 us (8192^2 at 8 / 16 rows) against 15.0 / 16.1 on the 64-column-strip kernel
+    if (L.g_idx && L.K >= 8192 && M <= 16 && L.bits == 4) return false;
+    // 3-bit layers beyond 64 Mi weights at up to 32 rows (no 64-column-strip kernel for them): 5120x13824 at 8 / 16 rows 18.0 / 18.0 -> 14.9 / 15.6 us, 13824x5120 32.7 / 19.5 -> 16.8 / 18.1
+    if (L.bits == 3 && kn > ((size_t)64 << 20) && kn <= ((size_t)128 << 20) && M <= 32) return true;
     const bool deep = L.K > 8192;
     // (17920x6656 at 128 rows: 65.8 against the tiled kernel's 51.2 -- up to 96 rows there, 128 only up to 80 Mi weights)
     // the WIDE largest layers (N >= 8192) at 17 .. 32 rows: 8192x28672 at 24 / 32 rows 41.8 / 42.7 us against 46.8 / 47.7 (one partial row panel) and 45.4 - 50.6 (the older
     // kernels), 6656x17920 24.1 / 24.9 against 26.6 / 25.7; from 33 rows the panel kernel has them
     if (kn > ((size_t)64 << 20) && !deep) return L.N >= 8192 && L.K > 4096 && M >= 17 && M <= 32;
-    if (kn > ((size_t)64 << 20)) return deep && M >= 33 && (M <= 64 || (M <= 96 && kn <= ((size_t)128 << 20)) || (M <= 128 && kn <= ((size_t)80 << 20)));
+    if (kn > ((size_t)64 << 20)) return deep && M >= 33 && (M <= 64 || (M <= 96 && kn <= ((size_t)128 << 20)));      // (13824x5120 at 128 rows: the panel kernel, every packing)
     if (M <= 64) return true;
     if (deep && M <= 128 && L.N <= 8192) return true;
     if (kn > (size_t)46000000 || L.N > 8192) return false;

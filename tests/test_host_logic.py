@@ -841,6 +841,9 @@ def test_batched_decode_rows_kernel_rules():
                         if M >= 33 and N >= 8192 and K <= 8192:      # round 6: 33 .. 64 rows of the wide layers = ONE (partial) row panel, 172+ tiles of the panel kernel (every packing of the copy)
                             assert d["kernel"] == "panel", (bits, gs, K, N, M, act, d)
                             continue
+                        if act and K >= 8192 and M <= 16 and bits == 4:      # late round 6: act-order layers of K >= 8192 at up to 16 rows keep the 64-column-strip kernel (the permute pre-pass costs more than it saves)
+                            assert d["kernel"] != "rows", (bits, gs, K, N, M, act, d)
+                            continue
                         assert d["kernel"] == "rows", (bits, gs, K, N, M, act, d)
                         rb, s = int(d["mt"]), int(d["tiles"].split("x")[1])
                         assert rb in (1, 2) and int(d["tiles"].split("x")[0]) == -(-M // (16 * rb)), d      # (the 64-row form only from 129 rows)

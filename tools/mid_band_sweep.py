@@ -14,6 +14,9 @@ from autogptq_amd import _lib  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default="28672x8192,17920x6656,13824x5120,14336x4096,11008x4096,8192x28672,6656x17920,5120x13824")
 ap.add_argument("--ms", default="24,32,48,64,96,128,192,256")
+ap.add_argument("--act", action="store_true")
+ap.add_argument("--bits", type=int, default=4)
+ap.add_argument("--gs", type=int, default=128)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 L = _lib.LAB
@@ -48,8 +51,8 @@ def timeit(ls, x, t):
 
 for shp in args.shapes.split(","):
     K, N = (int(v) for v in shp.split("x"))
-    n = max(4, -(-(320 << 20) // (K * N // 2)))
-    ls = [("b", K, N, bench.make_layer(K, N, dev, seed=9950 + i)) for i in range(n)]
+    n = max(4, -(-(320 << 20) // (K * N * args.bits // 8)))
+    ls = [("b", K, N, bench.make_layer(K, N, dev, bits=args.bits, gs=args.gs, act_order=args.act, seed=9950 + i)) for i in range(n)]
     for M in (int(m) for m in args.ms.split(",")):
         x = (torch.rand(M, K, device=dev) - 0.5).half()
         timeit(ls, x, None)
