@@ -58,7 +58,13 @@ bool wide_sk_pays(const gptq_layer_t& L, int M) {
     // below: 384 rows 1.18 - 2.09x on the two large shapes (0.97 - 1.05x on 4096^2), 256 rows 1.24 - 1.51x on 4096 -> 11008 only (0.71 - 0.94x elsewhere)
     if (L.bits != 4 || wide_sk_group_mode(L.group_size) == 2)
         return M >= 512 || (M >= 384 && (size_t)L.K * L.N >= ((size_t)32 << 20)) || (M >= 256 && L.N >= 2 * L.K && (size_t)L.K * L.N >= ((size_t)32 << 20));
-    return M >= 768 || (M >= 512 && (size_t)L.K * L.N >= ((size_t)32 << 20));
+    // late round 6 (tools/mid_band_sweep.py over the larger families, profiles/r06_mid_band_sweep4.log, default -> this kernel at 384 rows): wide / square layers of 56+ Mi
+    // weights 5120x13824 72.6 -> 62.3 us, 8192^2 71.3 -> 61.6, 4096x14336 61.4 -> 54.0, 6656x17920 116.3 -> 95.8; the deep ones lose there (13824x5120 58.5 against 70.1,
+    // 14336x4096 54.7 / 62.9) except the largest from 320 rows (17920x6656 114.6 -> 101.5, 28672x8192 190.9 -> 173.2)
+    const size_t kn = (size_t)L.K * L.N;
+    if (M >= 384 && kn >= ((size_t)56 << 20) && L.N >= L.K) return true;
+    if (M >= 320 && kn >= ((size_t)112 << 20) && L.K > L.N) return true;
+    return M >= 768 || (M >= 512 && kn >= ((size_t)32 << 20));
 }
 
 namespace mlpk { extern int g_cu_count[64]; }                 // per device ordinal, filled by gptq_init (mlp.hip); 0 = not initialised
