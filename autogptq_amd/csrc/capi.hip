@@ -157,6 +157,12 @@ bool want_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t
     if (M > 4 && !(t && t->path == 8) && n == 1 && rows_pays(*Ls[0], M)) return false;      // 5+ rows of one layer: the exchange-free batched-decode kernel (gemm_rows.hip: 4096^2 M = 5 / 8 7.1 / 7.3 -> 5.5 / 5.6 us)
     if (M > 4 && !(t && t->path == 8) && !tiled_rows8_pays(Ls, n)) return false;
     if (t && t->path != 0 && t->path != 8) return false;
+    // act-order layers at 3 - 4 rows from K = 5120: the in-kernel gather holds the raw AND the gathered rows of x in LDS (2 x 4 rows x K: one workgroup per CU from
+    // K = 5120) -- the permute pre-pass + the kernels of the 5+-row path are faster there (tools/m_sweep.py --act, profiles/r06_act_m4.log, 4 rows against 5:
+    // 5120x13824 26.5 / 14.7 us, 8192^2 18.3 / 14.8, 6656^2 16.7 / 15.6, 5120^2 13.1 / 12.3; 4096-deep layers keep this kernel: 4096x11008 11.7 / 12.9).  (act-order
+    // layers are never released to the host: nothing assumes the decode copy for them)
+    // narrow layers (tensor-parallel shards, N < 4096) keep it: 8192x3584 9.2 against 10.9, 8192x1024 8.1 / 9.8
+    if (!(t && t->path == 8) && M >= 3 && M <= 4 && Ls[0]->g_idx && Ls[0]->K >= 5120 && Ls[0]->N >= 4096 && n == 1) return false;
     const TiledPlan tp = plan_tiled(Ls, n, M, t);                  // act-order layers: the copy holds the re-sequenced rows, the kernel gathers x through perm
     if (plan_out) *plan_out = tp;
     return tp.ok;
