@@ -122,8 +122,11 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
     // the constants -- combined inside the launch through granules (stream_finish)
     int ks = (tune && tune->ksplit) ? tune->ksplit : 0;
     if (!ks) {
+        // Late round 6 (tools/tp_shard_sweep.py, profiles/r06_tp_shard_sweep.log: BASELINE config 4's shards): the exchange hop of a K slice costs more than the idle CUs
+        // of a narrow launch until the slices are deep -- 8192x1024 (64 strips) M = 1: 2 slices 5.69 us, none 5.31 (4.88 as 8 waves x 4 chunks), 8192x128 5.37 -> 4.73,
+        // 4096x1376 5.03 -> 3.77, 4096x512 4.75 -> 3.61; 28672x1024 wants FOUR (11.45 / 9.46 / 8.15 / 12.1 us with 1 / 2 / 4 / 8): slices of at least 40 chunks = 5120 k
         ks = 1;
-        while (!pair && strips * ks < 128 && chunks / (ks * 2) >= 8) ks *= 2;
+        while (!pair && strips * ks < 256 && chunks / (ks * 2) >= 40) ks *= 2;
     }
     if (pair && ks != 1) return pl;
     if (nstr > 1 && (ks != 1 || strips / nstr < 96)) nstr = 1;                    // K slices (narrow layers): one strip per workgroup, as before
@@ -163,6 +166,7 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         if (wgs <= 256) { waves = 16; u = 2; }
         else if (wgs <= 512) { waves = 8; u = 2; }
         else { waves = 4; u = 4; }
+        if (wgs <= 128 && chunks >= 64 && pl.ksplit == 1) { waves = 8; u = 4; }   // narrow launches of K >= 8192 (the shards above): 8 waves x 4 chunks 4.88 against 5.31 us
         if (pl.mt > 4) { waves = 8; u = 4; }                                      // 5..8 rows, 4096^2: 6.62 us (4 x 4: 6.82, 16 x 2: 6.92)
         if (pair && waves == 4) waves = 8;                                        // two strips per workgroup: the 4-wave form's work per wave
         if (nstr > 1) { waves = nstr == 4 ? 16 : 8; u = 4; }                      // four (two) strips x four waves x four chunks in flight

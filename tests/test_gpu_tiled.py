@@ -264,12 +264,18 @@ def test_tiled_decode_k_slices(ks):
                 for r, k in hot:
                     assert torch.equal(y[r], W[k])
                 _assert_all(y, x, W, None, dtype, f"tiled ksplit={ks} {K}x{N} M={M}")
-    L, q, W = _layer(8192, 1024, 128, torch.float16, 77)                    # Llama-2-70B attention shard at TP = 8
+    L, q, W = _layer(8192, 1024, 128, torch.float16, 77)                    # Llama-2-70B attention shard at TP = 8: no K slices since late round 6 (the hop costs more than the idle CUs)
     plan = _lib.describe_plan(q._layer, 1)
-    assert plan["kernel"] == "strips" and plan["ksplit"] >= 2
+    assert plan["kernel"] == "strips" and plan["ksplit"] == 1 and (plan["waves"], plan["u"]) == (8, 4), plan
     x, _ = _x(1, 8192, torch.float16, 3)
     with torch.no_grad():
-        _assert_all(q(x), x, W, None, torch.float16, "tiled 8192x1024 default (K slices)")
+        _assert_all(q(x), x, W, None, torch.float16, "tiled 8192x1024 default")
+    L, q, W = _layer(28672, 1024, 128, torch.float16, 78)                   # the down-projection shard: slices of 7168 k (deep enough to pay for the hop)
+    plan = _lib.describe_plan(q._layer, 1)
+    assert plan["kernel"] == "strips" and plan["ksplit"] == 4, plan
+    x, _ = _x(1, 28672, torch.float16, 4)
+    with torch.no_grad():
+        _assert_all(q(x), x, W, None, torch.float16, "tiled 28672x1024 default (K slices)")
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
@@ -386,9 +392,9 @@ def test_sticky_exchange_error_is_read_periodically():
     """A bounded in-launch wait that gives up raises the workspace's sticky error word (the kernels never hang); QuantLinear reads it every
     EXCHANGE_CHECK_EVERY workspace-taking calls instead of leaving it to the caller (round-3 advice)."""
     from autogptq_amd import qlinear_mi355x as qm
-    L, q, W = _layer(8192, 256, 128, torch.float16, 3)                    # 16 strips: K slices, i.e. a workspace and an exchange
+    L, q, W = _layer(28672, 256, 128, torch.float16, 3)                   # 16 strips of a 28672-deep layer: K slices (of 7168 k), i.e. a workspace and an exchange
     assert _lib.describe_plan(q._layer, 1)["ksplit"] >= 2
-    x, _ = _x(1, 8192, torch.float16, 1)
+    x, _ = _x(1, 28672, torch.float16, 1)
     saved = QuantLinear.EXCHANGE_CHECK_EVERY
     QuantLinear.EXCHANGE_CHECK_EVERY = 1
     try:
