@@ -169,6 +169,10 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         if (wgs <= 128 && chunks >= 64 && pl.ksplit == 1) { waves = 8; u = 4; }   // narrow launches of K >= 8192 (the shards above): 8 waves x 4 chunks 4.88 against 5.31 us
         if (pl.mt > 4) { waves = 8; u = 4; }                                      // 5..8 rows, 4096^2: 6.62 us (4 x 4: 6.82, 16 x 2: 6.92)
         if (pair && waves == 4) waves = 8;                                        // two strips per workgroup: the 4-wave form's work per wave
+        // the pair form where a strip's chunks do not divide into its passes of 16 (4 waves per half x 4 chunks) but do into passes of 8: 2 chunks in flight (tools/pair_geom_sweep.py,
+        // profiles/r06_pair_geom_sweep.log, M = 1 / 2 / 4: 13B 5120 -> 2 x 13824 19.5 / 20.1 / 21.3 -> 18.1 / 17.5 / 18.6 us, 30B 6656 -> 2 x 17920 29.5 / 29.5 / 34.0 -> 26.0 / 27.1 / 31.6;
+        // K = 4096 / 8192 divide evenly and keep 4)
+        if (pair && waves == 8 && u == 4 && (double)((chunks + 15) / 16 * 16) / chunks - (double)((chunks + 7) / 8 * 8) / chunks >= 0.1) u = 2;
         if (nstr > 1) { waves = nstr == 4 ? 16 : 8; u = 4; }                      // four (two) strips x four waves x four chunks in flight
         // 1 - 2 rows, two strips: TWO waves per strip up to K = 7168 (profiles/r06_strips_geom_sweep3.log, 8 -> 4 waves: 4096x22016 11.7 -> 11.5, 5120x27648 19.2 -> 16.9,
         // 6656x17920 M = 2 18.9 -> 16.9, 4096x16384 9.7 -> 9.3 us; 8192x28672 24.4 -> 25.5: deeper layers keep four)
