@@ -177,6 +177,9 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         // 1 - 2 rows, two strips: TWO waves per strip up to K = 7168 (profiles/r06_strips_geom_sweep3.log, 8 -> 4 waves: 4096x22016 11.7 -> 11.5, 5120x27648 19.2 -> 16.9,
         // 6656x17920 M = 2 18.9 -> 16.9, 4096x16384 9.7 -> 9.3 us; 8192x28672 24.4 -> 25.5: deeper layers keep four)
         if (nstr == 2 && pl.mt <= 2 && A.K <= 7168) waves = 4;
+        // two strips at 3 - 4 rows where a strip's chunks divide into passes of 8 but not of 16 (4 waves per strip): 2 chunks in flight -- 5120x13824 M = 4 12.6 -> 10.8 us
+        // (profiles/r06_strips_geom_sweep4.log)
+        if (nstr == 2 && pl.mt == 4 && waves == 8 && (double)((chunks + 15) / 16 * 16) / chunks - (double)((chunks + 7) / 8 * 8) / chunks >= 0.1) u = 2;
         // 3 - 4 rows of a deep layer, one strip per workgroup: the staged x (4 rows x K) is what limits the workgroups of a CU -- 4-wave workgroups of K = 6656+
         // leave it at 8 waves (two workgroups in 160 KiB); 8-wave workgroups keep 16 (profiles/r06_multi_geom_sweep.log, 4 -> 8 waves: 70B q|k|v 15.7 -> 13.3 us,
         // 30B q|k|v 23.2 -> 20.4; K = 5120 holds three 4-wave workgroups and LOSES with 8 waves: 14.1 -> 16.0)

@@ -57,7 +57,7 @@ for shp in args.shapes.split(","):
         base, _ = time_layers(ls, x, None)
         plan = bench._plan_dict(ls, K, N, M)
         row = [f"default[{plan.get('kernel')} w={plan.get('waves')} u={plan.get('u')} ks={plan.get('ksplit')}] {base:6.2f}"]
-        for name, t in (("16x2", tune(16, 2)), ("8x4", tune(8, 4)), ("4x4", tune(4, 4)), ("8x2", tune(8, 2)), ("2str8x4", tune(8, 4, 2)), ("2str4x4", tune(4, 4, 2)), ("1str4x4", tune(4, 4, 1)), ("1str8x2", tune(8, 2, 1))):
+        for name, t in (("16x2", tune(16, 2)), ("8x4", tune(8, 4)), ("4x4", tune(4, 4)), ("8x2", tune(8, 2)), ("2str8x4", tune(8, 4, 2)), ("2str4x4", tune(4, 4, 2)), ("1str4x4", tune(4, 4, 1)), ("1str8x2", tune(8, 2, 1)), ("1str4x2", tune(4, 2, 1)), ("1str2x4", tune(2, 4, 1))):
             us, err = time_layers(ls, x, t)
             row.append(f"{name} {us:6.2f}" if us is not None else f"{name} refused")
         print(f"{K}x{N} M={M}: " + " | ".join(row), flush=True)
