@@ -101,7 +101,7 @@ TiledPlan plan_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tun
         // way) LOSES 7 % with two strips below 1024 (q|k|v 7B, 4096x12288) and keeps one
         const int cke0 = 4 * tiled_kpl(A.bits), chunks0 = (A.K + cke0 - 1) / cke0;
         const double waste1 = (double)((chunks0 + 15) / 16 * 16) / chunks0, waste2 = (double)((chunks0 + 7) / 8 * 8) / chunks0;
-        const bool uneven = strips >= 768 && M <= 4 && A.bits == 4 && waste1 - waste2 >= 0.1;
+        const bool uneven = strips >= 768 && M <= 4 && (A.bits == 4 || (A.bits == 3 && M >= 3)) && waste1 - waste2 >= 0.1;      // (3 bits: the same 128-k chunks; its two-strip forms exist from 3 rows: 5120x13824 int3 M = 4 13.4 -> 11.2 us)
         const int want = (tune && tune->path == 8 && tune->reserved[1]) ? tune->reserved[1] : ((strips >= 1024 || uneven) ? 2 : 1);
         if (want == 2 || (want == 4 && M >= 3)) {
             nstr = want;
