@@ -1072,3 +1072,54 @@ def test_panel_kernel_is_planned_where_its_tiles_fill_the_chip():
     assert plan(1024, 256, 64, tune=t)[0]["kernel"] == "panel" and plan(1024, 256, 64, tune=t)[0]["tiles"] == "1x3"
     t.reserved[_lib.LAB.GEMM_VARIANT], t.reserved[0] = _lib.LAB.VARIANT_PANEL_OFF, 0
     assert plan(4096, 4096, 256, tune=t)[0]["kernel"] != "panel"
+
+
+def test_planner_rules_beyond_the_7b_shapes():
+    """gptq_describe_plan (host only), late round 6: the rules the row-count / geometry sweeps over the 13B / 30B / 70B / 8B layers produced (DESIGN.md 4.1 'the planner beyond
+    the Llama-7B shapes', 4.5 (i)-(v); tools/m_sweep.py, strips_geom_sweep.py, mid_band_sweep.py, tp_shard_sweep.py) -- pinned here so that a later threshold edit shows up
+    without a GPU."""
+    def plan(K, N, M, act=False, **kw):
+        L = _layer(K=K, N=N, **kw)
+        L.qweight_tiled = L.qconst_tiled = 0x2000
+        L.tiled_cols = 16
+        if act:
+            L.g_idx = L.qweight_seq = L.perm = 0x1000
+        return _lib.describe_plan(L, M, None)
+
+    # decode geometry: <= 256 workgroups 16 waves x 2 chunks, 257 .. 512 8 x 2 (two co-resident workgroups per CU), more 4 x 4
+    for (K, N), want in (((4096, 4096), (16, 2)), ((11008, 4096), (16, 2)), ((5120, 5120), (8, 2)), ((13824, 5120), (8, 2)), ((6656, 6656), (8, 2)), ((8192, 8192), (8, 2)),
+                         ((4096, 11008), (4, 4)), ((4096, 12288), (4, 4))):
+        p = plan(K, N, 1)
+        assert (p["kernel"], p["waves"], p["u"]) == ("strips",) + want, (K, N, p)
+    # two strips per workgroup from 768 strips where K = 5120 / 6656 do not divide into passes of 16 chunks (strips = workgroups: halved), not for K = 4096 below 1024 strips
+    assert plan(5120, 13824, 1)["strips"] == 432 and plan(4096, 12288, 1)["strips"] == 768 and plan(4096, 22016, 1)["strips"] == 688
+    p = plan(5120, 13824, 4)
+    assert (p["strips"], p["waves"], p["u"]) == (432, 8, 2), p
+    # BASELINE config 4's shards: no K slices below 5120 k per slice; four on the 28672-deep down shard
+    p = plan(8192, 1024, 1)
+    assert (p["ksplit"], p["waves"], p["u"]) == (1, 8, 4), p
+    assert plan(8192, 128, 1)["ksplit"] == 1 and plan(28672, 1024, 1)["ksplit"] == 4 and plan(4096, 1376, 1)["ksplit"] == 1
+    # act-order at 3 - 4 rows from K = 5120 (N >= 4096) leaves the in-kernel gather; 4096-deep layers and narrow shards keep it
+    assert plan(5120, 13824, 4, act=True)["kernel"] != "strips" and plan(8192, 8192, 3, act=True)["kernel"] != "strips"
+    assert plan(4096, 11008, 4, act=True)["kernel"] == "strips" and plan(8192, 3584, 4, act=True)["kernel"] == "strips" and plan(5120, 13824, 2, act=True)["kernel"] == "strips"
+    # the band between decode and prefill on the larger families
+    want = {
+        (5120, 13824): {16: "stream64", 24: "rows", 48: "panel", 64: "panel", 128: "panel", 384: "wide_sk"},      # wide: one (partial) row panel from 17 rows
+        (6656, 17920): {24: "rows", 33: "panel", 64: "panel"},                                                     # 17 .. 32 rows of the wide largest layers: the rows kernel
+        (8192, 28672): {24: "rows", 48: "panel", 64: "panel", 96: "tiled", 384: "wide_sk"},
+        (13824, 5120): {24: "mid", 48: "rows", 96: "rows", 128: "panel", 192: "panel", 384: "panel"},             # deep: the rows kernel beyond 64 Mi weights at 33 .. 96 rows
+        (17920, 6656): {48: "rows", 96: "rows", 128: "tiled", 192: "panel", 320: "wide_sk"},
+        (28672, 8192): {48: "rows", 64: "rows", 96: "tiled", 192: "panel", 320: "wide_sk"},
+        (14336, 4096): {96: "rows", 128: "rows", 192: "panel"},
+        (4096, 14336): {8: "stream64", 24: "panel", 64: "panel", 384: "wide_sk"},                                  # the widest K <= 4096 layers leave the rows kernel at up to 32 rows
+        (8192, 8192): {32: "rows", 48: "panel", 80: "panel", 384: "wide_sk"},
+        (8192, 3584): {96: "rows"},
+        (5120, 5120): {96: "rows", 128: "panel"},
+        (8192, 1024): {1024: "panel", 1536: "panel", 2048: "wide_sk"},
+    }
+    for (K, N), by_m in want.items():
+        for M, kern in by_m.items():
+            p = plan(K, N, M)
+            assert p["kernel"] == kern, (K, N, M, p)
+    assert plan(8192, 8192, 8, act=True)["kernel"] == "stream64" and plan(8192, 8192, 17, act=True)["kernel"] == "rows"      # act-order, K >= 8192, up to 16 rows: the 64-column-strip kernel
+    assert plan(13824, 5120, 8, bits=3, group_size=32)["kernel"] == "rows"                                                   # 3 bits beyond 64 Mi weights: no 64-column-strip kernel
