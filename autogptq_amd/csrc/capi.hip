@@ -163,6 +163,9 @@ bool want_tiled(const gptq_layer_t* const* Ls, int n, int M, const gptq_tuning_t
     // layers are never released to the host: nothing assumes the decode copy for them)
     // narrow layers (tensor-parallel shards, N < 4096) keep it: 8192x3584 9.2 against 10.9, 8192x1024 8.1 / 9.8
     if (!(t && t->path == 8) && M >= 3 && M <= 4 && Ls[0]->g_idx && Ls[0]->K >= 5120 && Ls[0]->N >= 4096 && n == 1) return false;
+    // ... and at 2 rows from K = 12288 (2 x 2 rows x K of LDS again leave one workgroup per CU): 13824x5120 21.4 us against 18.7 at THREE rows on the pre-pass + streamed kernel
+    // (layers of more than 256 strips only: 14336x4096 runs one workgroup per CU either way and keeps this kernel)
+    if (!(t && t->path == 8) && M == 2 && Ls[0]->g_idx && Ls[0]->K >= 12288 && Ls[0]->N > 4096 && n == 1) return false;
     const TiledPlan tp = plan_tiled(Ls, n, M, t);                  // act-order layers: the copy holds the re-sequenced rows, the kernel gathers x through perm
     if (plan_out) *plan_out = tp;
     return tp.ok;
